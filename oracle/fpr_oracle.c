@@ -1,0 +1,560 @@
+/*
+ * fpr_oracle.c -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * Plain-C restatement of the stencil hot path of ntselepidis/FinalProjectRepo.jl
+ * (Julia; cannot be executed in this environment: no `julia` binary).
+ * Every function cites the reference file:line it follows.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product (libfpr_hip.so) never links or calls it.
+ *
+ * Parity status: PINNED by the reference's own fixtures
+ *   - tests/golden/test_1.bson          (reference test/part1.jl:24-40, atol 1e-5)
+ *   - tests/golden/fortran/{Winit,S}.bin (reference test/part2.jl:8-38, atol 1e-8)
+ *   - operator identity vs the sparse 5-point matrix (reference test/multigrid.jl:102-138)
+ *   - convergence criteria (reference test/multigrid.jl:30-100, test/krylov.jl:19-36)
+ * see tests/test_oracle_pins.py.
+ *
+ * Conventions: Float64, Julia column-major (ix fastest), indices below are 0-based
+ * (Julia's 1-based `ix` == i+1).  Compile with -ffp-contract=off so that no FMA is
+ * formed: every expression rounds exactly as the Julia source does on a CPU.
+ * Reductions use a fixed pairwise tree (Julia's `sum` is pairwise too, but its exact
+ * tree is not reproduced: norms are pinned to tolerance only).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#define OMP_FOR _Pragma("omp parallel for schedule(static)")
+#define OMP_FOR2 _Pragma("omp parallel for collapse(2) schedule(static)")
+#else
+#define OMP_FOR
+#define OMP_FOR2
+#endif
+
+#define I3(i, j, k) ((size_t)(i) + (size_t)nx * ((size_t)(j) + (size_t)ny * (size_t)(k)))
+#define I2(i, j) ((size_t)(i) + (size_t)nx * (size_t)(j))
+
+/* ------------------------------------------------------------------------------------------ */
+/* reductions                                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* pairwise sum of f(x[i]) with a 1024-element sequential base case */
+static double pw_sumsq_scaled(const double *x, size_t n, double scale)
+{
+    if (n <= 1024) {
+        double s = 0.0;
+        for (size_t i = 0; i < n; ++i) {
+            double t = x[i] * scale;
+            s += t * t;
+        }
+        return s;
+    }
+    size_t h = n / 2;
+    return pw_sumsq_scaled(x, h, scale) + pw_sumsq_scaled(x + h, n - h, scale);
+}
+
+static double pw_dot(const double *x, const double *y, size_t n)
+{
+    if (n <= 1024) {
+        double s = 0.0;
+        for (size_t i = 0; i < n; ++i) s += x[i] * y[i];
+        return s;
+    }
+    size_t h = n / 2;
+    return pw_dot(x, y, h) + pw_dot(x + h, y + h, n - h);
+}
+
+#ifdef _OPENMP
+/* OpenMP build (cpu_baseline timing only): chunked pairwise, deterministic for a fixed
+ * thread count but NOT identical to the serial tree. */
+static double sumsq_scaled(const double *x, size_t n, double scale)
+{
+    int nt = omp_get_max_threads();
+    double part[256];
+    if (nt > 256) nt = 256;
+#pragma omp parallel num_threads(nt)
+    {
+        int t = omp_get_thread_num();
+        size_t lo = n * (size_t)t / (size_t)nt, hi = n * (size_t)(t + 1) / (size_t)nt;
+        part[t] = pw_sumsq_scaled(x + lo, hi - lo, scale);
+    }
+    double s = 0.0;
+    for (int t = 0; t < nt; ++t) s += part[t];
+    return s;
+}
+static double dot(const double *x, const double *y, size_t n)
+{
+    int nt = omp_get_max_threads();
+    double part[256];
+    if (nt > 256) nt = 256;
+#pragma omp parallel num_threads(nt)
+    {
+        int t = omp_get_thread_num();
+        size_t lo = n * (size_t)t / (size_t)nt, hi = n * (size_t)(t + 1) / (size_t)nt;
+        part[t] = pw_dot(x + lo, y + lo, hi - lo);
+    }
+    double s = 0.0;
+    for (int t = 0; t < nt; ++t) s += part[t];
+    return s;
+}
+#else
+static double sumsq_scaled(const double *x, size_t n, double scale) { return pw_sumsq_scaled(x, n, scale); }
+static double dot(const double *x, const double *y, size_t n) { return pw_dot(x, y, n); }
+#endif
+
+/* sum(x.^2) */
+double orc_sumsq(const double *x, size_t n) { return sumsq_scaled(x, n, 1.0); }
+double orc_dot(const double *x, const double *y, size_t n) { return dot(x, y, n); }
+
+int orc_has_openmp(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 0;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Part 1 -- 3D pseudo-transient diffusion                                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+/* A1: diffusion_3D_step_tau  -- scripts-part1/part1_kernel_programming.jl:46-58, flux macros :12-20.
+ * (A2, the shared-memory variant :75-97, is arithmetically identical.) */
+void orc_diffusion3d_step(const double *Ht, const double *Htau, double *Htau2, double *dHdtau,
+                          int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy,
+                          double _dz, double D_dx, double D_dy, double D_dz)
+{
+    OMP_FOR2
+    for (int k = 1; k < nz - 1; ++k)
+        for (int j = 1; j < ny - 1; ++j)
+            for (int i = 1; i < nx - 1; ++i) {
+                const double h = Htau[I3(i, j, k)];
+                /* @qx(ix+1) = -D_dx*(H[ix+1]-H[ix]) ; @qx(ix) = -D_dx*(H[ix]-H[ix-1])   (:12-14) */
+                const double qxp = -D_dx * (Htau[I3(i + 1, j, k)] - h);
+                const double qxm = -D_dx * (h - Htau[I3(i - 1, j, k)]);
+                const double qyp = -D_dy * (Htau[I3(i, j + 1, k)] - h);
+                const double qym = -D_dy * (h - Htau[I3(i, j - 1, k)]);
+                const double qzp = -D_dz * (Htau[I3(i, j, k + 1)] - h);
+                const double qzm = -D_dz * (h - Htau[I3(i, j, k - 1)]);
+                /* :48-53, n-ary + evaluated left to right */
+                const double r = (((qxp - qxm) * _dx + (qyp - qym) * _dy) + (qzp - qzm) * _dz) +
+                                 (h - Ht[I3(i, j, k)]) * _dt;
+                dHdtau[I3(i, j, k)] = r;
+                Htau2[I3(i, j, k)] = h - dtau * r; /* :54-55 */
+            }
+}
+
+/* A3 (clean split semantics): compute_flux!  -- part1_array_programming.jl:10-12
+ * qx is (nx-1, ny-2, nz-2); qy (nx-2, ny-1, nz-2); qz (nx-2, ny-2, nz-1).
+ * @d_xi(H)[i,j,k] = H[i+1, j+1, k+1] - H[i, j+1, k+1]  (inner in y,z)  [3P: FiniteDifferences3D] */
+void orc_diffusion3d_flux(double *qx, double *qy, double *qz, const double *Htau, int nx, int ny,
+                          int nz, double D, double dx, double dy, double dz)
+{
+    OMP_FOR2
+    for (int k = 0; k < nz - 2; ++k)
+        for (int j = 0; j < ny - 2; ++j)
+            for (int i = 0; i < nx - 1; ++i)
+                qx[(size_t)i + (size_t)(nx - 1) * ((size_t)j + (size_t)(ny - 2) * k)] =
+                    D * (Htau[I3(i + 1, j + 1, k + 1)] - Htau[I3(i, j + 1, k + 1)]) / dx;
+    OMP_FOR2
+    for (int k = 0; k < nz - 2; ++k)
+        for (int j = 0; j < ny - 1; ++j)
+            for (int i = 0; i < nx - 2; ++i)
+                qy[(size_t)i + (size_t)(nx - 2) * ((size_t)j + (size_t)(ny - 1) * k)] =
+                    D * (Htau[I3(i + 1, j + 1, k + 1)] - Htau[I3(i + 1, j, k + 1)]) / dy;
+    OMP_FOR2
+    for (int k = 0; k < nz - 1; ++k)
+        for (int j = 0; j < ny - 2; ++j)
+            for (int i = 0; i < nx - 2; ++i)
+                qz[(size_t)i + (size_t)(nx - 2) * ((size_t)j + (size_t)(ny - 2) * k)] =
+                    D * (Htau[I3(i + 1, j + 1, k + 1)] - Htau[I3(i + 1, j + 1, k)]) / dz;
+}
+
+/* compute_dHdtau!  -- part1_array_programming.jl:14-15 ; dHdtau is (nx-2, ny-2, nz-2) */
+void orc_diffusion3d_dHdtau(double *dHdtau, const double *Htau, const double *Ht, const double *qx,
+                            const double *qy, const double *qz, int nx, int ny, int nz, double dt,
+                            double dx, double dy, double dz)
+{
+    OMP_FOR2
+    for (int k = 0; k < nz - 2; ++k)
+        for (int j = 0; j < ny - 2; ++j)
+            for (int i = 0; i < nx - 2; ++i) {
+                const size_t qxi = (size_t)i + (size_t)(nx - 1) * ((size_t)j + (size_t)(ny - 2) * k);
+                const size_t qyi = (size_t)i + (size_t)(nx - 2) * ((size_t)j + (size_t)(ny - 1) * k);
+                const size_t qzi = (size_t)i + (size_t)(nx - 2) * ((size_t)j + (size_t)(ny - 2) * k);
+                const double dqx = (qx[qxi + 1] - qx[qxi]) / dx;
+                const double dqy = (qy[qyi + (size_t)(nx - 2)] - qy[qyi]) / dy;
+                const double dqz = (qz[qzi + (size_t)(nx - 2) * (size_t)(ny - 2)] - qz[qzi]) / dz;
+                const double tt = -(Htau[I3(i + 1, j + 1, k + 1)] - Ht[I3(i + 1, j + 1, k + 1)]) / dt;
+                dHdtau[qzi] = tt + ((dqx + dqy) + dqz);
+            }
+}
+
+/* update_H!  -- part1_array_programming.jl:16 */
+void orc_diffusion3d_update(double *Htau, const double *dHdtau, int nx, int ny, int nz, double dtau)
+{
+    OMP_FOR2
+    for (int k = 0; k < nz - 2; ++k)
+        for (int j = 0; j < ny - 2; ++j)
+            for (int i = 0; i < nx - 2; ++i) {
+                const size_t di = (size_t)i + (size_t)(nx - 2) * ((size_t)j + (size_t)(ny - 2) * k);
+                Htau[I3(i + 1, j + 1, k + 1)] = Htau[I3(i + 1, j + 1, k + 1)] + dHdtau[di] * dtau;
+            }
+}
+
+/* A4: dist_norm_L2(Rh*scale) local part -- part1_utils.jl:36-40 with the caller's `residual_H * dt`
+ * (part1_kernel_programming.jl:191).  Returns sum((x*scale)^2); caller all-reduces and takes sqrt. */
+double orc_sumsq_scaled(const double *x, size_t n, double scale) { return sumsq_scaled(x, n, scale); }
+
+/* A6: init_local_gaussian -- part1_utils.jl:1-12.  x_g(ix,dx,H) for a size-n array on a rank with
+ * 0-based Cartesian coordinate `c` is (c*(n-2) + (ix-1))*dx  [3P ImplicitGlobalGrid, overlap 2];
+ * pinned for c=0 by the BSON corner value (6.71e-21).  Here i = ix-1. */
+void orc_init_gaussian(double *H, int nx, int ny, int nz, double dx, double dy, double dz, double cx,
+                       double cy, double cz, int coordx, int coordy, int coordz)
+{
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                const double x = (double)((long)coordx * (nx - 2) + i) * dx;
+                const double y = (double)((long)coordy * (ny - 2) + j) * dy;
+                const double z = (double)((long)coordz * (nz - 2) + k) * dz;
+                const double ax = x + dx / 2 - cx, ay = y + dy / 2 - cy, az = z + dz / 2 - cz;
+                H[I3(i, j, k)] = 2 * exp(-1.0 * ((ax * ax + ay * ay) + az * az));
+            }
+}
+
+/* apply_boundary_conditions! -- part1_utils.jl:14-34.  NOTE the reference compares the 0-based
+ * Cartesian `coords` with 1 and with dims: on a single rank (coords=0, dims=1) nothing is zeroed. */
+void orc_apply_bc3d(double *H, int nx, int ny, int nz, const int *coords, const int *dims)
+{
+    if (coords[0] == 1)
+        for (int k = 0; k < nz; ++k)
+            for (int j = 0; j < ny; ++j) H[I3(0, j, k)] = 0.0;
+    if (coords[1] == 1)
+        for (int k = 0; k < nz; ++k)
+            for (int i = 0; i < nx; ++i) H[I3(i, 0, k)] = 0.0;
+    if (coords[2] == 1)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) H[I3(i, j, 0)] = 0.0;
+    if (coords[0] == dims[0])
+        for (int k = 0; k < nz; ++k)
+            for (int j = 0; j < ny; ++j) H[I3(nx - 1, j, k)] = 0.0;
+    if (coords[1] == dims[1])
+        for (int k = 0; k < nz; ++k)
+            for (int i = 0; i < nx; ++i) H[I3(i, ny - 1, k)] = 0.0;
+    if (coords[2] == dims[2])
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) H[I3(i, j, nz - 1)] = 0.0;
+}
+
+/* A5: single-rank host loop of diffusion_3D_kernel_programming -- part1_kernel_programming.jl:99-204.
+ * Ht must hold the initial condition (nx*ny*nz); on return Ht holds the field after `nt` physical
+ * steps.  iters_out[t] = inner iterations of step t; err_out[t] = last err of step t.
+ * fixed_iters > 0 : run exactly that many inner iterations per step (no convergence exit).
+ * Returns total inner iterations. */
+long orc_diffusion3d_solve(double *Ht, int nx, int ny, int nz, double lx, double ly, double lz,
+                           double D, double dt, int nt, double tol, long iter_max, long fixed_iters,
+                           long *iters_out, double *err_out, double *Htau_out, double *dHdtau_out)
+{
+    const size_t N = (size_t)nx * ny * nz;
+    const double dx = lx / nx, dy = ly / ny, dz = lz / nz; /* :117 with nx_g()==nx on one rank */
+    const double mn = fmin(fmin(dx, dy), dz);
+    const double dtau = mn * mn / D / 8.1; /* :128 */
+    const double _dt = 1.0 / dt, _dx = 1.0 / dx, _dy = 1.0 / dy, _dz = 1.0 / dz; /* :146-149 */
+    const double D_dx = D / dx, D_dy = D / dy, D_dz = D / dz;                     /* :150-152 */
+    const double sqrtN = sqrt((double)N);                                         /* :124 */
+    double *Htau = (double *)malloc(N * sizeof(double));
+    double *Htau2 = (double *)calloc(N, sizeof(double)); /* @zeros :141 */
+    double *res = (double *)calloc(N, sizeof(double));   /* @zeros :142 */
+    memcpy(Htau, Ht, N * sizeof(double));                /* :140 */
+    long total = 0;
+    for (int t = 0; t < nt; ++t) { /* :166 */
+        long it = 0;
+        double err = 2 * tol; /* :178 */
+        while (fixed_iters > 0 ? it < fixed_iters : (err > tol && it < iter_max)) { /* :179 */
+            orc_diffusion3d_step(Ht, Htau, Htau2, res, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz);
+            double *tmp = Htau; Htau = Htau2; Htau2 = tmp;  /* :190 */
+            err = sqrt(sumsq_scaled(res, N, dt)) / sqrtN;   /* :191 */
+            ++it;
+        }
+        if (iters_out) iters_out[t] = it;
+        if (err_out) err_out[t] = err;
+        total += it;
+        if (t == nt - 1) {
+            if (Htau_out) memcpy(Htau_out, Htau, N * sizeof(double));
+            if (dHdtau_out) memcpy(dHdtau_out, res, N * sizeof(double));
+        }
+        memcpy(Ht, Htau, N * sizeof(double)); /* :203 */
+    }
+    free(Htau); free(Htau2); free(res);
+    return total;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Part 2 -- 2D geometric multigrid                                                             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* B1: residual_2DPoisson! -- scripts-part2/multigrid.jl:173-188 (shmem variant :191-220 identical) */
+void orc_residual2d(const double *u, const double *f, double h, double c, double *res, int nx, int ny)
+{
+    const double C = 4.0 + c * (h * h);
+    const double _h2 = 1 / (h * h);
+    OMP_FOR
+    for (int j = 1; j < ny - 1; ++j)
+        for (int i = 1; i < nx - 1; ++i)
+            res[I2(i, j)] = ((((u[I2(i + 1, j)] + u[I2(i - 1, j)]) + u[I2(i, j + 1)]) + u[I2(i, j - 1)]) -
+                             C * u[I2(i, j)]) * _h2 - f[I2(i, j)];
+}
+
+/* B2: iteration_2DPoisson! -- multigrid.jl:245-258 ; returns r_rms measured BEFORE the update */
+double orc_jacobi2d(double *u, const double *f, double h, double c, double *res, int nx, int ny, double alpha)
+{
+    const size_t N = (size_t)nx * ny;
+    orc_residual2d(u, f, h, c, res, nx, ny);
+    const double r_rms = sqrt(sumsq_scaled(res, N, 1.0) / (double)N); /* :252 */
+    const double fac = alpha * ((h * h) / (4.0 + c * (h * h)));       /* :255 */
+    OMP_FOR
+    for (size_t n = 0; n < N; ++n) u[n] = u[n] + fac * res[n];
+    return r_rms;
+}
+
+/* B6: boundary conditions -- scripts-part2/part2_utils.jl:22-39 */
+void orc_bc_dirichlet2d(double *T, int nx, int ny)
+{
+    for (int i = 0; i < nx; ++i) T[I2(i, 0)] = 1.0;
+    for (int i = 0; i < nx; ++i) T[I2(i, ny - 1)] = 0.0;
+}
+void orc_bc_neumann2d(double *T, int nx, int ny)
+{
+    for (int j = 0; j < ny; ++j) T[I2(0, j)] = T[I2(1, j)];
+    for (int j = 0; j < ny; ++j) T[I2(nx - 1, j)] = T[I2(nx - 2, j)];
+}
+void orc_bc2d(double *T, int nx, int ny)
+{
+    orc_bc_dirichlet2d(T, nx, ny);
+    orc_bc_neumann2d(T, nx, ny);
+}
+
+/* B3: restrict_wrapper! + restrict! -- multigrid.jl:330-358 (injection).  (nx,ny) = fine dims */
+void orc_restrict2d(const double *fine, double *coarse, int nx, int ny, int apply_BCs)
+{
+    const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
+    memset(coarse, 0, (size_t)nxc * nyc * sizeof(double)); /* :346 */
+    /* 1-based odd ix in 3..nx-2  <=> 0-based even i in 2..nx-3 ; coarse index i/2 */
+    for (int j = 2; j <= ny - 3; j += 2)
+        for (int i = 2; i <= nx - 3; i += 2)
+            coarse[(size_t)(i / 2) + (size_t)nxc * (size_t)(j / 2)] = fine[I2(i, j)];
+    if (apply_BCs) orc_bc_neumann2d(coarse, nxc, nyc); /* :355-357 */
+}
+
+/* B4: prolongate_wrapper! + prolongate! -- multigrid.jl:427-472.  Scatter-add executed in the
+ * sequential column-major sweep order (iy outer, ix inner), which is what one CPU thread does
+ * [3P ParallelStencil Threads backend] and what prolongate_serial! :365-396 does. (nx,ny)=fine dims */
+void orc_prolongate2d(const double *coarse, double *fine, int nx, int ny, int apply_BCs)
+{
+    const int nxc = 1 + (nx - 1) / 2;
+    const double a2 = 1.0 / 2.0, a4 = 1.0 / 4.0;
+    memset(fine, 0, (size_t)nx * ny * sizeof(double)); /* :453 */
+    for (int j = 2; j <= ny - 3; j += 2)
+        for (int i = 2; i <= nx - 3; i += 2) {
+            const double cv = coarse[(size_t)(i / 2) + (size_t)nxc * (size_t)(j / 2)];
+            fine[I2(i, j)] = fine[I2(i, j)] + cv;
+            fine[I2(i + 1, j)] = fine[I2(i + 1, j)] + a2 * cv;
+            fine[I2(i - 1, j)] = fine[I2(i - 1, j)] + a2 * cv;
+            fine[I2(i, j + 1)] = fine[I2(i, j + 1)] + a2 * cv;
+            fine[I2(i, j - 1)] = fine[I2(i, j - 1)] + a2 * cv;
+            fine[I2(i + 1, j + 1)] = fine[I2(i + 1, j + 1)] + a4 * cv;
+            fine[I2(i + 1, j - 1)] = fine[I2(i + 1, j - 1)] + a4 * cv;
+            fine[I2(i - 1, j + 1)] = fine[I2(i - 1, j + 1)] + a4 * cv;
+            fine[I2(i - 1, j - 1)] = fine[I2(i - 1, j - 1)] + a4 * cv;
+        }
+    if (apply_BCs) orc_bc_neumann2d(fine, nx, ny); /* :468-470 */
+}
+
+/* B5: matrix_free_matvec_prod! -- scripts-part2/krylov.jl:7-13 (shmem variant :16-34 identical) */
+void orc_laplace_apply2d(const double *T, double hx, double hy, double c, double *dT2, int nx, int ny)
+{
+    const double hx2 = hx * hx, hy2 = hy * hy;
+    OMP_FOR
+    for (int j = 1; j < ny - 1; ++j)
+        for (int i = 1; i < nx - 1; ++i) {
+            const double t = T[I2(i, j)];
+            dT2[I2(i, j)] = (((T[I2(i + 1, j)] - 2 * t) + T[I2(i - 1, j)]) / hx2 +
+                             ((T[I2(i, j + 1)] - 2 * t) + T[I2(i, j - 1)]) / hy2) - c * t;
+        }
+}
+
+/* B9: cg! -- krylov.jl:55-91.  Starts from x=0 and overwrites x_in; p_hat = copy(r) so its boundary
+ * keeps b's boundary values for the whole solve (the matvec only writes the interior). */
+double orc_cg2d(double *x_in, const double *b, double hx, double hy, double c, double tol, int Nmax,
+                int nx, int ny, int *iters_out)
+{
+    const size_t N = (size_t)nx * ny;
+    const double normb = sqrt(dot(b, b, N)); /* :57 */
+    const double tolb = tol * normb;
+    double *r = (double *)malloc(N * sizeof(double));
+    double *p = (double *)malloc(N * sizeof(double));
+    double *p_hat = (double *)malloc(N * sizeof(double));
+    double *x = (double *)calloc(N, sizeof(double));
+    memcpy(r, b, N * sizeof(double));
+    memcpy(p, r, N * sizeof(double));
+    memcpy(p_hat, r, N * sizeof(double));
+    double normr = INFINITY;
+    double rho = dot(r, r, N); /* :64 */
+    int it = 0;
+    for (int i = 1; i <= Nmax; ++i) {
+        it = i;
+        orc_laplace_apply2d(p, hx, hy, c, p_hat, nx, ny);      /* :68 */
+        const double alpha = rho / dot(p, p_hat, N);            /* :69 */
+        for (size_t n = 0; n < N; ++n) x[n] = x[n] + alpha * p[n];     /* :70 */
+        for (size_t n = 0; n < N; ++n) r[n] = r[n] - alpha * p_hat[n]; /* :71 */
+        normr = sqrt(dot(r, r, N));                              /* :72 */
+        if (normr < tolb) break;                                 /* :76 */
+        const double rho_old = rho;
+        rho = dot(r, r, N);                                      /* :83 */
+        const double beta = rho / rho_old;
+        for (size_t n = 0; n < N; ++n) p[n] = r[n] + beta * p[n]; /* :85 */
+    }
+    memcpy(x_in, x, N * sizeof(double)); /* :88 */
+    const double out = sqrt(dot(r, r, N) / (double)N); /* :90 */
+    if (iters_out) *iters_out = it;
+    free(r); free(p); free(p_hat); free(x);
+    return out;
+}
+
+/* statistics of the last orc_vcycle2d / orc_mgsolve2d call (coarse-solver iteration counts) */
+static long g_coarse_iters = 0;
+long orc_last_coarse_iters(void) { return g_coarse_iters; }
+
+/* B7: Vcycle_2DPoisson! -- multigrid.jl:91-170.  coarse_solver: 0 = jacobi, 1 = conjugate_gradient.
+ * Level buffers are freshly zeroed per call exactly as :114-117 (the recursive call :133 passes no
+ * prealloc_dict, so the reference allocates fresh zero buffers too).  Returns res_rms; -1 on the
+ * reference's error("ERROR:not a power of 2") :95-97 / InexactError of Int(log2(..)) :103. */
+double orc_vcycle2d(double *u_f, const double *rhs, double h, double c, double tol, int coarse_solve_size,
+                    int coarse_solver, int apply_BCs, int nx, int ny)
+{
+    if ((nx - 1) != 2 * ((nx - 1) / 2) || (ny - 1) != 2 * ((ny - 1) / 2)) return -1.0;
+    {
+        int m = (nx < ny ? nx : ny) - 1;
+        if (m <= 0 || (m & (m - 1)) != 0) return -1.0; /* Int(log2(m)) must be exact :103 */
+    }
+    const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
+    const size_t N = (size_t)nx * ny, Nc = (size_t)nxc * nyc;
+    double res_rms = 0.0;
+    double *res_f = (double *)calloc(N, sizeof(double));
+    if ((nx < ny ? nx : ny) > coarse_solve_size) { /* :121 */
+        double *corr_f = (double *)calloc(N, sizeof(double));
+        double *corr_c = (double *)calloc(Nc, sizeof(double));
+        double *res_c = (double *)calloc(Nc, sizeof(double));
+        res_rms = orc_jacobi2d(u_f, rhs, h, c, res_f, nx, ny, 4.0 / 5.0); /* :124 */
+        res_rms = orc_jacobi2d(u_f, rhs, h, c, res_f, nx, ny, 4.0 / 5.0); /* :125 */
+        orc_residual2d(u_f, rhs, h, c, res_f, nx, ny);                    /* :128 */
+        orc_restrict2d(res_f, res_c, nx, ny, apply_BCs);                  /* :129 */
+        memset(corr_c, 0, Nc * sizeof(double));                           /* :132 */
+        res_rms = orc_vcycle2d(corr_c, res_c, h * 2, c, tol, coarse_solve_size, coarse_solver, apply_BCs, nxc, nyc); /* :133 */
+        if (res_rms < 0) { free(corr_f); free(corr_c); free(res_c); free(res_f); return res_rms; }
+        orc_prolongate2d(corr_c, corr_f, nx, ny, apply_BCs);              /* :136 */
+        for (size_t n = 0; n < N; ++n) u_f[n] = u_f[n] - corr_f[n];       /* :139 */
+        res_rms = orc_jacobi2d(u_f, rhs, h, c, res_f, nx, ny, 4.0 / 5.0); /* :142 */
+        res_rms = orc_jacobi2d(u_f, rhs, h, c, res_f, nx, ny, 4.0 / 5.0); /* :143 */
+        free(corr_f); free(corr_c); free(res_c);
+    } else if (coarse_solver == 0) { /* :147-159 */
+        const int iters = 20 * coarse_solve_size;
+        const double tol_rhs = tol * sqrt(sumsq_scaled(rhs, N, 1.0) / (double)N);
+        for (int i = 1; i <= iters; ++i) {
+            res_rms = orc_jacobi2d(u_f, rhs, h, c, res_f, nx, ny, 4.0 / 5.0);
+            ++g_coarse_iters;
+            if (res_rms < tol_rhs) break;
+        }
+    } else { /* :160-162 */
+        int it = 0;
+        res_rms = orc_cg2d(u_f, rhs, h, h, c, tol, 20 * coarse_solve_size, nx, ny, &it);
+        g_coarse_iters += it;
+    }
+    free(res_f);
+    return res_rms;
+}
+
+/* B8: MGsolve_2DPoisson! -- multigrid.jl:41-84.  history[it] = r_rms after V-cycle it (absolute);
+ * *ncycles_out = V-cycles executed.  Returns r_rms (or -2 on the reference's @assert failures :45-46). */
+double orc_mgsolve2d(double *u, const double *f, double h, double c, double tol, int niters, int apply_BCs,
+                     int coarse_solve_size, int coarse_solver, int nx, int ny, double *history,
+                     int *ncycles_out, double *f_rms_out)
+{
+    const size_t N = (size_t)nx * ny;
+    {
+        int m = coarse_solve_size - 1;
+        if (coarse_solve_size > (nx < ny ? nx : ny) || m <= 0 || (m & (m - 1)) != 0) return -2.0;
+    }
+    const double f_rms = sqrt(sumsq_scaled(f, N, 1.0) / (double)N); /* :53 */
+    const double tolf = tol * f_rms;
+    double r_rms = 0.0;
+    int n = 0;
+    g_coarse_iters = 0;
+    for (int iter = 1; iter <= niters; ++iter) {
+        if (apply_BCs) orc_bc2d(u, nx, ny); /* :60-62 */
+        r_rms = orc_vcycle2d(u, f, h, c, tol, coarse_solve_size, coarse_solver, apply_BCs, nx, ny);
+        if (history) history[n] = r_rms;
+        ++n;
+        if (r_rms < 0) break;
+        if (r_rms < tolf) break; /* :70 */
+    }
+    if (ncycles_out) *ncycles_out = n;
+    if (f_rms_out) *f_rms_out = f_rms;
+    return r_rms;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* NEXT row 8f-1: Navier-Stokes pointwise kernels -- scripts-part2/part2.jl:90-137               */
+/* ------------------------------------------------------------------------------------------ */
+
+void orc_compute_velocity(const double *S, double hx, double hy, double *vx, double *vy, int nx, int ny)
+{
+    for (int j = 1; j < ny - 1; ++j)
+        for (int i = 1; i < nx - 1; ++i) {
+            vx[I2(i, j)] = (S[I2(i, j + 1)] - S[I2(i, j - 1)]) / (2 * hy);   /* :92 */
+            vy[I2(i, j)] = -(S[I2(i + 1, j)] - S[I2(i - 1, j)]) / (2 * hx);  /* :93 */
+        }
+}
+
+void orc_compute_Ra_dTdx(double Ra, double hx, const double *T, double *out, int nx, int ny)
+{
+    for (int j = 1; j < ny - 1; ++j)
+        for (int i = 1; i < nx - 1; ++i)
+            out[I2(i, j)] = Ra * (T[I2(i + 1, j)] - T[I2(i - 1, j)]) / (2 * hx); /* :101 */
+}
+
+void orc_compute_diffusion2d(const double *T, double hx, double hy, double k, double *dT2, int nx, int ny)
+{
+    const double hx2 = hx * hx, hy2 = hy * hy;
+    for (int j = 1; j < ny - 1; ++j)
+        for (int i = 1; i < nx - 1; ++i) {
+            const double t = T[I2(i, j)];
+            dT2[I2(i, j)] = k * (((T[I2(i + 1, j)] - 2 * t) + T[I2(i - 1, j)]) / hx2 +
+                                 ((T[I2(i, j + 1)] - 2 * t) + T[I2(i, j - 1)]) / hy2); /* :109-110 */
+        }
+}
+
+void orc_compute_advection2d_x(const double *T, double hx, const double *vx, double *dTx, int nx, int ny)
+{
+    for (int j = 1; j < ny - 1; ++j)
+        for (int i = 1; i < nx - 1; ++i) {
+            const double v = vx[I2(i, j)];
+            if (v > 0) dTx[I2(i, j)] = v * (T[I2(i, j)] - T[I2(i - 1, j)]) / hx; /* :119 */
+            else       dTx[I2(i, j)] = v * (T[I2(i + 1, j)] - T[I2(i, j)]) / hx; /* :121 */
+        }
+}
+
+void orc_compute_advection2d_y(const double *T, double hy, const double *vy, double *dTy, int nx, int ny)
+{
+    for (int j = 1; j < ny - 1; ++j)
+        for (int i = 1; i < nx - 1; ++i) {
+            const double v = vy[I2(i, j)];
+            if (v > 0) dTy[I2(i, j)] = v * (T[I2(i, j)] - T[I2(i, j - 1)]) / hy; /* :131 */
+            else       dTy[I2(i, j)] = v * (T[I2(i, j + 1)] - T[I2(i, j)]) / hy; /* :133 */
+        }
+}

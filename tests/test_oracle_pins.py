@@ -1,0 +1,254 @@
+"""Pins the CPU oracle (oracle/fpr_oracle.c) against every fixture and known-answer test the
+reference's own test-suite holds for the hot path.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from fixtures_io import load_bin, part1_reference, splitmix64_uniform
+from oracle.oracle import asf, farr
+
+
+def stencil_5pt(nx, ny):
+    """scripts-part2/part2_utils.jl:42-49 (test oracle of the reference itself)."""
+    dx = sp.diags([np.ones(nx - 1), -2 * np.ones(nx), np.ones(nx - 1)], [-1, 0, 1])
+    dy = sp.diags([np.ones(ny - 1), -2 * np.ones(ny), np.ones(ny - 1)], [-1, 0, 1])
+    return (sp.kron(dy, sp.identity(nx)) + sp.kron(sp.identity(ny), dx)).tocsr()
+
+
+# ---------------------------------------------------------------- Part 1: test/part1.jl:24-40
+def test_part1_bson_reference(oracle):
+    ref = part1_reference()
+    n = 32
+    dx = 10.0 / n
+    Ht = oracle.init_gaussian((n, n, n), dx, dx, dx, (5.0, 5.0, 5.0))
+    oracle.apply_bc3d(Ht, (0, 0, 0), (1, 1, 1))  # no-op on one rank (part1_utils.jl:14-34)
+    assert abs(Ht[0, 0, 0] - 2 * math.exp(-3 * (dx / 2 - 5.0) ** 2)) < 1e-30
+    iters, err, _, _ = oracle.diffusion3d_solve(Ht, nt=5, tol=1e-8)
+    inds = np.ceil(np.linspace(1, n, 12)).astype(int) - 1  # test/part1.jl:25
+    H = Ht[:, :, 14][np.ix_(inds, inds)]
+    X = np.linspace(dx / 2, 10.0 - dx / 2, n)[inds]
+    assert np.allclose(X, ref["X"], rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(ref["X"][:2], [0.15625, 1.09375])
+    d = np.abs(H - ref["H"]).max()
+    assert d < 1e-5, d  # the reference's own tolerance (isapprox atol=1e-5)
+    assert d < 2e-6  # restatement sits 1.19e-6 from the (older) BSON file
+    # the file's corner is the untouched Gaussian boundary value: boundaries are NOT zeroed on a
+    # single rank (part1_utils.jl:14-34 compares 0-based coords with 1).  In the kernel variant the
+    # boundary ping-pongs between the IC (buffer Htau) and 0 (buffer Htau2 = @zeros), so after an odd
+    # total iteration count (927) the kernel result holds 0 there -- inside the reference's atol.
+    g = 2 * math.exp(-((dx / 2 - 5.0) ** 2 + (dx / 2 - 5.0) ** 2 + (14 * dx + dx / 2 - 5.0) ** 2))
+    assert abs(ref["H"][0, 0] - g) < 1e-30
+    assert Ht[0, 0, 14] in (0.0, g) and sum(iters) % 2 == 1 and Ht[0, 0, 14] == 0.0
+    assert iters == [188, 187, 185, 184, 183]  # SURVEY 4.4 known-answer
+    assert np.all(err <= 1e-8)
+
+
+def test_part1_split_equals_fused_at_fixed_iterations(oracle):
+    """compute_flux!/compute_dHdtau!/update_H! (clean semantics of part1_array_programming.jl:9-18)
+    vs the fused kernel (part1_kernel_programming.jl:46-58): same maths, different rounding."""
+    n = 24
+    dx = 10.0 / n
+    D, dt = 1.0, 0.2
+    dtau = dx * dx / D / 8.1
+    Ht = oracle.init_gaussian((n, n, n), dx, dx, dx, (5.0, 5.0, 5.0))
+    A = Ht.copy(order="F")
+    B = Ht.copy(order="F")
+    A2, rA = farr(n, n, n), farr(n, n, n)
+    qx, qy, qz = farr(n - 1, n - 2, n - 2), farr(n - 2, n - 1, n - 2), farr(n - 2, n - 2, n - 1)
+    dH = farr(n - 2, n - 2, n - 2)
+    for _ in range(20):
+        oracle.diffusion3d_step(Ht, A, A2, rA, dtau, 1 / dt, 1 / dx, 1 / dx, 1 / dx, D / dx, D / dx, D / dx)
+        A2[0, :, :], A2[-1, :, :], A2[:, 0, :], A2[:, -1, :], A2[:, :, 0], A2[:, :, -1] = (
+            A[0, :, :], A[-1, :, :], A[:, 0, :], A[:, -1, :], A[:, :, 0], A[:, :, -1])
+        A, A2 = A2, A
+        oracle.diffusion3d_flux(qx, qy, qz, B, D, dx, dx, dx)
+        oracle.diffusion3d_dHdtau(dH, B, Ht, qx, qy, qz, dt, dx, dx, dx)
+        oracle.diffusion3d_update(B, dH, dtau)
+    assert np.abs(A - B).max() < 1e-13
+    assert np.abs(rA[1:-1, 1:-1, 1:-1] + dH).max() < 1e-12  # opposite sign convention
+
+
+def test_part1_error_vs_tolerance_csv_value(oracle):
+    """benchmark-results/error_vs_tolerance_experiment_results.csv is at 128^3 (too slow for CI);
+    the 32^3 solve must at least converge monotonically in err per step."""
+    n = 16
+    dx = 10.0 / n
+    Ht = oracle.init_gaussian((n, n, n), dx, dx, dx, (5.0, 5.0, 5.0))
+    iters, err, _, _ = oracle.diffusion3d_solve(Ht, nt=2, tol=1e-6)
+    assert all(i > 1 for i in iters) and np.all(err <= 1e-6)
+
+
+# ---------------------------------------------------------------- Part 2: test/part2.jl
+def test_mgsolve_matches_fortran_streamfunction(oracle):
+    """test/part2.jl:8,29,36: MGsolve_2DPoisson!(S, Winit, h, 0, 1e-12, 50, false) vs S.bin, 1e-8."""
+    W = load_bin("Winit.bin")
+    Sref = load_bin("S.bin")
+    nx, ny = W.shape
+    assert (nx, ny) == (257, 65)
+    h = 1.0 / (ny - 1.0)
+    S = farr(nx, ny)
+    r, hist, frms = oracle.mgsolve2d(S, W, h, 0.0, 1e-12, 50)
+    assert np.abs(S[1:-1, 1:-1] - Sref[1:-1, 1:-1]).max() < 1e-8  # reference tolerance
+    assert np.abs(S[1:-1, 1:-1] - Sref[1:-1, 1:-1]).max() < 1e-13  # 5.2e-15
+    assert len(hist) == 14  # SURVEY 4.4 known-answer
+    rel = hist / frms
+    expect = [1.73e-1, 1.24e-2, 1.48e-3, 1.90e-4, 2.42e-5, 3.20e-6, 4.22e-7, 5.70e-8, 7.76e-9,
+              1.07e-9, 1.50e-10, 2.12e-11, 3.02e-12, 4.59e-13]
+    assert np.allclose(rel, expect, rtol=6e-3)
+    assert r < 1e-12 * frms
+
+
+def test_fortran_per_kernel_vectors(oracle):
+    """Unused-but-present fixtures pin the NEXT-row kernels (part2.jl:90-137, :229-230)."""
+    S, T0 = load_bin("S.bin"), load_bin("Tinit.bin")
+    W0 = load_bin("Winit.bin")
+    nx, ny = S.shape
+    h = 1.0 / (ny - 1.0)
+    Ra, Pr, k = 1.0e6, 1.0e-3, 1.0
+    vx, vy = farr(nx, ny), farr(nx, ny)
+    oracle.compute_velocity(S, h, h, vx, vy)
+    inner = (slice(1, -1), slice(1, -1))
+    assert np.abs(vx[inner] - load_bin("vx.bin")[inner]).max() < 1e-9
+    assert np.abs(vy[inner] - load_bin("vy.bin")[inner]).max() < 1e-9
+    T = T0.copy(order="F")
+    oracle.bc2d(T)
+    R = farr(nx, ny)
+    oracle.compute_Ra_dTdx(Ra, h, T, R)
+    assert np.abs(R[inner] - load_bin("Ra_dTdx.bin")[inner]).max() <= 1e-9 * np.abs(R).max()
+    dT2, dW2 = farr(nx, ny), farr(nx, ny)
+    oracle.compute_diffusion2d(T, h, h, k, dT2)
+    oracle.compute_diffusion2d(W0, h, h, Pr, dW2)
+    assert np.abs(dT2[inner] - load_bin("dT2.bin")[inner]).max() < 1e-9
+    assert np.abs(dW2[inner] - load_bin("dW2.bin")[inner]).max() < 1e-9
+    dTx, dTy, dWx, dWy = (farr(nx, ny) for _ in range(4))
+    oracle.compute_advection2d_x(T, h, vx, dTx)
+    oracle.compute_advection2d_y(T, h, vy, dTy)
+    oracle.compute_advection2d_x(W0, h, vx, dWx)
+    oracle.compute_advection2d_y(W0, h, vy, dWy)
+    v = np.sqrt(vx ** 2 + vy ** 2)
+    dt_dif = 0.15 * h * h / max(k, Pr)
+    dt_adv = 0.4 * min(h / np.abs(vx).max(), h / np.abs(vy).max())
+    dt = min(dt_dif, dt_adv) if v.max() != 0 else dt_dif
+    assert dt == dt_dif == 3.662109375e-05
+    T1 = T + dt * (dT2 - dTx - dTy)
+    W1 = W0 + dt * (dW2 - dWx - dWy - Pr * R)
+    assert np.abs(T1[inner] - load_bin("T.bin")[inner]).max() < 1e-8  # test/part2.jl:33
+    assert np.abs(W1[inner] - load_bin("W.bin")[inner]).max() < 1e-8
+    assert np.abs(T1[inner] - load_bin("T.bin")[inner]).max() < 1e-14
+
+
+# ---------------------------------------------------------------- test/multigrid.jl:102-138
+@pytest.mark.parametrize("n", [64, 33])
+def test_residual_operator_identity(oracle, n):
+    h = 1.0 / (n - 1)
+    c = 3.1415
+    u = asf(splitmix64_uniform(n * n, 7).reshape((n, n), order="F"))
+    u[0, :] = u[-1, :] = 0.0
+    u[:, 0] = u[:, -1] = 0.0
+    f = asf(splitmix64_uniform(n * n, 8).reshape((n, n), order="F"))
+    res = farr(n, n)
+    oracle.residual2d(u, f, h, c, res)
+    A = stencil_5pt(n - 2, n - 2) / h ** 2 - c * sp.identity((n - 2) ** 2)
+    ref = A @ u[1:-1, 1:-1].ravel(order="F") - f[1:-1, 1:-1].ravel(order="F")
+    got = res[1:-1, 1:-1].ravel(order="F")
+    assert np.allclose(got, ref, rtol=1.5e-8, atol=0)  # Julia `≈`: rtol sqrt(eps) on the norm
+    assert np.linalg.norm(got - ref) <= 1e-12 * np.linalg.norm(ref)
+    assert np.all(res[0, :] == 0) and np.all(res[:, 0] == 0)  # boundary untouched
+
+
+# ---------------------------------------------------------------- test/multigrid.jl:30-58
+@pytest.mark.parametrize("solver", [0, 1])
+@pytest.mark.parametrize("l", [2, 3])
+@pytest.mark.parametrize("k", [7, 8, 9])
+def test_multigrid_convergence(oracle, k, l, solver):
+    n = 2 ** k + 1
+    h = 1.0 / (n - 1)
+    tol = 1e-6
+    xref = farr(n, n)
+    xref[1:-1, 1:-1] = splitmix64_uniform((n - 2) ** 2, 3).reshape((n - 2, n - 2), order="F")
+    A = stencil_5pt(n - 2, n - 2) / h ** 2
+    b = farr(n, n)
+    b[1:-1, 1:-1] = (A @ xref[1:-1, 1:-1].ravel(order="F")).reshape((n - 2, n - 2), order="F")
+    x = farr(n, n)
+    r, hist, frms = oracle.mgsolve2d(x, b, h, 0.0, tol, 20, False, 2 ** l + 1, solver)
+    assert r < tol * math.sqrt((b ** 2).sum() / (n * n))
+    assert len(hist) <= 12
+
+
+def test_mgsolve_random_rhs_cycle_count(oracle):
+    """multigrid_bench.jl:29-42 protocol: x=0, b~U[0,1) incl. boundary, tol 1e-6, l=2 -> 7 V-cycles
+    (mesh independent)."""
+    for k in (8, 9):
+        n = 2 ** k + 1
+        b = asf(splitmix64_uniform(n * n, 1).reshape((n, n), order="F"))
+        x = farr(n, n)
+        r, hist, frms = oracle.mgsolve2d(x, b, 1.0 / (n - 1), 0.0, 1e-6, 100)
+        assert len(hist) == 7, hist / frms
+
+
+def test_mgsolve_asserts(oracle):
+    x, b = farr(33, 33), farr(33, 33)
+    assert oracle.mgsolve2d(x, b, 1 / 32, 0.0, 1e-6, 5, False, 6, 0)[0] == -2.0  # multigrid.jl:46
+    assert oracle.mgsolve2d(x, b, 1 / 32, 0.0, 1e-6, 5, False, 65, 0)[0] == -2.0  # multigrid.jl:45
+    x, b = farr(34, 34), farr(34, 34)
+    assert oracle.vcycle2d(x, b, 1 / 33, 0.0, 1e-6) == -1.0  # multigrid.jl:95-97
+
+
+# ---------------------------------------------------------------- test/multigrid.jl:60-100
+def test_jacobi_solver(oracle):
+    n = 33
+    h = 1.0 / (n - 1)
+    tol = 1e-6
+    xref = asf(splitmix64_uniform(n * n, 5).reshape((n, n), order="F"))
+    xref[0, :] = xref[-1, :] = 0.0
+    xref[:, 0] = xref[:, -1] = 0.0
+    A = stencil_5pt(n - 2, n - 2) / h ** 2
+    b = farr(n, n)
+    b[1:-1, 1:-1] = (A @ xref[1:-1, 1:-1].ravel(order="F")).reshape((n - 2, n - 2), order="F")
+    x, res = farr(n, n), farr(n, n)
+    tolb = tol * math.sqrt((b ** 2).sum() / (n * n))
+    for i in range(10000):
+        if oracle.jacobi2d(x, b, h, 0.0, res) < tolb:
+            break
+    assert i < 9999
+    assert np.linalg.norm(xref - x) / np.linalg.norm(xref) < tolb
+
+
+# ---------------------------------------------------------------- test/krylov.jl:19-36
+def test_cg(oracle):
+    n = 66
+    h = 1.0 / (n - 1)
+    b = asf(np.ones((n, n)))
+    b[0, :] = b[-1, :] = 0.0
+    b[:, 0] = b[:, -1] = 0.0
+    x = farr(n, n)
+    r, it = oracle.cg2d(x, b, h, h, 3.14, 1e-6, 1000)
+    assert r < 1e-6 * math.sqrt((b ** 2).sum() / n ** 2)
+    assert 1 < it < 1000
+    out = farr(n, n)
+    oracle.laplace_apply2d(x, h, h, 3.14, out)
+    assert np.abs(out[1:-1, 1:-1] - b[1:-1, 1:-1]).max() < 1e-4
+
+
+def test_restrict_prolongate_shapes_and_weights(oracle):
+    nx, ny = 17, 9
+    fine = asf(np.arange(nx * ny, dtype=float).reshape((nx, ny), order="F"))
+    coarse = asf(np.full((9, 5), 7.0))
+    oracle.restrict2d(fine, coarse)
+    assert np.all(coarse[0, :] == 0) and np.all(coarse[:, 0] == 0) and np.all(coarse[-1, :] == 0)
+    assert np.array_equal(coarse[1:-1, 1:-1], fine[2:-2:2, 2:-2:2])
+    coarse[:] = 0
+    coarse[3, 2] = 1.0
+    out = asf(np.full((nx, ny), 9.0))
+    oracle.prolongate2d(coarse, out)
+    w = out[5:8, 3:6]
+    assert np.array_equal(w, np.array([[0.25, 0.5, 0.25], [0.5, 1.0, 0.5], [0.25, 0.5, 0.25]]))
+    assert out.sum() == 4.0
+    # coarse boundary values are never scattered (sources are interior coarse points only)
+    coarse[:] = 1.0
+    oracle.prolongate2d(coarse, out)
+    assert np.all(out[0, :] == 0) and np.all(out[:, 0] == 0) and out[1, 1] == 0.25 and out[2, 2] == 1.0
+    oracle.prolongate2d(coarse, out, True)
+    assert np.array_equal(out[0, :], out[1, :]) and np.array_equal(out[-1, :], out[-2, :])

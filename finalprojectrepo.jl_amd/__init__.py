@@ -1,0 +1,47 @@
+"""finalprojectrepo.jl_amd -- MI355X-native stencil hot path of ntselepidis/FinalProjectRepo.jl.
+
+Host-side mirror (Python; Julia is not available in this environment -- see DESIGN.md) of the
+reference's script-level API for the hot path, on top of the C ABI of libfpr_hip.so (include/fpr.h):
+
+    part1       scripts-part1/part1_kernel_programming.jl, part1_array_programming.jl, part1_utils.jl
+    multigrid   scripts-part2/multigrid.jl, krylov.jl, part2_utils.jl
+    part2       scripts-part2/part2.jl (NEXT row 8f-1)
+    grid        ImplicitGlobalGrid's role: Cartesian decomposition + RCCL halo exchange
+
+Julia's `f!` is spelled `f_` here; Unicode names (Hτ, dτ, diffusion_3D_step_τ) are kept.
+There is NO CPU fallback: every compute entry point calls the HIP library and raises if it is missing.
+"""
+from . import _lib
+from ._lib import Context, FprError, asdevice, fzeros, fones, tonumpy, lib_path  # noqa: F401
+
+_default_ctx = None
+
+
+def init(device=0):
+    """@init_parallel_stencil(...) / select_device(): create the default context on `device`."""
+    global _default_ctx
+    if _default_ctx is None or _default_ctx.device != device:
+        _default_ctx = Context(device)
+    return _default_ctx
+
+
+def ctx():
+    if _default_ctx is None:
+        return init(0)
+    return _default_ctx
+
+
+def reset():
+    """@reset_parallel_stencil()"""
+    global _default_ctx
+    if _default_ctx is not None:
+        _default_ctx.close()
+    _default_ctx = None
+
+
+def synchronize():
+    """@synchronize()"""
+    ctx().synchronize()
+
+
+from . import part1, multigrid, part2, grid  # noqa: E402,F401

@@ -1,0 +1,215 @@
+"""ctypes binding of libfpr_hip.so (include/fpr.h) + device-array helpers.
+
+torch is used for device memory, streams and (in grid.py) torch.distributed -- plumbing only.
+Field arrays are torch float64 CUDA tensors with Julia (column-major) strides: a tensor of Julia
+shape (nx, ny, nz) has strides (1, nx, nx*ny); build them with fzeros()/asdevice().
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FPR_COARSE_JACOBI = 0
+FPR_COARSE_CG = 1
+ERRORS = {-1: "FPR_ERR_INVALID", -2: "FPR_ERR_HIP", -3: "FPR_ERR_NOT_POW2", -4: "FPR_ERR_ASSERT", -5: "FPR_ERR_NO_DEVICE"}
+
+
+class FprError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "FPR_ERR"), code, msg))
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libfpr_hip.so")
+
+
+def build(verbose=False):
+    """Compile libfpr_hip.so for gfx950 with hipcc (csrc/Makefile)."""
+    import subprocess
+
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"] + ([] if verbose else ["-s"])
+    subprocess.check_call(cmd)
+    return lib_path()
+
+
+_d, _i, _l, _z, _vp = C.c_double, C.c_int, C.c_long, C.c_size_t, C.c_void_p
+_dp = C.c_void_p  # device pointers travel as integers
+_SIG = {
+    "fpr_ctx_create": [C.POINTER(_vp), _i, _vp, _vp],
+    "fpr_ctx_destroy": [_vp],
+    "fpr_synchronize": [_vp],
+    "fpr_set_option": [_vp, C.c_char_p, _l],
+    "fpr_stream_wait": [_vp, _i, _i],
+    "fpr_kernel_timer": [_vp, _i],
+    "fpr_kernel_timer_read": [_vp, C.POINTER(_d), C.POINTER(_l)],
+    "fpr_diffusion3d_step": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8,
+    "fpr_diffusion3d_step_norm": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8 + [_d, _dp],
+    "fpr_diffusion3d_step_box": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8 + [C.POINTER(_i), C.POINTER(_i), _d, _dp, _i],
+    "fpr_diffusion3d_flux": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 4,
+    "fpr_diffusion3d_dHdtau": [_vp] + [_dp] * 6 + [_i] * 3 + [_d] * 4,
+    "fpr_diffusion3d_update": [_vp] + [_dp] * 2 + [_i] * 3 + [_d],
+    "fpr_sumsq_scaled_dev": [_vp, _dp, _z, _d, _dp],
+    "fpr_sumsq_scaled": [_vp, _dp, _z, _d, C.POINTER(_d)],
+    "fpr_dot": [_vp, _dp, _dp, _z, C.POINTER(_d)],
+    "fpr_absmax": [_vp, _dp, _z, C.POINTER(_d)],
+    "fpr_copy": [_vp, _dp, _dp, _z],
+    "fpr_fill": [_vp, _dp, _d, _z],
+    "fpr_init_gaussian3d": [_vp, _dp] + [_i] * 3 + [_d] * 6 + [_i] * 3,
+    "fpr_halo_pack3d": [_vp, _dp, _i, _i, _i, _i, _dp, _i],
+    "fpr_halo_unpack3d": [_vp, _dp, _i, _i, _i, _i, _dp, _i],
+    "fpr_residual2d": [_vp, _dp, _dp, _d, _d, _dp, _i, _i],
+    "fpr_jacobi2d": [_vp, _dp, _dp, _d, _d, _dp, _i, _i, _d, C.POINTER(_d)],
+    "fpr_restrict2d": [_vp, _dp, _dp, _i, _i, _i],
+    "fpr_prolongate2d": [_vp, _dp, _dp, _i, _i, _i],
+    "fpr_axmy2d": [_vp, _dp, _dp, _z],
+    "fpr_laplace_apply2d": [_vp, _dp, _d, _d, _d, _dp, _i, _i],
+    "fpr_bc_dirichlet2d": [_vp, _dp, _i, _i],
+    "fpr_bc_neumann2d": [_vp, _dp, _i, _i],
+    "fpr_bc2d": [_vp, _dp, _i, _i],
+    "fpr_vcycle2d": [_vp, _dp, _dp, _d, _d, _d, _i, _i, _i, _i, _i, C.POINTER(_d)],
+    "fpr_mgsolve2d": [_vp, _dp, _dp, _d, _d, _d, _i, _i, _i, _i, _i, _i, C.POINTER(_d), C.POINTER(_i), C.POINTER(_d),
+                      C.POINTER(_d), C.POINTER(_i)],
+    "fpr_cg2d": [_vp, _dp, _dp, _d, _d, _d, _d, _i, _i, _i, C.POINTER(_d), C.POINTER(_i)],
+    "fpr_compute_velocity2d": [_vp, _dp, _d, _d, _dp, _dp, _i, _i],
+    "fpr_compute_Ra_dTdx2d": [_vp, _d, _d, _dp, _dp, _i, _i],
+    "fpr_compute_diffusion2d": [_vp, _dp, _d, _d, _d, _dp, _i, _i],
+    "fpr_compute_advection2d_x": [_vp, _dp, _d, _dp, _dp, _i, _i],
+    "fpr_compute_advection2d_y": [_vp, _dp, _d, _dp, _dp, _i, _i],
+}
+# every symbol include/fpr.h declares (checked by tests/test_abi.py)
+ALL_SYMBOLS = sorted(list(_SIG) + ["fpr_last_error", "fpr_version", "fpr_get_option", "fpr_last_coarse_iters"])
+
+
+def load_library():
+    """dlopen libfpr_hip.so.  No fallback: a missing library is an error."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "libfpr_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path
+        )
+    L = C.CDLL(path)
+    for name, args in _SIG.items():
+        f = getattr(L, name)
+        f.argtypes = args
+        f.restype = _i
+    L.fpr_last_error.argtypes = [_vp]
+    L.fpr_last_error.restype = C.c_char_p
+    L.fpr_version.argtypes = []
+    L.fpr_version.restype = C.c_char_p
+    L.fpr_get_option.argtypes = [_vp, C.c_char_p]
+    L.fpr_get_option.restype = _l
+    L.fpr_last_coarse_iters.argtypes = [_vp]
+    L.fpr_last_coarse_iters.restype = _l
+    _LIB = L
+    return L
+
+
+# ------------------------------------------------------------------------------------------------
+# device arrays (Julia layout)
+# ------------------------------------------------------------------------------------------------
+def _torch():
+    import torch
+
+    return torch
+
+
+def fzeros(*shape, device=None):
+    """@zeros(nx, ny[, nz]) -- float64, column-major."""
+    torch = _torch()
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    t = torch.zeros(tuple(reversed(shape)), dtype=torch.float64, device=dev)
+    return t.permute(*reversed(range(len(shape))))
+
+
+def fones(*shape, device=None):
+    t = fzeros(*shape, device=device)
+    t.fill_(1.0)
+    return t
+
+
+def asdevice(a, device=None):
+    """Data.Array(host_array): numpy (any order) -> column-major device tensor."""
+    torch = _torch()
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    a = np.asarray(a, dtype=np.float64)
+    t = torch.from_numpy(np.ascontiguousarray(a.T)).to(dev)
+    return t.permute(*reversed(range(a.ndim)))
+
+
+def tonumpy(t):
+    """Array(device_array) -> Fortran-ordered numpy array."""
+    nd = t.dim()
+    return np.asfortranarray(t.permute(*reversed(range(nd))).contiguous().cpu().numpy().T)
+
+
+def fptr(t, ndim=None):
+    """Raw device pointer of a column-major float64 CUDA tensor (validated)."""
+    torch = _torch()
+    if not (isinstance(t, torch.Tensor) and t.dtype == torch.float64 and t.is_cuda):
+        raise TypeError("expected a float64 CUDA tensor")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError("expected a %d-D array, got %d-D" % (ndim, t.dim()))
+    st = 1
+    for n, s in zip(t.shape, t.stride()):
+        if n != 1 and s != st:
+            raise ValueError("array is not column-major contiguous: shape %s strides %s" % (tuple(t.shape), t.stride()))
+        st *= n
+    return t.data_ptr()
+
+
+class Context:
+    """fpr_ctx wrapper.  Two torch streams (compute, comm) are created and handed to the library so
+    torch ops, torch.cuda.Event timing and the library's kernels share them."""
+
+    def __init__(self, device=0):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the fpr hot path needs an MI355X (there is no CPU fallback)")
+        self.L = load_library()
+        self.device = device
+        torch.cuda.set_device(device)
+        # One dedicated compute stream becomes torch's CURRENT stream for this process, so torch
+        # allocations / fills / copies and the library's kernels are ordered on the same stream.
+        torch.cuda.synchronize(device)
+        self.compute = torch.cuda.Stream(device=device)
+        self.comm = torch.cuda.Stream(device=device)
+        torch.cuda.set_stream(self.compute)
+        h = _vp()
+        rc = self.L.fpr_ctx_create(C.byref(h), device, _vp(self.compute.cuda_stream), _vp(self.comm.cuda_stream))
+        if rc != 0:
+            raise FprError(rc, "fpr_ctx_create failed")
+        self.h = h
+        # scratch device scalars for fused norms
+        self.scal = torch.zeros(16, dtype=torch.float64, device=torch.device("cuda", device))
+        self._closed = False
+
+    def call(self, name, *args):
+        rc = getattr(self.L, name)(self.h, *args)
+        if rc != 0:
+            raise FprError(rc, self.L.fpr_last_error(self.h).decode())
+        return rc
+
+    def set_option(self, key, value):
+        self.call("fpr_set_option", key.encode(), int(value))
+
+    def synchronize(self):
+        self.call("fpr_synchronize")
+
+    def close(self):
+        if not self._closed:
+            self.L.fpr_ctx_destroy(self.h)
+            self._closed = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,295 @@
+// context.hip -- lifecycle, streams, reductions and flat-array utilities of libfpr_hip.so (gfx950).
+#include "fpr_internal.hpp"
+
+extern "C" const char* fpr_version(void) { return "fpr-hip 0.1 (gfx950, fp64, no-fma)"; }
+
+extern "C" int fpr_ctx_create(fpr_ctx** out, int device, void* compute_stream, void* comm_stream)
+{
+    if (!out) return FPR_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FPR_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return FPR_ERR_INVALID;
+    fpr_ctx* ctx = new fpr_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return FPR_ERR_HIP; }
+    void* given[2] = {compute_stream, comm_stream};
+    for (int s = 0; s < 2; ++s) {
+        if (given[s]) {
+            ctx->stream[s] = (hipStream_t)given[s];
+        } else {
+            if (hipStreamCreateWithFlags(&ctx->stream[s], hipStreamNonBlocking) != hipSuccess) { delete ctx; return FPR_ERR_HIP; }
+            ctx->own_stream[s] = true;
+        }
+        if (hipEventCreateWithFlags(&ctx->ev[s], hipEventDisableTiming) != hipSuccess) { delete ctx; return FPR_ERR_HIP; }
+    }
+    bool ok = hipMalloc(&ctx->partials, FPR_MAX_PARTIALS * sizeof(double)) == hipSuccess &&
+              hipMalloc(&ctx->partials2, FPR_MAX_PARTIALS * sizeof(double)) == hipSuccess &&
+              hipMalloc(&ctx->scalars, 64 * sizeof(double)) == hipSuccess &&
+              hipMalloc(&ctx->state, sizeof(FprSolveState)) == hipSuccess &&
+              hipHostMalloc(&ctx->state_h, sizeof(FprSolveState)) == hipSuccess &&
+              hipHostMalloc(&ctx->host_scalars, 64 * sizeof(double)) == hipSuccess;
+    if (!ok) { fpr_ctx_destroy(ctx); return FPR_ERR_HIP; }
+    hipMemset(ctx->scalars, 0, 64 * sizeof(double));
+    hipMemset(ctx->state, 0, sizeof(FprSolveState));
+    *out = ctx;
+    return FPR_OK;
+}
+
+extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
+{
+    if (!ctx) return FPR_OK;
+    hipSetDevice(ctx->device);
+    for (int s = 0; s < 2; ++s)
+        if (ctx->stream[s]) hipStreamSynchronize(ctx->stream[s]);
+    for (auto& kv : ctx->arenas)
+        for (auto& L : kv.second) {
+            if (L.tmp) hipFree(L.tmp);
+            if (L.res_c) hipFree(L.res_c);
+            if (L.corr_c) hipFree(L.corr_c);
+        }
+    for (auto& e : ctx->ktimer_ev) hipEventDestroy(e);
+    if (ctx->cg_buf) hipFree(ctx->cg_buf);
+    if (ctx->partials) hipFree(ctx->partials);
+    if (ctx->partials2) hipFree(ctx->partials2);
+    if (ctx->scalars) hipFree(ctx->scalars);
+    if (ctx->state) hipFree(ctx->state);
+    if (ctx->state_h) hipHostFree(ctx->state_h);
+    if (ctx->host_scalars) hipHostFree(ctx->host_scalars);
+    for (int s = 0; s < 2; ++s) {
+        if (ctx->ev[s]) hipEventDestroy(ctx->ev[s]);
+        if (ctx->own_stream[s] && ctx->stream[s]) hipStreamDestroy(ctx->stream[s]);
+    }
+    delete ctx;
+    return FPR_OK;
+}
+
+extern "C" int fpr_synchronize(fpr_ctx* ctx)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
+    FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));
+    return FPR_OK;
+}
+
+extern "C" const char* fpr_last_error(fpr_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+extern "C" int fpr_set_option(fpr_ctx* ctx, const char* key, long value)
+{
+    if (!ctx || !key) return FPR_ERR_INVALID;
+    ctx->options[key] = value;
+    return FPR_OK;
+}
+
+extern "C" long fpr_get_option(fpr_ctx* ctx, const char* key)
+{
+    if (!ctx || !key) return 0;
+    return fpr_opt(ctx, key, 0);
+}
+
+extern "C" int fpr_kernel_timer(fpr_ctx* ctx, int enable)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    if (enable && ctx->ktimer_ev.empty()) {
+        ctx->ktimer_ev.resize(2 * 8192);
+        for (auto& e : ctx->ktimer_ev) FPR_HIP(ctx, hipEventCreate(&e));
+    }
+    ctx->ktimer_on = enable != 0;
+    if (enable) ctx->ktimer_used = 0;
+    return FPR_OK;
+}
+
+extern "C" int fpr_kernel_timer_read(fpr_ctx* ctx, double* total_ms_host, long* count_host)
+{
+    if (!ctx || !total_ms_host || !count_host) return FPR_ERR_INVALID;
+    FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
+    FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < ctx->ktimer_used; i += 2) {
+        float ms = 0.f;
+        FPR_HIP(ctx, hipEventElapsedTime(&ms, ctx->ktimer_ev[i], ctx->ktimer_ev[i + 1]));
+        tot += ms;
+    }
+    *total_ms_host = tot;
+    *count_host = (long)(ctx->ktimer_used / 2);
+    return FPR_OK;
+}
+
+extern "C" int fpr_stream_wait(fpr_ctx* ctx, int waiter, int signaller)
+{
+    if (!ctx || waiter < 0 || waiter > 1 || signaller < 0 || signaller > 1) return FPR_ERR_INVALID;
+    if (waiter == signaller) return FPR_OK;
+    FPR_HIP(ctx, hipEventRecord(ctx->ev[signaller], ctx->stream[signaller]));
+    FPR_HIP(ctx, hipStreamWaitEvent(ctx->stream[waiter], ctx->ev[signaller], 0));
+    return FPR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// flat streaming kernels: 16 B per lane, grid-stride, grid capped at 8 blocks per CU
+// ---------------------------------------------------------------------------------------------
+static inline int flat_grid(size_t nvec)
+{
+    size_t b = (nvec + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+__global__ __launch_bounds__(256) void k_copy(double* __restrict__ dst, const double* __restrict__ src, size_t n)
+{
+    const size_t n2 = n / 2;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const bool aligned = (((uintptr_t)dst | (uintptr_t)src) & 15) == 0;
+    if (aligned) {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride)
+            reinterpret_cast<double2*>(dst)[i] = reinterpret_cast<const double2*>(src)[i];
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1];
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill(double* __restrict__ dst, double v, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = v;
+}
+
+// u .= u - corr   (multigrid.jl:139)
+__global__ __launch_bounds__(256) void k_axmy(double* __restrict__ u, const double* __restrict__ corr, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) u[i] = u[i] - corr[i];
+}
+
+template <int MODE>  // 0: sum((x*scale)^2)   1: sum(x*y)   2: max(|x|)
+__global__ __launch_bounds__(256) void k_reduce(const double* __restrict__ x, const double* __restrict__ y, size_t n,
+                                                 double scale, double* __restrict__ partials)
+{
+    __shared__ double red[16];
+    const size_t stride = (size_t)gridDim.x * 256;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        if constexpr (MODE == 0) { const double t = x[i] * scale; acc += t * t; }
+        else if constexpr (MODE == 1) acc += x[i] * y[i];
+        else acc = fmax(acc, fabs(x[i]));
+    }
+    if constexpr (MODE == 2) acc = fpr_block_max<256>(acc, red);
+    else acc = fpr_block_sum<256>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+template <int MODE>  // 0 store sum, 1 accumulate sum, 2 store max
+__global__ __launch_bounds__(256) void k_finish(const double* __restrict__ partials, int n, double* __restrict__ out)
+{
+    __shared__ double red[16];
+    if constexpr (MODE == 2) {
+        double m = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, partials[i]);
+        m = fpr_block_max<256>(m, red);
+        if (threadIdx.x == 0) out[0] = m;
+    } else {
+        const double s = fpr_sum_partials_256(partials, n, red);
+        if (threadIdx.x == 0) out[0] = (MODE == 1) ? out[0] + s : s;
+    }
+}
+
+int fprx_finish_sum(fpr_ctx* ctx, const double* partials, int nparts, double* out_dev, bool accumulate, int stream_sel)
+{
+    if (accumulate) k_finish<1><<<1, 256, 0, ctx->stream[stream_sel]>>>(partials, nparts, out_dev);
+    else k_finish<0><<<1, 256, 0, ctx->stream[stream_sel]>>>(partials, nparts, out_dev);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+int fprx_sumsq_scaled_dev(fpr_ctx* ctx, const double* x, size_t n, double scale, double* out_dev, int stream_sel)
+{
+    const int g = flat_grid(n);
+    double* part = stream_sel ? ctx->partials2 : ctx->partials;
+    k_reduce<0><<<g, 256, 0, ctx->stream[stream_sel]>>>(x, nullptr, n, scale, part);
+    FPR_CHECK_LAUNCH(ctx);
+    return fprx_finish_sum(ctx, part, g, out_dev, false, stream_sel);
+}
+
+int fprx_dot_dev(fpr_ctx* ctx, const double* x, const double* y, size_t n, double* out_dev)
+{
+    const int g = flat_grid(n);
+    k_reduce<1><<<g, 256, 0, ctx->stream[0]>>>(x, y, n, 1.0, ctx->partials);
+    FPR_CHECK_LAUNCH(ctx);
+    return fprx_finish_sum(ctx, ctx->partials, g, out_dev, false, 0);
+}
+
+static int read_scalar(fpr_ctx* ctx, const double* dev, double* out_host)
+{
+    FPR_HIP(ctx, hipMemcpyAsync(ctx->host_scalars, dev, sizeof(double), hipMemcpyDeviceToHost, ctx->stream[0]));
+    FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
+    *out_host = ctx->host_scalars[0];
+    return FPR_OK;
+}
+
+extern "C" int fpr_sumsq_scaled_dev(fpr_ctx* ctx, const double* x, size_t n, double scale, double* out_dev)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, x && out_dev, "null pointer");
+    return fprx_sumsq_scaled_dev(ctx, x, n, scale, out_dev, 0);
+}
+
+extern "C" int fpr_sumsq_scaled(fpr_ctx* ctx, const double* x, size_t n, double scale, double* out_host)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, x && out_host, "null pointer");
+    int rc = fprx_sumsq_scaled_dev(ctx, x, n, scale, ctx->scalars, 0);
+    if (rc) return rc;
+    return read_scalar(ctx, ctx->scalars, out_host);
+}
+
+extern "C" int fpr_dot(fpr_ctx* ctx, const double* x, const double* y, size_t n, double* out_host)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, x && y && out_host, "null pointer");
+    int rc = fprx_dot_dev(ctx, x, y, n, ctx->scalars);
+    if (rc) return rc;
+    return read_scalar(ctx, ctx->scalars, out_host);
+}
+
+extern "C" int fpr_absmax(fpr_ctx* ctx, const double* x, size_t n, double* out_host)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, x && out_host, "null pointer");
+    const int g = flat_grid(n);
+    k_reduce<2><<<g, 256, 0, ctx->stream[0]>>>(x, nullptr, n, 1.0, ctx->partials);
+    FPR_CHECK_LAUNCH(ctx);
+    k_finish<2><<<1, 256, 0, ctx->stream[0]>>>(ctx->partials, g, ctx->scalars);
+    FPR_CHECK_LAUNCH(ctx);
+    return read_scalar(ctx, ctx->scalars, out_host);
+}
+
+extern "C" int fpr_copy(fpr_ctx* ctx, double* dst, const double* src, size_t n)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, dst && src, "null pointer");
+    if (n == 0) return FPR_OK;
+    k_copy<<<flat_grid((n + 1) / 2), 256, 0, ctx->stream[0]>>>(dst, src, n);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+extern "C" int fpr_fill(fpr_ctx* ctx, double* dst, double value, size_t n)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, dst, "null pointer");
+    if (n == 0) return FPR_OK;
+    k_fill<<<flat_grid(n), 256, 0, ctx->stream[0]>>>(dst, value, n);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+extern "C" int fpr_axmy2d(fpr_ctx* ctx, double* u, const double* corr, size_t n)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, u && corr, "null pointer");
+    if (n == 0) return FPR_OK;
+    k_axmy<<<flat_grid(n), 256, 0, ctx->stream[0]>>>(u, corr, n);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}

@@ -1,0 +1,198 @@
+// diffusion3d.hip -- Part 1 entry points of libfpr_hip.so: fused 7-point pseudo-transient update,
+// the split compute_flux!/compute_dHdtau!/update_H! form, Gaussian initial condition.
+// Reference: scripts-part1/part1_kernel_programming.jl, part1_array_programming.jl, part1_utils.jl.
+#include "diffusion3d_kernels.hpp"
+#include "fpr_internal.hpp"
+
+// defined in diffusion3d_launch.hpp (shared with tools/diffusion_tune.hip)
+#include "diffusion3d_launch.hpp"
+
+static int diff3_run(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2, double* dHdtau, int nx, int ny,
+                     int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy,
+                     double D_dz, const int* lo, const int* hi, bool norm, double scale, double* sumsq_dev,
+                     bool accumulate, int stream_sel)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, Ht && Htau && Htau2 && dHdtau, "null field pointer");
+    FPR_REQUIRE(ctx, nx >= 3 && ny >= 3 && nz >= 3, "grid must be at least 3^3");
+    FPR_REQUIRE(ctx, Htau != Htau2, "Htau and Htau2 must be distinct buffers (Jacobi ping-pong)");
+    FPR_REQUIRE(ctx, stream_sel == 0 || stream_sel == 1, "stream_sel");
+    Diff3Args a;
+    a.Ht = Ht; a.Htau = Htau; a.Htau2 = Htau2; a.dHdtau = dHdtau;
+    a.nx = nx; a.ny = ny; a.nz = nz;
+    const int n[3] = {nx, ny, nz};
+    for (int d = 0; d < 3; ++d) {
+        a.lo[d] = lo ? (lo[d] < 1 ? 1 : lo[d]) : 1;
+        a.hi[d] = hi ? (hi[d] > n[d] - 1 ? n[d] - 1 : hi[d]) : n[d] - 1;
+    }
+    a.dtau = dtau; a._dt = _dt; a._dx = _dx; a._dy = _dy; a._dz = _dz;
+    a.D_dx = D_dx; a.D_dy = D_dy; a.D_dz = D_dz;
+    a.scale = scale;
+    a.partials = stream_sel ? ctx->partials2 : ctx->partials;
+    const bool empty = a.lo[0] >= a.hi[0] || a.lo[1] >= a.hi[1] || a.lo[2] >= a.hi[2];
+    int nparts = 0;
+    if (!empty) {
+        Diff3Tuning t;
+        t.variant = (int)fpr_opt(ctx, "diff3_variant", 0);
+        t.zc = (int)fpr_opt(ctx, "diff3_zc", 0);
+        t.xcd_remap = (int)fpr_opt(ctx, "diff3_xcd_remap", -1);
+        t.ry = (int)fpr_opt(ctx, "diff3_ry", 0);
+        t.nt = (int)fpr_opt(ctx, "diff3_nt", -1);
+        t.vx = (int)fpr_opt(ctx, "diff3_vx", 0);
+        const bool timed = ctx->ktimer_on && ctx->ktimer_used + 2 <= ctx->ktimer_ev.size();
+        if (timed) FPR_HIP(ctx, hipEventRecord(ctx->ktimer_ev[ctx->ktimer_used], ctx->stream[stream_sel]));
+        hipError_t e = diff3_launch(a, norm, t, ctx->stream[stream_sel], FPR_MAX_PARTIALS, &nparts);
+        if (timed) {
+            FPR_HIP(ctx, hipEventRecord(ctx->ktimer_ev[ctx->ktimer_used + 1], ctx->stream[stream_sel]));
+            ctx->ktimer_used += 2;
+        }
+        if (e != hipSuccess) return fpr_fail(ctx, FPR_ERR_HIP, "diffusion3d launch: %s", hipGetErrorString(e));
+    }
+    if (norm) {
+        if (empty) {
+            if (!accumulate) FPR_HIP(ctx, hipMemsetAsync(sumsq_dev, 0, sizeof(double), ctx->stream[stream_sel]));
+            return FPR_OK;
+        }
+        return fprx_finish_sum(ctx, a.partials, nparts, sumsq_dev, accumulate, stream_sel);
+    }
+    return FPR_OK;
+}
+
+extern "C" int fpr_diffusion3d_step(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2, double* dHdtau,
+                                    int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz,
+                                    double D_dx, double D_dy, double D_dz)
+{
+    return diff3_run(ctx, Ht, Htau, Htau2, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, nullptr,
+                     nullptr, false, 0.0, nullptr, false, 0);
+}
+
+extern "C" int fpr_diffusion3d_step_norm(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2,
+                                         double* dHdtau, int nx, int ny, int nz, double dtau, double _dt, double _dx,
+                                         double _dy, double _dz, double D_dx, double D_dy, double D_dz, double scale,
+                                         double* sumsq_dev)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, sumsq_dev, "sumsq_dev is null");
+    return diff3_run(ctx, Ht, Htau, Htau2, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, nullptr,
+                     nullptr, true, scale, sumsq_dev, false, 0);
+}
+
+extern "C" int fpr_diffusion3d_step_box(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2,
+                                        double* dHdtau, int nx, int ny, int nz, double dtau, double _dt, double _dx,
+                                        double _dy, double _dz, double D_dx, double D_dy, double D_dz, const int lo[3],
+                                        const int hi[3], double scale, double* sumsq_dev, int stream_sel)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, lo && hi, "null box");
+    return diff3_run(ctx, Ht, Htau, Htau2, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo, hi,
+                     sumsq_dev != nullptr, scale, sumsq_dev, true, stream_sel);
+}
+
+// ------------------------------------------------------------------------------------------------
+// split form: compute_flux! / compute_dHdtau! / update_H!   (part1_array_programming.jl:9-18)
+// plain one-thread-per-element kernels; these are API-parity entry points, not the fast path.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flux(double* __restrict__ q, const double* __restrict__ H, int nx, int ny,
+                                               int qnx, int qny, int qnz, int dim, double D, double dd)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    if (i >= qnx || j >= qny || k >= qnz) return;
+    // @d_xi: difference along `dim`, inner (offset +1) in the other two dimensions
+    const int hi = i + (dim == 0 ? 0 : 1), hj = j + (dim == 1 ? 0 : 1), hk = k + (dim == 2 ? 0 : 1);
+    const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+    const size_t id = (size_t)hi + sy * hj + sz * hk;
+    const size_t st = dim == 0 ? 1 : (dim == 1 ? sy : sz);
+    q[(size_t)i + (size_t)qnx * ((size_t)j + (size_t)qny * k)] = D * (H[id + st] - H[id]) / dd;
+}
+
+__global__ __launch_bounds__(256) void k_dHdtau(double* __restrict__ dH, const double* __restrict__ Htau,
+                                                 const double* __restrict__ Ht, const double* __restrict__ qx,
+                                                 const double* __restrict__ qy, const double* __restrict__ qz, int nx,
+                                                 int ny, int nz, double dt, double dx, double dy, double dz)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    if (i >= nx - 2 || j >= ny - 2 || k >= nz - 2) return;
+    const size_t qxi = (size_t)i + (size_t)(nx - 1) * ((size_t)j + (size_t)(ny - 2) * k);
+    const size_t qyi = (size_t)i + (size_t)(nx - 2) * ((size_t)j + (size_t)(ny - 1) * k);
+    const size_t qzi = (size_t)i + (size_t)(nx - 2) * ((size_t)j + (size_t)(ny - 2) * k);
+    const size_t hid = (size_t)(i + 1) + (size_t)nx * ((size_t)(j + 1) + (size_t)ny * (k + 1));
+    const double dqx = (qx[qxi + 1] - qx[qxi]) / dx;
+    const double dqy = (qy[qyi + (size_t)(nx - 2)] - qy[qyi]) / dy;
+    const double dqz = (qz[qzi + (size_t)(nx - 2) * (size_t)(ny - 2)] - qz[qzi]) / dz;
+    const double tt = -(Htau[hid] - Ht[hid]) / dt;
+    dH[qzi] = tt + ((dqx + dqy) + dqz);
+}
+
+__global__ __launch_bounds__(256) void k_updateH(double* __restrict__ Htau, const double* __restrict__ dH, int nx, int ny,
+                                                  int nz, double dtau)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    if (i >= nx - 2 || j >= ny - 2 || k >= nz - 2) return;
+    const size_t di = (size_t)i + (size_t)(nx - 2) * ((size_t)j + (size_t)(ny - 2) * k);
+    const size_t hid = (size_t)(i + 1) + (size_t)nx * ((size_t)(j + 1) + (size_t)ny * (k + 1));
+    Htau[hid] = Htau[hid] + dH[di] * dtau;
+}
+
+static inline dim3 grid3(int a, int b, int c) { return dim3((a + 63) / 64, (b + 3) / 4, c); }
+
+extern "C" int fpr_diffusion3d_flux(fpr_ctx* ctx, double* qx, double* qy, double* qz, const double* Htau, int nx, int ny,
+                                    int nz, double D, double dx, double dy, double dz)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, qx && qy && qz && Htau, "null pointer");
+    FPR_REQUIRE(ctx, nx >= 3 && ny >= 3 && nz >= 3, "grid must be at least 3^3");
+    const dim3 b(64, 4, 1);
+    k_flux<<<grid3(nx - 1, ny - 2, nz - 2), b, 0, ctx->stream[0]>>>(qx, Htau, nx, ny, nx - 1, ny - 2, nz - 2, 0, D, dx);
+    k_flux<<<grid3(nx - 2, ny - 1, nz - 2), b, 0, ctx->stream[0]>>>(qy, Htau, nx, ny, nx - 2, ny - 1, nz - 2, 1, D, dy);
+    k_flux<<<grid3(nx - 2, ny - 2, nz - 1), b, 0, ctx->stream[0]>>>(qz, Htau, nx, ny, nx - 2, ny - 2, nz - 1, 2, D, dz);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+extern "C" int fpr_diffusion3d_dHdtau(fpr_ctx* ctx, double* dHdtau, const double* Htau, const double* Ht,
+                                      const double* qx, const double* qy, const double* qz, int nx, int ny, int nz,
+                                      double dt, double dx, double dy, double dz)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, dHdtau && Htau && Ht && qx && qy && qz, "null pointer");
+    FPR_REQUIRE(ctx, nx >= 3 && ny >= 3 && nz >= 3, "grid must be at least 3^3");
+    k_dHdtau<<<grid3(nx - 2, ny - 2, nz - 2), dim3(64, 4, 1), 0, ctx->stream[0]>>>(dHdtau, Htau, Ht, qx, qy, qz, nx, ny,
+                                                                                   nz, dt, dx, dy, dz);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+extern "C" int fpr_diffusion3d_update(fpr_ctx* ctx, double* Htau, const double* dHdtau, int nx, int ny, int nz,
+                                      double dtau)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, Htau && dHdtau, "null pointer");
+    FPR_REQUIRE(ctx, nx >= 3 && ny >= 3 && nz >= 3, "grid must be at least 3^3");
+    k_updateH<<<grid3(nx - 2, ny - 2, nz - 2), dim3(64, 4, 1), 0, ctx->stream[0]>>>(Htau, dHdtau, nx, ny, nz, dtau);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+// init_local_gaussian -- part1_utils.jl:1-12
+__global__ __launch_bounds__(256) void k_gauss(double* __restrict__ H, int nx, int ny, int nz, double dx, double dy,
+                                                double dz, double cx, double cy, double cz, long ox, long oy, long oz)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    if (i >= nx || j >= ny || k >= nz) return;
+    const double x = (double)(ox + i) * dx, y = (double)(oy + j) * dy, z = (double)(oz + k) * dz;
+    const double ax = x + dx / 2 - cx, ay = y + dy / 2 - cy, az = z + dz / 2 - cz;
+    H[(size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * k)] = 2 * exp(-1.0 * ((ax * ax + ay * ay) + az * az));
+}
+
+extern "C" int fpr_init_gaussian3d(fpr_ctx* ctx, double* H, int nx, int ny, int nz, double dx, double dy, double dz,
+                                   double cx, double cy, double cz, int coordx, int coordy, int coordz)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, H, "null pointer");
+    FPR_REQUIRE(ctx, nx >= 1 && ny >= 1 && nz >= 1, "empty grid");
+    k_gauss<<<grid3(nx, ny, nz), dim3(64, 4, 1), 0, ctx->stream[0]>>>(H, nx, ny, nz, dx, dy, dz, cx, cy, cz,
+                                                                     (long)coordx * (nx - 2), (long)coordy * (ny - 2),
+                                                                     (long)coordz * (nz - 2));
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}

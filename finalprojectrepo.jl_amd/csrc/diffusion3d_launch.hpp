@@ -1,0 +1,112 @@
+// diffusion3d_launch.hpp -- host-side variant dispatch for the fused diffusion kernels.
+// Shared by diffusion3d.hip (library) and tools/diffusion_tune.hip (tuning harness).
+#pragma once
+#include <cstdint>
+
+#include "diffusion3d_kernels.hpp"
+
+struct Diff3Tuning {
+    int variant = 0;     // 0 = library default; 1 = naive; 2 = z-march (registers + shuffles);
+                         // 3 = z-march with LDS exchange of the inter-wave halo rows
+    int zc = 0;          // planes per z-chunk (0 = auto)
+    int xcd_remap = -1;  // -1 auto, 0 off, 1 on
+    int ry = 0;          // rows per lane (0 = auto; 1, 2 or 4)
+    int nt = -1;         // non-temporal stores: -1 auto, 0 off, 1 on
+    int vx = 0;          // cells per lane in x (0 = auto; 1 or 2)
+};
+
+#ifndef DIFF3_DEFAULT_VARIANT_ID
+#define DIFF3_DEFAULT_VARIANT_ID 2
+#endif
+#ifndef DIFF3_DEFAULT_RY
+#define DIFF3_DEFAULT_RY 4
+#endif
+#ifndef DIFF3_DEFAULT_NT
+#define DIFF3_DEFAULT_NT 0
+#endif
+#ifndef DIFF3_DEFAULT_XCD
+#define DIFF3_DEFAULT_XCD 1
+#endif
+#ifndef DIFF3_TARGET_BLOCKS
+#define DIFF3_TARGET_BLOCKS 1024
+#endif
+
+template <int VX, int RY, bool LDSY, bool NT>
+static inline void diff3_march_go(const Diff3Args& a, bool norm, int nblk, hipStream_t stream)
+{
+    if (norm) k_diff3_march<VX, RY, true, LDSY, NT><<<nblk, 256, 0, stream>>>(a);
+    else k_diff3_march<VX, RY, false, LDSY, NT><<<nblk, 256, 0, stream>>>(a);
+}
+
+template <int VX, int RY>
+static inline void diff3_march_go2(const Diff3Args& a, bool norm, bool ldsy, bool nt, int nblk, hipStream_t stream)
+{
+    if (ldsy) {
+        if (nt) diff3_march_go<VX, RY, true, true>(a, norm, nblk, stream);
+        else diff3_march_go<VX, RY, true, false>(a, norm, nblk, stream);
+    } else {
+        if (nt) diff3_march_go<VX, RY, false, true>(a, norm, nblk, stream);
+        else diff3_march_go<VX, RY, false, false>(a, norm, nblk, stream);
+    }
+}
+
+// Launches the selected variant on `stream`.  *nparts = number of block partials written (norm only).
+static inline hipError_t diff3_launch(Diff3Args a, bool norm, const Diff3Tuning& t, hipStream_t stream,
+                                      int max_partials, int* nparts)
+{
+    const int wx = a.hi[0] - a.lo[0], wy = a.hi[1] - a.lo[1], wz = a.hi[2] - a.lo[2];
+    int variant = t.variant ? t.variant : DIFF3_DEFAULT_VARIANT_ID;
+    *nparts = 0;
+    if (wx <= 0 || wy <= 0 || wz <= 0) return hipSuccess;
+    if (variant == 1) {
+        const dim3 grid((wx + 63) / 64, (wy + 3) / 4, wz);
+        const size_t nb = (size_t)grid.x * grid.y * grid.z;
+        if (norm && nb > (size_t)max_partials) return hipErrorInvalidValue;
+        if (norm) k_diff3_naive<true><<<grid, dim3(64, 4, 1), 0, stream>>>(a);
+        else k_diff3_naive<false><<<grid, dim3(64, 4, 1), 0, stream>>>(a);
+        *nparts = (int)nb;
+        return hipGetLastError();
+    }
+    if (variant != 2 && variant != 3) return hipErrorInvalidValue;
+    const bool ldsy = (variant == 3);
+    // 16-byte path needs even nx and 16-byte aligned arrays
+    const bool can16 = (a.nx % 2 == 0) &&
+                       ((((uintptr_t)a.Ht | (uintptr_t)a.Htau | (uintptr_t)a.Htau2 | (uintptr_t)a.dHdtau) & 15) == 0);
+    int vx = t.vx ? t.vx : 2;
+    if (!can16 || wx < 32) vx = 1;
+    int ry = t.ry ? t.ry : DIFF3_DEFAULT_RY;
+    if (ry != 1 && ry != 2 && ry != 4) return hipErrorInvalidValue;
+    while (ry > 1 && wy < ry * 2) ry >>= 1;
+    const int txw = 64 * vx;
+    const int xorg = a.lo[0] & ~(vx - 1);
+    a.ntx = (a.hi[0] - xorg + txw - 1) / txw;
+    a.nty = (wy + ry - 1) / ry;
+    const long tiles_xy = ldsy ? (long)a.ntx * ((a.nty + 3) / 4) : ((long)a.ntx * a.nty + 3) / 4;  // blocks per chunk
+    int zc = t.zc;
+    if (zc <= 0) {
+        long want = (DIFF3_TARGET_BLOCKS + tiles_xy - 1) / tiles_xy;  // chunks wanted
+        if (want < 1) want = 1;
+        zc = (int)((wz + want - 1) / want);
+        if (zc < 8) zc = wz < 8 ? wz : 8;
+    }
+    if (zc > wz) zc = wz;
+    a.zc = zc;
+    a.ntz = (wz + zc - 1) / zc;
+    long nblk;
+    if (ldsy) nblk = (long)a.ntx * ((a.nty + 3) / 4) * a.ntz;
+    else nblk = ((long)a.ntx * a.nty * a.ntz + 3) / 4;
+    if (nblk > 0x7fffffffL || (norm && nblk > max_partials)) return hipErrorInvalidValue;
+    a.xcd_remap = t.xcd_remap < 0 ? (DIFF3_DEFAULT_XCD && nblk >= 64) : t.xcd_remap;
+    const bool nt = t.nt < 0 ? DIFF3_DEFAULT_NT : (t.nt != 0);
+    if (vx == 2) {
+        if (ry == 4) diff3_march_go2<2, 4>(a, norm, ldsy, nt, (int)nblk, stream);
+        else if (ry == 2) diff3_march_go2<2, 2>(a, norm, ldsy, nt, (int)nblk, stream);
+        else diff3_march_go2<2, 1>(a, norm, ldsy, nt, (int)nblk, stream);
+    } else {
+        if (ry == 4) diff3_march_go2<1, 4>(a, norm, ldsy, nt, (int)nblk, stream);
+        else if (ry == 2) diff3_march_go2<1, 2>(a, norm, ldsy, nt, (int)nblk, stream);
+        else diff3_march_go2<1, 1>(a, norm, ldsy, nt, (int)nblk, stream);
+    }
+    *nparts = (int)nblk;
+    return hipGetLastError();
+}

@@ -1,0 +1,162 @@
+// fpr_internal.hpp -- context, error plumbing and device-side reduction helpers shared by the
+// gfx950 translation units of libfpr_hip.so.  Not part of the public ABI (include/fpr.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/fpr.h"
+
+constexpr int FPR_WAVE = 64;            // gfx950 wavefront
+constexpr int FPR_MAX_PARTIALS = 1 << 19;  // per-slot block partials (doubles)
+
+// device-side solver state shared by the coarse Jacobi / CG kernels (one per context)
+struct FprSolveState {
+    int done;        // 1 once the stopping criterion was met
+    int iters;       // iterations executed (including the one that met the criterion)
+    int nparts;      // number of valid block partials of the last reduction
+    int pad;
+    double last_rms; // r_rms of the last executed iteration
+    double thresh;   // tol * rms(rhs)   (Jacobi)  or  tol * ||b||  (CG)
+    double rho, rho_old, alpha, beta, pq;  // CG scalars
+};
+
+struct FprLevel {  // one multigrid level's scratch (role of prealloc_dict, multigrid.jl:25-38)
+    int nx = 0, ny = 0;
+    double* tmp = nullptr;    // ping-pong partner of u on this level
+    double* res_c = nullptr;  // restricted residual = rhs of the next coarser level
+    double* corr_c = nullptr; // coarse correction = u of the next coarser level
+};
+
+struct fpr_ctx {
+    int device = 0;
+    hipStream_t stream[2] = {nullptr, nullptr};  // 0 compute, 1 comm
+    bool own_stream[2] = {false, false};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    double* partials = nullptr;     // FPR_MAX_PARTIALS doubles: block partial sums (slot 0)
+    double* partials2 = nullptr;    // second slot (comm stream / second reduction of a kernel)
+    double* scalars = nullptr;      // 64 device doubles for results of reductions
+    FprSolveState* state = nullptr; // device
+    FprSolveState* state_h = nullptr;  // pinned host mirror
+    double* host_scalars = nullptr;    // pinned, 64 doubles
+    std::map<std::pair<int, int>, std::vector<FprLevel>> arenas;  // keyed by finest (nx, ny)
+    double* cg_buf = nullptr;          // CG work vectors (krylov.jl:59-62)
+    size_t cg_cap = 0;                 // capacity of cg_buf in doubles
+    std::map<std::string, long> options;
+    long last_coarse_iters = 0;
+    bool ktimer_on = false;            // fpr_kernel_timer
+    std::vector<hipEvent_t> ktimer_ev; // pairs (start, stop)
+    size_t ktimer_used = 0;
+    char err[512] = {0};
+};
+
+inline int fpr_fail(fpr_ctx* ctx, int code, const char* fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define FPR_HIP(ctx, call)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fpr_fail((ctx), FPR_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call,        \
+                            hipGetErrorString(e_));                                                 \
+    } while (0)
+
+#define FPR_CHECK_LAUNCH(ctx) FPR_HIP(ctx, hipGetLastError())
+
+#define FPR_REQUIRE(ctx, cond, msg)                                                                 \
+    do {                                                                                            \
+        if (!(cond)) return fpr_fail((ctx), FPR_ERR_INVALID, "invalid argument: %s", msg);          \
+    } while (0)
+
+inline long fpr_opt(fpr_ctx* ctx, const char* key, long dflt)
+{
+    auto it = ctx->options.find(key);
+    return it == ctx->options.end() ? dflt : it->second;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+__device__ __forceinline__ double fpr_wave_sum(double v)
+{
+#pragma unroll
+    for (int off = FPR_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, FPR_WAVE);
+    return v;  // valid in lane 0
+}
+
+__device__ __forceinline__ double fpr_wave_max(double v)
+{
+#pragma unroll
+    for (int off = FPR_WAVE / 2; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, FPR_WAVE));
+    return v;
+}
+
+// Block-wide sum in a fixed order (deterministic).  NT = threads per block (multiple of 64, <= 1024).
+// Result valid in thread 0.  `red` = __shared__ double[16].
+template <int NT>
+__device__ __forceinline__ double fpr_block_sum(double v, double* red)
+{
+    const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    v = fpr_wave_sum(v);
+    if constexpr (NT > FPR_WAVE) {
+        if ((tid & (FPR_WAVE - 1)) == 0) red[tid / FPR_WAVE] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double s = red[0];
+#pragma unroll
+            for (int w = 1; w < NT / FPR_WAVE; ++w) s += red[w];
+            v = s;
+        }
+    }
+    return v;
+}
+
+template <int NT>
+__device__ __forceinline__ double fpr_block_max(double v, double* red)
+{
+    const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    v = fpr_wave_max(v);
+    if constexpr (NT > FPR_WAVE) {
+        if ((tid & (FPR_WAVE - 1)) == 0) red[tid / FPR_WAVE] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double s = red[0];
+#pragma unroll
+            for (int w = 1; w < NT / FPR_WAVE; ++w) s = fmax(s, red[w]);
+            v = s;
+        }
+    }
+    return v;
+}
+
+// Deterministic sum of n block partials by ONE block of 256 threads: strided accumulation per
+// thread, then the fixed block tree.  Result valid in thread 0.
+__device__ __forceinline__ double fpr_sum_partials_256(const double* __restrict__ part, int n, double* red)
+{
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    return fpr_block_sum<256>(s, red);
+}
+
+#endif  // __HIPCC__
+
+// cross-TU internal entry points (implemented in reduce.hip)
+int fprx_sumsq_scaled_dev(fpr_ctx* ctx, const double* x, size_t n, double scale, double* out_dev, int stream_sel);
+int fprx_dot_dev(fpr_ctx* ctx, const double* x, const double* y, size_t n, double* out_dev);
+// finish a two-stage reduction: out_dev[0] (= or +=) sum(partials[0..nparts))
+int fprx_finish_sum(fpr_ctx* ctx, const double* partials, int nparts, double* out_dev, bool accumulate, int stream_sel);

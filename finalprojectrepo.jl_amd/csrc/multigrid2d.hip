@@ -1,0 +1,699 @@
+// multigrid2d.hip -- Part 2 of libfpr_hip.so: 2D geometric-multigrid V-cycle for (lap - c) u = f.
+// Reference: scripts-part2/multigrid.jl, krylov.jl, part2_utils.jl (file:line cited per function).
+//
+// Data layout: Float64, column-major nx*ny (ix fastest).  All kernels use 64x4 thread blocks: a wave
+// covers 64 consecutive x of one row (512 B coalesced per instruction; (2^k+1)-wide rows are only
+// 8-byte aligned, so 16-byte accesses are not generally possible).
+//
+// Inside fpr_vcycle2d the reference's passes are fused without changing a single rounding:
+//   * Jacobi sweep      : residual + update in one pass, ping-pong u <-> tmp   (multigrid.jl:245-258)
+//   * residual+restrict : the residual is evaluated only at the injected points  (:128-129, :330-358)
+//   * prolong+correct   : deterministic gather in the reference's accumulation order, subtracted
+//                         from u in the same pass                              (:136-139, :403-472)
+// The materialising entry points (fpr_residual2d, fpr_jacobi2d, fpr_restrict2d, fpr_prolongate2d)
+// keep the reference's buffers observable for API parity.
+#include "fpr_internal.hpp"
+
+#define BX 64
+#define BY 4
+static inline dim3 grid2(int nx, int ny) { return dim3((nx + BX - 1) / BX, (ny + BY - 1) / BY, 1); }
+static const dim3 blk2(BX, BY, 1);
+
+// residual at interior point (i,j): multigrid.jl:178-185
+__device__ __forceinline__ double res_at(const double* __restrict__ u, const double* __restrict__ f, size_t id, int nx,
+                                         double C, double _h2)
+{
+    return ((((u[id + 1] + u[id - 1]) + u[id + nx]) + u[id - nx]) - C * u[id]) * _h2 - f[id];
+}
+
+// ---- B1 -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_residual2d(const double* __restrict__ u, const double* __restrict__ f,
+                                                     double* __restrict__ res, int nx, int ny, double C, double _h2)
+{
+    const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+    if (i < 1 || j < 1 || i >= nx - 1 || j >= ny - 1) return;
+    const size_t id = (size_t)i + (size_t)nx * j;
+    res[id] = res_at(u, f, id, nx, C, _h2);
+}
+
+// u .+= fac .* res over the whole array (multigrid.jl:255)
+__global__ __launch_bounds__(256) void k_axpy_inplace(double* __restrict__ u, const double* __restrict__ res, double fac,
+                                                       size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) u[i] = u[i] + fac * res[i];
+}
+
+// ---- fused Jacobi sweep: uout = uin + fac*residual(uin) (interior), boundary copied --------------
+// STATE: coarse-solver form, skipped entirely once state->done is set.
+template <bool NORM, bool STATE>
+__global__ __launch_bounds__(256) void k_sweep2d(const double* __restrict__ uin, const double* __restrict__ f,
+                                                  double* __restrict__ uout, int nx, int ny, double C, double _h2,
+                                                  double fac, double* __restrict__ partials,
+                                                  const FprSolveState* __restrict__ state)
+{
+    __shared__ double red[16];
+    if constexpr (STATE) {
+        if (state->done) return;
+    }
+    const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+    double acc = 0.0;
+    if (i < nx && j < ny) {
+        const size_t id = (size_t)i + (size_t)nx * j;
+        const double uc = uin[id];
+        if (i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1) {
+            const double r = ((((uin[id + 1] + uin[id - 1]) + uin[id + nx]) + uin[id - nx]) - C * uc) * _h2 - f[id];
+            uout[id] = uc + fac * r;
+            if constexpr (NORM) acc = r * r;
+        } else {
+            uout[id] = uc;
+        }
+    }
+    if constexpr (NORM) {
+        const double s = fpr_block_sum<256>(acc, red);
+        if (threadIdx.x == 0 && threadIdx.y == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = s;
+    }
+}
+
+// ---- residual + injection (+ Neumann rows) into the coarse rhs ------------------------------------
+// one thread per COARSE point; (nx, ny) = fine dims.  multigrid.jl:128-129, 330-358
+__global__ __launch_bounds__(256) void k_restrict_residual2d(const double* __restrict__ u, const double* __restrict__ f,
+                                                              double* __restrict__ res_c, int nx, int ny, double C,
+                                                              double _h2, int apply_BCs)
+{
+    const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
+    const int ic = blockIdx.x * BX + threadIdx.x, jc = blockIdx.y * BY + threadIdx.y;
+    if (ic >= nxc || jc >= nyc) return;
+    double v = 0.0;
+    // interior coarse points take the fine residual at (2ic, 2jc); Neumann copies row 1 / nxc-2
+    int is = ic;
+    if (apply_BCs) is = (ic == 0) ? 1 : (ic == nxc - 1 ? nxc - 2 : ic);
+    if (is >= 1 && is <= nxc - 2 && jc >= 1 && jc <= nyc - 2) {
+        const size_t id = (size_t)(2 * is) + (size_t)nx * (size_t)(2 * jc);
+        v = res_at(u, f, id, nx, C, _h2);
+    }
+    res_c[(size_t)ic + (size_t)nxc * jc] = v;
+}
+
+// ---- bilinear prolongation as a gather -------------------------------------------------------------
+// value the reference's sequential scatter (iy outer, ix inner; multigrid.jl:427-444) leaves at fine (i,j)
+__device__ __forceinline__ double prolong_at(const double* __restrict__ cc, int i, int j, int nx, int ny, int nxc)
+{
+    // sources are interior coarse points only: fine even index in [2, n-3]
+    if (i < 1 || j < 1 || i > nx - 2 || j > ny - 2) return 0.0;
+    const int io = i & 1, jo = j & 1;
+    const int icl = i >> 1, jcl = j >> 1;  // lower coarse neighbour
+    const int nyc = 1 + (ny - 1) / 2;
+    auto src = [&](int ic, int jc) -> bool { return ic >= 1 && ic <= nxc - 2 && jc >= 1 && jc <= nyc - 2; };
+    auto cv = [&](int ic, int jc) -> double { return cc[(size_t)ic + (size_t)nxc * jc]; };
+    double v = 0.0;
+    if (!io && !jo) {
+        if (src(icl, jcl)) v = v + cv(icl, jcl);
+    } else if (io && !jo) {  // between two coarse points in x: lower-x source is visited first
+        if (src(icl, jcl)) v = v + 0.5 * cv(icl, jcl);
+        if (src(icl + 1, jcl)) v = v + 0.5 * cv(icl + 1, jcl);
+    } else if (!io && jo) {
+        if (src(icl, jcl)) v = v + 0.5 * cv(icl, jcl);
+        if (src(icl, jcl + 1)) v = v + 0.5 * cv(icl, jcl + 1);
+    } else {  // order: (ic,jc), (ic+1,jc), (ic,jc+1), (ic+1,jc+1)
+        if (src(icl, jcl)) v = v + 0.25 * cv(icl, jcl);
+        if (src(icl + 1, jcl)) v = v + 0.25 * cv(icl + 1, jcl);
+        if (src(icl, jcl + 1)) v = v + 0.25 * cv(icl, jcl + 1);
+        if (src(icl + 1, jcl + 1)) v = v + 0.25 * cv(icl + 1, jcl + 1);
+    }
+    return v;
+}
+
+// CORRECT = false: fine = P(coarse) (prolongate_wrapper!)   CORRECT = true: fine -= P(coarse) (:136-139)
+template <bool CORRECT>
+__global__ __launch_bounds__(256) void k_prolong2d(const double* __restrict__ cc, double* __restrict__ fine, int nx, int ny,
+                                                    int apply_BCs)
+{
+    const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+    if (i >= nx || j >= ny) return;
+    const int nxc = 1 + (nx - 1) / 2;
+    int is = i;
+    if (apply_BCs) is = (i == 0) ? 1 : (i == nx - 1 ? nx - 2 : i);  // Neumann rows (part2_utils.jl:35-39)
+    const double p = prolong_at(cc, is, j, nx, ny, nxc);
+    const size_t id = (size_t)i + (size_t)nx * j;
+    if constexpr (CORRECT) fine[id] = fine[id] - p;
+    else fine[id] = p;
+}
+
+// injection only (restrict_wrapper!, multigrid.jl:344-358)
+__global__ __launch_bounds__(256) void k_restrict2d(const double* __restrict__ fine, double* __restrict__ coarse, int nx,
+                                                     int ny, int apply_BCs)
+{
+    const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
+    const int ic = blockIdx.x * BX + threadIdx.x, jc = blockIdx.y * BY + threadIdx.y;
+    if (ic >= nxc || jc >= nyc) return;
+    int is = ic;
+    if (apply_BCs) is = (ic == 0) ? 1 : (ic == nxc - 1 ? nxc - 2 : ic);
+    double v = 0.0;
+    if (is >= 1 && is <= nxc - 2 && jc >= 1 && jc <= nyc - 2) v = fine[(size_t)(2 * is) + (size_t)nx * (size_t)(2 * jc)];
+    coarse[(size_t)ic + (size_t)nxc * jc] = v;
+}
+
+// ---- B5: (lap - c) T, krylov.jl:7-13 -------------------------------------------------------------
+__device__ __forceinline__ double lap_at(const double* __restrict__ T, size_t id, int nx, double hx2, double hy2, double c)
+{
+    const double t = T[id];
+    return (((T[id + 1] - 2 * t) + T[id - 1]) / hx2 + ((T[id + nx] - 2 * t) + T[id - nx]) / hy2) - c * t;
+}
+
+__global__ __launch_bounds__(256) void k_laplace2d(const double* __restrict__ T, double* __restrict__ out, int nx, int ny,
+                                                    double hx2, double hy2, double c)
+{
+    const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+    if (i < 1 || j < 1 || i >= nx - 1 || j >= ny - 1) return;
+    const size_t id = (size_t)i + (size_t)nx * j;
+    out[id] = lap_at(T, id, nx, hx2, hy2, c);
+}
+
+// ---- B6: boundary conditions, part2_utils.jl:22-39 ------------------------------------------------
+__global__ __launch_bounds__(256) void k_bc_dirichlet(double* __restrict__ T, int nx, int ny)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nx) return;
+    T[i] = 1.0;
+    T[(size_t)i + (size_t)nx * (ny - 1)] = 0.0;
+}
+__global__ __launch_bounds__(256) void k_bc_neumann(double* __restrict__ T, int nx, int ny)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ny) return;
+    T[(size_t)nx * j] = T[(size_t)nx * j + 1];
+    T[(size_t)nx * j + nx - 1] = T[(size_t)nx * j + nx - 2];
+}
+
+// ---- coarse-solver state kernels -------------------------------------------------------------------
+// thresh = tol * sqrt(sumsq/N)   (multigrid.jl:150)  /  tol * sqrt(sumsq)   (krylov.jl:57-58)
+__global__ void k_state_init(FprSolveState* st, const double* sumsq, double tol, double N, int cg)
+{
+    st->done = 0;
+    st->iters = 0;
+    st->last_rms = 0.0;
+    st->thresh = cg ? tol * sqrt(sumsq[0]) : tol * sqrt(sumsq[0] / N);
+    st->rho = sumsq[0];  // CG: rho = sum(r.*r) with r = b (krylov.jl:64)
+    st->rho_old = 0.0;
+    st->alpha = 0.0;
+    st->beta = 0.0;
+    st->pq = 0.0;
+}
+
+// after a Jacobi sweep: r_rms = sqrt(sum/N); stop when r_rms < thresh (multigrid.jl:152-155)
+__global__ __launch_bounds__(256) void k_jacobi_check(FprSolveState* st, const double* __restrict__ partials, int nparts,
+                                                       double N)
+{
+    __shared__ double red[16];
+    if (st->done) return;
+    const double s = fpr_sum_partials_256(partials, nparts, red);
+    if (threadIdx.x == 0) {
+        const double rms = sqrt(s / N);
+        st->iters += 1;
+        st->last_rms = rms;
+        if (rms < st->thresh) st->done = 1;
+    }
+}
+
+// ---- CG kernels (krylov.jl:55-91) -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cg_init(const double* __restrict__ b, double* __restrict__ r, double* __restrict__ p,
+                                                  double* __restrict__ ph, double* __restrict__ x, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const double v = b[i];
+        r[i] = v; p[i] = v; ph[i] = v; x[i] = 0.0;
+    }
+}
+
+// p_hat = A p on the interior (boundary of p_hat keeps b's values), partial sums of p .* p_hat over
+// the WHOLE array (krylov.jl:68-69)
+__global__ __launch_bounds__(256) void k_cg_matvec_dot(const double* __restrict__ p, double* __restrict__ ph, int nx, int ny,
+                                                        double hx2, double hy2, double c, double* __restrict__ partials,
+                                                        const FprSolveState* __restrict__ st)
+{
+    __shared__ double red[16];
+    if (st->done) return;
+    const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+    double acc = 0.0;
+    if (i < nx && j < ny) {
+        const size_t id = (size_t)i + (size_t)nx * j;
+        double q;
+        if (i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1) {
+            q = lap_at(p, id, nx, hx2, hy2, c);
+            ph[id] = q;
+        } else {
+            q = ph[id];
+        }
+        acc = p[id] * q;
+    }
+    const double s = fpr_block_sum<256>(acc, red);
+    if (threadIdx.x == 0 && threadIdx.y == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = s;
+}
+
+__global__ __launch_bounds__(256) void k_cg_alpha(FprSolveState* st, const double* __restrict__ partials, int nparts)
+{
+    __shared__ double red[16];
+    if (st->done) return;
+    const double s = fpr_sum_partials_256(partials, nparts, red);
+    if (threadIdx.x == 0) {
+        st->pq = s;
+        st->alpha = st->rho / s;  // krylov.jl:69
+    }
+}
+
+// x .+= alpha p ; r .-= alpha p_hat ; partial sums of r.^2   (krylov.jl:70-72)
+__global__ __launch_bounds__(256) void k_cg_update(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
+                                                    const double* __restrict__ ph, size_t n, double* __restrict__ partials,
+                                                    const FprSolveState* __restrict__ st)
+{
+    __shared__ double red[16];
+    if (st->done) return;
+    const double alpha = st->alpha;
+    const size_t stride = (size_t)gridDim.x * 256;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        x[i] = x[i] + alpha * p[i];
+        const double rn = r[i] - alpha * ph[i];
+        r[i] = rn;
+        acc += rn * rn;
+    }
+    const double s = fpr_block_sum<256>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_cg_check(FprSolveState* st, const double* __restrict__ partials, int nparts, double N)
+{
+    __shared__ double red[16];
+    if (st->done) return;
+    const double s = fpr_sum_partials_256(partials, nparts, red);
+    if (threadIdx.x == 0) {
+        const double normr = sqrt(s);
+        st->iters += 1;
+        st->last_rms = sqrt(s / N);  // krylov.jl:90
+        if (normr < st->thresh) {
+            st->done = 1;  // krylov.jl:76-81
+        } else {
+            st->rho_old = st->rho;
+            st->rho = s;                      // krylov.jl:83
+            st->beta = st->rho / st->rho_old; // krylov.jl:84
+        }
+    }
+}
+
+// p .= r + beta p  (krylov.jl:85)
+__global__ __launch_bounds__(256) void k_cg_p(double* __restrict__ p, const double* __restrict__ r, size_t n,
+                                               const FprSolveState* __restrict__ st)
+{
+    if (st->done) return;
+    const double beta = st->beta;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = r[i] + beta * p[i];
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+static inline int flat_grid(size_t n)
+{
+    size_t b = (n + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+static int check_dims(fpr_ctx* ctx, int nx, int ny)
+{
+    FPR_REQUIRE(ctx, nx >= 3 && ny >= 3, "grid must be at least 3x3");
+    return FPR_OK;
+}
+
+static int read_state(fpr_ctx* ctx)
+{
+    FPR_HIP(ctx, hipMemcpyAsync(ctx->state_h, ctx->state, sizeof(FprSolveState), hipMemcpyDeviceToHost, ctx->stream[0]));
+    FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
+    return FPR_OK;
+}
+
+static int read_scalar(fpr_ctx* ctx, const double* dev, double* out_host)
+{
+    FPR_HIP(ctx, hipMemcpyAsync(ctx->host_scalars, dev, sizeof(double), hipMemcpyDeviceToHost, ctx->stream[0]));
+    FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
+    *out_host = ctx->host_scalars[0];
+    return FPR_OK;
+}
+
+extern "C" int fpr_residual2d(fpr_ctx* ctx, const double* u, const double* f, double h, double c, double* res, int nx, int ny)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, u && f && res, "null pointer");
+    if (int rc = check_dims(ctx, nx, ny)) return rc;
+    const double C = 4.0 + c * (h * h), _h2 = 1 / (h * h);
+    k_residual2d<<<grid2(nx, ny), blk2, 0, ctx->stream[0]>>>(u, f, res, nx, ny, C, _h2);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+extern "C" int fpr_jacobi2d(fpr_ctx* ctx, double* u, const double* f, double h, double c, double* res, int nx, int ny,
+                            double alpha, double* rms_host)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, u && f && res, "null pointer");
+    if (int rc = check_dims(ctx, nx, ny)) return rc;
+    const size_t N = (size_t)nx * ny;
+    const double C = 4.0 + c * (h * h), _h2 = 1 / (h * h);
+    const double fac = alpha * ((h * h) / (4.0 + c * (h * h)));
+    k_residual2d<<<grid2(nx, ny), blk2, 0, ctx->stream[0]>>>(u, f, res, nx, ny, C, _h2);
+    FPR_CHECK_LAUNCH(ctx);
+    if (rms_host) {
+        // whole array, including whatever the caller keeps on res' boundary (multigrid.jl:252)
+        if (int rc = fprx_sumsq_scaled_dev(ctx, res, N, 1.0, ctx->scalars + 1, 0)) return rc;
+    }
+    k_axpy_inplace<<<flat_grid(N), 256, 0, ctx->stream[0]>>>(u, res, fac, N);
+    FPR_CHECK_LAUNCH(ctx);
+    if (rms_host) {
+        double s;
+        if (int rc = read_scalar(ctx, ctx->scalars + 1, &s)) return rc;
+        *rms_host = sqrt(s / (double)N);
+    }
+    return FPR_OK;
+}
+
+extern "C" int fpr_restrict2d(fpr_ctx* ctx, const double* fine, double* coarse, int nx, int ny, int apply_BCs)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, fine && coarse, "null pointer");
+    if (int rc = check_dims(ctx, nx, ny)) return rc;
+    FPR_REQUIRE(ctx, (nx & 1) && (ny & 1), "fine dims must be odd");
+    k_restrict2d<<<grid2(1 + (nx - 1) / 2, 1 + (ny - 1) / 2), blk2, 0, ctx->stream[0]>>>(fine, coarse, nx, ny, apply_BCs);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+extern "C" int fpr_prolongate2d(fpr_ctx* ctx, const double* coarse, double* fine, int nx, int ny, int apply_BCs)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, fine && coarse, "null pointer");
+    if (int rc = check_dims(ctx, nx, ny)) return rc;
+    FPR_REQUIRE(ctx, (nx & 1) && (ny & 1), "fine dims must be odd");
+    k_prolong2d<false><<<grid2(nx, ny), blk2, 0, ctx->stream[0]>>>(coarse, fine, nx, ny, apply_BCs);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+extern "C" int fpr_laplace_apply2d(fpr_ctx* ctx, const double* T, double hx, double hy, double c, double* dT2, int nx, int ny)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, T && dT2, "null pointer");
+    if (int rc = check_dims(ctx, nx, ny)) return rc;
+    k_laplace2d<<<grid2(nx, ny), blk2, 0, ctx->stream[0]>>>(T, dT2, nx, ny, hx * hx, hy * hy, c);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+extern "C" int fpr_bc_dirichlet2d(fpr_ctx* ctx, double* T, int nx, int ny)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, T && nx >= 1 && ny >= 1, "bad array");
+    k_bc_dirichlet<<<(nx + 255) / 256, 256, 0, ctx->stream[0]>>>(T, nx, ny);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+extern "C" int fpr_bc_neumann2d(fpr_ctx* ctx, double* T, int nx, int ny)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, T && nx >= 2 && ny >= 1, "bad array");
+    k_bc_neumann<<<(ny + 255) / 256, 256, 0, ctx->stream[0]>>>(T, nx, ny);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+extern "C" int fpr_bc2d(fpr_ctx* ctx, double* T, int nx, int ny)
+{
+    if (int rc = fpr_bc_dirichlet2d(ctx, T, nx, ny)) return rc;
+    return fpr_bc_neumann2d(ctx, T, nx, ny);
+}
+
+// ---- CG ---------------------------------------------------------------------------------------------
+struct CgWork { double *r, *p, *ph, *x; size_t n; };
+
+static int cg_work(fpr_ctx* ctx, size_t n, CgWork* w)
+{
+    // four work vectors (krylov.jl:59-62), kept by the context and grown on demand
+    if (ctx->cg_cap < 4 * n) {
+        if (ctx->cg_buf) {
+            FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
+            FPR_HIP(ctx, hipFree(ctx->cg_buf));
+            ctx->cg_buf = nullptr;
+            ctx->cg_cap = 0;
+        }
+        FPR_HIP(ctx, hipMalloc(&ctx->cg_buf, 4 * n * sizeof(double)));
+        ctx->cg_cap = 4 * n;
+    }
+    double* b = ctx->cg_buf;
+    w->r = b; w->p = b + n; w->ph = b + 2 * n; w->x = b + 3 * n; w->n = n;
+    return FPR_OK;
+}
+
+// runs cg! on the compute stream; leaves iters / last_rms in ctx->state_h (synchronises)
+static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, double hy, double c, double tol, int Nmax,
+                    int nx, int ny)
+{
+    const size_t N = (size_t)nx * ny;
+    CgWork w;
+    if (int rc = cg_work(ctx, N, &w)) return rc;
+    hipStream_t s = ctx->stream[0];
+    const int fg = flat_grid(N);
+    const dim3 g2 = grid2(nx, ny);
+    const int np2 = (int)(g2.x * g2.y);
+    if (np2 > FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
+    k_cg_init<<<fg, 256, 0, s>>>(b, w.r, w.p, w.ph, w.x, N);
+    FPR_CHECK_LAUNCH(ctx);
+    if (int rc = fprx_dot_dev(ctx, b, b, N, ctx->scalars + 2)) return rc;
+    k_state_init<<<1, 1, 0, s>>>(ctx->state, ctx->scalars + 2, tol, (double)N, 1);
+    FPR_CHECK_LAUNCH(ctx);
+    const int chunk = 32;
+    int done_iters = 0;
+    ctx->state_h->done = 0; ctx->state_h->iters = 0; ctx->state_h->last_rms = 0.0;
+    while (done_iters < Nmax) {
+        const int m = (Nmax - done_iters < chunk) ? Nmax - done_iters : chunk;
+        for (int i = 0; i < m; ++i) {
+            k_cg_matvec_dot<<<g2, blk2, 0, s>>>(w.p, w.ph, nx, ny, hx * hx, hy * hy, c, ctx->partials, ctx->state);
+            k_cg_alpha<<<1, 256, 0, s>>>(ctx->state, ctx->partials, np2);
+            k_cg_update<<<fg, 256, 0, s>>>(w.x, w.r, w.p, w.ph, N, ctx->partials2, ctx->state);
+            k_cg_check<<<1, 256, 0, s>>>(ctx->state, ctx->partials2, fg, (double)N);
+            k_cg_p<<<fg, 256, 0, s>>>(w.p, w.r, N, ctx->state);
+        }
+        FPR_CHECK_LAUNCH(ctx);
+        done_iters += m;
+        if (int rc = read_state(ctx)) return rc;
+        if (ctx->state_h->done) break;
+    }
+    if (Nmax <= 0) {  // loop body never runs: r = b, x = 0 (krylov.jl:66,88,90)
+        if (int rc = read_scalar(ctx, ctx->scalars + 2, &ctx->state_h->last_rms)) return rc;
+        ctx->state_h->last_rms = sqrt(ctx->state_h->last_rms / (double)N);
+    }
+    FPR_HIP(ctx, hipMemcpyAsync(x_in, w.x, N * sizeof(double), hipMemcpyDeviceToDevice, s));  // krylov.jl:88
+    return FPR_OK;
+}
+
+extern "C" int fpr_cg2d(fpr_ctx* ctx, double* x_in, const double* b, double hx, double hy, double c, double tol, int Nmax,
+                        int nx, int ny, double* rms_host, int* iters_host)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, x_in && b, "null pointer");
+    if (int rc = check_dims(ctx, nx, ny)) return rc;
+    if (int rc = cg_solve(ctx, x_in, b, hx, hy, c, tol, Nmax, nx, ny)) return rc;
+    FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
+    if (rms_host) *rms_host = ctx->state_h->last_rms;
+    if (iters_host) *iters_host = ctx->state_h->iters;
+    return FPR_OK;
+}
+
+// ---- V-cycle ----------------------------------------------------------------------------------------
+static int get_arena(fpr_ctx* ctx, int nx, int ny, int css, std::vector<FprLevel>** out)
+{
+    auto key = std::make_pair(nx, ny);
+    auto it = ctx->arenas.find(key);
+    if (it == ctx->arenas.end()) {
+        std::vector<FprLevel> v;
+        int lx = nx, ly = ny;
+        // allocate down to 3x3-ish so any coarse_solve_size can reuse the arena
+        while (true) {
+            FprLevel L;
+            L.nx = lx; L.ny = ly;
+            FPR_HIP(ctx, hipMalloc(&L.tmp, (size_t)lx * ly * sizeof(double)));
+            const bool can_coarsen = ((lx - 1) % 2 == 0) && ((ly - 1) % 2 == 0) && lx >= 5 && ly >= 5;
+            if (can_coarsen) {
+                const size_t nc = (size_t)(1 + (lx - 1) / 2) * (size_t)(1 + (ly - 1) / 2);
+                FPR_HIP(ctx, hipMalloc(&L.res_c, nc * sizeof(double)));
+                FPR_HIP(ctx, hipMalloc(&L.corr_c, nc * sizeof(double)));
+            }
+            v.push_back(L);
+            if (!can_coarsen) break;
+            lx = 1 + (lx - 1) / 2;
+            ly = 1 + (ly - 1) / 2;
+        }
+        it = ctx->arenas.emplace(key, std::move(v)).first;
+    }
+    (void)css;
+    *out = &it->second;
+    return FPR_OK;
+}
+
+// One level of Vcycle_2DPoisson! (multigrid.jl:91-170).  want_norm: top level only -- the r_rms of the
+// last post-smoothing sweep is left in ctx->scalars[0] (as sum of squares) for the caller.
+static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double* u, const double* rhs, double h, double c,
+                        double tol, int css, int solver, int apply_BCs, bool top, double* rms_out_host, bool* rms_is_host)
+{
+    FprLevel& L = A[d];
+    const int nx = L.nx, ny = L.ny;
+    hipStream_t s = ctx->stream[0];
+    if ((nx - 1) != 2 * ((nx - 1) / 2) || (ny - 1) != 2 * ((ny - 1) / 2))
+        return fpr_fail(ctx, FPR_ERR_NOT_POW2, "ERROR:not a power of 2 (nx=%d, ny=%d)", nx, ny);  // multigrid.jl:95-97
+    {
+        const int m = (nx < ny ? nx : ny) - 1;
+        if (m <= 0 || (m & (m - 1)) != 0)
+            return fpr_fail(ctx, FPR_ERR_NOT_POW2, "min(nx,ny)-1 = %d is not a power of 2 (multigrid.jl:103)", m);
+    }
+    const size_t N = (size_t)nx * ny;
+    const double C = 4.0 + c * (h * h), _h2 = 1 / (h * h);
+    const double fac = (4.0 / 5.0) * ((h * h) / (4.0 + c * (h * h)));
+    const dim3 g = grid2(nx, ny);
+    const int np = (int)(g.x * g.y);
+    if (np > FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
+
+    if ((nx < ny ? nx : ny) > css) {  // multigrid.jl:121
+        if (d + 1 >= A.size() || !L.res_c) return fpr_fail(ctx, FPR_ERR_INVALID, "level arena exhausted");
+        const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
+        // two pre-smoothing sweeps (:124-125)
+        k_sweep2d<false, false><<<g, blk2, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, nullptr, nullptr);
+        k_sweep2d<false, false><<<g, blk2, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, nullptr, nullptr);
+        // residual + restriction (:128-129), coarse correction starts from zero (:132)
+        k_restrict_residual2d<<<grid2(nxc, nyc), blk2, 0, s>>>(u, rhs, L.res_c, nx, ny, C, _h2, apply_BCs);
+        FPR_CHECK_LAUNCH(ctx);
+        FPR_HIP(ctx, hipMemsetAsync(L.corr_c, 0, (size_t)nxc * nyc * sizeof(double), s));
+        double dummy; bool dh;
+        if (int rc = vcycle_level(ctx, A, d + 1, L.corr_c, L.res_c, h * 2, c, tol, css, solver, apply_BCs, false, &dummy, &dh))
+            return rc;  // :133
+        // prolongation + correction (:136-139)
+        k_prolong2d<true><<<g, blk2, 0, s>>>(L.corr_c, u, nx, ny, apply_BCs);
+        // two post-smoothing sweeps (:142-143); only the very last one of the top level needs its norm
+        k_sweep2d<false, false><<<g, blk2, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, nullptr, nullptr);
+        if (top) {
+            k_sweep2d<true, false><<<g, blk2, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, ctx->partials, nullptr);
+            FPR_CHECK_LAUNCH(ctx);
+            if (int rc = fprx_finish_sum(ctx, ctx->partials, np, ctx->scalars, false, 0)) return rc;
+            *rms_is_host = false;
+        } else {
+            k_sweep2d<false, false><<<g, blk2, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, nullptr, nullptr);
+            FPR_CHECK_LAUNCH(ctx);
+        }
+        return FPR_OK;
+    }
+
+    // ---- coarsest level ----
+    const int iters = 20 * css;  // :149, :161
+    if (solver == FPR_COARSE_JACOBI) {
+        if (int rc = fprx_sumsq_scaled_dev(ctx, rhs, N, 1.0, ctx->scalars + 3, 0)) return rc;  // :150
+        k_state_init<<<1, 1, 0, s>>>(ctx->state, ctx->scalars + 3, tol, (double)N, 0);
+        FPR_CHECK_LAUNCH(ctx);
+        const int chunk = 64;
+        int launched = 0;
+        ctx->state_h->done = 0; ctx->state_h->iters = 0; ctx->state_h->last_rms = 0.0;
+        double* a = u;
+        double* b = L.tmp;
+        while (launched < iters) {
+            const int m = (iters - launched < chunk) ? iters - launched : chunk;
+            for (int i = 0; i < m; ++i) {
+                k_sweep2d<true, true><<<g, blk2, 0, s>>>(a, rhs, b, nx, ny, C, _h2, fac, ctx->partials, ctx->state);
+                k_jacobi_check<<<1, 256, 0, s>>>(ctx->state, ctx->partials, np, (double)N);
+                double* t = a; a = b; b = t;
+            }
+            FPR_CHECK_LAUNCH(ctx);
+            launched += m;
+            if (int rc = read_state(ctx)) return rc;
+            if (ctx->state_h->done) break;
+        }
+        // the solution sits in u after an even number of executed sweeps, else in tmp
+        if (ctx->state_h->iters & 1)
+            FPR_HIP(ctx, hipMemcpyAsync(u, L.tmp, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+    } else if (solver == FPR_COARSE_CG) {
+        if (int rc = cg_solve(ctx, u, rhs, h, h, c, tol, iters, nx, ny)) return rc;  // :162
+    } else {
+        return fpr_fail(ctx, FPR_ERR_INVALID, "unknown coarse solver %d", solver);  // :163-165 error()
+    }
+    ctx->last_coarse_iters += ctx->state_h->iters;
+    *rms_out_host = ctx->state_h->last_rms;
+    *rms_is_host = true;
+    return FPR_OK;
+}
+
+static int vcycle_run(fpr_ctx* ctx, double* u, const double* rhs, double h, double c, double tol, int css, int solver,
+                      int apply_BCs, int nx, int ny, double* rms_host)
+{
+    std::vector<FprLevel>* A;
+    if (int rc = get_arena(ctx, nx, ny, css, &A)) return rc;
+    double r = 0.0;
+    bool is_host = true;
+    if (int rc = vcycle_level(ctx, *A, 0, u, rhs, h, c, tol, css, solver, apply_BCs, true, &r, &is_host)) return rc;
+    if (rms_host) {
+        if (!is_host) {
+            double ssum;
+            if (int rc = read_scalar(ctx, ctx->scalars, &ssum)) return rc;
+            r = sqrt(ssum / ((double)nx * (double)ny));  // multigrid.jl:252
+        }
+        *rms_host = r;
+    }
+    return FPR_OK;
+}
+
+extern "C" int fpr_vcycle2d(fpr_ctx* ctx, double* u_f, const double* rhs, double h, double c, double tol,
+                            int coarse_solve_size, int coarse_solver, int apply_BCs, int nx, int ny, double* rms_host)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, u_f && rhs, "null pointer");
+    if (int rc = check_dims(ctx, nx, ny)) return rc;
+    ctx->last_coarse_iters = 0;
+    return vcycle_run(ctx, u_f, rhs, h, c, tol, coarse_solve_size, coarse_solver, apply_BCs, nx, ny, rms_host);
+}
+
+extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h, double c, double tol, int niters,
+                             int apply_BCs, int coarse_solve_size, int coarse_solver, int nx, int ny, double* rms_host,
+                             int* ncycles_host, double* history_host, double* frms_host, int* converged_host)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, u && f, "null pointer");
+    if (int rc = check_dims(ctx, nx, ny)) return rc;
+    {   // multigrid.jl:45-46
+        const int m = coarse_solve_size - 1;
+        if (coarse_solve_size > (nx < ny ? nx : ny) || m <= 0 || (m & (m - 1)) != 0)
+            return fpr_fail(ctx, FPR_ERR_ASSERT, "@assert failed: coarse_solve_size=%d (must be 2^l+1 and <= min(nx,ny))",
+                            coarse_solve_size);
+    }
+    const size_t N = (size_t)nx * ny;
+    double fs;
+    if (int rc = fpr_sumsq_scaled(ctx, f, N, 1.0, &fs)) return rc;
+    const double f_rms = sqrt(fs / (double)N);  // :53
+    const double tolf = tol * f_rms;
+    double r_rms = 0.0;
+    int n = 0;
+    ctx->last_coarse_iters = 0;
+    for (int iter = 1; iter <= niters; ++iter) {
+        if (apply_BCs)
+            if (int rc = fpr_bc2d(ctx, u, nx, ny)) return rc;  // :60-62
+        if (int rc = vcycle_run(ctx, u, f, h, c, tol, coarse_solve_size, coarse_solver, apply_BCs, nx, ny, &r_rms)) return rc;
+        if (history_host) history_host[n] = r_rms;
+        ++n;
+        if (r_rms < tolf) break;  // :70
+    }
+    if (rms_host) *rms_host = r_rms;
+    if (ncycles_host) *ncycles_host = n;
+    if (frms_host) *frms_host = f_rms;
+    if (converged_host) *converged_host = !(r_rms > tolf);  // :78-80 @warn condition
+    return FPR_OK;
+}
+
+extern "C" long fpr_last_coarse_iters(fpr_ctx* ctx) { return ctx ? ctx->last_coarse_iters : 0; }

@@ -1,0 +1,279 @@
+"""Implicit global grid for the domain-decomposed 3D diffusion path.
+
+Role of ImplicitGlobalGrid.jl in the reference (init_global_grid / nx_g / x_g / update_halo! /
+finalize_global_grid; call sites scripts-part1/part1_kernel_programming.jl:100-101,117,182,187) and of
+MPI.Allreduce! in dist_norm_L2 (part1_utils.jl:38), rebuilt for one process per GPU with
+torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).
+
+Local arrays are nx*ny*nz including a 1-cell halo on every side that has a neighbour (overlap 2), so
+the global grid has dims*(n-2)+2 cells per dimension.  Per pseudo-iteration (GlobalGrid.step):
+
+    compute stream : boundary slabs -> pack x/y faces ----> interior box ----------> unpack halos
+    comm stream    :                      wait(compute) -> isend/irecv (RCCL) -> done
+
+i.e. the halo exchange of the freshly written planes overlaps the interior update -- the role of
+`@hide_communication (8,8,8)` (:185-188).  Deviation from the reference, documented in DESIGN.md: the
+reference calls update_halo!(Hτ) on the OLD buffer (:182,187 before the swap :190); here the NEW buffer
+(Hτ2) is exchanged, which makes an N-shard run equal to the single-domain run on the same global grid.
+"""
+import math
+
+
+def dims_create(nprocs, ndims=3):
+    """MPI.Dims_create-like balanced factorisation, non-increasing: 2->(2,1,1) 4->(2,2,1) 8->(2,2,2)
+    (matches part1_scaling_experiments.jl:35-41)."""
+    dims = [1] * ndims
+    n = nprocs
+    f = 2
+    factors = []
+    while f * f <= n:
+        while n % f == 0:
+            factors.append(f)
+            n //= f
+        f += 1
+    if n > 1:
+        factors.append(n)
+    for p in sorted(factors, reverse=True):
+        dims[dims.index(min(dims))] *= p
+    return tuple(sorted(dims, reverse=True))
+
+
+class HaloExchanger:
+    """update_halo!(A): exchange one plane per face with each Cartesian neighbour.
+
+    For face (dim, side) the plane at local index 1 (side 0) / n-2 (side 1) is sent to the neighbour,
+    whose plane arrives in our halo plane 0 / n-1.  pack(A, face, buf) / unpack(A, face, buf) move a
+    plane between the field and a contiguous buffer; z-planes are contiguous in the column-major
+    layout and are sent / received in place (zero copy)."""
+
+    def __init__(self, shape, neighbors, rank_of, pack, unpack, new_buffer, dist=None, group=None):
+        self.shape = tuple(shape)
+        self.neighbors = neighbors  # {face: neighbour coords}
+        self.rank_of = rank_of
+        self.pack, self.unpack = pack, unpack
+        self.dist, self.group = dist, group
+        nx, ny, nz = self.shape
+        plane = {0: ny * nz, 1: nx * nz, 2: nx * ny}
+        self.sendbuf, self.recvbuf = {}, {}
+        for face in neighbors:
+            d = face >> 1
+            if d != 2:
+                self.sendbuf[face] = new_buffer(plane[d])
+                self.recvbuf[face] = new_buffer(plane[d])
+
+    def faces(self):
+        return sorted(self.neighbors)
+
+    @staticmethod
+    def _zplane(A, k):
+        # A has Julia shape (nx,ny,nz) with strides (1,nx,nx*ny): permute(2,1,0) is C-contiguous
+        return A.permute(2, 1, 0)[k]
+
+    def pack_all(self, A):
+        for face in self.faces():
+            if (face >> 1) != 2:
+                self.pack(A, face, self.sendbuf[face])
+
+    def post(self, A):
+        """Post all sends/receives of already packed planes (z planes in place); returns work handles."""
+        nz = self.shape[2]
+        ops = []
+        P2POp = self.dist.P2POp
+        for face in self.faces():
+            d, side = face >> 1, face & 1
+            peer = self.rank_of(self.neighbors[face])
+            if d == 2:
+                send_t = self._zplane(A, nz - 2 if side else 1)
+                recv_t = self._zplane(A, nz - 1 if side else 0)
+            else:
+                send_t, recv_t = self.sendbuf[face], self.recvbuf[face]
+            ops.append(P2POp(self.dist.isend, send_t, peer, group=self.group))
+            ops.append(P2POp(self.dist.irecv, recv_t, peer, group=self.group))
+        return self.dist.batch_isend_irecv(ops) if ops else []
+
+    @staticmethod
+    def wait(works):
+        for w in works:
+            w.wait()
+
+    def unpack_all(self, A):
+        for face in self.faces():
+            if (face >> 1) != 2:
+                self.unpack(A, face, self.recvbuf[face])
+
+    def update_halo_(self, A):
+        """Blocking update_halo!(A)."""
+        self.pack_all(A)
+        works = self.post(A)
+        self.wait(works)
+        self.unpack_all(A)
+
+
+class GlobalGrid:
+    """init_global_grid(nx, ny, nz): Cartesian process topology + implicit global grid."""
+
+    def __init__(self, nx, ny, nz, dims=None, group=None, use_dist=None):
+        self.nx, self.ny, self.nz = nx, ny, nz
+        dist = None
+        if use_dist is None or use_dist:
+            try:
+                import torch.distributed as _dist
+
+                if _dist.is_available() and _dist.is_initialized():
+                    dist = _dist
+            except ImportError:
+                dist = None
+        self.dist, self.group = dist, group
+        self.nprocs = dist.get_world_size(group) if dist else 1
+        self.me = dist.get_rank(group) if dist else 0
+        if dims is None:
+            dims = dims_create(self.nprocs)
+        dims = tuple(int(d) for d in dims)
+        if dims[0] * dims[1] * dims[2] != self.nprocs:
+            raise ValueError("dims %s do not match %d processes" % (dims, self.nprocs))
+        self.dims = dims
+        self.coords = self.coords_of(self.me)
+        self.neighbors = {}
+        for d in range(3):
+            for side in (0, 1):
+                c = list(self.coords)
+                c[d] += 1 if side else -1
+                if 0 <= c[d] < dims[d]:
+                    self.neighbors[2 * d + side] = tuple(c)
+        self._ex = None
+        self._sq_host = None
+
+    # ---- topology (MPI Cartesian order: last dimension varies fastest) ----
+    def coords_of(self, rank):
+        d = self.dims
+        return (rank // (d[1] * d[2]), (rank // d[2]) % d[1], rank % d[2])
+
+    def rank_of(self, coords):
+        d = self.dims
+        return (coords[0] * d[1] + coords[1]) * d[2] + coords[2]
+
+    # ---- implicit global grid ----
+    def nx_g(self):
+        return self.dims[0] * (self.nx - 2) + 2
+
+    def ny_g(self):
+        return self.dims[1] * (self.ny - 2) + 2
+
+    def nz_g(self):
+        return self.dims[2] * (self.nz - 2) + 2
+
+    def x_g(self, ix, dx, dim=0):
+        """Global coordinate of 1-based local index ix (size-n arrays)."""
+        n = (self.nx, self.ny, self.nz)[dim]
+        return (self.coords[dim] * (n - 2) + (ix - 1)) * dx
+
+    def global_offset(self):
+        """0-based global index of local cell (0,0,0)."""
+        return tuple(self.coords[d] * ((self.nx, self.ny, self.nz)[d] - 2) for d in range(3))
+
+    # ---- collectives ----
+    def allreduce_sum(self, t):
+        """MPI.Allreduce!(x, +, comm) of a 1-element tensor (part1_utils.jl:38); returns a float."""
+        if self.dist is not None and self.nprocs > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return float(t[0].item()) if hasattr(t, "item") else float(t)
+
+    def barrier(self):
+        if self.dist is not None and self.nprocs > 1:
+            self.dist.barrier(group=self.group)
+
+    # ---- halo exchange on device arrays (HIP pack/unpack + RCCL) ----
+    def exchanger(self):
+        if self._ex is None:
+            from . import ctx as _ctx
+            from ._lib import fptr, fzeros
+
+            c = _ctx()
+            nx, ny, nz = self.nx, self.ny, self.nz
+
+            def pack(A, face, buf):
+                c.call("fpr_halo_pack3d", fptr(A, 3), nx, ny, nz, face, buf.data_ptr(), 0)
+
+            def unpack(A, face, buf):
+                c.call("fpr_halo_unpack3d", fptr(A, 3), nx, ny, nz, face, buf.data_ptr(), 0)
+
+            self._ex = HaloExchanger((nx, ny, nz), self.neighbors, self.rank_of, pack, unpack,
+                                     lambda n: fzeros(n), dist=self.dist, group=self.group)
+        return self._ex
+
+    def update_halo_(self, A):
+        """update_halo!(A) -- blocking form."""
+        if self.neighbors:
+            self.exchanger().update_halo_(A)
+
+    # ---- one pseudo-iteration (kernel + halo exchange + optional norm) ----
+    def boundary_boxes(self):
+        """Thin boxes (0-based [lo,hi)) holding the interior cells next to faces with a neighbour, and
+        the remaining interior box.  Boxes are disjoint and cover the whole interior."""
+        n = (self.nx, self.ny, self.nz)
+        lo = [1, 1, 1]
+        hi = [n[0] - 1, n[1] - 1, n[2] - 1]
+        boxes = []
+        # peel z faces first (contiguous planes), then y, then x
+        for d in (2, 1, 0):
+            for side in (0, 1):
+                if (2 * d + side) in self.neighbors and hi[d] - lo[d] >= 1:
+                    blo, bhi = list(lo), list(hi)
+                    if side == 0:
+                        bhi[d] = lo[d] + 1
+                        lo[d] += 1
+                    else:
+                        blo[d] = hi[d] - 1
+                        hi[d] -= 1
+                    boxes.append((tuple(blo), tuple(bhi)))
+        return boxes, (tuple(lo), tuple(hi))
+
+    def step(self, Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq_dev):
+        """Hτ2, dHdτ <- update(Hτ); halos of Hτ2 refreshed; if sq_dev is given it receives the LOCAL
+        sum((dHdτ*norm_scale)^2) (all-reduce it with allreduce_sum)."""
+        from . import part1
+
+        if not self.neighbors:
+            if sq_dev is None:
+                part1.diffusion_3D_step_τ(Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
+            else:
+                part1.diffusion_3D_step_τ_norm(Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz,
+                                               norm_scale, sq_dev)
+            return
+        import torch
+        from . import ctx as _ctx
+
+        c = _ctx()
+        args = (Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
+        boxes, inner = self.boundary_boxes()
+        if sq_dev is not None:
+            sq_dev.zero_()
+        for lo, hi in boxes:  # 1. boundary slabs first
+            part1.diffusion_3D_step_τ_box(*args, lo, hi, norm_scale, sq_dev, 0)
+        ex = self.exchanger()
+        # 2. exchange the freshly written planes: packs on the compute stream, transfers on the comm stream
+        ex.pack_all(Hτ2)
+        c.comm.wait_stream(c.compute)
+        with torch.cuda.stream(c.comm):
+            works = ex.post(Hτ2)
+        # 3. interior update overlaps the exchange
+        part1.diffusion_3D_step_τ_box(*args, inner[0], inner[1], norm_scale, sq_dev, 0)
+        # 4. join: the compute stream waits for the transfers, then unpacks the x/y halos
+        with torch.cuda.stream(c.comm):
+            ex.wait(works)
+        c.compute.wait_stream(c.comm)
+        ex.unpack_all(Hτ2)
+
+    def gather_(self, A_host):
+        """gather!(A, A_global) onto rank 0 (part1_kernel_programming.jl:223): returns the list of all
+        ranks' local arrays (numpy) on rank 0, None elsewhere."""
+        if self.dist is None or self.nprocs == 1:
+            return [A_host]
+        out = [None] * self.nprocs if self.me == 0 else None
+        self.dist.gather_object(A_host, out, dst=0, group=self.group)
+        return out
+
+
+def finalize_global_grid():
+    """finalize_global_grid(): nothing to release (torch.distributed is owned by the caller)."""
+    return None

@@ -1,0 +1,223 @@
+"""Part 1 -- 3D pseudo-transient diffusion.  Host mirror of
+scripts-part1/part1_kernel_programming.jl, part1_array_programming.jl and part1_utils.jl.
+
+Kernel entry points keep the reference's argument lists; launch-geometry arguments of
+`@parallel blocks threads shmem=...` have no counterpart (the library picks its own).
+"""
+import ctypes as C
+import math
+import time
+from dataclasses import dataclass
+
+from . import _lib
+from ._lib import fptr, fzeros
+
+
+def _ctx():
+    from . import ctx
+
+    return ctx()
+
+
+@dataclass
+class BenchResults:
+    """part1_kernel_programming.jl:22-29"""
+
+    Δt: float
+    Work: float
+    Performance: float
+    Memory: float
+    Intensity: float
+    Throughput: float
+
+
+# ------------------------------------------------------------------------------------------------
+# kernels
+# ------------------------------------------------------------------------------------------------
+def diffusion_3D_step_τ(Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz):
+    """part1_kernel_programming.jl:46-58."""
+    nx, ny, nz = Ht.shape
+    _ctx().call("fpr_diffusion3d_step", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hτ2, 3), fptr(dHdτ, 3), nx, ny, nz,
+                dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
+
+
+# part1_kernel_programming.jl:75-97 -- same arithmetic; on gfx950 both names run the same kernel
+diffusion_3D_step_τ_shared_memory = diffusion_3D_step_τ
+
+
+def diffusion_3D_step_τ_norm(Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale, sumsq_dev):
+    """Fused update + local part of dist_norm_L2(residual_H*scale) (part1_kernel_programming.jl:191):
+    sumsq_dev[0] (device) = sum((dHdτ*scale)^2) over the interior.  No host sync."""
+    nx, ny, nz = Ht.shape
+    _ctx().call("fpr_diffusion3d_step_norm", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hτ2, 3), fptr(dHdτ, 3), nx, ny, nz,
+                dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale, sumsq_dev.data_ptr())
+
+
+def diffusion_3D_step_τ_box(Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo, hi, scale=0.0,
+                            sumsq_dev=None, stream_sel=0):
+    """Sub-box form (role of @hide_communication, part1_kernel_programming.jl:185-188); 0-based [lo, hi)."""
+    nx, ny, nz = Ht.shape
+    lo3 = (C.c_int * 3)(*lo)
+    hi3 = (C.c_int * 3)(*hi)
+    _ctx().call("fpr_diffusion3d_step_box", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hτ2, 3), fptr(dHdτ, 3), nx, ny, nz,
+                dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo3, hi3, scale,
+                sumsq_dev.data_ptr() if sumsq_dev is not None else None, stream_sel)
+
+
+def compute_flux_(qx, qy, qz, Hτ, D, dx, dy, dz):
+    """part1_array_programming.jl:10-12 (north_star: compute_flux!)."""
+    nx, ny, nz = Hτ.shape
+    _ctx().call("fpr_diffusion3d_flux", fptr(qx, 3), fptr(qy, 3), fptr(qz, 3), fptr(Hτ, 3), nx, ny, nz, D, dx, dy, dz)
+
+
+def compute_dHdτ_(dHdτ, Hτ, Ht, qx, qy, qz, dt, dx, dy, dz):
+    """part1_array_programming.jl:14-15 (north_star: compute_dHdτ!)."""
+    nx, ny, nz = Hτ.shape
+    _ctx().call("fpr_diffusion3d_dHdtau", fptr(dHdτ, 3), fptr(Hτ, 3), fptr(Ht, 3), fptr(qx, 3), fptr(qy, 3), fptr(qz, 3),
+                nx, ny, nz, dt, dx, dy, dz)
+
+
+def update_H_(Hτ, dHdτ, dτ):
+    """part1_array_programming.jl:16 (north_star: update_H!)."""
+    nx, ny, nz = Hτ.shape
+    _ctx().call("fpr_diffusion3d_update", fptr(Hτ, 3), fptr(dHdτ, 3), nx, ny, nz, dτ)
+
+
+def diffusion_3D_step_τ_(Ht, Hτ, dHdτ, dt, dτ, qx, qy, qz, dx, dy, dz, D):
+    """part1_array_programming.jl:9-18 with clean (barrier-separated) semantics, see SURVEY 8a-A3."""
+    compute_flux_(qx, qy, qz, Hτ, D, dx, dy, dz)
+    compute_dHdτ_(dHdτ, Hτ, Ht, qx, qy, qz, dt, dx, dy, dz)
+    update_H_(Hτ, dHdτ, dτ)
+
+
+# ------------------------------------------------------------------------------------------------
+# part1_utils.jl
+# ------------------------------------------------------------------------------------------------
+def init_local_gaussian(center, dx, dy, dz, H, coords=(0, 0, 0)):
+    """part1_utils.jl:1-12; fills and returns H."""
+    nx, ny, nz = H.shape
+    _ctx().call("fpr_init_gaussian3d", fptr(H, 3), nx, ny, nz, dx, dy, dz, center[0], center[1], center[2],
+                coords[0], coords[1], coords[2])
+    return H
+
+
+def apply_boundary_conditions_(H, coords, dims):
+    """part1_utils.jl:14-34 -- including the reference's 0-based-coords-vs-1 comparison."""
+    if coords[0] == 1:
+        H[0, :, :] = 0.0
+    if coords[1] == 1:
+        H[:, 0, :] = 0.0
+    if coords[2] == 1:
+        H[:, :, 0] = 0.0
+    if coords[0] == dims[0]:
+        H[-1, :, :] = 0.0
+    if coords[1] == dims[1]:
+        H[:, -1, :] = 0.0
+    if coords[2] == dims[2]:
+        H[:, :, -1] = 0.0
+
+
+def local_sumsq(Rh, scale=1.0):
+    """sum((Rh*scale).^2) -- part1_utils.jl:37 (host value; synchronises)."""
+    out = C.c_double(0.0)
+    _ctx().call("fpr_sumsq_scaled", fptr(Rh), Rh.numel(), scale, C.byref(out))
+    return out.value
+
+
+def dist_norm_L2(Rh, comm_cart=None, scale=1.0):
+    """part1_utils.jl:36-40: sqrt(allreduce_sum(sum((Rh*scale)^2)))."""
+    s = local_sumsq(Rh, scale)
+    if comm_cart is not None:
+        s = comm_cart.allreduce_sum(s)
+    return math.sqrt(s)
+
+
+# ------------------------------------------------------------------------------------------------
+# solver host loop
+# ------------------------------------------------------------------------------------------------
+def diffusion_3D_kernel_programming(*, nx, ny, nz, ttot=1.0, tol=1e-8, use_shared_memory=True, verbose=False,
+                                    scale_physical_size=False, iter_max=100000, fixed_iters=0, check_every=1,
+                                    global_grid=None, Ht_init=None, return_device=False):
+    """part1_kernel_programming.jl:99-228.
+
+    Extra keyword arguments (SURVEY section 5 "config / flags"):
+      iter_max     -- the reference hard-codes 1e5 (:130)
+      fixed_iters  -- run exactly this many pseudo-iterations per physical step (benchmark mode)
+      check_every  -- evaluate the convergence norm on the host every n-th iteration (1 = reference)
+      global_grid  -- grid.GlobalGrid for multi-GPU runs (None = single rank)
+      Ht_init      -- optional initial condition (device array) instead of the Gaussian
+    Returns (X_g, H, BenchResults, info) -- H is the local field (numpy, or device tensor).
+    """
+    import torch
+    from . import grid as _grid
+
+    ctx = _ctx()
+    gg = global_grid if global_grid is not None else _grid.GlobalGrid(nx, ny, nz, dims=(1, 1, 1))
+    me, dims, coords = gg.me, gg.dims, gg.coords
+    D = 1.0
+    if scale_physical_size:  # :110-114
+        lx, ly, lz = (d * 10.0 for d in dims)
+    else:
+        lx, ly, lz = 10.0, 10.0, 10.0
+    dx, dy, dz = lx / gg.nx_g(), ly / gg.ny_g(), lz / gg.nz_g()  # :117
+    total_N = dims[0] * dims[1] * dims[2] * nx * ny * nz  # :124
+    dt = 0.2
+    dτ = min(dx, dy, dz) ** 2 / D / 8.1  # :128
+    nt = int(round(ttot / dt)) if abs(ttot / dt - round(ttot / dt)) < 1e-9 else int(math.ceil(ttot / dt))
+    center = [lx / 2, ly / 2, lz / 2]
+    Ht = fzeros(nx, ny, nz)
+    if Ht_init is not None:
+        Ht.copy_(Ht_init)
+    else:
+        init_local_gaussian(center, dx, dy, dz, Ht, coords)  # :137-138
+    apply_boundary_conditions_(Ht, coords, dims)  # :139
+    Hτ = Ht.clone(memory_format=torch.preserve_format)  # :140
+    Hτ2 = fzeros(nx, ny, nz)  # :141
+    residual_H = fzeros(nx, ny, nz)  # :142
+    _dt, _dx, _dy, _dz = 1.0 / dt, 1.0 / dx, 1.0 / dy, 1.0 / dz  # :146-149
+    D_dx, D_dy, D_dz = D / dx, D / dy, D / dz  # :150-152
+    sq = ctx.scal[:1]
+    iter_outer = 0
+    timed_iter_total = 0
+    tic = time.time()
+    iters_per_step, err_per_step = [], []
+    sqrtN = math.sqrt(total_N)
+    for _ in range(nt):  # :166
+        if iter_outer == 3:  # manual warm-up, :170-176
+            ctx.synchronize()
+            tic = time.time()
+            timed_iter_total = 0
+        iter_inner = 0
+        err = 2 * tol
+        while (iter_inner < fixed_iters) if fixed_iters > 0 else (err > tol and iter_inner < iter_max):  # :179
+            need_norm = (fixed_iters == 0 and (iter_inner + 1) % check_every == 0) or \
+                        (fixed_iters > 0 and iter_inner + 1 == fixed_iters)
+            gg.step(Ht, Hτ, Hτ2, residual_H, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, dt, sq if need_norm else None)
+            Hτ, Hτ2 = Hτ2, Hτ  # :190
+            if need_norm:
+                err = math.sqrt(gg.allreduce_sum(sq)) / sqrtN  # :191
+            iter_inner += 1
+        if verbose and me == 0:
+            print("Converged after %d iterations." % iter_inner if err <= tol else
+                  "Couldn't converge within %d iterations." % iter_inner)
+        iters_per_step.append(iter_inner)
+        err_per_step.append(err)
+        timed_iter_total += iter_inner
+        iter_outer += 1
+        ctx.call("fpr_copy", fptr(Ht), fptr(Hτ), Ht.numel())  # Ht .= Hτ, :203
+    ctx.synchronize()
+    Δt = time.time() - tic
+    nranks = gg.nprocs
+    cells = (nx - 2) * (ny - 2) * (nz - 2)
+    Work = nranks * timed_iter_total * (25 + 2) * cells  # :210
+    Memory = nranks * timed_iter_total * ((6 + 1) if use_shared_memory else (14 + 1)) * 8 * cells  # :212-214
+    bench = BenchResults(Δt, Work, Work / Δt if Δt > 0 else 0.0, Memory, Work / Memory if Memory else 0.0,
+                         Memory / Δt if Δt > 0 else 0.0)
+    import numpy as np
+
+    X_g = np.linspace(dx / 2, lx - dx / 2, nx * dims[0])  # :221
+    info = {"iters": iters_per_step, "err": err_per_step, "dx": dx, "dτ": dτ, "A_eff_GBs":
+            (32.0 * cells * nranks * timed_iter_total / Δt / 1e9 if Δt > 0 else 0.0),
+            "Hτ": Hτ, "residual_H": residual_H}
+    H = Ht if return_device else _lib.tonumpy(Ht)
+    return X_g, H, bench, info

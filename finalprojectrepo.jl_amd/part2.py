@@ -1,0 +1,188 @@
+"""NEXT row 8f-1 -- stream-function / vorticity Navier-Stokes step around the V-cycle.
+Host mirror of scripts-part2/part2.jl (buoyancy-driven convection, Rayleigh/Prandtl; the reference has
+no lid-driven cavity).  Pointwise stencils run in libfpr_hip.so; the handful of whole-array
+broadcasts of the reference's driver (part2.jl:193,220,225,229-230) are torch elementwise ops.
+"""
+import ctypes as C
+import enum
+import math
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import multigrid as mg
+from ._lib import asdevice, fptr, fzeros, tonumpy
+
+
+def _ctx():
+    from . import ctx
+
+    return ctx()
+
+
+class Init_t(enum.Enum):
+    """part2.jl:23-27"""
+
+    cosine = 0
+    random = 1
+    W_from_file = 2
+
+
+cosine, random, W_from_file = Init_t.cosine, Init_t.random, Init_t.W_from_file
+
+
+class SimIn_t:
+    """part2.jl:30-46"""
+
+    def __init__(self):
+        self.k, self.Ra, self.Pr = 1.0, 1.0e6, 1.0e-3
+        self.nx, self.ny = 257, 65
+        self.ttot, self.beta, self.niters, self.tol = 0.1, 0.0, 50, 1.0e-3
+        self.a_dif, self.a_adv = 0.15, 0.4
+        self.T_init_strategy, self.W_init_strategy = cosine, random
+        self.W_init_file = None  # path of Winit.bin for W_from_file
+        self.seed = 1
+
+
+@dataclass
+class SimOut_t:
+    """part2.jl:49-55"""
+
+    T: np.ndarray
+    W: np.ndarray
+    S: np.ndarray
+    t_elapsed: float
+    timed_iters: float
+
+
+def splitmix64_uniform(n, seed=1):
+    """Counter-based U[0,1): identical on every platform."""
+    z = (np.arange(n, dtype=np.uint64) + np.uint64(seed)) * np.uint64(0x9E3779B97F4A7C15)
+    z ^= z >> np.uint64(30)
+    z *= np.uint64(0xBF58476D1CE4E5B9)
+    z ^= z >> np.uint64(27)
+    z *= np.uint64(0x94D049BB133111EB)
+    z ^= z >> np.uint64(31)
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def init_array_(M, scheme, h, width, opt=None):
+    """part2.jl:58-73"""
+    nx, ny = M.shape
+    if scheme == cosine:
+        i = np.arange(nx, dtype=np.float64)
+        col = 0.5 * (1.0 + np.cos((3.0 * math.pi * i * h) / width))
+        M.copy_(asdevice(np.repeat(col[:, None], ny, axis=1)))
+    elif scheme == random:
+        seed = opt.seed if opt is not None else 1
+        M.copy_(asdevice(splitmix64_uniform(nx * ny, seed).reshape((nx, ny), order="F")))
+    elif scheme == W_from_file:
+        M.copy_(asdevice(mg.load(opt.W_init_file)))
+    else:
+        raise RuntimeError("unknown init scheme")
+
+
+def compute_velocity_(S, hx, hy, vx, vy):
+    """part2.jl:90-96"""
+    _ctx().call("fpr_compute_velocity2d", fptr(S, 2), hx, hy, fptr(vx, 2), fptr(vy, 2), *S.shape)
+
+
+def compute_Ra_dTdx_(Ra, hx, T, Ra_dTdx):
+    """part2.jl:99-104"""
+    _ctx().call("fpr_compute_Ra_dTdx2d", Ra, hx, fptr(T, 2), fptr(Ra_dTdx, 2), *T.shape)
+
+
+def compute_diffusion2d_(T, hx, hy, k, dT2):
+    """part2.jl:107-113"""
+    _ctx().call("fpr_compute_diffusion2d", fptr(T, 2), hx, hy, k, fptr(dT2, 2), *T.shape)
+
+
+def compute_advection2d_x_(T, hx, vx, dTx):
+    """part2.jl:116-125"""
+    _ctx().call("fpr_compute_advection2d_x", fptr(T, 2), hx, fptr(vx, 2), fptr(dTx, 2), *T.shape)
+
+
+def compute_advection2d_y_(T, hy, vy, dTy):
+    """part2.jl:128-137"""
+    _ctx().call("fpr_compute_advection2d_y", fptr(T, 2), hy, fptr(vy, 2), fptr(dTy, 2), *T.shape)
+
+
+def _absmax(x):
+    out = C.c_double(0.0)
+    _ctx().call("fpr_absmax", fptr(x), x.numel(), C.byref(out))
+    return out.value
+
+
+def compute_dt(v, vx, vy, dt_dif, a_dif, a_adv, h, beta):
+    """part2.jl:76-87 (v >= 0, so maximum(v) == maximum(abs.(v)))"""
+    v_max = _absmax(v)
+    if v_max == 0:
+        return dt_dif
+    dt_adv = a_adv * min(h / _absmax(vx), h / _absmax(vy))
+    return dt_adv if beta >= 0.5 else min(dt_dif, dt_adv)
+
+
+def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_steps=None):
+    """part2.jl:140-262"""
+    import torch
+
+    opt = opt if opt is not None else SimIn_t()
+    nx, ny = opt.nx, opt.ny
+    h = 1.0 / (ny - 1.0)
+    width = (nx - 1.0) / (ny - 1.0)
+    dt_dif = (opt.a_dif * min(h, h) ** 2) / max(opt.k, opt.Pr)
+    names = "S vx vy v T dT2 dTx dTy T_rhs W dW2 dWx dWy W_rhs Ra_dTdx".split()
+    A = {n: fzeros(nx, ny) for n in names}
+    S, vx, vy, T, W = A["S"], A["vx"], A["vy"], A["T"], A["W"]
+    init_array_(T, opt.T_init_strategy, h, width, opt)
+    init_array_(W, opt.W_init_strategy, h, width, opt)
+    prealloc = mg.preallocate_buffers(nx, ny)
+    hx = hy = h
+    ctx = _ctx()
+    tic = time.time()
+    sim_time, step = 0.0, 0
+    mgopt = mg.MGOpt()
+    import warnings
+
+    while sim_time < opt.ttot:
+        if step == 3:
+            ctx.synchronize()
+            tic = time.time()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore" if not verbose else "default")
+            mg.MGsolve_2DPoisson_(S, W, h, 0.0, opt.tol, opt.niters, False, opt=mgopt, prealloc_dict=prealloc)  # :187
+            compute_velocity_(S, hx, hy, vx, vy)  # :190
+            torch.sqrt(vx * vx + vy * vy, out=A["v"])  # :193
+            dt = compute_dt(A["v"], vx, vy, dt_dif, opt.a_dif, opt.a_adv, h, opt.beta)  # :196
+            mg.apply_boundary_conditions_(T)  # :199
+            compute_Ra_dTdx_(opt.Ra, hx, T, A["Ra_dTdx"])  # :202
+            if not math.isclose(opt.beta, 1.0):  # :205-208
+                compute_diffusion2d_(T, hx, hy, opt.k, A["dT2"])
+                compute_diffusion2d_(W, hx, hy, opt.Pr, A["dW2"])
+            compute_advection2d_x_(T, hx, vx, A["dTx"])  # :211-214
+            compute_advection2d_y_(T, hy, vy, A["dTy"])
+            compute_advection2d_x_(W, hx, vx, A["dWx"])
+            compute_advection2d_y_(W, hy, vy, A["dWy"])
+            if opt.beta > 0.0:  # :217-226
+                c = 1.0 / (opt.beta * dt)
+                A["T_rhs"].copy_(-c * (T + dt * ((1.0 - opt.beta) * A["dT2"] - A["dTx"] - A["dTy"])))
+                mg.MGsolve_2DPoisson_(T, A["T_rhs"], h, c, opt.tol, opt.niters, True, opt=mgopt, prealloc_dict=prealloc)
+                c = c / opt.Pr
+                A["W_rhs"].copy_(-c * (W + dt * ((1.0 - opt.beta) * A["dW2"] - A["dWx"] - A["dWy"] - opt.Pr * A["Ra_dTdx"])))
+                mg.MGsolve_2DPoisson_(W, A["W_rhs"], h, c, opt.tol, opt.niters, False, opt=mgopt, prealloc_dict=prealloc)
+            else:  # :229-230
+                T.copy_(T + dt * (A["dT2"] - A["dTx"] - A["dTy"]))
+                W.copy_(W + dt * (A["dW2"] - A["dWx"] - A["dWy"] - opt.Pr * A["Ra_dTdx"]))
+        sim_time += dt
+        step += 1
+        if verbose and (step - 1) % 20 == 0:
+            print("time, step: %g %d" % (sim_time, step))
+        if testmode or (max_steps is not None and step >= max_steps):
+            break
+    ctx.synchronize()
+    t_elapsed = time.time() - tic
+    out = SimOut_t(tonumpy(T), tonumpy(W), tonumpy(S), t_elapsed, step - 3)
+    out.dt_last = dt
+    out.steps = step
+    return out

@@ -1,0 +1,186 @@
+/*
+ * fpr.h -- C ABI of libfpr_hip.so: the MI355X (gfx950) implementation of the stencil hot path of
+ * ntselepidis/FinalProjectRepo.jl.  One symbol per row of SURVEY.md section 8(a) plus lifecycle.
+ *
+ * The reference has no FFI: its boundary is the ParallelStencil call convention
+ *     @parallel [blocks threads shmem=n] kernel(args...)
+ * on Data.Array (= device Float64 arrays).  Each entry point below replaces one such kernel /
+ * wrapper and keeps its argument list (same order, same meaning); the launch-geometry arguments of
+ * the macro have no counterpart (the library picks its own).  The Julia binding a maintainer adds is
+ * in julia/FPRHip.jl and INTEGRATION.md.  Citations are file:line into the reference repository.
+ *
+ * Conventions
+ *   - all field arrays: Float64, column-major (Julia layout, ix fastest), DEVICE pointers, allocated
+ *     and freed by the host language (AMDGPU.jl ROCArray / torch tensor); the library never retains
+ *     them past the call.
+ *   - every call enqueues on the context's compute stream and returns; only calls that hand a scalar
+ *     back to the host (out-parameters named *_host) synchronise that stream.
+ *   - return value: 0 = FPR_OK, negative = error (fpr_last_error gives the text).
+ *   - arithmetic is compiled without FMA contraction: pointwise results are bit-identical to the
+ *     reference's CPU expressions; reductions differ only by summation order.
+ */
+#ifndef FPR_H
+#define FPR_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fpr_ctx fpr_ctx;
+
+enum {
+    FPR_OK = 0,
+    FPR_ERR_INVALID = -1,   /* bad argument (null pointer, size < 3, ...)                            */
+    FPR_ERR_HIP = -2,       /* a HIP runtime call failed                                             */
+    FPR_ERR_NOT_POW2 = -3,  /* reference: error("ERROR:not a power of 2")  multigrid.jl:95-97, :103   */
+    FPR_ERR_ASSERT = -4,    /* reference: @assert on coarse_solve_size      multigrid.jl:45-46        */
+    FPR_ERR_NO_DEVICE = -5  /* no HIP device visible                                                 */
+};
+
+/* coarse solvers -- multigrid.jl:10-13 (CoarseSolver_t) */
+enum { FPR_COARSE_JACOBI = 0, FPR_COARSE_CG = 1 };
+
+/* ---- lifecycle (replaces @init_parallel_stencil / select_device / @synchronize) ------------------ */
+
+/* device: HIP device ordinal.  compute_stream / comm_stream: hipStream_t handles owned by the caller
+ * (e.g. torch.cuda.Stream().cuda_stream, AMDGPU.jl HIPStream) or NULL to let the library create its own. */
+int fpr_ctx_create(fpr_ctx** out, int device, void* compute_stream, void* comm_stream);
+int fpr_ctx_destroy(fpr_ctx* ctx);
+/* @synchronize()  -- ParallelStencil; multigrid.jl:65, krylov.jl:51 */
+int fpr_synchronize(fpr_ctx* ctx);
+const char* fpr_last_error(fpr_ctx* ctx);
+const char* fpr_version(void);
+/* select the diffusion kernel variant (tuning knob, 0 = library default) */
+int fpr_set_option(fpr_ctx* ctx, const char* key, long value);
+long fpr_get_option(fpr_ctx* ctx, const char* key);
+
+/* Per-launch timing of the dominant kernel with hipEvents recorded on the launch stream (used by
+ * bench.py for the roofline figure).  enable=1 starts recording an event pair around every fused
+ * diffusion-step launch (up to 8192 pairs); read synchronises and returns the summed duration. */
+int fpr_kernel_timer(fpr_ctx* ctx, int enable);
+int fpr_kernel_timer_read(fpr_ctx* ctx, double* total_ms_host, long* count_host);
+
+/* ---- Part 1: 3D pseudo-transient diffusion ------------------------------------------------------- */
+
+/* A1/A2: diffusion_3D_step_tau(Ht, Htau, Htau2, dHdtau, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
+ * part1_kernel_programming.jl:46-58 (shared-memory variant :75-97 has the same arithmetic).
+ * Interior cells only; boundary cells of Htau2 / dHdtau are left untouched. */
+int fpr_diffusion3d_step(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2, double* dHdtau,
+                         int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz,
+                         double D_dx, double D_dy, double D_dz);
+
+/* Same update fused with the convergence norm of part1_kernel_programming.jl:191 /
+ * part1_utils.jl:36-37: *sumsq_dev (DEVICE double) = sum over interior cells of (dHdtau*scale)^2.
+ * (boundary entries of residual_H are zero in the reference, so this equals sum(abs2, residual_H*dt).) */
+int fpr_diffusion3d_step_norm(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2, double* dHdtau,
+                              int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz,
+                              double D_dx, double D_dy, double D_dz, double scale, double* sumsq_dev);
+
+/* Sub-box form used by the multi-GPU driver to split boundary slabs from the interior
+ * (role of @hide_communication (8,8,8), part1_kernel_programming.jl:185-188).  Updates cells with
+ * lo[d] <= index < hi[d] (0-based, clipped to the interior).  sumsq_dev may be NULL; when given,
+ * the partial sum of this box is ADDED to *sumsq_dev (zero it first).  stream_sel: 0 compute, 1 comm. */
+int fpr_diffusion3d_step_box(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2, double* dHdtau,
+                             int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz,
+                             double D_dx, double D_dy, double D_dz, const int lo[3], const int hi[3],
+                             double scale, double* sumsq_dev, int stream_sel);
+
+/* A3 split form (north_star names compute_flux! / compute_dHdtau! / update_H!), clean semantics of
+ * part1_array_programming.jl:9-18:  qx (nx-1,ny-2,nz-2), qy (nx-2,ny-1,nz-2), qz (nx-2,ny-2,nz-1),
+ * dHdtau (nx-2,ny-2,nz-2). */
+int fpr_diffusion3d_flux(fpr_ctx* ctx, double* qx, double* qy, double* qz, const double* Htau,
+                         int nx, int ny, int nz, double D, double dx, double dy, double dz);          /* :10-12 */
+int fpr_diffusion3d_dHdtau(fpr_ctx* ctx, double* dHdtau, const double* Htau, const double* Ht, const double* qx,
+                           const double* qy, const double* qz, int nx, int ny, int nz, double dt, double dx,
+                           double dy, double dz);                                                    /* :14-15 */
+int fpr_diffusion3d_update(fpr_ctx* ctx, double* Htau, const double* dHdtau, int nx, int ny, int nz,
+                           double dtau);                                                             /* :16    */
+
+/* A4: local part of dist_norm_L2(x*scale) -- part1_utils.jl:36-37: sum((x*scale)^2) over n elements.
+ * _dev form leaves the sum in device memory (no sync); _host form synchronises. */
+int fpr_sumsq_scaled_dev(fpr_ctx* ctx, const double* x, size_t n, double scale, double* out_dev);
+int fpr_sumsq_scaled(fpr_ctx* ctx, const double* x, size_t n, double scale, double* out_host);
+/* sum(x .* y) -- krylov.jl:64,69,83 */
+int fpr_dot(fpr_ctx* ctx, const double* x, const double* y, size_t n, double* out_host);
+
+/* A5: `Ht .= Htau` -- part1_kernel_programming.jl:203 */
+int fpr_copy(fpr_ctx* ctx, double* dst, const double* src, size_t n);
+int fpr_fill(fpr_ctx* ctx, double* dst, double value, size_t n);
+
+/* A6: init_local_gaussian -- part1_utils.jl:1-12; coord* = 0-based Cartesian coordinates of the shard */
+int fpr_init_gaussian3d(fpr_ctx* ctx, double* H, int nx, int ny, int nz, double dx, double dy, double dz,
+                        double cx, double cy, double cz, int coordx, int coordy, int coordz);
+
+/* update_halo! building blocks (ImplicitGlobalGrid, called at part1_kernel_programming.jl:182,187):
+ * face = 2*dim + side (dim 0..2, side 0 = low, 1 = high).  pack copies the plane the neighbour needs
+ * (local index 1 or n-2, 0-based) into a contiguous buffer; unpack writes a received plane into the
+ * halo plane (index 0 or n-1).  Plane sizes: ny*nz, nx*nz, nx*ny.  stream_sel as above. */
+int fpr_halo_pack3d(fpr_ctx* ctx, const double* A, int nx, int ny, int nz, int face, double* buf, int stream_sel);
+int fpr_halo_unpack3d(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face, const double* buf, int stream_sel);
+/* order stream `waiter` behind everything enqueued so far on stream `signaller` (0 compute, 1 comm) */
+int fpr_stream_wait(fpr_ctx* ctx, int waiter, int signaller);
+
+/* ---- Part 2: 2D geometric multigrid for (lap - c) u = f ------------------------------------------ */
+
+/* B1: residual_2DPoisson!(u, f, h, c, res) -- multigrid.jl:173-188 (:191-220 shmem); wrapper :223-238 */
+int fpr_residual2d(fpr_ctx* ctx, const double* u, const double* f, double h, double c, double* res, int nx, int ny);
+
+/* B2: iteration_2DPoisson!(u, f, h, c, res, policy; alpha) -- multigrid.jl:245-258.
+ * rms_host (nullable): sqrt(sum(res.^2)/(nx*ny)) measured before the update; non-NULL synchronises. */
+int fpr_jacobi2d(fpr_ctx* ctx, double* u, const double* f, double h, double c, double* res, int nx, int ny,
+                 double alpha, double* rms_host);
+
+/* B3: restrict_wrapper!(fine, coarse, apply_BCs, policy) -- multigrid.jl:330-358; (nx,ny) = fine size */
+int fpr_restrict2d(fpr_ctx* ctx, const double* fine, double* coarse, int nx, int ny, int apply_BCs);
+
+/* B4: prolongate_wrapper!(coarse, fine, apply_BCs, policy) -- multigrid.jl:403-472; (nx,ny) = fine size.
+ * Deterministic gather in the reference's sequential accumulation order (no atomics). */
+int fpr_prolongate2d(fpr_ctx* ctx, const double* coarse, double* fine, int nx, int ny, int apply_BCs);
+
+/* `u_f .= u_f - corr_f` -- multigrid.jl:139 */
+int fpr_axmy2d(fpr_ctx* ctx, double* u, const double* corr, size_t n);
+
+/* B5: matrix_free_matvec_prod!(T, hx, hy, c, dT2) -- krylov.jl:7-13 (:16-34 shmem); wrapper :37-52 */
+int fpr_laplace_apply2d(fpr_ctx* ctx, const double* T, double hx, double hy, double c, double* dT2, int nx, int ny);
+
+/* B6: apply_boundary_conditions{,_dirichlet,_neumann}! -- part2_utils.jl:22-39 */
+int fpr_bc_dirichlet2d(fpr_ctx* ctx, double* T, int nx, int ny);
+int fpr_bc_neumann2d(fpr_ctx* ctx, double* T, int nx, int ny);
+int fpr_bc2d(fpr_ctx* ctx, double* T, int nx, int ny);
+
+/* B7: Vcycle_2DPoisson!(u_f, rhs, h, c, tol, coarse_solve_size, coarse_solver, policy, apply_BCs)
+ * -- multigrid.jl:91-170.  The level arena (prealloc_dict, :25-38) is owned by the context.
+ * rms_host (nullable) = returned res_rms. */
+int fpr_vcycle2d(fpr_ctx* ctx, double* u_f, const double* rhs, double h, double c, double tol,
+                 int coarse_solve_size, int coarse_solver, int apply_BCs, int nx, int ny, double* rms_host);
+
+/* B8: MGsolve_2DPoisson!(u, f, h, c, tol, niters, apply_BCs; opt) -- multigrid.jl:41-84.
+ * rms_host = returned r_rms; ncycles_host = V-cycles executed; history_host (nullable, >= niters
+ * doubles) = r_rms after each cycle; frms_host (nullable) = rms(f); converged_host (nullable) = 0 when
+ * the reference would emit its @warn (:78-80) -- not an error. */
+int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h, double c, double tol, int niters,
+                  int apply_BCs, int coarse_solve_size, int coarse_solver, int nx, int ny, double* rms_host,
+                  int* ncycles_host, double* history_host, double* frms_host, int* converged_host);
+
+/* B9: cg!(x_in, b, hx, hy, c, tol, Nmax) -- krylov.jl:55-91 (starts from x = 0, overwrites x_in) */
+int fpr_cg2d(fpr_ctx* ctx, double* x_in, const double* b, double hx, double hy, double c, double tol, int Nmax,
+             int nx, int ny, double* rms_host, int* iters_host);
+
+/* coarse-solver iterations spent by the last fpr_vcycle2d / fpr_mgsolve2d call (diagnostics) */
+long fpr_last_coarse_iters(fpr_ctx* ctx);
+
+/* ---- NEXT: Navier-Stokes pointwise kernels, part2.jl:90-137 ------------------------- */
+int fpr_compute_velocity2d(fpr_ctx* ctx, const double* S, double hx, double hy, double* vx, double* vy, int nx, int ny);
+int fpr_compute_Ra_dTdx2d(fpr_ctx* ctx, double Ra, double hx, const double* T, double* out, int nx, int ny);
+int fpr_compute_diffusion2d(fpr_ctx* ctx, const double* T, double hx, double hy, double k, double* dT2, int nx, int ny);
+int fpr_compute_advection2d_x(fpr_ctx* ctx, const double* T, double hx, const double* vx, double* dTx, int nx, int ny);
+int fpr_compute_advection2d_y(fpr_ctx* ctx, const double* T, double hy, const double* vy, double* dTy, int nx, int ny);
+/* maximum(abs.(x)) -- part2.jl:77,82 */
+int fpr_absmax(fpr_ctx* ctx, const double* x, size_t n, double* out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPR_H */

@@ -1,0 +1,112 @@
+// diffusion_tune.hip -- standalone tuning harness for the fused 3D diffusion kernels (gfx950).
+// Runs every kernel variant / tiling of finalprojectrepo.jl_amd/csrc/diffusion3d_kernels.hpp on an
+// n^3 grid, checks each against the naive variant bit for bit on the device, and prints the
+// effective bandwidth (A_eff = 32 B per interior cell).  Usage: diffusion_tune [n] [iters] [filter]
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../finalprojectrepo.jl_amd/csrc/diffusion3d_launch.hpp"
+
+#define CK(x)                                                                              \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+            exit(1);                                                                       \
+        }                                                                                  \
+    } while (0)
+
+__global__ void k_fill_rand(double* a, size_t n, unsigned long long seed)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long z = (i + seed) * 0x9E3779B97F4A7C15ull;
+        z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+        a[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    }
+}
+
+__global__ void k_count_diff(const double* a, const double* b, size_t n, unsigned long long* cnt)
+{
+    unsigned long long c = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        c += (__double_as_longlong(a[i]) != __double_as_longlong(b[i]));
+    if (c) atomicAdd(cnt, c);
+}
+
+int main(int argc, char** argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 512;
+    const int iters = argc > 2 ? atoi(argv[2]) : 10;
+    const char* filter = argc > 3 ? argv[3] : "";
+    const size_t N = (size_t)n * n * n;
+    double *Ht, *Htau, *H2, *dH, *H2ref, *dHref, *parts;
+    unsigned long long* cnt;
+    CK(hipMalloc(&Ht, N * 8)); CK(hipMalloc(&Htau, N * 8)); CK(hipMalloc(&H2, N * 8)); CK(hipMalloc(&dH, N * 8));
+    CK(hipMalloc(&H2ref, N * 8)); CK(hipMalloc(&dHref, N * 8)); CK(hipMalloc(&parts, (1 << 22) * 8));
+    CK(hipMalloc(&cnt, 8));
+    k_fill_rand<<<2048, 256>>>(Ht, N, 1);
+    k_fill_rand<<<2048, 256>>>(Htau, N, 2);
+    CK(hipMemset(H2ref, 0, N * 8)); CK(hipMemset(dHref, 0, N * 8));
+    const double dx = 10.0 / n;
+    Diff3Args a;
+    a.Ht = Ht; a.Htau = Htau; a.nx = a.ny = a.nz = n;
+    for (int d = 0; d < 3; ++d) { a.lo[d] = 1; a.hi[d] = n - 1; }
+    a.dtau = dx * dx / 8.1; a._dt = 5.0; a._dx = a._dy = a._dz = 1 / dx; a.D_dx = a.D_dy = a.D_dz = 1 / dx;
+    a.scale = 0.2; a.partials = parts;
+    hipStream_t s; CK(hipStreamCreate(&s));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    int np;
+    // reference: naive variant
+    { Diff3Tuning t; t.variant = 1; a.Htau2 = H2ref; a.dHdtau = dHref; CK(diff3_launch(a, false, t, s, 1 << 22, &np)); CK(hipStreamSynchronize(s)); }
+    const double bytes = 32.0 * (double)(n - 2) * (n - 2) * (n - 2);
+    struct Cfg { int variant, ry, nt, xcd, zc, norm, vx; };
+    std::vector<Cfg> cfgs;
+    cfgs.push_back({1, 0, 0, 0, 0, 0, 0});
+    cfgs.push_back({1, 0, 0, 0, 0, 1, 0});
+    const int zcs[] = {0, 8, 16, 32, 64, 128, 1 << 20};
+    for (int variant : {2, 3})
+        for (int ry : {1, 2, 4})
+            for (int nt : {0, 1})
+                for (int xcd : {0, 1})
+                    for (int zc : zcs) cfgs.push_back({variant, ry, nt, xcd, zc, 0, 2});
+    for (int variant : {2, 3})
+        for (int ry : {2, 4}) {
+            cfgs.push_back({variant, ry, 0, 1, 0, 1, 2});   // with fused norm
+            cfgs.push_back({variant, ry, 0, 1, 0, 0, 1});   // 8-byte path
+        }
+    printf("# n=%d iters=%d  A_eff bytes/iter=%.4e\n", n, iters, bytes);
+    printf("%-8s %3s %3s %3s %3s %6s %5s %9s %9s %6s %s\n", "variant", "vx", "ry", "nt", "xcd", "zc", "norm", "ms", "GB/s", "%peak", "check");
+    for (const Cfg& c : cfgs) {
+        char name[64];
+        snprintf(name, sizeof name, "v%d-vx%d-ry%d-nt%d-xcd%d-zc%d-n%d", c.variant, c.vx, c.ry, c.nt, c.xcd, c.zc, c.norm);
+        if (filter[0] && !strstr(name, filter)) continue;
+        Diff3Tuning t; t.variant = c.variant; t.ry = c.ry; t.nt = c.nt; t.xcd_remap = c.xcd; t.zc = c.zc; t.vx = c.vx;
+        a.Htau2 = H2; a.dHdtau = dH;
+        CK(hipMemsetAsync(H2, 0, N * 8, s)); CK(hipMemsetAsync(dH, 0, N * 8, s));
+        hipError_t e = diff3_launch(a, c.norm != 0, t, s, 1 << 22, &np);
+        if (e != hipSuccess) { printf("%-40s launch failed: %s\n", name, hipGetErrorString(e)); continue; }
+        CK(hipMemsetAsync(cnt, 0, 8, s));
+        k_count_diff<<<2048, 256, 0, s>>>(H2, H2ref, N, cnt);
+        k_count_diff<<<2048, 256, 0, s>>>(dH, dHref, N, cnt);
+        unsigned long long bad = 0;
+        CK(hipMemcpyAsync(&bad, cnt, 8, hipMemcpyDeviceToHost, s));
+        CK(hipStreamSynchronize(s));
+        for (int i = 0; i < 2; ++i) CK(diff3_launch(a, c.norm != 0, t, s, 1 << 22, &np));
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) CK(diff3_launch(a, c.norm != 0, t, s, 1 << 22, &np));
+        CK(hipEventRecord(e1, s));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= iters;
+        const double gbs = bytes / (ms * 1e-3) / 1e9;
+        printf("%-8d %3d %3d %3d %3d %6d %5d %9.4f %9.1f %6.1f %s (blocks=%d)\n", c.variant, c.vx, c.ry, c.nt, c.xcd, c.zc, c.norm, ms, gbs,
+               100.0 * gbs / 8000.0, bad ? "MISMATCH" : "ok", np);
+        fflush(stdout);
+    }
+    return 0;
+}

@@ -16,16 +16,16 @@ struct Diff3Tuning {
 };
 
 #ifndef DIFF3_DEFAULT_VARIANT_ID
-#define DIFF3_DEFAULT_VARIANT_ID 2
+#define DIFF3_DEFAULT_VARIANT_ID 3
 #endif
 #ifndef DIFF3_DEFAULT_RY
 #define DIFF3_DEFAULT_RY 4
 #endif
 #ifndef DIFF3_DEFAULT_NT
-#define DIFF3_DEFAULT_NT 0
+#define DIFF3_DEFAULT_NT 1
 #endif
 #ifndef DIFF3_DEFAULT_XCD
-#define DIFF3_DEFAULT_XCD 1
+#define DIFF3_DEFAULT_XCD 0
 #endif
 #ifndef DIFF3_TARGET_BLOCKS
 #define DIFF3_TARGET_BLOCKS 1024

@@ -124,11 +124,12 @@ def test_cg_matches_oracle(fpr, oracle):
     # rhs with non-zero boundary (as the Neumann rows of a restricted residual): p_hat keeps b's boundary
     b2 = rnd((33, 17), 9)
     xr = farr(33, 17)
-    r_ref, it_ref = oracle.cg2d(xr, b2, 0.1, 0.1, 1.0, 1e-8, 60)
+    # (the system is inconsistent, CG does not converge and amplifies rounding: few iterations only)
+    r_ref, it_ref = oracle.cg2d(xr, b2, 0.1, 0.1, 1.0, 1e-8, 12)
     x = F.fzeros(33, 17)
-    r, it = mg.cg_(x, F.asdevice(b2), 0.1, 0.1, 1.0, 1e-8, 60, return_iters=True)
-    assert it == it_ref and abs(r - r_ref) <= 1e-7 * abs(r_ref)
-    assert np.abs(F.tonumpy(x) - xr).max() <= 1e-8 * np.abs(xr).max()
+    r, it = mg.cg_(x, F.asdevice(b2), 0.1, 0.1, 1.0, 1e-8, 12, return_iters=True)
+    assert it == it_ref == 12 and abs(r - r_ref) <= 1e-9 * abs(r_ref)
+    assert np.abs(F.tonumpy(x) - xr).max() <= 1e-9 * np.abs(xr).max()
 
 
 @pytest.mark.parametrize("solver", ["jacobi", "conjugate_gradient"])
@@ -137,6 +138,14 @@ def test_cg_matches_oracle(fpr, oracle):
 def test_single_vcycle_matches_oracle(fpr, oracle, shape, css, bc, c, solver):
     F, mg = fpr, fpr.multigrid
     u0, f = rnd(shape, 21), rnd(shape, 22)
+    if solver == "conjugate_gradient":
+        # cg! keeps b's boundary inside p_hat (krylov.jl:59-61): with a non-zero boundary on the coarse rhs
+        # (random f, or the Neumann rows of apply_BCs) the iteration is inconsistent and blows up to
+        # 1e10..NaN in the oracle as well -- chaotic, so parity is only meaningful on well-posed input.
+        if bc:
+            pytest.skip("CG coarse solve with Neumann rows on the coarse rhs diverges in the reference algorithm")
+        f[0, :] = f[-1, :] = 0.0
+        f[:, 0] = f[:, -1] = 0.0
     h = 1.0 / (shape[1] - 1)
     sv = getattr(mg, solver)
     u_ref = u0.copy(order="F")

@@ -240,8 +240,14 @@ class GlobalGrid:
                 part1.diffusion_3D_step_τ_norm(Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz,
                                                norm_scale, sq_dev)
             return
+        st = self.step_begin(Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq_dev)
+        self.step_end(st)
+
+    def step_begin(self, Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq_dev):
+        """Multi-rank step, first half: boundary slabs, pack, post the exchange (comm stream)."""
         import torch
         from . import ctx as _ctx
+        from . import part1
 
         c = _ctx()
         args = (Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
@@ -256,13 +262,24 @@ class GlobalGrid:
         c.comm.wait_stream(c.compute)
         with torch.cuda.stream(c.comm):
             works = ex.post(Hτ2)
+        return (args, inner, norm_scale, sq_dev, works)
+
+    def step_end(self, st):
+        """Second half: interior update (overlaps the transfers), join, unpack the received halos."""
+        import torch
+        from . import ctx as _ctx
+        from . import part1
+
+        c = _ctx()
+        args, inner, norm_scale, sq_dev, works = st
+        ex = self.exchanger()
         # 3. interior update overlaps the exchange
         part1.diffusion_3D_step_τ_box(*args, inner[0], inner[1], norm_scale, sq_dev, 0)
         # 4. join: the compute stream waits for the transfers, then unpacks the x/y halos
         with torch.cuda.stream(c.comm):
             ex.wait(works)
         c.compute.wait_stream(c.comm)
-        ex.unpack_all(Hτ2)
+        ex.unpack_all(args[2])
 
     def gather_(self, A_host):
         """gather!(A, A_global) onto rank 0 (part1_kernel_programming.jl:223): returns the list of all

@@ -1,0 +1,306 @@
+# FPRHip.jl -- Julia host shim for libfpr_hip.so (include/fpr.h).
+#
+# STATUS: written to the C ABI, NOT executed in this repository's CI: neither the build container nor
+# the MI355X boxes have a `julia` binary (DESIGN.md, "Host language").  tests/test_abi.py checks that
+# every symbol of include/fpr.h is bound below; the Python mirror (finalprojectrepo.jl_amd/) drives the
+# same ABI in every test and benchmark.
+#
+# Purpose: drop-in behind scripts-part1/part1.jl and scripts-part2/part2.jl of
+# ntselepidis/FinalProjectRepo.jl.  Replace the preamble
+#
+#     using CUDA; using ParallelStencil; using ParallelStencil.FiniteDifferences3D
+#     @init_parallel_stencil(CUDA, Float64, 3)
+#
+# by
+#
+#     include("FPRHip.jl"); using .FPRHip
+#     @init_parallel_stencil(AMDGPU, Float64, 3)
+#
+# and keep the rest of the scripts unchanged: `@parallel [blocks threads shmem=...] kernel(args...)`
+# drops the launch geometry and calls the HIP kernel of the same name through `ccall`.
+# AMDGPU.jl is used only for device-array allocation (ROCArray) and device selection.
+module FPRHip
+
+using AMDGPU
+
+export @init_parallel_stencil, @reset_parallel_stencil, @parallel, @zeros, @ones, @rand, @synchronize,
+       @hide_communication, Data,
+       diffusion_3D_step_τ, diffusion_3D_step_τ_shared_memory, diffusion_3D_step_τ!,
+       compute_flux!, compute_dHdτ!, update_H!, dist_norm_L2, init_local_gaussian_device!,
+       residual_2DPoisson!, residual_2DPoisson_shmem!, residual_2DPoisson_wrapper!, iteration_2DPoisson!,
+       restrict!, restrict_wrapper!, prolongate!, prolongate_with_atomic!, prolongate_wrapper!,
+       matrix_free_matvec_prod!, matrix_free_matvec_prod_shmem!, matrix_free_matvec_prod_wrapper!, cg!,
+       Vcycle_2DPoisson!, MGsolve_2DPoisson!, MGOpt, CoarseSolver_t, jacobi, conjugate_gradient,
+       ExecutionPolicy_t, serial, parallel, parallel_shmem, preallocate_buffers,
+       apply_boundary_conditions!, apply_boundary_conditions_dirichlet!, apply_boundary_conditions_neumann!,
+       compute_velocity!, compute_Ra_dTdx!, compute_diffusion2d!, compute_advection2d_x!, compute_advection2d_y!,
+       halo_pack!, halo_unpack!, fpr_version
+
+const libfpr = get(ENV, "FPR_HIP_LIB", joinpath(@__DIR__, "..", "finalprojectrepo.jl_amd", "lib", "libfpr_hip.so"))
+
+module Data
+    using AMDGPU
+    const Number = Float64
+    const Array = ROCArray{Float64}
+end
+
+const CTX = Ref{Ptr{Cvoid}}(C_NULL)
+
+struct FPRError <: Exception
+    code::Cint
+    msg::String
+end
+
+function check(rc::Cint)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:fpr_last_error, libfpr), Cstring, (Ptr{Cvoid},), CTX[]))
+    rc == -3 && error("ERROR:not a power of 2")            # multigrid.jl:95-97
+    rc == -4 && throw(AssertionError(msg))                 # multigrid.jl:45-46
+    throw(FPRError(rc, msg))
+end
+
+ctx() = (CTX[] == C_NULL && init_context(); CTX[])
+
+function init_context(device::Integer = AMDGPU.device_id(AMDGPU.device()) - 1)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    # NULL streams: the library creates its own compute / comm streams on `device`
+    rc = ccall((:fpr_ctx_create, libfpr), Cint, (Ptr{Ptr{Cvoid}}, Cint, Ptr{Cvoid}, Ptr{Cvoid}), h, device, C_NULL, C_NULL)
+    rc == 0 || throw(FPRError(rc, "fpr_ctx_create failed (no HIP device? there is no CPU fallback)"))
+    CTX[] = h[]
+    return nothing
+end
+
+fpr_version() = unsafe_string(ccall((:fpr_version, libfpr), Cstring, ()))
+set_option(key::String, v::Integer) = check(ccall((:fpr_set_option, libfpr), Cint, (Ptr{Cvoid}, Cstring, Clong), ctx(), key, v))
+get_option(key::String) = ccall((:fpr_get_option, libfpr), Clong, (Ptr{Cvoid}, Cstring), ctx(), key)
+kernel_timer(on::Bool) = check(ccall((:fpr_kernel_timer, libfpr), Cint, (Ptr{Cvoid}, Cint), ctx(), on))
+function kernel_timer_read()
+    ms = Ref{Cdouble}(0); n = Ref{Clong}(0)
+    check(ccall((:fpr_kernel_timer_read, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Clong}), ctx(), ms, n))
+    return ms[], n[]
+end
+stream_wait(waiter::Integer, signaller::Integer) = check(ccall((:fpr_stream_wait, libfpr), Cint, (Ptr{Cvoid}, Cint, Cint), ctx(), waiter, signaller))
+last_coarse_iters() = ccall((:fpr_last_coarse_iters, libfpr), Clong, (Ptr{Cvoid},), ctx())
+
+# ---- ParallelStencil surface ---------------------------------------------------------------------
+macro init_parallel_stencil(args...)
+    :(FPRHip.init_context())
+end
+macro reset_parallel_stencil()
+    quote
+        if FPRHip.CTX[] != C_NULL
+            ccall((:fpr_ctx_destroy, FPRHip.libfpr), Cint, (Ptr{Cvoid},), FPRHip.CTX[])
+            FPRHip.CTX[] = C_NULL
+        end
+    end
+end
+"`@parallel [blocks threads shmem=n] f(args...)` -> `f(args...)` (launch geometry is the library's)."
+macro parallel(args...)
+    esc(args[end])
+end
+"`@hide_communication (bx,by,bz) begin ... end`: the overlap is inside the multi-GPU step; run the body."
+macro hide_communication(args...)
+    esc(args[end])
+end
+macro zeros(dims...)
+    esc(:(AMDGPU.zeros(Float64, $(dims...))))
+end
+macro ones(dims...)
+    esc(:(AMDGPU.ones(Float64, $(dims...))))
+end
+macro rand(dims...)
+    esc(:(AMDGPU.rand(Float64, $(dims...))))
+end
+macro synchronize()
+    :(FPRHip.check(ccall((:fpr_synchronize, FPRHip.libfpr), Cint, (Ptr{Cvoid},), FPRHip.ctx())))
+end
+
+const DA = ROCArray{Float64}
+p(A::DA) = Ptr{Cdouble}(UInt(pointer(A)))
+
+# ---- Part 1 (scripts-part1/part1_kernel_programming.jl, part1_array_programming.jl, part1_utils.jl) ----
+function diffusion_3D_step_τ(Ht::DA, Hτ::DA, Hτ2::DA, dHdτ::DA, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
+    nx, ny, nz = size(Ht)
+    check(ccall((:fpr_diffusion3d_step, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint,
+                 Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble),
+                ctx(), p(Ht), p(Hτ), p(Hτ2), p(dHdτ), nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz))
+    return nothing
+end
+const diffusion_3D_step_τ_shared_memory = diffusion_3D_step_τ   # part1_kernel_programming.jl:75-97
+
+"Fused update + local sum((dHdτ*scale)^2) into the device scalar `sumsq` (1-element ROCArray)."
+function diffusion_3D_step_τ_norm(Ht::DA, Hτ::DA, Hτ2::DA, dHdτ::DA, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale, sumsq::DA)
+    nx, ny, nz = size(Ht)
+    check(ccall((:fpr_diffusion3d_step_norm, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint,
+                 Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cdouble}),
+                ctx(), p(Ht), p(Hτ), p(Hτ2), p(dHdτ), nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale, p(sumsq)))
+end
+
+"Sub-box form for boundary/interior splitting (0-based lo/hi); role of @hide_communication."
+function diffusion_3D_step_τ_box(Ht::DA, Hτ::DA, Hτ2::DA, dHdτ::DA, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz,
+                                 lo::NTuple{3,Int}, hi::NTuple{3,Int}; scale = 0.0, sumsq::Union{DA,Nothing} = nothing, stream_sel = 0)
+    nx, ny, nz = size(Ht)
+    lo3 = Cint[lo...]; hi3 = Cint[hi...]
+    check(ccall((:fpr_diffusion3d_step_box, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint,
+                 Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cint}, Ptr{Cint}, Cdouble, Ptr{Cdouble}, Cint),
+                ctx(), p(Ht), p(Hτ), p(Hτ2), p(dHdτ), nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo3, hi3, scale,
+                sumsq === nothing ? Ptr{Cdouble}(C_NULL) : p(sumsq), stream_sel))
+end
+
+function compute_flux!(qx::DA, qy::DA, qz::DA, Hτ::DA, D, dx, dy, dz)        # part1_array_programming.jl:10-12
+    nx, ny, nz = size(Hτ)
+    check(ccall((:fpr_diffusion3d_flux, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint, Cdouble, Cdouble, Cdouble, Cdouble),
+                ctx(), p(qx), p(qy), p(qz), p(Hτ), nx, ny, nz, D, dx, dy, dz))
+end
+function compute_dHdτ!(dHdτ::DA, Hτ::DA, Ht::DA, qx::DA, qy::DA, qz::DA, dt, dx, dy, dz)   # :14-15
+    nx, ny, nz = size(Hτ)
+    check(ccall((:fpr_diffusion3d_dHdtau, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint,
+                 Cdouble, Cdouble, Cdouble, Cdouble),
+                ctx(), p(dHdτ), p(Hτ), p(Ht), p(qx), p(qy), p(qz), nx, ny, nz, dt, dx, dy, dz))
+end
+function update_H!(Hτ::DA, dHdτ::DA, dτ)                                          # :16
+    nx, ny, nz = size(Hτ)
+    check(ccall((:fpr_diffusion3d_update, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint, Cdouble),
+                ctx(), p(Hτ), p(dHdτ), nx, ny, nz, dτ))
+end
+"part1_array_programming.jl:9-18 with clean (barrier-separated) semantics."
+function diffusion_3D_step_τ!(Ht, Hτ, dHdτ, dt, dτ, qx, qy, qz, dx, dy, dz, D)
+    compute_flux!(qx, qy, qz, Hτ, D, dx, dy, dz)
+    compute_dHdτ!(dHdτ, Hτ, Ht, qx, qy, qz, dt, dx, dy, dz)
+    update_H!(Hτ, dHdτ, dτ)
+end
+
+function sumsq_scaled(x::DA, scale = 1.0)
+    out = Ref{Cdouble}(0)
+    check(ccall((:fpr_sumsq_scaled, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Csize_t, Cdouble, Ptr{Cdouble}), ctx(), p(x), length(x), scale, out))
+    return out[]
+end
+sumsq_scaled_dev!(out::DA, x::DA, scale = 1.0) =
+    check(ccall((:fpr_sumsq_scaled_dev, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Csize_t, Cdouble, Ptr{Cdouble}), ctx(), p(x), length(x), scale, p(out)))
+function dot_dev(x::DA, y::DA)
+    out = Ref{Cdouble}(0)
+    check(ccall((:fpr_dot, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Csize_t, Ptr{Cdouble}), ctx(), p(x), p(y), length(x), out))
+    return out[]
+end
+function absmax(x::DA)
+    out = Ref{Cdouble}(0)
+    check(ccall((:fpr_absmax, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Csize_t, Ptr{Cdouble}), ctx(), p(x), length(x), out))
+    return out[]
+end
+"part1_utils.jl:36-40 with the scale of its call site folded in: dist_norm_L2(residual_H*dt, comm) == dist_norm_L2(residual_H, comm; scale=dt)."
+function dist_norm_L2(Rh::DA, comm_cart; scale = 1.0)
+    sq = [sumsq_scaled(Rh, scale)]
+    comm_cart === nothing || MPI.Allreduce!(sq, +, comm_cart)     # `import MPI` stays in the host script
+    return sqrt(sq[1])
+end
+copy_device!(dst::DA, src::DA) = check(ccall((:fpr_copy, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Csize_t), ctx(), p(dst), p(src), length(dst)))
+fill_device!(dst::DA, v) = check(ccall((:fpr_fill, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Csize_t), ctx(), p(dst), v, length(dst)))
+function init_local_gaussian_device!(H::DA, center, dx, dy, dz, coords)
+    nx, ny, nz = size(H)
+    check(ccall((:fpr_init_gaussian3d, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint),
+                ctx(), p(H), nx, ny, nz, dx, dy, dz, center[1], center[2], center[3], coords[1], coords[2], coords[3]))
+    return H
+end
+"update_halo! building blocks: face = 2*dim + side (0-based); buffers are ROCArray{Float64} planes."
+halo_pack!(buf::DA, A::DA, face; stream_sel = 0) = (n = size(A);
+    check(ccall((:fpr_halo_pack3d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint, Cint, Ptr{Cdouble}, Cint), ctx(), p(A), n[1], n[2], n[3], face, p(buf), stream_sel)))
+halo_unpack!(A::DA, buf::DA, face; stream_sel = 0) = (n = size(A);
+    check(ccall((:fpr_halo_unpack3d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint, Cint, Ptr{Cdouble}, Cint), ctx(), p(A), n[1], n[2], n[3], face, p(buf), stream_sel)))
+
+# ---- Part 2 (scripts-part2/multigrid.jl, krylov.jl, part2_utils.jl) -----------------------------------
+@enum ExecutionPolicy_t serial parallel parallel_shmem          # part2_utils.jl:4-8
+@enum CoarseSolver_t jacobi conjugate_gradient                  # multigrid.jl:10-13
+mutable struct MGOpt                                            # multigrid.jl:16-22
+    coarse_solve_size::Int
+    coarse_solver::CoarseSolver_t
+    execution_policy::ExecutionPolicy_t
+    MGOpt() = new(5, jacobi, parallel_shmem)
+end
+"multigrid.jl:25-38: the level arena is owned by the library context; a token keeps the call signature."
+preallocate_buffers(nx, ny) = Dict{Symbol,Any}(:nx => nx, :ny => ny)
+policy_ok(pol) = (pol in (parallel, parallel_shmem)) || error()    # multigrid.jl:233-236
+
+function residual_2DPoisson!(u::DA, f::DA, h::Float64, c::Float64, res::DA)
+    nx, ny = size(u)
+    check(ccall((:fpr_residual2d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{Cdouble}, Cint, Cint),
+                ctx(), p(u), p(f), h, c, p(res), nx, ny))
+end
+const residual_2DPoisson_shmem! = residual_2DPoisson!
+residual_2DPoisson_wrapper!(u_f, rhs, h, c, res_f, execution_policy) = (policy_ok(execution_policy); residual_2DPoisson!(u_f, rhs, h, c, res_f))
+
+function iteration_2DPoisson!(u::DA, f::DA, h, c, res::DA, execution_policy; alpha = 4.0 / 5.0)
+    policy_ok(execution_policy)
+    nx, ny = size(u); rms = Ref{Cdouble}(0)
+    check(ccall((:fpr_jacobi2d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{Cdouble}, Cint, Cint, Cdouble, Ptr{Cdouble}),
+                ctx(), p(u), p(f), h, c, p(res), nx, ny, alpha, rms))
+    return rms[]
+end
+
+function restrict_wrapper!(fine::DA, coarse::DA, apply_BCs, execution_policy)
+    nx, ny = size(fine)
+    check(ccall((:fpr_restrict2d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint), ctx(), p(fine), p(coarse), nx, ny, apply_BCs))
+end
+restrict!(fine, coarse) = restrict_wrapper!(fine, coarse, false, parallel)   # note: also zeroes the coarse boundary
+function prolongate_wrapper!(coarse::DA, fine::DA, apply_BCs, execution_policy)
+    nx, ny = size(fine)
+    check(ccall((:fpr_prolongate2d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint), ctx(), p(coarse), p(fine), nx, ny, apply_BCs))
+end
+prolongate!(coarse, fine) = prolongate_wrapper!(coarse, fine, false, parallel)
+const prolongate_with_atomic! = prolongate!
+correct!(u_f::DA, corr_f::DA) = check(ccall((:fpr_axmy2d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Csize_t), ctx(), p(u_f), p(corr_f), length(u_f)))
+
+function matrix_free_matvec_prod!(T::DA, hx, hy, c, dT2::DA)
+    nx, ny = size(T)
+    check(ccall((:fpr_laplace_apply2d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Cdouble, Cdouble, Ptr{Cdouble}, Cint, Cint), ctx(), p(T), hx, hy, c, p(dT2), nx, ny))
+end
+const matrix_free_matvec_prod_shmem! = matrix_free_matvec_prod!
+function matrix_free_matvec_prod_wrapper!(pp, hx, hy, c, p_hat; execution_policy = parallel_shmem)
+    policy_ok(execution_policy); matrix_free_matvec_prod!(pp, hx, hy, c, p_hat); @synchronize()
+end
+
+function cg!(x_in::DA, b::DA, hx, hy, c, tol, Nmax; execution_policy = parallel_shmem, verbose = false)
+    nx, ny = size(b); rms = Ref{Cdouble}(0); it = Ref{Cint}(0)
+    check(ccall((:fpr_cg2d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cint}),
+                ctx(), p(x_in), p(b), hx, hy, c, tol, Nmax, nx, ny, rms, it))
+    return rms[]
+end
+
+apply_boundary_conditions!(T::DA) = check(ccall((:fpr_bc2d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint), ctx(), p(T), size(T, 1), size(T, 2)))
+apply_boundary_conditions_dirichlet!(T::DA) = check(ccall((:fpr_bc_dirichlet2d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint), ctx(), p(T), size(T, 1), size(T, 2)))
+apply_boundary_conditions_neumann!(T::DA) = check(ccall((:fpr_bc_neumann2d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint), ctx(), p(T), size(T, 1), size(T, 2)))
+
+function Vcycle_2DPoisson!(u_f::DA, rhs::DA, h::Float64, c::Float64, tol::Float64, coarse_solve_size::Int, coarse_solver::CoarseSolver_t,
+                           execution_policy::ExecutionPolicy_t, apply_BCs::Bool; prealloc_dict = nothing)
+    policy_ok(execution_policy)
+    nx, ny = size(u_f); rms = Ref{Cdouble}(0)
+    check(ccall((:fpr_vcycle2d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint, Cint, Cint, Ptr{Cdouble}),
+                ctx(), p(u_f), p(rhs), h, c, tol, coarse_solve_size, Int(coarse_solver), apply_BCs, nx, ny, rms))
+    return rms[]
+end
+
+function MGsolve_2DPoisson!(u::DA, f::DA, h::Float64, c::Float64, tol::Float64, niters::Int, apply_BCs::Bool; opt = MGOpt(), verbose = false, prealloc_dict = nothing)
+    policy_ok(opt.execution_policy)
+    nx, ny = size(u)
+    rms = Ref{Cdouble}(0); ncyc = Ref{Cint}(0); frms = Ref{Cdouble}(0); conv = Ref{Cint}(0); hist = zeros(Cdouble, max(niters, 1))
+    check(ccall((:fpr_mgsolve2d, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}),
+                ctx(), p(u), p(f), h, c, tol, niters, apply_BCs, opt.coarse_solve_size, Int(opt.coarse_solver), nx, ny, rms, ncyc, hist, frms, conv))
+    verbose && foreach(i -> println("$(i) $(hist[i] / frms[])"), 1:ncyc[])
+    conv[] == 0 && @warn "V-cycle multigrid failed to converge within" niters "iterations."   # multigrid.jl:78-80
+    return rms[]
+end
+
+# ---- NEXT 8f-1 (scripts-part2/part2.jl:90-137) ---------------------------------------------------------
+compute_velocity!(S::DA, hx, hy, vx::DA, vy::DA) = check(ccall((:fpr_compute_velocity2d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint), ctx(), p(S), hx, hy, p(vx), p(vy), size(S, 1), size(S, 2)))
+compute_Ra_dTdx!(Ra, hx, T::DA, out::DA) = check(ccall((:fpr_compute_Ra_dTdx2d, libfpr), Cint, (Ptr{Cvoid}, Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint), ctx(), Ra, hx, p(T), p(out), size(T, 1), size(T, 2)))
+compute_diffusion2d!(T::DA, hx, hy, k, dT2::DA) = check(ccall((:fpr_compute_diffusion2d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Cdouble, Cdouble, Ptr{Cdouble}, Cint, Cint), ctx(), p(T), hx, hy, k, p(dT2), size(T, 1), size(T, 2)))
+compute_advection2d_x!(T::DA, hx, vx::DA, dTx::DA) = check(ccall((:fpr_compute_advection2d_x, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint), ctx(), p(T), hx, p(vx), p(dTx), size(T, 1), size(T, 2)))
+compute_advection2d_y!(T::DA, hy, vy::DA, dTy::DA) = check(ccall((:fpr_compute_advection2d_y, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint), ctx(), p(T), hy, p(vy), p(dTy), size(T, 1), size(T, 2)))
+
+end # module

@@ -1,0 +1,178 @@
+"""CPU tests of the multi-rank path: Cartesian topology, halo-plane conventions and the
+torch.distributed exchange, exercised with the `gloo` backend on world sizes 2, 4 and 8.
+
+Each rank advances its shard with the ORACLE's fused step (numpy) and refreshes halos through the
+product's HaloExchanger (with CPU pack/unpack supplied by this test: the HIP pack kernels need a GPU
+and are checked against the same plane convention in tests/test_gpu_halo.py).  Acceptance: the N-shard
+run equals the single-domain oracle run on the equivalent global grid bit for bit; the all-reduced
+norm agrees to 1e-13."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import fpr_amd
+
+grid = fpr_amd.pkg.grid
+
+
+def test_dims_create_matches_reference_table():
+    # part1_scaling_experiments.jl:35-41
+    assert grid.dims_create(1) == (1, 1, 1)
+    assert grid.dims_create(2) == (2, 1, 1)
+    assert grid.dims_create(4) == (2, 2, 1)
+    assert grid.dims_create(8) == (2, 2, 2)
+    assert grid.dims_create(6) == (3, 2, 1)
+    assert np.prod(grid.dims_create(12)) == 12
+
+
+def test_topology_and_global_sizes():
+    g = grid.GlobalGrid(10, 12, 14, dims=(1, 1, 1), use_dist=False)
+    assert (g.nx_g(), g.ny_g(), g.nz_g()) == (10, 12, 14) and g.neighbors == {} and g.coords == (0, 0, 0)
+    assert g.x_g(1, 0.5) == 0.0 and g.x_g(3, 0.5) == 1.0
+    boxes, inner = g.boundary_boxes()
+    assert boxes == [] and inner == ((1, 1, 1), (9, 11, 13))
+
+    class Fake(grid.GlobalGrid):
+        def __init__(self, rank, dims, n):
+            self.nx, self.ny, self.nz = n
+            self.dist, self.group, self.nprocs, self.me, self.dims = None, None, int(np.prod(dims)), rank, dims
+            self.coords = self.coords_of(rank)
+            self.neighbors = {}
+            for d in range(3):
+                for side in (0, 1):
+                    c = list(self.coords)
+                    c[d] += 1 if side else -1
+                    if 0 <= c[d] < dims[d]:
+                        self.neighbors[2 * d + side] = tuple(c)
+
+    dims = (2, 2, 2)
+    seen = set()
+    for r in range(8):
+        f = Fake(r, dims, (10, 10, 10))
+        assert f.rank_of(f.coords) == r
+        seen.add(f.coords)
+        assert len(f.neighbors) == 3
+        for face, nb in f.neighbors.items():
+            # neighbour relation is symmetric through the opposite face
+            o = Fake(f.rank_of(nb), dims, (10, 10, 10))
+            assert o.neighbors[face ^ 1] == f.coords
+        boxes, inner = f.boundary_boxes()
+        cells = sum((h[0] - l[0]) * (h[1] - l[1]) * (h[2] - l[2]) for l, h in boxes + [inner])
+        assert cells == 8 ** 3 and len(boxes) == 3
+        assert f.nx_g() == 18
+    assert len(seen) == 8
+    f = Fake(5, (1, 1, 8), (6, 6, 6))
+    assert f.coords == (0, 0, 5) and sorted(f.neighbors) == [4, 5] and f.nz_g() == 34 and f.global_offset() == (0, 0, 20)
+
+
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cpu_pack(A, face, buf):
+    d, side = face >> 1, face & 1
+    n = A.shape[d]
+    sl = A.select(d, n - 2 if side else 1)
+    buf.copy_(sl.permute(1, 0).reshape(-1))  # column-major flatten of the plane
+
+
+def _cpu_unpack(A, face, buf):
+    d, side = face >> 1, face & 1
+    n = A.shape[d]
+    sl = A.select(d, n - 1 if side else 0)
+    sl.copy_(buf.reshape(sl.shape[1], sl.shape[0]).permute(1, 0))
+
+
+def _worker(rank, world, port, dims, n, iters, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.oracle import Oracle, farr
+
+        orc = Oracle()
+        nx, ny, nz = n
+        gg = grid.GlobalGrid(nx, ny, nz, dims=dims)
+        assert gg.nprocs == world and gg.me == rank
+        lx, ly, lz = (d * 10.0 for d in dims)  # scale_physical_size=true
+        dx, dy, dz = lx / gg.nx_g(), ly / gg.ny_g(), lz / gg.nz_g()
+        D, dt = 1.0, 0.2
+        dtau = min(dx, dy, dz) ** 2 / D / 8.1
+        coef = (dtau, 1 / dt, 1 / dx, 1 / dy, 1 / dz, D / dx, D / dy, D / dz)
+        Ht = orc.init_gaussian(n, dx, dy, dz, (lx / 2, ly / 2, lz / 2), gg.coords)
+        A, B, R = Ht.copy(order="F"), farr(*n), farr(*n)
+        ex = grid.HaloExchanger(n, gg.neighbors, gg.rank_of, _cpu_pack, _cpu_unpack,
+                                lambda m: torch.zeros(m, dtype=torch.float64), dist=dist, group=None)
+        norms = []
+        for it in range(iters):
+            orc.diffusion3d_step(Ht, A, B, R, *coef)
+            tB = torch.from_numpy(B)
+            assert tB.stride() == (1, nx, nx * ny)
+            ex.update_halo_(tB)  # exchange the NEW buffer (deviation from the reference)
+            A, B = B, A
+            t = torch.tensor([orc.sumsq_scaled(R, dt)], dtype=torch.float64)
+            norms.append(gg.allreduce_sum(t))
+        np.save(os.path.join(outdir, "A_%d.npy" % rank), A)
+        np.save(os.path.join(outdir, "R_%d.npy" % rank), R)
+        if rank == 0:
+            np.save(os.path.join(outdir, "norms.npy"), np.array(norms))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dims,n", [((2, 1, 1), (10, 9, 8)), ((1, 1, 2), (12, 7, 9)), ((1, 2, 1), (6, 11, 7)),
+                                     ((2, 2, 1), (9, 8, 7)), ((2, 2, 2), (8, 8, 8)), ((1, 1, 4), (7, 6, 6))],
+                         ids=lambda v: "x".join(map(str, v)))
+def test_nshard_equals_single_domain(tmp_path, oracle, dims, n):
+    world = int(np.prod(dims))
+    iters = 7
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, dims, n, iters, str(tmp_path)), nprocs=world, join=True)
+    # single-domain oracle on the equivalent global grid
+    from oracle.oracle import farr
+
+    ng = tuple(d * (m - 2) + 2 for d, m in zip(dims, n))
+    lx, ly, lz = (d * 10.0 for d in dims)
+    dx, dy, dz = lx / ng[0], ly / ng[1], lz / ng[2]
+    D, dt = 1.0, 0.2
+    dtau = min(dx, dy, dz) ** 2 / D / 8.1
+    coef = (dtau, 1 / dt, 1 / dx, 1 / dy, 1 / dz, D / dx, D / dy, D / dz)
+    Ht = oracle.init_gaussian(ng, dx, dy, dz, (lx / 2, ly / 2, lz / 2))
+    A, B, R = Ht.copy(order="F"), farr(*ng), farr(*ng)
+    norms = []
+    for it in range(iters):
+        oracle.diffusion3d_step(Ht, A, B, R, *coef)
+        A, B = B, A
+        norms.append(oracle.sumsq_scaled(R, dt))
+    got_norms = np.load(tmp_path / "norms.npy")
+    assert np.allclose(got_norms, norms, rtol=1e-13, atol=0)
+    for r in range(world):
+        c = (r // (dims[1] * dims[2]), (r // dims[2]) % dims[1], r % dims[2])
+        off = tuple(ci * (m - 2) for ci, m in zip(c, n))
+        loc = np.load(tmp_path / ("A_%d.npy" % r))
+        glob = A[off[0]:off[0] + n[0], off[1]:off[1] + n[1], off[2]:off[2] + n[2]]
+        # interior cells and every exchanged halo plane (face interiors) agree bit for bit
+        assert np.array_equal(loc[1:-1, 1:-1, 1:-1], glob[1:-1, 1:-1, 1:-1]), "rank %d interior" % r
+        for d in range(3):
+            for side in (0, 1):
+                cc = list(c)
+                cc[d] += 1 if side else -1
+                if 0 <= cc[d] < dims[d]:
+                    idx = [slice(1, -1)] * 3
+                    idx[d] = -1 if side else 0
+                    assert np.array_equal(loc[tuple(idx)], glob[tuple(idx)]), "rank %d halo face %d" % (r, 2 * d + side)
+        locR = np.load(tmp_path / ("R_%d.npy" % r))
+        globR = R[off[0]:off[0] + n[0], off[1]:off[1] + n[1], off[2]:off[2] + n[2]]
+        assert np.array_equal(locR[1:-1, 1:-1, 1:-1], globR[1:-1, 1:-1, 1:-1])

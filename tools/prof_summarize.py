@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output directories into small text files (the raw traces are too big to keep).
+
+    prof_summarize.py stats  <dir> <out.txt>        kernel_stats.csv -> per-kernel calls / avg / total
+    prof_summarize.py pmc    <dir> <out.txt>        counter_collection.csv -> per-kernel mean counter value
+"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def find(d, pat):
+    r = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return r[0] if r else None
+
+
+def stats(d, out):
+    f = find(d, "*kernel_stats.csv")
+    rows = list(csv.DictReader(open(f)))
+    with open(out, "w") as o:
+        o.write("# rocprofv3 --kernel-trace --stats summary (%s)\n" % os.path.basename(f))
+        o.write("%-70s %8s %14s %14s %8s\n" % ("kernel", "calls", "avg_ns", "total_ns", "pct"))
+        for r in rows:
+            o.write("%-70s %8s %14s %14s %8s\n" % (r["Name"][:70], r["Calls"], r.get("AverageNs", r.get("AverageDurationNs", "?")),
+                                                  r.get("TotalDurationNs", r.get("Total(ns)", "?")), r.get("Percentage", "?")))
+
+
+def pmc(d, out):
+    f = find(d, "*counter_collection.csv")
+    acc = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    with open(out, "w") as o:
+        o.write("# rocprofv3 --pmc summary (%s): mean counter value per dispatch\n" % os.path.basename(f))
+        o.write("%-70s %-14s %8s %18s %18s %18s\n" % ("kernel", "counter", "n", "mean", "min", "max"))
+        for k, cs in sorted(acc.items()):
+            for c, v in sorted(cs.items()):
+                o.write("%-70s %-14s %8d %18.1f %18.1f %18.1f\n" % (k[:70], c, len(v), sum(v) / len(v), min(v), max(v)))
+
+
+if __name__ == "__main__":
+    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])

@@ -23,8 +23,8 @@ extern "C" int fpr_ctx_create(fpr_ctx** out, int device, void* compute_stream, v
         }
         if (hipEventCreateWithFlags(&ctx->ev[s], hipEventDisableTiming) != hipSuccess) { delete ctx; return FPR_ERR_HIP; }
     }
-    bool ok = hipMalloc(&ctx->partials, FPR_MAX_PARTIALS * sizeof(double)) == hipSuccess &&
-              hipMalloc(&ctx->partials2, FPR_MAX_PARTIALS * sizeof(double)) == hipSuccess &&
+    bool ok = hipMalloc(&ctx->partials, (FPR_MAX_PARTIALS + 256) * sizeof(double)) == hipSuccess &&
+              hipMalloc(&ctx->partials2, (FPR_MAX_PARTIALS + 256) * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->scalars, 64 * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->state, sizeof(FprSolveState)) == hipSuccess &&
               hipHostMalloc(&ctx->state_h, sizeof(FprSolveState)) == hipSuccess &&
@@ -194,8 +194,32 @@ __global__ __launch_bounds__(256) void k_finish(const double* __restrict__ parti
     }
 }
 
+// first stage for long partial lists: block b sums the slice [b*per, (b+1)*per) in a fixed order
+__global__ __launch_bounds__(256) void k_fold_partials(const double* __restrict__ partials, int n, int per,
+                                                        double* __restrict__ out)
+{
+    __shared__ double red[16];
+    const int lo = blockIdx.x * per;
+    int hi = lo + per;
+    if (hi > n) hi = n;
+    double s = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) s += partials[i];
+    s = fpr_block_sum<256>(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
 int fprx_finish_sum(fpr_ctx* ctx, const double* partials, int nparts, double* out_dev, bool accumulate, int stream_sel)
 {
+    if (nparts > 8192) {
+        // two-stage finish (deterministic): 128 slices folded in parallel, then the usual single block.
+        // The folded values live behind the partial list itself (the buffers hold FPR_MAX_PARTIALS + 256).
+        const int nb = 128;
+        const int per = (nparts + nb - 1) / nb;
+        double* fold = (stream_sel ? ctx->partials2 : ctx->partials) + FPR_MAX_PARTIALS;
+        k_fold_partials<<<nb, 256, 0, ctx->stream[stream_sel]>>>(partials, nparts, per, fold);
+        partials = fold;
+        nparts = nb;
+    }
     if (accumulate) k_finish<1><<<1, 256, 0, ctx->stream[stream_sel]>>>(partials, nparts, out_dev);
     else k_finish<0><<<1, 256, 0, ctx->stream[stream_sel]>>>(partials, nparts, out_dev);
     FPR_CHECK_LAUNCH(ctx);

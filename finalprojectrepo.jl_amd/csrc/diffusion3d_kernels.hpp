@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_diff3_march(Diff3Args a)
     // ---- block -> tile mapping (optionally XCD-contiguous) ----
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
-    if (a.xcd_remap) {
+    if (a.xcd_remap == 1) {
         const int q = nblk >> 3, rem = nblk & 7;
         const int xcd = bid & 7, slot = bid >> 3;
         bid = xcd * q + (xcd < rem ? xcd : rem) + slot;
@@ -153,9 +153,24 @@ __global__ __launch_bounds__(256) void k_diff3_march(Diff3Args a)
     if constexpr (LDSY) {
         // block = 4 waves stacked in y on the same x-tile / z-chunk
         const int nby = (a.nty + 3) >> 2;
-        tx = bid % a.ntx;
-        const int by = (bid / a.ntx) % nby;
-        tz = bid / (a.ntx * nby);
+        int by;
+        if (a.xcd_remap >= 2) {
+            // y-band ownership: groups of G = 2^(xcd_remap-2) consecutive block-rows are dealt round-robin
+            // to the 8 XCDs, so all x-tiles (and G block-rows) of a band share one L2 (host checks divisibility)
+            const int G = 1 << (a.xcd_remap - 2);
+            const int ng8 = (nby / G) >> 3;  // groups per XCD
+            const int xcd = blockIdx.x & 7;
+            int r = blockIdx.x >> 3;
+            tx = r % a.ntx; r /= a.ntx;
+            const int byl = r % G; r /= G;
+            const int gl = r % ng8;
+            tz = r / ng8;
+            by = (gl * 8 + xcd) * G + byl;
+        } else {
+            tx = bid % a.ntx;
+            by = (bid / a.ntx) % nby;
+            tz = bid / (a.ntx * nby);
+        }
         ty = by * 4 + w;
         wave_active = true;  // all waves run the loop (barriers); rows are masked
     } else {

@@ -96,7 +96,12 @@ static inline hipError_t diff3_launch(Diff3Args a, bool norm, const Diff3Tuning&
     if (ldsy) nblk = (long)a.ntx * ((a.nty + 3) / 4) * a.ntz;
     else nblk = ((long)a.ntx * a.nty * a.ntz + 3) / 4;
     if (nblk > 0x7fffffffL || (norm && nblk > max_partials)) return hipErrorInvalidValue;
-    a.xcd_remap = t.xcd_remap < 0 ? (DIFF3_DEFAULT_XCD && nblk >= 64) : t.xcd_remap;
+    a.xcd_remap = t.xcd_remap < 0 ? (nblk >= 64 ? DIFF3_DEFAULT_XCD : 0) : t.xcd_remap;
+    if (a.xcd_remap >= 2) {  // y-band ownership needs LDSY blocks and (block rows / G) divisible by 8
+        const int G = 1 << (a.xcd_remap - 2);
+        const int nby = (a.nty + 3) / 4;
+        if (!ldsy || a.xcd_remap > 6 || nby % (8 * G) != 0) a.xcd_remap = 0;
+    }
     const bool nt = t.nt < 0 ? DIFF3_DEFAULT_NT : (t.nt != 0);
     if (vx == 2) {
         if (ry == 4) diff3_march_go2<2, 4>(a, norm, ldsy, nt, (int)nblk, stream);

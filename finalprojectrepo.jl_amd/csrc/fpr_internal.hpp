@@ -19,7 +19,7 @@ constexpr int FPR_MAX_PARTIALS = 1 << 19;  // per-slot block partials (doubles)
 struct FprSolveState {
     int done;        // 1 once the stopping criterion was met
     int iters;       // iterations executed (including the one that met the criterion)
-    int nparts;      // number of valid block partials of the last reduction
+    int acc_iters;   // coarse-solver iterations accumulated over one V-cycle (k_mg_small adds to it)
     int pad;
     double last_rms; // r_rms of the last executed iteration
     double thresh;   // tol * rms(rhs)   (Jacobi)  or  tol * ||b||  (CG)
@@ -49,6 +49,8 @@ struct fpr_ctx {
     size_t cg_cap = 0;                 // capacity of cg_buf in doubles
     std::map<std::string, long> options;
     long last_coarse_iters = 0;
+    bool used_small = false;           // last V-cycle ran k_mg_small
+    bool top_is_coarsest = false;      // ... and the whole problem was the coarsest level
     bool ktimer_on = false;            // fpr_kernel_timer
     std::vector<hipEvent_t> ktimer_ev; // pairs (start, stop)
     size_t ktimer_used = 0;

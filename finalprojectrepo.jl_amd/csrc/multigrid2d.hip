@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_sweep2d(const double* __restrict__ uin,
 // one thread per COARSE point; (nx, ny) = fine dims.  multigrid.jl:128-129, 330-358
 __global__ __launch_bounds__(256) void k_restrict_residual2d(const double* __restrict__ u, const double* __restrict__ f,
                                                               double* __restrict__ res_c, int nx, int ny, double C,
-                                                              double _h2, int apply_BCs)
+                                                              double _h2, int apply_BCs, double* __restrict__ corr_c)
 {
     const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
     const int ic = blockIdx.x * BX + threadIdx.x, jc = blockIdx.y * BY + threadIdx.y;
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void k_restrict_residual2d(const double* __res
         v = res_at(u, f, id, nx, C, _h2);
     }
     res_c[(size_t)ic + (size_t)nxc * jc] = v;
+    if (corr_c) corr_c[(size_t)ic + (size_t)nxc * jc] = 0.0;  // `corr_c .= 0.` (multigrid.jl:132) in the same pass
 }
 
 // ---- bilinear prolongation as a gather -------------------------------------------------------------
@@ -310,6 +311,202 @@ __global__ __launch_bounds__(256) void k_cg_p(double* __restrict__ p, const doub
     const double beta = st->beta;
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = r[i] + beta * p[i];
+}
+
+// ================================================================================================
+// k_mg_small: a whole sub-hierarchy of the V-cycle in ONE workgroup, resident in LDS.
+//
+// Coarse multigrid levels are launch-latency bound (a 65^2 level costs ~8 dependent launches of ~2 us
+// each for ~0.1 us of work, and the 5x5 Jacobi solve another ~130).  Once a level and everything below
+// it fit in the CU's 160 KiB LDS (3 arrays per level: u, rhs, ping-pong partner; sum over levels
+// <= 20 000 doubles, i.e. up to 65x65 or 129x33), one 1024-thread workgroup executes
+// Vcycle_2DPoisson! (multigrid.jl:91-170) for that level and all coarser ones with __syncthreads()
+// between the passes: pre-smoothing, residual+injection, the Jacobi coarse solve with its early exit
+// (:147-159), prolongation+correction, post-smoothing.  Same pointwise arithmetic as the per-level
+// kernels (bit-identical fields); norms are block-tree sums.
+// ================================================================================================
+struct MgSmallArgs {
+    double* u;          // top level of the sub-hierarchy, global memory, in/out
+    const double* rhs;  // its right-hand side
+    int nx, ny, nlev;   // nlev = levels including the coarsest one
+    double h, c, tol;
+    int css, apply_BCs, want_norm;
+    double* out_sumsq;  // want_norm: sum(res.^2) of the last post-smoothing sweep of the top level
+    FprSolveState* state;
+};
+
+constexpr int MGS_NT = 1024;
+constexpr int MGS_RED = 32;  // doubles reserved for reductions / broadcasts
+
+__device__ __forceinline__ double mgs_block_sum(double v, double* red)
+{
+    // all MGS_NT threads call; returns the total in every thread
+    v = fpr_wave_sum(v);
+    const int tid = threadIdx.x;
+    __syncthreads();  // protect red[] from the previous use
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+        double s = red[0];
+#pragma unroll
+        for (int w = 1; w < MGS_NT / 64; ++w) s += red[w];
+        red[MGS_NT / 64] = s;
+    }
+    __syncthreads();
+    return red[MGS_NT / 64];
+}
+
+// uout = uin + fac*res(uin) on the interior, boundary copied; returns this thread's sum of res^2
+__device__ __forceinline__ double mgs_sweep(const double* uin, const double* f, double* uout, int nx, int ny, double C,
+                                            double _h2, double fac)
+{
+    double acc = 0.0;
+    const int N = nx * ny;
+    for (int idx = threadIdx.x; idx < N; idx += MGS_NT) {
+        const int j = idx / nx, i = idx - j * nx;
+        const double uc = uin[idx];
+        if (i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1) {
+            const double r = ((((uin[idx + 1] + uin[idx - 1]) + uin[idx + nx]) + uin[idx - nx]) - C * uc) * _h2 - f[idx];
+            uout[idx] = uc + fac * r;
+            acc += r * r;
+        } else {
+            uout[idx] = uc;
+        }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* red = sm;
+    double* arena = sm + MGS_RED;
+    const int tid = threadIdx.x;
+
+    // level d: dims ((nx-1)>>d)+1, arrays u|f|t at arena + off(d)
+    auto lnx = [&](int d) { return ((a.nx - 1) >> d) + 1; };
+    auto lny = [&](int d) { return ((a.ny - 1) >> d) + 1; };
+    auto off = [&](int d) {
+        int o = 0;
+        for (int e = 0; e < d; ++e) o += 3 * lnx(e) * lny(e);
+        return o;
+    };
+    auto hlev = [&](int d) {
+        double h = a.h;
+        for (int e = 0; e < d; ++e) h = h * 2;  // the recursion passes h*2 (multigrid.jl:133)
+        return h;
+    };
+
+    {   // load the top level
+        const int N = a.nx * a.ny;
+        double* U = arena;
+        double* F = arena + N;
+        for (int idx = tid; idx < N; idx += MGS_NT) {
+            U[idx] = a.u[idx];
+            F[idx] = a.rhs[idx];
+        }
+    }
+    __syncthreads();
+
+    const int c_lev = a.nlev - 1;
+    // ---- down sweep ----
+    for (int d = 0; d < c_lev; ++d) {
+        const int nx = lnx(d), ny = lny(d), N = nx * ny;
+        double* U = arena + off(d);
+        double* F = U + N;
+        double* T = F + N;
+        const double h = hlev(d);
+        const double C = 4.0 + a.c * (h * h), _h2 = 1 / (h * h);
+        const double fac = (4.0 / 5.0) * ((h * h) / (4.0 + a.c * (h * h)));
+        mgs_sweep(U, F, T, nx, ny, C, _h2, fac);  // :124
+        __syncthreads();
+        mgs_sweep(T, F, U, nx, ny, C, _h2, fac);  // :125
+        __syncthreads();
+        // residual + injection + Neumann rows into the next level's rhs; next level's u = 0 (:128-132)
+        const int nxc = lnx(d + 1), nyc = lny(d + 1), Nc = nxc * nyc;
+        double* Uc = arena + off(d + 1);
+        double* Fc = Uc + Nc;
+        for (int idx = tid; idx < Nc; idx += MGS_NT) {
+            const int jc = idx / nxc, ic = idx - jc * nxc;
+            int is = ic;
+            if (a.apply_BCs) is = (ic == 0) ? 1 : (ic == nxc - 1 ? nxc - 2 : ic);
+            double v = 0.0;
+            if (is >= 1 && is <= nxc - 2 && jc >= 1 && jc <= nyc - 2) {
+                const int id = 2 * is + nx * (2 * jc);
+                v = ((((U[id + 1] + U[id - 1]) + U[id + nx]) + U[id - nx]) - C * U[id]) * _h2 - F[id];
+            }
+            Fc[idx] = v;
+            Uc[idx] = 0.0;
+        }
+        __syncthreads();
+    }
+
+    // ---- coarsest level: Jacobi with early exit (:147-159) ----
+    double* ucur;  // where the coarse solution ends up
+    {
+        const int nx = lnx(c_lev), ny = lny(c_lev), N = nx * ny;
+        double* U = arena + off(c_lev);
+        double* F = U + N;
+        double* T = F + N;
+        const double h = hlev(c_lev);
+        const double C = 4.0 + a.c * (h * h), _h2 = 1 / (h * h);
+        const double fac = (4.0 / 5.0) * ((h * h) / (4.0 + a.c * (h * h)));
+        double acc = 0.0;
+        for (int idx = tid; idx < N; idx += MGS_NT) acc += F[idx] * F[idx];
+        const double tol_rhs = a.tol * sqrt(mgs_block_sum(acc, red) / (double)N);  // :150
+        const int iters = 20 * a.css;
+        double res_rms = 0.0;
+        int it = 0;
+        double* pin = U;
+        double* pout = T;
+        for (int i = 1; i <= iters; ++i) {
+            const double s = mgs_block_sum(mgs_sweep(pin, F, pout, nx, ny, C, _h2, fac), red);  // syncs inside
+            res_rms = sqrt(s / (double)N);
+            double* t = pin; pin = pout; pout = t;
+            it = i;
+            if (res_rms < tol_rhs) break;  // uniform: every thread holds the same value
+        }
+        ucur = pin;
+        if (tid == 0) {
+            a.state->acc_iters += it;
+            a.state->last_rms = res_rms;
+        }
+        __syncthreads();
+    }
+
+    // ---- up sweep ----
+    for (int d = c_lev - 1; d >= 0; --d) {
+        const int nx = lnx(d), ny = lny(d), N = nx * ny;
+        double* U = arena + off(d);
+        double* F = U + N;
+        double* T = F + N;
+        const double h = hlev(d);
+        const double C = 4.0 + a.c * (h * h), _h2 = 1 / (h * h);
+        const double fac = (4.0 / 5.0) * ((h * h) / (4.0 + a.c * (h * h)));
+        const int nxc = lnx(d + 1);
+        const double* Uc = (d + 1 == c_lev) ? ucur : arena + off(d + 1);
+        for (int idx = tid; idx < N; idx += MGS_NT) {  // prolongation + correction (:136-139)
+            const int j = idx / nx, i = idx - j * nx;
+            int is = i;
+            if (a.apply_BCs) is = (i == 0) ? 1 : (i == nx - 1 ? nx - 2 : i);
+            U[idx] = U[idx] - prolong_at(Uc, is, j, nx, ny, nxc);
+        }
+        __syncthreads();
+        mgs_sweep(U, F, T, nx, ny, C, _h2, fac);  // :142
+        __syncthreads();
+        const double acc = mgs_sweep(T, F, U, nx, ny, C, _h2, fac);  // :143
+        if (d == 0 && a.want_norm) {
+            const double s = mgs_block_sum(acc, red);
+            if (tid == 0) a.out_sumsq[0] = s;
+        }
+        __syncthreads();
+    }
+
+    {   // store the top level's solution
+        const int N = a.nx * a.ny;
+        const double* U = (c_lev == 0) ? ucur : arena;
+        for (int idx = tid; idx < N; idx += MGS_NT) a.u[idx] = U[idx];
+    }
 }
 
 // ================================================================================================
@@ -565,6 +762,44 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
     const int np = (int)(g.x * g.y);
     if (np > FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
 
+    // ---- LDS-resident sub-hierarchy: this level and everything below it in one workgroup ----
+    if (solver == FPR_COARSE_JACOBI && fpr_opt(ctx, "mg_small", 1)) {
+        int nlev = 1, lx = nx, ly = ny;
+        size_t tot = 3 * (size_t)lx * ly;
+        bool ok = true;
+        while ((lx < ly ? lx : ly) > css) {
+            if ((lx - 1) % 2 || (ly - 1) % 2) { ok = false; break; }
+            const int m = (lx < ly ? lx : ly) - 1;
+            if (m & (m - 1)) { ok = false; break; }
+            lx = 1 + (lx - 1) / 2;
+            ly = 1 + (ly - 1) / 2;
+            tot += 3 * (size_t)lx * ly;
+            ++nlev;
+            if (nlev > 16) { ok = false; break; }
+        }
+        if (ok && tot + MGS_RED <= 20000) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                FPR_HIP(ctx, hipFuncSetAttribute((const void*)k_mg_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_set = true;
+            }
+            MgSmallArgs a;
+            a.u = u; a.rhs = rhs; a.nx = nx; a.ny = ny; a.nlev = nlev;
+            a.h = h; a.c = c; a.tol = tol; a.css = css; a.apply_BCs = apply_BCs;
+            a.want_norm = (top && nlev > 1) ? 1 : 0;
+            a.out_sumsq = ctx->scalars;
+            a.state = ctx->state;
+            k_mg_small<<<1, MGS_NT, (tot + MGS_RED) * sizeof(double), s>>>(a);
+            FPR_CHECK_LAUNCH(ctx);
+            if (top) {
+                *rms_is_host = false;
+                ctx->top_is_coarsest = (nlev == 1);
+            }
+            ctx->used_small = true;
+            return FPR_OK;
+        }
+    }
+
     if ((nx < ny ? nx : ny) > css) {  // multigrid.jl:121
         if (d + 1 >= A.size() || !L.res_c) return fpr_fail(ctx, FPR_ERR_INVALID, "level arena exhausted");
         const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
@@ -572,9 +807,8 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
         k_sweep2d<false, false><<<g, blk2, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, nullptr, nullptr);
         k_sweep2d<false, false><<<g, blk2, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, nullptr, nullptr);
         // residual + restriction (:128-129), coarse correction starts from zero (:132)
-        k_restrict_residual2d<<<grid2(nxc, nyc), blk2, 0, s>>>(u, rhs, L.res_c, nx, ny, C, _h2, apply_BCs);
+        k_restrict_residual2d<<<grid2(nxc, nyc), blk2, 0, s>>>(u, rhs, L.res_c, nx, ny, C, _h2, apply_BCs, L.corr_c);
         FPR_CHECK_LAUNCH(ctx);
-        FPR_HIP(ctx, hipMemsetAsync(L.corr_c, 0, (size_t)nxc * nyc * sizeof(double), s));
         double dummy; bool dh;
         if (int rc = vcycle_level(ctx, A, d + 1, L.corr_c, L.res_c, h * 2, c, tol, css, solver, apply_BCs, false, &dummy, &dh))
             return rc;  // :133
@@ -638,13 +872,20 @@ static int vcycle_run(fpr_ctx* ctx, double* u, const double* rhs, double h, doub
     if (int rc = get_arena(ctx, nx, ny, css, &A)) return rc;
     double r = 0.0;
     bool is_host = true;
+    ctx->used_small = false;
+    ctx->top_is_coarsest = false;
+    FPR_HIP(ctx, hipMemsetAsync(&ctx->state->acc_iters, 0, sizeof(int), ctx->stream[0]));
     if (int rc = vcycle_level(ctx, *A, 0, u, rhs, h, c, tol, css, solver, apply_BCs, true, &r, &is_host)) return rc;
     if (rms_host) {
+        if (ctx->used_small)  // fetch the device-side iteration count / coarse rms with the same sync
+            FPR_HIP(ctx, hipMemcpyAsync(ctx->state_h, ctx->state, sizeof(FprSolveState), hipMemcpyDeviceToHost, ctx->stream[0]));
         if (!is_host) {
             double ssum;
             if (int rc = read_scalar(ctx, ctx->scalars, &ssum)) return rc;
             r = sqrt(ssum / ((double)nx * (double)ny));  // multigrid.jl:252
+            if (ctx->top_is_coarsest) r = ctx->state_h->last_rms;
         }
+        if (ctx->used_small) ctx->last_coarse_iters += ctx->state_h->acc_iters;
         *rms_host = r;
     }
     return FPR_OK;

@@ -20,6 +20,8 @@ struct FprSolveState {
     int done;        // 1 once the stopping criterion was met
     int iters;       // iterations executed (including the one that met the criterion)
     int acc_iters;   // coarse-solver iterations accumulated over one V-cycle (k_mg_small adds to it)
+    int redo;        // multi-sweep Jacobi: sweeps of group `group` that must be applied (exit inside a group)
+    int group;       // multi-sweep Jacobi: group in which the stopping criterion was met
     int pad;
     double last_rms; // r_rms of the last executed iteration
     double thresh;   // tol * rms(rhs)   (Jacobi)  or  tol * ||b||  (CG)

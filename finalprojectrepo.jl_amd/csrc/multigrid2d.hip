@@ -75,6 +75,190 @@ __global__ __launch_bounds__(256) void k_sweep2d(const double* __restrict__ uin,
     }
 }
 
+// ---- S fused Jacobi sweeps per pass (temporal blocking in LDS) -------------------------------------
+// A workgroup loads its TX x TY output tile plus a halo of S cells of u and f into LDS, applies up to S
+// damped-Jacobi sweeps there (the valid region shrinks by one ring per sweep, except along domain
+// boundaries, whose values are fixed) and writes the tile once: 2 sweeps cost one read of u and f and
+// one write of u instead of two.  Arithmetic per point is that of k_sweep2d, so results are
+// bit-identical.  NORM: 0 none, 1 sum(res^2) of the LAST executed sweep, 2 of EVERY sweep (coarse-solve
+// exit test); partials[s * nblocks + block] for sweep s, counted on the workgroup's own tile only.
+// STATE: skipped once state->done is set; nsw (<= S) = sweeps to execute.
+template <int S, int TX, int TY, int NORM, bool STATE>
+__global__ __launch_bounds__(256) void k_sweep2d_multi(const double* __restrict__ uin, const double* __restrict__ f,
+                                                        double* __restrict__ uout, int nx, int ny, double C, double _h2,
+                                                        double fac, int nsw, double* __restrict__ partials,
+                                                        const FprSolveState* __restrict__ state)
+{
+    constexpr int P = TX + 2 * S;       // LDS pitch
+    constexpr int RH = TY + 2 * S;      // LDS rows
+    __shared__ double bufA[P * RH];
+    __shared__ double bufB[P * RH];
+    __shared__ double bufF[P * RH];
+    __shared__ double red[16];
+    if constexpr (STATE) {
+        if (state->done) return;
+    }
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;           // own tile origin
+    const int rx0 = x0 - S < 0 ? 0 : x0 - S, ry0 = y0 - S < 0 ? 0 : y0 - S;
+    const int rx1 = x0 + TX + S > nx ? nx : x0 + TX + S, ry1 = y0 + TY + S > ny ? ny : y0 + TY + S;
+    const int RWr = rx1 - rx0, RHr = ry1 - ry0;                      // loaded region
+    const bool exl = rx0 > 0, exh = rx1 < nx, eyl = ry0 > 0, eyh = ry1 < ny;  // "open" (shrinking) edges
+    for (int idx = tid; idx < P * RH; idx += 256) {
+        const int r = idx / P, cc = idx - r * P;
+        if (r < RHr && cc < RWr) {
+            const size_t g = (size_t)(rx0 + cc) + (size_t)nx * (size_t)(ry0 + r);
+            bufA[idx] = uin[g];
+            bufF[idx] = f[g];
+        }
+    }
+    __syncthreads();
+    double* cur = bufA;
+    double* nxt = bufB;
+    const int blk = blockIdx.x + gridDim.x * blockIdx.y;
+    const int nblk = gridDim.x * gridDim.y;
+    for (int sIt = 0; sIt < nsw; ++sIt) {
+        const int clo = exl ? sIt + 1 : 0, chi = RWr - (exh ? sIt + 1 : 0);
+        const int rlo = eyl ? sIt + 1 : 0, rhi = RHr - (eyh ? sIt + 1 : 0);
+        double acc = 0.0;
+        for (int idx = tid; idx < P * RH; idx += 256) {
+            const int r = idx / P, cc = idx - r * P;
+            if (r >= rlo && r < rhi && cc >= clo && cc < chi) {
+                const int gi = rx0 + cc, gj = ry0 + r;
+                const double uc = cur[idx];
+                if (gi >= 1 && gj >= 1 && gi < nx - 1 && gj < ny - 1) {
+                    const double rr = ((((cur[idx + 1] + cur[idx - 1]) + cur[idx + P]) + cur[idx - P]) - C * uc) * _h2 - bufF[idx];
+                    nxt[idx] = uc + fac * rr;
+                    if constexpr (NORM != 0) {
+                        if (gi >= x0 && gi < x0 + TX && gj >= y0 && gj < y0 + TY) acc += rr * rr;
+                    }
+                } else {
+                    nxt[idx] = uc;
+                }
+            }
+        }
+        if constexpr (NORM == 2) {
+            const double sblk = fpr_block_sum<256>(acc, red);  // contains a barrier
+            if (tid == 0) partials[(size_t)sIt * nblk + blk] = sblk;
+        } else if constexpr (NORM == 1) {
+            if (sIt == nsw - 1) {
+                const double sblk = fpr_block_sum<256>(acc, red);
+                if (tid == 0) partials[blk] = sblk;
+            }
+        }
+        __syncthreads();
+        double* t = cur; cur = nxt; nxt = t;
+    }
+    // write the own tile
+    for (int idx = tid; idx < TX * TY; idx += 256) {
+        const int r = idx / TX, cc = idx - r * TX;
+        const int gi = x0 + cc, gj = y0 + r;
+        if (gi < nx && gj < ny) uout[(size_t)gi + (size_t)nx * gj] = cur[(gi - rx0) + P * (gj - ry0)];
+    }
+}
+
+// Branch-free form of the bilinear gather (same value, same accumulation order as prolong_at below):
+// v = (((0 + w00*c00) + w10*c10) + w01*c01) + w11*c11 with weights 1 | .5,.5 | .25 x4 by parity, a term
+// being dropped (exact +0) when its coarse point is not an interior source.
+__device__ __forceinline__ double prolong_bf(const double* __restrict__ cc, int i, int j, int nx, int ny, int nxc, int nyc)
+{
+    const bool in = i >= 1 && j >= 1 && i <= nx - 2 && j <= ny - 2;
+    const int io = i & 1, jo = j & 1;
+    const int icl = i >> 1, jcl = j >> 1;
+    const int ich = (icl + 1 < nxc) ? icl + 1 : nxc - 1, jch = (jcl + 1 < nyc) ? jcl + 1 : nyc - 1;
+    const double w = (io | jo) ? ((io & jo) ? 0.25 : 0.5) : 1.0;
+    const bool sx0 = icl >= 1 && icl <= nxc - 2, sx1 = io && (icl + 1 <= nxc - 2);
+    const bool sy0 = jcl >= 1 && jcl <= nyc - 2, sy1 = jo && (jcl + 1 <= nyc - 2);
+    const double c00 = cc[(size_t)icl + (size_t)nxc * jcl], c10 = cc[(size_t)ich + (size_t)nxc * jcl];
+    const double c01 = cc[(size_t)icl + (size_t)nxc * jch], c11 = cc[(size_t)ich + (size_t)nxc * jch];
+    double v = 0.0;
+    v = v + ((in && sx0 && sy0) ? w * c00 : 0.0);
+    v = v + ((in && sx1 && sy0) ? w * c10 : 0.0);
+    v = v + ((in && sx0 && sy1) ? w * c01 : 0.0);
+    v = v + ((in && sx1 && sy1) ? w * c11 : 0.0);
+    return v;
+}
+
+// ---- two fused Jacobi sweeps, register-rolling march in y (fine levels) ------------------------------
+// A wave owns a strip of 64 columns (one column per lane) and marches down a chunk of rows keeping a
+// 3-row window of u (sweep 0) and of the once-smoothed field (sweep 1) in registers; x-neighbours come
+// from wavefront shuffles, y-neighbours from the window.  Strips overlap by 4 columns (a wave loads 64
+// columns and owns the 60 in the middle: the two outer lanes on each side only feed the stencils), so
+// waves never communicate: no LDS, no barrier.  One pass reads u and f once and writes u once for TWO
+// sweeps (multigrid.jl:124-125 / :142-143).  Point arithmetic is that of k_sweep2d: bit-identical.
+// PROLONG: the input is corrected on the fly, u = uin - P(corr_c) (multigrid.jl:136-139 fused into the
+// post-smoothing pass: the prolongation/correction pass over the fine grid disappears).
+template <bool NORM, bool PROLONG>
+__global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict__ uin, const double* __restrict__ f,
+                                                        double* __restrict__ uout, int nx, int ny, double C, double _h2,
+                                                        double fac, int rows_per_chunk, int nstrips,
+                                                        double* __restrict__ partials, const double* __restrict__ corr_c,
+                                                        int apply_BCs)
+{
+    __shared__ double red[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + w;
+    const bool active = strip < nstrips;
+    const int gi = strip * 60 - 2 + lane;                    // global column of this lane
+    const bool col_ok = active && gi >= 0 && gi < nx;
+    const int gic = gi < 0 ? 0 : (gi > nx - 1 ? nx - 1 : gi);  // clamped for loads
+    const bool col_bnd = gi <= 0 || gi >= nx - 1;            // domain boundary column (or outside)
+    const bool owner = col_ok && lane >= 2 && lane < 62;
+    const int y0 = blockIdx.y * rows_per_chunk;
+    const int y1 = (y0 + rows_per_chunk < ny) ? y0 + rows_per_chunk : ny;  // output rows [y0, y1)
+    const int rs = y0 - 2 < 0 ? 0 : y0 - 2;
+    double acc = 0.0;
+    if (active) {
+        const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
+        int gis = gic;  // Neumann rows of the prolongated correction (part2_utils.jl:35-39)
+        if (PROLONG && apply_BCs) gis = (gic == 0) ? 1 : (gic == nx - 1 ? nx - 2 : gic);
+        auto ldu = [&](int r) {
+            const int rc = r > ny - 1 ? ny - 1 : r;
+            const double v = uin[(size_t)gic + (size_t)nx * rc];
+            if constexpr (PROLONG) return v - prolong_bf(corr_c, gis, rc, nx, ny, nxc, nyc);
+            else return v;
+        };
+        auto ldf = [&](int r) { const int rc = r > ny - 1 ? ny - 1 : r; return f[(size_t)gic + (size_t)nx * rc]; };
+        double a0 = 0.0, a1 = 0.0, a2 = ldu(rs);       // u   rows r-2, r-1, r
+        double b0 = 0.0, b1 = 0.0, b2 = 0.0;           // u1  rows r-3, r-2, r-1
+        double f0 = 0.0, f1 = 0.0, f2 = ldf(rs);       // f   rows r-2, r-1, r
+        double an = ldu(rs + 1), fn = ldf(rs + 1);     // prefetched row r+1
+        for (int r = rs; r <= y1 + 1; ++r) {
+            const double an2 = ldu(r + 2), fn2 = ldf(r + 2);  // issue the loads of row r+2
+            // ---- sweep 1 at row r-1 (needs u rows r-2, r-1, r) ----
+            const int j1 = r - 1;
+            double u1;
+            {
+                const double L = __shfl_up(a1, 1, 64), R = __shfl_down(a1, 1, 64);
+                const double rr = ((((R + L) + a2) + a0) - C * a1) * _h2 - f1;
+                const bool bnd = col_bnd || j1 <= 0 || j1 >= ny - 1;
+                u1 = bnd ? a1 : a1 + fac * rr;
+            }
+            b0 = b1; b1 = b2; b2 = u1;                 // u1 rows r-3, r-2, r-1
+            // ---- sweep 2 at row r-2 (needs u1 rows r-3, r-2, r-1) ----
+            const int j2 = r - 2;
+            {
+                const double L = __shfl_up(b1, 1, 64), R = __shfl_down(b1, 1, 64);
+                const double rr = ((((R + L) + b2) + b0) - C * b1) * _h2 - f0;
+                const bool bnd = col_bnd || j2 <= 0 || j2 >= ny - 1;
+                const double u2 = bnd ? b1 : b1 + fac * rr;
+                if (owner && j2 >= y0 && j2 < y1) {
+                    uout[(size_t)gi + (size_t)nx * j2] = u2;
+                    if constexpr (NORM) {
+                        if (!bnd) acc += rr * rr;
+                    }
+                }
+            }
+            a0 = a1; a1 = a2; a2 = an; an = an2;
+            f0 = f1; f1 = f2; f2 = fn; fn = fn2;
+        }
+    }
+    if constexpr (NORM) {
+        const double sblk = fpr_block_sum<256>(acc, red);
+        if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
+    }
+}
+
 // ---- residual + injection (+ Neumann rows) into the coarse rhs ------------------------------------
 // one thread per COARSE point; (nx, ny) = fine dims.  multigrid.jl:128-129, 330-358
 __global__ __launch_bounds__(256) void k_restrict_residual2d(const double* __restrict__ u, const double* __restrict__ f,
@@ -135,7 +319,7 @@ __global__ __launch_bounds__(256) void k_prolong2d(const double* __restrict__ cc
     const int nxc = 1 + (nx - 1) / 2;
     int is = i;
     if (apply_BCs) is = (i == 0) ? 1 : (i == nx - 1 ? nx - 2 : i);  // Neumann rows (part2_utils.jl:35-39)
-    const double p = prolong_at(cc, is, j, nx, ny, nxc);
+    const double p = prolong_bf(cc, is, j, nx, ny, nxc, 1 + (ny - 1) / 2);
     const size_t id = (size_t)i + (size_t)nx * j;
     if constexpr (CORRECT) fine[id] = fine[id] - p;
     else fine[id] = p;
@@ -193,6 +377,8 @@ __global__ void k_state_init(FprSolveState* st, const double* sumsq, double tol,
 {
     st->done = 0;
     st->iters = 0;
+    st->redo = 0;
+    st->group = -1;
     st->last_rms = 0.0;
     st->thresh = cg ? tol * sqrt(sumsq[0]) : tol * sqrt(sumsq[0] / N);
     st->rho = sumsq[0];  // CG: rho = sum(r.*r) with r = b (krylov.jl:64)
@@ -214,6 +400,33 @@ __global__ __launch_bounds__(256) void k_jacobi_check(FprSolveState* st, const d
         st->iters += 1;
         st->last_rms = rms;
         if (rms < st->thresh) st->done = 1;
+    }
+}
+
+// after a group of nsw fused sweeps: replay the per-sweep exit test in order (multigrid.jl:152-155)
+__global__ __launch_bounds__(256) void k_jacobi_check_multi(FprSolveState* st, const double* __restrict__ partials, int nblk,
+                                                             int nsw, double N, int group)
+{
+    __shared__ double red[16];
+    __shared__ int stop;
+    if (st->done) return;
+    if (threadIdx.x == 0) stop = 0;
+    __syncthreads();
+    for (int s = 0; s < nsw; ++s) {
+        const double sum = fpr_sum_partials_256(partials + (size_t)s * nblk, nblk, red);
+        if (threadIdx.x == 0) {
+            const double rms = sqrt(sum / N);
+            st->iters += 1;
+            st->last_rms = rms;
+            if (rms < st->thresh) {
+                st->done = 1;
+                st->redo = s + 1;
+                st->group = group;
+                stop = 1;
+            }
+        }
+        __syncthreads();
+        if (stop) return;
     }
 }
 
@@ -803,6 +1016,61 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
     if ((nx < ny ? nx : ny) > css) {  // multigrid.jl:121
         if (d + 1 >= A.size() || !L.res_c) return fpr_fail(ctx, FPR_ERR_INVALID, "level arena exhausted");
         const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
+        if (fpr_opt(ctx, "mg_multi", 1) == 1 && nx >= 64 && ny >= 16) {
+            // temporal blocking, register-rolling march: each smoothing pair is ONE pass (u -> tmp, tmp -> u)
+            const int nstrips = (nx + 59) / 60;
+            int rpc = (int)fpr_opt(ctx, "mg_rows_per_chunk", 0);
+            if (rpc <= 0) {  // enough chunks for >= ~16 waves per CU, chunks of at least 16 rows
+                rpc = 64;
+                while (rpc > 16 && (long)nstrips * ((ny + rpc - 1) / rpc) < 4096) rpc >>= 1;
+            }
+            const dim3 gm((nstrips + 3) / 4, (ny + rpc - 1) / rpc);
+            const int npm = (int)(gm.x * gm.y);
+            const bool fuse_p = fpr_opt(ctx, "mg_fuse_prolong", 1) != 0;
+            k_smooth2_march<false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0);  // :124-125
+            k_restrict_residual2d<<<grid2(nxc, nyc), blk2, 0, s>>>(L.tmp, rhs, L.res_c, nx, ny, C, _h2, apply_BCs, L.corr_c);  // :128-132
+            FPR_CHECK_LAUNCH(ctx);
+            double dummy; bool dh;
+            if (int rc = vcycle_level(ctx, A, d + 1, L.corr_c, L.res_c, h * 2, c, tol, css, solver, apply_BCs, false, &dummy, &dh))
+                return rc;  // :133
+            if (!fuse_p) k_prolong2d<true><<<g, blk2, 0, s>>>(L.corr_c, L.tmp, nx, ny, apply_BCs);  // :136-139
+            // post-smoothing pair (:142-143); with fuse_p the correction u - P(corr_c) is applied while loading
+            if (top) {
+                if (fuse_p) k_smooth2_march<true, true><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs);
+                else k_smooth2_march<true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, 0);
+                FPR_CHECK_LAUNCH(ctx);
+                if (int rc = fprx_finish_sum(ctx, ctx->partials, npm, ctx->scalars, false, 0)) return rc;
+                *rms_is_host = false;
+            } else {
+                if (fuse_p) k_smooth2_march<false, true><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs);
+                else k_smooth2_march<false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0);
+                FPR_CHECK_LAUNCH(ctx);
+            }
+            return FPR_OK;
+        }
+        if (fpr_opt(ctx, "mg_multi", 1) == 2 && nx >= 64 && ny >= 32) {
+            // temporal blocking, LDS tile variant (kept for A/B comparison; slower than the march on gfx950)
+            constexpr int TX = 64, TY = 32;
+            const dim3 gm((nx + TX - 1) / TX, (ny + TY - 1) / TY);
+            const int npm = (int)(gm.x * gm.y);
+            k_sweep2d_multi<2, TX, TY, 0, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, 2, nullptr, nullptr);  // :124-125
+            k_restrict_residual2d<<<grid2(nxc, nyc), blk2, 0, s>>>(L.tmp, rhs, L.res_c, nx, ny, C, _h2, apply_BCs, L.corr_c);  // :128-132
+            FPR_CHECK_LAUNCH(ctx);
+            double dummy; bool dh;
+            if (int rc = vcycle_level(ctx, A, d + 1, L.corr_c, L.res_c, h * 2, c, tol, css, solver, apply_BCs, false, &dummy, &dh))
+                return rc;  // :133
+            k_prolong2d<true><<<g, blk2, 0, s>>>(L.corr_c, L.tmp, nx, ny, apply_BCs);  // :136-139
+            if (top) {
+                k_sweep2d_multi<2, TX, TY, 1, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, 2, ctx->partials, nullptr);  // :142-143
+                FPR_CHECK_LAUNCH(ctx);
+                if (int rc = fprx_finish_sum(ctx, ctx->partials, npm, ctx->scalars, false, 0)) return rc;
+                *rms_is_host = false;
+            } else {
+                k_sweep2d_multi<2, TX, TY, 0, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, 2, nullptr, nullptr);
+                FPR_CHECK_LAUNCH(ctx);
+            }
+            return FPR_OK;
+        }
         // two pre-smoothing sweeps (:124-125)
         k_sweep2d<false, false><<<g, blk2, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, nullptr, nullptr);
         k_sweep2d<false, false><<<g, blk2, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, nullptr, nullptr);
@@ -834,9 +1102,51 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
         if (int rc = fprx_sumsq_scaled_dev(ctx, rhs, N, 1.0, ctx->scalars + 3, 0)) return rc;  // :150
         k_state_init<<<1, 1, 0, s>>>(ctx->state, ctx->scalars + 3, tol, (double)N, 0);
         FPR_CHECK_LAUNCH(ctx);
+        ctx->state_h->done = 0; ctx->state_h->iters = 0; ctx->state_h->last_rms = 0.0;
+        if (fpr_opt(ctx, "mg_multi", 1) && nx >= 32 && ny >= 32) {
+            // groups of S fused sweeps per launch; the exit test is replayed per sweep on the device
+            constexpr int S = 8, TX = 16, TY = 16;
+            const dim3 gm((nx + TX - 1) / TX, (ny + TY - 1) / TY);
+            const int nblk = (int)(gm.x * gm.y);
+            if ((size_t)nblk * S > (size_t)FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
+            const int groups = (iters + S - 1) / S;
+            double* a = u;
+            double* b = L.tmp;
+            int gdone = 0;
+            while (gdone < groups) {
+                const int gend = (gdone + 8 < groups) ? gdone + 8 : groups;  // poll the state every 64 sweeps
+                for (int gi = gdone; gi < gend; ++gi) {
+                    const int nsw = (iters - gi * S < S) ? iters - gi * S : S;
+                    k_sweep2d_multi<S, TX, TY, 2, true><<<gm, 256, 0, s>>>(a, rhs, b, nx, ny, C, _h2, fac, nsw, ctx->partials, ctx->state);
+                    k_jacobi_check_multi<<<1, 256, 0, s>>>(ctx->state, ctx->partials, nblk, nsw, (double)N, gi);
+                    double* t = a; a = b; b = t;
+                }
+                FPR_CHECK_LAUNCH(ctx);
+                gdone = gend;
+                if (int rc = read_state(ctx)) return rc;
+                if (ctx->state_h->done) break;
+            }
+            double* result;
+            if (ctx->state_h->done) {
+                const int gs = ctx->state_h->group, redo = ctx->state_h->redo;
+                double* in = (gs & 1) ? L.tmp : u;
+                double* out = (gs & 1) ? u : L.tmp;
+                const int nsw_g = (iters - gs * S < S) ? iters - gs * S : S;
+                if (redo < nsw_g)  // the exit fell inside the group: recompute exactly `redo` sweeps from its input
+                    k_sweep2d_multi<S, TX, TY, 0, false><<<gm, 256, 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, redo, nullptr, nullptr);
+                result = out;
+            } else {
+                result = (groups & 1) ? L.tmp : u;
+            }
+            if (result != u) FPR_HIP(ctx, hipMemcpyAsync(u, result, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+            FPR_CHECK_LAUNCH(ctx);
+            ctx->last_coarse_iters += ctx->state_h->iters;
+            *rms_out_host = ctx->state_h->last_rms;
+            *rms_is_host = true;
+            return FPR_OK;
+        }
         const int chunk = 64;
         int launched = 0;
-        ctx->state_h->done = 0; ctx->state_h->iters = 0; ctx->state_h->last_rms = 0.0;
         double* a = u;
         double* b = L.tmp;
         while (launched < iters) {

@@ -261,3 +261,45 @@ def test_full_size_4097_properties(fpr):
     x.zero_()
     r5, hist5, _, cit = mg.MGsolve_2DPoisson_(x, b, h, 0.0, 1e-6, 100, False, opt=opt, return_history=True)
     assert r5 < 1e-6 * frms and len(hist5) <= 12 and cit > 0
+
+
+@pytest.mark.parametrize("tol", [0.9, 0.7, 0.5, 0.4, 0.3, 0.25, 0.2, 0.15, 1e-9])
+def test_coarse_jacobi_exit_inside_a_fused_group(fpr, oracle, tol):
+    """The coarse Jacobi solve runs 8 fused sweeps per launch; when the exit test (multigrid.jl:152-155)
+    fires inside a group the group is recomputed with exactly the right number of sweeps."""
+    F, mg = fpr, fpr.multigrid
+    shape = (129, 129)  # too large for the LDS-resident path: exercises the multi-sweep launches
+    u0, f = rnd(shape, 31), rnd(shape, 32)
+    f[0, :] = f[-1, :] = 0.0
+    f[:, 0] = f[:, -1] = 0.0
+    h = 1.0 / 128
+    u_ref = u0.copy(order="F")
+    r_ref = oracle.vcycle2d(u_ref, f, h, 0.0, tol, 129, 0, False)
+    gu = F.asdevice(u0)
+    r = mg.Vcycle_2DPoisson_(gu, F.asdevice(f), h, 0.0, tol, 129, mg.jacobi, mg.parallel_shmem, False)
+    assert abs(r - r_ref) <= 1e-12 * abs(r_ref)
+    assert np.array_equal(F.tonumpy(gu), u_ref)
+
+
+def test_multisweep_and_single_sweep_paths_agree(fpr):
+    """Temporal blocking (mg_multi) and the LDS-resident coarse hierarchy (mg_small) change no bit."""
+    F, mg = fpr, fpr.multigrid
+    shape = (513, 257)
+    u0, f = rnd(shape, 41), rnd(shape, 42)
+    outs = []
+    for multi, small in ((1, 1), (0, 1), (2, 1), (1, 0), (0, 0)):
+        F.ctx().set_option("mg_multi", multi)
+        F.ctx().set_option("mg_small", small)
+        gu = F.asdevice(u0)
+        r = mg.Vcycle_2DPoisson_(gu, F.asdevice(f), 1.0 / 256, 0.3, 1e-7, 5, mg.jacobi, mg.parallel, True)
+        outs.append((r, F.tonumpy(gu)))
+    F.ctx().set_option("mg_multi", 1)
+    F.ctx().set_option("mg_small", 1)
+    F.ctx().set_option("mg_fuse_prolong", 0)
+    gu = F.asdevice(u0)
+    r = mg.Vcycle_2DPoisson_(gu, F.asdevice(f), 1.0 / 256, 0.3, 1e-7, 5, mg.jacobi, mg.parallel, True)
+    outs.append((r, F.tonumpy(gu)))
+    F.ctx().set_option("mg_fuse_prolong", 1)
+    for r, u in outs[1:]:
+        assert np.array_equal(u, outs[0][1])
+        assert abs(r - outs[0][0]) <= 1e-13 * abs(outs[0][0])

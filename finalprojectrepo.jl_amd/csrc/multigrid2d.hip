@@ -259,6 +259,152 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
     }
 }
 
+// ---- S fused Jacobi sweeps, register patches (coarse solve on grids too large for one workgroup) ------
+// The coarse-grid Jacobi solve of the "few levels" configurations (e.g. 257^2, 5140 sweeps per V-cycle)
+// is latency bound: ~1 MFLOP per sweep.  A workgroup of 16x16 threads holds a 32x32 region in
+// registers (2x2 points per thread, f too), exchanges patch edges through a double-buffered LDS image
+// (one barrier per sweep), and applies up to S = 8 sweeps per launch; the inner 16x16 tile (S cells away
+// from the region's edge) is exact and is the only part written back.  Per-sweep sums of res^2 over the
+// own tile are kept in registers and reduced once at the end: partials[s * nblocks + block].
+// STATE: the launch first replays the exit test of the PREVIOUS group (prev_nsw sweeps, partial sums in
+// prev_partials) -- every workgroup evaluates it redundantly and identically, workgroup 0 records it in
+// the solver state -- and does nothing once the criterion has been met.  This removes the separate
+// check launch from the dependent chain (one launch per 8 sweeps instead of two).
+template <int S, bool NORM, bool STATE>
+__global__ __launch_bounds__(256) void k_jacobi_patch(const double* __restrict__ uin, const double* __restrict__ f,
+                                                       double* __restrict__ uout, int nx, int ny, double C, double _h2,
+                                                       double fac, int nsw, double* __restrict__ partials,
+                                                       FprSolveState* __restrict__ state,
+                                                       const double* __restrict__ prev_partials, int prev_nsw,
+                                                       int prev_group, double Ntot)
+{
+    constexpr int P = 32;  // region = 32 x 32 points, own tile = inner 16 x 16
+    constexpr int T = P - 2 * S;
+    __shared__ __attribute__((aligned(16))) double img[2][P * P];
+    __shared__ double red[4][S];
+    __shared__ int stop_flag;
+    const int tid = threadIdx.x;
+    // the field loads are issued first so that they overlap the replay of the previous group's exit test
+    const int tx = tid & 15, ty = tid >> 4;
+    const int lx = 2 * tx, ly = 2 * ty;                      // patch origin inside the region
+    const int x0 = blockIdx.x * T, y0 = blockIdx.y * T;      // own tile origin
+    const int gx = x0 - S + lx, gy = y0 - S + ly;            // global coords of the patch origin
+    double u[2][2], ff[2][2];
+    bool inter[2][2], own[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int gi = gx + a, gj = gy + b;
+            const bool in = gi >= 0 && gj >= 0 && gi < nx && gj < ny;
+            const size_t g = in ? (size_t)gi + (size_t)nx * gj : 0;
+            u[b][a] = in ? uin[g] : 0.0;
+            ff[b][a] = in ? f[g] : 0.0;
+            inter[b][a] = gi >= 1 && gj >= 1 && gi < nx - 1 && gj < ny - 1;     // updated points
+            own[b][a] = in && gi >= x0 && gi < x0 + T && gj >= y0 && gj < y0 + T;
+        }
+    if constexpr (STATE) {
+        if (state->done) return;
+        if (prev_nsw > 0) {
+            const int nblk = gridDim.x * gridDim.y;
+            const int lane = tid & 63, wv = tid >> 6;
+            for (int s = wv; s < prev_nsw; s += 4) {  // same summation order as k_jacobi_check_multi
+                double a = 0.0;
+                for (int i = lane; i < nblk; i += 64) a += prev_partials[(size_t)s * nblk + i];
+                a = fpr_wave_sum(a);
+                if (lane == 0) red[0][s] = a;  // S >= prev_nsw
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const double thresh = state->thresh;
+                int conv = -1;
+                double rms = 0.0;
+                for (int s = 0; s < prev_nsw; ++s) {
+                    rms = sqrt(red[0][s] / Ntot);
+                    if (rms < thresh) { conv = s; break; }
+                }
+                stop_flag = conv >= 0;
+                if (blockIdx.x == 0 && blockIdx.y == 0) {
+                    state->iters += (conv >= 0) ? conv + 1 : prev_nsw;
+                    state->last_rms = rms;
+                    if (conv >= 0) {
+                        state->redo = conv + 1;
+                        state->group = prev_group;
+                        state->done = 1;
+                    }
+                }
+            }
+            __syncthreads();
+            if (stop_flag) return;
+        }
+    }
+    double acc[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc[s] = 0.0;
+    // clamped neighbour offsets (reads beyond the region return the thread's own edge value: such
+    // garbage stays more than S cells away from the own tile)
+    const int xl = lx > 0 ? lx - 1 : lx, xr = lx + 2 < P ? lx + 2 : lx + 1;
+    const int yd = ly > 0 ? ly - 1 : ly, yu = ly + 2 < P ? ly + 2 : ly + 1;
+    {
+        double* w = img[0];
+        *reinterpret_cast<double2*>(&w[lx + P * ly]) = make_double2(u[0][0], u[0][1]);
+        *reinterpret_cast<double2*>(&w[lx + P * (ly + 1)]) = make_double2(u[1][0], u[1][1]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s < nsw) {
+            const double* cur = img[s & 1];
+            double* nxt = img[(s + 1) & 1];
+            const double wl0 = cur[xl + P * ly], wl1 = cur[xl + P * (ly + 1)];
+            const double er0 = cur[xr + P * ly], er1 = cur[xr + P * (ly + 1)];
+            const double2 dn = *reinterpret_cast<const double2*>(&cur[lx + P * yd]);
+            const double2 up = *reinterpret_cast<const double2*>(&cur[lx + P * yu]);
+            // E, W, N, S of each patch point
+            const double E[2][2] = {{u[0][1], er0}, {u[1][1], er1}};
+            const double W[2][2] = {{wl0, u[0][0]}, {wl1, u[1][0]}};
+            const double N[2][2] = {{u[1][0], u[1][1]}, {up.x, up.y}};
+            const double Sx[2][2] = {{dn.x, dn.y}, {u[0][0], u[0][1]}};
+            double un[2][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const double rr = ((((E[b][a] + W[b][a]) + N[b][a]) + Sx[b][a]) - C * u[b][a]) * _h2 - ff[b][a];
+                    un[b][a] = inter[b][a] ? u[b][a] + fac * rr : u[b][a];
+                    if constexpr (NORM) {
+                        if (inter[b][a] && own[b][a]) acc[s] += rr * rr;
+                    }
+                }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) u[b][a] = un[b][a];
+            *reinterpret_cast<double2*>(&nxt[lx + P * ly]) = make_double2(u[0][0], u[0][1]);
+            *reinterpret_cast<double2*>(&nxt[lx + P * (ly + 1)]) = make_double2(u[1][0], u[1][1]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+            if (own[b][a]) uout[(size_t)(gx + a) + (size_t)nx * (gy + b)] = u[b][a];
+    if constexpr (NORM) {
+        const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const double v = fpr_wave_sum(acc[s]);
+            if (lane == 0) red[wv][s] = v;
+        }
+        __syncthreads();
+        if (tid < S) {
+            const int blk = blockIdx.x + gridDim.x * blockIdx.y, nblk = gridDim.x * gridDim.y;
+            partials[(size_t)tid * nblk + blk] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        }
+    }
+}
+
 // ---- residual + injection (+ Neumann rows) into the coarse rhs ------------------------------------
 // one thread per COARSE point; (nx, ny) = fine dims.  multigrid.jl:128-129, 330-358
 __global__ __launch_bounds__(256) void k_restrict_residual2d(const double* __restrict__ u, const double* __restrict__ f,
@@ -407,26 +553,31 @@ __global__ __launch_bounds__(256) void k_jacobi_check(FprSolveState* st, const d
 __global__ __launch_bounds__(256) void k_jacobi_check_multi(FprSolveState* st, const double* __restrict__ partials, int nblk,
                                                              int nsw, double N, int group)
 {
-    __shared__ double red[16];
-    __shared__ int stop;
+    __shared__ double sums[16];
     if (st->done) return;
-    if (threadIdx.x == 0) stop = 0;
+    // wave w sums the partials of sweeps w, w+4, ... in a fixed order; then thread 0 replays the tests
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int s = wv; s < nsw; s += 4) {
+        double a = 0.0;
+        for (int i = lane; i < nblk; i += 64) a += partials[(size_t)s * nblk + i];
+        a = fpr_wave_sum(a);
+        if (lane == 0) sums[s] = a;
+    }
     __syncthreads();
-    for (int s = 0; s < nsw; ++s) {
-        const double sum = fpr_sum_partials_256(partials + (size_t)s * nblk, nblk, red);
-        if (threadIdx.x == 0) {
-            const double rms = sqrt(sum / N);
-            st->iters += 1;
+    if (threadIdx.x == 0) {
+        int it = st->iters;
+        for (int s = 0; s < nsw; ++s) {
+            const double rms = sqrt(sums[s] / N);
+            it += 1;
             st->last_rms = rms;
             if (rms < st->thresh) {
                 st->done = 1;
                 st->redo = s + 1;
                 st->group = group;
-                stop = 1;
+                break;
             }
         }
-        __syncthreads();
-        if (stop) return;
+        st->iters = it;
     }
 }
 
@@ -1106,19 +1257,37 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
         if (fpr_opt(ctx, "mg_multi", 1) && nx >= 32 && ny >= 32) {
             // groups of S fused sweeps per launch; the exit test is replayed per sweep on the device
             constexpr int S = 8, TX = 16, TY = 16;
+            const bool patch = fpr_opt(ctx, "mg_patch", 1) != 0;
             const dim3 gm((nx + TX - 1) / TX, (ny + TY - 1) / TY);
             const int nblk = (int)(gm.x * gm.y);
             if ((size_t)nblk * S > (size_t)FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
-            const int groups = (iters + S - 1) / S;
+            int Sg = (int)fpr_opt(ctx, "mg_group_sweeps", S);  // sweeps per launch (<= S; tuning/diagnostic knob)
+            if (Sg < 1 || Sg > S) Sg = S;
+            const int groups = (iters + Sg - 1) / Sg;
             double* a = u;
             double* b = L.tmp;
             int gdone = 0;
+            int chunk_groups = 8;
+            if ((size_t)nblk * S * 2 > (size_t)FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
             while (gdone < groups) {
-                const int gend = (gdone + 8 < groups) ? gdone + 8 : groups;  // poll the state every 64 sweeps
+                // poll the solver state after 8 groups, then after ever longer chunks (up to 64 groups = 512 sweeps)
+                const int gend = (gdone + chunk_groups < groups) ? gdone + chunk_groups : groups;
+                if (chunk_groups < 64) chunk_groups *= 2;
                 for (int gi = gdone; gi < gend; ++gi) {
-                    const int nsw = (iters - gi * S < S) ? iters - gi * S : S;
-                    k_sweep2d_multi<S, TX, TY, 2, true><<<gm, 256, 0, s>>>(a, rhs, b, nx, ny, C, _h2, fac, nsw, ctx->partials, ctx->state);
-                    k_jacobi_check_multi<<<1, 256, 0, s>>>(ctx->state, ctx->partials, nblk, nsw, (double)N, gi);
+                    const int nsw = (iters - gi * Sg < Sg) ? iters - gi * Sg : Sg;
+                    if (patch) {
+                        // group gi writes partial slot gi&1 and first replays the exit test of group gi-1
+                        double* slot = ctx->partials + (size_t)(gi & 1) * S * nblk;
+                        const double* pslot = ctx->partials + (size_t)((gi + 1) & 1) * S * nblk;
+                        const bool pending = gi > gdone;  // the previous group of THIS chunk is still unchecked
+                        k_jacobi_patch<S, true, true><<<gm, 256, 0, s>>>(a, rhs, b, nx, ny, C, _h2, fac, nsw, slot, ctx->state,
+                                                                          pslot, pending ? Sg : 0, gi - 1, (double)N);
+                        if (gi == gend - 1)  // last group of the chunk: stand-alone check before the host polls
+                            k_jacobi_check_multi<<<1, 256, 0, s>>>(ctx->state, slot, nblk, nsw, (double)N, gi);
+                    } else {
+                        k_sweep2d_multi<S, TX, TY, 2, true><<<gm, 256, 0, s>>>(a, rhs, b, nx, ny, C, _h2, fac, nsw, ctx->partials, ctx->state);
+                        k_jacobi_check_multi<<<1, 256, 0, s>>>(ctx->state, ctx->partials, nblk, nsw, (double)N, gi);
+                    }
                     double* t = a; a = b; b = t;
                 }
                 FPR_CHECK_LAUNCH(ctx);
@@ -1131,9 +1300,11 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                 const int gs = ctx->state_h->group, redo = ctx->state_h->redo;
                 double* in = (gs & 1) ? L.tmp : u;
                 double* out = (gs & 1) ? u : L.tmp;
-                const int nsw_g = (iters - gs * S < S) ? iters - gs * S : S;
-                if (redo < nsw_g)  // the exit fell inside the group: recompute exactly `redo` sweeps from its input
-                    k_sweep2d_multi<S, TX, TY, 0, false><<<gm, 256, 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, redo, nullptr, nullptr);
+                const int nsw_g = (iters - gs * Sg < Sg) ? iters - gs * Sg : Sg;
+                if (redo < nsw_g) {  // the exit fell inside the group: recompute exactly `redo` sweeps from its input
+                    if (patch) k_jacobi_patch<S, false, false><<<gm, 256, 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, redo, nullptr, nullptr, nullptr, 0, 0, 0.0);
+                    else k_sweep2d_multi<S, TX, TY, 0, false><<<gm, 256, 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, redo, nullptr, nullptr);
+                }
                 result = out;
             } else {
                 result = (groups & 1) ? L.tmp : u;

@@ -275,10 +275,13 @@ def test_coarse_jacobi_exit_inside_a_fused_group(fpr, oracle, tol):
     h = 1.0 / 128
     u_ref = u0.copy(order="F")
     r_ref = oracle.vcycle2d(u_ref, f, h, 0.0, tol, 129, 0, False)
-    gu = F.asdevice(u0)
-    r = mg.Vcycle_2DPoisson_(gu, F.asdevice(f), h, 0.0, tol, 129, mg.jacobi, mg.parallel_shmem, False)
-    assert abs(r - r_ref) <= 1e-12 * abs(r_ref)
-    assert np.array_equal(F.tonumpy(gu), u_ref)
+    for patch in (1, 0):  # register-patch kernel (default) and the generic LDS-tile kernel
+        F.ctx().set_option("mg_patch", patch)
+        gu = F.asdevice(u0)
+        r = mg.Vcycle_2DPoisson_(gu, F.asdevice(f), h, 0.0, tol, 129, mg.jacobi, mg.parallel_shmem, False)
+        F.ctx().set_option("mg_patch", 1)
+        assert abs(r - r_ref) <= 1e-12 * abs(r_ref)
+        assert np.array_equal(F.tonumpy(gu), u_ref)
 
 
 def test_multisweep_and_single_sweep_paths_agree(fpr):

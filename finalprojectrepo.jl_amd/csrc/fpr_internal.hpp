@@ -26,6 +26,7 @@ struct FprSolveState {
     double last_rms; // r_rms of the last executed iteration
     double thresh;   // tol * rms(rhs)   (Jacobi)  or  tol * ||b||  (CG)
     double rho, rho_old, alpha, beta, pq;  // CG scalars
+    double rho2[2];  // CG: rho double-buffered by iteration parity (fused 3-launch iteration)
 };
 
 struct FprLevel {  // one multigrid level's scratch (role of prealloc_dict, multigrid.jl:25-38)

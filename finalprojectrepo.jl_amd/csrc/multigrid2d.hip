@@ -188,25 +188,33 @@ __device__ __forceinline__ double prolong_bf(const double* __restrict__ cc, int 
 // sweeps (multigrid.jl:124-125 / :142-143).  Point arithmetic is that of k_sweep2d: bit-identical.
 // PROLONG: the input is corrected on the fly, u = uin - P(corr_c) (multigrid.jl:136-139 fused into the
 // post-smoothing pass: the prolongation/correction pass over the fine grid disappears).
-template <bool NORM, bool PROLONG>
+// RESTRICT: a third stage evaluates the residual of the twice-smoothed field at the injected points
+// (even row, even column) from a 3-row window of the output and writes the coarse right-hand side and
+// the zero initial coarse correction (multigrid.jl:128-132): the residual/restriction pass disappears
+// too.  Strips then overlap by 6 columns and chunks by 3+2 rows.  Coarse boundary points get 0; the
+// Neumann rows of apply_BCs are copied afterwards by k_bc_neumann on the (small) coarse array.
+template <bool NORM, bool PROLONG, bool RESTRICT>
 __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict__ uin, const double* __restrict__ f,
                                                         double* __restrict__ uout, int nx, int ny, double C, double _h2,
                                                         double fac, int rows_per_chunk, int nstrips,
                                                         double* __restrict__ partials, const double* __restrict__ corr_c,
-                                                        int apply_BCs)
+                                                        int apply_BCs, double* __restrict__ res_c_out,
+                                                        double* __restrict__ corr_c_out)
 {
     __shared__ double red[16];
+    constexpr int HX = RESTRICT ? 3 : 2;                     // feeder lanes on each side of a strip
+    constexpr int SW = 64 - 2 * HX;                          // columns owned by a strip
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + w;
     const bool active = strip < nstrips;
-    const int gi = strip * 60 - 2 + lane;                    // global column of this lane
+    const int gi = strip * SW - HX + lane;                   // global column of this lane
     const bool col_ok = active && gi >= 0 && gi < nx;
     const int gic = gi < 0 ? 0 : (gi > nx - 1 ? nx - 1 : gi);  // clamped for loads
     const bool col_bnd = gi <= 0 || gi >= nx - 1;            // domain boundary column (or outside)
-    const bool owner = col_ok && lane >= 2 && lane < 62;
+    const bool owner = col_ok && lane >= HX && lane < 64 - HX;
     const int y0 = blockIdx.y * rows_per_chunk;
     const int y1 = (y0 + rows_per_chunk < ny) ? y0 + rows_per_chunk : ny;  // output rows [y0, y1)
-    const int rs = y0 - 2 < 0 ? 0 : y0 - 2;
+    const int rs = y0 - HX < 0 ? 0 : y0 - HX;
     double acc = 0.0;
     if (active) {
         const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
@@ -222,8 +230,10 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
         double a0 = 0.0, a1 = 0.0, a2 = ldu(rs);       // u   rows r-2, r-1, r
         double b0 = 0.0, b1 = 0.0, b2 = 0.0;           // u1  rows r-3, r-2, r-1
         double f0 = 0.0, f1 = 0.0, f2 = ldf(rs);       // f   rows r-2, r-1, r
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0, fm = 0.0; // RESTRICT: u2 rows r-4, r-3, r-2 and f row r-3
         double an = ldu(rs + 1), fn = ldf(rs + 1);     // prefetched row r+1
-        for (int r = rs; r <= y1 + 1; ++r) {
+        const int nxc_r = 1 + (nx - 1) / 2, nyc_r = 1 + (ny - 1) / 2;
+        for (int r = rs; r <= y1 + (RESTRICT ? 2 : 1); ++r) {
             const double an2 = ldu(r + 2), fn2 = ldf(r + 2);  // issue the loads of row r+2
             // ---- sweep 1 at row r-1 (needs u rows r-2, r-1, r) ----
             const int j1 = r - 1;
@@ -248,6 +258,23 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
                         if (!bnd) acc += rr * rr;
                     }
                 }
+                if constexpr (RESTRICT) {
+                    c0 = c1; c1 = c2; c2 = u2;         // u2 rows r-4, r-3, r-2
+                }
+            }
+            if constexpr (RESTRICT) {
+                // ---- residual of u2 at row r-3, injected at even (row, column) ----
+                const int j3 = r - 3;
+                const double L = __shfl_up(c1, 1, 64), R = __shfl_down(c1, 1, 64);
+                const double rr = ((((R + L) + c2) + c0) - C * c1) * _h2 - fm;
+                if (owner && j3 >= y0 && j3 < y1 && !(j3 & 1) && !(gi & 1)) {
+                    const int ic = gi >> 1, jc = j3 >> 1;
+                    const bool cint = ic >= 1 && ic <= nxc_r - 2 && jc >= 1 && jc <= nyc_r - 2;
+                    const size_t cid = (size_t)ic + (size_t)nxc_r * jc;
+                    res_c_out[cid] = cint ? rr : 0.0;
+                    corr_c_out[cid] = 0.0;
+                }
+                fm = f0;                               // becomes f row (r+1)-3
             }
             a0 = a1; a1 = a2; a2 = an; an = an2;
             f0 = f1; f1 = f2; f2 = fn; fn = fn2;
@@ -528,6 +555,8 @@ __global__ void k_state_init(FprSolveState* st, const double* sumsq, double tol,
     st->last_rms = 0.0;
     st->thresh = cg ? tol * sqrt(sumsq[0]) : tol * sqrt(sumsq[0] / N);
     st->rho = sumsq[0];  // CG: rho = sum(r.*r) with r = b (krylov.jl:64)
+    st->rho2[0] = sumsq[0];
+    st->rho2[1] = 0.0;
     st->rho_old = 0.0;
     st->alpha = 0.0;
     st->beta = 0.0;
@@ -665,6 +694,69 @@ __global__ __launch_bounds__(256) void k_cg_check(FprSolveState* st, const doubl
             st->beta = st->rho / st->rho_old; // krylov.jl:84
         }
     }
+}
+
+// ---- fused CG iteration: 3 dependent launches instead of 5 ---------------------------------------------
+// k_cg_matvec_dot -> k_cg_update_f (every workgroup derives alpha from the dot partials) ->
+// k_cg_p_f (every workgroup derives ||r||, the exit test and beta from the r.r partials).
+// rho is double-buffered by iteration parity so that workgroup 0 can publish the new value while the
+// others still read the old one.  `it` = 0-based iteration index.
+__global__ __launch_bounds__(256) void k_cg_update_f(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
+                                                      const double* __restrict__ ph, size_t n, const double* __restrict__ pq_partials,
+                                                      int npq, double* __restrict__ partials, FprSolveState* __restrict__ st, int it)
+{
+    __shared__ double red[16];
+    __shared__ double s_alpha;
+    if (st->done) return;
+    const double pq = fpr_sum_partials_256(pq_partials, npq, red);
+    if (threadIdx.x == 0) {
+        const double alpha = st->rho2[it & 1] / pq;  // krylov.jl:69
+        s_alpha = alpha;
+        if (blockIdx.x == 0) { st->pq = pq; st->alpha = alpha; }
+    }
+    __syncthreads();
+    const double alpha = s_alpha;
+    const size_t stride = (size_t)gridDim.x * 256;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        x[i] = x[i] + alpha * p[i];
+        const double rn = r[i] - alpha * ph[i];
+        r[i] = rn;
+        acc += rn * rn;
+    }
+    __syncthreads();
+    const double sblk = fpr_block_sum<256>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = sblk;
+}
+
+__global__ __launch_bounds__(256) void k_cg_p_f(double* __restrict__ p, const double* __restrict__ r, size_t n,
+                                                 const double* __restrict__ rr_partials, int nrr, FprSolveState* __restrict__ st,
+                                                 int it, double N)
+{
+    __shared__ double red[16];
+    __shared__ double s_beta;
+    __shared__ int s_conv;
+    if (st->done) return;
+    const double rr = fpr_sum_partials_256(rr_partials, nrr, red);
+    if (threadIdx.x == 0) {
+        const double normr = sqrt(rr);
+        const int conv = normr < st->thresh;          // krylov.jl:76
+        const double rho_old = st->rho2[it & 1];
+        const double beta = rr / rho_old;             // krylov.jl:83-84
+        s_conv = conv;
+        s_beta = beta;
+        if (blockIdx.x == 0) {
+            st->iters = it + 1;
+            st->last_rms = sqrt(rr / N);              // krylov.jl:90
+            if (conv) st->done = 1;
+            else { st->rho2[(it + 1) & 1] = rr; st->rho_old = rho_old; st->rho = rr; st->beta = beta; }
+        }
+    }
+    __syncthreads();
+    if (s_conv) return;
+    const double beta = s_beta;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = r[i] + beta * p[i];  // krylov.jl:85
 }
 
 // p .= r + beta p  (krylov.jl:85)
@@ -1035,17 +1127,24 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
     if (int rc = fprx_dot_dev(ctx, b, b, N, ctx->scalars + 2)) return rc;
     k_state_init<<<1, 1, 0, s>>>(ctx->state, ctx->scalars + 2, tol, (double)N, 1);
     FPR_CHECK_LAUNCH(ctx);
-    const int chunk = 32;
+    const int chunk = 64;
+    const bool fused = fpr_opt(ctx, "cg_fused", 1) != 0;
     int done_iters = 0;
     ctx->state_h->done = 0; ctx->state_h->iters = 0; ctx->state_h->last_rms = 0.0;
     while (done_iters < Nmax) {
         const int m = (Nmax - done_iters < chunk) ? Nmax - done_iters : chunk;
         for (int i = 0; i < m; ++i) {
+            const int it = done_iters + i;
             k_cg_matvec_dot<<<g2, blk2, 0, s>>>(w.p, w.ph, nx, ny, hx * hx, hy * hy, c, ctx->partials, ctx->state);
-            k_cg_alpha<<<1, 256, 0, s>>>(ctx->state, ctx->partials, np2);
-            k_cg_update<<<fg, 256, 0, s>>>(w.x, w.r, w.p, w.ph, N, ctx->partials2, ctx->state);
-            k_cg_check<<<1, 256, 0, s>>>(ctx->state, ctx->partials2, fg, (double)N);
-            k_cg_p<<<fg, 256, 0, s>>>(w.p, w.r, N, ctx->state);
+            if (fused) {
+                k_cg_update_f<<<fg, 256, 0, s>>>(w.x, w.r, w.p, w.ph, N, ctx->partials, np2, ctx->partials2, ctx->state, it);
+                k_cg_p_f<<<fg, 256, 0, s>>>(w.p, w.r, N, ctx->partials2, fg, ctx->state, it, (double)N);
+            } else {
+                k_cg_alpha<<<1, 256, 0, s>>>(ctx->state, ctx->partials, np2);
+                k_cg_update<<<fg, 256, 0, s>>>(w.x, w.r, w.p, w.ph, N, ctx->partials2, ctx->state);
+                k_cg_check<<<1, 256, 0, s>>>(ctx->state, ctx->partials2, fg, (double)N);
+                k_cg_p<<<fg, 256, 0, s>>>(w.p, w.r, N, ctx->state);
+            }
         }
         FPR_CHECK_LAUNCH(ctx);
         done_iters += m;
@@ -1169,7 +1268,9 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
         const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
         if (fpr_opt(ctx, "mg_multi", 1) == 1 && nx >= 64 && ny >= 16) {
             // temporal blocking, register-rolling march: each smoothing pair is ONE pass (u -> tmp, tmp -> u)
+            const bool fuse_r = fpr_opt(ctx, "mg_fuse_restrict", 1) != 0;
             const int nstrips = (nx + 59) / 60;
+            const int nstrips_r = (nx + 57) / 58;  // strips of the restricting pre-smoothing pass
             int rpc = (int)fpr_opt(ctx, "mg_rows_per_chunk", 0);
             if (rpc <= 0) {  // enough chunks for >= ~16 waves per CU, chunks of at least 16 rows
                 rpc = 64;
@@ -1178,8 +1279,14 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             const dim3 gm((nstrips + 3) / 4, (ny + rpc - 1) / rpc);
             const int npm = (int)(gm.x * gm.y);
             const bool fuse_p = fpr_opt(ctx, "mg_fuse_prolong", 1) != 0;
-            k_smooth2_march<false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0);  // :124-125
-            k_restrict_residual2d<<<grid2(nxc, nyc), blk2, 0, s>>>(L.tmp, rhs, L.res_c, nx, ny, C, _h2, apply_BCs, L.corr_c);  // :128-132
+            if (fuse_r) {  // pre-smoothing pair + residual + injection + zero coarse guess in ONE pass (:124-132)
+                const dim3 gr((nstrips_r + 3) / 4, (ny + rpc - 1) / rpc);
+                k_smooth2_march<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, 0, L.res_c, L.corr_c);
+                if (apply_BCs) k_bc_neumann<<<(nyc + 255) / 256, 256, 0, s>>>(L.res_c, nxc, nyc);  // :355-357
+            } else {
+                k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0, nullptr, nullptr);  // :124-125
+                k_restrict_residual2d<<<grid2(nxc, nyc), blk2, 0, s>>>(L.tmp, rhs, L.res_c, nx, ny, C, _h2, apply_BCs, L.corr_c);  // :128-132
+            }
             FPR_CHECK_LAUNCH(ctx);
             double dummy; bool dh;
             if (int rc = vcycle_level(ctx, A, d + 1, L.corr_c, L.res_c, h * 2, c, tol, css, solver, apply_BCs, false, &dummy, &dh))
@@ -1187,14 +1294,14 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             if (!fuse_p) k_prolong2d<true><<<g, blk2, 0, s>>>(L.corr_c, L.tmp, nx, ny, apply_BCs);  // :136-139
             // post-smoothing pair (:142-143); with fuse_p the correction u - P(corr_c) is applied while loading
             if (top) {
-                if (fuse_p) k_smooth2_march<true, true><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs);
-                else k_smooth2_march<true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, 0);
+                if (fuse_p) k_smooth2_march<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs, nullptr, nullptr);
+                else k_smooth2_march<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, 0, nullptr, nullptr);
                 FPR_CHECK_LAUNCH(ctx);
                 if (int rc = fprx_finish_sum(ctx, ctx->partials, npm, ctx->scalars, false, 0)) return rc;
                 *rms_is_host = false;
             } else {
-                if (fuse_p) k_smooth2_march<false, true><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs);
-                else k_smooth2_march<false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0);
+                if (fuse_p) k_smooth2_march<false, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs, nullptr, nullptr);
+                else k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0, nullptr, nullptr);
                 FPR_CHECK_LAUNCH(ctx);
             }
             return FPR_OK;

@@ -220,11 +220,39 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
         const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
         int gis = gic;  // Neumann rows of the prolongated correction (part2_utils.jl:35-39)
         if (PROLONG && apply_BCs) gis = (gic == 0) ? 1 : (gic == nx - 1 ? nx - 2 : gic);
+        // PROLONG: the two coarse columns this lane interpolates from, cached for coarse rows pj and pj+1
+        // (rows are visited in increasing order, so a coarse row is loaded once per two fine rows)
+        const int p_io = gis & 1, p_icl = gis >> 1, p_ich = (p_icl + 1 < nxc) ? p_icl + 1 : nxc - 1;
+        const bool p_sx0 = p_icl >= 1 && p_icl <= nxc - 2, p_sx1 = p_io && (p_icl + 1 <= nxc - 2);
+        const bool p_inx = gis >= 1 && gis <= nx - 2;
+        int pj = -2;
+        double pc00 = 0.0, pc10 = 0.0, pc01 = 0.0, pc11 = 0.0;
         auto ldu = [&](int r) {
             const int rc = r > ny - 1 ? ny - 1 : r;
             const double v = uin[(size_t)gic + (size_t)nx * rc];
-            if constexpr (PROLONG) return v - prolong_bf(corr_c, gis, rc, nx, ny, nxc, nyc);
-            else return v;
+            if constexpr (PROLONG) {
+                const int jo = rc & 1, jcl = rc >> 1;
+                if (jcl != pj) {
+                    const int jch = (jcl + 1 < nyc) ? jcl + 1 : nyc - 1;
+                    if (jcl == pj + 1) { pc00 = pc01; pc10 = pc11; }
+                    else { pc00 = corr_c[(size_t)p_icl + (size_t)nxc * jcl]; pc10 = corr_c[(size_t)p_ich + (size_t)nxc * jcl]; }
+                    pc01 = corr_c[(size_t)p_icl + (size_t)nxc * jch];
+                    pc11 = corr_c[(size_t)p_ich + (size_t)nxc * jch];
+                    pj = jcl;
+                }
+                // same value and accumulation order as prolong_bf
+                const bool in = p_inx && rc >= 1 && rc <= ny - 2;
+                const double wgt = (p_io | jo) ? ((p_io & jo) ? 0.25 : 0.5) : 1.0;
+                const bool sy0 = jcl >= 1 && jcl <= nyc - 2, sy1 = jo && (jcl + 1 <= nyc - 2);
+                double pv = 0.0;
+                pv = pv + ((in && p_sx0 && sy0) ? wgt * pc00 : 0.0);
+                pv = pv + ((in && p_sx1 && sy0) ? wgt * pc10 : 0.0);
+                pv = pv + ((in && p_sx0 && sy1) ? wgt * pc01 : 0.0);
+                pv = pv + ((in && p_sx1 && sy1) ? wgt * pc11 : 0.0);
+                return v - pv;
+            } else {
+                return v;
+            }
         };
         auto ldf = [&](int r) { const int rc = r > ny - 1 ? ny - 1 : r; return f[(size_t)gic + (size_t)nx * rc]; };
         double a0 = 0.0, a1 = 0.0, a2 = ldu(rs);       // u   rows r-2, r-1, r
@@ -915,6 +943,35 @@ __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
         int it = 0;
         double* pin = U;
         double* pout = T;
+        if (N <= 64) {
+            // tiny coarsest grid (5x5, 9x5, ...): one point per lane of wave 0, all in registers --
+            // neighbours by wavefront shuffles, norm by a butterfly (every lane gets the same bits), no barrier
+            if (tid < 64) {
+                const int lane = tid;
+                const bool in = lane < N;
+                const int j = lane / nx, i = lane - j * nx;
+                const bool inter = in && i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1;
+                double uu = in ? U[lane] : 0.0;
+                const double fv = in ? F[lane] : 0.0;
+                for (int k = 1; k <= iters; ++k) {
+                    const double E = __shfl(uu, lane + 1, 64), W = __shfl(uu, lane - 1, 64);
+                    const double Nn = __shfl(uu, lane + nx, 64), Ss = __shfl(uu, lane - nx, 64);
+                    const double r = ((((E + W) + Nn) + Ss) - C * uu) * _h2 - fv;
+                    double sq = inter ? r * r : 0.0;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+                    res_rms = sqrt(sq / (double)N);
+                    if (inter) uu = uu + fac * r;
+                    it = k;
+                    if (res_rms < tol_rhs) break;
+                }
+                if (in) U[lane] = uu;
+                if (tid == 0) { red[MGS_RED - 1] = res_rms; red[MGS_RED - 2] = (double)it; }
+            }
+            __syncthreads();
+            res_rms = red[MGS_RED - 1];
+            it = (int)red[MGS_RED - 2];
+        } else
         for (int i = 1; i <= iters; ++i) {
             const double s = mgs_block_sum(mgs_sweep(pin, F, pout, nx, ny, C, _h2, fac), red);  // syncs inside
             res_rms = sqrt(s / (double)N);

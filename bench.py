@@ -92,6 +92,18 @@ def vcycle_secondary(F, steps=3):
         t = sorted(ts)[len(ts) // 2]
         out[label] = {"mgsolve_s": t, "vcycles": ncyc, "s_per_vcycle": t / max(ncyc, 1), "coarse_iters": int(cit),
                       "rel_residual": r / frms}
+    # BASELINE config 5: Navier-Stokes step around the V-cycle at 2049^2 (buoyancy-driven convection --
+    # the reference has no lid-driven cavity), semi-implicit beta=0.5, tol 1e-7, 3 MG solves per step
+    try:
+        p2 = F.part2
+        opt = p2.SimIn_t()
+        opt.nx = opt.ny = 2049
+        opt.beta, opt.tol, opt.Pr, opt.ttot = 0.5, 1.0e-7, 1.0, 1.0e9
+        res = p2.navier_stokes_2D(opt=opt, verbose=False, max_steps=7)
+        out["ns_semi_implicit_2049sq"] = {"s_per_step": res.t_elapsed / max(res.timed_iters, 1), "timed_steps": res.timed_iters,
+                                          "note": "beta=0.5, Pr=1, Ra=1e6, tol=1e-7, niters=50; T solve hits niters as in the reference"}
+    except Exception as e:
+        out["ns_semi_implicit_2049sq"] = {"error": repr(e)}
     return out
 
 

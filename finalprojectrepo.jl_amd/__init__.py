@@ -44,4 +44,4 @@ def synchronize():
     ctx().synchronize()
 
 
-from . import part1, multigrid, part2, grid  # noqa: E402,F401
+from . import part1, multigrid, part2, grid, experiments  # noqa: E402,F401

@@ -1330,8 +1330,9 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             const int nstrips_r = (nx + 57) / 58;  // strips of the restricting pre-smoothing pass
             int rpc = (int)fpr_opt(ctx, "mg_rows_per_chunk", 0);
             if (rpc <= 0) {  // enough chunks for >= ~16 waves per CU, chunks of at least 16 rows
+                const long target = fpr_opt(ctx, "mg_wave_target", 4096);
                 rpc = 64;
-                while (rpc > 16 && (long)nstrips * ((ny + rpc - 1) / rpc) < 4096) rpc >>= 1;
+                while (rpc > 16 && (long)nstrips * ((ny + rpc - 1) / rpc) < target) rpc >>= 1;
             }
             const dim3 gm((nstrips + 3) / 4, (ny + rpc - 1) / rpc);
             const int npm = (int)(gm.x * gm.y);

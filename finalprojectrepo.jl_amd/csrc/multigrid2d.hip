@@ -460,6 +460,191 @@ __global__ __launch_bounds__(256) void k_jacobi_patch(const double* __restrict__
     }
 }
 
+// ---- k_smooth2_march, two columns per lane (opt-in; measured slower) -------------------------------------------------
+// Same algorithm as k_smooth2_march with a strip of 128 columns per wave: a lane holds two adjacent
+// columns, loads/stores them with one 16-byte access (the hardware accepts the 8-byte alignment that
+// (2^k+1)-wide rows impose), needs a shuffle only for the outer neighbour of each pair, and halves the
+// loop and address arithmetic per point.
+struct __attribute__((aligned(8))) FprD2 { double x, y; };
+
+template <bool NORM, bool PROLONG, bool RESTRICT>
+__global__ __launch_bounds__(256) void k_smooth2_march2(const double* __restrict__ uin, const double* __restrict__ f,
+                                                         double* __restrict__ uout, int nx, int ny, double C, double _h2,
+                                                         double fac, int rows_per_chunk, int nstrips,
+                                                         double* __restrict__ partials, const double* __restrict__ corr_c,
+                                                         int apply_BCs, double* __restrict__ res_c_out,
+                                                         double* __restrict__ corr_c_out)
+{
+    __shared__ double red[16];
+    constexpr int HX = RESTRICT ? 3 : 2;   // feeder COLUMNS on each side of a strip
+    constexpr int SW = 128 - 2 * HX;       // columns owned by a strip
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + w;
+    const bool active = strip < nstrips;
+    const int g0 = strip * SW - HX + 2 * lane;   // global column of element 0 (element 1 = g0 + 1)
+    const int y0 = blockIdx.y * rows_per_chunk;
+    const int y1 = (y0 + rows_per_chunk < ny) ? y0 + rows_per_chunk : ny;
+    const int rs = y0 - HX < 0 ? 0 : y0 - HX;
+    double acc = 0.0;
+    if (active) {
+        const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
+        int gi[2], gic[2], gis[2];
+        bool colbnd[2], owner[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            gi[e] = g0 + e;
+            gic[e] = gi[e] < 0 ? 0 : (gi[e] > nx - 1 ? nx - 1 : gi[e]);
+            colbnd[e] = gi[e] <= 0 || gi[e] >= nx - 1;
+            const int q = 2 * lane + e;
+            owner[e] = gi[e] >= 0 && gi[e] < nx && q >= HX && q < 128 - HX;
+            gis[e] = gic[e];
+            if (PROLONG && apply_BCs) gis[e] = (gic[e] == 0) ? 1 : (gic[e] == nx - 1 ? nx - 2 : gic[e]);
+        }
+        const bool vec_ok = g0 >= 0 && g0 + 1 < nx;  // both columns exist: one 16-byte access
+        // PROLONG: per element, the two coarse columns it interpolates from, cached for coarse rows pj, pj+1
+        int p_icl[2], p_ich[2], p_io[2];
+        bool p_sx0[2], p_sx1[2], p_inx[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            p_io[e] = gis[e] & 1;
+            p_icl[e] = gis[e] >> 1;
+            p_ich[e] = (p_icl[e] + 1 < nxc) ? p_icl[e] + 1 : nxc - 1;
+            p_sx0[e] = p_icl[e] >= 1 && p_icl[e] <= nxc - 2;
+            p_sx1[e] = p_io[e] && (p_icl[e] + 1 <= nxc - 2);
+            p_inx[e] = gis[e] >= 1 && gis[e] <= nx - 2;
+        }
+        int pj = -2;
+        double pc00[2] = {0.0, 0.0}, pc10[2] = {0.0, 0.0}, pc01[2] = {0.0, 0.0}, pc11[2] = {0.0, 0.0};
+        auto ld2 = [&](const double* __restrict__ p, int r, double& v0, double& v1) {
+            const int rc = r > ny - 1 ? ny - 1 : r;
+            const size_t row = (size_t)nx * rc;
+            if (vec_ok) {
+                const FprD2 t = *reinterpret_cast<const FprD2*>(p + row + g0);
+                v0 = t.x; v1 = t.y;
+            } else {
+                v0 = p[row + gic[0]]; v1 = p[row + gic[1]];
+            }
+        };
+        auto ldu = [&](int r, double& v0, double& v1) {
+            ld2(uin, r, v0, v1);
+            if constexpr (PROLONG) {
+                const int rc = r > ny - 1 ? ny - 1 : r;
+                const int jo = rc & 1, jcl = rc >> 1;
+                if (jcl != pj) {
+                    const int jch = (jcl + 1 < nyc) ? jcl + 1 : nyc - 1;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (jcl == pj + 1) { pc00[e] = pc01[e]; pc10[e] = pc11[e]; }
+                        else { pc00[e] = corr_c[(size_t)p_icl[e] + (size_t)nxc * jcl]; pc10[e] = corr_c[(size_t)p_ich[e] + (size_t)nxc * jcl]; }
+                        pc01[e] = corr_c[(size_t)p_icl[e] + (size_t)nxc * jch];
+                        pc11[e] = corr_c[(size_t)p_ich[e] + (size_t)nxc * jch];
+                    }
+                    pj = jcl;
+                }
+                const bool sy0 = jcl >= 1 && jcl <= nyc - 2, sy1 = jo && (jcl + 1 <= nyc - 2);
+                const bool iny = rc >= 1 && rc <= ny - 2;
+                double pv[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {  // same value and accumulation order as prolong_bf
+                    const bool in = p_inx[e] && iny;
+                    const double wgt = (p_io[e] | jo) ? ((p_io[e] & jo) ? 0.25 : 0.5) : 1.0;
+                    double t = 0.0;
+                    t = t + ((in && p_sx0[e] && sy0) ? wgt * pc00[e] : 0.0);
+                    t = t + ((in && p_sx1[e] && sy0) ? wgt * pc10[e] : 0.0);
+                    t = t + ((in && p_sx0[e] && sy1) ? wgt * pc01[e] : 0.0);
+                    t = t + ((in && p_sx1[e] && sy1) ? wgt * pc11[e] : 0.0);
+                    pv[e] = t;
+                }
+                v0 = v0 - pv[0];
+                v1 = v1 - pv[1];
+            }
+        };
+        double a0[2] = {0, 0}, a1[2] = {0, 0}, a2[2], an[2];   // u  rows r-2, r-1, r, r+1
+        double b0[2] = {0, 0}, b1[2] = {0, 0}, b2[2] = {0, 0}; // u1 rows r-3, r-2, r-1
+        double c0[2] = {0, 0}, c1[2] = {0, 0}, c2[2] = {0, 0}; // u2 rows r-4, r-3, r-2 (RESTRICT)
+        double f0[2] = {0, 0}, f1[2] = {0, 0}, f2[2], fn[2], fm[2] = {0, 0};
+        ldu(rs, a2[0], a2[1]);
+        ld2(f, rs, f2[0], f2[1]);
+        ldu(rs + 1, an[0], an[1]);
+        ld2(f, rs + 1, fn[0], fn[1]);
+        for (int r = rs; r <= y1 + (RESTRICT ? 2 : 1); ++r) {
+            double an2[2], fn2[2];
+            ldu(r + 2, an2[0], an2[1]);
+            ld2(f, r + 2, fn2[0], fn2[1]);
+            // ---- sweep 1 at row r-1 ----
+            const int j1 = r - 1;
+            double u1[2];
+            {
+                const double Lo = __shfl_up(a1[1], 1, 64), Ro = __shfl_down(a1[0], 1, 64);
+                const bool rowb = j1 <= 0 || j1 >= ny - 1;
+                const double rr0 = ((((a1[1] + Lo) + a2[0]) + a0[0]) - C * a1[0]) * _h2 - f1[0];
+                const double rr1 = ((((Ro + a1[0]) + a2[1]) + a0[1]) - C * a1[1]) * _h2 - f1[1];
+                u1[0] = (rowb || colbnd[0]) ? a1[0] : a1[0] + fac * rr0;
+                u1[1] = (rowb || colbnd[1]) ? a1[1] : a1[1] + fac * rr1;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { b0[e] = b1[e]; b1[e] = b2[e]; b2[e] = u1[e]; }
+            // ---- sweep 2 at row r-2 ----
+            const int j2 = r - 2;
+            {
+                const double Lo = __shfl_up(b1[1], 1, 64), Ro = __shfl_down(b1[0], 1, 64);
+                const bool rowb = j2 <= 0 || j2 >= ny - 1;
+                const double rr0 = ((((b1[1] + Lo) + b2[0]) + b0[0]) - C * b1[0]) * _h2 - f0[0];
+                const double rr1 = ((((Ro + b1[0]) + b2[1]) + b0[1]) - C * b1[1]) * _h2 - f0[1];
+                const bool bn0 = rowb || colbnd[0], bn1 = rowb || colbnd[1];
+                const double u20 = bn0 ? b1[0] : b1[0] + fac * rr0;
+                const double u21 = bn1 ? b1[1] : b1[1] + fac * rr1;
+                if (j2 >= y0 && j2 < y1) {
+                    const size_t o = (size_t)nx * j2;
+                    if (owner[0] && owner[1]) {
+                        FprD2 t; t.x = u20; t.y = u21;
+                        *reinterpret_cast<FprD2*>(uout + o + g0) = t;
+                    } else {
+                        if (owner[0]) uout[o + gi[0]] = u20;
+                        if (owner[1]) uout[o + gi[1]] = u21;
+                    }
+                    if constexpr (NORM) {
+                        if (owner[0] && !bn0) acc += rr0 * rr0;
+                        if (owner[1] && !bn1) acc += rr1 * rr1;
+                    }
+                }
+                if constexpr (RESTRICT) {
+                    c0[0] = c1[0]; c1[0] = c2[0]; c2[0] = u20;
+                    c0[1] = c1[1]; c1[1] = c2[1]; c2[1] = u21;
+                }
+            }
+            if constexpr (RESTRICT) {
+                // ---- residual of u2 at row r-3, injected at even (row, column): one of the lane's two columns ----
+                const int j3 = r - 3;
+                const double Lo = __shfl_up(c1[1], 1, 64), Ro = __shfl_down(c1[0], 1, 64);
+                const double rr0 = ((((c1[1] + Lo) + c2[0]) + c0[0]) - C * c1[0]) * _h2 - fm[0];
+                const double rr1 = ((((Ro + c1[0]) + c2[1]) + c0[1]) - C * c1[1]) * _h2 - fm[1];
+                if (j3 >= y0 && j3 < y1 && !(j3 & 1)) {
+                    const int e = (gi[0] & 1) ? 1 : 0;  // the even column
+                    const double rr = e ? rr1 : rr0;
+                    if (e ? owner[1] : owner[0]) {
+                        const int ic = (e ? gi[1] : gi[0]) >> 1, jc = j3 >> 1;
+                        const bool cint = ic >= 1 && ic <= nxc - 2 && jc >= 1 && jc <= nyc - 2;
+                        const size_t cid = (size_t)ic + (size_t)nxc * jc;
+                        res_c_out[cid] = cint ? rr : 0.0;
+                        corr_c_out[cid] = 0.0;
+                    }
+                }
+                fm[0] = f0[0]; fm[1] = f0[1];
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                a0[e] = a1[e]; a1[e] = a2[e]; a2[e] = an[e]; an[e] = an2[e];
+                f0[e] = f1[e]; f1[e] = f2[e]; f2[e] = fn[e]; fn[e] = fn2[e];
+            }
+        }
+    }
+    if constexpr (NORM) {
+        const double sblk = fpr_block_sum<256>(acc, red);
+        if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
+    }
+}
+
 // ---- residual + injection (+ Neumann rows) into the coarse rhs ------------------------------------
 // one thread per COARSE point; (nx, ny) = fine dims.  multigrid.jl:128-129, 330-358
 __global__ __launch_bounds__(256) void k_restrict_residual2d(const double* __restrict__ u, const double* __restrict__ f,
@@ -1326,8 +1511,12 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
         if (fpr_opt(ctx, "mg_multi", 1) == 1 && nx >= 64 && ny >= 16) {
             // temporal blocking, register-rolling march: each smoothing pair is ONE pass (u -> tmp, tmp -> u)
             const bool fuse_r = fpr_opt(ctx, "mg_fuse_restrict", 1) != 0;
-            const int nstrips = (nx + 59) / 60;
-            const int nstrips_r = (nx + 57) / 58;  // strips of the restricting pre-smoothing pass
+            // two columns per lane (128-column strips, 16-byte accesses at 8-byte alignment): measured 10 % SLOWER than
+            // one column per lane on MI355X (3.54 vs 3.20 ms per 4097^2 solve), so it is opt-in (mg_vx = 2)
+            const bool vx2 = fpr_opt(ctx, "mg_vx", 1) == 2 && nx >= 128;
+            const int sw = vx2 ? 124 : 60, sw_r = vx2 ? 122 : 58;
+            const int nstrips = (nx + sw - 1) / sw;
+            const int nstrips_r = (nx + sw_r - 1) / sw_r;  // strips of the restricting pre-smoothing pass
             int rpc = (int)fpr_opt(ctx, "mg_rows_per_chunk", 0);
             if (rpc <= 0) {  // enough chunks for >= ~16 waves per CU, chunks of at least 16 rows
                 const long target = fpr_opt(ctx, "mg_wave_target", 4096);
@@ -1339,10 +1528,10 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             const bool fuse_p = fpr_opt(ctx, "mg_fuse_prolong", 1) != 0;
             if (fuse_r) {  // pre-smoothing pair + residual + injection + zero coarse guess in ONE pass (:124-132)
                 const dim3 gr((nstrips_r + 3) / 4, (ny + rpc - 1) / rpc);
-                k_smooth2_march<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, 0, L.res_c, L.corr_c);
+                { if (vx2) k_smooth2_march2<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, 0, L.res_c, L.corr_c); else k_smooth2_march<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, 0, L.res_c, L.corr_c); }
                 if (apply_BCs) k_bc_neumann<<<(nyc + 255) / 256, 256, 0, s>>>(L.res_c, nxc, nyc);  // :355-357
             } else {
-                k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0, nullptr, nullptr);  // :124-125
+                { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0, nullptr, nullptr); else k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0, nullptr, nullptr); }  // :124-125
                 k_restrict_residual2d<<<grid2(nxc, nyc), blk2, 0, s>>>(L.tmp, rhs, L.res_c, nx, ny, C, _h2, apply_BCs, L.corr_c);  // :128-132
             }
             FPR_CHECK_LAUNCH(ctx);
@@ -1352,14 +1541,14 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             if (!fuse_p) k_prolong2d<true><<<g, blk2, 0, s>>>(L.corr_c, L.tmp, nx, ny, apply_BCs);  // :136-139
             // post-smoothing pair (:142-143); with fuse_p the correction u - P(corr_c) is applied while loading
             if (top) {
-                if (fuse_p) k_smooth2_march<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs, nullptr, nullptr);
-                else k_smooth2_march<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, 0, nullptr, nullptr);
+                if (fuse_p) { if (vx2) k_smooth2_march2<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs, nullptr, nullptr); else k_smooth2_march<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs, nullptr, nullptr); }
+                else { if (vx2) k_smooth2_march2<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, 0, nullptr, nullptr); else k_smooth2_march<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, 0, nullptr, nullptr); }
                 FPR_CHECK_LAUNCH(ctx);
                 if (int rc = fprx_finish_sum(ctx, ctx->partials, npm, ctx->scalars, false, 0)) return rc;
                 *rms_is_host = false;
             } else {
-                if (fuse_p) k_smooth2_march<false, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs, nullptr, nullptr);
-                else k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0, nullptr, nullptr);
+                if (fuse_p) { if (vx2) k_smooth2_march2<false, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs, nullptr, nullptr); else k_smooth2_march<false, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs, nullptr, nullptr); }
+                else { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0, nullptr, nullptr); else k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0, nullptr, nullptr); }
                 FPR_CHECK_LAUNCH(ctx);
             }
             return FPR_OK;

@@ -308,6 +308,11 @@ def test_multisweep_and_single_sweep_paths_agree(fpr):
     r = mg.Vcycle_2DPoisson_(gu, F.asdevice(f), 1.0 / 256, 0.3, 1e-7, 5, mg.jacobi, mg.parallel, True)
     outs.append((r, F.tonumpy(gu)))
     F.ctx().set_option("mg_fuse_restrict", 1)
+    F.ctx().set_option("mg_vx", 2)
+    gu = F.asdevice(u0)
+    r = mg.Vcycle_2DPoisson_(gu, F.asdevice(f), 1.0 / 256, 0.3, 1e-7, 5, mg.jacobi, mg.parallel, True)
+    outs.append((r, F.tonumpy(gu)))
+    F.ctx().set_option("mg_vx", 1)
     for r, u in outs[1:]:
         assert np.array_equal(u, outs[0][1])
         assert abs(r - outs[0][0]) <= 1e-13 * abs(outs[0][0])

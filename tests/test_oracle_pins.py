@@ -252,3 +252,34 @@ def test_restrict_prolongate_shapes_and_weights(oracle):
     assert np.all(out[0, :] == 0) and np.all(out[:, 0] == 0) and out[1, 1] == 0.25 and out[2, 2] == 1.0
     oracle.prolongate2d(coarse, out, True)
     assert np.array_equal(out[0, :], out[1, :]) and np.array_equal(out[-1, :], out[-2, :])
+
+
+# ---------------------------------------------------------------- outputs of the reference itself
+def _published(name):
+    import csv
+    import os
+
+    from fixtures_io import GOLDEN
+
+    with open(os.path.join(GOLDEN, "published", name)) as fh:
+        return list(csv.DictReader(fh))
+
+
+def probe_index(n):
+    """part1_error_vs_grid_size_experiments.jl:31-35: ix = round(Int, 4.5/dx + 1) with dx = X[2]-X[1]."""
+    dx = 10.0 / n
+    X = np.linspace(dx / 2, 10.0 - dx / 2, n)
+    return int(np.round(4.5 / (X[1] - X[0]) + 1)) - 1
+
+
+@pytest.mark.parametrize("n", [16, 23, 32, 45, 64])
+def test_part1_published_grid_size_values_bit_exact(oracle, n):
+    """benchmark-results/error_vs_grid_size_experiment_results.csv was written by the reference itself
+    (diffusion_3D_kernel_programming, ttot=2, tol=1e-6).  The oracle reproduces H[ix,iy,iz] to the last
+    printed digit -- including every convergence decision of the 10 x O(100) inner iterations."""
+    row = [r for r in _published("error_vs_grid_size_experiment_results.csv") if int(r["nx"]) == n][0]
+    dx = 10.0 / n
+    Ht = oracle.init_gaussian((n, n, n), dx, dx, dx, (5.0, 5.0, 5.0))
+    oracle.diffusion3d_solve(Ht, nt=10, tol=1e-6)
+    i = probe_index(n)
+    assert Ht[i, i, i] == float(row["val"])

@@ -40,6 +40,22 @@ __device__ __forceinline__ double diff3_point(double h, double xm, double xp, do
     return r;
 }
 
+// neighbour-lane moves by DPP wave shifts (see fpr_internal.hpp); edge lanes keep their own value
+__device__ __forceinline__ double diff3_lane_up1(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double diff3_lane_down1(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double diff3_wave_sum(double v)
 {
 #pragma unroll
@@ -276,8 +292,8 @@ __global__ __launch_bounds__(256) void k_diff3_march(Diff3Args a)
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             // x-neighbours by wavefront shuffle; edge lanes use the fetched edge cell
-            const double fromL = __shfl_up(c[r].v[VX - 1], 1, 64);
-            const double fromR = __shfl_down(c[r].v[0], 1, 64);
+            const double fromL = diff3_lane_up1(c[r].v[VX - 1]);
+            const double fromR = diff3_lane_down1(c[r].v[0]);
             const double xl0 = (lane == 0) ? ec[r] : fromL;
             const double xrL = (lane == 63) ? ec[r] : fromR;
             double res[VX], h2[VX];

@@ -97,6 +97,24 @@ inline long fpr_opt(fpr_ctx* ctx, const char* key, long dflt)
 // ---------------------------------------------------------------------------------------------
 #ifdef __HIPCC__
 
+// Neighbour-lane moves by DPP wave shifts (gfx9 family: v_mov_b32_dpp wave_shr:1 / wave_shl:1): no LDS
+// crossbar round trip as with ds_bpermute (__shfl_up/__shfl_down).  Edge lanes keep their own value,
+// like __shfl_up / __shfl_down do.
+__device__ __forceinline__ double fpr_lane_up1(double v)  // lane i <- lane i-1
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double fpr_lane_down1(double v)  // lane i <- lane i+1
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double fpr_wave_sum(double v)
 {
 #pragma unroll

@@ -204,6 +204,8 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
     __shared__ double red[16];
     constexpr int HX = RESTRICT ? 3 : 2;                     // feeder lanes on each side of a strip
     constexpr int SW = 64 - 2 * HX;                          // columns owned by a strip
+    const bool nt_store = (apply_BCs & 256) != 0;            // bit 8: non-temporal stores of the smoothed field
+    apply_BCs &= 255;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + w;
     const bool active = strip < nstrips;
@@ -259,15 +261,23 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
         double b0 = 0.0, b1 = 0.0, b2 = 0.0;           // u1  rows r-3, r-2, r-1
         double f0 = 0.0, f1 = 0.0, f2 = ldf(rs);       // f   rows r-2, r-1, r
         double c0 = 0.0, c1 = 0.0, c2 = 0.0, fm = 0.0; // RESTRICT: u2 rows r-4, r-3, r-2 and f row r-3
-        double an = ldu(rs + 1), fn = ldf(rs + 1);     // prefetched row r+1
+        // software pipeline: rows r+1 .. r+PF are in flight (PF loads of u and of f per lane)
+        constexpr int PF = 4;
+        double pu[PF], pfv[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) { pu[q] = ldu(rs + 1 + q); pfv[q] = ldf(rs + 1 + q); }
         const int nxc_r = 1 + (nx - 1) / 2, nyc_r = 1 + (ny - 1) / 2;
         for (int r = rs; r <= y1 + (RESTRICT ? 2 : 1); ++r) {
-            const double an2 = ldu(r + 2), fn2 = ldf(r + 2);  // issue the loads of row r+2
+            const double an = pu[0], fn = pfv[0];
+#pragma unroll
+            for (int q = 0; q + 1 < PF; ++q) { pu[q] = pu[q + 1]; pfv[q] = pfv[q + 1]; }
+            pu[PF - 1] = ldu(r + 1 + PF);                      // issue the loads of row r+1+PF
+            pfv[PF - 1] = ldf(r + 1 + PF);
             // ---- sweep 1 at row r-1 (needs u rows r-2, r-1, r) ----
             const int j1 = r - 1;
             double u1;
             {
-                const double L = __shfl_up(a1, 1, 64), R = __shfl_down(a1, 1, 64);
+                const double L = fpr_lane_up1(a1), R = fpr_lane_down1(a1);
                 const double rr = ((((R + L) + a2) + a0) - C * a1) * _h2 - f1;
                 const bool bnd = col_bnd || j1 <= 0 || j1 >= ny - 1;
                 u1 = bnd ? a1 : a1 + fac * rr;
@@ -276,12 +286,13 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
             // ---- sweep 2 at row r-2 (needs u1 rows r-3, r-2, r-1) ----
             const int j2 = r - 2;
             {
-                const double L = __shfl_up(b1, 1, 64), R = __shfl_down(b1, 1, 64);
+                const double L = fpr_lane_up1(b1), R = fpr_lane_down1(b1);
                 const double rr = ((((R + L) + b2) + b0) - C * b1) * _h2 - f0;
                 const bool bnd = col_bnd || j2 <= 0 || j2 >= ny - 1;
                 const double u2 = bnd ? b1 : b1 + fac * rr;
                 if (owner && j2 >= y0 && j2 < y1) {
-                    uout[(size_t)gi + (size_t)nx * j2] = u2;
+                    if (nt_store) __builtin_nontemporal_store(u2, &uout[(size_t)gi + (size_t)nx * j2]);
+                    else uout[(size_t)gi + (size_t)nx * j2] = u2;
                     if constexpr (NORM) {
                         if (!bnd) acc += rr * rr;
                     }
@@ -293,7 +304,7 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
             if constexpr (RESTRICT) {
                 // ---- residual of u2 at row r-3, injected at even (row, column) ----
                 const int j3 = r - 3;
-                const double L = __shfl_up(c1, 1, 64), R = __shfl_down(c1, 1, 64);
+                const double L = fpr_lane_up1(c1), R = fpr_lane_down1(c1);
                 const double rr = ((((R + L) + c2) + c0) - C * c1) * _h2 - fm;
                 if (owner && j3 >= y0 && j3 < y1 && !(j3 & 1) && !(gi & 1)) {
                     const int ic = gi >> 1, jc = j3 >> 1;
@@ -304,8 +315,8 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
                 }
                 fm = f0;                               // becomes f row (r+1)-3
             }
-            a0 = a1; a1 = a2; a2 = an; an = an2;
-            f0 = f1; f1 = f2; f2 = fn; fn = fn2;
+            a0 = a1; a1 = a2; a2 = an;
+            f0 = f1; f1 = f2; f2 = fn;
         }
     }
     if constexpr (NORM) {
@@ -575,7 +586,7 @@ __global__ __launch_bounds__(256) void k_smooth2_march2(const double* __restrict
             const int j1 = r - 1;
             double u1[2];
             {
-                const double Lo = __shfl_up(a1[1], 1, 64), Ro = __shfl_down(a1[0], 1, 64);
+                const double Lo = fpr_lane_up1(a1[1]), Ro = fpr_lane_down1(a1[0]);
                 const bool rowb = j1 <= 0 || j1 >= ny - 1;
                 const double rr0 = ((((a1[1] + Lo) + a2[0]) + a0[0]) - C * a1[0]) * _h2 - f1[0];
                 const double rr1 = ((((Ro + a1[0]) + a2[1]) + a0[1]) - C * a1[1]) * _h2 - f1[1];
@@ -587,7 +598,7 @@ __global__ __launch_bounds__(256) void k_smooth2_march2(const double* __restrict
             // ---- sweep 2 at row r-2 ----
             const int j2 = r - 2;
             {
-                const double Lo = __shfl_up(b1[1], 1, 64), Ro = __shfl_down(b1[0], 1, 64);
+                const double Lo = fpr_lane_up1(b1[1]), Ro = fpr_lane_down1(b1[0]);
                 const bool rowb = j2 <= 0 || j2 >= ny - 1;
                 const double rr0 = ((((b1[1] + Lo) + b2[0]) + b0[0]) - C * b1[0]) * _h2 - f0[0];
                 const double rr1 = ((((Ro + b1[0]) + b2[1]) + b0[1]) - C * b1[1]) * _h2 - f0[1];
@@ -616,7 +627,7 @@ __global__ __launch_bounds__(256) void k_smooth2_march2(const double* __restrict
             if constexpr (RESTRICT) {
                 // ---- residual of u2 at row r-3, injected at even (row, column): one of the lane's two columns ----
                 const int j3 = r - 3;
-                const double Lo = __shfl_up(c1[1], 1, 64), Ro = __shfl_down(c1[0], 1, 64);
+                const double Lo = fpr_lane_up1(c1[1]), Ro = fpr_lane_down1(c1[0]);
                 const double rr0 = ((((c1[1] + Lo) + c2[0]) + c0[0]) - C * c1[0]) * _h2 - fm[0];
                 const double rr1 = ((((Ro + c1[0]) + c2[1]) + c0[1]) - C * c1[1]) * _h2 - fm[1];
                 if (j3 >= y0 && j3 < y1 && !(j3 & 1)) {
@@ -1511,6 +1522,7 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
         if (fpr_opt(ctx, "mg_multi", 1) == 1 && nx >= 64 && ny >= 16) {
             // temporal blocking, register-rolling march: each smoothing pair is ONE pass (u -> tmp, tmp -> u)
             const bool fuse_r = fpr_opt(ctx, "mg_fuse_restrict", 1) != 0;
+            const int ntf = fpr_opt(ctx, "mg_nt", 0) ? 256 : 0;
             // two columns per lane (128-column strips, 16-byte accesses at 8-byte alignment): measured 10 % SLOWER than
             // one column per lane on MI355X (3.54 vs 3.20 ms per 4097^2 solve), so it is opt-in (mg_vx = 2)
             const bool vx2 = fpr_opt(ctx, "mg_vx", 1) == 2 && nx >= 128;
@@ -1528,10 +1540,10 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             const bool fuse_p = fpr_opt(ctx, "mg_fuse_prolong", 1) != 0;
             if (fuse_r) {  // pre-smoothing pair + residual + injection + zero coarse guess in ONE pass (:124-132)
                 const dim3 gr((nstrips_r + 3) / 4, (ny + rpc - 1) / rpc);
-                { if (vx2) k_smooth2_march2<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, 0, L.res_c, L.corr_c); else k_smooth2_march<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, 0, L.res_c, L.corr_c); }
+                { if (vx2) k_smooth2_march2<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c); else k_smooth2_march<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c); }
                 if (apply_BCs) k_bc_neumann<<<(nyc + 255) / 256, 256, 0, s>>>(L.res_c, nxc, nyc);  // :355-357
             } else {
-                { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0, nullptr, nullptr); else k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0, nullptr, nullptr); }  // :124-125
+                { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr); else k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr); }  // :124-125
                 k_restrict_residual2d<<<grid2(nxc, nyc), blk2, 0, s>>>(L.tmp, rhs, L.res_c, nx, ny, C, _h2, apply_BCs, L.corr_c);  // :128-132
             }
             FPR_CHECK_LAUNCH(ctx);
@@ -1541,14 +1553,14 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             if (!fuse_p) k_prolong2d<true><<<g, blk2, 0, s>>>(L.corr_c, L.tmp, nx, ny, apply_BCs);  // :136-139
             // post-smoothing pair (:142-143); with fuse_p the correction u - P(corr_c) is applied while loading
             if (top) {
-                if (fuse_p) { if (vx2) k_smooth2_march2<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs, nullptr, nullptr); else k_smooth2_march<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs, nullptr, nullptr); }
-                else { if (vx2) k_smooth2_march2<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, 0, nullptr, nullptr); else k_smooth2_march<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, 0, nullptr, nullptr); }
+                if (fuse_p) { if (vx2) k_smooth2_march2<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs | ntf, nullptr, nullptr); else k_smooth2_march<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs | ntf, nullptr, nullptr); }
+                else { if (vx2) k_smooth2_march2<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, ntf, nullptr, nullptr); else k_smooth2_march<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, ntf, nullptr, nullptr); }
                 FPR_CHECK_LAUNCH(ctx);
                 if (int rc = fprx_finish_sum(ctx, ctx->partials, npm, ctx->scalars, false, 0)) return rc;
                 *rms_is_host = false;
             } else {
-                if (fuse_p) { if (vx2) k_smooth2_march2<false, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs, nullptr, nullptr); else k_smooth2_march<false, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs, nullptr, nullptr); }
-                else { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0, nullptr, nullptr); else k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0, nullptr, nullptr); }
+                if (fuse_p) { if (vx2) k_smooth2_march2<false, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs | ntf, nullptr, nullptr); else k_smooth2_march<false, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs | ntf, nullptr, nullptr); }
+                else { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr); else k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr); }
                 FPR_CHECK_LAUNCH(ctx);
             }
             return FPR_OK;

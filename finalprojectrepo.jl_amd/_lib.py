@@ -48,6 +48,7 @@ _SIG = {
     "fpr_kernel_timer_read": [_vp, C.POINTER(_d), C.POINTER(_l)],
     "fpr_diffusion3d_step": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8,
     "fpr_diffusion3d_step_norm": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8 + [_d, _dp],
+    "fpr_diffusion3d_step_norm_host": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8 + [_d, C.POINTER(_d)],
     "fpr_diffusion3d_step_box": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8 + [C.POINTER(_i), C.POINTER(_i), _d, _dp, _i],
     "fpr_diffusion3d_flux": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 4,
     "fpr_diffusion3d_dHdtau": [_vp] + [_dp] * 6 + [_i] * 3 + [_d] * 4,

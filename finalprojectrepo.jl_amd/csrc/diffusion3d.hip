@@ -77,6 +77,22 @@ extern "C" int fpr_diffusion3d_step_norm(fpr_ctx* ctx, const double* Ht, const d
                      nullptr, true, scale, sumsq_dev, false, 0);
 }
 
+extern "C" int fpr_diffusion3d_step_norm_host(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2,
+                                              double* dHdtau, int nx, int ny, int nz, double dtau, double _dt, double _dx,
+                                              double _dy, double _dz, double D_dx, double D_dy, double D_dz, double scale,
+                                              double* sumsq_host)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, sumsq_host, "sumsq_host is null");
+    double* pinned = ctx->host_scalars + 8;  // device-visible pinned host memory: the finish kernel writes it directly
+    int rc = diff3_run(ctx, Ht, Htau, Htau2, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, nullptr,
+                       nullptr, true, scale, pinned, false, 0);
+    if (rc) return rc;
+    FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
+    *sumsq_host = *(volatile double*)pinned;
+    return FPR_OK;
+}
+
 extern "C" int fpr_diffusion3d_step_box(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2,
                                         double* dHdtau, int nx, int ny, int nz, double dtau, double _dt, double _dx,
                                         double _dy, double _dz, double D_dx, double D_dy, double D_dz, const int lo[3],

@@ -53,6 +53,15 @@ def diffusion_3D_step_τ_norm(Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_d
                 dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale, sumsq_dev.data_ptr())
 
 
+def diffusion_3D_step_τ_norm_host(Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale):
+    """Fused update + norm returned to the host (one stream sync): sum((dHdτ*scale)^2) over the interior."""
+    nx, ny, nz = Ht.shape
+    out = C.c_double(0.0)
+    _ctx().call("fpr_diffusion3d_step_norm_host", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hτ2, 3), fptr(dHdτ, 3), nx, ny, nz,
+                dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale, C.byref(out))
+    return out.value
+
+
 def diffusion_3D_step_τ_box(Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo, hi, scale=0.0,
                             sumsq_dev=None, stream_sel=0):
     """Sub-box form (role of @hide_communication, part1_kernel_programming.jl:185-188); 0-based [lo, hi)."""
@@ -192,6 +201,13 @@ def diffusion_3D_kernel_programming(*, nx, ny, nz, ttot=1.0, tol=1e-8, use_share
         while (iter_inner < fixed_iters) if fixed_iters > 0 else (err > tol and iter_inner < iter_max):  # :179
             need_norm = (fixed_iters == 0 and (iter_inner + 1) % check_every == 0) or \
                         (fixed_iters > 0 and iter_inner + 1 == fixed_iters)
+            if need_norm and gg.nprocs == 1:
+                # single rank: kernel + reduction + one stream sync, the sum lands in pinned host memory
+                s_loc = diffusion_3D_step_τ_norm_host(Ht, Hτ, Hτ2, residual_H, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, dt)
+                Hτ, Hτ2 = Hτ2, Hτ  # :190
+                err = math.sqrt(s_loc) / sqrtN  # :191
+                iter_inner += 1
+                continue
             gg.step(Ht, Hτ, Hτ2, residual_H, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, dt, sq if need_norm else None)
             Hτ, Hτ2 = Hτ2, Hτ  # :190
             if need_norm:

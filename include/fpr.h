@@ -78,6 +78,13 @@ int fpr_diffusion3d_step_norm(fpr_ctx* ctx, const double* Ht, const double* Htau
                               int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz,
                               double D_dx, double D_dy, double D_dz, double scale, double* sumsq_dev);
 
+/* Same as fpr_diffusion3d_step_norm, but the sum is handed to the HOST: the reduction writes straight into
+ * pinned host memory and the call synchronises the compute stream (one round trip per pseudo-iteration,
+ * as the reference's `err = dist_norm_L2(...)` at part1_kernel_programming.jl:191 requires). */
+int fpr_diffusion3d_step_norm_host(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2, double* dHdtau,
+                                   int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz,
+                                   double D_dx, double D_dy, double D_dz, double scale, double* sumsq_host);
+
 /* Sub-box form used by the multi-GPU driver to split boundary slabs from the interior
  * (role of @hide_communication (8,8,8), part1_kernel_programming.jl:185-188).  Updates cells with
  * lo[d] <= index < hi[d] (0-based, clipped to the interior).  sumsq_dev may be NULL; when given,

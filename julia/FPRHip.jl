@@ -138,6 +138,16 @@ function diffusion_3D_step_τ_norm(Ht::DA, Hτ::DA, Hτ2::DA, dHdτ::DA, dτ, _d
                 ctx(), p(Ht), p(Hτ), p(Hτ2), p(dHdτ), nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale, p(sumsq)))
 end
 
+"Fused update + norm handed to the host (one stream synchronisation per pseudo-iteration)."
+function diffusion_3D_step_τ_norm_host(Ht::DA, Hτ::DA, Hτ2::DA, dHdτ::DA, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale)
+    nx, ny, nz = size(Ht); out = Ref{Cdouble}(0)
+    check(ccall((:fpr_diffusion3d_step_norm_host, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint,
+                 Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cdouble}),
+                ctx(), p(Ht), p(Hτ), p(Hτ2), p(dHdτ), nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale, out))
+    return out[]
+end
+
 "Sub-box form for boundary/interior splitting (0-based lo/hi); role of @hide_communication."
 function diffusion_3D_step_τ_box(Ht::DA, Hτ::DA, Hτ2::DA, dHdτ::DA, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz,
                                  lo::NTuple{3,Int}, hi::NTuple{3,Int}; scale = 0.0, sumsq::Union{DA,Nothing} = nothing, stream_sel = 0)

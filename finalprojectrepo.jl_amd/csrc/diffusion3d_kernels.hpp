@@ -10,6 +10,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 struct Diff3Args {
     const double* __restrict__ Ht;
     const double* __restrict__ Htau;
@@ -61,6 +63,16 @@ __device__ __forceinline__ double diff3_wave_sum(double v)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a memory fence, for
+// which hipcc emits `s_waitcnt vmcnt(0)`: inside the z-march that would drain the prefetched global loads
+// of the next planes at every plane.  Here only the LDS counter is waited on, so global loads issued
+// before the barrier stay in flight across it.
+__device__ __forceinline__ void diff3_lds_barrier()
+{
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) alone (gfx9 encoding: vmcnt and expcnt fields left at max)
+    __builtin_amdgcn_s_barrier();
 }
 
 // fixed-order block sum for 256-thread blocks; result in thread 0
@@ -144,7 +156,13 @@ __device__ __forceinline__ DVec<VX> diff3_ldv(const double* __restrict__ p)
     return o;
 }
 
-template <int VX, int RY, bool NORM, bool LDSY, bool NT>
+// PIPE = true: the z-pipeline is written as a ring of 4 register sets with compile-time roles (the loop
+// is unrolled by 4), so no register of an in-flight load is ever copied: the loads of plane k+3 (and of
+// the halo rows / Ht of plane k+2) are issued right after plane k has been computed, into the registers
+// plane k-1 occupied, and stay in flight for two full iterations -- across the LDS barrier as well.
+// (With PIPE = false the rotation `zm=c; c=zp; zp=zpp` and the merge of the LDS / global halo rows make
+// hipcc wait for the just-issued loads: `s_waitcnt vmcnt(0)` once per plane.)
+template <int VX, int RY, bool NORM, bool LDSY, bool NT, bool PIPE = false>
 __global__ __launch_bounds__(256) void k_diff3_march(Diff3Args a)
 {
     constexpr int TXW = 64 * VX;  // tile width in cells
@@ -237,6 +255,129 @@ __global__ __launch_bounds__(256) void k_diff3_march(Diff3Args a)
     const bool need_gd = !LDSY || (w == 0);   // bottom halo row from global
     const bool need_gu = !LDSY || (w == 3);   // top halo row from global
 
+    if constexpr (PIPE) {
+        const int kendp = LDSY ? k1 : (wave_active ? k1 : k0);
+        DVec<VX> P[4][RY];          // planes (k-1, k, k+1, k+2) in slots ((k-k0)+{0,1,2,3}) & 3
+        DVec<VX> HT[2][RY];         // Ht of planes k, k+1 in slots (k-k0) & 1
+        DVec<VX> YD[2], YU[2];      // global halo rows of planes k, k+1
+        double ED[2][RY];           // tile-edge cells of planes k, k+1
+        auto load_plane = [&](DVec<VX>(&dst)[RY], int k) {
+#pragma unroll
+            for (int r = 0; r < RY; ++r) dst[r] = diff3_ldv<VX>(H + (size_t)ibc + sy * jr[r] + sz * kcl(k));
+        };
+        auto load_aux = [&](DVec<VX>(&ht)[RY], DVec<VX>& yd, DVec<VX>& yu, double (&e)[RY], int k) {
+            const int kc = kcl(k);
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                ht[r] = diff3_ldv<VX>(a.Ht + (size_t)ibc + sy * jr[r] + sz * kc);
+                e[r] = is_edge ? H[(size_t)ie + sy * jr[r] + sz * kc] : 0.0;
+            }
+            if (need_gd) yd = diff3_ldv<VX>(H + (size_t)ibc + sy * jd + sz * kc);
+            if (need_gu) yu = diff3_ldv<VX>(H + (size_t)ibc + sy * ju + sz * kc);
+        };
+        if (kendp > k0) {
+            load_plane(P[0], k0 - 1);
+            load_plane(P[1], k0);
+            load_plane(P[2], k0 + 1);
+            load_plane(P[3], k0 + 2);
+            load_aux(HT[0], YD[0], YU[0], ED[0], k0);
+            load_aux(HT[1], YD[1], YU[1], ED[1], k0 + 1);
+        }
+        auto step = [&](auto Sc, int k) {
+            constexpr int S = decltype(Sc)::value;
+            DVec<VX>(&zmR)[RY] = P[S & 3];
+            DVec<VX>(&cR)[RY] = P[(S + 1) & 3];
+            DVec<VX>(&zpR)[RY] = P[(S + 2) & 3];
+            constexpr int hsl = S & 1;
+            DVec<VX> ydv = YD[hsl], yuv = YU[hsl];
+            if constexpr (LDSY) {
+                double* buf = xrow + (size_t)(k & 1) * (4 * 2 * TXW);
+                double* mine = buf + (size_t)w * (2 * TXW) + lane * VX;
+#pragma unroll
+                for (int v = 0; v < VX; ++v) {
+                    mine[v] = cR[0].v[v];
+                    mine[TXW + v] = cR[RY - 1].v[v];
+                }
+                diff3_lds_barrier();
+                const double* od = buf + (size_t)(w > 0 ? w - 1 : 0) * (2 * TXW) + TXW + lane * VX;  // last row of the wave below
+                const double* ou = buf + (size_t)(w < 3 ? w + 1 : 3) * (2 * TXW) + lane * VX;        // first row of the wave above
+#pragma unroll
+                for (int v = 0; v < VX; ++v) {
+                    const double ld = od[v], lu = ou[v];
+                    ydv.v[v] = (w > 0) ? ld : ydv.v[v];
+                    yuv.v[v] = (w < 3) ? lu : yuv.v[v];
+                }
+            }
+            double res[RY][VX], h2[RY][VX];
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                const double fromL = diff3_lane_up1(cR[r].v[VX - 1]);
+                const double fromR = diff3_lane_down1(cR[r].v[0]);
+                const double xl0 = (lane == 0) ? ED[hsl][r] : fromL;
+                const double xrL = (lane == 63) ? ED[hsl][r] : fromR;
+#pragma unroll
+                for (int v = 0; v < VX; ++v) {
+                    const double xm = (v == 0) ? xl0 : cR[r].v[v == 0 ? 0 : v - 1];
+                    const double xp = (v == VX - 1) ? xrL : cR[r].v[v == VX - 1 ? v : v + 1];
+                    const double ym = (r == 0) ? ydv.v[v] : cR[r == 0 ? 0 : r - 1].v[v];
+                    const double yp = (r == RY - 1) ? yuv.v[v] : cR[r == RY - 1 ? r : r + 1].v[v];
+                    res[r][v] = diff3_point(cR[r].v[v], xm, xp, ym, yp, zmR[r].v[v], zpR[r].v[v], HT[hsl][r].v[v], cf, h2[r][v]);
+                }
+            }
+            // plane k-1, and the halo rows / Ht of plane k, are dead now: refill them (planes k+3 and k+2)
+            if (k + 1 < kendp) {
+                load_plane(P[S & 3], k + 3);
+                load_aux(HT[hsl], YD[hsl], YU[hsl], ED[hsl], k + 2);
+            }
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                if (rm[r]) {
+                    const size_t id = (size_t)ib + sy * (size_t)(j0 + r) + sz * (size_t)k;
+                    if constexpr (VX == 2) {
+                        if (cm[0] && cm[1]) {
+                            if constexpr (NT) {
+                                typedef double d2v __attribute__((ext_vector_type(2)));
+                                d2v rv, hv;
+                                rv.x = res[r][0]; rv.y = res[r][1];
+                                hv.x = h2[r][0]; hv.y = h2[r][1];
+                                __builtin_nontemporal_store(rv, reinterpret_cast<d2v*>(a.dHdtau + id));
+                                __builtin_nontemporal_store(hv, reinterpret_cast<d2v*>(a.Htau2 + id));
+                            } else {
+                                *reinterpret_cast<double2*>(a.dHdtau + id) = make_double2(res[r][0], res[r][1]);
+                                *reinterpret_cast<double2*>(a.Htau2 + id) = make_double2(h2[r][0], h2[r][1]);
+                            }
+                        } else {
+                            if (cm[0]) { a.dHdtau[id] = res[r][0]; a.Htau2[id] = h2[r][0]; }
+                            if (cm[1]) { a.dHdtau[id + 1] = res[r][1]; a.Htau2[id + 1] = h2[r][1]; }
+                        }
+                    } else {
+                        if (cm[0]) { a.dHdtau[id] = res[r][0]; a.Htau2[id] = h2[r][0]; }
+                    }
+                    if constexpr (NORM) {
+#pragma unroll
+                        for (int v = 0; v < VX; ++v)
+                            if (cm[v]) { const double t = res[r][v] * a.scale; acc += t * t; }
+                    }
+                }
+            }
+        };
+        int k = k0;
+        for (; k + 3 < kendp; k += 4) {
+            step(std::integral_constant<int, 0>{}, k);
+            step(std::integral_constant<int, 1>{}, k + 1);
+            step(std::integral_constant<int, 2>{}, k + 2);
+            step(std::integral_constant<int, 3>{}, k + 3);
+        }
+        if (k < kendp) { step(std::integral_constant<int, 0>{}, k); ++k; }
+        if (k < kendp) { step(std::integral_constant<int, 1>{}, k); ++k; }
+        if (k < kendp) { step(std::integral_constant<int, 2>{}, k); ++k; }
+        if constexpr (NORM) {
+            const double s = diff3_block_sum256(acc, red, tid);
+            if (tid == 0) a.partials[blockIdx.x] = s;
+        }
+        return;
+    }
+
     if (wave_active && k0 < k1) {
         // ---- prologue: planes k0-1, k0, k0+1 ----
 #pragma unroll
@@ -275,7 +416,7 @@ __global__ __launch_bounds__(256) void k_diff3_march(Diff3Args a)
                 mine[v] = c[0].v[v];
                 mine[TXW + v] = c[RY - 1].v[v];
             }
-            __syncthreads();
+            diff3_lds_barrier();
             if (w > 0) {
                 const double* o = buf + (size_t)(w - 1) * (2 * TXW) + TXW + lane * VX;  // last row of wave below
 #pragma unroll

@@ -7,7 +7,8 @@
 
 struct Diff3Tuning {
     int variant = 0;     // 0 = library default; 1 = naive; 2 = z-march (registers + shuffles);
-                         // 3 = z-march with LDS exchange of the inter-wave halo rows
+                         // 3 = z-march with LDS exchange of the inter-wave halo rows;
+                         // 4 / 5 = 2 / 3 with the ring-pipelined z-loop (16-byte path, ry 2 or 4; else falls back)
     int zc = 0;          // planes per z-chunk (0 = auto)
     int xcd_remap = -1;  // -1 auto, 0 off, 1 on
     int ry = 0;          // rows per lane (0 = auto; 1, 2 or 4)
@@ -36,6 +37,21 @@ static inline void diff3_march_go(const Diff3Args& a, bool norm, int nblk, hipSt
 {
     if (norm) k_diff3_march<VX, RY, true, LDSY, NT><<<nblk, 256, 0, stream>>>(a);
     else k_diff3_march<VX, RY, false, LDSY, NT><<<nblk, 256, 0, stream>>>(a);
+}
+
+// ring-pipelined form (PIPE = true), instantiated for the 16-byte path with 2 or 4 rows per lane
+template <int RY>
+static inline void diff3_pipe_go(const Diff3Args& a, bool norm, bool ldsy, bool nt, int nblk, hipStream_t stream)
+{
+#define DIFF3_PIPE_CASE(N_, L_, T_)                                                              \
+    if (norm == N_ && ldsy == L_ && nt == T_) {                                                    \
+        k_diff3_march<2, RY, N_, L_, T_, true><<<nblk, 256, 0, stream>>>(a);                        \
+        return;                                                                                    \
+    }
+    DIFF3_PIPE_CASE(false, false, false) DIFF3_PIPE_CASE(false, false, true) DIFF3_PIPE_CASE(false, true, false)
+    DIFF3_PIPE_CASE(false, true, true) DIFF3_PIPE_CASE(true, false, false) DIFF3_PIPE_CASE(true, false, true)
+    DIFF3_PIPE_CASE(true, true, false) DIFF3_PIPE_CASE(true, true, true)
+#undef DIFF3_PIPE_CASE
 }
 
 template <int VX, int RY>
@@ -67,8 +83,9 @@ static inline hipError_t diff3_launch(Diff3Args a, bool norm, const Diff3Tuning&
         *nparts = (int)nb;
         return hipGetLastError();
     }
-    if (variant != 2 && variant != 3) return hipErrorInvalidValue;
-    const bool ldsy = (variant == 3);
+    if (variant < 2 || variant > 5) return hipErrorInvalidValue;
+    bool pipe = variant >= 4;  // 4 = variant 2 + ring pipeline, 5 = variant 3 + ring pipeline
+    const bool ldsy = (variant == 3 || variant == 5);
     // 16-byte path needs even nx and 16-byte aligned arrays
     const bool can16 = (a.nx % 2 == 0) &&
                        ((((uintptr_t)a.Ht | (uintptr_t)a.Htau | (uintptr_t)a.Htau2 | (uintptr_t)a.dHdtau) & 15) == 0);
@@ -103,7 +120,10 @@ static inline hipError_t diff3_launch(Diff3Args a, bool norm, const Diff3Tuning&
         if (!ldsy || a.xcd_remap > 6 || nby % (8 * G) != 0) a.xcd_remap = 0;
     }
     const bool nt = t.nt < 0 ? DIFF3_DEFAULT_NT : (t.nt != 0);
-    if (vx == 2) {
+    if (pipe && vx == 2 && (ry == 4 || ry == 2)) {
+        if (ry == 4) diff3_pipe_go<4>(a, norm, ldsy, nt, (int)nblk, stream);
+        else diff3_pipe_go<2>(a, norm, ldsy, nt, (int)nblk, stream);
+    } else if (vx == 2) {
         if (ry == 4) diff3_march_go2<2, 4>(a, norm, ldsy, nt, (int)nblk, stream);
         else if (ry == 2) diff3_march_go2<2, 2>(a, norm, ldsy, nt, (int)nblk, stream);
         else diff3_march_go2<2, 1>(a, norm, ldsy, nt, (int)nblk, stream);

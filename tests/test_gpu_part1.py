@@ -18,6 +18,8 @@ VARIANTS = [dict(diff3_variant=1), dict(diff3_variant=2, diff3_ry=1), dict(diff3
             dict(diff3_variant=2, diff3_ry=4), dict(diff3_variant=2, diff3_ry=4, diff3_vx=1),
             dict(diff3_variant=2, diff3_ry=4, diff3_nt=1, diff3_zc=5), dict(diff3_variant=3, diff3_ry=1),
             dict(diff3_variant=3, diff3_ry=2, diff3_zc=7), dict(diff3_variant=3, diff3_ry=4, diff3_xcd_remap=1),
+            dict(diff3_variant=4, diff3_ry=4), dict(diff3_variant=4, diff3_ry=2, diff3_zc=3),
+            dict(diff3_variant=5, diff3_ry=2, diff3_zc=7), dict(diff3_variant=5, diff3_ry=4, diff3_nt=0),
             dict()]
 ALL_OPTS = ["diff3_variant", "diff3_ry", "diff3_vx", "diff3_nt", "diff3_zc", "diff3_xcd_remap"]
 
@@ -179,7 +181,8 @@ def test_full_size_512_properties(fpr):
     Hτ.copy_(Ht)
     Hτ.mul_(1.0 + 0.001 * torch.arange(n, device=Hτ.device, dtype=torch.float64).reshape(n, 1, 1))  # break symmetry in x
     results = []
-    for opts in (dict(diff3_variant=1), dict(diff3_variant=2), dict(diff3_variant=3), dict()):
+    for opts in (dict(diff3_variant=1), dict(diff3_variant=2), dict(diff3_variant=3), dict(diff3_variant=4),
+                 dict(diff3_variant=5, diff3_zc=16), dict()):
         set_opts(F, opts)
         H2.zero_(); dH.zero_()
         F.part1.diffusion_3D_step_τ(Ht, Hτ, H2, dH, *coef)

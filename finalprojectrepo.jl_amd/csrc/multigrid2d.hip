@@ -592,12 +592,17 @@ __global__ __launch_bounds__(256) void k_smooth2_march2(const double* __restrict
         double f0[2] = {0, 0}, f1[2] = {0, 0}, f2[2], fn[2], fm[2] = {0, 0};
         ldu(rs, a2[0], a2[1]);
         ld2(f, rs, f2[0], f2[1]);
-        ldu(rs + 1, an[0], an[1]);
-        ld2(f, rs + 1, fn[0], fn[1]);
-        for (int r = rs; r <= y1 + (RESTRICT ? 2 : 1); ++r) {
-            double an2[2], fn2[2];
-            ldu(r + 2, an2[0], an2[1]);
-            ld2(f, r + 2, fn2[0], fn2[1]);
+        // prefetch ring with compile-time slots (see k_smooth2_march): rows r+1 .. r+PF in flight
+        constexpr int PF = 4;
+        double pu[PF][2], pfv[PF][2];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) { ldu(rs + 1 + q, pu[q][0], pu[q][1]); ld2(f, rs + 1 + q, pfv[q][0], pfv[q][1]); }
+        auto step = [&](auto Qc, int r) {
+            constexpr int Q = decltype(Qc)::value;
+            an[0] = pu[Q][0]; an[1] = pu[Q][1];
+            fn[0] = pfv[Q][0]; fn[1] = pfv[Q][1];
+            ldu(r + 1 + PF, pu[Q][0], pu[Q][1]);
+            ld2(f, r + 1 + PF, pfv[Q][0], pfv[Q][1]);
             // ---- sweep 1 at row r-1 ----
             const int j1 = r - 1;
             double u1[2];
@@ -661,10 +666,21 @@ __global__ __launch_bounds__(256) void k_smooth2_march2(const double* __restrict
             }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                a0[e] = a1[e]; a1[e] = a2[e]; a2[e] = an[e]; an[e] = an2[e];
-                f0[e] = f1[e]; f1[e] = f2[e]; f2[e] = fn[e]; fn[e] = fn2[e];
+                a0[e] = a1[e]; a1[e] = a2[e]; a2[e] = an[e];
+                f0[e] = f1[e]; f1[e] = f2[e]; f2[e] = fn[e];
             }
+        };
+        const int rend = y1 + (RESTRICT ? 2 : 1);
+        int r = rs;
+        for (; r + PF - 1 <= rend; r += PF) {
+            step(std::integral_constant<int, 0>{}, r);
+            step(std::integral_constant<int, 1>{}, r + 1);
+            step(std::integral_constant<int, 2>{}, r + 2);
+            step(std::integral_constant<int, 3>{}, r + 3);
         }
+        if (r <= rend) { step(std::integral_constant<int, 0>{}, r); ++r; }
+        if (r <= rend) { step(std::integral_constant<int, 1>{}, r); ++r; }
+        if (r <= rend) { step(std::integral_constant<int, 2>{}, r); ++r; }
     }
     if constexpr (NORM) {
         const double sblk = fpr_block_sum<256>(acc, red);

@@ -141,7 +141,7 @@ def asdevice(a, device=None):
     torch = _torch()
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     a = np.asarray(a, dtype=np.float64)
-    t = torch.from_numpy(np.ascontiguousarray(a.T)).to(dev)
+    t = torch.from_numpy(np.array(a.T, dtype=np.float64, order="C", copy=True)).to(dev)
     return t.permute(*reversed(range(a.ndim)))
 
 

@@ -50,3 +50,69 @@ def test_one_explicit_step_matches_fortran(fpr):
         assert got.shape == ref.shape
         assert np.abs(got[1:-1, 1:-1] - ref[1:-1, 1:-1]).max() < 1e-8, name
     assert out.dt_last == 3.662109375e-05
+
+
+def _oracle_ns_steps(oracle, T, W, nx, ny, Ra, Pr, k, beta, tol, niters, nsteps):
+    """part2.jl:181-250 restated with the oracle's kernels (semi-implicit and explicit branches)."""
+    h = 1.0 / (ny - 1.0)
+    dt_dif = 0.15 * h * h / max(k, Pr)
+    S = farr(nx, ny)
+    out = []
+    for _ in range(nsteps):
+        oracle.mgsolve2d(S, W, h, 0.0, tol, niters)
+        vx, vy = farr(nx, ny), farr(nx, ny)
+        oracle.compute_velocity(S, h, h, vx, vy)
+        v = np.sqrt(vx * vx + vy * vy)
+        if v.max() == 0:
+            dt = dt_dif
+        else:
+            dt_adv = 0.4 * min(h / np.abs(vx).max(), h / np.abs(vy).max())
+            dt = dt_adv if beta >= 0.5 else min(dt_dif, dt_adv)
+        oracle.bc2d(T)
+        R, dT2, dW2 = farr(nx, ny), farr(nx, ny), farr(nx, ny)
+        oracle.compute_Ra_dTdx(Ra, h, T, R)
+        oracle.compute_diffusion2d(T, h, h, k, dT2)
+        oracle.compute_diffusion2d(W, h, h, Pr, dW2)
+        dTx, dTy, dWx, dWy = (farr(nx, ny) for _ in range(4))
+        oracle.compute_advection2d_x(T, h, vx, dTx)
+        oracle.compute_advection2d_y(T, h, vy, dTy)
+        oracle.compute_advection2d_x(W, h, vx, dWx)
+        oracle.compute_advection2d_y(W, h, vy, dWy)
+        if beta > 0.0:
+            c = 1.0 / (beta * dt)
+            T_rhs = np.asfortranarray(-c * (T + dt * ((1.0 - beta) * dT2 - dTx - dTy)))
+            oracle.mgsolve2d(T, T_rhs, h, c, tol, niters, True)
+            c = c / Pr
+            W_rhs = np.asfortranarray(-c * (W + dt * ((1.0 - beta) * dW2 - dWx - dWy - Pr * R)))
+            oracle.mgsolve2d(W, W_rhs, h, c, tol, niters, False)
+        else:
+            T[:] = T + dt * (dT2 - dTx - dTy)
+            W[:] = W + dt * (dW2 - dWx - dWy - Pr * R)
+        out.append(dt)
+    return S, out
+
+
+@pytest.mark.parametrize("beta", [0.0, 0.5])
+def test_driver_steps_match_oracle(fpr, oracle, beta):
+    """Three steps of navier_stokes_2D (explicit and semi-implicit with its apply_BCs / c>0 MG solves) vs the
+    same loop restated with the oracle: identical time steps, fields to 1e-10."""
+    import warnings
+
+    F, p2 = fpr, fpr.part2
+    opt = p2.SimIn_t()
+    opt.nx, opt.ny, opt.beta, opt.tol, opt.Pr, opt.niters, opt.ttot = 129, 33, beta, 1.0e-7, 1.0e-1, 50, 1e9
+    opt.W_init_strategy = p2.random
+    nx, ny = opt.nx, opt.ny
+    h = 1.0 / (ny - 1.0)
+    width = (nx - 1.0) / (ny - 1.0)
+    T = np.asfortranarray(np.repeat((0.5 * (1.0 + np.cos((3.0 * np.pi * np.arange(nx) * h) / width)))[:, None], ny, axis=1))
+    W = np.asfortranarray(p2.splitmix64_uniform(nx * ny, opt.seed).reshape((nx, ny), order="F"))
+    S_o, dts = _oracle_ns_steps(oracle, T, W, nx, ny, opt.Ra, opt.Pr, opt.k, beta, opt.tol, opt.niters, 3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = p2.navier_stokes_2D(opt=opt, verbose=False, max_steps=3)
+    assert out.steps == 3 and abs(out.dt_last - dts[-1]) <= 1e-12 * dts[-1]
+    for name, ref in (("T", T), ("W", W), ("S", S_o)):
+        got = getattr(out, name)
+        scale = max(np.abs(ref).max(), 1e-300)
+        assert np.abs(got - ref).max() <= 1e-10 * scale, (name, np.abs(got - ref).max(), scale)

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_fold_partials(const double* __restrict_
 
 int fprx_finish_sum(fpr_ctx* ctx, const double* partials, int nparts, double* out_dev, bool accumulate, int stream_sel)
 {
-    if (nparts > 8192) {
+    if (nparts > 2048) {
         // two-stage finish (deterministic): 128 slices folded in parallel, then the usual single block.
         // The folded values live behind the partial list itself (the buffers hold FPR_MAX_PARTIALS + 256).
         const int nb = 128;

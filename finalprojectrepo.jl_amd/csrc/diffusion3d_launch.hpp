@@ -17,7 +17,7 @@ struct Diff3Tuning {
 };
 
 #ifndef DIFF3_DEFAULT_VARIANT_ID
-#define DIFF3_DEFAULT_VARIANT_ID 3
+#define DIFF3_DEFAULT_VARIANT_ID 5
 #endif
 #ifndef DIFF3_DEFAULT_RY
 #define DIFF3_DEFAULT_RY 4
@@ -29,7 +29,7 @@ struct Diff3Tuning {
 #define DIFF3_DEFAULT_XCD 0
 #endif
 #ifndef DIFF3_TARGET_BLOCKS
-#define DIFF3_TARGET_BLOCKS 1024
+#define DIFF3_TARGET_BLOCKS 4096
 #endif
 
 template <int VX, int RY, bool LDSY, bool NT>

@@ -81,6 +81,8 @@ int main(int argc, char** argv)
                     for (int nrm : {0, 1}) cfgs.push_back({variant, ry, nt, 0, zc, nrm, 2});
     for (int xcd : {2, 3, 4})
         for (int zc : {0, 16, 32, 128}) cfgs.push_back({3, 4, 1, xcd, zc, 0, 2});
+    for (int xcd : {1, 2, 3, 4})
+        for (int zc : {8, 16, 32}) cfgs.push_back({5, 4, 1, xcd, zc, 0, 2});
     for (int variant : {2, 3})
         for (int ry : {2, 4}) {
             for (int nt : {0, 1})

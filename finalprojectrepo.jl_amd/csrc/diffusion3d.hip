@@ -93,6 +93,45 @@ extern "C" int fpr_diffusion3d_step_norm_host(fpr_ctx* ctx, const double* Ht, co
     return FPR_OK;
 }
 
+extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, double* Htau2, double* dHdtau, int nx, int ny,
+                                     int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx,
+                                     double D_dy, double D_dz, double dt, double total_N, int nt, double tol, long iter_max,
+                                     long fixed_iters, int check_every, long* iters_host, double* err_host, int* swapped_host)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, Ht && Htau && Htau2 && dHdtau, "null field pointer");
+    FPR_REQUIRE(ctx, nt >= 0 && check_every >= 1, "nt >= 0 and check_every >= 1");
+    const size_t N = (size_t)nx * ny * nz;
+    const double sqrtN = sqrt(total_N);
+    double* cur = Htau;
+    double* oth = Htau2;
+    volatile double* pinned = ctx->host_scalars + 8;
+    int swaps = 0;
+    for (int t = 0; t < nt; ++t) {
+        long it = 0;
+        double err = 2 * tol;  // :178
+        while (fixed_iters > 0 ? it < fixed_iters : (err > tol && it < iter_max)) {  // :179
+            const bool need_norm = fixed_iters > 0 ? (it + 1 == fixed_iters) : ((it + 1) % check_every == 0);
+            int rc = diff3_run(ctx, Ht, cur, oth, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, nullptr,
+                               nullptr, need_norm, dt, (double*)pinned, false, 0);
+            if (rc) return rc;
+            double* tmp = cur; cur = oth; oth = tmp;  // :190
+            ++swaps;
+            if (need_norm) {
+                FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
+                err = sqrt(*pinned) / sqrtN;  // :191
+            }
+            ++it;
+        }
+        if (iters_host) iters_host[t] = it;
+        if (err_host) err_host[t] = err;
+        int rc = fpr_copy(ctx, Ht, cur, N);  // Ht .= Htau  :203
+        if (rc) return rc;
+    }
+    if (swapped_host) *swapped_host = swaps & 1;
+    return FPR_OK;
+}
+
 extern "C" int fpr_diffusion3d_step_box(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2,
                                         double* dHdtau, int nx, int ny, int nz, double dtau, double _dt, double _dx,
                                         double _dy, double _dz, double D_dx, double D_dy, double D_dz, const int lo[3],

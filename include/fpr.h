@@ -85,6 +85,18 @@ int fpr_diffusion3d_step_norm_host(fpr_ctx* ctx, const double* Ht, const double*
                                    int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz,
                                    double D_dx, double D_dy, double D_dz, double scale, double* sumsq_host);
 
+/* A5: the single-rank host loop of diffusion_3D_kernel_programming (part1_kernel_programming.jl:166-204) in
+ * native code: for each of `nt` physical steps iterate the fused update until err <= tol (err =
+ * sqrt(sum((dHdtau*dt)^2)) / sqrt(total_N), :191) or iter_max / fixed_iters, then `Ht .= Htau` (:203).
+ * check_every = n evaluates the norm (one host round trip) only every n-th pseudo-iteration (1 = reference).
+ * fixed_iters > 0 runs exactly that many iterations per step.  iters_host / err_host: nt entries each.
+ * The two work buffers swap roles every iteration (:190): *swapped_host = 1 means the current Htau lives in the
+ * memory passed as Htau2 (and the last residual is in dHdtau either way). */
+int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, double* Htau2, double* dHdtau, int nx, int ny, int nz,
+                          double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy, double D_dz,
+                          double dt, double total_N, int nt, double tol, long iter_max, long fixed_iters, int check_every,
+                          long* iters_host, double* err_host, int* swapped_host);
+
 /* Sub-box form used by the multi-GPU driver to split boundary slabs from the interior
  * (role of @hide_communication (8,8,8), part1_kernel_programming.jl:185-188).  Updates cells with
  * lo[d] <= index < hi[d] (0-based, clipped to the interior).  sumsq_dev may be NULL; when given,

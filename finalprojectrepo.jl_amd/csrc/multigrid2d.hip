@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_jacobi_patch(const double* __restrict__
     }
 }
 
-// ---- k_smooth2_march, two columns per lane (opt-in; measured slower) -------------------------------------------------
+// ---- k_smooth2_march, two columns per lane (opt-in; measured slower, see vcycle_level) -------------------------------------------------
 // Same algorithm as k_smooth2_march with a strip of 128 columns per wave: a lane holds two adjacent
 // columns, loads/stores them with one 16-byte access (the hardware accepts the 8-byte alignment that
 // (2^k+1)-wide rows impose), needs a shuffle only for the outer neighbour of each pair, and halves the
@@ -503,8 +503,13 @@ __global__ __launch_bounds__(256) void k_smooth2_march2(const double* __restrict
                                                          double* __restrict__ corr_c_out)
 {
     __shared__ double red[16];
-    constexpr int HX = RESTRICT ? 3 : 2;   // feeder COLUMNS on each side of a strip
-    constexpr int SW = 128 - 2 * HX;       // columns owned by a strip
+    // Feeder COLUMNS: HXL on the left, HXR on the right.  On rows whose start is only 8-byte aligned (odd rows of
+    // an odd-width grid) the lane <-> column mapping is shifted by one column so that every 16-byte access stays
+    // 16-byte aligned; the wave then loses its last column on those rows, hence one more feeder on the right.
+    // All widths are even so that strips start on even columns.
+    constexpr int HX = RESTRICT ? 4 : 2;   // left feeders (3 needed with RESTRICT, rounded up to an even number)
+    constexpr int HXR = RESTRICT ? 4 : 4;  // right feeders: needed (2 or 3) + 1 lost column, rounded up to even
+    constexpr int SW = 128 - HX - HXR;     // columns owned by a strip
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + w;
     const bool active = strip < nstrips;
@@ -523,11 +528,15 @@ __global__ __launch_bounds__(256) void k_smooth2_march2(const double* __restrict
             gic[e] = gi[e] < 0 ? 0 : (gi[e] > nx - 1 ? nx - 1 : gi[e]);
             colbnd[e] = gi[e] <= 0 || gi[e] >= nx - 1;
             const int q = 2 * lane + e;
-            owner[e] = gi[e] >= 0 && gi[e] < nx && q >= HX && q < 128 - HX;
+            owner[e] = gi[e] >= 0 && gi[e] < nx && q >= HX && q < 128 - HXR;
             gis[e] = gic[e];
             if (PROLONG && apply_BCs) gis[e] = (gic[e] == 0) ? 1 : (gic[e] == nx - 1 ? nx - 2 : gic[e]);
         }
-        const bool vec_ok = g0 >= 0 && g0 + 1 < nx;  // both columns exist: one 16-byte access
+        const bool vec_ok = g0 >= 0 && g0 + 1 < nx;   // both columns exist: one 16-byte access (unshifted rows)
+        const bool vec_ok_s = g0 >= 1 && g0 < nx;     // columns g0-1, g0 exist (shifted rows)
+        const bool odd_pitch = (nx & 1) != 0;
+        // element 1 of the previous lane is owned / exists (needed for the shifted store)
+        const bool owner_prev = (2 * lane - 1 >= HX) && (2 * lane - 1 < 128 - HXR) && g0 - 1 >= 0 && g0 - 1 < nx;
         // PROLONG: per element, the two coarse columns it interpolates from, cached for coarse rows pj, pj+1
         int p_icl[2], p_ich[2], p_io[2];
         bool p_sx0[2], p_sx1[2], p_inx[2];
@@ -545,11 +554,26 @@ __global__ __launch_bounds__(256) void k_smooth2_march2(const double* __restrict
         auto ld2 = [&](const double* __restrict__ p, int r, double& v0, double& v1) {
             const int rc = r > ny - 1 ? ny - 1 : r;
             const size_t row = (size_t)nx * rc;
-            if (vec_ok) {
-                const FprD2 t = *reinterpret_cast<const FprD2*>(p + row + g0);
-                v0 = t.x; v1 = t.y;
+            if (odd_pitch && (rc & 1)) {
+                // shifted row: this lane fetches columns (g0-1, g0), 16-byte aligned; element 1 (column g0+1) is the
+                // first element of the next lane's pair
+                double s0, s1;
+                if (vec_ok_s) {
+                    const double2 t = *reinterpret_cast<const double2*>(p + row + (g0 - 1));
+                    s0 = t.x; s1 = t.y;
+                } else {
+                    const int c0 = g0 - 1 < 0 ? 0 : (g0 - 1 > nx - 1 ? nx - 1 : g0 - 1);
+                    s0 = p[row + c0]; s1 = p[row + gic[0]];
+                }
+                v0 = s1;
+                v1 = fpr_lane_down1(s0);
             } else {
-                v0 = p[row + gic[0]]; v1 = p[row + gic[1]];
+                if (vec_ok) {
+                    const double2 t = *reinterpret_cast<const double2*>(p + row + g0);
+                    v0 = t.x; v1 = t.y;
+                } else {
+                    v0 = p[row + gic[0]]; v1 = p[row + gic[1]];
+                }
             }
         };
         auto ldu = [&](int r, double& v0, double& v1) {
@@ -626,11 +650,20 @@ __global__ __launch_bounds__(256) void k_smooth2_march2(const double* __restrict
                 const bool bn0 = rowb || colbnd[0], bn1 = rowb || colbnd[1];
                 const double u20 = bn0 ? b1[0] : b1[0] + fac * rr0;
                 const double u21 = bn1 ? b1[1] : b1[1] + fac * rr1;
+                const bool shifted_row = odd_pitch && (j2 & 1) && j2 >= 0;
+                const double prev21 = fpr_lane_up1(u21);  // column g0-1 (element 1 of the previous lane)
                 if (j2 >= y0 && j2 < y1) {
                     const size_t o = (size_t)nx * j2;
-                    if (owner[0] && owner[1]) {
-                        FprD2 t; t.x = u20; t.y = u21;
-                        *reinterpret_cast<FprD2*>(uout + o + g0) = t;
+                    if (shifted_row) {
+                        if (owner_prev && owner[0]) {
+                            *reinterpret_cast<double2*>(uout + o + (g0 - 1)) = make_double2(prev21, u20);
+                        } else {
+                            if (owner_prev) uout[o + g0 - 1] = prev21;
+                            if (owner[0]) uout[o + gi[0]] = u20;
+                        }
+                        // (this lane's element 1, column g0+1, is stored by the next lane as its `prev21`)
+                    } else if (owner[0] && owner[1]) {
+                        *reinterpret_cast<double2*>(uout + o + g0) = make_double2(u20, u21);
                     } else {
                         if (owner[0]) uout[o + gi[0]] = u20;
                         if (owner[1]) uout[o + gi[1]] = u21;
@@ -1555,10 +1588,11 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             // temporal blocking, register-rolling march: each smoothing pair is ONE pass (u -> tmp, tmp -> u)
             const bool fuse_r = fpr_opt(ctx, "mg_fuse_restrict", 1) != 0;
             const int ntf = fpr_opt(ctx, "mg_nt", 0) ? 256 : 0;
-            // two columns per lane (128-column strips, 16-byte accesses at 8-byte alignment): measured 10 % SLOWER than
-            // one column per lane on MI355X (3.54 vs 3.20 ms per 4097^2 solve), so it is opt-in (mg_vx = 2)
-            const bool vx2 = fpr_opt(ctx, "mg_vx", 1) == 2 && nx >= 128;
-            const int sw = vx2 ? 124 : 60, sw_r = vx2 ? 122 : 58;
+            // two columns per lane (128-column strips, aligned 16-byte accesses with a per-row lane shift): bit-identical but
+            // measured SLOWER on MI355X (4.4 vs 2.8 ms per 4097^2 solve; 114-204 VGPRs against 36-60), so it is opt-in (mg_vx = 2)
+            const bool al16 = ((((uintptr_t)u | (uintptr_t)rhs | (uintptr_t)L.tmp) & 15) == 0);
+            const bool vx2 = fpr_opt(ctx, "mg_vx", 1) == 2 && nx >= 128 && al16;
+            const int sw = vx2 ? 122 : 60, sw_r = vx2 ? 120 : 58;
             const int nstrips = (nx + sw - 1) / sw;
             const int nstrips_r = (nx + sw_r - 1) / sw_r;  // strips of the restricting pre-smoothing pass
             int rpc = (int)fpr_opt(ctx, "mg_rows_per_chunk", 0);

@@ -14,7 +14,11 @@ def run(label):
             r = mg.MGsolve_2DPoisson_(x, b, 1.0/(n-1), 0.0, 1e-6, 100, False)
         F.synchronize(); ts.append(time.time() - t0)
     print("%-28s %.3f ms (min %.3f)" % (label, sorted(ts)[len(ts)//2]*1e3, min(ts)*1e3))
-F.ctx().set_option("mg_vx", 1)
-for tgt in (2048, 4096, 8192, 16384, 4096):
+F.ctx().set_option("mg_wave_target", 4096)
+for vx in (1, 2, 1, 2):
+    F.ctx().set_option("mg_vx", vx)
+    run("mg_vx=%d" % vx)
+F.ctx().set_option("mg_vx", 2)
+for tgt in (2048, 8192):
     F.ctx().set_option("mg_wave_target", tgt)
-    run("mg_wave_target=%d" % tgt)
+    run("mg_vx=2 target=%d" % tgt)

@@ -386,33 +386,47 @@ __global__ __launch_bounds__(256) void k_jacobi_patch(const double* __restrict__
             own[b][a] = in && gi >= x0 && gi < x0 + T && gj >= y0 && gj < y0 + T;
         }
     if constexpr (STATE) {
-        if (state->done) return;
+        // Replay of the previous group's exit test.  All loads (flag, threshold, partial sums) are issued together;
+        // wave w sums the partials of sweeps w, w+4 (same order as k_jacobi_check_multi), lanes 0..prev_nsw-1 of
+        // wave 0 then evaluate sqrt(sum/N) < thresh in parallel and a ballot finds the first sweep that met it.
+        const int done0 = state->done;
+        const double thresh = state->thresh;
+        const int nblk = gridDim.x * gridDim.y;
+        const int lane = tid & 63, wv = tid >> 6;
+        double part_acc[2] = {0.0, 0.0};
         if (prev_nsw > 0) {
-            const int nblk = gridDim.x * gridDim.y;
-            const int lane = tid & 63, wv = tid >> 6;
-            for (int s = wv; s < prev_nsw; s += 4) {  // same summation order as k_jacobi_check_multi
-                double a = 0.0;
-                for (int i = lane; i < nblk; i += 64) a += prev_partials[(size_t)s * nblk + i];
-                a = fpr_wave_sum(a);
-                if (lane == 0) red[0][s] = a;  // S >= prev_nsw
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int sidx = wv + 4 * h;
+                if (sidx < prev_nsw)
+                    for (int i = lane; i < nblk; i += 64) part_acc[h] += prev_partials[(size_t)sidx * nblk + i];
+            }
+        }
+        if (done0) return;
+        if (prev_nsw > 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int sidx = wv + 4 * h;
+                const double a = fpr_wave_sum(part_acc[h]);
+                if (lane == 0 && sidx < prev_nsw) red[0][sidx] = a;  // S >= prev_nsw
             }
             __syncthreads();
-            if (tid == 0) {
-                const double thresh = state->thresh;
-                int conv = -1;
-                double rms = 0.0;
-                for (int s = 0; s < prev_nsw; ++s) {
-                    rms = sqrt(red[0][s] / Ntot);
-                    if (rms < thresh) { conv = s; break; }
-                }
-                stop_flag = conv >= 0;
-                if (blockIdx.x == 0 && blockIdx.y == 0) {
-                    state->iters += (conv >= 0) ? conv + 1 : prev_nsw;
-                    state->last_rms = rms;
-                    if (conv >= 0) {
-                        state->redo = conv + 1;
-                        state->group = prev_group;
-                        state->done = 1;
+            if (wv == 0) {
+                const double rms = (lane < prev_nsw) ? sqrt(red[0][lane < S ? lane : 0] / Ntot) : 0.0;
+                const unsigned long long hit = __ballot(lane < prev_nsw && rms < thresh);
+                const int conv = hit ? (int)__builtin_ctzll(hit) : -1;
+                const int last = conv >= 0 ? conv : prev_nsw - 1;
+                const double rms_last = __shfl(rms, last, 64);
+                if (lane == 0) {
+                    stop_flag = conv >= 0;
+                    if (blockIdx.x == 0 && blockIdx.y == 0) {
+                        state->iters += (conv >= 0) ? conv + 1 : prev_nsw;
+                        state->last_rms = rms_last;
+                        if (conv >= 0) {
+                            state->redo = conv + 1;
+                            state->group = prev_group;
+                            state->done = 1;
+                        }
                     }
                 }
             }
@@ -1712,8 +1726,13 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                         double* slot = ctx->partials + (size_t)(gi & 1) * S * nblk;
                         const double* pslot = ctx->partials + (size_t)((gi + 1) & 1) * S * nblk;
                         const bool pending = gi > gdone;  // the previous group of THIS chunk is still unchecked
+                        const long dbg = fpr_opt(ctx, "mg_patch_dbg", 0);  // timing diagnostics only (results invalid when set)
+                        if (dbg & 2)
+                            k_jacobi_patch<S, false, true><<<gm, 256, 0, s>>>(a, rhs, b, nx, ny, C, _h2, fac, nsw, slot, ctx->state,
+                                                                               pslot, 0, gi - 1, (double)N);
+                        else
                         k_jacobi_patch<S, true, true><<<gm, 256, 0, s>>>(a, rhs, b, nx, ny, C, _h2, fac, nsw, slot, ctx->state,
-                                                                          pslot, pending ? Sg : 0, gi - 1, (double)N);
+                                                                          pslot, (pending && !(dbg & 1)) ? Sg : 0, gi - 1, (double)N);
                         if (gi == gend - 1)  // last group of the chunk: stand-alone check before the host polls
                             k_jacobi_check_multi<<<1, 256, 0, s>>>(ctx->state, slot, nblk, nsw, (double)N, gi);
                     } else {

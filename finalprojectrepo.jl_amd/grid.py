@@ -291,6 +291,19 @@ class GlobalGrid:
         return out
 
 
+def assemble_global(parts, dims):
+    """gather!(A, A_global) layout (part1_kernel_programming.jl:144,223): the local arrays, halos included, side by
+    side in Cartesian order -> array of shape (nx*dims[0], ny*dims[1], nz*dims[2])."""
+    import numpy as np
+
+    nx, ny, nz = parts[0].shape
+    G = np.zeros((nx * dims[0], ny * dims[1], nz * dims[2]), order="F")
+    for r, a in enumerate(parts):
+        c = (r // (dims[1] * dims[2]), (r // dims[2]) % dims[1], r % dims[2])
+        G[c[0] * nx:(c[0] + 1) * nx, c[1] * ny:(c[1] + 1) * ny, c[2] * nz:(c[2] + 1) * nz] = a
+    return G
+
+
 def finalize_global_grid():
     """finalize_global_grid(): nothing to release (torch.distributed is owned by the caller)."""
     return None

@@ -141,6 +141,46 @@ def dist_norm_L2(Rh, comm_cart=None, scale=1.0):
     return math.sqrt(s)
 
 
+LOCATION_OF_INTEREST = (4.5, 4.5, 4.5)  # part1_error_vs_*_experiments.jl:20
+
+
+def linear_interpolate_3D(H, dx, location=LOCATION_OF_INTEREST):
+    """part1_utils.jl:42-71 (NEXT row 8f-4).  H: host array (numpy, Julia index order).
+
+    The reference builds an 8x8 trilinear system whose z column holds z0 eight times (:57), so the matrix is
+    singular by construction, `M \\ cvec` throws, and the `catch` branch (:67-69) returns H[ix, iy, iz] with
+    ix = Int(x ÷ dx) + 1.  The published `interp_val` columns confirm this (tests/test_oracle_pins.py).  The
+    system is still assembled here so that the behaviour follows from the same data."""
+    import numpy as np
+
+    dy = dz = dx
+    ix, iy, iz = (int(c // dx) + 1 for c in location)  # 1-based, :45
+    x0, x1 = ix * dx + dx / 2, (ix + 1) * dx + dx / 2
+    y0, y1 = iy * dy + dy / 2, (iy + 1) * dy + dy / 2
+    z0 = iz * dz + dz / 2
+    h = lambda a, b, c: float(H[a - 1, b - 1, c - 1])
+    cvec = np.array([h(ix, iy, iz), h(ix + 1, iy, iz), h(ix, iy + 1, iz), h(ix + 1, iy + 1, iz), h(ix, iy, iz + 1),
+                     h(ix + 1, iy, iz + 1), h(ix, iy + 1, iz + 1), h(ix + 1, iy + 1, iz + 1)])
+    xvec = np.tile([x0, x1], 4)
+    yvec = np.tile([y0, y0, y1, y1], 2)
+    zvec = np.full(8, z0)  # :57 -- z1 is never used
+    M = np.column_stack([np.ones(8), xvec, yvec, zvec, xvec * yvec, xvec * zvec, yvec * zvec, xvec * yvec * zvec])
+    if np.linalg.matrix_rank(M) < 8:  # always true: the z columns are multiples of the others
+        return cvec[0]
+    avec = np.linalg.solve(M, cvec)
+    x, y, z = location
+    return float(np.array([1, x, y, z, x * y, x * z, y * z, x * z * z]) @ avec)  # :64 (sic: x*z*z)
+
+
+def probe_value(H, X):
+    """`val` of part1_error_vs_*_experiments.jl:31-37: H[ix,iy,iz] with ix = round(Int, 4.5/dx + 1), dx = X[2]-X[1]."""
+    import numpy as np
+
+    dx = X[1] - X[0]
+    i, j, k = (int(np.round(c / dx + 1)) - 1 for c in LOCATION_OF_INTEREST)
+    return float(H[i, j, k]), dx
+
+
 # ------------------------------------------------------------------------------------------------
 # solver host loop
 # ------------------------------------------------------------------------------------------------

@@ -283,3 +283,30 @@ def test_part1_published_grid_size_values_bit_exact(oracle, n):
     oracle.diffusion3d_solve(Ht, nt=10, tol=1e-6)
     i = probe_index(n)
     assert Ht[i, i, i] == float(row["val"])
+
+
+@pytest.mark.parametrize("n", [16, 23, 32, 45, 64])
+def test_part1_published_interp_values(oracle, n):
+    """`interp_val` of the published CSV = linear_interpolate_3D (part1_utils.jl:42-71).  Its 8x8 system is
+    singular by construction, so the reference's catch branch returns H[ix,iy,iz], ix = Int(4.5 ÷ dx) + 1:
+    reproduced to the last digit (for 64^3 this is a different cell than `val`)."""
+    import fpr_amd
+
+    row = [r for r in _published("error_vs_grid_size_experiment_results.csv") if int(r["nx"]) == n][0]
+    dx = 10.0 / n
+    Ht = oracle.init_gaussian((n, n, n), dx, dx, dx, (5.0, 5.0, 5.0))
+    oracle.diffusion3d_solve(Ht, nt=10, tol=1e-6)
+    X = np.linspace(dx / 2, 10.0 - dx / 2, n)
+    v = fpr_amd.pkg.part1.linear_interpolate_3D(Ht, X[1] - X[0])
+    assert v == float(row["interp_val"])
+    assert fpr_amd.pkg.part1.probe_value(Ht, X)[0] == float(row["val"])
+
+
+def test_assemble_global_layout():
+    import fpr_amd
+
+    dims = (2, 1, 2)
+    parts = [np.full((3, 2, 2), float(r), order="F") for r in range(4)]
+    G = fpr_amd.pkg.grid.assemble_global(parts, dims)
+    assert G.shape == (6, 2, 4)
+    assert G[0, 0, 0] == 0 and G[0, 0, 2] == 1 and G[3, 0, 0] == 2 and G[5, 1, 3] == 3

@@ -316,3 +316,27 @@ def test_multisweep_and_single_sweep_paths_agree(fpr):
     for r, u in outs[1:]:
         assert np.array_equal(u, outs[0][1])
         assert abs(r - outs[0][0]) <= 1e-13 * abs(outs[0][0])
+
+
+@pytest.mark.parametrize("bc", [False, True])
+@pytest.mark.parametrize("shape,css", [((5, 5), 5), ((9, 9), 5), ((9, 33), 5), ((33, 9), 3), ((17, 5), 5), ((65, 17), 9),
+                                        ((129, 33), 5), ((3, 3), 3), ((1025, 257), 5)], ids=str)
+def test_small_and_rectangular_hierarchies(fpr, oracle, shape, css, bc):
+    """Tiny, rectangular (lambda_x != lambda_y, multigrid.jl:27-28) and LDS-resident hierarchies: full solve parity."""
+    F, mg = fpr, fpr.multigrid
+    u0, f = rnd(shape, 51), rnd(shape, 52)
+    h = 1.0 / (min(shape) - 1)
+    c = 0.0 if not bc else 2.5
+    opt = mg.MGOpt()
+    opt.coarse_solve_size = css
+    u_ref = u0.copy(order="F")
+    r_ref, hist_ref, frms_ref = oracle.mgsolve2d(u_ref, f, h, c, 1e-9, 6, bc, css, 0)
+    gu = F.asdevice(u0)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r, hist, frms, cit = mg.MGsolve_2DPoisson_(gu, F.asdevice(f), h, c, 1e-9, 6, bc, opt=opt, return_history=True)
+    assert len(hist) == len(hist_ref)
+    assert np.allclose(hist, hist_ref, rtol=1e-10, atol=0)
+    assert np.array_equal(F.tonumpy(gu), u_ref)
+    assert cit == oracle.last_coarse_iters()

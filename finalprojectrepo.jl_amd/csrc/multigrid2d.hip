@@ -274,7 +274,11 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
         // for that load) and PF rows stay in flight per lane.
         auto step = [&](auto Qc, int r) {
             constexpr int Q = decltype(Qc)::value;
-            const double an = pu[Q], fn = pfv[Q];
+            // An explicit register copy of the (completed) row ends the live range of the slot, so the refill below
+            // can target the slot's own registers and nothing in flight has to be copied at the loop's back edge.
+            double an, fn;
+            asm volatile("v_mov_b64 %0, %1" : "=v"(an) : "v"(pu[Q]));
+            asm volatile("v_mov_b64 %0, %1" : "=v"(fn) : "v"(pfv[Q]));
             pu[Q] = ldu(r + 1 + PF);                           // issue the loads of row r+1+PF
             pfv[Q] = ldf(r + 1 + PF);
             // ---- sweep 1 at row r-1 (needs u rows r-2, r-1, r) ----

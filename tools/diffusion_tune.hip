@@ -11,6 +11,8 @@
 #include <vector>
 
 #include "../finalprojectrepo.jl_amd/csrc/diffusion3d_launch.hpp"
+#include "../finalprojectrepo.jl_amd/csrc/diffusion3d_fused2.hpp"
+#include <cmath>
 
 #define CK(x)                                                                              \
     do {                                                                                   \
@@ -130,6 +132,88 @@ int main(int argc, char** argv)
         printf("%-8d %3d %3d %3d %3d %6d %5d %9.4f %9.1f %6.1f %s (blocks=%d)\n", c.variant, c.vx, c.ry, c.nt, c.xcd, c.zc, c.norm, ms, gbs,
                100.0 * gbs / 8000.0, bad ? "MISMATCH" : "ok", np);
         fflush(stdout);
+    }
+
+    // ---- fused two-step kernel (diffusion3d_fused2.hpp): checked against two naive steps ----
+    if (!filter[0] || strstr("f2", filter) || strstr(filter, "f2")) {
+        double *B, *Bref, *Cref, *C, *parts2;
+        CK(hipMalloc(&B, N * 8)); CK(hipMalloc(&Bref, N * 8)); CK(hipMalloc(&Cref, N * 8)); CK(hipMalloc(&C, N * 8));
+        CK(hipMalloc(&parts2, (1 << 22) * 8));
+        k_fill_rand<<<2048, 256, 0, s>>>(B, N, 3);
+        CK(hipMemcpyAsync(Bref, B, N * 8, hipMemcpyDeviceToDevice, s));
+        CK(hipMemsetAsync(Cref, 0, N * 8, s));
+        CK(hipMemsetAsync(dHref, 0, N * 8, s));
+        double ref1 = 0, ref2 = 0;
+        std::vector<double> hp(1 << 22);
+        {   // reference: A -> Bref (keeps B's boundary), Bref -> Cref; norms from the naive kernel's partials
+            Diff3Tuning t; t.variant = 1;
+            a.Htau = Htau; a.Htau2 = Bref; a.dHdtau = dHref;
+            CK(diff3_launch(a, true, t, s, 1 << 22, &np)); CK(hipStreamSynchronize(s));
+            CK(hipMemcpy(hp.data(), parts, (size_t)np * 8, hipMemcpyDeviceToHost));
+            for (int i = 0; i < np; ++i) ref1 += hp[i];
+            a.Htau = Bref; a.Htau2 = Cref;
+            CK(diff3_launch(a, true, t, s, 1 << 22, &np)); CK(hipStreamSynchronize(s));
+            CK(hipMemcpy(hp.data(), parts, (size_t)np * 8, hipMemcpyDeviceToHost));
+            for (int i = 0; i < np; ++i) ref2 += hp[i];
+            a.Htau = Htau;
+        }
+        Diff3Args2 f;
+        f.Ht = Ht; f.A = Htau; f.B = B; f.C = C; f.dH = dH;
+        f.nx = f.ny = f.nz = n;
+        for (int d = 0; d < 3; ++d) { f.lo[d] = 1; f.hi[d] = n - 1; }
+        f.dtau = a.dtau; f._dt = a._dt; f._dx = a._dx; f._dy = a._dy; f._dz = a._dz;
+        f.D_dx = a.D_dx; f.D_dy = a.D_dy; f.D_dz = a.D_dz; f.scale = a.scale;
+        f.partials1 = parts; f.partials2 = parts2;
+        printf("# fused two-step kernel: ms per LAUNCH (= 2 iterations), GB/s in the per-iteration A_eff metric\n");
+        for (int xcd : {0, 1})
+            for (int zc : {0, 16, 24, 32, 48, 64, 128})
+                for (int nrm : {0, 1}) {
+                    char name[64];
+                    snprintf(name, sizeof name, "f2-xcd%d-zc%d-n%d", xcd, zc, nrm);
+                    if (filter[0] && !strstr(name, filter)) continue;
+                    CK(hipMemsetAsync(C, 0, N * 8, s)); CK(hipMemsetAsync(dH, 0, N * 8, s));
+                    hipError_t e = diff3_launch2(f, nrm != 0, zc, xcd, s, 1 << 22, &np);
+                    if (e != hipSuccess) { printf("%-24s launch failed: %s\n", name, hipGetErrorString(e)); continue; }
+                    CK(hipMemsetAsync(cnt, 0, 8, s));
+                    k_count_diff<<<2048, 256, 0, s>>>(C, Cref, N, cnt);
+                    k_count_diff<<<2048, 256, 0, s>>>(dH, dHref, N, cnt);
+                    unsigned long long bad = 0;
+                    CK(hipMemcpyAsync(&bad, cnt, 8, hipMemcpyDeviceToHost, s));
+                    CK(hipStreamSynchronize(s));
+                    double n1 = 0, n2 = 0;
+                    if (nrm) {
+                        CK(hipMemcpy(hp.data(), parts, (size_t)np * 8, hipMemcpyDeviceToHost));
+                        for (int i = 0; i < np; ++i) n1 += hp[i];
+                        CK(hipMemcpy(hp.data(), parts2, (size_t)np * 8, hipMemcpyDeviceToHost));
+                        for (int i = 0; i < np; ++i) n2 += hp[i];
+                    }
+                    const bool nbad = nrm && (fabs(n1 - ref1) > 1e-12 * ref1 || fabs(n2 - ref2) > 1e-12 * ref2);
+                    CK(hipEventRecord(e0, s));
+                    for (int w = 0; w < 200; ++w) {
+                        CK(diff3_launch2(f, nrm != 0, zc, xcd, s, 1 << 22, &np));
+                        if ((w & 15) == 15) {
+                            CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                            float wm; CK(hipEventElapsedTime(&wm, e0, e1));
+                            if (wm > 60.f) break;
+                        }
+                    }
+                    float r[3];
+                    for (int round = 0; round < 3; ++round) {
+                        CK(hipEventRecord(e0, s));
+                        for (int i = 0; i < iters; ++i) CK(diff3_launch2(f, nrm != 0, zc, xcd, s, 1 << 22, &np));
+                        CK(hipEventRecord(e1, s));
+                        CK(hipEventSynchronize(e1));
+                        CK(hipEventElapsedTime(&r[round], e0, e1));
+                        r[round] /= iters;
+                    }
+                    float ms = r[0] > r[1] ? (r[1] > r[2] ? r[1] : (r[0] > r[2] ? r[2] : r[0])) : (r[0] > r[2] ? r[0] : (r[1] > r[2] ? r[2] : r[1]));
+                    const double gbs = 2.0 * bytes / (ms * 1e-3) / 1e9;
+                    printf("%-24s %9.4f ms/launch %9.1f GB/s(A_eff) %6.1f%%  %s%s (blocks=%d)\n", name, ms, gbs, 100.0 * gbs / 8000.0,
+                           bad ? "MISMATCH" : "ok", nbad ? " NORM-MISMATCH" : "", np);
+                    if (nbad) printf("   norms: %.17g vs %.17g ; %.17g vs %.17g\n", n1, ref1, n2, ref2);
+                    if (bad) printf("   mismatching values: %llu\n", bad);
+                    fflush(stdout);
+                }
     }
     return 0;
 }

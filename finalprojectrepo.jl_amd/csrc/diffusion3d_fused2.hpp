@@ -23,8 +23,8 @@
 //     work: 16/14 in y, (zc+2)/zc in z; x uses 5 tiles of ~102 owned cells for a 512-cell line);
 //   * domain-boundary cells of L1 are taken from B: the registers that would hold the (non-existent) L0 halo
 //     beyond the boundary carry the B value instead, so the steady-state loop has no extra loads.
-// Requirements (the caller falls back to two single-step launches otherwise): nx even, all arrays 16-byte
-// aligned, ny >= 16, nz >= 3.
+// Requirements (the caller falls back to two single-step launches otherwise): nx even and >= 128, all
+// arrays 16-byte aligned, ny >= 16, nz >= 3.
 #pragma once
 #include "diffusion3d_kernels.hpp"
 
@@ -44,17 +44,82 @@ struct Diff3Args2 {
     int xcd_remap;
 };
 
+// DPP wave shifts without an `old` operand: the edge lane receives 0 (no register copy needed)
+__device__ __forceinline__ double diff3_lane_up1_z(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double diff3_lane_down1_z(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// DPP wave shifts whose edge lane (lane 0 for "up", lane 63 for "down") receives `edge` instead of a neighbour
+__device__ __forceinline__ double diff3_lane_up1_edge(double v, double edge)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double diff3_lane_down1_edge(double v, double edge)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x130, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Buffer addressing: address = descriptor base (4 SGPRs, loop-invariant) + per-lane byte offset (1 VGPR,
+// loop-invariant) + scalar byte offset (1 SGPR: plane and row).  No 64-bit address arithmetic per access;
+// the hardware range check (num_records) turns the one possible read beyond the last plane into a zero.
+typedef double diff3_d2v __attribute__((ext_vector_type(2)));
+typedef unsigned diff3_u4v __attribute__((ext_vector_type(4)));
+typedef unsigned diff3_u2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t diff3_rsrc(uintptr_t p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ DVec<2> diff3_bld2(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
+{
+    const diff3_d2v t = __builtin_bit_cast(diff3_d2v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    DVec<2> o;
+    o.v[0] = t.x;
+    o.v[1] = t.y;
+    return o;
+}
+__device__ __forceinline__ double diff3_bld1(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void diff3_bst2_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, double x, double y)
+{
+    diff3_d2v t;
+    t.x = x;
+    t.y = y;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(diff3_u4v, t), r, voff, soff, 2 /* nt */);
+}
+__device__ __forceinline__ void diff3_bst1(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, double x)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(diff3_u2v, x), r, voff, soff, 0);
+}
+
 template <bool NORM>
 __global__ __launch_bounds__(256) void k_diff3_march2(Diff3Args2 a)
 {
     constexpr int VX = 2, RY = 4, TXW = 128, SYB = 4 * RY - 2;
+    constexpr int SLOT = 4 * TXW;  // doubles per wave slot: L0 first row, L0 last row, L1 first row, L1 last row
     __shared__ double red[8];
-    // [parity][wave][L0 first row, L0 last row, L1 first row, L1 last row][TXW]
-    __shared__ __attribute__((aligned(16))) double xrow[2 * 4 * 4 * TXW];
+    // [parity][slot 0..5][row kind][TXW]; wave w owns slot w+1, slot 0 / 5 receive the global halo rows of
+    // waves 0 / 3, so every wave reads "the slot below" and "the slot above" without a select
+    __shared__ __attribute__((aligned(16))) double xrow[2 * 6 * SLOT];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int w = tid >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: rows, halo sources and row masks stay scalar
 
     int bid = blockIdx.x;
     if (a.xcd_remap == 1) {
@@ -70,20 +135,27 @@ __global__ __launch_bounds__(256) void k_diff3_march2(Diff3Args2 a)
     const int nx = a.nx, ny = a.ny, nz = a.nz;
     const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
 
-    // ---- x: owned output cells [ol, oh); the tile's own cells start at the even index s <= ol-1 ----
-    const int ol = a.lo[0] + tx * a.sx;
-    const int oh = (ol + a.sx < a.hi[0]) ? ol + a.sx : a.hi[0];
-    const int s = (ol - 1) & ~1;
+    // ---- x: owned output cells [ol, oh) (cut points between tiles are even); own cells [s, s+128) ----
+    const int e0 = a.lo[0] & ~1;
+    const int olr = e0 + tx * a.sx, ohr = olr + a.sx;
+    const int ol = olr > a.lo[0] ? olr : a.lo[0];
+    const int oh = ohr < a.hi[0] ? ohr : a.hi[0];
+    int s = (ol - 1) & ~1;
+    s = s < nx - TXW ? s : nx - TXW;                 // the x-boundary cell nx-1, if in the tile, belongs to lane 63
     const int ib = s + lane * VX;
     int ilast = (oh + 1) & ~1;                       // last pair that is needed (L0 at oh+1)
     ilast = ilast < nx - 2 ? ilast : nx - 2;
     const int ibc = ib < ilast ? ib : ilast;         // lanes beyond re-read the last needed pair
-    const bool bndL = (ib == 0);                     // own cell v=0 is the x-boundary
-    const bool bndR = (ib + 1 == nx - 1);            // own cell v=1 is the x-boundary
-    const bool is_edge = (lane == 0) || (lane == 63) || bndR;
-    const double* __restrict__ Esrc = (bndL || bndR) ? a.B : a.A;
-    int ie = bndL ? 0 : (bndR ? nx - 1 : (lane == 0 ? ib - 1 : ib + VX));
+    const unsigned voff = (unsigned)ibc * 8u;        // per-lane byte offset inside a row
+    const bool xb_tile = (s == 0) || (s + TXW == nx);   // uniform: the tile holds an x-boundary cell
+    const bool bndL = (ib == 0);                     // own cell v=0 is the x-boundary (lane 0 of tile 0)
+    const bool bndR = (ib + 1 == nx - 1);            // own cell v=1 is the x-boundary (lane 63 of the last tile)
+    const bool is_edge = (lane == 0) || (lane == 63);
+    // edge register: L0 cell beyond the tile, or -- for the lane holding an x-boundary cell -- that cell's B value
+    int ie = (lane == 0) ? ib - 1 : ib + VX;
     ie = ie < 0 ? 0 : (ie > nx - 1 ? nx - 1 : ie);
+    const unsigned eoff = (unsigned)ie * 8u;                      // L0 edge cell (from A)
+    const unsigned boff = bndL ? 0u : (unsigned)(nx - 1) * 8u;    // x-boundary own cell (from B)
 
     // ---- y: owned rows [oly, ohy); block rows y1 .. y1+15 ----
     const int oly = a.lo[1] + by * SYB;
@@ -92,11 +164,11 @@ __global__ __launch_bounds__(256) void k_diff3_march2(Diff3Args2 a)
     const int j0 = y1 + w * RY;
     const bool bb = (w == 0) && (y1 == 0);                    // own row 0 of wave 0 is the y-boundary
     const bool bt = (w == 3) && (y1 + 4 * RY - 1 == ny - 1);  // own last row of wave 3 is the y-boundary
-    const bool need_gd = (w == 0), need_gu = (w == 3);
     const int jd = bb ? 0 : (j0 > 0 ? j0 - 1 : 0);
     const int ju = bt ? ny - 1 : (j0 + RY < ny - 1 ? j0 + RY : ny - 1);
-    const double* __restrict__ YDsrc = bb ? a.B : a.A;
-    const double* __restrict__ YUsrc = bt ? a.B : a.A;
+    const bool hwave = (w == 0) || (w == 3);                  // waves that own a global halo row
+    const double* Hsrc = (w == 0) ? (bb ? a.B : a.A) : (bt ? a.B : a.A);
+    const int hrow = (w == 0) ? jd : ju;
 
     // ---- z: owned planes [k0, k1); iterations m0 .. m1 ----
     const int k0 = a.lo[2] + tz * a.zc;
@@ -107,133 +179,168 @@ __global__ __launch_bounds__(256) void k_diff3_march2(Diff3Args2 a)
 #pragma unroll
     for (int v = 0; v < VX; ++v) cm[v] = (ib + v >= ol) && (ib + v < oh);
 #pragma unroll
-    for (int r = 0; r < RY; ++r) rm[r] = (j0 + r >= oly) && (j0 + r < ohy);
+    for (int r = 0; r < RY; ++r) rm[r] = (j0 + r >= oly) && (j0 + r < ohy);   // uniform
+    const bool cmp = cm[0] && cm[1];
+    const bool has_split = ((ol | oh) & 1) != 0;     // uniform: some lane owns only one cell of its pair
+    const unsigned soff = (unsigned)ib * 8u;
 
     const Diff3Coef cf{a.dtau, a._dt, a._dx, a._dy, a._dz, a.D_dx, a.D_dy, a.D_dz};
-    const double* __restrict__ H = a.A;
     auto kcl = [&](int k) { return k < 0 ? 0 : (k > nz - 1 ? nz - 1 : k); };
 
-    DVec<VX> P[4][RY];        // L0 planes (m-1, m, m+1, m+2) in slots ((m-m0)+{0,1,2,3}) & 3
-    DVec<VX> HT[2][RY];       // Ht of planes m, m+1 in slots (m-m0) & 1
-    DVec<VX> HTo[2][RY];      // Ht of plane m-1 (copied from HT before its slot is refilled)
-    DVec<VX> YD[2], YU[2];    // global L0 halo rows of planes m, m+1 (or the B boundary row, see bb / bt)
+    // ---- buffer descriptors: base = array + (pbA + plane shift) planes + first row; every access of iteration m
+    //      uses the same scalar offsets so[r] = (m + 3 - pbA) * ps + r * rs (see the shifts below) ----
+    const int ps = (int)(sz * 8), rs = (int)(sy * 8);   // plane / row stride in bytes (host: (zc + 8) * ps < 2^31)
+    const int pbA = m0 - 1 > 0 ? m0 - 1 : 0;
+    auto basep = [&](const double* X, int pshift, int row) -> uintptr_t {
+        return (uintptr_t)X + (uintptr_t)(((long)(pbA + pshift) * (long)sz + (long)row * (long)sy) * 8);
+    };
+    const size_t remA = (sz * (size_t)nz - ((size_t)pbA * sz + (size_t)j0 * sy)) * 8;
+    const __amdgpu_buffer_rsrc_t rA = diff3_rsrc(basep(a.A, 0, j0), remA > 0xffffffffull ? 0xffffffffu : (unsigned)remA);  // L0 plane m+3
+    const __amdgpu_buffer_rsrc_t rHt = diff3_rsrc(basep(a.Ht, -1, j0), 0xffffffffu);   // Ht plane m+2
+    const __amdgpu_buffer_rsrc_t rEA = diff3_rsrc(basep(a.A, -1, j0), 0xffffffffu);    // L0 edge cells, plane m+2
+    const __amdgpu_buffer_rsrc_t rEB = diff3_rsrc(basep(a.B, -1, j0), 0xffffffffu);    // B x-boundary cells, plane m+2
+    const __amdgpu_buffer_rsrc_t rH = diff3_rsrc(basep(Hsrc, -1, hrow), 0xffffffffu);  // halo row, plane m+2
+    const __amdgpu_buffer_rsrc_t rC = diff3_rsrc(basep(a.C, -4, j0), 0xffffffffu);     // L2 plane m-1
+    const __amdgpu_buffer_rsrc_t rD = diff3_rsrc(basep(a.dH, -4, j0), 0xffffffffu);
+
+    DVec<VX> P[4][RY];        // L0 planes m-1 .. m+2; plane p lives in slot (p - m0 + 1) & 3
+    DVec<VX> HT[4][RY];       // Ht planes m-1 .. m+2, same slot rule
+    DVec<VX> Q[4][RY];        // L1 planes m-2 .. m in slots (p - m0 + 1) & 3 (one slot is free for the next plane)
+    DVec<VX> YH[2];           // global L0 halo row of planes m, m+1 (waves 0 / 3; the B boundary row if bb / bt)
     double ED[2][RY];         // L0 tile-edge cells of planes m, m+1 (or the B boundary cell, see bndL / bndR)
-    DVec<VX> Qm[RY], Qc[RY], Qn[RY];  // L1 planes m-2, m-1, m
-    double acc1 = 0.0, acc2 = 0.0;
+    double acc1[VX], acc2[VX];
 #pragma unroll
-    for (int r = 0; r < RY; ++r)
+    for (int v = 0; v < VX; ++v) { acc1[v] = 0.0; acc2[v] = 0.0; }
 #pragma unroll
-        for (int v = 0; v < VX; ++v) { Qm[r].v[v] = 0.0; Qc[r].v[v] = 0.0; HTo[0][r].v[v] = 0.0; HTo[1][r].v[v] = 0.0; }
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < RY; ++r)
+#pragma unroll
+            for (int v = 0; v < VX; ++v) Q[q][r].v[v] = 0.0;
+#pragma unroll
+    for (int r = 0; r < RY; ++r) { ED[0][r] = 0.0; ED[1][r] = 0.0; }
+#pragma unroll
+    for (int v = 0; v < VX; ++v) { YH[0].v[v] = YH[1].v[v] = 0.0; }
 
-    auto load_plane = [&](DVec<VX>(&dst)[RY], int k) {
-        const size_t base = (size_t)ibc + sz * kcl(k);
+    // soff = scalar offset of (plane, row 0) relative to the descriptor in use
+    auto load_rows = [&](DVec<VX>(&dst)[RY], __amdgpu_buffer_rsrc_t rsrc, int soff) {
 #pragma unroll
-        for (int r = 0; r < RY; ++r) dst[r] = diff3_ldv<VX>(H + base + sy * (j0 + r));
+        for (int r = 0; r < RY; ++r) dst[r] = diff3_bld2(rsrc, voff, soff + r * rs);
     };
-    auto load_aux = [&](DVec<VX>(&ht)[RY], DVec<VX>& yd, DVec<VX>& yu, double (&e)[RY], int k) {
-        const size_t kc = sz * kcl(k);
+    auto load_halo = [&](DVec<VX>& yh, double (&e)[RY], int soff) {
+        if (is_edge) {
 #pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            ht[r] = diff3_ldv<VX>(a.Ht + (size_t)ibc + sy * (j0 + r) + kc);
-            e[r] = is_edge ? Esrc[(size_t)ie + sy * (j0 + r) + kc] : 0.0;
+            for (int r = 0; r < RY; ++r) e[r] = diff3_bld1(rEA, eoff, soff + r * rs);
         }
-        if (need_gd) yd = diff3_ldv<VX>(YDsrc + (size_t)ibc + sy * jd + kc);
-        if (need_gu) yu = diff3_ldv<VX>(YUsrc + (size_t)ibc + sy * ju + kc);
+        if (xb_tile) {
+            if (bndL || bndR) {   // issued after the A load of the same register: loads return in order
+#pragma unroll
+                for (int r = 0; r < RY; ++r) e[r] = diff3_bld1(rEB, boff, soff + r * rs);
+            }
+        }
+        if (hwave) yh = diff3_bld2(rH, voff, soff);
     };
 
-    load_plane(P[0], m0 - 1);
-    load_plane(P[1], m0);
-    load_plane(P[2], m0 + 1);
-    load_plane(P[3], m0 + 2);
-    load_aux(HT[0], YD[0], YU[0], ED[0], m0);
-    load_aux(HT[1], YD[1], YU[1], ED[1], m0 + 1);
+    // slots: plane m0-1 -> 0, m0 -> 1, m0+1 -> 2, m0+2 -> 3
+    load_rows(P[0], rA, (kcl(m0 - 1) - pbA) * ps);
+    load_rows(P[1], rA, (m0 - pbA) * ps);
+    load_rows(P[2], rA, (m0 + 1 - pbA) * ps);
+    load_rows(P[3], rA, (m0 + 2 - pbA) * ps);
+    load_rows(HT[1], rHt, (m0 + 1 - pbA) * ps);
+    load_rows(HT[2], rHt, (m0 + 2 - pbA) * ps);
+    load_halo(YH[0], ED[0], (m0 + 1 - pbA) * ps);
+    load_halo(YH[1], ED[1], (m0 + 2 - pbA) * ps);
+    int so = (m0 + 3 - pbA) * ps;   // scalar offset of iteration m0: plane m0+3 of rA = plane m0+2 of rHt/rEA/rH = plane m0-1 of rC/rD
 
     auto step = [&](auto Sc, int m) {
-        constexpr int S = decltype(Sc)::value;
+        constexpr int S = decltype(Sc)::value;       // (m - m0) & 3
         DVec<VX>(&zmR)[RY] = P[S & 3];
         DVec<VX>(&cR)[RY] = P[(S + 1) & 3];
         DVec<VX>(&zpR)[RY] = P[(S + 2) & 3];
+        DVec<VX>(&Qm)[RY] = Q[(S + 3) & 3];
+        DVec<VX>(&Qc)[RY] = Q[S & 3];
+        DVec<VX>(&Qn)[RY] = Q[(S + 1) & 3];
         constexpr int hsl = S & 1;
 
         // ---- one LDS exchange for both levels: L0 rows of plane m, L1 rows of plane m-1 ----
-        double* buf = xrow + (size_t)(m & 1) * (4 * 4 * TXW);
-        double* mine = buf + (size_t)w * (4 * TXW) + lane * VX;
-#pragma unroll
-        for (int v = 0; v < VX; ++v) {
-            mine[v] = cR[0].v[v];
-            mine[TXW + v] = cR[RY - 1].v[v];
-            mine[2 * TXW + v] = Qc[0].v[v];
-            mine[3 * TXW + v] = Qc[RY - 1].v[v];
+        double* buf = xrow + (size_t)(m & 1) * (6 * SLOT);
+        {
+            typedef double d2l __attribute__((ext_vector_type(2)));
+            double* mine = buf + (size_t)(w + 1) * SLOT + lane * VX;
+            d2l t;
+            t.x = cR[0].v[0]; t.y = cR[0].v[1];           *reinterpret_cast<d2l*>(mine) = t;
+            t.x = cR[RY - 1].v[0]; t.y = cR[RY - 1].v[1]; *reinterpret_cast<d2l*>(mine + TXW) = t;
+            t.x = Qc[0].v[0]; t.y = Qc[0].v[1];           *reinterpret_cast<d2l*>(mine + 2 * TXW) = t;
+            t.x = Qc[RY - 1].v[0]; t.y = Qc[RY - 1].v[1]; *reinterpret_cast<d2l*>(mine + 3 * TXW) = t;
+            if (hwave) {   // wave 0: slot 0 "last row"; wave 3: slot 5 "first row"
+                t.x = YH[hsl].v[0]; t.y = YH[hsl].v[1];
+                *reinterpret_cast<d2l*>(buf + (w == 0 ? TXW : 5 * SLOT) + lane * VX) = t;
+            }
         }
         diff3_lds_barrier();
-        const double* od = buf + (size_t)(w > 0 ? w - 1 : 0) * (4 * TXW) + lane * VX;  // wave below: rows 1 (L0 last), 3 (L1 last)
-        const double* ou = buf + (size_t)(w < 3 ? w + 1 : 3) * (4 * TXW) + lane * VX;  // wave above: rows 0 (L0 first), 2 (L1 first)
-        DVec<VX> yd0 = YD[hsl], yu0 = YU[hsl], yd1, yu1;
-#pragma unroll
-        for (int v = 0; v < VX; ++v) {
-            const double ld0 = od[TXW + v], lu0 = ou[v];
-            yd0.v[v] = (w > 0) ? ld0 : yd0.v[v];
-            yu0.v[v] = (w < 3) ? lu0 : yu0.v[v];
-            yd1.v[v] = od[3 * TXW + v];
-            yu1.v[v] = ou[2 * TXW + v];
+        DVec<VX> yd0, yu0, yd1, yu1;
+        {
+            typedef double d2l __attribute__((ext_vector_type(2)));
+            const double* od = buf + (size_t)w * SLOT + lane * VX;         // slot below: rows 1 (L0 last), 3 (L1 last)
+            const double* ou = buf + (size_t)(w + 2) * SLOT + lane * VX;   // slot above: rows 0 (L0 first), 2 (L1 first)
+            d2l t;
+            t = *reinterpret_cast<const d2l*>(od + TXW);     yd0.v[0] = t.x; yd0.v[1] = t.y;
+            t = *reinterpret_cast<const d2l*>(ou);           yu0.v[0] = t.x; yu0.v[1] = t.y;
+            t = *reinterpret_cast<const d2l*>(od + 3 * TXW); yd1.v[0] = t.x; yd1.v[1] = t.y;
+            t = *reinterpret_cast<const d2l*>(ou + 2 * TXW); yu1.v[0] = t.x; yu1.v[1] = t.y;
         }
 
         // ---- first step: L1 on plane m ----
         const bool zb = (m <= 0) || (m >= nz - 1);   // block-uniform: a z-boundary plane of L1 comes from B
         if (zb) {
-            const size_t base = (size_t)ibc + sz * kcl(m);
-#pragma unroll
-            for (int r = 0; r < RY; ++r) Qn[r] = diff3_ldv<VX>(a.B + base + sy * (j0 + r));
+            const __amdgpu_buffer_rsrc_t rB = diff3_rsrc((uintptr_t)(a.B + sz * (size_t)m + sy * (size_t)j0), 0xffffffffu);
+            load_rows(Qn, rB, 0);
         } else {
             const bool own_plane = (m >= k0) && (m < k1);
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
-                const double fromL = diff3_lane_up1(cR[r].v[VX - 1]);
-                const double fromR = diff3_lane_down1(cR[r].v[0]);
-                const double xl0 = (lane == 0) ? ED[hsl][r] : fromL;
-                const double xrL = (lane == 63) ? ED[hsl][r] : fromR;
+                // x-neighbours across lanes; lane 0 / lane 63 receive the edge register instead
+                const double xl0 = diff3_lane_up1_edge(cR[r].v[VX - 1], ED[hsl][r]);
+                const double xrL = diff3_lane_down1_edge(cR[r].v[0], ED[hsl][r]);
+                double r1[VX];
 #pragma unroll
                 for (int v = 0; v < VX; ++v) {
                     const double xm = (v == 0) ? xl0 : cR[r].v[v == 0 ? 0 : v - 1];
                     const double xp = (v == VX - 1) ? xrL : cR[r].v[v == VX - 1 ? v : v + 1];
                     const double ym = (r == 0) ? yd0.v[v] : cR[r == 0 ? 0 : r - 1].v[v];
                     const double yp = (r == RY - 1) ? yu0.v[v] : cR[r == RY - 1 ? r : r + 1].v[v];
-                    double h1;
-                    const double r1 = diff3_point(cR[r].v[v], xm, xp, ym, yp, zmR[r].v[v], zpR[r].v[v],
-                                                  HT[hsl][r].v[v], cf, h1);
-                    Qn[r].v[v] = h1;
-                    if constexpr (NORM) {
-                        if (own_plane && rm[r] && cm[v]) { const double t = r1 * a.scale; acc1 += t * t; }
+                    r1[v] = diff3_point(cR[r].v[v], xm, xp, ym, yp, zmR[r].v[v], zpR[r].v[v],
+                                        HT[(S + 1) & 3][r].v[v], cf, Qn[r].v[v]);
+                }
+                if constexpr (NORM) {
+                    if (own_plane && rm[r]) {
+#pragma unroll
+                        for (int v = 0; v < VX; ++v) acc1[v] = __builtin_fma(r1[v], r1[v], acc1[v]);
                     }
                 }
-                // x-boundary own cells of L1 come from B (carried in the edge register)
-                Qn[r].v[0] = bndL ? ED[hsl][r] : Qn[r].v[0];
-                Qn[r].v[VX - 1] = bndR ? ED[hsl][r] : Qn[r].v[VX - 1];
+                if (xb_tile) {   // x-boundary own cells of L1 come from B (it arrived through the edge register)
+                    Qn[r].v[0] = bndL ? xl0 : Qn[r].v[0];
+                    Qn[r].v[VX - 1] = bndR ? xrL : Qn[r].v[VX - 1];
+                }
             }
             // y-boundary own rows of L1 come from B (carried in the halo-row registers)
-#pragma unroll
-            for (int v = 0; v < VX; ++v) {
-                Qn[0].v[v] = bb ? YD[hsl].v[v] : Qn[0].v[v];
-                Qn[RY - 1].v[v] = bt ? YU[hsl].v[v] : Qn[RY - 1].v[v];
-            }
+            if (bb) Qn[0] = YH[hsl];
+            if (bt) Qn[RY - 1] = YH[hsl];
         }
 
-        // plane m-1 of L0 and the aux registers of plane m are dead: keep Ht(m) for the second step of the next
-        // iteration, then refill (L0 plane m+3, aux of plane m+2) so the loads fly during the second step
-#pragma unroll
-        for (int r = 0; r < RY; ++r) HTo[hsl][r] = HT[hsl][r];
+        // L0 plane m-1 and the halo registers of plane m are dead: refill (L0 plane m+3; Ht and halos of plane m+2)
         if (m + 2 <= m1) {
-            load_plane(P[S & 3], m + 3);
-            load_aux(HT[hsl], YD[hsl], YU[hsl], ED[hsl], m + 2);
+            load_rows(P[S & 3], rA, so);
+            load_rows(HT[(S + 3) & 3], rHt, so);
+            load_halo(YH[hsl], ED[hsl], so);
         }
 
         // ---- second step: L2 on plane m-1 ----
         if (m - 1 >= k0) {
-            const int k = m - 1;
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
-                const double fromL = diff3_lane_up1(Qc[r].v[VX - 1]);
-                const double fromR = diff3_lane_down1(Qc[r].v[0]);
+                const double fromL = diff3_lane_up1_z(Qc[r].v[VX - 1]);   // edge lanes: L2 there is never owned
+                const double fromR = diff3_lane_down1_z(Qc[r].v[0]);
                 double res[VX], h2[VX];
 #pragma unroll
                 for (int v = 0; v < VX; ++v) {
@@ -241,34 +348,31 @@ __global__ __launch_bounds__(256) void k_diff3_march2(Diff3Args2 a)
                     const double xp = (v == VX - 1) ? fromR : Qc[r].v[v == VX - 1 ? v : v + 1];
                     const double ym = (r == 0) ? yd1.v[v] : Qc[r == 0 ? 0 : r - 1].v[v];
                     const double yp = (r == RY - 1) ? yu1.v[v] : Qc[r == RY - 1 ? r : r + 1].v[v];
-                    res[v] = diff3_point(Qc[r].v[v], xm, xp, ym, yp, Qm[r].v[v], Qn[r].v[v], HTo[hsl ^ 1][r].v[v], cf,
-                                         h2[v]);
+                    res[v] = diff3_point(Qc[r].v[v], xm, xp, ym, yp, Qm[r].v[v], Qn[r].v[v], HT[S & 3][r].v[v], cf, h2[v]);
                 }
                 if (rm[r]) {
-                    const size_t id = (size_t)ib + sy * (size_t)(j0 + r) + sz * (size_t)k;
-                    if (cm[0] && cm[1]) {
-                        typedef double d2v __attribute__((ext_vector_type(2)));
-                        d2v rv, hv;
-                        rv.x = res[0]; rv.y = res[1];
-                        hv.x = h2[0]; hv.y = h2[1];
-                        __builtin_nontemporal_store(rv, reinterpret_cast<d2v*>(a.dH + id));
-                        __builtin_nontemporal_store(hv, reinterpret_cast<d2v*>(a.C + id));
-                    } else {
-                        if (cm[0]) { a.dH[id] = res[0]; a.C[id] = h2[0]; }
-                        if (cm[1]) { a.dH[id + 1] = res[1]; a.C[id + 1] = h2[1]; }
+                    if (cmp) {
+                        diff3_bst2_nt(rD, soff, so + r * rs, res[0], res[1]);
+                        diff3_bst2_nt(rC, soff, so + r * rs, h2[0], h2[1]);
+                    }
+                    if (has_split) {
+                        if (cm[0] && !cm[1]) {
+                            diff3_bst1(rD, soff, so + r * rs, res[0]);
+                            diff3_bst1(rC, soff, so + r * rs, h2[0]);
+                        }
+                        if (cm[1] && !cm[0]) {
+                            diff3_bst1(rD, soff + 8u, so + r * rs, res[1]);
+                            diff3_bst1(rC, soff + 8u, so + r * rs, h2[1]);
+                        }
                     }
                     if constexpr (NORM) {
 #pragma unroll
-                        for (int v = 0; v < VX; ++v)
-                            if (cm[v]) { const double t = res[v] * a.scale; acc2 += t * t; }
+                        for (int v = 0; v < VX; ++v) acc2[v] = __builtin_fma(res[v], res[v], acc2[v]);
                     }
                 }
             }
         }
-
-        // ---- rotate the L1 window (plain register copies: none of these is a load destination) ----
-#pragma unroll
-        for (int r = 0; r < RY; ++r) { Qm[r] = Qc[r]; Qc[r] = Qn[r]; }
+        so += ps;
     };
 
     int m = m0;
@@ -283,8 +387,12 @@ __global__ __launch_bounds__(256) void k_diff3_march2(Diff3Args2 a)
     if (m <= m1) { step(std::integral_constant<int, 2>{}, m); ++m; }
 
     if constexpr (NORM) {
-        const double s1 = diff3_block_sum256(acc1, red, tid);
-        const double s2 = diff3_block_sum256(acc2, red + 4, tid);
+        // lanes accumulate every cell of the owned rows / planes; cells the lane does not own are dropped here
+        const double sc2 = a.scale * a.scale;
+        const double l1 = ((cm[0] ? acc1[0] : 0.0) + (cm[1] ? acc1[1] : 0.0)) * sc2;
+        const double l2 = ((cm[0] ? acc2[0] : 0.0) + (cm[1] ? acc2[1] : 0.0)) * sc2;
+        const double s1 = diff3_block_sum256(l1, red, tid);
+        const double s2 = diff3_block_sum256(l2, red + 4, tid);
         if (tid == 0) { a.partials1[blockIdx.x] = s1; a.partials2[blockIdx.x] = s2; }
     }
 }
@@ -294,7 +402,7 @@ static inline bool diff3_can_fuse2(const double* Ht, const double* A, const doub
                                    int nx, int ny, int nz)
 {
     const uintptr_t al = (uintptr_t)Ht | (uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)dH;
-    return (nx % 2 == 0) && nx >= 4 && ny >= 16 && nz >= 3 && (al & 15) == 0;
+    return (nx % 2 == 0) && nx >= 128 && ny >= 16 && nz >= 3 && (al & 15) == 0;
 }
 
 #ifndef DIFF3_TARGET_BLOCKS2
@@ -309,11 +417,12 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
     *nparts = 0;
     if (wx <= 0 || wy <= 0 || wz <= 0) return hipSuccess;
     if (!diff3_can_fuse2(a.Ht, a.A, a.B, a.C, a.dH, a.nx, a.ny, a.nz)) return hipErrorInvalidValue;
-    // owned cells per x-tile: the tile's own cells [s, s+128) with s = (ol-1)&~1 must contain ol-1 .. oh
-    const int maxsx = ((a.lo[0] - 1) & 1) ? 124 : 126;
-    a.ntx = (wx + maxsx - 1) / maxsx;
-    a.sx = (wx + a.ntx - 1) / a.ntx;
-    a.sx += a.sx & 1;   // even, so every tile start has the parity of the first
+    // owned cells per x-tile: cut points at even cells e0 + t*sx; the tile's own cells [s, s+128) with
+    // s = (ol-1)&~1 must contain ol-1 .. oh, hence sx <= 124
+    const int span = a.hi[0] - (a.lo[0] & ~1);
+    a.ntx = (span + 123) / 124;
+    a.sx = (span + a.ntx - 1) / a.ntx;
+    a.sx += a.sx & 1;
     a.nby = (wy + 13) / 14;
     const long tiles_xy = (long)a.ntx * a.nby;
     int zc = zc_opt;

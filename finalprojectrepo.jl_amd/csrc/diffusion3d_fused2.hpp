@@ -42,6 +42,7 @@ struct Diff3Args2 {
     double* partials2;              // same for the second step
     int zc, ntx, nby, ntz, sx;      // planes per chunk, tile counts, owned cells per tile in x
     int xcd_remap;
+    int dbg;                        // tuning harness only: 1 = drop all stores, 2 = drop all loads of the z-loop
 };
 
 // DPP wave shifts without an `old` operand: the edge lane receives 0 (no register copy needed)
@@ -107,11 +108,17 @@ __device__ __forceinline__ void diff3_bst1(__amdgpu_buffer_rsrc_t r, unsigned vo
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(diff3_u2v, x), r, voff, soff, 0);
 }
 
+// Every global load and store inside the z-loop is issued UNCONDITIONALLY: rows, planes and lanes that must not
+// be touched get an out-of-range buffer offset instead (the hardware range check drops the access without memory
+// traffic).  With conditional memory instructions hipcc cannot count the operations that are younger than a
+// prefetch and falls back to `s_waitcnt vmcnt(0)` -- draining the prefetched planes at every iteration.
 template <bool NORM>
-__global__ __launch_bounds__(256) void k_diff3_march2(Diff3Args2 a)
+__global__ __launch_bounds__(256, 2) void k_diff3_march2(Diff3Args2 a)
 {
     constexpr int VX = 2, RY = 4, TXW = 128, SYB = 4 * RY - 2;
-    constexpr int SLOT = 4 * TXW;  // doubles per wave slot: L0 first row, L0 last row, L1 first row, L1 last row
+    constexpr int NR = 3;                         // ring length = loop unroll: <= 256 registers, two workgroups per CU
+    constexpr int SLOT = 4 * TXW;                 // doubles per wave slot: L0 first row, L0 last row, L1 first row, L1 last row
+    constexpr unsigned OOR = 0x7fffffffu;         // offset beyond every descriptor's num_records
     __shared__ double red[8];
     // [parity][slot 0..5][row kind][TXW]; wave w owns slot w+1, slot 0 / 5 receive the global halo rows of
     // waves 0 / 3, so every wave reads "the slot below" and "the slot above" without a select
@@ -128,9 +135,19 @@ __global__ __launch_bounds__(256) void k_diff3_march2(Diff3Args2 a)
         const int xcd = bid & 7, slot = bid >> 3;
         bid = xcd * q + (xcd < rem ? xcd : rem) + slot;
     }
-    const int tx = bid % a.ntx;
-    const int by = (bid / a.ntx) % a.nby;
-    const int tz = bid / (a.ntx * a.nby);
+    int tx = bid % a.ntx;
+    int by = (bid / a.ntx) % a.nby;
+    int tz = bid / (a.ntx * a.nby);
+    if (a.xcd_remap == 2) {
+        // z-chunk ownership: XCD x (= blockIdx % 8, the hardware's round-robin) processes the chunks tz = x, x+8, ...
+        // one after the other, so the workgroups resident on an XCD are x/y neighbours of ONE chunk (host: ntz % 8 == 0)
+        const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+        const int per = a.ntx * a.nby;
+        tz = xcd + 8 * (l / per);
+        const int rem = l % per;
+        tx = rem % a.ntx;
+        by = rem / a.ntx;
+    }
 
     const int nx = a.nx, ny = a.ny, nz = a.nz;
     const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
@@ -145,17 +162,19 @@ __global__ __launch_bounds__(256) void k_diff3_march2(Diff3Args2 a)
     const int ib = s + lane * VX;
     int ilast = (oh + 1) & ~1;                       // last pair that is needed (L0 at oh+1)
     ilast = ilast < nx - 2 ? ilast : nx - 2;
-    const int ibc = ib < ilast ? ib : ilast;         // lanes beyond re-read the last needed pair
+    int ifirst = (ol - 2) & ~1;                      // first pair that is needed (L0 at ol-2)
+    ifirst = ifirst > 0 ? ifirst : 0;
+    const int ibc = ib < ifirst ? ifirst : (ib < ilast ? ib : ilast);   // lanes outside re-read the nearest needed pair
     const unsigned voff = (unsigned)ibc * 8u;        // per-lane byte offset inside a row
     const bool xb_tile = (s == 0) || (s + TXW == nx);   // uniform: the tile holds an x-boundary cell
     const bool bndL = (ib == 0);                     // own cell v=0 is the x-boundary (lane 0 of tile 0)
     const bool bndR = (ib + 1 == nx - 1);            // own cell v=1 is the x-boundary (lane 63 of the last tile)
-    const bool is_edge = (lane == 0) || (lane == 63);
-    // edge register: L0 cell beyond the tile, or -- for the lane holding an x-boundary cell -- that cell's B value
-    int ie = (lane == 0) ? ib - 1 : ib + VX;
-    ie = ie < 0 ? 0 : (ie > nx - 1 ? nx - 1 : ie);
-    const unsigned eoff = (unsigned)ie * 8u;                      // L0 edge cell (from A)
-    const unsigned boff = bndL ? 0u : (unsigned)(nx - 1) * 8u;    // x-boundary own cell (from B)
+    // edge register: lane 0 / 63 fetch the L0 cell beyond the tile (other lanes re-read their own first cell: a cache
+    // hit, but unconditional); the lane holding an x-boundary cell fetches that cell's B value instead
+    int ie = (lane == 0) ? ib - 1 : ((lane == 63) ? ib + VX : ibc);
+    ie = ie < ifirst ? ifirst : (ie > ilast + 1 ? ilast + 1 : ie);
+    const unsigned eoff = (bndL || bndR) ? OOR : (unsigned)ie * 8u;                               // from A
+    const unsigned boff = bndL ? 0u : (bndR ? (unsigned)(nx - 1) * 8u : OOR);                     // from B
 
     // ---- y: owned rows [oly, ohy); block rows y1 .. y1+15 ----
     const int oly = a.lo[1] + by * SYB;
@@ -166,8 +185,8 @@ __global__ __launch_bounds__(256) void k_diff3_march2(Diff3Args2 a)
     const bool bt = (w == 3) && (y1 + 4 * RY - 1 == ny - 1);  // own last row of wave 3 is the y-boundary
     const int jd = bb ? 0 : (j0 > 0 ? j0 - 1 : 0);
     const int ju = bt ? ny - 1 : (j0 + RY < ny - 1 ? j0 + RY : ny - 1);
-    const bool hwave = (w == 0) || (w == 3);                  // waves that own a global halo row
-    const double* Hsrc = (w == 0) ? (bb ? a.B : a.A) : (bt ? a.B : a.A);
+    const bool hwave = (w == 0) || (w == 3);                  // waves that own a global halo row (the others re-read a
+    const double* Hsrc = (w == 0) ? (bb ? a.B : a.A) : (bt ? a.B : a.A);   //  neighbour's row: unconditional load, value unused)
     const int hrow = (w == 0) ? jd : ju;
 
     // ---- z: owned planes [k0, k1); iterations m0 .. m1 ----
@@ -180,87 +199,79 @@ __global__ __launch_bounds__(256) void k_diff3_march2(Diff3Args2 a)
     for (int v = 0; v < VX; ++v) cm[v] = (ib + v >= ol) && (ib + v < oh);
 #pragma unroll
     for (int r = 0; r < RY; ++r) rm[r] = (j0 + r >= oly) && (j0 + r < ohy);   // uniform
-    const bool cmp = cm[0] && cm[1];
     const bool has_split = ((ol | oh) & 1) != 0;     // uniform: some lane owns only one cell of its pair
-    const unsigned soff = (unsigned)ib * 8u;
+    // per-lane store offsets: 16-byte store if the lane owns its pair, 8-byte store of the one owned cell otherwise
+    const unsigned sv4 = (cm[0] && cm[1]) ? (unsigned)ib * 8u : OOR;
+    const unsigned sv2 = (cm[0] != cm[1]) ? (unsigned)(ib + (cm[1] ? 1 : 0)) * 8u : OOR;
 
     const Diff3Coef cf{a.dtau, a._dt, a._dx, a._dy, a._dz, a.D_dx, a.D_dy, a.D_dz};
     auto kcl = [&](int k) { return k < 0 ? 0 : (k > nz - 1 ? nz - 1 : k); };
 
     // ---- buffer descriptors: base = array + (pbA + plane shift) planes + first row; every access of iteration m
-    //      uses the same scalar offsets so[r] = (m + 3 - pbA) * ps + r * rs (see the shifts below) ----
+    //      uses the scalar offsets so + r * rs with so = (m + 2 - pbA) * ps (see the shifts below) ----
     const int ps = (int)(sz * 8), rs = (int)(sy * 8);   // plane / row stride in bytes (host: (zc + 8) * ps < 2^31)
     const int pbA = m0 - 1 > 0 ? m0 - 1 : 0;
     auto basep = [&](const double* X, int pshift, int row) -> uintptr_t {
         return (uintptr_t)X + (uintptr_t)(((long)(pbA + pshift) * (long)sz + (long)row * (long)sy) * 8);
     };
-    const size_t remA = (sz * (size_t)nz - ((size_t)pbA * sz + (size_t)j0 * sy)) * 8;
-    const __amdgpu_buffer_rsrc_t rA = diff3_rsrc(basep(a.A, 0, j0), remA > 0xffffffffull ? 0xffffffffu : (unsigned)remA);  // L0 plane m+3
-    const __amdgpu_buffer_rsrc_t rHt = diff3_rsrc(basep(a.Ht, -1, j0), 0xffffffffu);   // Ht plane m+2
-    const __amdgpu_buffer_rsrc_t rEA = diff3_rsrc(basep(a.A, -1, j0), 0xffffffffu);    // L0 edge cells, plane m+2
-    const __amdgpu_buffer_rsrc_t rEB = diff3_rsrc(basep(a.B, -1, j0), 0xffffffffu);    // B x-boundary cells, plane m+2
-    const __amdgpu_buffer_rsrc_t rH = diff3_rsrc(basep(Hsrc, -1, hrow), 0xffffffffu);  // halo row, plane m+2
-    const __amdgpu_buffer_rsrc_t rC = diff3_rsrc(basep(a.C, -4, j0), 0xffffffffu);     // L2 plane m-1
-    const __amdgpu_buffer_rsrc_t rD = diff3_rsrc(basep(a.dH, -4, j0), 0xffffffffu);
+    const __amdgpu_buffer_rsrc_t rA = diff3_rsrc(basep(a.A, 0, j0), OOR);       // L0 plane m+2
+    const __amdgpu_buffer_rsrc_t rHt = diff3_rsrc(basep(a.Ht, 0, j0), OOR);     // Ht plane m+2
+    const __amdgpu_buffer_rsrc_t rEA = diff3_rsrc(basep(a.A, -1, j0), OOR);     // L0 edge cells, plane m+1
+    const __amdgpu_buffer_rsrc_t rEB = diff3_rsrc(basep(a.B, -1, j0), OOR);     // B x-boundary cells, plane m+1
+    const __amdgpu_buffer_rsrc_t rH = diff3_rsrc(basep(Hsrc, -1, hrow), OOR);   // halo row, plane m+1
+    const __amdgpu_buffer_rsrc_t rC = diff3_rsrc(basep(a.C, -NR, j0), OOR);     // L2 plane m-1
+    const __amdgpu_buffer_rsrc_t rD = diff3_rsrc(basep(a.dH, -NR, j0), OOR);
 
-    DVec<VX> P[4][RY];        // L0 planes m-1 .. m+2; plane p lives in slot (p - m0 + 1) & 3
-    DVec<VX> HT[4][RY];       // Ht planes m-1 .. m+2, same slot rule
-    DVec<VX> Q[4][RY];        // L1 planes m-2 .. m in slots (p - m0 + 1) & 3 (one slot is free for the next plane)
-    DVec<VX> YH[2];           // global L0 halo row of planes m, m+1 (waves 0 / 3; the B boundary row if bb / bt)
-    double ED[2][RY];         // L0 tile-edge cells of planes m, m+1 (or the B boundary cell, see bndL / bndR)
+    DVec<VX> P[NR][RY];       // L0 planes m-1, m, m+1; plane p lives in slot (p - m0 + 1) % NR
+    DVec<VX> HT[NR][RY];      // Ht planes m-1, m, m+1 (in flight), same slot rule
+    DVec<VX> Q[NR][RY];       // L1 planes m-2, m-1, m, same slot rule
+    DVec<VX> YH;              // global L0 halo row of plane m (waves 0 / 3; the B boundary row if bb / bt)
+    double ED[RY];            // L0 tile-edge cells of plane m (or the B boundary cell, see bndL / bndR)
     double acc1[VX], acc2[VX];
 #pragma unroll
     for (int v = 0; v < VX; ++v) { acc1[v] = 0.0; acc2[v] = 0.0; }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NR; ++q)
 #pragma unroll
         for (int r = 0; r < RY; ++r)
 #pragma unroll
             for (int v = 0; v < VX; ++v) Q[q][r].v[v] = 0.0;
-#pragma unroll
-    for (int r = 0; r < RY; ++r) { ED[0][r] = 0.0; ED[1][r] = 0.0; }
-#pragma unroll
-    for (int v = 0; v < VX; ++v) { YH[0].v[v] = YH[1].v[v] = 0.0; }
 
-    // soff = scalar offset of (plane, row 0) relative to the descriptor in use
+    // soff = scalar offset of (plane, row 0) relative to the descriptor in use (OOR: nothing is fetched, zeros return)
+    auto row_off = [&](int soff, int r) { return soff == (int)OOR ? (int)OOR : soff + r * rs; };
     auto load_rows = [&](DVec<VX>(&dst)[RY], __amdgpu_buffer_rsrc_t rsrc, int soff) {
 #pragma unroll
-        for (int r = 0; r < RY; ++r) dst[r] = diff3_bld2(rsrc, voff, soff + r * rs);
+        for (int r = 0; r < RY; ++r) dst[r] = diff3_bld2(rsrc, voff, row_off(soff, r));
     };
     auto load_halo = [&](DVec<VX>& yh, double (&e)[RY], int soff) {
-        if (is_edge) {
 #pragma unroll
-            for (int r = 0; r < RY; ++r) e[r] = diff3_bld1(rEA, eoff, soff + r * rs);
+        for (int r = 0; r < RY; ++r) {
+            const double ea = diff3_bld1(rEA, eoff, row_off(soff, r));   // 0 for the lane that holds an x-boundary cell
+            const double eb = diff3_bld1(rEB, boff, row_off(soff, r));   // 0 for every other lane
+            e[r] = __longlong_as_double(__double_as_longlong(ea) | __double_as_longlong(eb));
         }
-        if (xb_tile) {
-            if (bndL || bndR) {   // issued after the A load of the same register: loads return in order
-#pragma unroll
-                for (int r = 0; r < RY; ++r) e[r] = diff3_bld1(rEB, boff, soff + r * rs);
-            }
-        }
-        if (hwave) yh = diff3_bld2(rH, voff, soff);
+        yh = diff3_bld2(rH, voff, soff);
     };
 
-    // slots: plane m0-1 -> 0, m0 -> 1, m0+1 -> 2, m0+2 -> 3
+    // slots: plane m0-1 -> 0, m0 -> 1, m0+1 -> 2
     load_rows(P[0], rA, (kcl(m0 - 1) - pbA) * ps);
     load_rows(P[1], rA, (m0 - pbA) * ps);
     load_rows(P[2], rA, (m0 + 1 - pbA) * ps);
-    load_rows(P[3], rA, (m0 + 2 - pbA) * ps);
-    load_rows(HT[1], rHt, (m0 + 1 - pbA) * ps);
-    load_rows(HT[2], rHt, (m0 + 2 - pbA) * ps);
-    load_halo(YH[0], ED[0], (m0 + 1 - pbA) * ps);
-    load_halo(YH[1], ED[1], (m0 + 2 - pbA) * ps);
-    int so = (m0 + 3 - pbA) * ps;   // scalar offset of iteration m0: plane m0+3 of rA = plane m0+2 of rHt/rEA/rH = plane m0-1 of rC/rD
+    load_rows(HT[1], rHt, (m0 - pbA) * ps);
+    load_rows(HT[2], rHt, (m0 + 1 - pbA) * ps);
+    load_halo(YH, ED, (m0 + 1 - pbA) * ps);
+    // scalar offset of iteration m: plane m+2 of rA / rHt = plane m+1 of rEA / rEB / rH = plane m-1 of rC / rD
+    int so = (m0 + 2 - pbA) * ps;
 
-    auto step = [&](auto Sc, int m) {
-        constexpr int S = decltype(Sc)::value;       // (m - m0) & 3
-        DVec<VX>(&zmR)[RY] = P[S & 3];
-        DVec<VX>(&cR)[RY] = P[(S + 1) & 3];
-        DVec<VX>(&zpR)[RY] = P[(S + 2) & 3];
-        DVec<VX>(&Qm)[RY] = Q[(S + 3) & 3];
-        DVec<VX>(&Qc)[RY] = Q[S & 3];
-        DVec<VX>(&Qn)[RY] = Q[(S + 1) & 3];
-        constexpr int hsl = S & 1;
+    auto step = [&](auto Sc, auto Do2c, int m) {
+        constexpr int S = decltype(Sc)::value;       // (m - m0) % NR
+        constexpr bool DO2 = decltype(Do2c)::value;  // false in the two warm-up iterations (no L2 plane yet)
+        DVec<VX>(&zmR)[RY] = P[S % NR];
+        DVec<VX>(&cR)[RY] = P[(S + 1) % NR];
+        DVec<VX>(&zpR)[RY] = P[(S + 2) % NR];
+        DVec<VX>(&Qm)[RY] = Q[(S + NR - 1) % NR];
+        DVec<VX>(&Qc)[RY] = Q[S % NR];
+        DVec<VX>(&Qn)[RY] = Q[(S + 1) % NR];
 
         // ---- one LDS exchange for both levels: L0 rows of plane m, L1 rows of plane m-1 ----
         double* buf = xrow + (size_t)(m & 1) * (6 * SLOT);
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(256) void k_diff3_march2(Diff3Args2 a)
             t.x = Qc[0].v[0]; t.y = Qc[0].v[1];           *reinterpret_cast<d2l*>(mine + 2 * TXW) = t;
             t.x = Qc[RY - 1].v[0]; t.y = Qc[RY - 1].v[1]; *reinterpret_cast<d2l*>(mine + 3 * TXW) = t;
             if (hwave) {   // wave 0: slot 0 "last row"; wave 3: slot 5 "first row"
-                t.x = YH[hsl].v[0]; t.y = YH[hsl].v[1];
+                t.x = YH.v[0]; t.y = YH.v[1];
                 *reinterpret_cast<d2l*>(buf + (w == 0 ? TXW : 5 * SLOT) + lane * VX) = t;
             }
         }
@@ -293,15 +304,17 @@ __global__ __launch_bounds__(256) void k_diff3_march2(Diff3Args2 a)
         // ---- first step: L1 on plane m ----
         const bool zb = (m <= 0) || (m >= nz - 1);   // block-uniform: a z-boundary plane of L1 comes from B
         if (zb) {
-            const __amdgpu_buffer_rsrc_t rB = diff3_rsrc((uintptr_t)(a.B + sz * (size_t)m + sy * (size_t)j0), 0xffffffffu);
+            // rare (first / last chunk only): synchronous, so that no load of this branch is pending at the join
+            const __amdgpu_buffer_rsrc_t rB = diff3_rsrc((uintptr_t)(a.B + sz * (size_t)m + sy * (size_t)j0), OOR);
             load_rows(Qn, rB, 0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         } else {
             const bool own_plane = (m >= k0) && (m < k1);
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
                 // x-neighbours across lanes; lane 0 / lane 63 receive the edge register instead
-                const double xl0 = diff3_lane_up1_edge(cR[r].v[VX - 1], ED[hsl][r]);
-                const double xrL = diff3_lane_down1_edge(cR[r].v[0], ED[hsl][r]);
+                const double xl0 = diff3_lane_up1_edge(cR[r].v[VX - 1], ED[r]);
+                const double xrL = diff3_lane_down1_edge(cR[r].v[0], ED[r]);
                 double r1[VX];
 #pragma unroll
                 for (int v = 0; v < VX; ++v) {
@@ -310,7 +323,7 @@ __global__ __launch_bounds__(256) void k_diff3_march2(Diff3Args2 a)
                     const double ym = (r == 0) ? yd0.v[v] : cR[r == 0 ? 0 : r - 1].v[v];
                     const double yp = (r == RY - 1) ? yu0.v[v] : cR[r == RY - 1 ? r : r + 1].v[v];
                     r1[v] = diff3_point(cR[r].v[v], xm, xp, ym, yp, zmR[r].v[v], zpR[r].v[v],
-                                        HT[(S + 1) & 3][r].v[v], cf, Qn[r].v[v]);
+                                        HT[(S + 1) % NR][r].v[v], cf, Qn[r].v[v]);
                 }
                 if constexpr (NORM) {
                     if (own_plane && rm[r]) {
@@ -323,20 +336,19 @@ __global__ __launch_bounds__(256) void k_diff3_march2(Diff3Args2 a)
                     Qn[r].v[VX - 1] = bndR ? xrL : Qn[r].v[VX - 1];
                 }
             }
-            // y-boundary own rows of L1 come from B (carried in the halo-row registers)
-            if (bb) Qn[0] = YH[hsl];
-            if (bt) Qn[RY - 1] = YH[hsl];
+            // y-boundary own rows of L1 come from B (carried in the halo-row register)
+            if (bb) Qn[0] = YH;
+            if (bt) Qn[RY - 1] = YH;
         }
 
-        // L0 plane m-1 and the halo registers of plane m are dead: refill (L0 plane m+3; Ht and halos of plane m+2)
-        if (m + 2 <= m1) {
-            load_rows(P[S & 3], rA, so);
-            load_rows(HT[(S + 3) & 3], rHt, so);
-            load_halo(YH[hsl], ED[hsl], so);
-        }
+        // L0 plane m-1 and the halo registers of plane m are dead: refill with L0 plane m+2 and the halos of plane m+1
+        // (out of range, i.e. nothing, once the chunk ends)
+        const int so1 = (m + 1 <= m1 && !(a.dbg & 2)) ? so : (int)OOR;
+        load_rows(P[S % NR], rA, (m + 2 <= nz - 1) ? so1 : (int)OOR);   // plane nz does not exist (only a z-boundary L1 plane would use it)
+        load_halo(YH, ED, so1);
 
         // ---- second step: L2 on plane m-1 ----
-        if (m - 1 >= k0) {
+        if constexpr (DO2) {
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
                 const double fromL = diff3_lane_up1_z(Qc[r].v[VX - 1]);   // edge lanes: L2 there is never owned
@@ -348,43 +360,48 @@ __global__ __launch_bounds__(256) void k_diff3_march2(Diff3Args2 a)
                     const double xp = (v == VX - 1) ? fromR : Qc[r].v[v == VX - 1 ? v : v + 1];
                     const double ym = (r == 0) ? yd1.v[v] : Qc[r == 0 ? 0 : r - 1].v[v];
                     const double yp = (r == RY - 1) ? yu1.v[v] : Qc[r == RY - 1 ? r : r + 1].v[v];
-                    res[v] = diff3_point(Qc[r].v[v], xm, xp, ym, yp, Qm[r].v[v], Qn[r].v[v], HT[S & 3][r].v[v], cf, h2[v]);
+                    res[v] = diff3_point(Qc[r].v[v], xm, xp, ym, yp, Qm[r].v[v], Qn[r].v[v], HT[S % NR][r].v[v], cf, h2[v]);
                 }
-                if (rm[r]) {
-                    if (cmp) {
-                        diff3_bst2_nt(rD, soff, so + r * rs, res[0], res[1]);
-                        diff3_bst2_nt(rC, soff, so + r * rs, h2[0], h2[1]);
-                    }
-                    if (has_split) {
-                        if (cm[0] && !cm[1]) {
-                            diff3_bst1(rD, soff, so + r * rs, res[0]);
-                            diff3_bst1(rC, soff, so + r * rs, h2[0]);
-                        }
-                        if (cm[1] && !cm[0]) {
-                            diff3_bst1(rD, soff + 8u, so + r * rs, res[1]);
-                            diff3_bst1(rC, soff + 8u, so + r * rs, h2[1]);
-                        }
-                    }
-                    if constexpr (NORM) {
+                const int sor = (rm[r] && !(a.dbg & 1)) ? so + r * rs : (int)OOR;   // rows the block does not own: dropped by the range check
+                // lanes that own one cell of their pair (first / last owned cell of an odd-aligned range)
+                double r2 = res[0], g2 = h2[0];
+                if (has_split) { r2 = cm[0] ? res[0] : res[1]; g2 = cm[0] ? h2[0] : h2[1]; }
+                diff3_bst2_nt(rD, sv4, sor, res[0], res[1]);
+                diff3_bst2_nt(rC, sv4, sor, h2[0], h2[1]);
+                diff3_bst1(rD, sv2, sor, r2);
+                diff3_bst1(rC, sv2, sor, g2);
+                // Observed on gfx950: the upper 8 bytes of a 16-byte buffer store's data can still be read after a VALU
+                // write to those registers issued 1-2 instructions later (hipcc assumes MUBUF stores with an SGPR
+                // soffset are free of this hazard).  Keep a few wait states between the stores and the next row.
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 7");
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NORM) {
+                    if (rm[r]) {
 #pragma unroll
                         for (int v = 0; v < VX; ++v) acc2[v] = __builtin_fma(res[v], res[v], acc2[v]);
                     }
                 }
             }
         }
+        // Ht plane m-1 is dead: refill with plane m+2
+        load_rows(HT[S % NR], rHt, (m + 2 <= m1 && !(a.dbg & 2)) ? so : (int)OOR);
         so += ps;
     };
 
-    int m = m0;
-    for (; m + 3 <= m1; m += 4) {
-        step(std::integral_constant<int, 0>{}, m);
-        step(std::integral_constant<int, 1>{}, m + 1);
-        step(std::integral_constant<int, 2>{}, m + 2);
-        step(std::integral_constant<int, 3>{}, m + 3);
+    using T = std::true_type;
+    using F = std::false_type;
+    // two warm-up iterations (L1 planes k0-1, k0), then the steady state in ring order 2, 0, 1
+    step(std::integral_constant<int, 0>{}, F{}, m0);
+    step(std::integral_constant<int, 1>{}, F{}, m0 + 1);
+    int m = m0 + 2;
+    for (; m + NR - 1 <= m1; m += NR) {
+        step(std::integral_constant<int, 2>{}, T{}, m);
+        step(std::integral_constant<int, 0>{}, T{}, m + 1);
+        step(std::integral_constant<int, 1>{}, T{}, m + 2);
     }
-    if (m <= m1) { step(std::integral_constant<int, 0>{}, m); ++m; }
-    if (m <= m1) { step(std::integral_constant<int, 1>{}, m); ++m; }
-    if (m <= m1) { step(std::integral_constant<int, 2>{}, m); ++m; }
+    if (m <= m1) { step(std::integral_constant<int, 2>{}, T{}, m); ++m; }
+    if (m <= m1) { step(std::integral_constant<int, 0>{}, T{}, m); ++m; }
 
     if constexpr (NORM) {
         // lanes accumulate every cell of the owned rows / planes; cells the lane does not own are dropped here
@@ -411,7 +428,7 @@ static inline bool diff3_can_fuse2(const double* Ht, const double* A, const doub
 
 // Launch on `stream`; *nparts = number of per-block partials written to each of partials1/partials2 (norm only).
 static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int xcd_opt, hipStream_t stream,
-                                       int max_partials, int* nparts)
+                                       int max_partials, int* nparts, int ring = 3)
 {
     const int wx = a.hi[0] - a.lo[0], wy = a.hi[1] - a.lo[1], wz = a.hi[2] - a.lo[2];
     *nparts = 0;
@@ -433,11 +450,18 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
         if (zc < 16) zc = wz < 16 ? wz : 16;
     }
     if (zc > wz) zc = wz;
+    // scalar byte offsets inside a chunk are 32-bit: (zc + 8) planes must stay below 2 GiB
+    const long psb = (long)a.nx * a.ny * 8;
+    if (psb * 12 >= (1L << 31)) return hipErrorInvalidValue;
+    if ((zc + 8) * psb >= (1L << 31)) zc = (int)((1L << 31) / psb) - 8;
     a.zc = zc;
     a.ntz = (wz + zc - 1) / zc;
     const long nblk = tiles_xy * a.ntz;
     if (nblk > 0x7fffffffL || (norm && nblk > max_partials)) return hipErrorInvalidValue;
-    a.xcd_remap = (xcd_opt == 1 && nblk >= 64) ? 1 : 0;
+    a.dbg = xcd_opt >> 4;
+    xcd_opt &= 15;
+    a.xcd_remap = (xcd_opt == 1 && nblk >= 64) ? 1 : ((xcd_opt == 2 && a.ntz % 8 == 0) ? 2 : 0);
+    (void)ring;
     if (norm) k_diff3_march2<true><<<(int)nblk, 256, 0, stream>>>(a);
     else k_diff3_march2<false><<<(int)nblk, 256, 0, stream>>>(a);
     *nparts = (int)nblk;

@@ -40,6 +40,15 @@ __global__ void k_count_diff(const double* a, const double* b, size_t n, unsigne
     if (c) atomicAdd(cnt, c);
 }
 
+__global__ void k_find_diff(const double* a, const double* b, size_t n, unsigned long long* cnt, unsigned long long* idx, int cap)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        if (__double_as_longlong(a[i]) != __double_as_longlong(b[i])) {
+            const unsigned long long k = atomicAdd(cnt, 1ull);
+            if (k < (unsigned long long)cap) idx[k] = i;
+        }
+}
+
 int main(int argc, char** argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 512;
@@ -165,14 +174,15 @@ int main(int argc, char** argv)
         f.D_dx = a.D_dx; f.D_dy = a.D_dy; f.D_dz = a.D_dz; f.scale = a.scale;
         f.partials1 = parts; f.partials2 = parts2;
         printf("# fused two-step kernel: ms per LAUNCH (= 2 iterations), GB/s in the per-iteration A_eff metric\n");
-        for (int xcd : {0, 1})
-            for (int zc : {0, 16, 24, 32, 48, 64, 128})
+        for (int ring : {3})
+          for (int xcd : {0, 1, 2, 16, 32, 48})
+            for (int zc : {0, 16, 22, 24, 32, 48, 64, 128})
                 for (int nrm : {0, 1}) {
                     char name[64];
-                    snprintf(name, sizeof name, "f2-xcd%d-zc%d-n%d", xcd, zc, nrm);
+                    snprintf(name, sizeof name, "f2-r%d-xcd%d-zc%d-n%d", ring, xcd, zc, nrm);
                     if (filter[0] && !strstr(name, filter)) continue;
                     CK(hipMemsetAsync(C, 0, N * 8, s)); CK(hipMemsetAsync(dH, 0, N * 8, s));
-                    hipError_t e = diff3_launch2(f, nrm != 0, zc, xcd, s, 1 << 22, &np);
+                    hipError_t e = diff3_launch2(f, nrm != 0, zc, xcd, s, 1 << 22, &np, ring);
                     if (e != hipSuccess) { printf("%-24s launch failed: %s\n", name, hipGetErrorString(e)); continue; }
                     CK(hipMemsetAsync(cnt, 0, 8, s));
                     k_count_diff<<<2048, 256, 0, s>>>(C, Cref, N, cnt);
@@ -190,7 +200,7 @@ int main(int argc, char** argv)
                     const bool nbad = nrm && (fabs(n1 - ref1) > 1e-12 * ref1 || fabs(n2 - ref2) > 1e-12 * ref2);
                     CK(hipEventRecord(e0, s));
                     for (int w = 0; w < 200; ++w) {
-                        CK(diff3_launch2(f, nrm != 0, zc, xcd, s, 1 << 22, &np));
+                        CK(diff3_launch2(f, nrm != 0, zc, xcd, s, 1 << 22, &np, ring));
                         if ((w & 15) == 15) {
                             CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
                             float wm; CK(hipEventElapsedTime(&wm, e0, e1));
@@ -200,7 +210,7 @@ int main(int argc, char** argv)
                     float r[3];
                     for (int round = 0; round < 3; ++round) {
                         CK(hipEventRecord(e0, s));
-                        for (int i = 0; i < iters; ++i) CK(diff3_launch2(f, nrm != 0, zc, xcd, s, 1 << 22, &np));
+                        for (int i = 0; i < iters; ++i) CK(diff3_launch2(f, nrm != 0, zc, xcd, s, 1 << 22, &np, ring));
                         CK(hipEventRecord(e1, s));
                         CK(hipEventSynchronize(e1));
                         CK(hipEventElapsedTime(&r[round], e0, e1));
@@ -211,7 +221,23 @@ int main(int argc, char** argv)
                     printf("%-24s %9.4f ms/launch %9.1f GB/s(A_eff) %6.1f%%  %s%s (blocks=%d)\n", name, ms, gbs, 100.0 * gbs / 8000.0,
                            bad ? "MISMATCH" : "ok", nbad ? " NORM-MISMATCH" : "", np);
                     if (nbad) printf("   norms: %.17g vs %.17g ; %.17g vs %.17g\n", n1, ref1, n2, ref2);
-                    if (bad) printf("   mismatching values: %llu\n", bad);
+                    if (bad) {
+                        printf("   mismatching values: %llu\n", bad);
+                        unsigned long long* didx; CK(hipMalloc(&didx, 64 * 8));
+                        for (int arr = 0; arr < 2; ++arr) {
+                            CK(hipMemsetAsync(cnt, 0, 8, s));
+                            k_find_diff<<<2048, 256, 0, s>>>(arr ? dH : C, arr ? dHref : Cref, N, cnt, didx, 64);
+                            unsigned long long hidx[64], c2 = 0;
+                            CK(hipMemcpyAsync(&c2, cnt, 8, hipMemcpyDeviceToHost, s));
+                            CK(hipMemcpyAsync(hidx, didx, 64 * 8, hipMemcpyDeviceToHost, s));
+                            CK(hipStreamSynchronize(s));
+                            printf("   %s: %llu mismatches; some (x,y,z):", arr ? "dH" : "C", c2);
+                            for (unsigned long long q = 0; q < (c2 < 24 ? c2 : 24); ++q)
+                                printf(" (%llu,%llu,%llu)", hidx[q] % n, (hidx[q] / n) % n, hidx[q] / ((unsigned long long)n * n));
+                            printf("\n");
+                        }
+                        CK(hipFree(didx));
+                    }
                     fflush(stdout);
                 }
     }

@@ -52,6 +52,7 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
     if (ctx->cg_buf) hipFree(ctx->cg_buf);
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->partials2) hipFree(ctx->partials2);
+    if (ctx->diff3_scratch) hipFree(ctx->diff3_scratch);
     if (ctx->scalars) hipFree(ctx->scalars);
     if (ctx->state) hipFree(ctx->state);
     if (ctx->state_h) hipHostFree(ctx->state_h);
@@ -222,6 +223,25 @@ int fprx_finish_sum(fpr_ctx* ctx, const double* partials, int nparts, double* ou
     }
     if (accumulate) k_finish<1><<<1, 256, 0, ctx->stream[stream_sel]>>>(partials, nparts, out_dev);
     else k_finish<0><<<1, 256, 0, ctx->stream[stream_sel]>>>(partials, nparts, out_dev);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+// two partial lists of equal length -> out[0], out[1] in ONE launch (block b sums list b; fixed order)
+template <int ACC>
+__global__ __launch_bounds__(256) void k_finish2(const double* __restrict__ p0, const double* __restrict__ p1, int n,
+                                                  double* __restrict__ out)
+{
+    __shared__ double red[16];
+    const double s = fpr_sum_partials_256(blockIdx.x ? p1 : p0, n, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = ACC ? out[blockIdx.x] + s : s;
+}
+
+int fprx_finish_sum2(fpr_ctx* ctx, const double* p0, const double* p1, int nparts, double* out2_dev, bool accumulate,
+                     int stream_sel)
+{
+    if (accumulate) k_finish2<1><<<2, 256, 0, ctx->stream[stream_sel]>>>(p0, p1, nparts, out2_dev);
+    else k_finish2<0><<<2, 256, 0, ctx->stream[stream_sel]>>>(p0, p1, nparts, out2_dev);
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
 }

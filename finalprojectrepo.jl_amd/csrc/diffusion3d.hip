@@ -6,6 +6,8 @@
 
 // defined in diffusion3d_launch.hpp (shared with tools/diffusion_tune.hip)
 #include "diffusion3d_launch.hpp"
+// two pseudo-iterations per pass (temporal blocking)
+#include "diffusion3d_fused2.hpp"
 
 static int diff3_run(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2, double* dHdtau, int nx, int ny,
                      int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy,
@@ -93,6 +95,94 @@ extern "C" int fpr_diffusion3d_step_norm_host(fpr_ctx* ctx, const double* Ht, co
     return FPR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two pseudo-iterations in one pass: step(Ht, A -> [B]); step(Ht, [B] -> C) with B never materialised.
+// ------------------------------------------------------------------------------------------------
+static bool diff3_fuse2_ok(fpr_ctx* ctx, const double* Ht, const double* A, const double* B, const double* C,
+                           const double* dH, int nx, int ny, int nz)
+{
+    return fpr_opt(ctx, "diff3_fuse2", 1) != 0 && diff3_can_fuse2(Ht, A, B, C, dH, nx, ny, nz) &&
+           (long)nx * ny * 8 * 12 < (1L << 31);
+}
+
+// sumsq2_dev: two doubles (first, second iteration); nullptr = no norm
+static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const double* B, double* C, double* dH, int nx,
+                      int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy,
+                      double D_dz, const int* lo, const int* hi, double scale, double* sumsq2_dev, bool accumulate,
+                      int stream_sel)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, Ht && A && B && C && dH, "null field pointer");
+    FPR_REQUIRE(ctx, A != C && B != C && A != B, "Htau, Hmid and Hout must be three distinct buffers");
+    FPR_REQUIRE(ctx, stream_sel == 0 || stream_sel == 1, "stream_sel");
+    FPR_REQUIRE(ctx, diff3_fuse2_ok(ctx, Ht, A, B, C, dH, nx, ny, nz), "problem not supported by the fused two-step kernel");
+    Diff3Args2 a;
+    a.Ht = Ht; a.A = A; a.B = B; a.C = C; a.dH = dH;
+    a.nx = nx; a.ny = ny; a.nz = nz;
+    const int n[3] = {nx, ny, nz};
+    for (int d = 0; d < 3; ++d) {
+        a.lo[d] = lo ? (lo[d] < 1 ? 1 : lo[d]) : 1;
+        a.hi[d] = hi ? (hi[d] > n[d] - 1 ? n[d] - 1 : hi[d]) : n[d] - 1;
+    }
+    a.dtau = dtau; a._dt = _dt; a._dx = _dx; a._dy = _dy; a._dz = _dz;
+    a.D_dx = D_dx; a.D_dy = D_dy; a.D_dz = D_dz;
+    a.scale = scale;
+    double* base = stream_sel ? ctx->partials2 : ctx->partials;
+    a.partials1 = base;
+    a.partials2 = base + FPR_MAX_PARTIALS / 2;
+    const bool norm = sumsq2_dev != nullptr;
+    const bool empty = a.lo[0] >= a.hi[0] || a.lo[1] >= a.hi[1] || a.lo[2] >= a.hi[2];
+    int nparts = 0;
+    if (!empty) {
+        const bool timed = ctx->ktimer_on && ctx->ktimer_used + 2 <= ctx->ktimer_ev.size();
+        if (timed) FPR_HIP(ctx, hipEventRecord(ctx->ktimer_ev[ctx->ktimer_used], ctx->stream[stream_sel]));
+        hipError_t e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), (int)fpr_opt(ctx, "diff3_xcd2", 0),
+                                     ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2, &nparts);
+        if (timed) {
+            FPR_HIP(ctx, hipEventRecord(ctx->ktimer_ev[ctx->ktimer_used + 1], ctx->stream[stream_sel]));
+            ctx->ktimer_used += 2;
+        }
+        if (e != hipSuccess) return fpr_fail(ctx, FPR_ERR_HIP, "fused diffusion3d launch: %s", hipGetErrorString(e));
+    }
+    if (norm) {
+        if (empty) {
+            if (!accumulate) FPR_HIP(ctx, hipMemsetAsync(sumsq2_dev, 0, 2 * sizeof(double), ctx->stream[stream_sel]));
+            return FPR_OK;
+        }
+        return fprx_finish_sum2(ctx, a.partials1, a.partials2, nparts, sumsq2_dev, accumulate, stream_sel);
+    }
+    return FPR_OK;
+}
+
+extern "C" int fpr_diffusion3d_can_step2(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hmid,
+                                         const double* Hout, const double* dHdtau, int nx, int ny, int nz)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    return (Ht && Htau && Hmid && Hout && dHdtau && Htau != Hout && Hmid != Hout && Htau != Hmid &&
+            diff3_fuse2_ok(ctx, Ht, Htau, Hmid, Hout, dHdtau, nx, ny, nz))
+               ? 1
+               : 0;
+}
+
+extern "C" int fpr_diffusion3d_step2(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hmid, double* Hout,
+                                     double* dHdtau, int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy,
+                                     double _dz, double D_dx, double D_dy, double D_dz, double scale, double* sumsq2_dev)
+{
+    return diff3_run2(ctx, Ht, Htau, Hmid, Hout, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, nullptr,
+                      nullptr, scale, sumsq2_dev, false, 0);
+}
+
+extern "C" int fpr_diffusion3d_step2_box(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hmid,
+                                         double* Hout, double* dHdtau, int nx, int ny, int nz, double dtau, double _dt,
+                                         double _dx, double _dy, double _dz, double D_dx, double D_dy, double D_dz,
+                                         const int lo[3], const int hi[3], double scale, double* sumsq2_dev, int stream_sel)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, lo && hi, "null box");
+    return diff3_run2(ctx, Ht, Htau, Hmid, Hout, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo, hi,
+                      scale, sumsq2_dev, true, stream_sel);
+}
+
 extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, double* Htau2, double* dHdtau, int nx, int ny,
                                      int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx,
                                      double D_dy, double D_dz, double dt, double total_N, int nt, double tol, long iter_max,
@@ -103,19 +193,70 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
     FPR_REQUIRE(ctx, nt >= 0 && check_every >= 1, "nt >= 0 and check_every >= 1");
     const size_t N = (size_t)nx * ny * nz;
     const double sqrtN = sqrt(total_N);
-    double* cur = Htau;
-    double* oth = Htau2;
-    volatile double* pinned = ctx->host_scalars + 8;
-    int swaps = 0;
+    volatile double* pinned = ctx->host_scalars + 8;   // [0], [1]: sums of the first / second iteration of a launch
+
+    // The reference's two work buffers keep their own boundary values (the kernel writes interior cells only), so
+    // the field alternates between an "even" buffer (Htau's boundary) and an "odd" one (Htau2's).  With a third
+    // buffer E1 that carries Htau's boundary two iterations run as one fused launch even -> even, reading only the
+    // boundary of Htau2 (diffusion3d_fused2.hpp); single steps handle odd states and odd iteration counts.
+    double* E1 = nullptr;
+    bool fuse = false;
+    if (fpr_opt(ctx, "diff3_fuse2", 1) != 0 && (long)nx * ny * 8 * 12 < (1L << 31)) {
+        if (ctx->diff3_scratch_n < N) {
+            if (ctx->diff3_scratch) hipFree(ctx->diff3_scratch);
+            ctx->diff3_scratch = nullptr;
+            ctx->diff3_scratch_n = 0;
+            if (hipMalloc(&ctx->diff3_scratch, N * sizeof(double)) == hipSuccess) ctx->diff3_scratch_n = N;
+            else (void)hipGetLastError();   // no memory for the third buffer: single steps only
+        }
+        E1 = ctx->diff3_scratch_n >= N ? ctx->diff3_scratch : nullptr;
+        fuse = E1 && diff3_can_fuse2(Ht, Htau, Htau2, E1, dHdtau, nx, ny, nz);
+        if (fuse) {
+            int rc = fpr_copy(ctx, E1, Htau, N);   // boundary of the even buffers (interior is overwritten)
+            if (rc) return rc;
+        }
+    }
+    double* cur = Htau;   // current field
+    int parity = 0;       // 0: cur is an even buffer (Htau or E1), 1: cur == Htau2
+    long swaps = 0;
     for (int t = 0; t < nt; ++t) {
         long it = 0;
         double err = 2 * tol;  // :178
-        while (fixed_iters > 0 ? it < fixed_iters : (err > tol && it < iter_max)) {  // :179
-            const bool need_norm = fixed_iters > 0 ? (it + 1 == fixed_iters) : ((it + 1) % check_every == 0);
-            int rc = diff3_run(ctx, Ht, cur, oth, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, nullptr,
+        auto more = [&]() { return fixed_iters > 0 ? it < fixed_iters : (err > tol && it < iter_max); };  // :179
+        auto want_norm = [&](long j) { return fixed_iters > 0 ? (j == fixed_iters) : (j % check_every == 0); };
+        while (more()) {
+            const long left = fixed_iters > 0 ? fixed_iters - it : iter_max - it;
+            if (fuse && parity == 0 && left >= 2) {
+                double* out = (cur == Htau) ? E1 : Htau;
+                const bool n1 = want_norm(it + 1), n2 = want_norm(it + 2);
+                int rc = diff3_run2(ctx, Ht, cur, Htau2, out, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz,
+                                    nullptr, nullptr, dt, (n1 || n2) ? (double*)pinned : nullptr, false, 0);
+                if (rc) return rc;
+                if (n1 || n2) FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
+                if (n1 && fixed_iters <= 0) {
+                    const double e1 = sqrt(pinned[0]) / sqrtN;  // :191 after the first of the two iterations
+                    if (!(e1 > tol)) {
+                        // the reference stops here: redo that one iteration from the (intact) input
+                        rc = diff3_run(ctx, Ht, cur, Htau2, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz,
+                                       nullptr, nullptr, false, 0.0, nullptr, false, 0);
+                        if (rc) return rc;
+                        cur = Htau2; parity = 1; ++swaps; ++it;
+                        err = e1;
+                        continue;
+                    }
+                    err = e1;
+                }
+                cur = out; swaps += 2; it += 2;
+                if (n2) err = sqrt(pinned[1]) / sqrtN;
+                continue;
+            }
+            // single iteration: even -> odd (into Htau2) or odd -> even (into Htau)
+            double* out = parity ? Htau : Htau2;
+            const bool need_norm = want_norm(it + 1);
+            int rc = diff3_run(ctx, Ht, cur, out, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, nullptr,
                                nullptr, need_norm, dt, (double*)pinned, false, 0);
             if (rc) return rc;
-            double* tmp = cur; cur = oth; oth = tmp;  // :190
+            cur = out; parity ^= 1;  // :190
             ++swaps;
             if (need_norm) {
                 FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
@@ -128,7 +269,11 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
         int rc = fpr_copy(ctx, Ht, cur, N);  // Ht .= Htau  :203
         if (rc) return rc;
     }
-    if (swapped_host) *swapped_host = swaps & 1;
+    if (cur == E1) {   // hand the field back in the caller's even buffer
+        int rc = fpr_copy(ctx, Htau, E1, N);
+        if (rc) return rc;
+    }
+    if (swapped_host) *swapped_host = (int)(swaps & 1);
     return FPR_OK;
 }
 

@@ -43,6 +43,8 @@ struct fpr_ctx {
     hipEvent_t ev[2] = {nullptr, nullptr};
     double* partials = nullptr;     // FPR_MAX_PARTIALS doubles: block partial sums (slot 0)
     double* partials2 = nullptr;    // second slot (comm stream / second reduction of a kernel)
+    double* diff3_scratch = nullptr;   // third field buffer of the fused two-step diffusion solve (lazily allocated)
+    size_t diff3_scratch_n = 0;
     double* scalars = nullptr;      // 64 device doubles for results of reductions
     FprSolveState* state = nullptr; // device
     FprSolveState* state_h = nullptr;  // pinned host mirror
@@ -183,3 +185,5 @@ int fprx_sumsq_scaled_dev(fpr_ctx* ctx, const double* x, size_t n, double scale,
 int fprx_dot_dev(fpr_ctx* ctx, const double* x, const double* y, size_t n, double* out_dev);
 // finish a two-stage reduction: out_dev[0] (= or +=) sum(partials[0..nparts))
 int fprx_finish_sum(fpr_ctx* ctx, const double* partials, int nparts, double* out_dev, bool accumulate, int stream_sel);
+int fprx_finish_sum2(fpr_ctx* ctx, const double* p0, const double* p1, int nparts, double* out2_dev, bool accumulate,
+                     int stream_sel);

@@ -243,6 +243,91 @@ class GlobalGrid:
         st = self.step_begin(Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq_dev)
         self.step_end(st)
 
+    def can_step2(self, Ht, Hτ, Hτ2, Hout, dHdτ):
+        """True if step2 can run two iterations as fused launches on this grid (else call step twice)."""
+        from . import part1
+
+        if not part1.can_step_τ2(Ht, Hτ, Hτ2, Hout, dHdτ):
+            return False
+        # multi-rank: z-slab decompositions only (the x / y faces of a slab are physical boundaries), and enough planes
+        return all((f >> 1) == 2 for f in self.neighbors) and (not self.neighbors or self.nz >= 8)
+
+    def step2(self, Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq2_dev):
+        """TWO pseudo-iterations: Hout <- update(update(Hτ)), dHdτ <- residual of the second, halos of Hout refreshed.
+        Hτ2 plays the reference's second work buffer: only its boundary cells (and, between ranks, its z-halo planes)
+        are used.  Hout must carry Hτ's physical-boundary values.  sq2_dev (2 doubles, or None) receives the LOCAL
+        sums of (dHdτ*norm_scale)^2 of the first and second iteration.  Bit-identical to two calls of step()."""
+        from . import part1
+
+        args = (Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
+        if not self.neighbors:
+            part1.diffusion_3D_step_τ2(*args, norm_scale, sq2_dev)
+            return
+        st = self.step2_begin(*args, norm_scale, sq2_dev)
+        self.step2_middle(st)
+        self.step2_end(st)
+
+    # z-slab choreography of two fused iterations (the level-1 field = state after the first iteration):
+    #   begin : single-step boxes on the planes next to a z-neighbour (level 1 there, into Hτ2) -> post their exchange;
+    #           fused launch on the lower half of the planes that need no neighbour data (overlaps the exchange)
+    #   middle: join; fused launches on the two planes next to the halos (their level-1 halo plane just arrived and is
+    #           read from Hτ2 like a physical boundary) -> post the exchange of the new field's halo planes
+    #   end   : fused launch on the upper half (overlaps that exchange); join
+    def step2_begin(self, Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq2_dev):
+        import torch
+        from . import ctx as _ctx
+        from . import part1
+
+        c = _ctx()
+        nx, ny, nz = self.nx, self.ny, self.nz
+        has_lo, has_hi = 4 in self.neighbors, 5 in self.neighbors
+        coef = (dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
+        if sq2_dev is not None:
+            sq2_dev.zero_()
+        for on, k in ((has_lo, 1), (has_hi, nz - 2)):
+            if on:
+                part1.diffusion_3D_step_τ_box(Ht, Hτ, Hτ2, dHdτ, *coef, (1, 1, k), (nx - 1, ny - 1, k + 1), 0.0, None, 0)
+        ex = self.exchanger()
+        c.comm.wait_stream(c.compute)
+        with torch.cuda.stream(c.comm):
+            works = ex.post(Hτ2)
+        zl, zh = (2 if has_lo else 1), (nz - 2 if has_hi else nz - 1)
+        zmid = (zl + zh) // 2
+        fused = (Ht, Hτ, Hτ2, Hout, dHdτ) + coef
+        part1.diffusion_3D_step_τ2_box(*fused, (1, 1, zl), (nx - 1, ny - 1, zmid), norm_scale, sq2_dev, 0)
+        return dict(fused=fused, scale=norm_scale, sq=sq2_dev, works=works, z=(zmid, zh), lo=has_lo, hi=has_hi, out=Hout)
+
+    def step2_middle(self, st):
+        import torch
+        from . import ctx as _ctx
+        from . import part1
+
+        c = _ctx()
+        nx, ny, nz = self.nx, self.ny, self.nz
+        ex = self.exchanger()
+        with torch.cuda.stream(c.comm):
+            ex.wait(st["works"])
+        c.compute.wait_stream(c.comm)
+        for on, k in ((st["lo"], 1), (st["hi"], nz - 2)):
+            if on:
+                part1.diffusion_3D_step_τ2_box(*st["fused"], (1, 1, k), (nx - 1, ny - 1, k + 1), st["scale"], st["sq"], 0)
+        c.comm.wait_stream(c.compute)
+        with torch.cuda.stream(c.comm):
+            st["works"] = ex.post(st["out"])
+
+    def step2_end(self, st):
+        import torch
+        from . import ctx as _ctx
+        from . import part1
+
+        c = _ctx()
+        nx, ny = self.nx, self.ny
+        zmid, zh = st["z"]
+        part1.diffusion_3D_step_τ2_box(*st["fused"], (1, 1, zmid), (nx - 1, ny - 1, zh), st["scale"], st["sq"], 0)
+        with torch.cuda.stream(c.comm):
+            self.exchanger().wait(st["works"])
+        c.compute.wait_stream(c.comm)
+
     def step_begin(self, Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq_dev):
         """Multi-rank step, first half: boundary slabs, pack, post the exchange (comm stream)."""
         import torch

@@ -73,6 +73,36 @@ def diffusion_3D_step_τ_box(Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx
                 sumsq_dev.data_ptr() if sumsq_dev is not None else None, stream_sel)
 
 
+def can_step_τ2(Ht, Hτ, Hmid, Hout, dHdτ):
+    """True if the fused two-iteration kernel serves these arrays (else use two single steps)."""
+    nx, ny, nz = Ht.shape
+    c = _ctx()
+    return c.L.fpr_diffusion3d_can_step2(c.h, fptr(Ht, 3), fptr(Hτ, 3), fptr(Hmid, 3), fptr(Hout, 3), fptr(dHdτ, 3),
+                                         nx, ny, nz) == 1
+
+
+def diffusion_3D_step_τ2(Ht, Hτ, Hmid, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale=0.0, sumsq2_dev=None):
+    """Two trips through the loop body of part1_kernel_programming.jl:179-192 in one pass over memory:
+    step(Hτ -> Hmid); step(Hmid -> Hout) with Hmid never written (only its boundary cells are read).  Hout gets
+    interior cells only and must already carry Hτ's boundary.  sumsq2_dev: 2 device doubles (norm sums of the
+    first / second iteration), or None."""
+    nx, ny, nz = Ht.shape
+    _ctx().call("fpr_diffusion3d_step2", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hmid, 3), fptr(Hout, 3), fptr(dHdτ, 3), nx, ny, nz,
+                dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale,
+                sumsq2_dev.data_ptr() if sumsq2_dev is not None else None)
+
+
+def diffusion_3D_step_τ2_box(Ht, Hτ, Hmid, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo, hi, scale=0.0,
+                             sumsq2_dev=None, stream_sel=0):
+    """Sub-box form of diffusion_3D_step_τ2 (0-based [lo, hi)); the two sums are accumulated into sumsq2_dev."""
+    nx, ny, nz = Ht.shape
+    lo3 = (C.c_int * 3)(*lo)
+    hi3 = (C.c_int * 3)(*hi)
+    _ctx().call("fpr_diffusion3d_step2_box", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hmid, 3), fptr(Hout, 3), fptr(dHdτ, 3),
+                nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo3, hi3, scale,
+                sumsq2_dev.data_ptr() if sumsq2_dev is not None else None, stream_sel)
+
+
 def compute_flux_(qx, qy, qz, Hτ, D, dx, dy, dz):
     """part1_array_programming.jl:10-12 (north_star: compute_flux!)."""
     nx, ny, nz = Hτ.shape

@@ -85,13 +85,37 @@ int fpr_diffusion3d_step_norm_host(fpr_ctx* ctx, const double* Ht, const double*
                                    int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz,
                                    double D_dx, double D_dy, double D_dz, double scale, double* sumsq_host);
 
+/* A1x2: TWO pseudo-transient iterations in one pass over memory (temporal blocking of two trips through the loop body
+ * part1_kernel_programming.jl:179-192).  Equivalent, bit for bit, to
+ *     fpr_diffusion3d_step(Ht, Htau -> Hmid, dHdtau);  fpr_diffusion3d_step(Ht, Hmid -> Hout, dHdtau)
+ * except that the intermediate field is never written: of Hmid only the BOUNDARY cells are read (the reference's
+ * kernel writes interior cells only, so the boundary cells of its second work buffer are what the intermediate field
+ * carries there).  Hout receives interior cells only and must already hold Htau's boundary values to stand in for the
+ * reference's first work buffer afterwards.  Htau, Hmid, Hout: three distinct buffers.  dHdtau = residual of the
+ * second iteration.  sumsq2_dev (may be NULL): two device doubles, sum((r*scale)^2) of the first and of the second
+ * iteration (deterministic two-stage reductions).  Requirements: nx even and >= 128, ny >= 16, 16-byte aligned
+ * arrays, nx*ny*96 < 2^31 -- query with fpr_diffusion3d_can_step2 (1 = supported, 0 = use two single steps).
+ * _box: output box [lo, hi) as fpr_diffusion3d_step_box; sums are ACCUMULATED into sumsq2_dev. */
+int fpr_diffusion3d_can_step2(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hmid, const double* Hout,
+                              const double* dHdtau, int nx, int ny, int nz);
+int fpr_diffusion3d_step2(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hmid, double* Hout,
+                          double* dHdtau, int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy,
+                          double _dz, double D_dx, double D_dy, double D_dz, double scale, double* sumsq2_dev);
+int fpr_diffusion3d_step2_box(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hmid, double* Hout,
+                              double* dHdtau, int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy,
+                              double _dz, double D_dx, double D_dy, double D_dz, const int lo[3], const int hi[3],
+                              double scale, double* sumsq2_dev, int stream_sel);
+
 /* A5: the single-rank host loop of diffusion_3D_kernel_programming (part1_kernel_programming.jl:166-204) in
  * native code: for each of `nt` physical steps iterate the fused update until err <= tol (err =
  * sqrt(sum((dHdtau*dt)^2)) / sqrt(total_N), :191) or iter_max / fixed_iters, then `Ht .= Htau` (:203).
  * check_every = n evaluates the norm (one host round trip) only every n-th pseudo-iteration (1 = reference).
  * fixed_iters > 0 runs exactly that many iterations per step.  iters_host / err_host: nt entries each.
  * The two work buffers swap roles every iteration (:190): *swapped_host = 1 means the current Htau lives in the
- * memory passed as Htau2 (and the last residual is in dHdtau either way). */
+ * memory passed as Htau2 (and the last residual is in dHdtau either way).  Where fpr_diffusion3d_step2 applies,
+ * pairs of iterations run as one fused launch (a third field-sized buffer is kept in the context; an iteration
+ * whose norm ends the loop is replayed alone, so fields, iteration counts and errors are those of the plain loop;
+ * option "diff3_fuse2" = 0 turns this off). */
 int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, double* Htau2, double* dHdtau, int nx, int ny, int nz,
                           double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy, double D_dz,
                           double dt, double total_N, int nt, double tol, long iter_max, long fixed_iters, int check_every,

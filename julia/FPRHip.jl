@@ -173,6 +173,31 @@ function diffusion_3D_step_τ_box(Ht::DA, Hτ::DA, Hτ2::DA, dHdτ::DA, dτ, _dt
                 sumsq === nothing ? Ptr{Cdouble}(C_NULL) : p(sumsq), stream_sel))
 end
 
+"Two loop trips (part1_kernel_programming.jl:179-192) in one pass: step(Hτ -> Hmid); step(Hmid -> Hout), Hmid never written."
+can_step_τ2(Ht::DA, Hτ::DA, Hmid::DA, Hout::DA, dHdτ::DA) =
+    ccall((:fpr_diffusion3d_can_step2, libfpr), Cint,
+          (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint),
+          ctx(), p(Ht), p(Hτ), p(Hmid), p(Hout), p(dHdτ), size(Ht)...) == 1
+function diffusion_3D_step_τ2(Ht::DA, Hτ::DA, Hmid::DA, Hout::DA, dHdτ::DA, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz;
+                              scale = 0.0, sumsq2::Union{DA,Nothing} = nothing)
+    nx, ny, nz = size(Ht)
+    check(ccall((:fpr_diffusion3d_step2, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint,
+                 Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cdouble}),
+                ctx(), p(Ht), p(Hτ), p(Hmid), p(Hout), p(dHdτ), nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale,
+                sumsq2 === nothing ? Ptr{Cdouble}(C_NULL) : p(sumsq2)))
+end
+function diffusion_3D_step_τ2_box(Ht::DA, Hτ::DA, Hmid::DA, Hout::DA, dHdτ::DA, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz,
+                                  lo::NTuple{3,Int}, hi::NTuple{3,Int}; scale = 0.0, sumsq2::Union{DA,Nothing} = nothing, stream_sel = 0)
+    nx, ny, nz = size(Ht)
+    lo3 = Cint[lo...]; hi3 = Cint[hi...]
+    check(ccall((:fpr_diffusion3d_step2_box, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint,
+                 Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cint}, Ptr{Cint}, Cdouble, Ptr{Cdouble}, Cint),
+                ctx(), p(Ht), p(Hτ), p(Hmid), p(Hout), p(dHdτ), nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo3, hi3, scale,
+                sumsq2 === nothing ? Ptr{Cdouble}(C_NULL) : p(sumsq2), stream_sel))
+end
+
 function compute_flux!(qx::DA, qy::DA, qz::DA, Hτ::DA, D, dx, dy, dz)        # part1_array_programming.jl:10-12
     nx, ny, nz = size(Hτ)
     check(ccall((:fpr_diffusion3d_flux, libfpr), Cint,

@@ -125,3 +125,72 @@ def test_step_choreography_emulated_ranks(fpr, oracle, dims, n):
             idx = [slice(1, -1)] * 3
             idx[d] = -1 if side else 0
             assert np.array_equal(loc[tuple(idx)], glob[tuple(idx)])
+
+
+def _emulated_ranks(F, oracle, dims, n, mail):
+    world = int(np.prod(dims))
+    ng = tuple(d * (m - 2) + 2 for d, m in zip(dims, n))
+    lx, ly, lz = (d * 10.0 for d in dims)
+    dx, dy, dz = lx / ng[0], ly / ng[1], lz / ng[2]
+    ranks = []
+    for r in range(world):
+        gg = F.grid.GlobalGrid(*n, dims=(1, 1, 1), use_dist=False)
+        gg.dims, gg.nprocs, gg.me = dims, world, r
+        gg.coords = gg.coords_of(r)
+        gg.neighbors = {}
+        for d in range(3):
+            for side in (0, 1):
+                cc = list(gg.coords)
+                cc[d] += 1 if side else -1
+                if 0 <= cc[d] < dims[d]:
+                    gg.neighbors[2 * d + side] = tuple(cc)
+        gg.dist = FakeDist(mail, r)
+        Ht = F.asdevice(oracle.init_gaussian(n, dx, dy, dz, (lx / 2, ly / 2, lz / 2), gg.coords))
+        ranks.append(dict(gg=gg, Ht=Ht))
+    return ranks, ng, (dx, dy, dz), (lx, ly, lz)
+
+
+@pytest.mark.parametrize("dims,n", [((1, 1, 2), (128, 18, 10)), ((1, 1, 3), (130, 33, 9)), ((1, 1, 4), (128, 16, 8))], ids=str)
+def test_fused_pair_choreography_emulated_z_slabs(fpr, oracle, dims, n):
+    """GlobalGrid.step2 (two iterations per fused launch, level-1 halo planes exchanged in between) on emulated
+    z-slab ranks equals the single-domain oracle bit for bit, including both per-iteration norms."""
+    F = fpr
+    mail = {}
+    ranks, ng, (dx, dy, dz), (lx, ly, lz) = _emulated_ranks(F, oracle, dims, n, mail)
+    D, dt = 1.0, 0.2
+    dτ = min(dx, dy, dz) ** 2 / D / 8.1
+    coef = (dτ, 1 / dt, 1 / dx, 1 / dy, 1 / dz, D / dx, D / dy, D / dz)
+    for s in ranks:
+        s.update(A=s["Ht"].clone(), O=F.fzeros(*n), C=s["Ht"].clone(), R=F.fzeros(*n), sq=F.fzeros(2))
+        assert s["gg"].can_step2(s["Ht"], s["A"], s["O"], s["C"], s["R"])
+    Hg = oracle.init_gaussian(ng, dx, dy, dz, (lx / 2, ly / 2, lz / 2))
+    Ag, Bg, Rg = Hg.copy(order="F"), farr(*ng), farr(*ng)
+    for pair in range(3):
+        sts = [s["gg"].step2_begin(s["Ht"], s["A"], s["O"], s["C"], s["R"], *coef, dt, s["sq"]) for s in ranks]
+        for s, st in zip(ranks, sts):
+            s["gg"].step2_middle(st)
+        for s, st in zip(ranks, sts):
+            s["gg"].step2_end(st)
+            s["A"], s["C"] = s["C"], s["A"]
+        refs = []
+        for _ in range(2):
+            oracle.diffusion3d_step(Hg, Ag, Bg, Rg, *coef)
+            Ag, Bg = Bg, Ag
+            refs.append(oracle.sumsq_scaled(Rg, dt))
+        for j in range(2):
+            tot = sum(float(s["sq"][j].item()) for s in ranks)
+            assert abs(tot - refs[j]) <= 1e-13 * refs[j]
+    assert all(len(v) == 0 for v in mail.values())
+    nx, ny, nz = n
+    for s in ranks:
+        c = s["gg"].coords
+        off = tuple(ci * (m - 2) for ci, m in zip(c, n))
+        loc = F.tonumpy(s["A"])
+        glob = Ag[off[0]:off[0] + nx, off[1]:off[1] + ny, off[2]:off[2] + nz]
+        assert np.array_equal(loc[1:-1, 1:-1, 1:-1], glob[1:-1, 1:-1, 1:-1])
+        assert np.array_equal(F.tonumpy(s["R"])[1:-1, 1:-1, 1:-1], Rg[off[0]:off[0] + nx, off[1]:off[1] + ny, off[2]:off[2] + nz][1:-1, 1:-1, 1:-1])
+        for face in s["gg"].neighbors:
+            d, side = face >> 1, face & 1
+            idx = [slice(1, -1)] * 3
+            idx[d] = -1 if side else 0
+            assert np.array_equal(loc[tuple(idx)], glob[tuple(idx)])

@@ -244,3 +244,144 @@ def test_published_tolerance_sweep_128(fpr, oracle, k):
     iv = float(row["interp_val"])
     assert abs(info["interp"] - iv) <= 2.5e-16 * abs(iv), (info["interp"], iv)
     print("tol %g: value %.17g published %.17g exact=%s iters=%d" % (tol, v, ref, v == ref, sum(info["iters"])))
+
+
+# ---------------------------------------------------------------- fused two-iteration kernel (temporal blocking)
+SHAPES2 = [(128, 20, 12), (130, 33, 17), (256, 64, 40), (254, 16, 3), (128, 16, 4), (384, 47, 9), (132, 30, 35)]
+
+
+def _two_oracle_steps(oracle, Ht, A, B):
+    """A -> B' (keeps B's boundary) -> C' (keeps A's boundary); returns C', residual of step 2, sums of both steps."""
+    shape = A.shape
+    Bp = B.copy(order="F")
+    dH1 = asf(np.zeros(shape))
+    oracle.diffusion3d_step(Ht, A, Bp, dH1, *COEF.values())
+    Cp = A.copy(order="F")
+    dH2 = asf(np.full(shape, -9.0))
+    oracle.diffusion3d_step(Ht, Bp, Cp, dH2, *COEF.values())
+    s1 = oracle.sumsq_scaled(dH1[1:-1, 1:-1, 1:-1].copy(order="F"), 0.2)
+    s2 = oracle.sumsq_scaled(dH2[1:-1, 1:-1, 1:-1].copy(order="F"), 0.2)
+    return Cp, dH2, s1, s2
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(diff3_zc2=5), dict(diff3_zc2=16, diff3_xcd2=1), dict(diff3_xcd2=2, diff3_zc2=3)],
+                         ids=["default", "zc5", "zc16-xcd1", "zc3-xcd2"])
+@pytest.mark.parametrize("shape", SHAPES2, ids=lambda s: "x".join(map(str, s)))
+def test_fused_two_steps_bit_exact(fpr, oracle, shape, opts):
+    """fpr_diffusion3d_step2 == two oracle steps, bit for bit; the intermediate buffer is not written, only its
+    boundary is read (random here, so a wrong boundary source cannot go unnoticed); sentinels outside the interior."""
+    F = fpr
+    c = F.ctx()
+    for k in ("diff3_zc2", "diff3_xcd2"):
+        c.set_option(k, opts.get(k, 0))
+    try:
+        Ht, A, B = rnd(shape, 21), rnd(shape, 22), rnd(shape, 23)
+        C_ref, dH_ref, s1, s2 = _two_oracle_steps(oracle, Ht, A, B)
+        dHt, dA, dB = F.asdevice(Ht), F.asdevice(A), F.asdevice(B)
+        dC, dD = F.asdevice(A), F.asdevice(np.full(shape, -9.0))
+        assert F.part1.can_step_τ2(dHt, dA, dB, dC, dD)
+        F.part1.diffusion_3D_step_τ2(dHt, dA, dB, dC, dD, *COEF.values())
+        assert np.array_equal(F.tonumpy(dC), C_ref)
+        assert np.array_equal(F.tonumpy(dD), dH_ref)
+        assert np.array_equal(F.tonumpy(dB), B) and np.array_equal(F.tonumpy(dA), A)
+        # with the two fused norms
+        dC.copy_(dA); dD.fill_(-9.0)
+        sq2 = c.scal[:2]
+        F.part1.diffusion_3D_step_τ2(dHt, dA, dB, dC, dD, *COEF.values(), 0.2, sq2)
+        assert np.array_equal(F.tonumpy(dC), C_ref) and np.array_equal(F.tonumpy(dD), dH_ref)
+        g1, g2 = (float(x) for x in sq2.tolist())
+        assert abs(g1 - s1) <= 1e-13 * s1 and abs(g2 - s2) <= 1e-13 * s2
+    finally:
+        for k in ("diff3_zc2", "diff3_xcd2"):
+            c.set_option(k, 0)
+
+
+def test_fused_two_steps_unsupported_shapes_are_reported(fpr):
+    F = fpr
+    for shape in [(64, 32, 32), (129, 32, 32), (128, 15, 32)]:
+        a = [F.fzeros(*shape) for _ in range(5)]
+        assert not F.part1.can_step_τ2(*a)
+        with pytest.raises(Exception):
+            F.part1.diffusion_3D_step_τ2(*a, *COEF.values())
+    a = [F.fzeros(128, 16, 8) for _ in range(4)]
+    assert not F.part1.can_step_τ2(a[0], a[1], a[2], a[1], a[3])   # output aliases the input
+
+
+@pytest.mark.parametrize("box", [((1, 1, 1), (129, 32, 23)), ((1, 1, 2), (129, 32, 22)), ((1, 1, 1), (129, 32, 2)),
+                                 ((1, 1, 22), (129, 32, 23)), ((7, 3, 5), (100, 20, 11)), ((2, 1, 1), (129, 17, 23)),
+                                 ((64, 15, 9), (66, 17, 10))])
+def test_fused_two_steps_box(fpr, oracle, box):
+    """Sub-box form: inside the box the result equals two full oracle steps, outside nothing is written; the sums
+    are accumulated and cover the box only."""
+    F = fpr
+    shape = (130, 33, 24)
+    lo, hi = box
+    Ht, A, B = rnd(shape, 31), rnd(shape, 32), rnd(shape, 33)
+    C_ref, dH_ref, _, _ = _two_oracle_steps(oracle, Ht, A, B)
+    # first-step residual for the box norm
+    Bp, dH1 = B.copy(order="F"), asf(np.zeros(shape))
+    oracle.diffusion3d_step(Ht, A, Bp, dH1, *COEF.values())
+    sl = tuple(slice(l, h) for l, h in zip(lo, hi))
+    dC, dD = F.asdevice(np.full(shape, -3.0)), F.asdevice(np.full(shape, -9.0))
+    sq2 = F.ctx().scal[:2]
+    sq2.fill_(1.5)
+    F.part1.diffusion_3D_step_τ2_box(F.asdevice(Ht), F.asdevice(A), F.asdevice(B), dC, dD, *COEF.values(), lo, hi, 0.2, sq2)
+    C, D = F.tonumpy(dC), F.tonumpy(dD)
+    assert np.array_equal(C[sl], C_ref[sl]) and np.array_equal(D[sl], dH_ref[sl])
+    C[sl] = -3.0; D[sl] = -9.0
+    assert (C == -3.0).all() and (D == -9.0).all()
+    s1 = oracle.sumsq_scaled(dH1[sl].copy(order="F"), 0.2) + 1.5
+    s2 = oracle.sumsq_scaled(dH_ref[sl].copy(order="F"), 0.2) + 1.5
+    g1, g2 = (float(x) for x in sq2.tolist())
+    assert abs(g1 - s1) <= 1e-13 * s1 and abs(g2 - s2) <= 1e-13 * s2
+
+
+@pytest.mark.parametrize("case", [dict(tol=1e-6, check_every=1), dict(tol=3e-5, check_every=1), dict(tol=1e-5, check_every=3),
+                                  dict(fixed_iters=51), dict(fixed_iters=50), dict(tol=1e-9, iter_max=77, check_every=1)],
+                         ids=["tol1e-6", "tol3e-5", "every3", "fixed51", "fixed50", "itermax77"])
+def test_solve_with_fused_pairs_equals_plain_loop(fpr, oracle, case):
+    """fpr_diffusion3d_solve runs pairs of iterations as fused launches; fields, iteration counts, errors and the
+    final residual must be those of the plain one-iteration-per-launch loop (option diff3_fuse2 = 0)."""
+    F = fpr
+    c = F.ctx()
+    n = (128, 24, 20)
+    Ht0 = oracle.init_gaussian(n, 10.0 / n[0], 10.0 / n[1], 10.0 / n[2], (5.0, 5.0, 5.0))
+    out = []
+    for fuse in (0, 1):
+        c.set_option("diff3_fuse2", fuse)
+        try:
+            kw = dict(nx=n[0], ny=n[1], nz=n[2], ttot=0.6, Ht_init=F.asdevice(Ht0))
+            kw.update(case)
+            _, H, _, info = F.part1.diffusion_3D_kernel_programming(**kw)
+            out.append((H, info["iters"], info["err"], F.tonumpy(info["residual_H"])))
+        finally:
+            c.set_option("diff3_fuse2", 1)
+    (H0, it0, e0, r0), (H1, it1, e1, r1) = out
+    assert it0 == it1 and len(it0) == 3
+    assert np.array_equal(H0, H1) and np.array_equal(r0, r1)
+    assert np.allclose(e0, e1, rtol=1e-12, atol=0)
+
+
+def test_full_size_512_fused_equals_two_steps(fpr):
+    """BASELINE config 2 size: the fused launch equals two single launches bit for bit at 512^3 (norms to 1e-13)."""
+    import torch
+
+    F = fpr
+    n = 512
+    dx = 10.0 / n
+    coef = (dx * dx / 8.1, 5.0, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx)
+    Ht, A, B = F.fzeros(n, n, n), F.fzeros(n, n, n), F.fzeros(n, n, n)
+    F.part1.init_local_gaussian((5.0, 5.0, 5.0), dx, dx, dx, Ht)
+    A.copy_(Ht)
+    A.mul_(1.0 + 0.001 * torch.arange(n, device=A.device, dtype=torch.float64).reshape(n, 1, 1))
+    B.copy_(A).mul_(0.5)                     # a second buffer with its own boundary values
+    Bw, C1, dH1 = B.clone(), A.clone(), F.fzeros(n, n, n)
+    sq = F.ctx().scal[:4]
+    F.part1.diffusion_3D_step_τ_norm(Ht, A, Bw, dH1, *coef, 0.2, sq[0:1])
+    F.part1.diffusion_3D_step_τ_norm(Ht, Bw, C1, dH1, *coef, 0.2, sq[1:2])
+    del Bw
+    C2, dH2 = A.clone(), F.fzeros(n, n, n)
+    F.part1.diffusion_3D_step_τ2(Ht, A, B, C2, dH2, *coef, 0.2, sq[2:4])
+    assert torch.equal(C1, C2) and torch.equal(dH1, dH2)
+    s = [float(x) for x in sq.tolist()]
+    assert abs(s[2] - s[0]) <= 1e-13 * s[0] and abs(s[3] - s[1]) <= 1e-13 * s[1]

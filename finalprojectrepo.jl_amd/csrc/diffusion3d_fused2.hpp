@@ -423,7 +423,7 @@ static inline bool diff3_can_fuse2(const double* Ht, const double* A, const doub
 }
 
 #ifndef DIFF3_TARGET_BLOCKS2
-#define DIFF3_TARGET_BLOCKS2 3072
+#define DIFF3_TARGET_BLOCKS2 4096
 #endif
 
 // Launch on `stream`; *nparts = number of per-block partials written to each of partials1/partials2 (norm only).

@@ -216,7 +216,6 @@ __global__ __launch_bounds__(256, 2) void k_diff3_march2(Diff3Args2 a)
     };
     const __amdgpu_buffer_rsrc_t rA = diff3_rsrc(basep(a.A, 0, j0), OOR);       // L0 plane m+2
     const __amdgpu_buffer_rsrc_t rHt = diff3_rsrc(basep(a.Ht, 0, j0), OOR);     // Ht plane m+2
-    const __amdgpu_buffer_rsrc_t rEA = diff3_rsrc(basep(a.A, -1, j0), OOR);     // L0 edge cells, plane m+1
     const __amdgpu_buffer_rsrc_t rEB = diff3_rsrc(basep(a.B, -1, j0), OOR);     // B x-boundary cells, plane m+1
     const __amdgpu_buffer_rsrc_t rH = diff3_rsrc(basep(Hsrc, -1, hrow), OOR);   // halo row, plane m+1
     const __amdgpu_buffer_rsrc_t rC = diff3_rsrc(basep(a.C, -NR, j0), OOR);     // L2 plane m-1
@@ -243,10 +242,11 @@ __global__ __launch_bounds__(256, 2) void k_diff3_march2(Diff3Args2 a)
 #pragma unroll
         for (int r = 0; r < RY; ++r) dst[r] = diff3_bld2(rsrc, voff, row_off(soff, r));
     };
-    auto load_halo = [&](DVec<VX>& yh, double (&e)[RY], int soff) {
+    // soff: plane offset for the descriptors based one plane earlier (rEB, rH); soffA: the same plane relative to rA
+    auto load_halo = [&](DVec<VX>& yh, double (&e)[RY], int soff, int soffA) {
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-            const double ea = diff3_bld1(rEA, eoff, row_off(soff, r));   // 0 for the lane that holds an x-boundary cell
+            const double ea = diff3_bld1(rA, eoff, row_off(soffA, r));   // 0 for the lane that holds an x-boundary cell
             const double eb = diff3_bld1(rEB, boff, row_off(soff, r));   // 0 for every other lane
             e[r] = __longlong_as_double(__double_as_longlong(ea) | __double_as_longlong(eb));
         }
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void k_diff3_march2(Diff3Args2 a)
     load_rows(P[2], rA, (m0 + 1 - pbA) * ps);
     load_rows(HT[1], rHt, (m0 - pbA) * ps);
     load_rows(HT[2], rHt, (m0 + 1 - pbA) * ps);
-    load_halo(YH, ED, (m0 + 1 - pbA) * ps);
+    load_halo(YH, ED, (m0 + 1 - pbA) * ps, (m0 - pbA) * ps);
     // scalar offset of iteration m: plane m+2 of rA / rHt = plane m+1 of rEA / rEB / rH = plane m-1 of rC / rD
     int so = (m0 + 2 - pbA) * ps;
 
@@ -332,20 +332,21 @@ __global__ __launch_bounds__(256, 2) void k_diff3_march2(Diff3Args2 a)
                     }
                 }
                 if (xb_tile) {   // x-boundary own cells of L1 come from B (it arrived through the edge register)
+                    asm volatile("" ::: "memory");   // keep this a (uniform) branch: hipcc would turn it into selects for all tiles
                     Qn[r].v[0] = bndL ? xl0 : Qn[r].v[0];
                     Qn[r].v[VX - 1] = bndR ? xrL : Qn[r].v[VX - 1];
                 }
             }
             // y-boundary own rows of L1 come from B (carried in the halo-row register)
-            if (bb) Qn[0] = YH;
-            if (bt) Qn[RY - 1] = YH;
+            if (bb) { asm volatile("" ::: "memory"); Qn[0] = YH; }
+            if (bt) { asm volatile("" ::: "memory"); Qn[RY - 1] = YH; }
         }
 
         // L0 plane m-1 and the halo registers of plane m are dead: refill with L0 plane m+2 and the halos of plane m+1
         // (out of range, i.e. nothing, once the chunk ends)
         const int so1 = (m + 1 <= m1 && !(a.dbg & 2)) ? so : (int)OOR;
         load_rows(P[S % NR], rA, (m + 2 <= nz - 1) ? so1 : (int)OOR);   // plane nz does not exist (only a z-boundary L1 plane would use it)
-        load_halo(YH, ED, so1);
+        load_halo(YH, ED, so1, so1 == (int)OOR ? (int)OOR : so1 - ps);
 
         // ---- second step: L2 on plane m-1 ----
         if constexpr (DO2) {
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void k_diff3_march2(Diff3Args2 a)
                 const int sor = (rm[r] && !(a.dbg & 1)) ? so + r * rs : (int)OOR;   // rows the block does not own: dropped by the range check
                 // lanes that own one cell of their pair (first / last owned cell of an odd-aligned range)
                 double r2 = res[0], g2 = h2[0];
-                if (has_split) { r2 = cm[0] ? res[0] : res[1]; g2 = cm[0] ? h2[0] : h2[1]; }
+                if (has_split) { asm volatile("" ::: "memory"); r2 = cm[0] ? res[0] : res[1]; g2 = cm[0] ? h2[0] : h2[1]; }
                 diff3_bst2_nt(rD, sv4, sor, res[0], res[1]);
                 diff3_bst2_nt(rC, sv4, sor, h2[0], h2[1]);
                 diff3_bst1(rD, sv2, sor, r2);

@@ -181,6 +181,25 @@ __device__ __forceinline__ double prolong_bf(const double* __restrict__ cc, int 
     return v;
 }
 
+// ---- buffer addressing helpers (descriptor base + per-lane byte offset + scalar byte offset) ---------------------
+// An offset of FPR_OOR is beyond every descriptor's num_records: the hardware drops the access (loads return 0).  The
+// marching kernels use it instead of branches around loads / stores: with conditional memory instructions hipcc cannot
+// count the operations younger than a prefetch and waits for more than it has to (finding 1).
+constexpr unsigned FPR_OOR = 0x7fffffffu;
+typedef unsigned fpr_u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fpr_rsrc(const void* p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)FPR_OOR, 0x00020000);
+}
+__device__ __forceinline__ double fpr_bld(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void fpr_bst(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, double x)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fpr_u2v, x), r, voff, soff, 0);
+}
+
 // ---- two fused Jacobi sweeps, register-rolling march in y (fine levels) ------------------------------
 // A wave owns a strip of 64 columns (one column per lane) and marches down a chunk of rows keeping a
 // 3-row window of u (sweep 0) and of the once-smoothed field (sweep 1) in registers; x-neighbours come
@@ -206,8 +225,7 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
     __shared__ double red[16];
     constexpr int HX = RESTRICT ? 3 : 2;                     // feeder lanes on each side of a strip
     constexpr int SW = 64 - 2 * HX;                          // columns owned by a strip
-    const bool nt_store = (apply_BCs & 256) != 0;            // bit 8: non-temporal stores of the smoothed field
-    apply_BCs &= 255;
+    apply_BCs &= 255;                                        // (bit 8, non-temporal stores, is ignored by this kernel)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + w;
     const bool active = strip < nstrips;
@@ -231,9 +249,15 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
         const bool p_inx = gis >= 1 && gis <= nx - 2;
         int pj = -2;
         double pc00 = 0.0, pc10 = 0.0, pc01 = 0.0, pc11 = 0.0;
+        // rows are addressed relative to the first row of the chunk: (rows_per_chunk + 8) * nx * 8 < 2^31
+        const int rowB = nx * 8;
+        const __amdgpu_buffer_rsrc_t rUin = fpr_rsrc(uin + (size_t)nx * rs), rF = fpr_rsrc(f + (size_t)nx * rs);
+        const __amdgpu_buffer_rsrc_t rUout = fpr_rsrc(uout + (size_t)nx * rs);
+        const unsigned vld = (unsigned)gic * 8u;
+        const unsigned vst = owner ? (unsigned)gi * 8u : FPR_OOR;   // lanes that own nothing store out of range
         auto ldu = [&](int r) {
             const int rc = r > ny - 1 ? ny - 1 : r;
-            const double v = uin[(size_t)gic + (size_t)nx * rc];
+            const double v = fpr_bld(rUin, vld, (rc - rs) * rowB);
             if constexpr (PROLONG) {
                 const int jo = rc & 1, jcl = rc >> 1;
                 if (jcl != pj) {
@@ -258,7 +282,7 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
                 return v;
             }
         };
-        auto ldf = [&](int r) { const int rc = r > ny - 1 ? ny - 1 : r; return f[(size_t)gic + (size_t)nx * rc]; };
+        auto ldf = [&](int r) { const int rc = r > ny - 1 ? ny - 1 : r; return fpr_bld(rF, vld, (rc - rs) * rowB); };
         double a0 = 0.0, a1 = 0.0, a2 = ldu(rs);       // u   rows r-2, r-1, r
         double b0 = 0.0, b1 = 0.0, b2 = 0.0;           // u1  rows r-3, r-2, r-1
         double f0 = 0.0, f1 = 0.0, f2 = ldf(rs);       // f   rows r-2, r-1, r
@@ -269,6 +293,9 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
 #pragma unroll
         for (int q = 0; q < PF; ++q) { pu[q] = ldu(rs + 1 + q); pfv[q] = ldf(rs + 1 + q); }
         const int nxc_r = 1 + (nx - 1) / 2, nyc_r = 1 + (ny - 1) / 2;
+        // RESTRICT: coarse arrays (whole-array descriptors: nxc * nyc * 8 < 2^31), even owned columns only
+        const __amdgpu_buffer_rsrc_t rResC = fpr_rsrc(res_c_out), rCorC = fpr_rsrc(corr_c_out);
+        const unsigned vstc = (RESTRICT && owner && !(gi & 1)) ? (unsigned)(gi >> 1) * 8u : FPR_OOR;
         // The ring slot is a compile-time constant (the row loop is unrolled by PF): a slot is consumed and
         // refilled in place, so no register of an in-flight load is ever copied (a copy would make hipcc wait
         // for that load) and PF rows stay in flight per lane.
@@ -298,12 +325,10 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
                 const double rr = ((((R + L) + b2) + b0) - C * b1) * _h2 - f0;
                 const bool bnd = col_bnd || j2 <= 0 || j2 >= ny - 1;
                 const double u2 = bnd ? b1 : b1 + fac * rr;
-                if (owner && j2 >= y0 && j2 < y1) {
-                    if (nt_store) __builtin_nontemporal_store(u2, &uout[(size_t)gi + (size_t)nx * j2]);
-                    else uout[(size_t)gi + (size_t)nx * j2] = u2;
-                    if constexpr (NORM) {
-                        if (!bnd) acc += rr * rr;
-                    }
+                const bool row_own = j2 >= y0 && j2 < y1;        // uniform
+                fpr_bst(rUout, vst, row_own ? (j2 - rs) * rowB : (int)FPR_OOR, u2);   // unconditional (see FPR_OOR)
+                if constexpr (NORM) {
+                    if (owner && row_own && !bnd) acc += rr * rr;
                 }
                 if constexpr (RESTRICT) {
                     c0 = c1; c1 = c2; c2 = u2;         // u2 rows r-4, r-3, r-2
@@ -314,12 +339,13 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
                 const int j3 = r - 3;
                 const double L = fpr_lane_up1(c1), R = fpr_lane_down1(c1);
                 const double rr = ((((R + L) + c2) + c0) - C * c1) * _h2 - fm;
-                if (owner && j3 >= y0 && j3 < y1 && !(j3 & 1) && !(gi & 1)) {
+                {
                     const int ic = gi >> 1, jc = j3 >> 1;
                     const bool cint = ic >= 1 && ic <= nxc_r - 2 && jc >= 1 && jc <= nyc_r - 2;
-                    const size_t cid = (size_t)ic + (size_t)nxc_r * jc;
-                    res_c_out[cid] = cint ? rr : 0.0;
-                    corr_c_out[cid] = 0.0;
+                    const bool row_inj = j3 >= y0 && j3 < y1 && !(j3 & 1);   // uniform
+                    const int sc = row_inj ? jc * (nxc_r * 8) : (int)FPR_OOR;
+                    fpr_bst(rResC, vstc, sc, cint ? rr : 0.0);
+                    fpr_bst(rCorC, vstc, sc, 0.0);
                 }
                 fm = f0;                               // becomes f row (r+1)-3
             }

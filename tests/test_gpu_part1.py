@@ -385,3 +385,29 @@ def test_full_size_512_fused_equals_two_steps(fpr):
     assert torch.equal(C1, C2) and torch.equal(dH1, dH2)
     s = [float(x) for x in sq.tolist()]
     assert abs(s[2] - s[0]) <= 1e-13 * s[0] and abs(s[3] - s[1]) <= 1e-13 * s[1]
+
+
+def test_fused_two_steps_random_shapes_and_boxes(fpr, oracle):
+    """Seeded sweep over grid sizes (1..6 x-tiles, ragged y / z, odd/even box edges) and chunk sizes."""
+    F = fpr
+    c = F.ctx()
+    rng = np.random.RandomState(20261003)
+    try:
+        for trial in range(14):
+            shape = (int(rng.randint(64, 360)) * 2, int(rng.randint(16, 61)), int(rng.randint(3, 22)))
+            lo = tuple(int(rng.randint(1, max(2, n // 3))) if rng.rand() < 0.6 else 1 for n in shape)
+            hi = tuple(int(rng.randint(max(l + 1, 2 * n // 3), n)) if rng.rand() < 0.6 else n - 1 for l, n in zip(lo, shape))
+            c.set_option("diff3_zc2", int(rng.choice([0, 3, 4, 7, 16])))
+            c.set_option("diff3_xcd2", int(rng.choice([0, 1])))
+            Ht, A, B = rnd(shape, 100 + trial), rnd(shape, 200 + trial), rnd(shape, 300 + trial)
+            C_ref, dH_ref, _, _ = _two_oracle_steps(oracle, Ht, A, B)
+            sl = tuple(slice(l, h) for l, h in zip(lo, hi))
+            dC, dD = F.asdevice(np.full(shape, -3.0)), F.asdevice(np.full(shape, -9.0))
+            F.part1.diffusion_3D_step_τ2_box(F.asdevice(Ht), F.asdevice(A), F.asdevice(B), dC, dD, *COEF.values(), lo, hi)
+            Cg, Dg = F.tonumpy(dC), F.tonumpy(dD)
+            assert np.array_equal(Cg[sl], C_ref[sl]) and np.array_equal(Dg[sl], dH_ref[sl]), (trial, shape, lo, hi)
+            Cg[sl] = -3.0; Dg[sl] = -9.0
+            assert (Cg == -3.0).all() and (Dg == -9.0).all(), (trial, shape, lo, hi)
+    finally:
+        c.set_option("diff3_zc2", 0)
+        c.set_option("diff3_xcd2", 0)

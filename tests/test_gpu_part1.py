@@ -411,3 +411,29 @@ def test_fused_two_steps_random_shapes_and_boxes(fpr, oracle):
     finally:
         c.set_option("diff3_zc2", 0)
         c.set_option("diff3_xcd2", 0)
+
+
+@pytest.mark.parametrize("case", [dict(tol=3e-5, check_every=1), dict(tol=1e-5, check_every=3), dict(fixed_iters=51)],
+                         ids=["tol3e-5", "every3", "fixed51"])
+def test_python_loop_with_fused_pairs_equals_native_loop(fpr, oracle, case):
+    """The Python host loop (the one multi-rank runs use, GlobalGrid.step2 + replay of a converging first iteration)
+    gives the fields / iteration counts / errors of the native loop and of the plain one-iteration loop."""
+    F = fpr
+    c = F.ctx()
+    n = (128, 24, 20)
+    Ht0 = oracle.init_gaussian(n, 10.0 / n[0], 10.0 / n[1], 10.0 / n[2], (5.0, 5.0, 5.0))
+    out = []
+    for native, fuse in ((True, 1), (False, 1), (False, 0)):
+        c.set_option("diff3_fuse2", fuse)
+        try:
+            kw = dict(nx=n[0], ny=n[1], nz=n[2], ttot=0.6, Ht_init=F.asdevice(Ht0), native_loop=native)
+            kw.update(case)
+            _, H, _, info = F.part1.diffusion_3D_kernel_programming(**kw)
+            out.append((H, info["iters"], info["err"], F.tonumpy(info["residual_H"]), F.tonumpy(info["Hτ"])))
+        finally:
+            c.set_option("diff3_fuse2", 1)
+    for H, it, e, r, ht in out[1:]:
+        assert it == out[0][1]
+        assert np.array_equal(H, out[0][0]) and np.array_equal(r, out[0][3])
+        assert np.allclose(e, out[0][2], rtol=1e-12, atol=0)
+        assert np.array_equal(ht[1:-1, 1:-1, 1:-1], H[1:-1, 1:-1, 1:-1])

@@ -136,8 +136,13 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
     if (!empty) {
         const bool timed = ctx->ktimer_on && ctx->ktimer_used + 2 <= ctx->ktimer_ev.size();
         if (timed) FPR_HIP(ctx, hipEventRecord(ctx->ktimer_ev[ctx->ktimer_used], ctx->stream[stream_sel]));
+        if (ctx->ncu <= 0) {
+            int v = 0;
+            ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
+        }
         hipError_t e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), (int)fpr_opt(ctx, "diff3_xcd2", 0),
-                                     ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2, &nparts);
+                                     ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2, &nparts,
+                                     (int)fpr_opt(ctx, "diff3_nw2", 0), ctx->ncu);
         if (timed) {
             FPR_HIP(ctx, hipEventRecord(ctx->ktimer_ev[ctx->ktimer_used + 1], ctx->stream[stream_sel]));
             ctx->ktimer_used += 2;

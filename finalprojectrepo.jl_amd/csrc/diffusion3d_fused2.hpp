@@ -41,6 +41,7 @@ struct Diff3Args2 {
     double* partials1;              // per-block sum((r1*scale)^2) over owned cells (first step)
     double* partials2;              // same for the second step
     int zc, ntx, nby, ntz, sx;      // planes per chunk, tile counts, owned cells per tile in x
+    int nw;                         // waves per workgroup (4, or 8: 32-row blocks)
     int xcd_remap;
     int dbg;                        // tuning harness only: 1 = drop all stores, 2 = drop all loads of the z-loop
 };
@@ -112,17 +113,33 @@ __device__ __forceinline__ void diff3_bst1(__amdgpu_buffer_rsrc_t r, unsigned vo
 // be touched get an out-of-range buffer offset instead (the hardware range check drops the access without memory
 // traffic).  With conditional memory instructions hipcc cannot count the operations that are younger than a
 // prefetch and falls back to `s_waitcnt vmcnt(0)` -- draining the prefetched planes at every iteration.
-template <bool NORM>
-__global__ __launch_bounds__(256, 2) void k_diff3_march2(Diff3Args2 a)
+// NW = waves per workgroup, stacked in y (block tile 128 x 4*NW rows): 4 (two workgroups per CU) or 8 (one).
+// fixed-order block sum over NW waves; result in thread 0
+template <int NW>
+__device__ __forceinline__ double diff3_block_sum_waves(double v, double* red, int tid)
 {
-    constexpr int VX = 2, RY = 4, TXW = 128, SYB = 4 * RY - 2;
+    v = diff3_wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) s += red[i];
+    }
+    return s;
+}
+
+template <bool NORM, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3Args2 a)
+{
+    constexpr int VX = 2, RY = 4, TXW = 128, SYB = NW * RY - 2;
     constexpr int NR = 3;                         // ring length = loop unroll: <= 256 registers, two workgroups per CU
     constexpr int SLOT = 4 * TXW;                 // doubles per wave slot: L0 first row, L0 last row, L1 first row, L1 last row
     constexpr unsigned OOR = 0x7fffffffu;         // offset beyond every descriptor's num_records
-    __shared__ double red[8];
+    __shared__ double red[2 * NW];
     // [parity][slot 0..5][row kind][TXW]; wave w owns slot w+1, slot 0 / 5 receive the global halo rows of
     // waves 0 / 3, so every wave reads "the slot below" and "the slot above" without a select
-    __shared__ __attribute__((aligned(16))) double xrow[2 * 6 * SLOT];
+    __shared__ __attribute__((aligned(16))) double xrow[2 * (NW + 2) * SLOT];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -179,13 +196,13 @@ __global__ __launch_bounds__(256, 2) void k_diff3_march2(Diff3Args2 a)
     // ---- y: owned rows [oly, ohy); block rows y1 .. y1+15 ----
     const int oly = a.lo[1] + by * SYB;
     const int ohy = (oly + SYB < a.hi[1]) ? oly + SYB : a.hi[1];
-    const int y1 = (oly - 1 < ny - 4 * RY) ? oly - 1 : ny - 4 * RY;
+    const int y1 = (oly - 1 < ny - NW * RY) ? oly - 1 : ny - NW * RY;
     const int j0 = y1 + w * RY;
     const bool bb = (w == 0) && (y1 == 0);                    // own row 0 of wave 0 is the y-boundary
-    const bool bt = (w == 3) && (y1 + 4 * RY - 1 == ny - 1);  // own last row of wave 3 is the y-boundary
+    const bool bt = (w == NW - 1) && (y1 + NW * RY - 1 == ny - 1);  // own last row of the top wave is the y-boundary
     const int jd = bb ? 0 : (j0 > 0 ? j0 - 1 : 0);
     const int ju = bt ? ny - 1 : (j0 + RY < ny - 1 ? j0 + RY : ny - 1);
-    const bool hwave = (w == 0) || (w == 3);                  // waves that own a global halo row (the others re-read a
+    const bool hwave = (w == 0) || (w == NW - 1);             // waves that own a global halo row (the others re-read a
     const double* Hsrc = (w == 0) ? (bb ? a.B : a.A) : (bt ? a.B : a.A);   //  neighbour's row: unconditional load, value unused)
     const int hrow = (w == 0) ? jd : ju;
 
@@ -274,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void k_diff3_march2(Diff3Args2 a)
         DVec<VX>(&Qn)[RY] = Q[(S + 1) % NR];
 
         // ---- one LDS exchange for both levels: L0 rows of plane m, L1 rows of plane m-1 ----
-        double* buf = xrow + (size_t)(m & 1) * (6 * SLOT);
+        double* buf = xrow + (size_t)(m & 1) * ((NW + 2) * SLOT);
         {
             typedef double d2l __attribute__((ext_vector_type(2)));
             double* mine = buf + (size_t)(w + 1) * SLOT + lane * VX;
@@ -285,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void k_diff3_march2(Diff3Args2 a)
             t.x = Qc[RY - 1].v[0]; t.y = Qc[RY - 1].v[1]; *reinterpret_cast<d2l*>(mine + 3 * TXW) = t;
             if (hwave) {   // wave 0: slot 0 "last row"; wave 3: slot 5 "first row"
                 t.x = YH.v[0]; t.y = YH.v[1];
-                *reinterpret_cast<d2l*>(buf + (w == 0 ? TXW : 5 * SLOT) + lane * VX) = t;
+                *reinterpret_cast<d2l*>(buf + (w == 0 ? TXW : (NW + 1) * SLOT) + lane * VX) = t;
             }
         }
         diff3_lds_barrier();
@@ -409,8 +426,8 @@ __global__ __launch_bounds__(256, 2) void k_diff3_march2(Diff3Args2 a)
         const double sc2 = a.scale * a.scale;
         const double l1 = ((cm[0] ? acc1[0] : 0.0) + (cm[1] ? acc1[1] : 0.0)) * sc2;
         const double l2 = ((cm[0] ? acc2[0] : 0.0) + (cm[1] ? acc2[1] : 0.0)) * sc2;
-        const double s1 = diff3_block_sum256(l1, red, tid);
-        const double s2 = diff3_block_sum256(l2, red + 4, tid);
+        const double s1 = diff3_block_sum_waves<NW>(l1, red, tid);
+        const double s2 = diff3_block_sum_waves<NW>(l2, red + NW, tid);
         if (tid == 0) { a.partials1[blockIdx.x] = s1; a.partials2[blockIdx.x] = s2; }
     }
 }
@@ -423,13 +440,11 @@ static inline bool diff3_can_fuse2(const double* Ht, const double* A, const doub
     return (nx % 2 == 0) && nx >= 128 && ny >= 16 && nz >= 3 && (al & 15) == 0;
 }
 
-#ifndef DIFF3_TARGET_BLOCKS2
-#define DIFF3_TARGET_BLOCKS2 4096
-#endif
-
 // Launch on `stream`; *nparts = number of per-block partials written to each of partials1/partials2 (norm only).
+// zc_opt: planes per z-chunk (0 = auto), nw_opt: waves per workgroup (0 = auto, 4 or 8), ncu: compute units of the
+// device (for the chunking heuristic).
 static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int xcd_opt, hipStream_t stream,
-                                       int max_partials, int* nparts, int ring = 3)
+                                       int max_partials, int* nparts, int nw_opt = 0, int ncu = 256)
 {
     const int wx = a.hi[0] - a.lo[0], wy = a.hi[1] - a.lo[1], wz = a.hi[2] - a.lo[2];
     *nparts = 0;
@@ -441,20 +456,36 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
     a.ntx = (span + 123) / 124;
     a.sx = (span + a.ntx - 1) / a.ntx;
     a.sx += a.sx & 1;
-    a.nby = (wy + 13) / 14;
+    // 8 waves per workgroup (32-row blocks, 30 owned: less redundant level-1 work and fewer re-read rows; one
+    // workgroup per CU) when the grid is tall enough, else 4 (16-row blocks, two workgroups per CU)
+    a.nw = (nw_opt == 4 || nw_opt == 8) ? nw_opt : ((a.ny >= 32 && wy >= 24) ? 8 : 4);
+    if (a.nw == 8 && a.ny < 32) a.nw = 4;
+    const int syb = a.nw * 4 - 2;
+    a.nby = (wy + syb - 1) / syb;
     const long tiles_xy = (long)a.ntx * a.nby;
-    int zc = zc_opt;
-    if (zc <= 0) {
-        long want = (DIFF3_TARGET_BLOCKS2 + tiles_xy - 1) / tiles_xy;
-        if (want < 1) want = 1;
-        zc = (int)((wz + want - 1) / want);
-        if (zc < 16) zc = wz < 16 ? wz : 16;
-    }
-    if (zc > wz) zc = wz;
     // scalar byte offsets inside a chunk are 32-bit: (zc + 8) planes must stay below 2 GiB
     const long psb = (long)a.nx * a.ny * 8;
     if (psb * 12 >= (1L << 31)) return hipErrorInvalidValue;
-    if ((zc + 8) * psb >= (1L << 31)) zc = (int)((1L << 31) / psb) - 8;
+    const int zc_max = (int)((1L << 31) / psb) - 8;
+    int zc = zc_opt;
+    if (zc <= 0) {
+        // chunking: workgroups run in rounds of `slots` (what the device holds at once); a chunk of zc planes costs
+        // zc + 6 plane-iterations (2 warm-up iterations, prologue / epilogue).  Pick the chunk count with the least
+        // rounds x cost; ties go to more workgroups.
+        const long slots = (long)(ncu > 0 ? ncu : 256) * (a.nw == 8 ? 1 : 2);
+        long best = -1;
+        for (int ntz = 1; ntz <= wz; ++ntz) {
+            const int z = (wz + ntz - 1) / ntz;
+            if (z > zc_max) continue;
+            if (z < 4 && ntz > 1) break;
+            const long nb = tiles_xy * ((wz + z - 1) / z);
+            const long cost = ((nb + slots - 1) / slots) * (z + 6);
+            if (best < 0 || cost <= best) { best = cost; zc = z; }
+        }
+        if (zc <= 0) zc = wz < zc_max ? wz : zc_max;
+    }
+    if (zc > wz) zc = wz;
+    if (zc > zc_max) zc = zc_max;
     a.zc = zc;
     a.ntz = (wz + zc - 1) / zc;
     const long nblk = tiles_xy * a.ntz;
@@ -462,9 +493,13 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
     a.dbg = xcd_opt >> 4;
     xcd_opt &= 15;
     a.xcd_remap = (xcd_opt == 1 && nblk >= 64) ? 1 : ((xcd_opt == 2 && a.ntz % 8 == 0) ? 2 : 0);
-    (void)ring;
-    if (norm) k_diff3_march2<true><<<(int)nblk, 256, 0, stream>>>(a);
-    else k_diff3_march2<false><<<(int)nblk, 256, 0, stream>>>(a);
+    if (a.nw == 8) {
+        if (norm) k_diff3_march2<true, 8><<<(int)nblk, 512, 0, stream>>>(a);
+        else k_diff3_march2<false, 8><<<(int)nblk, 512, 0, stream>>>(a);
+    } else {
+        if (norm) k_diff3_march2<true, 4><<<(int)nblk, 256, 0, stream>>>(a);
+        else k_diff3_march2<false, 4><<<(int)nblk, 256, 0, stream>>>(a);
+    }
     *nparts = (int)nblk;
     return hipGetLastError();
 }

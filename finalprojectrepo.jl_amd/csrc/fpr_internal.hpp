@@ -45,6 +45,7 @@ struct fpr_ctx {
     double* partials2 = nullptr;    // second slot (comm stream / second reduction of a kernel)
     double* diff3_scratch = nullptr;   // third field buffer of the fused two-step diffusion solve (lazily allocated)
     size_t diff3_scratch_n = 0;
+    int ncu = 0;                       // compute units of the device (queried on first use)
     double* scalars = nullptr;      // 64 device doubles for results of reductions
     FprSolveState* state = nullptr; // device
     FprSolveState* state_h = nullptr;  // pinned host mirror

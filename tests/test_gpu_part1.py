@@ -264,15 +264,16 @@ def _two_oracle_steps(oracle, Ht, A, B):
     return Cp, dH2, s1, s2
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(diff3_zc2=5), dict(diff3_zc2=16, diff3_xcd2=1), dict(diff3_xcd2=2, diff3_zc2=3)],
-                         ids=["default", "zc5", "zc16-xcd1", "zc3-xcd2"])
+@pytest.mark.parametrize("opts", [dict(), dict(diff3_zc2=5), dict(diff3_zc2=16, diff3_xcd2=1), dict(diff3_xcd2=2, diff3_zc2=3),
+                                  dict(diff3_nw2=4), dict(diff3_nw2=8, diff3_zc2=7)],
+                         ids=["default", "zc5", "zc16-xcd1", "zc3-xcd2", "nw4", "nw8-zc7"])
 @pytest.mark.parametrize("shape", SHAPES2, ids=lambda s: "x".join(map(str, s)))
 def test_fused_two_steps_bit_exact(fpr, oracle, shape, opts):
     """fpr_diffusion3d_step2 == two oracle steps, bit for bit; the intermediate buffer is not written, only its
     boundary is read (random here, so a wrong boundary source cannot go unnoticed); sentinels outside the interior."""
     F = fpr
     c = F.ctx()
-    for k in ("diff3_zc2", "diff3_xcd2"):
+    for k in ("diff3_zc2", "diff3_xcd2", "diff3_nw2"):
         c.set_option(k, opts.get(k, 0))
     try:
         Ht, A, B = rnd(shape, 21), rnd(shape, 22), rnd(shape, 23)
@@ -292,7 +293,7 @@ def test_fused_two_steps_bit_exact(fpr, oracle, shape, opts):
         g1, g2 = (float(x) for x in sq2.tolist())
         assert abs(g1 - s1) <= 1e-13 * s1 and abs(g2 - s2) <= 1e-13 * s2
     finally:
-        for k in ("diff3_zc2", "diff3_xcd2"):
+        for k in ("diff3_zc2", "diff3_xcd2", "diff3_nw2"):
             c.set_option(k, 0)
 
 
@@ -399,6 +400,7 @@ def test_fused_two_steps_random_shapes_and_boxes(fpr, oracle):
             hi = tuple(int(rng.randint(max(l + 1, 2 * n // 3), n)) if rng.rand() < 0.6 else n - 1 for l, n in zip(lo, shape))
             c.set_option("diff3_zc2", int(rng.choice([0, 3, 4, 7, 16])))
             c.set_option("diff3_xcd2", int(rng.choice([0, 1])))
+            c.set_option("diff3_nw2", int(rng.choice([0, 4, 8])))
             Ht, A, B = rnd(shape, 100 + trial), rnd(shape, 200 + trial), rnd(shape, 300 + trial)
             C_ref, dH_ref, _, _ = _two_oracle_steps(oracle, Ht, A, B)
             sl = tuple(slice(l, h) for l, h in zip(lo, hi))
@@ -411,6 +413,7 @@ def test_fused_two_steps_random_shapes_and_boxes(fpr, oracle):
     finally:
         c.set_option("diff3_zc2", 0)
         c.set_option("diff3_xcd2", 0)
+        c.set_option("diff3_nw2", 0)
 
 
 @pytest.mark.parametrize("case", [dict(tol=3e-5, check_every=1), dict(tol=1e-5, check_every=3), dict(fixed_iters=51)],

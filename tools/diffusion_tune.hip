@@ -166,6 +166,9 @@ int main(int argc, char** argv)
             for (int i = 0; i < np; ++i) ref2 += hp[i];
             a.Htau = Htau;
         }
+        int ncu = 256;
+        CK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
+        printf("# compute units: %d\n", ncu);
         Diff3Args2 f;
         f.Ht = Ht; f.A = Htau; f.B = B; f.C = C; f.dH = dH;
         f.nx = f.ny = f.nz = n;
@@ -174,15 +177,15 @@ int main(int argc, char** argv)
         f.D_dx = a.D_dx; f.D_dy = a.D_dy; f.D_dz = a.D_dz; f.scale = a.scale;
         f.partials1 = parts; f.partials2 = parts2;
         printf("# fused two-step kernel: ms per LAUNCH (= 2 iterations), GB/s in the per-iteration A_eff metric\n");
-        for (int ring : {3})
+        for (int ring : {0, 4, 8})
           for (int xcd : {0, 1, 2, 16, 32, 48})
-            for (int zc : {0, 16, 22, 24, 32, 48, 64, 128})
+            for (int zc : {0, 16, 22, 24, 32, 43, 47, 48, 57, 64, 85, 128, 170})
                 for (int nrm : {0, 1}) {
                     char name[64];
                     snprintf(name, sizeof name, "f2-r%d-xcd%d-zc%d-n%d", ring, xcd, zc, nrm);
                     if (filter[0] && !strstr(name, filter)) continue;
                     CK(hipMemsetAsync(C, 0, N * 8, s)); CK(hipMemsetAsync(dH, 0, N * 8, s));
-                    hipError_t e = diff3_launch2(f, nrm != 0, zc, xcd, s, 1 << 22, &np, ring);
+                    hipError_t e = diff3_launch2(f, nrm != 0, zc, xcd, s, 1 << 22, &np, ring, ncu);
                     if (e != hipSuccess) { printf("%-24s launch failed: %s\n", name, hipGetErrorString(e)); continue; }
                     CK(hipMemsetAsync(cnt, 0, 8, s));
                     k_count_diff<<<2048, 256, 0, s>>>(C, Cref, N, cnt);
@@ -200,7 +203,7 @@ int main(int argc, char** argv)
                     const bool nbad = nrm && (fabs(n1 - ref1) > 1e-12 * ref1 || fabs(n2 - ref2) > 1e-12 * ref2);
                     CK(hipEventRecord(e0, s));
                     for (int w = 0; w < 200; ++w) {
-                        CK(diff3_launch2(f, nrm != 0, zc, xcd, s, 1 << 22, &np, ring));
+                        CK(diff3_launch2(f, nrm != 0, zc, xcd, s, 1 << 22, &np, ring, ncu));
                         if ((w & 15) == 15) {
                             CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
                             float wm; CK(hipEventElapsedTime(&wm, e0, e1));
@@ -210,7 +213,7 @@ int main(int argc, char** argv)
                     float r[3];
                     for (int round = 0; round < 3; ++round) {
                         CK(hipEventRecord(e0, s));
-                        for (int i = 0; i < iters; ++i) CK(diff3_launch2(f, nrm != 0, zc, xcd, s, 1 << 22, &np, ring));
+                        for (int i = 0; i < iters; ++i) CK(diff3_launch2(f, nrm != 0, zc, xcd, s, 1 << 22, &np, ring, ncu));
                         CK(hipEventRecord(e1, s));
                         CK(hipEventSynchronize(e1));
                         CK(hipEventElapsedTime(&r[round], e0, e1));

@@ -12,19 +12,20 @@
 // cells are the boundary cells of the reference's *other* buffer (`B` here, only its boundary is read), and
 // C must carry A's boundary (the caller copies it once).
 //
-// Geometry (wave64, 2 cells per lane, 4 rows per lane, 4 waves stacked in y = block tile 128 x 16):
-//   * the block marches in z; iteration m computes L1 on plane m for its whole tile (from the L0 ring of 4
-//     register planes m-1..m+2, exactly as k_diff3_march<PIPE>), then L2 on plane m-1 from the three L1
-//     planes m-2, m-1, m held in registers;
-//   * x-neighbours by DPP wave shifts for both levels; y-neighbours between the 4 waves through ONE LDS
-//     exchange + raw s_barrier per iteration that carries the first/last rows of L0(m) and of L1(m-1);
-//   * L1 is valid on the whole 128 x 16 tile (L0 halo cells / rows come from global memory as before), L2 on
-//     the tile shrunk by one cell: tiles overlap by 2 in x and y and chunks by 2 planes in z (redundant L1
-//     work: 16/14 in y, (zc+2)/zc in z; x uses 5 tiles of ~102 owned cells for a 512-cell line);
+// Geometry (wave64, 2 cells per lane, 4 rows per lane, NW = 8 or 4 waves stacked in y = block tile 128 x 4*NW):
+//   * the block marches in z; iteration m computes L1 on plane m for its whole tile (from a ring of 3 register
+//     planes of L0: m-1, m, m+1, refilled one iteration ahead), then L2 on plane m-1 from the three L1 planes
+//     m-2, m-1, m held in a second ring; Ht has its own ring of 3 (both steps need it);
+//   * x-neighbours by DPP wave shifts for both levels; y-neighbours between the waves through ONE LDS exchange +
+//     raw s_barrier per iteration that carries the first/last rows of L0(m) and of L1(m-1);
+//   * L1 is valid on the whole tile (L0 halo cells / rows come from global memory as in k_diff3_march), L2 on the
+//     tile shrunk by one cell: tiles overlap by 2 in x and y and chunks by 2 planes in z (redundant L1 work:
+//     32/30 or 16/14 in y, (zc+2)/zc in z; x uses 5 tiles of ~102 owned cells for a 512-cell line);
 //   * domain-boundary cells of L1 are taken from B: the registers that would hold the (non-existent) L0 halo
-//     beyond the boundary carry the B value instead, so the steady-state loop has no extra loads.
+//     beyond the boundary carry the B value instead, so the steady-state loop has no extra loads;
+//   * <= 256 registers, so every SIMD holds two waves (NW = 8: one 512-thread workgroup per CU; NW = 4: two).
 // Requirements (the caller falls back to two single-step launches otherwise): nx even and >= 128, all
-// arrays 16-byte aligned, ny >= 16, nz >= 3.
+// arrays 16-byte aligned, ny >= 16, nz >= 3, nx * ny * 96 < 2^31.
 #pragma once
 #include "diffusion3d_kernels.hpp"
 
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
     constexpr unsigned OOR = 0x7fffffffu;         // offset beyond every descriptor's num_records
     __shared__ double red[2 * NW];
     // [parity][slot 0..5][row kind][TXW]; wave w owns slot w+1, slot 0 / 5 receive the global halo rows of
-    // waves 0 / 3, so every wave reads "the slot below" and "the slot above" without a select
+    // the bottom / top wave, so every wave reads "the slot below" and "the slot above" without a select
     __shared__ __attribute__((aligned(16))) double xrow[2 * (NW + 2) * SLOT];
 
     const int tid = threadIdx.x;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
     DVec<VX> P[NR][RY];       // L0 planes m-1, m, m+1; plane p lives in slot (p - m0 + 1) % NR
     DVec<VX> HT[NR][RY];      // Ht planes m-1, m, m+1 (in flight), same slot rule
     DVec<VX> Q[NR][RY];       // L1 planes m-2, m-1, m, same slot rule
-    DVec<VX> YH;              // global L0 halo row of plane m (waves 0 / 3; the B boundary row if bb / bt)
+    DVec<VX> YH;              // global L0 halo row of plane m (bottom / top wave; the B boundary row if bb / bt)
     double ED[RY];            // L0 tile-edge cells of plane m (or the B boundary cell, see bndL / bndR)
     double acc1[VX], acc2[VX];
 #pragma unroll
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
             t.x = cR[RY - 1].v[0]; t.y = cR[RY - 1].v[1]; *reinterpret_cast<d2l*>(mine + TXW) = t;
             t.x = Qc[0].v[0]; t.y = Qc[0].v[1];           *reinterpret_cast<d2l*>(mine + 2 * TXW) = t;
             t.x = Qc[RY - 1].v[0]; t.y = Qc[RY - 1].v[1]; *reinterpret_cast<d2l*>(mine + 3 * TXW) = t;
-            if (hwave) {   // wave 0: slot 0 "last row"; wave 3: slot 5 "first row"
+            if (hwave) {   // bottom wave: slot 0 "last row"; top wave: slot NW+1 "first row"
                 t.x = YH.v[0]; t.y = YH.v[1];
                 *reinterpret_cast<d2l*>(buf + (w == 0 ? TXW : (NW + 1) * SLOT) + lane * VX) = t;
             }

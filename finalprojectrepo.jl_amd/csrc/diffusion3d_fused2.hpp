@@ -43,6 +43,7 @@ struct Diff3Args2 {
     double* partials2;              // same for the second step
     int zc, ntx, nby, ntz, sx;      // planes per chunk, tile counts, owned cells per tile in x
     int nw;                         // waves per workgroup (4, or 8: 32-row blocks)
+    int xalign;                     // 1: x-tile cut points sit in the middle of 128-byte lines
     int xcd_remap;
     int dbg;                        // tuning harness only: 1 = drop all stores, 2 = drop all loads of the z-loop
 };
@@ -172,7 +173,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
 
     // ---- x: owned output cells [ol, oh) (cut points between tiles are even); own cells [s, s+128) ----
     const int e0 = a.lo[0] & ~1;
-    const int olr = e0 + tx * a.sx, ohr = olr + a.sx;
+    // cut points between x-tiles: e0 + t*sx, moved (xalign) to the middle of a 128-byte line (cell 16k+8): a seam then
+    // costs one shared line instead of two
+    auto cut = [&](int t) {
+        const int c = e0 + t * a.sx;
+        return a.xalign ? (c & ~15) + 8 : c;
+    };
+    const int olr = tx == 0 ? a.lo[0] : cut(tx), ohr = tx == a.ntx - 1 ? a.hi[0] : cut(tx + 1);
     const int ol = olr > a.lo[0] ? olr : a.lo[0];
     const int oh = ohr < a.hi[0] ? ohr : a.hi[0];
     int s = (ol - 1) & ~1;
@@ -187,11 +194,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
     const bool xb_tile = (s == 0) || (s + TXW == nx);   // uniform: the tile holds an x-boundary cell
     const bool bndL = (ib == 0);                     // own cell v=0 is the x-boundary (lane 0 of tile 0)
     const bool bndR = (ib + 1 == nx - 1);            // own cell v=1 is the x-boundary (lane 63 of the last tile)
-    // edge register: lane 0 / 63 fetch the L0 cell beyond the tile (other lanes re-read their own first cell: a cache
-    // hit, but unconditional); the lane holding an x-boundary cell fetches that cell's B value instead
-    int ie = (lane == 0) ? ib - 1 : ((lane == 63) ? ib + VX : ibc);
+    // edge register: lane 0 / 63 fetch the L0 cell beyond the tile; the lane holding an x-boundary cell fetches that
+    // cell's B value instead.  All other lanes issue the (unconditional) load with an out-of-range offset: nothing is
+    // fetched -- re-reading an own cell looked free but missed the L2 often enough to add 20 % to the read traffic.
+    int ie = (lane == 0) ? ib - 1 : ib + VX;
     ie = ie < ifirst ? ifirst : (ie > ilast + 1 ? ilast + 1 : ie);
-    const unsigned eoff = (bndL || bndR) ? OOR : (unsigned)ie * 8u;                               // from A
+    const unsigned eoff = ((lane == 0 || lane == 63) && !(bndL || bndR)) ? (unsigned)ie * 8u : OOR;   // from A
     const unsigned boff = bndL ? 0u : (bndR ? (unsigned)(nx - 1) * 8u : OOR);                     // from B
 
     // ---- y: owned rows [oly, ohy); block rows y1 .. y1+15 ----
@@ -203,8 +211,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
     const bool bt = (w == NW - 1) && (y1 + NW * RY - 1 == ny - 1);  // own last row of the top wave is the y-boundary
     const int jd = bb ? 0 : (j0 > 0 ? j0 - 1 : 0);
     const int ju = bt ? ny - 1 : (j0 + RY < ny - 1 ? j0 + RY : ny - 1);
-    const bool hwave = (w == 0) || (w == NW - 1);             // waves that own a global halo row (the others re-read a
-    const double* Hsrc = (w == 0) ? (bb ? a.B : a.A) : (bt ? a.B : a.A);   //  neighbour's row: unconditional load, value unused)
+    const bool hwave = (w == 0) || (w == NW - 1);             // waves that own a global halo row
+    const double* Hsrc = (w == 0) ? (bb ? a.B : a.A) : (bt ? a.B : a.A);
     const int hrow = (w == 0) ? jd : ju;
 
     // ---- z: owned planes [k0, k1); iterations m0 .. m1 ----
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
             const double eb = diff3_bld1(rEB, boff, row_off(soff, r));   // 0 for every other lane
             e[r] = __longlong_as_double(__double_as_longlong(ea) | __double_as_longlong(eb));
         }
-        yh = diff3_bld2(rH, voff, soff);
+        yh = diff3_bld2(rH, voff, hwave ? soff : (int)OOR);   // waves without a global halo row fetch nothing
     };
 
     // slots: plane m0-1 -> 0, m0 -> 1, m0+1 -> 2
@@ -457,6 +465,7 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
     a.ntx = (span + 123) / 124;
     a.sx = (span + a.ntx - 1) / a.ntx;
     a.sx += a.sx & 1;
+    a.xalign = (a.sx >= 32 && a.sx <= 108 && a.nx % 16 == 0 && ((((uintptr_t)a.A | (uintptr_t)a.Ht)) & 127) == 0) ? 1 : 0;
     // 8 waves per workgroup (32-row blocks, 30 owned: less redundant level-1 work and fewer re-read rows; one
     // workgroup per CU) when the grid is tall enough, else 4 (16-row blocks, two workgroups per CU)
     a.nw = (nw_opt == 4 || nw_opt == 8) ? nw_opt : ((a.ny >= 32 && wy >= 24) ? 8 : 4);

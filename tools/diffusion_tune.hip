@@ -176,9 +176,32 @@ int main(int argc, char** argv)
         f.dtau = a.dtau; f._dt = a._dt; f._dx = a._dx; f._dy = a._dy; f._dz = a._dz;
         f.D_dx = a.D_dx; f.D_dy = a.D_dy; f.D_dz = a.D_dz; f.scale = a.scale;
         f.partials1 = parts; f.partials2 = parts2;
+        if (strstr(filter, "f2ab")) {
+            // interleaved A/B of launch options (box-to-box and run-to-run noise is +-5 %): usage  f2ab:<nw>,<zc>,<xcd>:<nw>,<zc>,<xcd>
+            int cfg[2][3] = {{0, 0, 1}, {0, 0, 3}};
+            sscanf(strstr(filter, "f2ab") + 4, ":%d,%d,%d:%d,%d,%d", &cfg[0][0], &cfg[0][1], &cfg[0][2], &cfg[1][0], &cfg[1][1], &cfg[1][2]);
+            double sum[2] = {0, 0}, sq[2] = {0, 0};
+            const int reps = 12;
+            for (int w = 0; w < 60; ++w) CK(diff3_launch2(f, true, cfg[w & 1][1], cfg[w & 1][2], s, 1 << 22, &np, cfg[w & 1][0], ncu));
+            for (int rep = 0; rep < reps; ++rep)
+                for (int c = 0; c < 2; ++c) {
+                    CK(hipEventRecord(e0, s));
+                    for (int i = 0; i < 20; ++i) CK(diff3_launch2(f, true, cfg[c][1], cfg[c][2], s, 1 << 22, &np, cfg[c][0], ncu));
+                    CK(hipEventRecord(e1, s));
+                    CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                    ms /= 20; sum[c] += ms; sq[c] += (double)ms * ms;
+                }
+            for (int c = 0; c < 2; ++c) {
+                const double m = sum[c] / reps, sd = sqrt(fmax(0.0, sq[c] / reps - m * m));
+                printf("f2ab cfg %c (nw=%d zc=%d xcd=%d): %.4f ms/launch +- %.4f  (%.0f GB/s A_eff)\n", 'A' + c, cfg[c][0], cfg[c][1], cfg[c][2], m, sd,
+                       2.0 * bytes / (m * 1e-3) / 1e9);
+            }
+            return 0;
+        }
         printf("# fused two-step kernel: ms per LAUNCH (= 2 iterations), GB/s in the per-iteration A_eff metric\n");
         for (int ring : {0, 4, 8})
-          for (int xcd : {0, 1, 2, 16, 32, 48})
+          for (int xcd : {0, 1, 2, 3, 16, 32, 48})
             for (int zc : {0, 16, 22, 24, 32, 43, 47, 48, 57, 64, 85, 128, 170})
                 for (int nrm : {0, 1}) {
                     char name[64];

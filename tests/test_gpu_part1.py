@@ -394,8 +394,9 @@ def test_fused_two_steps_random_shapes_and_boxes(fpr, oracle):
     c = F.ctx()
     rng = np.random.RandomState(20261003)
     try:
-        for trial in range(14):
-            shape = (int(rng.randint(64, 360)) * 2, int(rng.randint(16, 61)), int(rng.randint(3, 22)))
+        for trial in range(18):
+            nx = int(rng.randint(8, 46)) * 16 if trial % 2 else int(rng.randint(64, 360)) * 2   # line-aligned rows every other trial
+            shape = (nx, int(rng.randint(16, 61)), int(rng.randint(3, 22)))
             lo = tuple(int(rng.randint(1, max(2, n // 3))) if rng.rand() < 0.6 else 1 for n in shape)
             hi = tuple(int(rng.randint(max(l + 1, 2 * n // 3), n)) if rng.rand() < 0.6 else n - 1 for l, n in zip(lo, shape))
             c.set_option("diff3_zc2", int(rng.choice([0, 3, 4, 7, 16])))

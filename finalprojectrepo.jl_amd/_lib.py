@@ -55,6 +55,7 @@ _SIG = {
     "fpr_diffusion3d_can_step2": [_vp] + [_dp] * 5 + [_i] * 3,
     "fpr_diffusion3d_step2": [_vp] + [_dp] * 5 + [_i] * 3 + [_d] * 8 + [_d, _dp],
     "fpr_diffusion3d_step2_box": [_vp] + [_dp] * 5 + [_i] * 3 + [_d] * 8 + [C.POINTER(_i), C.POINTER(_i), _d, _dp, _i],
+    "fpr_diffusion3d_step2_box2": [_vp] + [_dp] * 5 + [_i] * 3 + [_d] * 8 + [C.POINTER(_i), C.POINTER(_i), _i, _i, _d, _dp, _i],
     "fpr_diffusion3d_flux": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 4,
     "fpr_diffusion3d_dHdtau": [_vp] + [_dp] * 6 + [_i] * 3 + [_d] * 4,
     "fpr_diffusion3d_update": [_vp] + [_dp] * 2 + [_i] * 3 + [_d],

@@ -109,7 +109,7 @@ static bool diff3_fuse2_ok(fpr_ctx* ctx, const double* Ht, const double* A, cons
 static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const double* B, double* C, double* dH, int nx,
                       int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy,
                       double D_dz, const int* lo, const int* hi, double scale, double* sumsq2_dev, bool accumulate,
-                      int stream_sel)
+                      int stream_sel, int zlo2 = 0, int zhi2 = 0)
 {
     if (!ctx) return FPR_ERR_INVALID;
     FPR_REQUIRE(ctx, Ht && A && B && C && dH, "null field pointer");
@@ -142,7 +142,8 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
         }
         hipError_t e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), (int)fpr_opt(ctx, "diff3_xcd2", 0),
                                      ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2, &nparts,
-                                     (int)fpr_opt(ctx, "diff3_nw2", 0), ctx->ncu);
+                                     (int)fpr_opt(ctx, "diff3_nw2", 0), ctx->ncu, zlo2 < 1 ? 1 : zlo2,
+                                     zhi2 > nz - 1 ? nz - 1 : zhi2);
         if (timed) {
             FPR_HIP(ctx, hipEventRecord(ctx->ktimer_ev[ctx->ktimer_used + 1], ctx->stream[stream_sel]));
             ctx->ktimer_used += 2;
@@ -280,6 +281,19 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
     }
     if (swapped_host) *swapped_host = (int)(swaps & 1);
     return FPR_OK;
+}
+
+extern "C" int fpr_diffusion3d_step2_box2(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hmid,
+                                          double* Hout, double* dHdtau, int nx, int ny, int nz, double dtau, double _dt,
+                                          double _dx, double _dy, double _dz, double D_dx, double D_dy, double D_dz,
+                                          const int lo[3], const int hi[3], int zlo2, int zhi2, double scale,
+                                          double* sumsq2_dev, int stream_sel)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, lo && hi, "null box");
+    FPR_REQUIRE(ctx, zlo2 >= hi[2] || zhi2 <= lo[2] || zhi2 <= zlo2, "the two z-ranges must not overlap");
+    return diff3_run2(ctx, Ht, Htau, Hmid, Hout, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo, hi,
+                      scale, sumsq2_dev, true, stream_sel, zlo2, zhi2);
 }
 
 extern "C" int fpr_diffusion3d_step_box(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2,

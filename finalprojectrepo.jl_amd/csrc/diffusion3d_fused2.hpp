@@ -44,6 +44,7 @@ struct Diff3Args2 {
     int zc, ntx, nby, ntz, sx;      // planes per chunk, tile counts, owned cells per tile in x
     int nw;                         // waves per workgroup (4, or 8: 32-row blocks)
     int xalign;                     // 1: x-tile cut points sit in the middle of 128-byte lines
+    int zb_lo, zb_hi, ntz_a;        // optional second z-range [zb_lo, zb_hi) with the same x/y box: chunks tz >= ntz_a
     int xcd_remap;
     int dbg;                        // tuning harness only: 1 = drop all stores, 2 = drop all loads of the z-loop
 };
@@ -216,8 +217,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
     const int hrow = (w == 0) ? jd : ju;
 
     // ---- z: owned planes [k0, k1); iterations m0 .. m1 ----
-    const int k0 = a.lo[2] + tz * a.zc;
-    const int k1 = (k0 + a.zc < a.hi[2]) ? k0 + a.zc : a.hi[2];
+    const bool zsecond = tz >= a.ntz_a;          // chunk of the second z-range (two thin boxes in one launch)
+    const int zlo = zsecond ? a.zb_lo : a.lo[2], zhi = zsecond ? a.zb_hi : a.hi[2];
+    const int k0 = zlo + (zsecond ? tz - a.ntz_a : tz) * a.zc;
+    const int k1 = (k0 + a.zc < zhi) ? k0 + a.zc : zhi;
     const int m0 = k0 - 1, m1 = k1;
 
     bool cm[VX], rm[RY];
@@ -453,9 +456,11 @@ static inline bool diff3_can_fuse2(const double* Ht, const double* A, const doub
 // zc_opt: planes per z-chunk (0 = auto), nw_opt: waves per workgroup (0 = auto, 4 or 8), ncu: compute units of the
 // device (for the chunking heuristic).
 static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int xcd_opt, hipStream_t stream,
-                                       int max_partials, int* nparts, int nw_opt = 0, int ncu = 256)
+                                       int max_partials, int* nparts, int nw_opt = 0, int ncu = 256, int zb_lo = 0,
+                                       int zb_hi = 0)
 {
     const int wx = a.hi[0] - a.lo[0], wy = a.hi[1] - a.lo[1], wz = a.hi[2] - a.lo[2];
+    const int wzb = zb_hi > zb_lo ? zb_hi - zb_lo : 0;   // second z-range (same x/y box), may be empty
     *nparts = 0;
     if (wx <= 0 || wy <= 0 || wz <= 0) return hipSuccess;
     if (!diff3_can_fuse2(a.Ht, a.A, a.B, a.C, a.dH, a.nx, a.ny, a.nz)) return hipErrorInvalidValue;
@@ -488,7 +493,7 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
             const int z = (wz + ntz - 1) / ntz;
             if (z > zc_max) continue;
             if (z < 4 && ntz > 1) break;
-            const long nb = tiles_xy * ((wz + z - 1) / z);
+            const long nb = tiles_xy * ((wz + z - 1) / z + (wzb + z - 1) / z);
             const long cost = ((nb + slots - 1) / slots) * (z + 6);
             if (best < 0 || cost <= best) { best = cost; zc = z; }
         }
@@ -497,7 +502,10 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
     if (zc > wz) zc = wz;
     if (zc > zc_max) zc = zc_max;
     a.zc = zc;
-    a.ntz = (wz + zc - 1) / zc;
+    a.ntz_a = (wz + zc - 1) / zc;
+    a.zb_lo = zb_lo;
+    a.zb_hi = zb_lo + wzb;
+    a.ntz = a.ntz_a + (wzb + zc - 1) / zc;
     const long nblk = tiles_xy * a.ntz;
     if (nblk > 0x7fffffffL || (norm && nblk > max_partials)) return hipErrorInvalidValue;
     a.dbg = xcd_opt >> 4;

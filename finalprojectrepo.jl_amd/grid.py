@@ -308,9 +308,13 @@ class GlobalGrid:
         with torch.cuda.stream(c.comm):
             ex.wait(st["works"])
         c.compute.wait_stream(c.comm)
-        for on, k in ((st["lo"], 1), (st["hi"], nz - 2)):
-            if on:
-                part1.diffusion_3D_step_τ2_box(*st["fused"], (1, 1, k), (nx - 1, ny - 1, k + 1), st["scale"], st["sq"], 0)
+        if st["lo"] and st["hi"]:   # both thin slabs in one launch
+            part1.diffusion_3D_step_τ2_box(*st["fused"], (1, 1, 1), (nx - 1, ny - 1, 2), st["scale"], st["sq"], 0,
+                                           z2=(nz - 2, nz - 1))
+        else:
+            for on, k in ((st["lo"], 1), (st["hi"], nz - 2)):
+                if on:
+                    part1.diffusion_3D_step_τ2_box(*st["fused"], (1, 1, k), (nx - 1, ny - 1, k + 1), st["scale"], st["sq"], 0)
         c.comm.wait_stream(c.compute)
         with torch.cuda.stream(c.comm):
             st["works"] = ex.post(st["out"])

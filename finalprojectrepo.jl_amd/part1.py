@@ -93,11 +93,17 @@ def diffusion_3D_step_τ2(Ht, Hτ, Hmid, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D
 
 
 def diffusion_3D_step_τ2_box(Ht, Hτ, Hmid, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo, hi, scale=0.0,
-                             sumsq2_dev=None, stream_sel=0):
-    """Sub-box form of diffusion_3D_step_τ2 (0-based [lo, hi)); the two sums are accumulated into sumsq2_dev."""
+                             sumsq2_dev=None, stream_sel=0, z2=None):
+    """Sub-box form of diffusion_3D_step_τ2 (0-based [lo, hi)); the two sums are accumulated into sumsq2_dev.
+    z2 = (zlo2, zhi2): a second, disjoint z-range with the same x/y extent handled by the same launch."""
     nx, ny, nz = Ht.shape
     lo3 = (C.c_int * 3)(*lo)
     hi3 = (C.c_int * 3)(*hi)
+    if z2 is not None:
+        _ctx().call("fpr_diffusion3d_step2_box2", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hmid, 3), fptr(Hout, 3), fptr(dHdτ, 3),
+                    nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo3, hi3, int(z2[0]), int(z2[1]), scale,
+                    sumsq2_dev.data_ptr() if sumsq2_dev is not None else None, stream_sel)
+        return
     _ctx().call("fpr_diffusion3d_step2_box", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hmid, 3), fptr(Hout, 3), fptr(dHdτ, 3),
                 nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo3, hi3, scale,
                 sumsq2_dev.data_ptr() if sumsq2_dev is not None else None, stream_sel)

@@ -105,6 +105,12 @@ int fpr_diffusion3d_step2_box(fpr_ctx* ctx, const double* Ht, const double* Htau
                               double* dHdtau, int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy,
                               double _dz, double D_dx, double D_dy, double D_dz, const int lo[3], const int hi[3],
                               double scale, double* sumsq2_dev, int stream_sel);
+/* _box2: the box [lo, hi) plus a second z-range [zlo2, zhi2) with the same x/y extent in ONE launch (the two thin
+ * slabs next to the z-halos of a rank, role of @hide_communication's boundary width); the ranges must not overlap. */
+int fpr_diffusion3d_step2_box2(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hmid, double* Hout,
+                               double* dHdtau, int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy,
+                               double _dz, double D_dx, double D_dy, double D_dz, const int lo[3], const int hi[3],
+                               int zlo2, int zhi2, double scale, double* sumsq2_dev, int stream_sel);
 
 /* A5: the single-rank host loop of diffusion_3D_kernel_programming (part1_kernel_programming.jl:166-204) in
  * native code: for each of `nt` physical steps iterate the fused update until err <= tol (err =

@@ -198,6 +198,19 @@ function diffusion_3D_step_τ2_box(Ht::DA, Hτ::DA, Hmid::DA, Hout::DA, dHdτ::D
                 sumsq2 === nothing ? Ptr{Cdouble}(C_NULL) : p(sumsq2), stream_sel))
 end
 
+"As diffusion_3D_step_τ2_box plus a second, disjoint z-range [zlo2, zhi2) with the same x/y extent in the same launch."
+function diffusion_3D_step_τ2_box2(Ht::DA, Hτ::DA, Hmid::DA, Hout::DA, dHdτ::DA, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz,
+                                   lo::NTuple{3,Int}, hi::NTuple{3,Int}, zlo2::Int, zhi2::Int; scale = 0.0,
+                                   sumsq2::Union{DA,Nothing} = nothing, stream_sel = 0)
+    nx, ny, nz = size(Ht)
+    lo3 = Cint[lo...]; hi3 = Cint[hi...]
+    check(ccall((:fpr_diffusion3d_step2_box2, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint,
+                 Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cint}, Ptr{Cint}, Cint, Cint, Cdouble, Ptr{Cdouble}, Cint),
+                ctx(), p(Ht), p(Hτ), p(Hmid), p(Hout), p(dHdτ), nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo3, hi3,
+                zlo2, zhi2, scale, sumsq2 === nothing ? Ptr{Cdouble}(C_NULL) : p(sumsq2), stream_sel))
+end
+
 function compute_flux!(qx::DA, qy::DA, qz::DA, Hτ::DA, D, dx, dy, dz)        # part1_array_programming.jl:10-12
     nx, ny, nz = size(Hτ)
     check(ccall((:fpr_diffusion3d_flux, libfpr), Cint,

@@ -441,3 +441,32 @@ def test_python_loop_with_fused_pairs_equals_native_loop(fpr, oracle, case):
         assert np.array_equal(H, out[0][0]) and np.array_equal(r, out[0][3])
         assert np.allclose(e, out[0][2], rtol=1e-12, atol=0)
         assert np.array_equal(ht[1:-1, 1:-1, 1:-1], H[1:-1, 1:-1, 1:-1])
+
+
+@pytest.mark.parametrize("z2", [(22, 23), (20, 23), (12, 14)])
+def test_fused_two_steps_two_z_ranges_in_one_launch(fpr, oracle, z2):
+    """fpr_diffusion3d_step2_box2: the box plus a second, disjoint z-range with the same x/y extent (the two thin
+    slabs next to a rank's z-halos) in one launch; sums accumulate over both."""
+    F = fpr
+    shape = (130, 33, 24)
+    lo, hi = (1, 1, 1), (129, 32, 2)
+    Ht, A, B = rnd(shape, 41), rnd(shape, 42), rnd(shape, 43)
+    C_ref, dH_ref, _, _ = _two_oracle_steps(oracle, Ht, A, B)
+    Bp, dH1 = B.copy(order="F"), asf(np.zeros(shape))
+    oracle.diffusion3d_step(Ht, A, Bp, dH1, *COEF.values())
+    dC, dD = F.asdevice(np.full(shape, -3.0)), F.asdevice(np.full(shape, -9.0))
+    sq2 = F.ctx().scal[:2]
+    sq2.zero_()
+    F.part1.diffusion_3D_step_τ2_box(F.asdevice(Ht), F.asdevice(A), F.asdevice(B), dC, dD, *COEF.values(), lo, hi, 0.2, sq2,
+                                     z2=z2)
+    C, D = F.tonumpy(dC), F.tonumpy(dD)
+    s1 = s2 = 0.0
+    for zr in ((lo[2], hi[2]), z2):
+        sl = (slice(1, 129), slice(1, 32), slice(zr[0], zr[1]))
+        assert np.array_equal(C[sl], C_ref[sl]) and np.array_equal(D[sl], dH_ref[sl])
+        C[sl] = -3.0; D[sl] = -9.0
+        s1 += oracle.sumsq_scaled(dH1[sl].copy(order="F"), 0.2)
+        s2 += oracle.sumsq_scaled(dH_ref[sl].copy(order="F"), 0.2)
+    assert (C == -3.0).all() and (D == -9.0).all()
+    g1, g2 = (float(x) for x in sq2.tolist())
+    assert abs(g1 - s1) <= 1e-13 * s1 and abs(g2 - s2) <= 1e-13 * s2

@@ -140,7 +140,7 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
             int v = 0;
             ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
         }
-        hipError_t e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), (int)fpr_opt(ctx, "diff3_xcd2", 0),
+        hipError_t e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), (int)fpr_opt(ctx, "diff3_xcd2", 0) & 3,   // (higher bits are harness-only ablation switches)
                                      ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2, &nparts,
                                      (int)fpr_opt(ctx, "diff3_nw2", 0), ctx->ncu, zlo2 < 1 ? 1 : zlo2,
                                      zhi2 > nz - 1 ? nz - 1 : zhi2);

@@ -401,6 +401,63 @@ def diffusion_3D_kernel_programming(*, nx, ny, nz, ttot=1.0, tol=1e-8, use_share
                    dτ, Ht, Hτ, residual_H, return_device)
 
 
+def diffusion_3D_array_programming(*, nx, ny, nz, do_vis=False, verbose=True, ttot=1.0, tol=1e-8, iter_max=100000,
+                                   fixed_iters=0, Ht_init=None, return_info=False):
+    """part1_array_programming.jl:20-92 (BASELINE config 1) on the split kernels compute_flux! / compute_dHdτ! /
+    update_H! (clean semantics of the reference's single array kernel :9-18).  Single rank: the
+    reference's update_halo!(Hτ) (:67) has no neighbour to talk to there, and its multi-rank runs use the
+    kernel-programming solver (part1_scaling_experiments.jl).  One host round trip per pseudo-iteration for the
+    norm, as in the reference (:68).  Returns (X_g, H_g) like the reference; with return_info also a dict.
+
+    Extra keyword arguments: ttot / tol / iter_max are hard-coded in the reference (:24,43-44); fixed_iters runs
+    exactly that many pseudo-iterations per physical step (config 1: 50); Ht_init replaces the Gaussian."""
+    import numpy as np
+    import torch
+
+    lx, ly, lz = 10.0, 10.0, 10.0  # :22
+    D = 1.0  # :23
+    dx, dy, dz = lx / nx, ly / ny, lz / nz  # :30, nx_g() == nx on one rank
+    total_N = nx * ny * nz  # :37
+    dt = 0.2  # :40
+    dτ = min(dx, dy, dz) ** 2 / D / 8.1  # :41
+    center = [lx / 2, ly / 2, lz / 2]  # :47
+    qx = fzeros(nx - 1, ny - 2, nz - 2)  # :48-50
+    qy = fzeros(nx - 2, ny - 1, nz - 2)
+    qz = fzeros(nx - 2, ny - 2, nz - 1)
+    Ht = fzeros(nx, ny, nz)  # :51
+    if Ht_init is not None:
+        Ht.copy_(Ht_init)
+    else:
+        init_local_gaussian(center, dx, dy, dz, Ht)  # :52
+    apply_boundary_conditions_(Ht, (0, 0, 0), (1, 1, 1))  # :53 -- a no-op on one rank (part1_utils.jl:14-34)
+    Hτ = Ht.clone(memory_format=torch.preserve_format)  # :54
+    dHdt = fzeros(nx - 2, ny - 2, nz - 2)  # :55
+    sqrtN = math.sqrt(total_N)
+    t = 0.0
+    iter_total = 0
+    iters_per_step, err_per_step = [], []
+    while t < ttot:  # :61
+        iter_inner = 0
+        err = 2 * tol  # :64
+        while (iter_inner < fixed_iters) if fixed_iters > 0 else (err > tol and iter_inner < iter_max):  # :65
+            diffusion_3D_step_τ_(Ht, Hτ, dHdt, dt, dτ, qx, qy, qz, dx, dy, dz, D)  # :66
+            err = math.sqrt(local_sumsq(dHdt, dt)) / sqrtN  # :68  dist_norm_L2(dHdt * dt, comm_cart) / sqrt(total_N)
+            iter_inner += 1
+        if verbose:  # :71-77
+            print("Converged after %d iterations." % iter_inner if err <= tol else
+                  "Couldn't converge within %d iterations." % iter_max)
+        iters_per_step.append(iter_inner)
+        err_per_step.append(err)
+        iter_total += iter_inner
+        t += dt  # :80
+        _ctx().call("fpr_copy", fptr(Ht), fptr(Hτ), Ht.numel())  # Ht .= Hτ, :81
+    X_g = np.linspace(dx / 2, lx - dx / 2, nx)  # :85
+    H_g = _lib.tonumpy(Ht)  # gather!(Array(Ht), H_g), :87
+    if return_info:
+        return X_g, H_g, {"iters": iters_per_step, "err": err_per_step, "dHdt": dHdt, "Hτ": Hτ, "dτ": dτ, "dx": dx}
+    return X_g, H_g
+
+
 def _finish(gg, nx, ny, nz, dims, dx, lx, Δt, timed_iter_total, use_shared_memory, iters_per_step, err_per_step, dτ,
             Ht, Hτ, residual_H, return_device):
     """Benchmark accounting and return values of diffusion_3D_kernel_programming (:209-227)."""

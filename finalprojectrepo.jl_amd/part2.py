@@ -123,8 +123,9 @@ def compute_dt(v, vx, vy, dt_dif, a_dif, a_adv, h, beta):
     return dt_adv if beta >= 0.5 else min(dt_dif, dt_adv)
 
 
-def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_steps=None):
-    """part2.jl:140-262"""
+def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_steps=None, trace=None):
+    """part2.jl:140-262.  trace: optional list; one dict per time step is appended with the step's dt and the
+    residual histories of its multigrid solves (diagnostics for the parity tests; costs nothing when None)."""
     import torch
 
     opt = opt if opt is not None else SimIn_t()
@@ -151,7 +152,17 @@ def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_s
             tic = time.time()
         with warnings.catch_warnings():
             warnings.simplefilter("ignore" if not verbose else "default")
-            mg.MGsolve_2DPoisson_(S, W, h, 0.0, opt.tol, opt.niters, False, opt=mgopt, prealloc_dict=prealloc)  # :187
+            rec = {} if trace is not None else None
+
+            def solve(name, u, f, c, bcs):
+                if rec is None:
+                    mg.MGsolve_2DPoisson_(u, f, h, c, opt.tol, opt.niters, bcs, opt=mgopt, prealloc_dict=prealloc)
+                else:
+                    r, hist, frms, cit = mg.MGsolve_2DPoisson_(u, f, h, c, opt.tol, opt.niters, bcs, opt=mgopt,
+                                                               prealloc_dict=prealloc, return_history=True)
+                    rec[name] = {"r_rms": r, "history": hist, "f_rms": frms, "coarse_iters": cit, "c": c}
+
+            solve("S", S, W, 0.0, False)  # :187
             compute_velocity_(S, hx, hy, vx, vy)  # :190
             torch.sqrt(vx * vx + vy * vy, out=A["v"])  # :193
             dt = compute_dt(A["v"], vx, vy, dt_dif, opt.a_dif, opt.a_adv, h, opt.beta)  # :196
@@ -167,13 +178,16 @@ def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_s
             if opt.beta > 0.0:  # :217-226
                 c = 1.0 / (opt.beta * dt)
                 A["T_rhs"].copy_(-c * (T + dt * ((1.0 - opt.beta) * A["dT2"] - A["dTx"] - A["dTy"])))
-                mg.MGsolve_2DPoisson_(T, A["T_rhs"], h, c, opt.tol, opt.niters, True, opt=mgopt, prealloc_dict=prealloc)
+                solve("T", T, A["T_rhs"], c, True)  # :221
                 c = c / opt.Pr
                 A["W_rhs"].copy_(-c * (W + dt * ((1.0 - opt.beta) * A["dW2"] - A["dWx"] - A["dWy"] - opt.Pr * A["Ra_dTdx"])))
-                mg.MGsolve_2DPoisson_(W, A["W_rhs"], h, c, opt.tol, opt.niters, False, opt=mgopt, prealloc_dict=prealloc)
+                solve("W", W, A["W_rhs"], c, False)  # :226
             else:  # :229-230
                 T.copy_(T + dt * (A["dT2"] - A["dTx"] - A["dTy"]))
                 W.copy_(W + dt * (A["dW2"] - A["dWx"] - A["dWy"] - opt.Pr * A["Ra_dTdx"]))
+        if rec is not None:
+            rec["dt"] = dt
+            trace.append(rec)
         sim_time += dt
         step += 1
         if verbose and (step - 1) % 20 == 0:

@@ -294,6 +294,55 @@ long orc_diffusion3d_solve(double *Ht, int nx, int ny, int nz, double lx, double
     return total;
 }
 
+/* Host loop of diffusion_3D_array_programming -- part1_array_programming.jl:20-92 (BASELINE config 1),
+ * single rank, with the clean (barrier-separated) semantics of the three statements of its kernel
+ * (:9-18).  Differences from the kernel-programming loop that matter for the result:
+ * the update is in place (one work buffer, :16), dHdt is (nx-2,ny-2,nz-2) (:55), divisions instead of
+ * reciprocal multiplies, and the outer loop is `while t < ttot; ...; t += dt` (:61,80).
+ * Ht holds the initial condition on entry and the final field on return.  iters_out / err_out: one entry
+ * per physical step (at most max_steps are written).  Returns the number of physical steps executed. */
+int orc_diffusion3d_array_solve(double *Ht, int nx, int ny, int nz, double lx, double ly, double lz,
+                                double D, double dt, double ttot, double tol, long iter_max,
+                                long fixed_iters, int max_steps, long *iters_out, double *err_out,
+                                double *dHdt_out)
+{
+    const size_t N = (size_t)nx * ny * nz;
+    const size_t NI = (size_t)(nx - 2) * (ny - 2) * (nz - 2);
+    const double dx = lx / nx, dy = ly / ny, dz = lz / nz; /* :30 with nx_g()==nx on one rank */
+    const double mn = fmin(fmin(dx, dy), dz);
+    const double dtau = mn * mn / D / 8.1; /* :41 */
+    const double sqrtN = sqrt((double)N);  /* :37 */
+    double *qx = (double *)calloc((size_t)(nx - 1) * (ny - 2) * (nz - 2), sizeof(double)); /* :48 */
+    double *qy = (double *)calloc((size_t)(nx - 2) * (ny - 1) * (nz - 2), sizeof(double)); /* :49 */
+    double *qz = (double *)calloc((size_t)(nx - 2) * (ny - 2) * (nz - 1), sizeof(double)); /* :50 */
+    double *Htau = (double *)malloc(N * sizeof(double));
+    double *dHdt = (double *)calloc(NI, sizeof(double)); /* :55 */
+    memcpy(Htau, Ht, N * sizeof(double));                /* :54 */
+    double t = 0.0;
+    int step = 0;
+    while (t < ttot) { /* :61 */
+        long it = 0;
+        double err = 2 * tol; /* :64 */
+        while (fixed_iters > 0 ? it < fixed_iters : (err > tol && it < iter_max)) { /* :65 */
+            orc_diffusion3d_flux(qx, qy, qz, Htau, nx, ny, nz, D, dx, dy, dz);            /* :10-12 */
+            orc_diffusion3d_dHdtau(dHdt, Htau, Ht, qx, qy, qz, nx, ny, nz, dt, dx, dy, dz); /* :14-15 */
+            orc_diffusion3d_update(Htau, dHdt, nx, ny, nz, dtau);                         /* :16 */
+            err = sqrt(sumsq_scaled(dHdt, NI, dt)) / sqrtN;                               /* :68 */
+            ++it;
+        }
+        if (step < max_steps) {
+            if (iters_out) iters_out[step] = it;
+            if (err_out) err_out[step] = err;
+        }
+        ++step;
+        t += dt;                              /* :80 */
+        memcpy(Ht, Htau, N * sizeof(double)); /* :81 */
+    }
+    if (dHdt_out) memcpy(dHdt_out, dHdt, NI * sizeof(double));
+    free(qx); free(qy); free(qz); free(Htau); free(dHdt);
+    return step;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* Part 2 -- 2D geometric multigrid                                                             */
 /* ------------------------------------------------------------------------------------------ */

@@ -53,6 +53,7 @@ class Oracle:
             "orc_init_gaussian": (None, [_dp] + [i] * 3 + [d] * 6 + [i] * 3),
             "orc_apply_bc3d": (None, [_dp] + [i] * 3 + [C.POINTER(i)] * 2),
             "orc_diffusion3d_solve": (l, [_dp] + [i] * 3 + [d] * 5 + [i, d, l, l, C.POINTER(l), _dp, _dp, _dp]),
+            "orc_diffusion3d_array_solve": (i, [_dp] + [i] * 3 + [d] * 7 + [l, l, i, C.POINTER(l), _dp, _dp]),
             "orc_residual2d": (None, [_dp, _dp, d, d, _dp, i, i]),
             "orc_jacobi2d": (d, [_dp, _dp, d, d, _dp, i, i, d]),
             "orc_bc_dirichlet2d": (None, [_dp, i, i]),
@@ -117,6 +118,19 @@ class Oracle:
         self.lib.orc_diffusion3d_solve(_p(Ht), nx, ny, nz, lx, ly, lz, D, dt, nt, tol, iter_max,
                                        fixed_iters, iters, err.ctypes.data_as(_dp), _p(Htau), _p(dH))
         return list(iters), err, Htau, dH
+
+    def diffusion3d_array_solve(self, Ht, lx=10.0, ly=10.0, lz=10.0, D=1.0, dt=0.2, ttot=1.0, tol=1e-8,
+                                iter_max=100000, fixed_iters=0):
+        """diffusion_3D_array_programming (part1_array_programming.jl:20-92) in place on Ht;
+        returns (iters[steps], err[steps], dHdt (nx-2,ny-2,nz-2))."""
+        nx, ny, nz = Ht.shape
+        cap = 4096
+        iters = (C.c_long * cap)()
+        err = np.zeros(cap)
+        dH = farr(nx - 2, ny - 2, nz - 2)
+        n = self.lib.orc_diffusion3d_array_solve(_p(Ht), nx, ny, nz, lx, ly, lz, D, dt, ttot, tol, iter_max,
+                                                 fixed_iters, cap, iters, err.ctypes.data_as(_dp), _p(dH))
+        return list(iters)[:n], err[:n].copy(), dH
 
     # ---- Part 2 ----
     def residual2d(self, u, f, h, c, res):

@@ -263,6 +263,71 @@ def test_full_size_4097_properties(fpr):
     assert r5 < 1e-6 * frms and len(hist5) <= 12 and cit > 0
 
 
+CG_RTOL = 1e-4   # see the comment in test_config3_five_levels_4097
+
+
+def test_config3_known_answer_k10_l6_jacobi(fpr, oracle):
+    """SURVEY 4.4 known answer of the multigrid_bench.jl protocol (x=0, b~U[0,1) incl. boundary, tol 1e-6):
+    k=10, l=6 (coarse 65^2, Jacobi capped at 20*65 = 1300 sweeps per V-cycle) takes exactly 11 V-cycles."""
+    F, mg = fpr, fpr.multigrid
+    n = 1025
+    h = 1.0 / (n - 1)
+    b = asf(splitmix64_uniform(n * n, 1).reshape((n, n), order="F"))
+    opt = mg.MGOpt()
+    opt.coarse_solve_size, opt.coarse_solver = 65, mg.jacobi
+    xo = farr(n, n)
+    r_o, hist_o, frms_o = oracle.mgsolve2d(xo, b, h, 0.0, 1e-6, 100, False, 65, 0)
+    x = F.fzeros(n, n)
+    r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, F.asdevice(b), h, 0.0, 1e-6, 100, False, opt=opt, return_history=True)
+    assert len(hist) == len(hist_o) == 11
+    assert np.allclose(hist, hist_o, rtol=1e-10, atol=0)
+    assert cit == oracle.last_coarse_iters() == 11 * 1300   # the coarse solve never reaches its tolerance
+    assert np.array_equal(F.tonumpy(x), xo)
+
+
+def test_config3_five_levels_4097(fpr, oracle):
+    """BASELINE config 3 as named: 4097^2, 5 grids (l=8, coarse 257^2), 2+2 Jacobi smooths, multigrid_bench.jl
+    protocol.  Jacobi coarse solver: 44 V-cycles / 226 160 coarse sweeps to tol 1e-6 (the coarse solve is capped at
+    20*257 = 5140 sweeps and never converges), first three residuals and the field after three cycles equal to the
+    oracle's; CG coarse solver: 7 V-cycles, first three residuals equal to the oracle's."""
+    F, mg = fpr, fpr.multigrid
+    n = 4097
+    h = 1.0 / (n - 1)
+    b = asf(splitmix64_uniform(n * n, 1).reshape((n, n), order="F"))
+    gb = F.asdevice(b)
+    opt = mg.MGOpt()
+    opt.coarse_solve_size = 257
+    import warnings
+    for solver, ncyc, rtol in ((mg.jacobi, 44, 1e-10), (mg.conjugate_gradient, 7, CG_RTOL)):
+        opt.coarse_solver = solver
+        xo = farr(n, n)
+        _, hist_o, frms_o = oracle.mgsolve2d(xo, b, h, 0.0, 1e-6, 3, False, 257, solver.value)
+        cit_o = oracle.last_coarse_iters()
+        x = F.fzeros(n, n)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")   # 3 cycles do not converge: the reference's @warn (multigrid.jl:78-80)
+            _, hist3, frms, cit3 = mg.MGsolve_2DPoisson_(x, gb, h, 0.0, 1e-6, 3, False, opt=opt, return_history=True)
+        assert len(hist3) == len(hist_o) == 3
+        assert np.allclose(hist3, hist_o, rtol=rtol, atol=0), (hist3, hist_o)
+        assert abs(frms - frms_o) <= 1e-13 * frms_o
+        if solver is mg.jacobi:
+            assert cit3 == cit_o == 3 * 5140
+            assert np.array_equal(F.tonumpy(x), xo)
+        else:
+            # CG stops on ||r|| < tol*||b|| (krylov.jl:71): dot products differ by summation order between the two
+            # implementations, which ~600 iterations per solve amplify -- counts agree to a few iterations and the
+            # V-cycle residuals to the coarse tolerance (1e-6) times the cycle's contraction, not to rounding
+            print("config 3 l=8 CG: coarse iterations gpu/oracle", cit3, cit_o, "hist", hist3, hist_o)
+            assert abs(cit3 - cit_o) <= 0.02 * cit_o
+            assert np.abs(F.tonumpy(x) - xo).max() <= 1e-5 * np.abs(xo).max()
+        x.zero_()
+        r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, gb, h, 0.0, 1e-6, 100, False, opt=opt, return_history=True)
+        assert len(hist) == ncyc and r < 1e-6 * frms
+        assert np.allclose(hist[:3], hist_o, rtol=rtol, atol=0)
+        if solver is mg.jacobi:
+            assert cit == 44 * 5140 == 226160
+
+
 @pytest.mark.parametrize("tol", [0.9, 0.7, 0.5, 0.4, 0.3, 0.25, 0.2, 0.15, 1e-9])
 def test_coarse_jacobi_exit_inside_a_fused_group(fpr, oracle, tol):
     """The coarse Jacobi solve runs 8 fused sweeps per launch; when the exit test (multigrid.jl:152-155)

@@ -1,5 +1,6 @@
 """GPU parity tests for the NEXT row 8f-1 (Navier-Stokes step around the V-cycle), pinned by the
 reference's FORTRAN fixtures (test/part2.jl)."""
+import math
 import os
 
 import numpy as np
@@ -52,14 +53,15 @@ def test_one_explicit_step_matches_fortran(fpr):
     assert out.dt_last == 3.662109375e-05
 
 
-def _oracle_ns_steps(oracle, T, W, nx, ny, Ra, Pr, k, beta, tol, niters, nsteps):
+def _oracle_ns_steps(oracle, T, W, nx, ny, Ra, Pr, k, beta, tol, niters, nsteps, trace=None):
     """part2.jl:181-250 restated with the oracle's kernels (semi-implicit and explicit branches)."""
     h = 1.0 / (ny - 1.0)
     dt_dif = 0.15 * h * h / max(k, Pr)
     S = farr(nx, ny)
     out = []
     for _ in range(nsteps):
-        oracle.mgsolve2d(S, W, h, 0.0, tol, niters)
+        rec = {}
+        rec["S"] = oracle.mgsolve2d(S, W, h, 0.0, tol, niters)
         vx, vy = farr(nx, ny), farr(nx, ny)
         oracle.compute_velocity(S, h, h, vx, vy)
         v = np.sqrt(vx * vx + vy * vy)
@@ -81,14 +83,16 @@ def _oracle_ns_steps(oracle, T, W, nx, ny, Ra, Pr, k, beta, tol, niters, nsteps)
         if beta > 0.0:
             c = 1.0 / (beta * dt)
             T_rhs = np.asfortranarray(-c * (T + dt * ((1.0 - beta) * dT2 - dTx - dTy)))
-            oracle.mgsolve2d(T, T_rhs, h, c, tol, niters, True)
+            rec["T"] = oracle.mgsolve2d(T, T_rhs, h, c, tol, niters, True)
             c = c / Pr
             W_rhs = np.asfortranarray(-c * (W + dt * ((1.0 - beta) * dW2 - dWx - dWy - Pr * R)))
-            oracle.mgsolve2d(W, W_rhs, h, c, tol, niters, False)
+            rec["W"] = oracle.mgsolve2d(W, W_rhs, h, c, tol, niters, False)
         else:
             T[:] = T + dt * (dT2 - dTx - dTy)
             W[:] = W + dt * (dW2 - dWx - dWy - Pr * R)
         out.append(dt)
+        if trace is not None:
+            trace.append(rec)
     return S, out
 
 
@@ -116,3 +120,99 @@ def test_driver_steps_match_oracle(fpr, oracle, beta):
         got = getattr(out, name)
         scale = max(np.abs(ref).max(), 1e-300)
         assert np.abs(got - ref).max() <= 1e-10 * scale, (name, np.abs(got - ref).max(), scale)
+
+
+def _config5_inputs(p2, nx, ny, seed=1):
+    h = 1.0 / (ny - 1.0)
+    width = (nx - 1.0) / (ny - 1.0)
+    T = np.asfortranarray(np.repeat((0.5 * (1.0 + np.cos((3.0 * np.pi * np.arange(nx) * h) / width)))[:, None], ny, axis=1))
+    W = np.asfortranarray(p2.splitmix64_uniform(nx * ny, seed).reshape((nx, ny), order="F"))
+    return T, W
+
+
+def _config5_opt(p2, nx, ny, niters):
+    """BASELINE config 5 as the reference can run it: buoyancy-driven convection (the reference has
+    no lid-driven cavity), semi-implicit beta = 0.5, MG tol 1e-7 (part2_semi_implicit_vs_explicit_experiments.jl:35-44),
+    Pr = 1, Ra = 1e6, cosine T, counter-based random W."""
+    opt = p2.SimIn_t()
+    opt.nx, opt.ny, opt.beta, opt.tol, opt.Pr, opt.niters, opt.ttot = nx, ny, 0.5, 1.0e-7, 1.0, niters, 1e9
+    opt.W_init_strategy = p2.random
+    return opt
+
+
+def test_config5_semi_implicit_513x129_three_steps_match_oracle(fpr, oracle):
+    """Config 5 at a size the oracle runs whole: three semi-implicit steps (3 MG solves each, the T solve with
+    apply_BCs and c > 0 running into niters = 50 as in the reference) -- identical time steps, residual histories of
+    all nine solves to 1e-10, fields to 1e-10."""
+    import warnings
+
+    F, p2 = fpr, fpr.part2
+    nx, ny = 513, 129
+    opt = _config5_opt(p2, nx, ny, 50)
+    T, W = _config5_inputs(p2, nx, ny)
+    tr_o, tr = [], []
+    S_o, dts = _oracle_ns_steps(oracle, T, W, nx, ny, opt.Ra, opt.Pr, opt.k, opt.beta, opt.tol, opt.niters, 3, trace=tr_o)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = p2.navier_stokes_2D(opt=opt, verbose=False, max_steps=3, trace=tr)
+    assert out.steps == 3 and len(tr) == 3
+    for step in range(3):
+        assert abs(tr[step]["dt"] - dts[step]) <= 1e-12 * dts[step]
+        for name in ("S", "T", "W"):
+            r_o, hist_o, frms_o = tr_o[step][name]
+            g = tr[step][name]
+            assert len(g["history"]) == len(hist_o), (step, name, len(g["history"]), len(hist_o))
+            assert np.allclose(g["history"], hist_o, rtol=1e-10, atol=0), (step, name)
+    # the first T solve does not converge in niters (SURVEY 4.4; the reference emits its @warn); with the tiny time
+    # steps that follow c = 1/(beta dt) dominates the operator and the later ones converge in a few cycles
+    assert len(tr[0]["T"]["history"]) == 50 and len(tr[1]["T"]["history"]) < 50
+    for name, ref in (("T", T), ("W", W), ("S", S_o)):
+        got = getattr(out, name)
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= 1e-10 * scale, (name, np.abs(got - ref).max(), scale)
+
+
+def test_config5_semi_implicit_2049sq(fpr, oracle):
+    """BASELINE config 5 at its full size (2049^2 = nearest valid grid to 2048^2), the reference's niters = 50.
+    The first step against the oracle: residual histories of the S solve (converges), of the T solve (apply_BCs,
+    c > 0: runs into niters, the reference's @warn path) and of the W solve to 1e-10, the time step, and the fields
+    after the step to 1e-10.  Steps 2 and 3 (the oracle needs ~20 s per step at this size): size-independent
+    properties -- Dirichlet columns exact, fields finite, time steps positive, S and W solves converged."""
+    import warnings
+
+    F, p2 = fpr, fpr.part2
+    nx = ny = 2049
+    T, W = _config5_inputs(p2, nx, ny)
+    opt = _config5_opt(p2, nx, ny, 50)
+    tr_o, tr, snap = [], [], {}
+    S_o, dts = _oracle_ns_steps(oracle, T, W, nx, ny, opt.Ra, opt.Pr, opt.k, opt.beta, opt.tol, opt.niters, 1, trace=tr_o)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out1 = p2.navier_stokes_2D(opt=opt, verbose=False, max_steps=1, trace=tr)
+    assert abs(tr[0]["dt"] - dts[0]) <= 1e-12 * dts[0]
+    for name in ("S", "T", "W"):
+        r_o, hist_o, frms_o = tr_o[0][name]
+        g = tr[0][name]
+        assert len(g["history"]) == len(hist_o), (name, len(g["history"]), len(hist_o))
+        assert np.allclose(g["history"], hist_o, rtol=1e-10, atol=0), (name, g["history"], hist_o)
+        assert abs(g["f_rms"] - frms_o) <= 1e-12 * frms_o
+    assert len(tr[0]["T"]["history"]) == 50 and len(tr[0]["S"]["history"]) < 50 and len(tr[0]["W"]["history"]) < 50
+    for name, ref in (("T", T), ("W", W), ("S", S_o)):
+        got = getattr(out1, name)
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= 1e-10 * scale, (name, np.abs(got - ref).max(), scale)
+    tr = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = p2.navier_stokes_2D(opt=opt, verbose=False, max_steps=3, trace=tr)
+    assert out.steps == 3
+    assert tr[0]["dt"] == out1.dt_last                      # deterministic: the same first step again
+    assert len(tr[0]["T"]["history"]) == 50 and tr[0]["T"]["r_rms"] > opt.tol * tr[0]["T"]["f_rms"]   # @warn path
+    for rec in tr:
+        assert rec["dt"] > 0 and math.isfinite(rec["dt"])
+        assert rec["S"]["r_rms"] < opt.tol * rec["S"]["f_rms"] and rec["W"]["r_rms"] < opt.tol * rec["W"]["f_rms"]
+    for name in ("T", "W", "S"):
+        assert np.isfinite(getattr(out, name)).all(), name
+    # Dirichlet columns of T (part2_utils.jl:28-29) are re-imposed before every V-cycle and never touched by it
+    assert np.all(out.T[:, 0] == 1.0) and np.all(out.T[:, -1] == 0.0)
+    assert np.all(out.S[0, :] == 0.0) and np.all(out.S[:, 0] == 0.0)   # S keeps its zero boundary (x = 0 start)

@@ -45,6 +45,24 @@ def test_part1_bson_reference(oracle):
     assert np.all(err <= 1e-8)
 
 
+def test_part1_bson_reference_array_programming(oracle):
+    """test/part1.jl:24-26,37: the array-programming solver (part1_array_programming.jl:20-92, BASELINE config 1)
+    against the same BSON file, atol 1e-5."""
+    ref = part1_reference()
+    n = 32
+    dx = 10.0 / n
+    Ht = oracle.init_gaussian((n, n, n), dx, dx, dx, (5.0, 5.0, 5.0))
+    corner = Ht[0, 0, 14]
+    iters, err, dH = oracle.diffusion3d_array_solve(Ht, ttot=1.0, tol=1e-8)
+    inds = np.ceil(np.linspace(1, n, 12)).astype(int) - 1
+    d = np.abs(Ht[:, :, 14][np.ix_(inds, inds)] - ref["H"]).max()
+    assert d < 1e-5 and d < 2e-6, d
+    assert iters == [188, 187, 185, 184, 183] and np.all(err <= 1e-8)   # `while t < ttot` with t += 0.2: five steps
+    # in-place update of the interior only: the boundary keeps the Gaussian, like the file's corner sample
+    assert Ht[0, 0, 14] == corner and abs(corner - ref["H"][0, 0]) < 1e-30
+    assert dH.shape == (n - 2, n - 2, n - 2)
+
+
 def test_part1_split_equals_fused_at_fixed_iterations(oracle):
     """compute_flux!/compute_dHdtau!/update_H! (clean semantics of part1_array_programming.jl:9-18)
     vs the fused kernel (part1_kernel_programming.jl:46-58): same maths, different rounding."""

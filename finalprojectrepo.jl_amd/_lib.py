@@ -14,7 +14,8 @@ _LIB = None
 
 FPR_COARSE_JACOBI = 0
 FPR_COARSE_CG = 1
-ERRORS = {-1: "FPR_ERR_INVALID", -2: "FPR_ERR_HIP", -3: "FPR_ERR_NOT_POW2", -4: "FPR_ERR_ASSERT", -5: "FPR_ERR_NO_DEVICE"}
+ERRORS = {-1: "FPR_ERR_INVALID", -2: "FPR_ERR_HIP", -3: "FPR_ERR_NOT_POW2", -4: "FPR_ERR_ASSERT", -5: "FPR_ERR_NO_DEVICE",
+          -6: "FPR_ERR_RCCL"}
 
 
 class FprError(RuntimeError):
@@ -68,6 +69,16 @@ _SIG = {
     "fpr_init_gaussian3d": [_vp, _dp] + [_i] * 3 + [_d] * 6 + [_i] * 3,
     "fpr_halo_pack3d": [_vp, _dp, _i, _i, _i, _i, _dp, _i],
     "fpr_halo_unpack3d": [_vp, _dp, _i, _i, _i, _i, _dp, _i],
+    "fpr_comm_init": [_vp, _i, _i, _vp],
+    "fpr_comm_finalize": [_vp],
+    "fpr_grid_init": [_vp] + [_i] * 9 + [C.POINTER(_i)] * 4,
+    "fpr_grid_info": [_vp, C.POINTER(_i), C.POINTER(_i)],
+    "fpr_halo_exchange3d": [_vp, _dp, _i, _i, _i],
+    "fpr_halo_exchange3d_begin": [_vp, _dp, _i, _i, _i, _i],
+    "fpr_halo_exchange3d_end": [_vp, _dp, _i, _i, _i, _i],
+    "fpr_allreduce_sum_dev": [_vp, _dp, _i, _i],
+    "fpr_allreduce_sum1": [_vp, C.POINTER(_d)],
+    "fpr_gather3d": [_vp, _dp, _i, _i, _i, _vp],
     "fpr_residual2d": [_vp, _dp, _dp, _d, _d, _dp, _i, _i],
     "fpr_jacobi2d": [_vp, _dp, _dp, _d, _d, _dp, _i, _i, _d, C.POINTER(_d)],
     "fpr_restrict2d": [_vp, _dp, _dp, _i, _i, _i],
@@ -88,7 +99,8 @@ _SIG = {
     "fpr_compute_advection2d_y": [_vp, _dp, _d, _dp, _dp, _i, _i],
 }
 # every symbol include/fpr.h declares (checked by tests/test_abi.py)
-ALL_SYMBOLS = sorted(list(_SIG) + ["fpr_last_error", "fpr_version", "fpr_get_option", "fpr_last_coarse_iters"])
+ALL_SYMBOLS = sorted(list(_SIG) + ["fpr_last_error", "fpr_version", "fpr_get_option", "fpr_last_coarse_iters",
+                                   "fpr_comm_get_unique_id", "fpr_comm_rank", "fpr_comm_size"])
 
 
 def load_library():
@@ -115,6 +127,11 @@ def load_library():
     L.fpr_get_option.restype = _l
     L.fpr_last_coarse_iters.argtypes = [_vp]
     L.fpr_last_coarse_iters.restype = _l
+    L.fpr_comm_get_unique_id.argtypes = [_vp]
+    L.fpr_comm_get_unique_id.restype = _i
+    for name in ("fpr_comm_rank", "fpr_comm_size"):
+        getattr(L, name).argtypes = [_vp]
+        getattr(L, name).restype = _i
     _LIB = L
     return L
 
@@ -197,6 +214,7 @@ class Context:
         # scratch device scalars for fused norms
         self.scal = torch.zeros(16, dtype=torch.float64, device=torch.device("cuda", device))
         self._closed = False
+        self.comm_ready = False   # fpr_comm_init done (grid.rccl_bootstrap)
 
     def call(self, name, *args):
         rc = getattr(self.L, name)(self.h, *args)

@@ -42,6 +42,7 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
     hipSetDevice(ctx->device);
     for (int s = 0; s < 2; ++s)
         if (ctx->stream[s]) hipStreamSynchronize(ctx->stream[s]);
+    fpr_comm_finalize(ctx);
     for (auto& kv : ctx->arenas)
         for (auto& L : kv.second) {
             if (L.tmp) hipFree(L.tmp);

@@ -36,8 +36,21 @@ struct FprLevel {  // one multigrid level's scratch (role of prealloc_dict, mult
     double* corr_c = nullptr; // coarse correction = u of the next coarser level
 };
 
+struct FprGrid {  // implicit global grid of the decomposed diffusion path (role of ImplicitGlobalGrid's global state)
+    bool on = false;
+    int n[3] = {0, 0, 0};        // local array size, halos included
+    int dims[3] = {1, 1, 1}, coords[3] = {0, 0, 0}, periods[3] = {0, 0, 0};
+    int nb[6] = {-1, -1, -1, -1, -1, -1};   // neighbour rank per face (2*dim + side), -1 = none
+    double* sendbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // packed x / y planes
+    double* recvbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* stage = nullptr;     // gather!: one local array (rank 0)
+};
+
 struct fpr_ctx {
     int device = 0;
+    void* comm = nullptr;        // ncclComm_t (comm.hip); nullptr = single rank
+    int comm_rank = 0, comm_size = 1;
+    FprGrid grid;
     hipStream_t stream[2] = {nullptr, nullptr};  // 0 compute, 1 comm
     bool own_stream[2] = {false, false};
     hipEvent_t ev[2] = {nullptr, nullptr};

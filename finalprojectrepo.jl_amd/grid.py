@@ -2,8 +2,16 @@
 
 Role of ImplicitGlobalGrid.jl in the reference (init_global_grid / nx_g / x_g / update_halo! /
 finalize_global_grid; call sites scripts-part1/part1_kernel_programming.jl:100-101,117,182,187) and of
-MPI.Allreduce! in dist_norm_L2 (part1_utils.jl:38), rebuilt for one process per GPU with
-torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).
+MPI.Allreduce! in dist_norm_L2 (part1_utils.jl:38), rebuilt for one process per GPU.
+
+Two transports behind the same choreography:
+  "rccl"  the product path: the halo exchange and the all-reduce run INSIDE libfpr_hip.so (fpr_comm_init,
+          fpr_grid_init, fpr_halo_exchange3d[_begin/_end], fpr_allreduce_sum_dev -- RCCL over xGMI; csrc/comm.hip),
+          exactly what the Julia shim calls.  torch.distributed is used for ONE thing: broadcasting the 128-byte
+          RCCL unique id at start-up (any backend; bench.py uses gloo as its control plane).
+  "dist"  point-to-point through a torch.distributed-like object with the product's pack / unpack callbacks: gloo
+          on CPU (tests/test_grid_cpu.py, oracle kernels per shard) and an in-process fake for several emulated
+          ranks on one GPU (tests/test_gpu_halo.py).  Same faces, same planes, same order as csrc/comm.hip.
 
 Local arrays are nx*ny*nz including a 1-cell halo on every side that has a neighbour (overlap 2), so
 the global grid has dims*(n-2)+2 cells per dimension.  Per pseudo-iteration (GlobalGrid.step):
@@ -38,6 +46,10 @@ def dims_create(nprocs, ndims=3):
     return tuple(sorted(dims, reverse=True))
 
 
+ALLFACES = 63          # bit 2*dim + side
+ZFACES = 3 << 4
+
+
 class HaloExchanger:
     """update_halo!(A): exchange one plane per face with each Cartesian neighbour.
 
@@ -69,26 +81,30 @@ class HaloExchanger:
         # A has Julia shape (nx,ny,nz) with strides (1,nx,nx*ny): permute(2,1,0) is C-contiguous
         return A.permute(2, 1, 0)[k]
 
-    def pack_all(self, A):
+    def pack_all(self, A, mask=63):
         for face in self.faces():
-            if (face >> 1) != 2:
+            if (face >> 1) != 2 and (mask >> face) & 1:
                 self.pack(A, face, self.sendbuf[face])
 
-    def post(self, A):
-        """Post all sends/receives of already packed planes (z planes in place); returns work handles."""
+    def post(self, A, mask=63):
+        """Post all sends/receives of already packed planes (z planes in place); returns work handles.
+        Order as in csrc/comm.hip post_group: receives low side first, sends high side first, so that with the same
+        peer on both sides of a dimension (periodic, dims <= 2) the k-th send pairs with the peer's k-th receive."""
         nz = self.shape[2]
-        ops = []
         P2POp = self.dist.P2POp
-        for face in self.faces():
-            d, side = face >> 1, face & 1
-            peer = self.rank_of(self.neighbors[face])
-            if d == 2:
-                send_t = self._zplane(A, nz - 2 if side else 1)
-                recv_t = self._zplane(A, nz - 1 if side else 0)
-            else:
-                send_t, recv_t = self.sendbuf[face], self.recvbuf[face]
-            ops.append(P2POp(self.dist.isend, send_t, peer, group=self.group))
-            ops.append(P2POp(self.dist.irecv, recv_t, peer, group=self.group))
+        recvs, sends = [], []
+        for d in range(3):
+            for side in (0, 1):
+                face = 2 * d + side
+                if face in self.neighbors and (mask >> face) & 1:
+                    t = self._zplane(A, nz - 1 if side else 0) if d == 2 else self.recvbuf[face]
+                    recvs.append(P2POp(self.dist.irecv, t, self.rank_of(self.neighbors[face]), group=self.group))
+            for side in (1, 0):
+                face = 2 * d + side
+                if face in self.neighbors and (mask >> face) & 1:
+                    t = self._zplane(A, nz - 2 if side else 1) if d == 2 else self.sendbuf[face]
+                    sends.append(P2POp(self.dist.isend, t, self.rank_of(self.neighbors[face]), group=self.group))
+        ops = recvs + sends
         return self.dist.batch_isend_irecv(ops) if ops else []
 
     @staticmethod
@@ -96,9 +112,9 @@ class HaloExchanger:
         for w in works:
             w.wait()
 
-    def unpack_all(self, A):
+    def unpack_all(self, A, mask=63):
         for face in self.faces():
-            if (face >> 1) != 2:
+            if (face >> 1) != 2 and (mask >> face) & 1:
                 self.unpack(A, face, self.recvbuf[face])
 
     def update_halo_(self, A):
@@ -109,10 +125,100 @@ class HaloExchanger:
         self.unpack_all(A)
 
 
-class GlobalGrid:
-    """init_global_grid(nx, ny, nz): Cartesian process topology + implicit global grid."""
+class _DistTransport:
+    """Exchange through a torch.distributed-like P2P object (gloo on CPU, in-process fake for emulated ranks)."""
 
-    def __init__(self, nx, ny, nz, dims=None, group=None, use_dist=None):
+    def __init__(self, gg):
+        self.gg = gg
+
+    def begin(self, A, mask=63):
+        import torch
+        from . import ctx as _ctx
+
+        c = _ctx()
+        ex = self.gg.exchanger()
+        ex.pack_all(A, mask)                      # compute stream
+        c.comm.wait_stream(c.compute)
+        with torch.cuda.stream(c.comm):
+            return ex.post(A, mask)
+
+    def end(self, A, mask, works):
+        import torch
+        from . import ctx as _ctx
+
+        c = _ctx()
+        ex = self.gg.exchanger()
+        with torch.cuda.stream(c.comm):
+            ex.wait(works)
+        c.compute.wait_stream(c.comm)
+        ex.unpack_all(A, mask)
+
+    def update_halo_(self, A):
+        self.gg.exchanger().update_halo_(A)
+
+    def allreduce_(self, t):
+        gg = self.gg
+        if gg.dist is not None and gg.nprocs > 1:
+            gg.dist.all_reduce(t, op=gg.dist.ReduceOp.SUM, group=gg.group)
+
+
+class _RcclTransport:
+    """The product path: exchange and all-reduce inside libfpr_hip.so (csrc/comm.hip), RCCL over xGMI."""
+
+    def __init__(self, gg):
+        from . import ctx as _ctx
+        from ._lib import fptr
+
+        self.gg, self.c, self.fptr = gg, _ctx(), fptr
+        self.n = (gg.nx, gg.ny, gg.nz)
+
+    def begin(self, A, mask=63):
+        self.c.call("fpr_halo_exchange3d_begin", self.fptr(A, 3), *self.n, int(mask))
+        return None
+
+    def end(self, A, mask, token):
+        self.c.call("fpr_halo_exchange3d_end", self.fptr(A, 3), *self.n, int(mask))
+
+    def update_halo_(self, A):
+        self.c.call("fpr_halo_exchange3d", self.fptr(A, 3), *self.n)
+
+    def allreduce_(self, t):
+        self.c.call("fpr_allreduce_sum_dev", t.data_ptr(), t.numel(), 0)
+
+
+def rccl_bootstrap(ctx, rank, world, dist=None, group=None):
+    """fpr_comm_init on every rank: rank 0 draws the RCCL unique id, `dist` (torch.distributed, any backend)
+    carries its 128 bytes to the others -- the only thing torch.distributed does for the data path."""
+    import ctypes as C
+
+    if ctx.L.fpr_comm_size(ctx.h) == world and (world > 1 or ctx.comm_ready):
+        return
+    buf = C.create_string_buffer(128)
+    if rank == 0:
+        rc = ctx.L.fpr_comm_get_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError("fpr_comm_get_unique_id failed (%d)" % rc)
+    if world > 1:
+        if dist is None:
+            raise RuntimeError("several ranks need torch.distributed (any backend) to broadcast the RCCL unique id")
+        box = [buf.raw if rank == 0 else None]
+        src = 0 if group is None else dist.get_global_rank(group, 0)
+        dist.broadcast_object_list(box, src=src, group=group)
+        buf = C.create_string_buffer(box[0], 128)
+    ctx.call("fpr_comm_init", int(rank), int(world), buf)
+    ctx.comm_ready = True
+
+
+class GlobalGrid:
+    """init_global_grid(nx, ny, nz; dimx, dimy, dimz, periodx, periody, periodz): Cartesian process topology +
+    implicit global grid.  transport: "rccl" (library, the product path), "dist" (torch.distributed-like P2P object,
+    tests) or None = "rccl" when torch.distributed is initialised with several ranks and a GPU is visible."""
+
+    periods = (0, 0, 0)          # class defaults (a subclass may build the topology by hand)
+    transport_kind = "dist"
+    _tr = _ex = _sq_host = None
+
+    def __init__(self, nx, ny, nz, dims=None, group=None, use_dist=None, periods=(0, 0, 0), transport=None):
         self.nx, self.ny, self.nz = nx, ny, nz
         dist = None
         if use_dist is None or use_dist:
@@ -132,6 +238,7 @@ class GlobalGrid:
         if dims[0] * dims[1] * dims[2] != self.nprocs:
             raise ValueError("dims %s do not match %d processes" % (dims, self.nprocs))
         self.dims = dims
+        self.periods = tuple(int(bool(p)) for p in periods)
         self.coords = self.coords_of(self.me)
         self.neighbors = {}
         for d in range(3):
@@ -140,8 +247,49 @@ class GlobalGrid:
                 c[d] += 1 if side else -1
                 if 0 <= c[d] < dims[d]:
                     self.neighbors[2 * d + side] = tuple(c)
+                elif self.periods[d]:
+                    c[d] %= dims[d]
+                    self.neighbors[2 * d + side] = tuple(c)
+        if transport is None:
+            transport = "dist"
+            if self.neighbors and dist is not None:
+                try:
+                    import torch
+
+                    if torch.cuda.is_available():
+                        transport = "rccl"
+                except ImportError:
+                    pass
+        if transport not in ("rccl", "dist"):
+            raise ValueError("transport must be 'rccl' or 'dist'")
+        self.transport_kind = transport
+        self._tr = None
         self._ex = None
         self._sq_host = None
+        if transport == "rccl":
+            self._init_rccl()
+
+    def _init_rccl(self):
+        """fpr_comm_init + fpr_grid_init: the library learns the topology and owns the pack buffers."""
+        import ctypes as C
+        from . import ctx as _ctx
+
+        c = _ctx()
+        rccl_bootstrap(c, self.me, self.nprocs, self.dist, self.group)
+        me, npr = C.c_int(0), C.c_int(0)
+        dims_o, coords_o = (C.c_int * 3)(), (C.c_int * 3)()
+        c.call("fpr_grid_init", self.nx, self.ny, self.nz, *self.dims, *self.periods, C.byref(me), dims_o, C.byref(npr), coords_o)
+        ng, nb = (C.c_int * 3)(), (C.c_int * 6)()
+        c.call("fpr_grid_info", ng, nb)
+        # the library's topology must be the one this object computed (same Cartesian order, same neighbours)
+        assert (me.value, npr.value, tuple(dims_o), tuple(coords_o)) == (self.me, self.nprocs, self.dims, self.coords)
+        assert tuple(ng) == (self.nx_g(), self.ny_g(), self.nz_g())
+        assert {f: nb[f] for f in range(6) if nb[f] >= 0} == {f: self.rank_of(cc) for f, cc in self.neighbors.items()}
+
+    def transport(self):
+        if self._tr is None:
+            self._tr = _RcclTransport(self) if self.transport_kind == "rccl" else _DistTransport(self)
+        return self._tr
 
     # ---- topology (MPI Cartesian order: last dimension varies fastest) ----
     def coords_of(self, rank):
@@ -154,13 +302,13 @@ class GlobalGrid:
 
     # ---- implicit global grid ----
     def nx_g(self):
-        return self.dims[0] * (self.nx - 2) + 2
+        return self.dims[0] * (self.nx - 2) + (0 if self.periods[0] else 2)
 
     def ny_g(self):
-        return self.dims[1] * (self.ny - 2) + 2
+        return self.dims[1] * (self.ny - 2) + (0 if self.periods[1] else 2)
 
     def nz_g(self):
-        return self.dims[2] * (self.nz - 2) + 2
+        return self.dims[2] * (self.nz - 2) + (0 if self.periods[2] else 2)
 
     def x_g(self, ix, dx, dim=0):
         """Global coordinate of 1-based local index ix (size-n arrays)."""
@@ -174,9 +322,15 @@ class GlobalGrid:
     # ---- collectives ----
     def allreduce_sum(self, t):
         """MPI.Allreduce!(x, +, comm) of a 1-element tensor (part1_utils.jl:38); returns a float."""
-        if self.dist is not None and self.nprocs > 1:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        if self.nprocs > 1:
+            self.transport().allreduce_(t)
         return float(t[0].item()) if hasattr(t, "item") else float(t)
+
+    def allreduce_(self, t):
+        """In-place sum over all ranks of a small device tensor (several norms in one call); no host sync."""
+        if self.nprocs > 1:
+            self.transport().allreduce_(t)
+        return t
 
     def barrier(self):
         if self.dist is not None and self.nprocs > 1:
@@ -202,9 +356,9 @@ class GlobalGrid:
         return self._ex
 
     def update_halo_(self, A):
-        """update_halo!(A) -- blocking form."""
+        """update_halo!(A) (part1_kernel_programming.jl:182,187): ordered on the compute stream."""
         if self.neighbors:
-            self.exchanger().update_halo_(A)
+            self.transport().update_halo_(A)
 
     # ---- one pseudo-iteration (kernel + halo exchange + optional norm) ----
     def boundary_boxes(self):
@@ -274,11 +428,8 @@ class GlobalGrid:
     #           read from Hτ2 like a physical boundary) -> post the exchange of the new field's halo planes
     #   end   : fused launch on the upper half (overlaps that exchange); join
     def step2_begin(self, Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq2_dev):
-        import torch
-        from . import ctx as _ctx
         from . import part1
 
-        c = _ctx()
         nx, ny, nz = self.nx, self.ny, self.nz
         has_lo, has_hi = 4 in self.neighbors, 5 in self.neighbors
         coef = (dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
@@ -287,27 +438,21 @@ class GlobalGrid:
         for on, k in ((has_lo, 1), (has_hi, nz - 2)):
             if on:
                 part1.diffusion_3D_step_τ_box(Ht, Hτ, Hτ2, dHdτ, *coef, (1, 1, k), (nx - 1, ny - 1, k + 1), 0.0, None, 0)
-        ex = self.exchanger()
-        c.comm.wait_stream(c.compute)
-        with torch.cuda.stream(c.comm):
-            works = ex.post(Hτ2)
+        tr = self.transport()
+        works = tr.begin(Hτ2, ZFACES)
         zl, zh = (2 if has_lo else 1), (nz - 2 if has_hi else nz - 1)
         zmid = (zl + zh) // 2
         fused = (Ht, Hτ, Hτ2, Hout, dHdτ) + coef
         part1.diffusion_3D_step_τ2_box(*fused, (1, 1, zl), (nx - 1, ny - 1, zmid), norm_scale, sq2_dev, 0)
-        return dict(fused=fused, scale=norm_scale, sq=sq2_dev, works=works, z=(zmid, zh), lo=has_lo, hi=has_hi, out=Hout)
+        return dict(fused=fused, scale=norm_scale, sq=sq2_dev, works=works, z=(zmid, zh), lo=has_lo, hi=has_hi, out=Hout,
+                    mid=Hτ2)
 
     def step2_middle(self, st):
-        import torch
-        from . import ctx as _ctx
         from . import part1
 
-        c = _ctx()
         nx, ny, nz = self.nx, self.ny, self.nz
-        ex = self.exchanger()
-        with torch.cuda.stream(c.comm):
-            ex.wait(st["works"])
-        c.compute.wait_stream(c.comm)
+        tr = self.transport()
+        tr.end(st["mid"], ZFACES, st["works"])
         if st["lo"] and st["hi"]:   # both thin slabs in one launch
             part1.diffusion_3D_step_τ2_box(*st["fused"], (1, 1, 1), (nx - 1, ny - 1, 2), st["scale"], st["sq"], 0,
                                            z2=(nz - 2, nz - 1))
@@ -315,69 +460,69 @@ class GlobalGrid:
             for on, k in ((st["lo"], 1), (st["hi"], nz - 2)):
                 if on:
                     part1.diffusion_3D_step_τ2_box(*st["fused"], (1, 1, k), (nx - 1, ny - 1, k + 1), st["scale"], st["sq"], 0)
-        c.comm.wait_stream(c.compute)
-        with torch.cuda.stream(c.comm):
-            st["works"] = ex.post(st["out"])
+        st["works"] = tr.begin(st["out"], ZFACES)
 
     def step2_end(self, st):
-        import torch
-        from . import ctx as _ctx
         from . import part1
 
-        c = _ctx()
         nx, ny = self.nx, self.ny
         zmid, zh = st["z"]
         part1.diffusion_3D_step_τ2_box(*st["fused"], (1, 1, zmid), (nx - 1, ny - 1, zh), st["scale"], st["sq"], 0)
-        with torch.cuda.stream(c.comm):
-            self.exchanger().wait(st["works"])
-        c.compute.wait_stream(c.comm)
+        self.transport().end(st["out"], ZFACES, st["works"])
 
     def step_begin(self, Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq_dev):
-        """Multi-rank step, first half: boundary slabs, pack, post the exchange (comm stream)."""
-        import torch
-        from . import ctx as _ctx
+        """Multi-rank step, first half: boundary slabs, then the exchange of the freshly written planes is posted
+        (packs on the compute stream, transfers on the comm stream)."""
         from . import part1
 
-        c = _ctx()
         args = (Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
         boxes, inner = self.boundary_boxes()
         if sq_dev is not None:
             sq_dev.zero_()
         for lo, hi in boxes:  # 1. boundary slabs first
             part1.diffusion_3D_step_τ_box(*args, lo, hi, norm_scale, sq_dev, 0)
-        ex = self.exchanger()
-        # 2. exchange the freshly written planes: packs on the compute stream, transfers on the comm stream
-        ex.pack_all(Hτ2)
-        c.comm.wait_stream(c.compute)
-        with torch.cuda.stream(c.comm):
-            works = ex.post(Hτ2)
+        works = self.transport().begin(Hτ2, ALLFACES)   # 2.
         return (args, inner, norm_scale, sq_dev, works)
 
     def step_end(self, st):
         """Second half: interior update (overlaps the transfers), join, unpack the received halos."""
-        import torch
-        from . import ctx as _ctx
         from . import part1
 
-        c = _ctx()
         args, inner, norm_scale, sq_dev, works = st
-        ex = self.exchanger()
         # 3. interior update overlaps the exchange
         part1.diffusion_3D_step_τ_box(*args, inner[0], inner[1], norm_scale, sq_dev, 0)
         # 4. join: the compute stream waits for the transfers, then unpacks the x/y halos
-        with torch.cuda.stream(c.comm):
-            ex.wait(works)
-        c.compute.wait_stream(c.comm)
-        ex.unpack_all(args[2])
+        self.transport().end(args[2], ALLFACES, works)
 
     def gather_(self, A_host):
         """gather!(A, A_global) onto rank 0 (part1_kernel_programming.jl:223): returns the list of all
         ranks' local arrays (numpy) on rank 0, None elsewhere."""
-        if self.dist is None or self.nprocs == 1:
+        if self.nprocs == 1:
             return [A_host]
+        if self.dist is None:
+            raise RuntimeError("gather_ of host arrays needs torch.distributed; device arrays: gather_global_")
         out = [None] * self.nprocs if self.me == 0 else None
         self.dist.gather_object(A_host, out, dst=0, group=self.group)
         return out
+
+
+def gather_global_(gg, A):
+    """gather!(Array(A), A_global) through the library (fpr_gather3d): rank 0 gets the (nx*dims[0], ny*dims[1],
+    nz*dims[2]) host array with every rank's local array, halos included, as a block; the other ranks get None."""
+    import ctypes as C
+
+    import numpy as np
+    from . import ctx as _ctx
+    from ._lib import fptr
+
+    c = _ctx()
+    if gg.transport_kind != "rccl":
+        c.call("fpr_grid_init", gg.nx, gg.ny, gg.nz, 1, 1, 1, 0, 0, 0, None, None, None, None)
+    G = None
+    if gg.me == 0:
+        G = np.zeros((gg.nx * gg.dims[0], gg.ny * gg.dims[1], gg.nz * gg.dims[2]), order="F")
+    c.call("fpr_gather3d", fptr(A, 3), gg.nx, gg.ny, gg.nz, G.ctypes.data_as(C.c_void_p) if G is not None else None)
+    return G
 
 
 def assemble_global(parts, dims):
@@ -394,5 +539,11 @@ def assemble_global(parts, dims):
 
 
 def finalize_global_grid():
-    """finalize_global_grid(): nothing to release (torch.distributed is owned by the caller)."""
+    """finalize_global_grid(): releases the library's communicator and pack buffers (fpr_comm_finalize);
+    torch.distributed, if used for the bootstrap, is owned by the caller."""
+    from . import _default_ctx
+
+    if _default_ctx is not None and getattr(_default_ctx, "comm_ready", False):
+        _default_ctx.call("fpr_comm_finalize")
+        _default_ctx.comm_ready = False
     return None

@@ -36,7 +36,8 @@ enum {
     FPR_ERR_HIP = -2,       /* a HIP runtime call failed                                             */
     FPR_ERR_NOT_POW2 = -3,  /* reference: error("ERROR:not a power of 2")  multigrid.jl:95-97, :103   */
     FPR_ERR_ASSERT = -4,    /* reference: @assert on coarse_solve_size      multigrid.jl:45-46        */
-    FPR_ERR_NO_DEVICE = -5  /* no HIP device visible                                                 */
+    FPR_ERR_NO_DEVICE = -5, /* no HIP device visible                                                 */
+    FPR_ERR_RCCL = -6       /* an RCCL call failed (fpr_last_error carries ncclGetErrorString)       */
 };
 
 /* coarse solvers -- multigrid.jl:10-13 (CoarseSolver_t) */
@@ -170,6 +171,56 @@ int fpr_halo_pack3d(fpr_ctx* ctx, const double* A, int nx, int ny, int nz, int f
 int fpr_halo_unpack3d(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face, const double* buf, int stream_sel);
 /* order stream `waiter` behind everything enqueued so far on stream `signaller` (0 compute, 1 comm) */
 int fpr_stream_wait(fpr_ctx* ctx, int waiter, int signaller);
+
+/* ---- process / device boundary of the decomposed diffusion path: RCCL over xGMI, one process per GPU ------
+ * Replaces ImplicitGlobalGrid + MPI in the reference:
+ *   init_global_grid / finalize_global_grid     part1_kernel_programming.jl:100-101,225; part1_array_programming.jl:28-29,89
+ *   nx_g() ny_g() nz_g(), x_g y_g z_g            part1_kernel_programming.jl:117; part1_utils.jl:5-7
+ *   update_halo!(A)                              part1_kernel_programming.jl:182,187; part1_array_programming.jl:67
+ *   MPI.Allreduce!(sq_residual, +, comm_cart)    part1_utils.jl:38
+ *   gather!(Array(Ht), H_g)                      part1_kernel_programming.jl:223; part1_array_programming.jl:87
+ * Bootstrap: rank 0 calls fpr_comm_get_unique_id and the host language broadcasts the FPR_UNIQUE_ID_BYTES bytes by
+ * whatever it has (MPI.Bcast in Julia, a torch.distributed store in Python); every rank then calls fpr_comm_init
+ * on a context created on ITS device (select_device() = fpr_ctx_create(device = local rank)). */
+#define FPR_UNIQUE_ID_BYTES 128
+int fpr_comm_get_unique_id(void* id_out /* FPR_UNIQUE_ID_BYTES */);
+int fpr_comm_init(fpr_ctx* ctx, int rank, int nranks, const void* unique_id);
+int fpr_comm_finalize(fpr_ctx* ctx);   /* finalize_global_grid(); also done by fpr_ctx_destroy */
+int fpr_comm_rank(fpr_ctx* ctx);
+int fpr_comm_size(fpr_ctx* ctx);
+
+/* init_global_grid(nx, ny, nz; dimx, dimy, dimz, periodx, periody, periodz) -> me, dims, nprocs, coords.
+ * dim* = 0 lets the library factorise (MPI.Dims_create order: 2 -> (2,1,1), 4 -> (2,2,1), 8 -> (2,2,2), the table of
+ * part1_scaling_experiments.jl:35-41).  Local arrays are nx*ny*nz including one halo cell on every side that has a
+ * neighbour (overlap 2).  Ranks in MPI Cartesian order (last dimension fastest).  Works without a communicator
+ * for the single-rank, non-periodic grid.  Out-pointers may be NULL; dims_out / coords_out: 3 ints. */
+int fpr_grid_init(fpr_ctx* ctx, int nx, int ny, int nz, int dimx, int dimy, int dimz, int periodx, int periody,
+                  int periodz, int* me_out, int* dims_out, int* nprocs_out, int* coords_out);
+/* n_g_out[3] = nx_g(), ny_g(), nz_g() = dims*(n-2)+2 (dims*(n-2) in a periodic dimension); neighbors_out[6] = rank
+ * beyond face 2*dim+side, or -1.  x_g(ix, dx, A) = (coords[0]*(nx-2) + ix-1)*dx follows from coords (host side). */
+int fpr_grid_info(fpr_ctx* ctx, int* n_g_out, int* neighbors_out);
+
+/* update_halo!(A): every halo plane of A that has a neighbour receives the neighbour's adjacent interior plane
+ * (and vice versa), dimension by dimension as ImplicitGlobalGrid does, so edge / corner halo cells are consistent.
+ * Enqueued on the context's streams (x / y planes: pack kernel -> ncclSend/ncclRecv -> unpack kernel; z planes in
+ * place); the caller's next kernel on the compute stream is ordered behind it.  No host synchronisation. */
+int fpr_halo_exchange3d(fpr_ctx* ctx, double* A, int nx, int ny, int nz);
+/* Split form for overlap (role of @hide_communication (8,8,8), part1_kernel_programming.jl:185-188): begin packs on
+ * the compute stream and posts ONE group of sends / receives on the comm stream; end makes the compute stream wait
+ * for them and unpacks.  Kernels enqueued in between overlap the transfers.  face_mask: bit 2*dim+side (63 = all
+ * faces).  All faces travel at once: edge / corner halo cells are not refreshed (a 7-point stencil reads none). */
+int fpr_halo_exchange3d_begin(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face_mask);
+int fpr_halo_exchange3d_end(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face_mask);
+
+/* MPI.Allreduce!(x, +, comm_cart) -- part1_utils.jl:38.  _dev: `count` device doubles in place on stream
+ * stream_sel, no host sync (norms of several iterations can be reduced in one call).  _sum1: the reference's form,
+ * one host double in / out, synchronises the compute stream.  Both are no-ops on a single rank. */
+int fpr_allreduce_sum_dev(fpr_ctx* ctx, double* x_dev, int count, int stream_sel);
+int fpr_allreduce_sum1(fpr_ctx* ctx, double* x_host_inout);
+
+/* gather!(A, A_global): the local arrays, halos included, side by side in Cartesian order in the HOST array
+ * A_global (nx*dims[0], ny*dims[1], nz*dims[2]) of rank 0 (NULL on the other ranks).  Synchronises. */
+int fpr_gather3d(fpr_ctx* ctx, const double* A, int nx, int ny, int nz, double* A_global_host);
 
 /* ---- Part 2: 2D geometric multigrid for (lap - c) u = f ------------------------------------------ */
 

@@ -22,6 +22,7 @@
 module FPRHip
 
 using AMDGPU
+import MPI      # bootstrap only: broadcast of the 128-byte RCCL unique id and the node-local rank (init_global_grid)
 
 export @init_parallel_stencil, @reset_parallel_stencil, @parallel, @zeros, @ones, @rand, @synchronize,
        @hide_communication, Data,
@@ -34,7 +35,9 @@ export @init_parallel_stencil, @reset_parallel_stencil, @parallel, @zeros, @ones
        ExecutionPolicy_t, serial, parallel, parallel_shmem, preallocate_buffers,
        apply_boundary_conditions!, apply_boundary_conditions_dirichlet!, apply_boundary_conditions_neumann!,
        compute_velocity!, compute_Ra_dTdx!, compute_diffusion2d!, compute_advection2d_x!, compute_advection2d_y!,
-       halo_pack!, halo_unpack!, fpr_version
+       halo_pack!, halo_unpack!, fpr_version,
+       init_global_grid, finalize_global_grid, select_device, update_halo!, gather!, nx_g, ny_g, nz_g, x_g, y_g, z_g,
+       halo_exchange_begin!, halo_exchange_end!, allreduce_sum!, diffusion_3D_array_programming
 
 const libfpr = get(ENV, "FPR_HIP_LIB", joinpath(@__DIR__, "..", "finalprojectrepo.jl_amd", "lib", "libfpr_hip.so"))
 
@@ -61,12 +64,34 @@ end
 
 ctx() = (CTX[] == C_NULL && init_context(); CTX[])
 
+const COMM_STREAM = Ref{Any}(nothing)   # keeps the second HIPStream alive for the lifetime of the context
+
+raw_stream(s) = reinterpret(Ptr{Cvoid}, s.stream)   # AMDGPU.HIPStream -> hipStream_t
+
+"""
+Create the library context on `device` (0-based).  The COMPUTE stream handed to the library is AMDGPU.jl's current
+task stream, so the broadcasts and reductions the reference's host code runs between kernels (`Ht .= Hτ`,
+`u_f .= u_f - corr_f`, `sum(rhs.^2)`, `residual_H*dt`, `@zeros` fills) and the library's kernels are ordered on ONE
+stream; the comm stream is a second HIPStream owned by this module.  Call from the task that runs the solver.
+"""
 function init_context(device::Integer = AMDGPU.device_id(AMDGPU.device()) - 1)
+    destroy_context()
+    AMDGPU.device!(AMDGPU.devices()[device + 1])
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    # NULL streams: the library creates its own compute / comm streams on `device`
-    rc = ccall((:fpr_ctx_create, libfpr), Cint, (Ptr{Ptr{Cvoid}}, Cint, Ptr{Cvoid}, Ptr{Cvoid}), h, device, C_NULL, C_NULL)
+    COMM_STREAM[] = AMDGPU.HIPStream(:high)
+    rc = ccall((:fpr_ctx_create, libfpr), Cint, (Ptr{Ptr{Cvoid}}, Cint, Ptr{Cvoid}, Ptr{Cvoid}), h, device,
+               raw_stream(AMDGPU.stream()), raw_stream(COMM_STREAM[]))
     rc == 0 || throw(FPRError(rc, "fpr_ctx_create failed (no HIP device? there is no CPU fallback)"))
     CTX[] = h[]
+    return nothing
+end
+
+function destroy_context()
+    if CTX[] != C_NULL
+        ccall((:fpr_ctx_destroy, libfpr), Cint, (Ptr{Cvoid},), CTX[])
+        CTX[] = C_NULL
+        GRID[] = nothing
+    end
     return nothing
 end
 
@@ -87,12 +112,7 @@ macro init_parallel_stencil(args...)
     :(FPRHip.init_context())
 end
 macro reset_parallel_stencil()
-    quote
-        if FPRHip.CTX[] != C_NULL
-            ccall((:fpr_ctx_destroy, FPRHip.libfpr), Cint, (Ptr{Cvoid},), FPRHip.CTX[])
-            FPRHip.CTX[] = C_NULL
-        end
-    end
+    :(FPRHip.destroy_context())
 end
 "`@parallel [blocks threads shmem=n] f(args...)` -> `f(args...)` (launch geometry is the library's)."
 macro parallel(args...)
@@ -111,8 +131,12 @@ end
 macro rand(dims...)
     esc(:(AMDGPU.rand(Float64, $(dims...))))
 end
+"`@synchronize()`: the library's two streams (the compute stream IS AMDGPU.jl's task stream) and AMDGPU.jl itself."
 macro synchronize()
-    :(FPRHip.check(ccall((:fpr_synchronize, FPRHip.libfpr), Cint, (Ptr{Cvoid},), FPRHip.ctx())))
+    quote
+        FPRHip.check(ccall((:fpr_synchronize, FPRHip.libfpr), Cint, (Ptr{Cvoid},), FPRHip.ctx()))
+        FPRHip.AMDGPU.synchronize()
+    end
 end
 
 const DA = ROCArray{Float64}
@@ -253,11 +277,20 @@ function absmax(x::DA)
     check(ccall((:fpr_absmax, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Csize_t, Ptr{Cdouble}), ctx(), p(x), length(x), out))
     return out[]
 end
+"MPI.Allreduce!(x, +, comm_cart) of one host Float64 (part1_utils.jl:38) over RCCL; identity on a single rank."
+function allreduce_sum1(x::Float64)
+    r = Ref{Cdouble}(x)
+    check(ccall((:fpr_allreduce_sum1, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), ctx(), r))
+    return r[]
+end
+"In-place sum over all ranks of a small device vector (e.g. the norms of several iterations); no host sync."
+allreduce_sum!(x::DA; stream_sel = 0) =
+    check(ccall((:fpr_allreduce_sum_dev, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint), ctx(), p(x), length(x), stream_sel))
 "part1_utils.jl:36-40 with the scale of its call site folded in: dist_norm_L2(residual_H*dt, comm) == dist_norm_L2(residual_H, comm; scale=dt)."
 function dist_norm_L2(Rh::DA, comm_cart; scale = 1.0)
-    sq = [sumsq_scaled(Rh, scale)]
-    comm_cart === nothing || MPI.Allreduce!(sq, +, comm_cart)     # `import MPI` stays in the host script
-    return sqrt(sq[1])
+    sq = sumsq_scaled(Rh, scale)                                  # part1_utils.jl:37
+    comm_cart === nothing || (sq = allreduce_sum1(sq))            # part1_utils.jl:38
+    return sqrt(sq)
 end
 copy_device!(dst::DA, src::DA) = check(ccall((:fpr_copy, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Csize_t), ctx(), p(dst), p(src), length(dst)))
 fill_device!(dst::DA, v) = check(ccall((:fpr_fill, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Csize_t), ctx(), p(dst), v, length(dst)))
@@ -273,6 +306,134 @@ halo_pack!(buf::DA, A::DA, face; stream_sel = 0) = (n = size(A);
     check(ccall((:fpr_halo_pack3d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint, Cint, Ptr{Cdouble}, Cint), ctx(), p(A), n[1], n[2], n[3], face, p(buf), stream_sel)))
 halo_unpack!(A::DA, buf::DA, face; stream_sel = 0) = (n = size(A);
     check(ccall((:fpr_halo_unpack3d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint, Cint, Ptr{Cdouble}, Cint), ctx(), p(A), n[1], n[2], n[3], face, p(buf), stream_sel)))
+
+# ---- ImplicitGlobalGrid surface (part1_kernel_programming.jl:100-101,117,121,182,187,223,225) over RCCL ----
+# One process per GPU.  MPI.jl is used for two bootstrap steps only (node-local rank, broadcast of the RCCL unique
+# id); every byte of the data path (halo planes, the norm's all-reduce, gather!) travels through the library.
+const GRID = Ref{Any}(nothing)   # (me, dims, nprocs, coords, n = (nx,ny,nz), periods, comm)
+grid() = (GRID[] === nothing && error("init_global_grid has not been called"); GRID[])
+
+"`select_device()`: bind this rank to GPU (node-local rank mod device count); returns the 0-based device id."
+function select_device()
+    loc = MPI.Comm_split_type(MPI.COMM_WORLD, MPI.COMM_TYPE_SHARED, MPI.Comm_rank(MPI.COMM_WORLD))
+    dev = MPI.Comm_rank(loc) % length(AMDGPU.devices())
+    if CTX[] == C_NULL || AMDGPU.device_id(AMDGPU.device()) - 1 != dev
+        GRID[] === nothing || error("select_device() after init_global_grid must not change the device")
+        init_context(dev)
+    end
+    return dev
+end
+
+"""
+`init_global_grid(nx, ny, nz; dimx, dimy, dimz, periodx, periody, periodz, init_MPI, quiet)` ->
+`(me, dims, nprocs, coords, comm_cart)` as ImplicitGlobalGrid returns them.  Unlike IGG the device is bound HERE
+(the RCCL communicator belongs to a device), so the `select_device()` call that follows in the reference's solvers
+(part1_kernel_programming.jl:121) finds the device already selected.
+"""
+function init_global_grid(nx::Integer, ny::Integer, nz::Integer; dimx = 0, dimy = 0, dimz = 0, periodx = 0, periody = 0,
+                          periodz = 0, init_MPI = true, quiet = false, kwargs...)
+    init_MPI && !MPI.Initialized() && MPI.Init()
+    comm = MPI.COMM_WORLD
+    me, np = MPI.Comm_rank(comm), MPI.Comm_size(comm)
+    select_device()
+    id = zeros(UInt8, 128)                                       # FPR_UNIQUE_ID_BYTES
+    me == 0 && (ccall((:fpr_comm_get_unique_id, libfpr), Cint, (Ptr{UInt8},), id) == 0 || error("fpr_comm_get_unique_id failed"))
+    MPI.Bcast!(id, 0, comm)
+    if ccall((:fpr_comm_size, libfpr), Cint, (Ptr{Cvoid},), ctx()) != np || ccall((:fpr_comm_rank, libfpr), Cint, (Ptr{Cvoid},), ctx()) != me || np > 1
+        check(ccall((:fpr_comm_finalize, libfpr), Cint, (Ptr{Cvoid},), ctx()))
+        check(ccall((:fpr_comm_init, libfpr), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), ctx(), me, np, id))
+    end
+    me_o = Ref{Cint}(0); np_o = Ref{Cint}(0); dims = zeros(Cint, 3); coords = zeros(Cint, 3)
+    check(ccall((:fpr_grid_init, libfpr), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}),
+                ctx(), nx, ny, nz, dimx, dimy, dimz, periodx, periody, periodz, me_o, dims, np_o, coords))
+    GRID[] = (me = Int(me_o[]), dims = Int.(dims), nprocs = Int(np_o[]), coords = Int.(coords), n = (Int(nx), Int(ny), Int(nz)),
+              periods = (periodx, periody, periodz), comm = comm)
+    quiet || me != 0 || println("Global grid: $(nx_g())x$(ny_g())x$(nz_g()) (nprocs: $np, dims: $(dims[1])x$(dims[2])x$(dims[3]))")
+    return GRID[].me, GRID[].dims, GRID[].nprocs, GRID[].coords, comm
+end
+
+"`finalize_global_grid(; finalize_MPI)`: releases the RCCL communicator and the library's pack buffers."
+function finalize_global_grid(; finalize_MPI = true)
+    CTX[] == C_NULL || check(ccall((:fpr_comm_finalize, libfpr), Cint, (Ptr{Cvoid},), CTX[]))
+    GRID[] = nothing
+    finalize_MPI && MPI.Initialized() && !MPI.Finalized() && MPI.Finalize()
+    return nothing
+end
+
+function grid_sizes_g()
+    ng = zeros(Cint, 3); nb = zeros(Cint, 6)
+    check(ccall((:fpr_grid_info, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}), ctx(), ng, nb))
+    return Int.(ng), Int.(nb)
+end
+nx_g() = grid_sizes_g()[1][1]      # dims[1]*(nx-2)+2  (part1_kernel_programming.jl:117)
+ny_g() = grid_sizes_g()[1][2]
+nz_g() = grid_sizes_g()[1][3]
+"Global coordinate of local index `i` (1-based) in dimension `d` of array `A` (ImplicitGlobalGrid's x_g/y_g/z_g; part1_utils.jl:5-7)."
+function coord_g(d::Int, i::Integer, dd::Real, A)
+    g = grid(); n = g.n[d]
+    x0 = 0.5 * (n - size(A, d)) * dd                       # staggered arrays sit half a cell in
+    return (g.coords[d] * (n - 2) + (i - 1)) * dd + x0
+end
+x_g(ix::Integer, dx::Real, A) = coord_g(1, ix, dx, A)
+y_g(iy::Integer, dy::Real, A) = coord_g(2, iy, dy, A)
+z_g(iz::Integer, dz::Real, A) = coord_g(3, iz, dz, A)
+
+"`update_halo!(A...)` (part1_kernel_programming.jl:182,187): ordered on the compute stream, no host synchronisation."
+function update_halo!(As::DA...)
+    for A in As
+        n = size(A)
+        check(ccall((:fpr_halo_exchange3d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint), ctx(), p(A), n[1], n[2], n[3]))
+    end
+    return nothing
+end
+"Split form: kernels launched between begin and end overlap the transfers (role of `@hide_communication`)."
+halo_exchange_begin!(A::DA; faces = 63) = (n = size(A);
+    check(ccall((:fpr_halo_exchange3d_begin, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint, Cint), ctx(), p(A), n[1], n[2], n[3], faces)))
+halo_exchange_end!(A::DA; faces = 63) = (n = size(A);
+    check(ccall((:fpr_halo_exchange3d_end, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint, Cint), ctx(), p(A), n[1], n[2], n[3], faces)))
+
+"`gather!(A, A_global)` (part1_kernel_programming.jl:223): A_global (host, rank 0; `nothing` elsewhere) receives all local arrays."
+function gather!(A::DA, A_global::Union{Array{Float64,3},Nothing})
+    n = size(A)
+    check(ccall((:fpr_gather3d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint, Ptr{Cdouble}), ctx(), p(A), n[1], n[2], n[3],
+                A_global === nothing ? Ptr{Cdouble}(C_NULL) : pointer(A_global)))
+    return nothing
+end
+gather!(A::Array{Float64,3}, A_global) = gather!(ROCArray(A), grid().me == 0 ? A_global : nothing)   # the reference passes Array(Ht)
+
+"part1_array_programming.jl:20-92 on the split kernels (BASELINE config 1); returns (X_g, H_g) like the reference."
+function diffusion_3D_array_programming(; nx, ny, nz, do_vis = false, verbose = true, init_and_finalize_MPI = !isinteractive())
+    lx, ly, lz = 10.0, 10.0, 10.0; D = 1.0; ttot = 1.0
+    me, dims, _nprocs, coords, comm_cart = init_global_grid(nx, ny, nz; init_MPI = init_and_finalize_MPI, quiet = !verbose)
+    dx, dy, dz = lx / nx_g(), ly / ny_g(), lz / nz_g()
+    select_device()
+    total_N = prod(dims) * nx * ny * nz
+    dt = 0.2; dτ = min(dx, dy, dz)^2 / D / 8.1; tol = 1e-8; iter_max = 1e5
+    qx = AMDGPU.zeros(Float64, nx - 1, ny - 2, nz - 2); qy = AMDGPU.zeros(Float64, nx - 2, ny - 1, nz - 2)
+    qz = AMDGPU.zeros(Float64, nx - 2, ny - 2, nz - 1)
+    Ht = AMDGPU.zeros(Float64, nx, ny, nz)
+    init_local_gaussian_device!(Ht, [lx / 2, ly / 2, lz / 2], dx, dy, dz, coords)
+    Hτ = copy(Ht); dHdt = AMDGPU.zeros(Float64, nx - 2, ny - 2, nz - 2)
+    H_g = me == 0 ? zeros(nx * dims[1], ny * dims[2], nz * dims[3]) : nothing
+    t = 0.0
+    while t < ttot
+        iter_inner = 0; err = 2 * tol
+        while err > tol && iter_inner < iter_max
+            diffusion_3D_step_τ!(Ht, Hτ, dHdt, dt, dτ, qx, qy, qz, dx, dy, dz, D)
+            update_halo!(Hτ)
+            err = dist_norm_L2(dHdt, comm_cart; scale = dt) / sqrt(total_N)
+            iter_inner += 1
+        end
+        verbose && me == 0 && println(err <= tol ? "Converged after $iter_inner iterations." : "Couldn't converge within $iter_max iterations.")
+        t += dt
+        copy_device!(Ht, Hτ)
+    end
+    X_g = LinRange(0 + dx / 2, lx - dx / 2, nx * dims[1])
+    gather!(Ht, H_g)
+    finalize_global_grid(; finalize_MPI = init_and_finalize_MPI)
+    return X_g, H_g
+end
 
 # ---- Part 2 (scripts-part2/multigrid.jl, krylov.jl, part2_utils.jl) -----------------------------------
 @enum ExecutionPolicy_t serial parallel parallel_shmem          # part2_utils.jl:4-8

@@ -1,0 +1,137 @@
+"""The RCCL transport of libfpr_hip.so (csrc/comm.hip) on ONE GPU: a single rank that is its own neighbour through
+periodic boundaries, so every plane really travels through ncclSend / ncclRecv on the comm stream (RCCL refuses two
+ranks on one device, and a box has one GPU; N > 1 runs only in the driver's scaling bench).  Checks update_halo!
+semantics (dimension by dimension, corners consistent), the split begin / end form, the all-reduce, gather!, and
+the step / fused-pair choreographies of GlobalGrid over this transport against the oracle with wrapped halos."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from fixtures_io import splitmix64_uniform
+from oracle.oracle import asf, farr
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(shape, seed):
+    return asf(splitmix64_uniform(int(np.prod(shape)), seed).reshape(shape, order="F"))
+
+
+def wrap(A, dims=(0, 1, 2)):
+    """Periodic halo update of a single rank, dimension by dimension (what update_halo! does there)."""
+    for d in dims:
+        lo, hi = [slice(None)] * 3, [slice(None)] * 3
+        src_hi, src_lo = [slice(None)] * 3, [slice(None)] * 3
+        lo[d], hi[d], src_hi[d], src_lo[d] = 0, -1, -2, 1
+        A[tuple(lo)] = A[tuple(src_hi)]
+        A[tuple(hi)] = A[tuple(src_lo)]
+    return A
+
+
+@pytest.fixture()
+def periodic_grid(fpr):
+    grids = []
+
+    def make(n, periods):
+        gg = fpr.grid.GlobalGrid(*n, dims=(1, 1, 1), periods=periods, transport="rccl", use_dist=False)
+        grids.append(gg)
+        return gg
+
+    yield make
+    fpr.grid.finalize_global_grid()
+
+
+@pytest.mark.parametrize("n", [(10, 9, 8), (64, 5, 7), (33, 34, 35)], ids=str)
+def test_update_halo_self_neighbour(fpr, periodic_grid, n):
+    F = fpr
+    gg = periodic_grid(n, (1, 1, 1))
+    assert sorted(gg.neighbors) == [0, 1, 2, 3, 4, 5] and gg.nx_g() == n[0] - 2
+    c = F.ctx()
+    assert c.L.fpr_comm_size(c.h) == 1 and c.L.fpr_comm_rank(c.h) == 0
+    A = rnd(n, 3)
+    gA = F.asdevice(A)
+    gg.update_halo_(gA)
+    assert np.array_equal(F.tonumpy(gA), wrap(A.copy(order="F")))   # corners / edges included
+    # split form, z faces only: x / y halos stay, z planes wrap (in place, no pack buffers)
+    B = rnd(n, 4)
+    gB = F.asdevice(B)
+    tr = gg.transport()
+    tok = tr.begin(gB, F.grid.ZFACES)
+    tr.end(gB, F.grid.ZFACES, tok)
+    assert np.array_equal(F.tonumpy(gB), wrap(B.copy(order="F"), dims=(2,)))
+    # all faces at once: face interiors as a wrap of the ORIGINAL array (edges / corners are not refreshed)
+    D = rnd(n, 5)
+    gD = F.asdevice(D)
+    tok = tr.begin(gD, F.grid.ALLFACES)
+    tr.end(gD, F.grid.ALLFACES, tok)
+    got = F.tonumpy(gD)
+    for d in range(3):
+        idx = [slice(1, -1)] * 3
+        src = [slice(1, -1)] * 3
+        idx[d], src[d] = 0, -2
+        assert np.array_equal(got[tuple(idx)], D[tuple(src)])
+        idx[d], src[d] = -1, 1
+        assert np.array_equal(got[tuple(idx)], D[tuple(src)])
+    assert np.array_equal(got[1:-1, 1:-1, 1:-1], D[1:-1, 1:-1, 1:-1])
+
+
+def test_allreduce_and_gather_single_rank(fpr, periodic_grid):
+    F = fpr
+    n = (12, 10, 9)
+    gg = periodic_grid(n, (0, 0, 1))
+    c = F.ctx()
+    t = F.asdevice(np.array([1.5, -2.25, 3.0]))
+    c.call("fpr_allreduce_sum_dev", t.data_ptr(), 3, 0)      # a real ncclAllReduce on a 1-rank communicator
+    assert t.cpu().tolist() == [1.5, -2.25, 3.0]
+    x = C.c_double(0.625)
+    c.call("fpr_allreduce_sum1", C.byref(x))
+    assert x.value == 0.625
+    A = rnd(n, 9)
+    G = F.grid.gather_global_(gg, F.asdevice(A))
+    assert G.shape == n and np.array_equal(G, A)
+
+
+@pytest.mark.parametrize("n", [(20, 12, 10), (128, 24, 16)], ids=str)
+def test_step_and_fused_pair_over_rccl_periodic_z(fpr, oracle, periodic_grid, n):
+    """GlobalGrid.step / step2 with the library's transport: periodic z on one rank = the oracle's step followed by a
+    wrap of the z halo planes of the NEW buffer.  Fields, residuals and norms bit-exact / 1e-13."""
+    F = fpr
+    gg = periodic_grid(n, (0, 0, 1))
+    nx, ny, nz = n
+    dx, dy, dz = 10.0 / nx, 10.0 / ny, 10.0 / (nz - 2)
+    D, dt = 1.0, 0.2
+    dτ = min(dx, dy, dz) ** 2 / D / 8.1
+    coef = (dτ, 1 / dt, 1 / dx, 1 / dy, 1 / dz, D / dx, D / dy, D / dz)
+    Ht = wrap(rnd(n, 11), dims=(2,))
+    A, B, R = Ht.copy(order="F"), farr(*n), farr(*n)
+    gHt, gA, gB, gR = F.asdevice(Ht), F.asdevice(A), F.fzeros(*n), F.fzeros(*n)
+    sq = F.fzeros(1)
+    for it in range(4):
+        oracle.diffusion3d_step(Ht, A, B, R, *coef)
+        wrap(B, dims=(2,))
+        A, B = B, A
+        gg.step(gHt, gA, gB, gR, *coef, dt, sq)
+        gA, gB = gB, gA
+        ref = oracle.sumsq_scaled(R, dt)
+        assert abs(float(sq.item()) - ref) <= 1e-13 * ref
+    assert np.array_equal(F.tonumpy(gA), A) and np.array_equal(F.tonumpy(gR), R)
+    gC = gA.clone()
+    if not gg.can_step2(gHt, gA, gB, gC, gR):
+        assert nx < 128
+        return
+    # fused pairs: B plays the reference's second buffer (its z halo planes receive level 1), C carries A's boundary
+    sq2 = F.fzeros(2)
+    for it in range(3):
+        refs = []
+        for k in range(2):
+            oracle.diffusion3d_step(Ht, A, B, R, *coef)
+            wrap(B, dims=(2,))
+            A, B = B, A
+            refs.append(oracle.sumsq_scaled(R, dt))
+        gg.step2(gHt, gA, gB, gC, gR, *coef, dt, sq2)
+        gA, gC = gC, gA
+        got = sq2.cpu().tolist()
+        assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs))
+        assert np.array_equal(F.tonumpy(gA)[1:-1, 1:-1, :], A[1:-1, 1:-1, :])
+        assert np.array_equal(F.tonumpy(gR), R)

@@ -4,18 +4,26 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one pseudo-transient iteration of the 3D diffusion hot path on a 512^3 local grid per
-GPU (BASELINE.json configs[1] / configs[3]): fused 7-point update + fused convergence norm, plus, for
-N > 1, the RCCL halo exchange overlapped with the interior update and the all-reduce of the norm.
-Consecutive iterations run in pairs as ONE fused launch (temporal blocking, bit-identical to two single
-launches; --no-fuse2 times the one-iteration-per-launch path); every iteration's norm is still computed.
-Metric: effective memory throughput A_eff = 32 B per interior cell per iteration, summed
-over all GPUs.  Prints ONE JSON line on rank 0.
+With --gpus N > 1 and no RANK in the environment the script starts its N ranks ITSELF (one child process per GPU,
+before anything touches a GPU); under torch.distributed.run it uses the ranks it is given.
+
+One "step" = one pseudo-transient iteration of the 3D diffusion hot path on a 512^3 local grid per GPU
+(BASELINE.json configs[1] / configs[3]): fused 7-point update + fused convergence norm, plus, for N > 1, the RCCL
+halo exchange (inside libfpr_hip.so, overlapped with the interior update on a second stream) and the all-reduce of
+the norm.  Consecutive iterations run in pairs as ONE launch (temporal blocking, bit-identical to two single
+launches); every iteration's norm is still computed.  A second, separately reported leg times the
+one-iteration-per-launch kernel.
+
+Metric (`value`): effective memory throughput A_eff = 32 B per interior cell per ITERATION, summed over
+all GPUs.  `roofline` is physical: bytes one launch has to move at the very least / its measured duration (<= 1 of
+peak by construction); the per-iteration (effective) figure is reported beside it.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,14 +32,52 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 A_EFF_BYTES = 32.0     # read Htau + read Ht + write Htau2 + write dHdtau, per interior cell
+KT_STEP, KT_STEP2, KT_MG_PRE, KT_MG_POST = 0, 1, 2, 3   # include/fpr.h FPR_KT_*
 
 
-def cpu_baseline(n, budget_s=12.0):
-    """C restatement of the reference CPU path (oracle/, kind 'port') timed on the host cores:
-    a bounded sample of the same workload -- pseudo-iterations of the fused update + the unfused norm
-    pass (as the reference does, part1_kernel_programming.jl:181-191) on an n^3 grid."""
-    import numpy as np
+# ------------------------------------------------------------------------------------------------------------
+# launcher: one process per GPU (role of `mpiexecjl -np N` in run_all_benchmarks.sh:21-28)
+# ------------------------------------------------------------------------------------------------------------
+def self_launch(n):
+    """Start n ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), wait for them and
+    exit with the first non-zero exit code.  Runs before torch or HIP is imported: nothing here touches a GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FPR_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between processes)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        alive = list(procs)
+        while alive:
+            for p in list(alive):
+                r = p.poll()
+                if r is None:
+                    continue
+                alive.remove(p)
+                if r != 0 and rc == 0:
+                    rc = r
+                    for q in alive:      # a failed rank would leave the others waiting in a collective
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
 
+
+# ------------------------------------------------------------------------------------------------------------
+# CPU baselines (oracle/, kind "port"): rank 0, N = 1 only, bounded samples
+# ------------------------------------------------------------------------------------------------------------
+def cpu_baseline_diffusion(n, budget_s=10.0):
+    """C restatement of the reference CPU path timed on the host cores: pseudo-iterations of the fused update + the
+    unfused norm pass (as the reference does, part1_kernel_programming.jl:181-191) on an n^3 grid."""
     threads = min(os.cpu_count() or 1, 16)
     os.environ["OMP_NUM_THREADS"] = str(threads)
     from oracle.oracle import Oracle, farr
@@ -64,51 +110,142 @@ def cpu_baseline(n, budget_s=12.0):
     }
 
 
-def vcycle_secondary(F, steps=3):
-    """Secondary metric: MGsolve / V-cycle wall time at 4097^2 (multigrid_bench.jl protocol)."""
+def cpu_baseline_vcycle(n, b_host):
+    """One V-cycle of the oracle's MGsolve (multigrid_bench.jl:27-42 protocol: x = 0, b ~ U[0,1), c = 0, l = 2, Jacobi
+    coarse solver) at n^2 on the host cores."""
     import numpy as np
 
+    threads = min(os.cpu_count() or 1, 16)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    from oracle.oracle import Oracle, farr
+
+    orc = Oracle(openmp=True)
+    x = farr(n, n)
+    orc.mgsolve2d(x, b_host, 1.0 / (n - 1), 0.0, 1e-6, 1)   # warm-up / page touch (one V-cycle)
+    ts = []
+    for _ in range(3):
+        x[:] = 0.0
+        t0 = time.time()
+        orc.mgsolve2d(x, b_host, 1.0 / (n - 1), 0.0, 1e-6, 1)
+        ts.append(time.time() - t0)
+    t = sorted(ts)[1]
+    return {"value": t, "unit": "s", "cores": threads, "kind": "port",
+            "sample": "one V-cycle (MGsolve with niters = 1: rms(f) + V-cycle) of the C port at %d^2, l = 2, Jacobi coarse "
+                      "solver, OpenMP %d threads, median of 3" % (n, threads)}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# second half of the metric: V-cycle wall time at 4097^2 (+ the NS step around it)
+# ------------------------------------------------------------------------------------------------------------
+def timer_read(ctx, kind):
+    import ctypes as C
+
+    tot, cnt = C.c_double(0.0), C.c_long(0)
+    ctx.call("fpr_kernel_timer_read", int(kind), C.byref(tot), C.byref(cnt))
+    return tot.value, cnt.value
+
+
+def vcycle_block(F, with_cpu=True, steps=5):
+    """MGsolve / V-cycle wall time at 4097^2 (multigrid_bench.jl protocol) with the roofline of its
+    dominant kernels and the CPU baseline beside it."""
+    import warnings
+
     mg = F.multigrid
+    ctx = F.ctx()
     n = 4097
     h = 1.0 / (n - 1)
-    b = F.asdevice(F.part2.splitmix64_uniform(n * n, 1).reshape((n, n), order="F"))
+    b_host = F.part2.splitmix64_uniform(n * n, 1).reshape((n, n), order="F")
+    b = F.asdevice(b_host)
     x = F.fzeros(n, n)
     out = {}
+    kern = {}
     for label, css, solver in (("l2_jacobi", 5, mg.jacobi), ("l8_cg", 257, mg.conjugate_gradient),
                                ("l8_jacobi", 257, mg.jacobi)):
         opt = mg.MGOpt()
         opt.coarse_solve_size, opt.coarse_solver = css, solver
         ts = []
         ncyc = 0
-        for i in range(steps if label != "l8_jacobi" else 1):
+        reps = steps if label == "l2_jacobi" else (3 if label == "l8_cg" else 1)
+        for i in range(reps + 1):
             x.zero_()
             F.synchronize()
-            t0 = time.time()
-            import warnings
+            timed_kernels = label == "l2_jacobi" and i == reps   # last repetition: events around the finest passes
+            if timed_kernels:
+                ctx.call("fpr_kernel_timer", 1)
+            t0 = time.perf_counter()
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, b, h, 0.0, 1e-6, 100, False, opt=opt, return_history=True)
             F.synchronize()
-            ts.append(time.time() - t0)
+            if i > 0 or reps == 0:
+                ts.append(time.perf_counter() - t0)
             ncyc = len(hist)
+            if timed_kernels:
+                for name, kind in (("pre", KT_MG_PRE), ("post", KT_MG_POST)):
+                    ms, cnt = timer_read(ctx, kind)
+                    kern[name] = (ms / max(cnt, 1), cnt)
+                ctx.call("fpr_kernel_timer", 0)
         t = sorted(ts)[len(ts) // 2]
         out[label] = {"mgsolve_s": t, "vcycles": ncyc, "s_per_vcycle": t / max(ncyc, 1), "coarse_iters": int(cit),
                       "rel_residual": r / frms}
-    # BASELINE config 5: Navier-Stokes step around the V-cycle at 2049^2 (buoyancy-driven convection --
-    # the reference has no lid-driven cavity), semi-implicit beta=0.5, tol 1e-7, 3 MG solves per step
-    try:
-        p2 = F.part2
-        opt = p2.SimIn_t()
-        opt.nx = opt.ny = 2049
-        opt.beta, opt.tol, opt.Pr, opt.ttot = 0.5, 1.0e-7, 1.0, 1.0e9
-        res = p2.navier_stokes_2D(opt=opt, verbose=False, max_steps=7)
-        out["ns_semi_implicit_2049sq"] = {"s_per_step": res.t_elapsed / max(res.timed_iters, 1), "timed_steps": res.timed_iters,
-                                          "note": "beta=0.5, Pr=1, Ra=1e6, tol=1e-7, niters=50; T solve hits niters as in the reference"}
-    except Exception as e:
-        out["ns_semi_implicit_2049sq"] = {"error": repr(e)}
-    return out
+    # --- byte accounting of one l = 2 V-cycle (11 grids): SURVEY 8d / DESIGN 4.2 ---
+    pts = sum((2 ** k + 1) ** 2 for k in range(3, 13))            # smoothing levels k = 12 .. 3 (l = 2 is solved)
+    acct_bytes = 132.0 * pts                                      # one pass per operation: 2.955 GB
+    phys_bytes = 54.0 * pts                                       # two passes per level: 28 B/pt + 26 B/pt
+    spv = out["l2_jacobi"]["s_per_vcycle"]
+    N2 = float(n * n)
+    pre_ms, pre_cnt = kern.get("pre", (0.0, 0))
+    post_ms, post_cnt = kern.get("post", (0.0, 0))
+    pre_bytes, post_bytes = 28.0 * N2, 26.0 * N2
+    dom = ("post", post_ms, post_bytes) if post_ms >= pre_ms else ("pre", pre_ms, pre_bytes)
+    gbs = lambda byts, ms: byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    roof = {
+        "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "kernel": "k_smooth2_march<NORM,PROLONG> (finest level: prolongation + correction + 2 sweeps + norm)" if dom[0] == "post"
+                  else "k_smooth2_march<RESTRICT> (finest level: 2 sweeps + residual + injection)",
+        "achieved": gbs(dom[2], dom[1]), "frac": gbs(dom[2], dom[1]) / HBM_PEAK_GBS, "traffic": None,
+        "kernel_ms": dom[1], "bytes_per_launch": dom[2],
+        "kernels": {"finest_pre_pass": {"ms": pre_ms, "launches": pre_cnt, "bytes": pre_bytes, "GBs": gbs(pre_bytes, pre_ms),
+                                        "accounting": "read u, f; write u'' + res_c, corr_c (1/4 each): 28 B/pt"},
+                    "finest_post_pass": {"ms": post_ms, "launches": post_cnt, "bytes": post_bytes, "GBs": gbs(post_bytes, post_ms),
+                                         "accounting": "read u, f, corr_c (1/4); write u'': 26 B/pt"}},
+        "vcycle_physical_bytes": phys_bytes, "vcycle_physical_GBs": phys_bytes / spv / 1e9,
+        "vcycle_physical_frac": phys_bytes / spv / 1e9 / HBM_PEAK_GBS,
+        "vcycle_accounting_bytes": acct_bytes, "vcycle_effective_GBs": acct_bytes / spv / 1e9,
+        "vcycle_effective_frac": acct_bytes / spv / 1e9 / HBM_PEAK_GBS,
+        "note": "frac: the dominant kernel's compulsory bytes / its hipEvent duration; vcycle_physical_*: the bytes a whole "
+                "V-cycle of this implementation must move (54 B/pt/level) / wall time per V-cycle (includes the "
+                "launch-latency-bound coarse levels); vcycle_effective_*: SURVEY 8d's one-pass-per-operation accounting "
+                "(132 B/pt/level = 2.955 GB) / the same time -- above what moves because two sweeps share a pass",
+    }
+    block = {"metric": "vcycle_wall_time_4097sq", "value": spv, "unit": "s", "higher_is_better": False, "dtype": "f64",
+             "config": {"workload": "2D Poisson V-cycle 4097^2, 2+2 Jacobi smooths, 11 grids (l=2), Jacobi coarse solver; "
+                                    "multigrid_bench.jl protocol (x=0, b~U[0,1), c=0, tol 1e-6)",
+                        "mgsolve_s": out["l2_jacobi"]["mgsolve_s"], "vcycles": out["l2_jacobi"]["vcycles"]},
+             "roofline": roof,
+             "variants": {"five_levels_l8_cg": out["l8_cg"], "five_levels_l8_jacobi": out["l8_jacobi"]}}
+    if with_cpu:
+        try:
+            block["cpu_baseline"] = cpu_baseline_vcycle(n, b_host)
+        except Exception as e:
+            block["cpu_baseline"] = {"value": None, "unit": "s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    return block
 
 
+def ns_block(F):
+    """BASELINE config 5: Navier-Stokes step around the V-cycle at 2049^2 (buoyancy-driven convection -- the reference
+    has no lid-driven cavity), semi-implicit beta = 0.5, tol 1e-7, 3 MG solves per step."""
+    p2 = F.part2
+    opt = p2.SimIn_t()
+    opt.nx = opt.ny = 2049
+    opt.beta, opt.tol, opt.Pr, opt.ttot = 0.5, 1.0e-7, 1.0, 1.0e9
+    res = p2.navier_stokes_2D(opt=opt, verbose=False, max_steps=7)
+    return {"metric": "ns_semi_implicit_step_2049sq", "value": res.t_elapsed / max(res.timed_iters, 1), "unit": "s",
+            "timed_steps": res.timed_iters,
+            "note": "beta=0.5, Pr=1, Ra=1e6, tol=1e-7, niters=50; the first T solve hits niters as in the reference"}
+
+
+# ------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,10 +256,16 @@ def main():
     ap.add_argument("--check-every", type=int, default=16, help="host convergence check every n iterations")
     ap.add_argument("--prewarm-ms", type=float, default=300.0, help="untimed pre-warm before the W warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the V-cycle / NS blocks")
+    ap.add_argument("--no-single-leg", action="store_true", help="skip the one-iteration-per-launch leg")
     ap.add_argument("--variant", type=str, default="", help="k=v,... diffusion kernel options (diff3_*)")
-    ap.add_argument("--no-fuse2", action="store_true", help="one iteration per launch (k_diff3_march) instead of fused pairs")
+    ap.add_argument("--no-fuse2", action="store_true", help="main leg with one iteration per launch (k_diff3_march)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / control-plane rehearsal on CPU (gloo): no GPU, no compute, one JSON line")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args.gpus)   # never returns
 
     import torch
     import torch.distributed as dist
@@ -130,13 +273,33 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # launched by torch.distributed.run
+    use_dist = "RANK" in os.environ and world > 1
     if use_dist:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # control plane only (RCCL unique id, barriers, max over ranks): gloo on the host.  The data path -- halo planes
+        # and the norm's all-reduce -- is RCCL inside libfpr_hip.so.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
 
+    if args.dry_run:
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        seen = torch.ones(1, dtype=torch.float64)
+        if use_dist:
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(seen)
+        if rank == 0:
+            print(json.dumps({"metric": "diffusion3d_effective_memory_throughput", "value": None, "unit": "GB/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                              "ranks_seen": int(seen.item()), "max_over_ranks": float(t.item()),
+                              "self_launched": os.environ.get("FPR_BENCH_SELF_LAUNCHED") == "1",
+                              "control_plane": "gloo" if use_dist else "none"}))
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    torch.cuda.set_device(local_rank)
     import fpr_amd
 
     F = fpr_amd.load(local_rank)
@@ -147,7 +310,8 @@ def main():
 
     n = args.n
     dims = tuple(int(x) for x in args.dims.split(",")) if args.dims else (1, 1, world)
-    gg = F.grid.GlobalGrid(n, n, n, dims=dims)
+    gg = F.grid.GlobalGrid(n, n, n, dims=dims, transport="rccl" if world > 1 else None)
+    rccl_ranks = ctx.L.fpr_comm_size(ctx.h)
     # physics as diffusion_3D_kernel_programming with scale_physical_size=true (weak scaling keeps dx fixed)
     lx, ly, lz = (d * 10.0 for d in dims)
     dx, dy, dz = lx / gg.nx_g(), ly / gg.ny_g(), lz / gg.nz_g()
@@ -162,17 +326,15 @@ def main():
     # third work buffer for the fused pairs: carries Hτ's boundary; the field alternates between Hτ and Hτ3 while
     # Hτ2 keeps playing the reference's second buffer (its boundary cells / halo planes are all that is read)
     Hτ3 = Hτ.clone(memory_format=torch.preserve_format)
-    fuse2 = (not args.no_fuse2) and gg.can_step2(Ht, Hτ, Hτ2, Hτ3, res)
-    if not fuse2:
-        del Hτ3
+    can_fuse2 = gg.can_step2(Ht, Hτ, Hτ2, Hτ3, res)
     K, W, ce = args.steps, args.warmup, max(1, args.check_every)
-    sq = torch.zeros(K + W + ce, dtype=torch.float64, device=Ht.device)
-    errs = []
+    sq = torch.zeros(2 * (K + W + ce) + 64, dtype=torch.float64, device=Ht.device)
     sqrtN = math.sqrt(world * n ** 3)
 
     # field state: `cur` is the buffer holding the current field; parity 0 = an "even" buffer (Hτ or Hτ3, the
     # reference's first work buffer and its stand-in), parity 1 = Hτ2.  Fused pairs run even -> even.
     state = {"cur": Hτ, "parity": 0}
+    errs = []
 
     def one_step(sq1):
         if state["parity"] == 0:
@@ -182,7 +344,7 @@ def main():
             gg.step(Ht, Hτ2, Hτ, res, *coef, dt, sq1)
             state["cur"], state["parity"] = Hτ, 0
 
-    def run(nsteps, base):
+    def run(nsteps, base, fuse2):
         i = 0
         while i < nsteps:
             prev = i
@@ -194,56 +356,91 @@ def main():
             else:
                 one_step(sq[base + i:base + i + 1])
                 i += 1
-            if i // ce > prev // ce or i == nsteps:  # convergence check: all-reduce the chunk, host reads it
+            if i // ce > prev // ce or i == nsteps:  # convergence check: all-reduce the chunk (RCCL), host reads it
                 chunk = sq[base + (prev // ce) * ce:base + i]
-                if use_dist:
-                    dist.all_reduce(chunk)
+                gg.allreduce_(chunk)
                 errs.append(math.sqrt(float(chunk[-1].item())) / sqrtN)
 
-    # untimed pre-warm (clock ramp, RCCL channel set-up), then the W warm-up steps of the contract
-    tpre = time.perf_counter()
-    while time.perf_counter() - tpre < args.prewarm_ms * 1e-3:
-        run(8, 0)
+    def barrier():
         torch.cuda.synchronize()
-    errs.clear()
-    run(W, 0)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ctx.call("fpr_kernel_timer", 1)
-    t0 = time.perf_counter()
-    run(K, W)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    import ctypes as C
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    ktot, kcnt = C.c_double(0.0), C.c_long(0)
-    ctx.call("fpr_kernel_timer_read", C.byref(ktot), C.byref(kcnt))
-    ctx.call("fpr_kernel_timer", 0)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=Ht.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_leg(fuse2, prewarm_ms):
+        """W (+1 if needed to start from an even state) untimed warm-up steps, then EXACTLY K timed steps between
+        barriers; returns max-over-ranks wall time and the per-kernel event times of the timed region."""
+        tpre = time.perf_counter()
+        while time.perf_counter() - tpre < prewarm_ms * 1e-3:   # clock ramp, RCCL channel set-up
+            run(8, 0, fuse2)
+            torch.cuda.synchronize()
+        run(W, 0, fuse2)
+        extra = 0
+        if fuse2 and state["parity"] == 1:     # every timed launch of the fused leg must be the fused kernel
+            run(1, W, False)
+            extra = 1
+        errs.clear()
+        barrier()
+        ctx.call("fpr_kernel_timer", 1)
+        t0 = time.perf_counter()
+        run(K, W + extra, fuse2)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kt = {kind: timer_read(ctx, kind) for kind in (KT_STEP, KT_STEP2)}
+        ctx.call("fpr_kernel_timer", 0)
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, kt, extra
 
     cells = (n - 2) ** 3
+    min_bytes = A_EFF_BYTES * cells     # what ONE launch must move at the very least, however many iterations it fuses
+
+    def kernel_roofline(kind, kt, traffic_entry):
+        ms_tot, cnt = kt[kind]
+        kms = ms_tot / cnt if cnt else 0.0
+        ipl = 2 if kind == KT_STEP2 else 1
+        ach = min_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "kernel": "k_diff3_march2 (two iterations per launch)" if kind == KT_STEP2 else "k_diff3_march (one iteration per launch)",
+             "achieved": ach, "frac": ach / HBM_PEAK_GBS, "kernel_ms": kms, "launches": cnt,
+             "bytes_per_launch": min_bytes, "iterations_per_launch": ipl,
+             "accounting": "32 B per interior cell per LAUNCH: read Htau, read Ht, write the new field, write dHdtau (the "
+                           "field between two fused iterations never leaves the chip)",
+             "effective_achieved": ach * ipl, "effective_frac": ach * ipl / HBM_PEAK_GBS,
+             "effective_accounting": "SURVEY 8d: 32 B per interior cell per ITERATION x iterations per launch",
+             "traffic": None, "traffic_source": None}
+        if traffic_entry:
+            r["traffic"] = traffic_entry["traffic_bytes_per_launch"]
+            r["traffic_source"] = traffic_entry.get("source")
+            r["achieved_traffic"] = r["traffic"] / (kms * 1e-3) / 1e9 if kms > 0 else None
+        return r
+
+    def traffic_for(fused):
+        """HBM-side bytes per launch from rocprofv3 --pmc passes of this very command (FETCH_SIZE x2 gfx950 correction +
+        WRITE_SIZE, collected in separate passes -- tools/pmc_fused2.sh); recorded under profiles/, not measured live."""
+        try:
+            for tj in json.load(open(os.path.join(ROOT, "profiles", "diffusion_traffic.json")))["entries"]:
+                if tj.get("n") == n and world == 1 and tj.get("fuse2") == bool(fused):
+                    return tj
+        except Exception:
+            pass
+        return None
+
+    main_fused = can_fuse2 and not args.no_fuse2
+    elapsed, kt, extra = timed_leg(main_fused, args.prewarm_ms)
+    last_err = errs[-1] if errs else None
     value = A_EFF_BYTES * cells * world * K / elapsed / 1e9
-    # dominant kernel: HIP events around every diffusion-kernel launch of the timed region (fpr_kernel_timer), on the
-    # library's compute stream.  At N = 1 each launch is one k_diff3_march2 (two iterations) / k_diff3_march (one).
-    launches = max(1, kcnt.value)
-    its_per_launch = K / launches
-    kernel_ms = ktot.value / launches                     # average launch duration
-    alg_bytes_launch = A_EFF_BYTES * cells * its_per_launch   # SURVEY 8d per-unit figure x units one launch processes
-    achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic = None
-    try:  # HBM-side bytes per launch from the rocprofv3 PMC passes committed under profiles/ (same command)
-        for tj in json.load(open(os.path.join(ROOT, "profiles", "diffusion_traffic.json")))["entries"]:
-            if tj.get("n") == n and world == 1 and tj.get("fuse2") == bool(fuse2):
-                traffic = tj["traffic_bytes_per_launch"]
-    except Exception:
-        traffic = None
+    main_kind = KT_STEP2 if main_fused else KT_STEP
+    roofline = kernel_roofline(main_kind, kt, traffic_for(main_fused))
+    other_kind = KT_STEP if main_fused else KT_STEP2
+    if kt[other_kind][1]:
+        roofline["other_launches_in_timed_region"] = {"kind": other_kind, "launches": kt[other_kind][1],
+                                                      "ms_total": kt[other_kind][0]}
+    legs = {"fused_pairs" if main_fused else "single_steps":
+            {"ms_per_step": elapsed / K * 1e3, "value_GBs": value, "kernel_ms": roofline["kernel_ms"],
+             "launches": roofline["launches"], "warmup_extra_steps": extra}}
     out = {
         "metric": "diffusion3d_effective_memory_throughput",
         "value": value,
@@ -258,43 +455,53 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "3D pseudo-transient diffusion, %d^3 cells per GPU, fused 7-pt update + fused norm%s"
-                               % (n, ", two iterations per launch (temporal blocking)" if fuse2 else ""),
+                               % (n, ", two iterations per launch (temporal blocking)" if main_fused else ""),
                    "local_grid": [n, n, n], "process_grid": list(dims), "global_grid": [gg.nx_g(), gg.ny_g(), gg.nz_g()],
-                   "bytes_per_cell": A_EFF_BYTES, "norm": "fused every iteration; all-reduce + host check every %d" % ce,
-                   "halo": "RCCL isend/irecv on comm stream overlapped with interior update" if world > 1 else "none (1 rank)",
-                   "pct_of_hbm_peak_per_gpu": 100.0 * value / world / HBM_PEAK_GBS,
-                   "last_err": errs[-1] if errs else None},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "k_diff3_march2" if fuse2 else "k_diff3_march", "kernel_ms": kernel_ms,
-                     "launches": launches, "iterations_per_launch": its_per_launch,
-                     "algorithmic_bytes_per_launch": alg_bytes_launch,
-                     # what one launch has to move at the very least (read Htau, Ht; write the new field, dHdtau
-                     # ONCE, however many iterations it fuses) and the rate against that figure: with two iterations
-                     # per launch `frac` can exceed 1 -- the intermediate field never travels to HBM
-                     "min_bytes_per_launch": A_EFF_BYTES * cells,
-                     "achieved_min_bytes": A_EFF_BYTES * cells / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
-                     "achieved_traffic": traffic / (kernel_ms * 1e-3) / 1e9 if (traffic and kernel_ms > 0) else None},
+                   "bytes_per_cell_per_iteration": A_EFF_BYTES,
+                   "norm": "fused every iteration; all-reduce + host check every %d" % ce,
+                   "halo": ("RCCL ncclSend/ncclRecv groups inside libfpr_hip.so on the comm stream, overlapped with the "
+                            "interior update") if world > 1 else "none (1 rank)",
+                   "rccl_ranks": rccl_ranks, "control_plane": "gloo" if use_dist else "none",
+                   "self_launched": os.environ.get("FPR_BENCH_SELF_LAUNCHED") == "1",
+                   "pct_of_hbm_peak_effective_per_gpu": 100.0 * value / world / HBM_PEAK_GBS,
+                   "pct_of_hbm_peak_physical_dominant_kernel": 100.0 * roofline["frac"],
+                   "last_err": last_err},
+        "roofline": roofline,
+        "legs": legs,
     }
+    # second leg: the one-iteration-per-launch kernel (north_star's ">= 60 % of HBM peak on the inner update" in
+    # the one-pass accounting), with its own event timer; not part of `value`
+    if world == 1 and main_fused and not args.no_single_leg:
+        state["cur"], state["parity"] = Hτ, 0
+        Hτ.copy_(Ht)
+        e2, kt2, _ = timed_leg(False, 50.0)
+        r2 = kernel_roofline(KT_STEP, kt2, traffic_for(False))
+        out["roofline_single"] = r2
+        legs["single_steps"] = {"ms_per_step": e2 / K * 1e3, "value_GBs": A_EFF_BYTES * cells * K / e2 / 1e9,
+                                "kernel_ms": r2["kernel_ms"], "launches": r2["launches"]}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(n)
+                out["cpu_baseline"] = cpu_baseline_diffusion(n)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         if not args.no_secondary and world == 1:
             state.clear()
-            del Ht, Hτ, Hτ2, res
-            if fuse2:
-                del Hτ3
+            del Ht, Hτ, Hτ2, res, Hτ3
             torch.cuda.empty_cache()
             try:
-                out["secondary"] = {"metric": "mgsolve_wall_time_4097sq", "unit": "s", "results": vcycle_secondary(F)}
+                out["vcycle"] = vcycle_block(F, with_cpu=not args.no_cpu_baseline)
             except Exception as e:
-                out["secondary"] = {"error": repr(e)}
+                out["vcycle"] = {"error": repr(e)}
+            try:
+                out["ns_step"] = ns_block(F)
+            except Exception as e:
+                out["ns_step"] = {"error": repr(e)}
         print(json.dumps(out))
+        sys.stdout.flush()
     if use_dist:
         dist.barrier()
+        F.grid.finalize_global_grid()
         dist.destroy_process_group()
 
 

@@ -46,7 +46,7 @@ _SIG = {
     "fpr_set_option": [_vp, C.c_char_p, _l],
     "fpr_stream_wait": [_vp, _i, _i],
     "fpr_kernel_timer": [_vp, _i],
-    "fpr_kernel_timer_read": [_vp, C.POINTER(_d), C.POINTER(_l)],
+    "fpr_kernel_timer_read": [_vp, _i, C.POINTER(_d), C.POINTER(_l)],
     "fpr_diffusion3d_step": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8,
     "fpr_diffusion3d_step_norm": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8 + [_d, _dp],
     "fpr_diffusion3d_step_norm_host": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8 + [_d, C.POINTER(_d)],

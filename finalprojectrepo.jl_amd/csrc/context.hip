@@ -94,6 +94,7 @@ extern "C" int fpr_kernel_timer(fpr_ctx* ctx, int enable)
     if (!ctx) return FPR_ERR_INVALID;
     if (enable && ctx->ktimer_ev.empty()) {
         ctx->ktimer_ev.resize(2 * 8192);
+        ctx->ktimer_kind.assign(8192, -1);
         for (auto& e : ctx->ktimer_ev) FPR_HIP(ctx, hipEventCreate(&e));
     }
     ctx->ktimer_on = enable != 0;
@@ -101,19 +102,22 @@ extern "C" int fpr_kernel_timer(fpr_ctx* ctx, int enable)
     return FPR_OK;
 }
 
-extern "C" int fpr_kernel_timer_read(fpr_ctx* ctx, double* total_ms_host, long* count_host)
+extern "C" int fpr_kernel_timer_read(fpr_ctx* ctx, int kind, double* total_ms_host, long* count_host)
 {
     if (!ctx || !total_ms_host || !count_host) return FPR_ERR_INVALID;
     FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
     FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));
     double tot = 0.0;
+    long cnt = 0;
     for (size_t i = 0; i + 1 < ctx->ktimer_used; i += 2) {
+        if (kind >= 0 && ctx->ktimer_kind[i / 2] != kind) continue;
         float ms = 0.f;
         FPR_HIP(ctx, hipEventElapsedTime(&ms, ctx->ktimer_ev[i], ctx->ktimer_ev[i + 1]));
         tot += ms;
+        ++cnt;
     }
     *total_ms_host = tot;
-    *count_host = (long)(ctx->ktimer_used / 2);
+    *count_host = cnt;
     return FPR_OK;
 }
 

@@ -41,13 +41,9 @@ static int diff3_run(fpr_ctx* ctx, const double* Ht, const double* Htau, double*
         t.ry = (int)fpr_opt(ctx, "diff3_ry", 0);
         t.nt = (int)fpr_opt(ctx, "diff3_nt", -1);
         t.vx = (int)fpr_opt(ctx, "diff3_vx", 0);
-        const bool timed = ctx->ktimer_on && ctx->ktimer_used + 2 <= ctx->ktimer_ev.size();
-        if (timed) FPR_HIP(ctx, hipEventRecord(ctx->ktimer_ev[ctx->ktimer_used], ctx->stream[stream_sel]));
+        const bool timed = fpr_ktimer_begin(ctx, FPR_KT_DIFF3_STEP, ctx->stream[stream_sel]);
         hipError_t e = diff3_launch(a, norm, t, ctx->stream[stream_sel], FPR_MAX_PARTIALS, &nparts);
-        if (timed) {
-            FPR_HIP(ctx, hipEventRecord(ctx->ktimer_ev[ctx->ktimer_used + 1], ctx->stream[stream_sel]));
-            ctx->ktimer_used += 2;
-        }
+        fpr_ktimer_end(ctx, timed, ctx->stream[stream_sel]);
         if (e != hipSuccess) return fpr_fail(ctx, FPR_ERR_HIP, "diffusion3d launch: %s", hipGetErrorString(e));
     }
     if (norm) {
@@ -134,20 +130,16 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
     const bool empty = a.lo[0] >= a.hi[0] || a.lo[1] >= a.hi[1] || a.lo[2] >= a.hi[2];
     int nparts = 0;
     if (!empty) {
-        const bool timed = ctx->ktimer_on && ctx->ktimer_used + 2 <= ctx->ktimer_ev.size();
-        if (timed) FPR_HIP(ctx, hipEventRecord(ctx->ktimer_ev[ctx->ktimer_used], ctx->stream[stream_sel]));
         if (ctx->ncu <= 0) {
             int v = 0;
             ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
         }
+        const bool timed = fpr_ktimer_begin(ctx, FPR_KT_DIFF3_STEP2, ctx->stream[stream_sel]);
         hipError_t e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), (int)fpr_opt(ctx, "diff3_xcd2", 0) & 3,   // (higher bits are harness-only ablation switches)
                                      ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2, &nparts,
                                      (int)fpr_opt(ctx, "diff3_nw2", 0), ctx->ncu, zlo2 < 1 ? 1 : zlo2,
                                      zhi2 > nz - 1 ? nz - 1 : zhi2);
-        if (timed) {
-            FPR_HIP(ctx, hipEventRecord(ctx->ktimer_ev[ctx->ktimer_used + 1], ctx->stream[stream_sel]));
-            ctx->ktimer_used += 2;
-        }
+        fpr_ktimer_end(ctx, timed, ctx->stream[stream_sel]);
         if (e != hipSuccess) return fpr_fail(ctx, FPR_ERR_HIP, "fused diffusion3d launch: %s", hipGetErrorString(e));
     }
     if (norm) {

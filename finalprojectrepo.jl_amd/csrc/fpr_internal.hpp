@@ -72,6 +72,7 @@ struct fpr_ctx {
     bool top_is_coarsest = false;      // ... and the whole problem was the coarsest level
     bool ktimer_on = false;            // fpr_kernel_timer
     std::vector<hipEvent_t> ktimer_ev; // pairs (start, stop)
+    std::vector<int> ktimer_kind;      // kernel kind of each pair (FPR_KT_*)
     size_t ktimer_used = 0;
     char err[512] = {0};
 };
@@ -101,6 +102,21 @@ inline int fpr_fail(fpr_ctx* ctx, int code, const char* fmt, ...)
     do {                                                                                            \
         if (!(cond)) return fpr_fail((ctx), FPR_ERR_INVALID, "invalid argument: %s", msg);          \
     } while (0)
+
+// fpr_kernel_timer: one hipEvent pair around a launch, recorded on the stream the kernel is launched on
+inline bool fpr_ktimer_begin(fpr_ctx* ctx, int kind, hipStream_t s)
+{
+    if (!ctx->ktimer_on || ctx->ktimer_used + 2 > ctx->ktimer_ev.size()) return false;
+    if (hipEventRecord(ctx->ktimer_ev[ctx->ktimer_used], s) != hipSuccess) return false;
+    ctx->ktimer_kind[ctx->ktimer_used / 2] = kind;
+    return true;
+}
+inline void fpr_ktimer_end(fpr_ctx* ctx, bool timed, hipStream_t s)
+{
+    if (!timed) return;
+    (void)hipEventRecord(ctx->ktimer_ev[ctx->ktimer_used + 1], s);
+    ctx->ktimer_used += 2;
+}
 
 inline long fpr_opt(fpr_ctx* ctx, const char* key, long dflt)
 {

@@ -1650,7 +1650,9 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             const bool fuse_p = fpr_opt(ctx, "mg_fuse_prolong", 1) != 0;
             if (fuse_r) {  // pre-smoothing pair + residual + injection + zero coarse guess in ONE pass (:124-132)
                 const dim3 gr((nstrips_r + 3) / 4, (ny + rpc - 1) / rpc);
+                const bool timed = top && fpr_ktimer_begin(ctx, FPR_KT_MG_PRE, s);
                 { if (vx2) k_smooth2_march2<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c); else k_smooth2_march<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c); }
+                fpr_ktimer_end(ctx, timed, s);
                 if (apply_BCs) k_bc_neumann<<<(nyc + 255) / 256, 256, 0, s>>>(L.res_c, nxc, nyc);  // :355-357
             } else {
                 { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr); else k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr); }  // :124-125
@@ -1663,8 +1665,10 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             if (!fuse_p) k_prolong2d<true><<<g, blk2, 0, s>>>(L.corr_c, L.tmp, nx, ny, apply_BCs);  // :136-139
             // post-smoothing pair (:142-143); with fuse_p the correction u - P(corr_c) is applied while loading
             if (top) {
+                const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_POST, s);
                 if (fuse_p) { if (vx2) k_smooth2_march2<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs | ntf, nullptr, nullptr); else k_smooth2_march<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs | ntf, nullptr, nullptr); }
                 else { if (vx2) k_smooth2_march2<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, ntf, nullptr, nullptr); else k_smooth2_march<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, ntf, nullptr, nullptr); }
+                fpr_ktimer_end(ctx, timed, s);
                 FPR_CHECK_LAUNCH(ctx);
                 if (int rc = fprx_finish_sum(ctx, ctx->partials, npm, ctx->scalars, false, 0)) return rc;
                 *rms_is_host = false;

@@ -57,11 +57,17 @@ const char* fpr_version(void);
 int fpr_set_option(fpr_ctx* ctx, const char* key, long value);
 long fpr_get_option(fpr_ctx* ctx, const char* key);
 
-/* Per-launch timing of the dominant kernel with hipEvents recorded on the launch stream (used by
- * bench.py for the roofline figure).  enable=1 starts recording an event pair around every fused
- * diffusion-step launch (up to 8192 pairs); read synchronises and returns the summed duration. */
+/* Per-launch timing of the dominant kernels with hipEvents recorded on the launch stream (used by bench.py for the
+ * roofline figures).  enable=1 starts recording an event pair around every launch of the kernels below (up to 8192
+ * pairs); read synchronises and returns the summed duration and the number of launches of one kind (-1 = all). */
+enum {
+    FPR_KT_DIFF3_STEP = 0,    /* k_diff3_march: one pseudo-iteration per launch                               */
+    FPR_KT_DIFF3_STEP2 = 1,   /* k_diff3_march2: two pseudo-iterations per launch                             */
+    FPR_KT_MG_PRE = 2,        /* finest level of a V-cycle: 2 sweeps + residual + injection in one pass       */
+    FPR_KT_MG_POST = 3        /* finest level of a V-cycle: prolongation + correction + 2 sweeps (+ norm)     */
+};
 int fpr_kernel_timer(fpr_ctx* ctx, int enable);
-int fpr_kernel_timer_read(fpr_ctx* ctx, double* total_ms_host, long* count_host);
+int fpr_kernel_timer_read(fpr_ctx* ctx, int kind, double* total_ms_host, long* count_host);
 
 /* ---- Part 1: 3D pseudo-transient diffusion ------------------------------------------------------- */
 

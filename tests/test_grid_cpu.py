@@ -176,3 +176,26 @@ def test_nshard_equals_single_domain(tmp_path, oracle, dims, n):
         locR = np.load(tmp_path / ("R_%d.npy" % r))
         globR = R[off[0]:off[0] + n[0], off[1]:off[1] + n[1], off[2]:off[2] + n[2]]
         assert np.array_equal(locR[1:-1, 1:-1, 1:-1], globR[1:-1, 1:-1, 1:-1])
+
+
+def test_bench_self_launcher_dry_run_world2():
+    """`python bench.py --gpus 2` without torchrun must start its two ranks itself (run_all_benchmarks.sh:21-28 uses
+    mpiexecjl -np N): CPU rehearsal of the launcher and the gloo control plane, no GPU, no compute."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout          # ONE JSON line, printed by rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["max_over_ranks"] == 2.0
+    assert d["self_launched"] is True and d["control_plane"] == "gloo" and d["dry_run"] is True
+    # a failing rank must fail the launch (exit code propagated, the other rank is not left hanging)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-such-flag"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0

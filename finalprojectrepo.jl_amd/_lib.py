@@ -50,7 +50,7 @@ _SIG = {
     "fpr_diffusion3d_step": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8,
     "fpr_diffusion3d_step_norm": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8 + [_d, _dp],
     "fpr_diffusion3d_step_norm_host": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8 + [_d, C.POINTER(_d)],
-    "fpr_diffusion3d_solve": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8 + [_d, _d, _i, _d, _l, _l, _i, C.POINTER(_l), C.POINTER(_d),
+    "fpr_diffusion3d_solve": [_vp] + [_dp] * 5 + [_i] * 3 + [_d] * 8 + [_d, _d, _i, _d, _l, _l, _i, C.POINTER(_l), C.POINTER(_d),
                               C.POINTER(_i)],
     "fpr_diffusion3d_step_box": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8 + [C.POINTER(_i), C.POINTER(_i), _d, _dp, _i],
     "fpr_diffusion3d_can_step2": [_vp] + [_dp] * 5 + [_i] * 3,

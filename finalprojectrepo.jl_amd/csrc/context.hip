@@ -53,7 +53,6 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
     if (ctx->cg_buf) hipFree(ctx->cg_buf);
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->partials2) hipFree(ctx->partials2);
-    if (ctx->diff3_scratch) hipFree(ctx->diff3_scratch);
     if (ctx->scalars) hipFree(ctx->scalars);
     if (ctx->state) hipFree(ctx->state);
     if (ctx->state_h) hipHostFree(ctx->state_h);

@@ -127,6 +127,12 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
     a.partials1 = base;
     a.partials2 = base + FPR_MAX_PARTIALS / 2;
     const bool norm = sumsq2_dev != nullptr;
+    if (zlo2 < 1) zlo2 = 1;
+    if (zhi2 > nz - 1) zhi2 = nz - 1;
+    if (a.lo[2] >= a.hi[2] && zhi2 > zlo2) {   // empty first z-range: the second one takes its place
+        a.lo[2] = zlo2; a.hi[2] = zhi2;
+        zlo2 = zhi2 = 0;
+    }
     const bool empty = a.lo[0] >= a.hi[0] || a.lo[1] >= a.hi[1] || a.lo[2] >= a.hi[2];
     int nparts = 0;
     if (!empty) {
@@ -137,8 +143,7 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
         const bool timed = fpr_ktimer_begin(ctx, FPR_KT_DIFF3_STEP2, ctx->stream[stream_sel]);
         hipError_t e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), (int)fpr_opt(ctx, "diff3_xcd2", 0) & 3,   // (higher bits are harness-only ablation switches)
                                      ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2, &nparts,
-                                     (int)fpr_opt(ctx, "diff3_nw2", 0), ctx->ncu, zlo2 < 1 ? 1 : zlo2,
-                                     zhi2 > nz - 1 ? nz - 1 : zhi2);
+                                     (int)fpr_opt(ctx, "diff3_nw2", 0), ctx->ncu, zlo2, zhi2);
         fpr_ktimer_end(ctx, timed, ctx->stream[stream_sel]);
         if (e != hipSuccess) return fpr_fail(ctx, FPR_ERR_HIP, "fused diffusion3d launch: %s", hipGetErrorString(e));
     }
@@ -181,8 +186,8 @@ extern "C" int fpr_diffusion3d_step2_box(fpr_ctx* ctx, const double* Ht, const d
                       scale, sumsq2_dev, true, stream_sel);
 }
 
-extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, double* Htau2, double* dHdtau, int nx, int ny,
-                                     int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx,
+extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, double* Htau2, double* Htau3, double* dHdtau,
+                                     int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx,
                                      double D_dy, double D_dz, double dt, double total_N, int nt, double tol, long iter_max,
                                      long fixed_iters, int check_every, long* iters_host, double* err_host, int* swapped_host)
 {
@@ -197,22 +202,20 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
     // the field alternates between an "even" buffer (Htau's boundary) and an "odd" one (Htau2's).  With a third
     // buffer E1 that carries Htau's boundary two iterations run as one fused launch even -> even, reading only the
     // boundary of Htau2 (diffusion3d_fused2.hpp); single steps handle odd states and odd iteration counts.
+    // Htau3: the caller's third work buffer (the library allocates no field-sized memory).  NULL = one iteration per
+    // launch.  Given but unusable (size / alignment outside the fused kernel's range): an error, not a silent detour.
     double* E1 = nullptr;
     bool fuse = false;
-    if (fpr_opt(ctx, "diff3_fuse2", 1) != 0 && (long)nx * ny * 8 * 12 < (1L << 31)) {
-        if (ctx->diff3_scratch_n < N) {
-            if (ctx->diff3_scratch) hipFree(ctx->diff3_scratch);
-            ctx->diff3_scratch = nullptr;
-            ctx->diff3_scratch_n = 0;
-            if (hipMalloc(&ctx->diff3_scratch, N * sizeof(double)) == hipSuccess) ctx->diff3_scratch_n = N;
-            else (void)hipGetLastError();   // no memory for the third buffer: single steps only
-        }
-        E1 = ctx->diff3_scratch_n >= N ? ctx->diff3_scratch : nullptr;
-        fuse = E1 && diff3_can_fuse2(Ht, Htau, Htau2, E1, dHdtau, nx, ny, nz);
-        if (fuse) {
-            int rc = fpr_copy(ctx, E1, Htau, N);   // boundary of the even buffers (interior is overwritten)
-            if (rc) return rc;
-        }
+    if (Htau3 && fpr_opt(ctx, "diff3_fuse2", 1) != 0) {
+        FPR_REQUIRE(ctx, Htau3 != Ht && Htau3 != Htau && Htau3 != Htau2 && Htau3 != dHdtau, "Htau3 must be a buffer of its own");
+        if (!diff3_fuse2_ok(ctx, Ht, Htau, Htau2, Htau3, dHdtau, nx, ny, nz))
+            return fpr_fail(ctx, FPR_ERR_INVALID, "Htau3 given, but %dx%dx%d / these pointers are outside the fused two-iteration "
+                            "kernel's range (nx even >= 128, ny >= 16, 16-byte aligned arrays): pass NULL (see "
+                            "fpr_diffusion3d_can_step2)", nx, ny, nz);
+        E1 = Htau3;
+        fuse = true;
+        int rc = fpr_copy(ctx, E1, Htau, N);   // boundary of the even buffers (interior is overwritten)
+        if (rc) return rc;
     }
     double* cur = Htau;   // current field
     int parity = 0;       // 0: cur is an even buffer (Htau or E1), 1: cur == Htau2

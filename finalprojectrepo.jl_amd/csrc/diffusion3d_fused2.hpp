@@ -46,8 +46,17 @@ struct Diff3Args2 {
     int xalign;                     // 1: x-tile cut points sit in the middle of 128-byte lines
     int zb_lo, zb_hi, ntz_a;        // optional second z-range [zb_lo, zb_hi) with the same x/y box: chunks tz >= ntz_a
     int xcd_remap;
-    int dbg;                        // tuning harness only: 1 = drop all stores, 2 = drop all loads of the z-loop
+#ifdef FPR_TUNE
+    int dbg;                        // tuning harness only (tools/, -DFPR_TUNE): 1 = drop all stores, 2 = drop all loads of the z-loop
+#endif
 };
+
+// ablation switches exist in the tuning harness only; the production library compiles them out
+#ifdef FPR_TUNE
+#define DIFF3_DBG(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define DIFF3_DBG(a, bit) false
+#endif
 
 // DPP wave shifts without an `old` operand: the edge lane receives 0 (no register copy needed)
 __device__ __forceinline__ double diff3_lane_up1_z(double v)
@@ -78,8 +87,12 @@ __device__ __forceinline__ double diff3_lane_down1_edge(double v, double edge)
 }
 
 // Buffer addressing: address = descriptor base (4 SGPRs, loop-invariant) + per-lane byte offset (1 VGPR,
-// loop-invariant) + scalar byte offset (1 SGPR: plane and row).  No 64-bit address arithmetic per access;
-// the hardware range check (num_records) turns the one possible read beyond the last plane into a zero.
+// loop-invariant) + scalar byte offset (1 SGPR: plane and row).  No 64-bit address arithmetic per access.
+// Every descriptor's num_records is the number of bytes from its base to the END OF THE ARRAY (capped below the
+// sentinel), so the hardware range check bounds every access to the array whatever the guards in the code say; an
+// access is dropped on purpose by giving it the sentinel offset OOR > num_records, in the VGPR or in the SGPR
+// offset: gfx950 compares voffset + soffset against num_records for raw (stride 0) descriptors, measured by
+// tools/oob_probe.hip (profiles/r2_oob_probe.txt) -- LLVM's documentation lists soffset as unchecked.
 typedef double diff3_d2v __attribute__((ext_vector_type(2)));
 typedef unsigned diff3_u4v __attribute__((ext_vector_type(4)));
 typedef unsigned diff3_u2v __attribute__((ext_vector_type(2)));
@@ -240,15 +253,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
     //      uses the scalar offsets so + r * rs with so = (m + 2 - pbA) * ps (see the shifts below) ----
     const int ps = (int)(sz * 8), rs = (int)(sy * 8);   // plane / row stride in bytes (host: (zc + 8) * ps < 2^31)
     const int pbA = m0 - 1 > 0 ? m0 - 1 : 0;
-    auto basep = [&](const double* X, int pshift, int row) -> uintptr_t {
-        return (uintptr_t)X + (uintptr_t)(((long)(pbA + pshift) * (long)sz + (long)row * (long)sy) * 8);
+    const long array_bytes = (long)sz * (long)nz * 8;
+    // descriptor based at (plane pbA + pshift, row): num_records = bytes left in the array from there (a base before the
+    // array's first byte -- pshift < 0 in the first chunk -- only makes the window longer, never past the array's end)
+    auto rsrc_at = [&](const double* X, int pshift, int row) -> __amdgpu_buffer_rsrc_t {
+        const long off = ((long)(pbA + pshift) * (long)sz + (long)row * (long)sy) * 8;
+        long rem = array_bytes - off;
+        rem = rem < 0 ? 0 : (rem > 0x7ffffff0L ? 0x7ffffff0L : rem);
+        return diff3_rsrc((uintptr_t)X + (uintptr_t)off, (unsigned)rem);
     };
-    const __amdgpu_buffer_rsrc_t rA = diff3_rsrc(basep(a.A, 0, j0), OOR);       // L0 plane m+2
-    const __amdgpu_buffer_rsrc_t rHt = diff3_rsrc(basep(a.Ht, 0, j0), OOR);     // Ht plane m+2
-    const __amdgpu_buffer_rsrc_t rEB = diff3_rsrc(basep(a.B, -1, j0), OOR);     // B x-boundary cells, plane m+1
-    const __amdgpu_buffer_rsrc_t rH = diff3_rsrc(basep(Hsrc, -1, hrow), OOR);   // halo row, plane m+1
-    const __amdgpu_buffer_rsrc_t rC = diff3_rsrc(basep(a.C, -NR, j0), OOR);     // L2 plane m-1
-    const __amdgpu_buffer_rsrc_t rD = diff3_rsrc(basep(a.dH, -NR, j0), OOR);
+    const __amdgpu_buffer_rsrc_t rA = rsrc_at(a.A, 0, j0);       // L0 plane m+2
+    const __amdgpu_buffer_rsrc_t rHt = rsrc_at(a.Ht, 0, j0);     // Ht plane m+2
+    const __amdgpu_buffer_rsrc_t rEB = rsrc_at(a.B, -1, j0);     // B x-boundary cells, plane m+1
+    const __amdgpu_buffer_rsrc_t rH = rsrc_at(Hsrc, -1, hrow);   // halo row, plane m+1
+    const __amdgpu_buffer_rsrc_t rC = rsrc_at(a.C, -NR, j0);     // L2 plane m-1
+    const __amdgpu_buffer_rsrc_t rD = rsrc_at(a.dH, -NR, j0);
 
     DVec<VX> P[NR][RY];       // L0 planes m-1, m, m+1; plane p lives in slot (p - m0 + 1) % NR
     DVec<VX> HT[NR][RY];      // Ht planes m-1, m, m+1 (in flight), same slot rule
@@ -334,7 +353,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
         const bool zb = (m <= 0) || (m >= nz - 1);   // block-uniform: a z-boundary plane of L1 comes from B
         if (zb) {
             // rare (first / last chunk only): synchronous, so that no load of this branch is pending at the join
-            const __amdgpu_buffer_rsrc_t rB = diff3_rsrc((uintptr_t)(a.B + sz * (size_t)m + sy * (size_t)j0), OOR);
+            const long offB = ((long)sz * m + (long)sy * j0) * 8;
+            const long remB = array_bytes - offB;
+            const __amdgpu_buffer_rsrc_t rB = diff3_rsrc((uintptr_t)a.B + (uintptr_t)offB, (unsigned)(remB > 0x7ffffff0L ? 0x7ffffff0L : remB));
             load_rows(Qn, rB, 0);
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         } else {
@@ -373,7 +394,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
 
         // L0 plane m-1 and the halo registers of plane m are dead: refill with L0 plane m+2 and the halos of plane m+1
         // (out of range, i.e. nothing, once the chunk ends)
-        const int so1 = (m + 1 <= m1 && !(a.dbg & 2)) ? so : (int)OOR;
+        const int so1 = (m + 1 <= m1 && !DIFF3_DBG(a, 2)) ? so : (int)OOR;
         load_rows(P[S % NR], rA, (m + 2 <= nz - 1) ? so1 : (int)OOR);   // plane nz does not exist (only a z-boundary L1 plane would use it)
         load_halo(YH, ED, so1, so1 == (int)OOR ? (int)OOR : so1 - ps);
 
@@ -392,7 +413,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
                     const double yp = (r == RY - 1) ? yu1.v[v] : Qc[r == RY - 1 ? r : r + 1].v[v];
                     res[v] = diff3_point(Qc[r].v[v], xm, xp, ym, yp, Qm[r].v[v], Qn[r].v[v], HT[S % NR][r].v[v], cf, h2[v]);
                 }
-                const int sor = (rm[r] && !(a.dbg & 1)) ? so + r * rs : (int)OOR;   // rows the block does not own: dropped by the range check
+                const int sor = (rm[r] && !DIFF3_DBG(a, 1)) ? so + r * rs : (int)OOR;   // rows the block does not own: dropped by the range check
                 // lanes that own one cell of their pair (first / last owned cell of an odd-aligned range)
                 double r2 = res[0], g2 = h2[0];
                 if (has_split) { asm volatile("" ::: "memory"); r2 = cm[0] ? res[0] : res[1]; g2 = cm[0] ? h2[0] : h2[1]; }
@@ -415,7 +436,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
             }
         }
         // Ht plane m-1 is dead: refill with plane m+2
-        load_rows(HT[S % NR], rHt, (m + 2 <= m1 && !(a.dbg & 2)) ? so : (int)OOR);
+        load_rows(HT[S % NR], rHt, (m + 2 <= m1 && !DIFF3_DBG(a, 2)) ? so : (int)OOR);
         so += ps;
     };
 
@@ -508,7 +529,9 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
     a.ntz = a.ntz_a + (wzb + zc - 1) / zc;
     const long nblk = tiles_xy * a.ntz;
     if (nblk > 0x7fffffffL || (norm && nblk > max_partials)) return hipErrorInvalidValue;
+#ifdef FPR_TUNE
     a.dbg = xcd_opt >> 4;
+#endif
     xcd_opt &= 15;
     // block -> XCD mapping: 0 = auto, 1 = contiguous range of tiles per XCD, 2 = z-chunk ownership, 3 = hardware order.
     // With at most ~two rounds of workgroups the contiguous mapping puts y-neighbours (which share 4 of 34 rows) on

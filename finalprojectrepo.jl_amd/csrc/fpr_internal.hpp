@@ -56,8 +56,6 @@ struct fpr_ctx {
     hipEvent_t ev[2] = {nullptr, nullptr};
     double* partials = nullptr;     // FPR_MAX_PARTIALS doubles: block partial sums (slot 0)
     double* partials2 = nullptr;    // second slot (comm stream / second reduction of a kernel)
-    double* diff3_scratch = nullptr;   // third field buffer of the fused two-step diffusion solve (lazily allocated)
-    size_t diff3_scratch_n = 0;
     int ncu = 0;                       // compute units of the device (queried on first use)
     double* scalars = nullptr;      // 64 device doubles for results of reductions
     FprSolveState* state = nullptr; // device

@@ -1760,13 +1760,8 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                         double* slot = ctx->partials + (size_t)(gi & 1) * S * nblk;
                         const double* pslot = ctx->partials + (size_t)((gi + 1) & 1) * S * nblk;
                         const bool pending = gi > gdone;  // the previous group of THIS chunk is still unchecked
-                        const long dbg = fpr_opt(ctx, "mg_patch_dbg", 0);  // timing diagnostics only (results invalid when set)
-                        if (dbg & 2)
-                            k_jacobi_patch<S, false, true><<<gm, 256, 0, s>>>(a, rhs, b, nx, ny, C, _h2, fac, nsw, slot, ctx->state,
-                                                                               pslot, 0, gi - 1, (double)N);
-                        else
                         k_jacobi_patch<S, true, true><<<gm, 256, 0, s>>>(a, rhs, b, nx, ny, C, _h2, fac, nsw, slot, ctx->state,
-                                                                          pslot, (pending && !(dbg & 1)) ? Sg : 0, gi - 1, (double)N);
+                                                                          pslot, pending ? Sg : 0, gi - 1, (double)N);
                         if (gi == gend - 1)  // last group of the chunk: stand-alone check before the host polls
                             k_jacobi_check_multi<<<1, 256, 0, s>>>(ctx->state, slot, nblk, nsw, (double)N, gi);
                     } else {

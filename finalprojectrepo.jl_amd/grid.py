@@ -410,7 +410,8 @@ class GlobalGrid:
         """TWO pseudo-iterations: Hout <- update(update(Hτ)), dHdτ <- residual of the second, halos of Hout refreshed.
         Hτ2 plays the reference's second work buffer: only its boundary cells (and, between ranks, its z-halo planes)
         are used.  Hout must carry Hτ's physical-boundary values.  sq2_dev (2 doubles, or None) receives the LOCAL
-        sums of (dHdτ*norm_scale)^2 of the first and second iteration.  Bit-identical to two calls of step()."""
+        sums of (dHdτ*norm_scale)^2 of the first and second iteration.  Fields bit-identical to two calls of step(); the
+        two sums equal step()'s to ~1e-13 relative (another summation order, see include/fpr.h)."""
         from . import part1
 
         args = (Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)

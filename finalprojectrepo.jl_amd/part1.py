@@ -268,13 +268,19 @@ def diffusion_3D_kernel_programming(*, nx, ny, nz, ttot=1.0, tol=1e-8, use_share
     sq = ctx.scal[:1]
     if native_loop and gg.nprocs == 1:
         # the whole host loop (:166-204) runs inside libfpr_hip.so; the timing rule of :170-176 (timer starts at
-        # the 4th physical step) is reproduced by splitting the call
+        # the 4th physical step) is reproduced by splitting the call.  The third work buffer of the fused pairs is
+        # allocated HERE (field arrays belong to the host language); None = one iteration per launch.
+        Hτ3 = fzeros(nx, ny, nz)
+        if not can_step_τ2(Ht, Hτ, Hτ2, Hτ3, residual_H):
+            Hτ3 = None
+
         def run_steps(n_steps):
             nonlocal Hτ, Hτ2
             its = (C.c_long * max(n_steps, 1))()
             errs = (C.c_double * max(n_steps, 1))()
             sw = C.c_int(0)
-            ctx.call("fpr_diffusion3d_solve", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hτ2, 3), fptr(residual_H, 3), nx, ny, nz,
+            ctx.call("fpr_diffusion3d_solve", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hτ2, 3),
+                     fptr(Hτ3, 3) if Hτ3 is not None else None, fptr(residual_H, 3), nx, ny, nz,
                      dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, dt, float(total_N), n_steps, tol, int(iter_max),
                      int(fixed_iters), int(check_every), its, errs, C.byref(sw))
             if sw.value:

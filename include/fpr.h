@@ -100,7 +100,9 @@ int fpr_diffusion3d_step_norm_host(fpr_ctx* ctx, const double* Ht, const double*
  * carries there).  Hout receives interior cells only and must already hold Htau's boundary values to stand in for the
  * reference's first work buffer afterwards.  Htau, Hmid, Hout: three distinct buffers.  dHdtau = residual of the
  * second iteration.  sumsq2_dev (may be NULL): two device doubles, sum((r*scale)^2) of the first and of the second
- * iteration (deterministic two-stage reductions).  Requirements: nx even and >= 128, ny >= 16, 16-byte aligned
+ * iteration (deterministic two-stage reductions).  "Bit for bit" is a statement about the FIELDS (Hout, dHdtau): the
+ * two sums are accumulated as sum(r*r) per lane with scale^2 applied once at the end, the single-step kernel adds
+ * (r*scale)^2 per cell -- both deterministic, equal to about 1e-13 relative, like any two summation orders.  Requirements: nx even and >= 128, ny >= 16, 16-byte aligned
  * arrays, nx*ny*96 < 2^31 -- query with fpr_diffusion3d_can_step2 (1 = supported, 0 = use two single steps).
  * _box: output box [lo, hi) as fpr_diffusion3d_step_box; sums are ACCUMULATED into sumsq2_dev. */
 int fpr_diffusion3d_can_step2(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hmid, const double* Hout,
@@ -125,11 +127,13 @@ int fpr_diffusion3d_step2_box2(fpr_ctx* ctx, const double* Ht, const double* Hta
  * check_every = n evaluates the norm (one host round trip) only every n-th pseudo-iteration (1 = reference).
  * fixed_iters > 0 runs exactly that many iterations per step.  iters_host / err_host: nt entries each.
  * The two work buffers swap roles every iteration (:190): *swapped_host = 1 means the current Htau lives in the
- * memory passed as Htau2 (and the last residual is in dHdtau either way).  Where fpr_diffusion3d_step2 applies,
- * pairs of iterations run as one fused launch (a third field-sized buffer is kept in the context; an iteration
- * whose norm ends the loop is replayed alone, so fields, iteration counts and errors are those of the plain loop;
- * option "diff3_fuse2" = 0 turns this off). */
-int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, double* Htau2, double* dHdtau, int nx, int ny, int nz,
+ * memory passed as Htau2 (and the last residual is in dHdtau either way).
+ * Htau3 (nullable): a THIRD field-sized work buffer owned by the caller -- the library allocates no field memory.
+ * With it, pairs of iterations run as one fused launch (fpr_diffusion3d_step2; an iteration whose norm ends the loop
+ * is replayed alone, so fields, iteration counts and errors are those of the plain loop; option "diff3_fuse2" = 0
+ * turns this off).  NULL: one iteration per launch.  Non-NULL for a problem the fused kernel cannot serve
+ * (fpr_diffusion3d_can_step2 == 0) is FPR_ERR_INVALID, never a silent fallback. */
+int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, double* Htau2, double* Htau3, double* dHdtau, int nx, int ny, int nz,
                           double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy, double D_dz,
                           double dt, double total_N, int nt, double tol, long iter_max, long fixed_iters, int check_every,
                           long* iters_host, double* err_host, int* swapped_host);

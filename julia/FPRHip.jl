@@ -172,16 +172,19 @@ function diffusion_3D_step_Ï„_norm_host(Ht::DA, HÏ„::DA, HÏ„2::DA, dHdÏ„::DA, dÏ
     return out[]
 end
 
-"Native single-rank host loop (part1_kernel_programming.jl:166-204); returns (iters, errs, swapped)."
-function diffusion_3D_solve!(Ht::DA, HÏ„::DA, HÏ„2::DA, dHdÏ„::DA, dÏ„, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, dt, total_N, nt;
+"""
+Native single-rank host loop (part1_kernel_programming.jl:166-204); returns (iters, errs, swapped).  `HÏ„3`: a third work
+array owned by the caller (`nothing` = one iteration per launch); with it pairs of iterations run as fused launches.
+"""
+function diffusion_3D_solve!(Ht::DA, HÏ„::DA, HÏ„2::DA, HÏ„3::Union{DA,Nothing}, dHdÏ„::DA, dÏ„, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, dt, total_N, nt;
                              tol = 1e-8, iter_max = 100000, fixed_iters = 0, check_every = 1)
     nx, ny, nz = size(Ht); its = zeros(Clong, max(nt, 1)); errs = zeros(Cdouble, max(nt, 1)); sw = Ref{Cint}(0)
     check(ccall((:fpr_diffusion3d_solve, libfpr), Cint,
-                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint,
                  Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cdouble, Clong, Clong, Cint,
                  Ptr{Clong}, Ptr{Cdouble}, Ptr{Cint}),
-                ctx(), p(Ht), p(HÏ„), p(HÏ„2), p(dHdÏ„), nx, ny, nz, dÏ„, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, dt, total_N, nt, tol,
-                iter_max, fixed_iters, check_every, its, errs, sw))
+                ctx(), p(Ht), p(HÏ„), p(HÏ„2), HÏ„3 === nothing ? Ptr{Cdouble}(C_NULL) : p(HÏ„3), p(dHdÏ„), nx, ny, nz,
+                dÏ„, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, dt, total_N, nt, tol, iter_max, fixed_iters, check_every, its, errs, sw))
     return its[1:nt], errs[1:nt], sw[] != 0
 end
 

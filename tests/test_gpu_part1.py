@@ -344,6 +344,48 @@ def test_fused_two_steps_bit_exact(fpr, oracle, shape, opts):
             c.set_option(k, 0)
 
 
+@pytest.mark.parametrize("shape", [(128, 16, 5), (130, 20, 9), (256, 33, 12), (128, 64, 3)], ids=lambda s: "x".join(map(str, s)))
+def test_fused_two_steps_stay_inside_their_arrays(fpr, oracle, shape):
+    """The fused kernel addresses memory through buffer descriptors and drops rows / planes / lanes by out-of-range
+    offsets: the five arrays sit back to back inside ONE allocation, separated by canary-filled gaps; after full and
+    boxed launches (every chunking) the gaps are untouched, the inputs unchanged and the results equal the oracle's."""
+    import torch
+
+    F = fpr
+    c = F.ctx()
+    n = int(np.prod(shape))
+    gap = 4096
+    flat = torch.full((5 * n + 6 * gap,), 7.25, dtype=torch.float64, device="cuda")
+
+    def carve(i):
+        off = gap + i * (n + gap)
+        return flat[off:off + n].view(shape[2], shape[1], shape[0]).permute(2, 1, 0)
+
+    dHt, dA, dB, dC, dD = (carve(i) for i in range(5))
+    Ht, A, B = rnd(shape, 61), rnd(shape, 62), rnd(shape, 63)
+    C_ref, dH_ref, s1, s2 = _two_oracle_steps(oracle, Ht, A, B)
+    try:
+        for zc, nw in ((0, 0), (1, 4), (2, 8), (3, 0), (7, 4)):
+            c.set_option("diff3_zc2", zc)
+            c.set_option("diff3_nw2", nw)
+            for box in (None, ((1, 1, 1), (shape[0] - 1, shape[1] - 1, 2)), ((3, 2, shape[2] - 2), (shape[0] - 5, shape[1] - 1, shape[2] - 1))):
+                dHt.copy_(F.asdevice(Ht)); dA.copy_(F.asdevice(A)); dB.copy_(F.asdevice(B)); dC.copy_(dA); dD.fill_(-9.0)
+                if box is None:
+                    F.part1.diffusion_3D_step_τ2(dHt, dA, dB, dC, dD, *COEF.values())
+                    assert np.array_equal(F.tonumpy(dC), C_ref) and np.array_equal(F.tonumpy(dD), dH_ref)
+                else:
+                    F.part1.diffusion_3D_step_τ2_box(dHt, dA, dB, dC, dD, *COEF.values(), box[0], box[1])
+                    sl = tuple(slice(l, h) for l, h in zip(*box))
+                    assert np.array_equal(F.tonumpy(dC)[sl], C_ref[sl]) and np.array_equal(F.tonumpy(dD)[sl], dH_ref[sl])
+                for i in range(6):   # canaries in front of, between and behind the arrays
+                    g = flat[i * (n + gap):i * (n + gap) + gap]
+                    assert bool((g == 7.25).all()), ("gap", i, zc, nw, box)
+                assert np.array_equal(F.tonumpy(dHt), Ht) and np.array_equal(F.tonumpy(dA), A) and np.array_equal(F.tonumpy(dB), B)
+    finally:
+        c.set_option("diff3_zc2", 0)
+        c.set_option("diff3_nw2", 0)
+
+
 def test_fused_two_steps_unsupported_shapes_are_reported(fpr):
     F = fpr
     for shape in [(64, 32, 32), (129, 32, 32), (128, 15, 32)]:
@@ -353,6 +395,23 @@ def test_fused_two_steps_unsupported_shapes_are_reported(fpr):
             F.part1.diffusion_3D_step_τ2(*a, *COEF.values())
     a = [F.fzeros(128, 16, 8) for _ in range(4)]
     assert not F.part1.can_step_τ2(a[0], a[1], a[2], a[1], a[3])   # output aliases the input
+    # native solve: the third work buffer is the caller's; given for a size the fused kernel cannot serve it is an
+    # error (no silent one-iteration detour), NULL means one iteration per launch, and nothing is allocated inside
+    import ctypes as C
+    from fpr_amd import pkg
+    c = F.ctx()
+    shape = (64, 32, 32)
+    Ht, A, B, E, R = (F.fzeros(*shape) for _ in range(5))
+    its, errs, sw = (C.c_long * 1)(), (C.c_double * 1)(), C.c_int(0)
+    args = (*shape, *COEF.values(), 0.2, float(np.prod(shape)), 1, 1e-8, 100000, 4, 1, its, errs, C.byref(sw))
+    fp = pkg._lib.fptr
+    with pytest.raises(pkg.FprError, match="outside the fused"):
+        c.call("fpr_diffusion3d_solve", fp(Ht), fp(A), fp(B), fp(E), fp(R), *args)
+    c.call("fpr_diffusion3d_solve", fp(Ht), fp(A), fp(B), None, fp(R), *args)
+    assert its[0] == 4
+    with pytest.raises(pkg.FprError, match="buffer of its own"):
+        big = [F.fzeros(128, 16, 8) for _ in range(4)]
+        c.call("fpr_diffusion3d_solve", fp(big[0]), fp(big[1]), fp(big[2]), fp(big[1]), fp(big[3]), 128, 16, 8, *args[3:])
 
 
 @pytest.mark.parametrize("box", [((1, 1, 1), (129, 32, 23)), ((1, 1, 2), (129, 32, 22)), ((1, 1, 1), (129, 32, 2)),

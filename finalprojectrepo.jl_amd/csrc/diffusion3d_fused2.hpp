@@ -29,6 +29,11 @@
 #pragma once
 #include "diffusion3d_kernels.hpp"
 
+// wait states after the 16-byte stores of a row (s_nop N = N+1 states; -1 = none: harness only, WRONG results)
+#ifndef DIFF3_STORE_NOP
+#define DIFF3_STORE_NOP 7
+#endif
+
 struct Diff3Args2 {
     const double* __restrict__ Ht;
     const double* __restrict__ A;   // L0 (Htau)
@@ -421,12 +426,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
                 diff3_bst2_nt(rC, sv4, sor, h2[0], h2[1]);
                 diff3_bst1(rD, sv2, sor, r2);
                 diff3_bst1(rC, sv2, sor, g2);
-                // Observed on gfx950: the upper 8 bytes of a 16-byte buffer store's data can still be read after a VALU
-                // write to those registers issued 1-2 instructions later (hipcc assumes MUBUF stores with an SGPR
-                // soffset are free of this hazard).  Keep a few wait states between the stores and the next row.
+                // Store-data hazard (gfx9 family, "VMEM store of more than 64 bits followed by a VALU write of its data
+                // VGPRs: 1 wait state -- not needed when the store takes its offset from an SGPR"): hipcc relies on the
+                // exemption, these stores do take an SGPR soffset, and on gfx950 the upper 8 bytes of their data were
+                // nevertheless taken from a VALU result written 1-2 instructions later (2e-5 of the cells, odd cells
+                // only, only with every CU busy).  DIFF3_STORE_NOP wait states between a row's stores and the next VALU
+                // instruction; tools/hazard_soak.hip bisects the count (profiles/r2_hazard_soak.txt).
+#if DIFF3_STORE_NOP >= 0
                 __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 7");
+                asm volatile("s_nop %0" ::"n"(DIFF3_STORE_NOP));
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 if constexpr (NORM) {
                     if (rm[r]) {
 #pragma unroll

@@ -29,9 +29,14 @@
 #pragma once
 #include "diffusion3d_kernels.hpp"
 
-// wait states after the 16-byte stores of a row (s_nop N = N+1 states; -1 = none: harness only, WRONG results)
+// Wait states after the stores of a row (s_nop N = N+1 states; -1 = none, harness only).  Round 1 found corrupted
+// upper halves of 16-byte store data with a VALU write 1-2 instructions behind the store and used s_nop 7.  Round 2
+// soak (tools/hazard_soak.hip: 200-400 launches each at 512^3, 768^3, 640x200x300, every cell compared, second stream
+// copying; profiles/r2_hazard_soak.txt): with today's instruction order -- the two 16-byte stores of a row are
+// followed by its two 8-byte stores, pinned by sched_barrier -- every count from none to 7 is clean.  Kept: s_nop 1 =
+// the two wait states the gfx9 rule asks for when the SGPR-offset exemption is NOT assumed.
 #ifndef DIFF3_STORE_NOP
-#define DIFF3_STORE_NOP 7
+#define DIFF3_STORE_NOP 1
 #endif
 
 struct Diff3Args2 {
@@ -431,7 +436,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
                 // exemption, these stores do take an SGPR soffset, and on gfx950 the upper 8 bytes of their data were
                 // nevertheless taken from a VALU result written 1-2 instructions later (2e-5 of the cells, odd cells
                 // only, only with every CU busy).  DIFF3_STORE_NOP wait states between a row's stores and the next VALU
-                // instruction; tools/hazard_soak.hip bisects the count (profiles/r2_hazard_soak.txt).
+                // instruction; tools/hazard_soak.hip bisects the count (profiles/r2_hazard_soak.txt).  The barriers pin
+                // the order 16-byte stores, 8-byte stores, wait states, next row.
 #if DIFF3_STORE_NOP >= 0
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_nop %0" ::"n"(DIFF3_STORE_NOP));

@@ -6,8 +6,9 @@
 
 // defined in diffusion3d_launch.hpp (shared with tools/diffusion_tune.hip)
 #include "diffusion3d_launch.hpp"
-// two pseudo-iterations per pass (temporal blocking)
+// two pseudo-iterations per pass (temporal blocking): main kernel and the kernel for boxes that are narrow in x
 #include "diffusion3d_fused2.hpp"
+#include "diffusion3d_slab2.hpp"
 
 static int diff3_run(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2, double* dHdtau, int nx, int ny,
                      int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy,
@@ -140,10 +141,25 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
             int v = 0;
             ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
         }
+        // boxes up to 12 cells wide in x (the slab next to an x-neighbour of a decomposed run) go to the kernel whose
+        // lanes run along y; everything else to the wave-tile kernel.  A second z-range rides along in either case.
+        const bool narrow = (a.hi[0] - a.lo[0]) <= (int)fpr_opt(ctx, "diff3_slab_max", 12);
         const bool timed = fpr_ktimer_begin(ctx, FPR_KT_DIFF3_STEP2, ctx->stream[stream_sel]);
-        hipError_t e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), (int)fpr_opt(ctx, "diff3_xcd2", 0) & 3,   // (higher bits are harness-only ablation switches)
-                                     ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2, &nparts,
-                                     (int)fpr_opt(ctx, "diff3_nw2", 0), ctx->ncu, zlo2, zhi2);
+        hipError_t e;
+        if (narrow) {
+            e = diff3_launch_slab2(a, norm, ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2, &nparts);
+            if (e == hipSuccess && zhi2 > zlo2) {
+                Diff3Args2 b = a;
+                b.lo[2] = zlo2; b.hi[2] = zhi2;
+                b.partials1 = a.partials1 + nparts; b.partials2 = a.partials2 + nparts;
+                int np2 = 0;
+                e = diff3_launch_slab2(b, norm, ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2 - nparts, &np2);
+                nparts += np2;
+            }
+        } else
+            e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), (int)fpr_opt(ctx, "diff3_xcd2", 0) & 3,
+                              ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2, &nparts,
+                              (int)fpr_opt(ctx, "diff3_nw2", 0), ctx->ncu, zlo2, zhi2);
         fpr_ktimer_end(ctx, timed, ctx->stream[stream_sel]);
         if (e != hipSuccess) return fpr_fail(ctx, FPR_ERR_HIP, "fused diffusion3d launch: %s", hipGetErrorString(e));
     }

@@ -43,7 +43,12 @@ static int diff3_run(fpr_ctx* ctx, const double* Ht, const double* Htau, double*
         t.nt = (int)fpr_opt(ctx, "diff3_nt", -1);
         t.vx = (int)fpr_opt(ctx, "diff3_vx", 0);
         const bool timed = fpr_ktimer_begin(ctx, FPR_KT_DIFF3_STEP, ctx->stream[stream_sel]);
-        hipError_t e = diff3_launch(a, norm, t, ctx->stream[stream_sel], FPR_MAX_PARTIALS, &nparts);
+        // a box up to 8 cells wide in x (the slab next to an x-neighbour) goes to the kernel whose lanes run along y;
+        // needs 8-byte loads through buffer descriptors only, so any size / alignment qualifies
+        const bool narrow = t.variant == 0 && (a.hi[0] - a.lo[0]) <= (int)fpr_opt(ctx, "diff3_slab_max1", 8) &&
+                            (long)nx * ny * 8 * 12 < (1L << 31) && ny >= 3;
+        hipError_t e = narrow ? diff3_launch_slab1(a, norm, ctx->stream[stream_sel], FPR_MAX_PARTIALS, &nparts)
+                              : diff3_launch(a, norm, t, ctx->stream[stream_sel], FPR_MAX_PARTIALS, &nparts);
         fpr_ktimer_end(ctx, timed, ctx->stream[stream_sel]);
         if (e != hipSuccess) return fpr_fail(ctx, FPR_ERR_HIP, "diffusion3d launch: %s", hipGetErrorString(e));
     }

@@ -197,3 +197,125 @@ static inline hipError_t diff3_launch_slab2(Diff3Args2 a, bool norm, hipStream_t
     *nparts = (int)nblk;
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// ONE pseudo-transient iteration on a narrow box (the x-slab next to an x-neighbour: level 1 there has to exist in
+// memory before the halo exchange of a fused pair, and the wave-tile kernel k_diff3_march would spend a 128-cell tile
+// on it).  Same lane layout as k_diff3_slab2: lanes along y, W owned columns per lane, z-march with a three-plane
+// window of Htau; no second level, so every lane but the two outermost owns its row (62 rows per wave).
+// Writes Htau2 and dHdtau on the box, exactly like fpr_diffusion3d_step_box.
+template <bool NORM, int W>
+__global__ __launch_bounds__(256) void k_diff3_slab1(Diff3Args a)
+{
+    constexpr int C0 = W + 2;   // Htau columns xs-1 .. xs+W
+    constexpr unsigned OOR = 0x7fffffffu;
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
+    const long sy = nx, sz = (long)nx * ny;
+    const int wx = a.hi[0] - a.lo[0], wy = a.hi[1] - a.lo[1], wz = a.hi[2] - a.lo[2];
+    const int ncg = (wx + W - 1) / W, nyt = (wy + 61) / 62, ntz = (wz + a.zc - 1) / a.zc;
+    const long item = (long)blockIdx.x * 4 + wv;
+    double acc = 0.0;
+    if (item < (long)ncg * nyt * ntz) {
+        const int cg = (int)(item % ncg), ty = (int)((item / ncg) % nyt), tz = (int)(item / ((long)ncg * nyt));
+        const int xs = a.lo[0] + cg * W;
+        const int xe = xs + W < a.hi[0] ? xs + W : a.hi[0];
+        const int oly = a.lo[1] + ty * 62;
+        const int ohy = oly + 62 < a.hi[1] ? oly + 62 : a.hi[1];
+        const int j = oly - 1 + lane;
+        const int jc = j < 0 ? 0 : (j > ny - 1 ? ny - 1 : j);
+        const bool row_in = j >= 0 && j <= ny - 1;
+        const bool row_own = lane >= 1 && lane <= 62 && j >= oly && j < ohy;
+        const int k0 = a.lo[2] + tz * a.zc;
+        const int k1 = k0 + a.zc < a.hi[2] ? k0 + a.zc : a.hi[2];
+        const Diff3Coef cf{a.dtau, a._dt, a._dx, a._dy, a._dz, a.D_dx, a.D_dy, a.D_dz};
+        const long array_bytes = sz * nz * 8;
+        const long pbase = (long)(k0 - 1) * sz * 8;                          // k0 >= 1
+        auto mk = [&](const double* X) {
+            const long rem = array_bytes - pbase;
+            return diff3_rsrc((uintptr_t)X + (uintptr_t)pbase, (unsigned)(rem > 0x7ffffff0L ? 0x7ffffff0L : rem));
+        };
+        const __amdgpu_buffer_rsrc_t rA = mk(a.Htau), rHt = mk(a.Ht), rC = mk(a.Htau2), rD = mk(a.dHdtau);
+        const long rowoff = ((long)jc * sy + (xs - 1)) * 8;                 // column xs-1 >= 0
+        const unsigned vld = row_in ? (unsigned)rowoff : OOR;
+        const unsigned vst = row_own ? (unsigned)rowoff : OOR;
+        auto poff = [&](int k) { return (int)((long)k * sz * 8 - pbase); };
+        auto colv = [&](int c) { const int x = xs - 1 + c; return x <= nx - 1 && x <= xe; };   // uniform
+        double P[3][C0];
+        auto loadP = [&](double (&dst)[C0], int k) {
+            const bool pv = k >= 0 && k <= nz - 1;
+#pragma unroll
+            for (int c = 0; c < C0; ++c) dst[c] = diff3_bld1(rA, vld + 8u * c, (pv && colv(c)) ? poff(k) : (int)OOR);
+        };
+        loadP(P[0], k0 - 1);
+        loadP(P[1], k0);
+        loadP(P[2], k0 + 1);
+        auto step = [&](auto Sc, int k) {
+            constexpr int S = decltype(Sc)::value;   // (k - k0) % 3: plane k-1 in slot S, k in S+1, k+1 in S+2
+            double(&Pm)[C0] = P[S % 3];
+            double(&Pc)[C0] = P[(S + 1) % 3];
+            double(&Pp)[C0] = P[(S + 2) % 3];
+            double ht[W];
+            const int so = poff(k);
+#pragma unroll
+            for (int c = 0; c < W; ++c) ht[c] = diff3_bld1(rHt, vld + 8u * (c + 1), xs + c < xe ? so : (int)OOR);
+#pragma unroll
+            for (int c = 0; c < W; ++c) {
+                const double h = Pc[c + 1];
+                const double ym = diff3_lane_up1(h), yp = diff3_lane_down1(h);
+                double h2;
+                const double r = diff3_point(h, Pc[c], Pc[c + 2], ym, yp, Pm[c + 1], Pp[c + 1], ht[c], cf, h2);
+                const int soc = xs + c < xe ? so : (int)OOR;
+                diff3_bst1(rD, vst + 8u * (c + 1), soc, r);
+                diff3_bst1(rC, vst + 8u * (c + 1), soc, h2);
+                if constexpr (NORM) {
+                    if (row_own && xs + c < xe) { const double t = r * a.scale; acc += t * t; }
+                }
+            }
+            loadP(Pm, k + 2 <= k1 ? k + 2 : -1);   // plane k-1 is dead: refill with plane k+2
+        };
+        int k = k0;
+        for (; k + 2 < k1; k += 3) {
+            step(std::integral_constant<int, 0>{}, k);
+            step(std::integral_constant<int, 1>{}, k + 1);
+            step(std::integral_constant<int, 2>{}, k + 2);
+        }
+        if (k < k1) { step(std::integral_constant<int, 0>{}, k); ++k; }
+        if (k < k1) { step(std::integral_constant<int, 1>{}, k); ++k; }
+    }
+    if constexpr (NORM) {
+        const double w1 = diff3_wave_sum(acc);
+        if (lane == 0) red[wv] = w1;
+        __syncthreads();
+        if (tid == 0) a.partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    }
+}
+
+static inline hipError_t diff3_launch_slab1(Diff3Args a, bool norm, hipStream_t stream, int max_partials, int* nparts)
+{
+    const int wx = a.hi[0] - a.lo[0], wy = a.hi[1] - a.lo[1], wz = a.hi[2] - a.lo[2];
+    *nparts = 0;
+    if (wx <= 0 || wy <= 0 || wz <= 0) return hipSuccess;
+    const long psb = (long)a.nx * a.ny * 8;
+    const int zc_max = (int)((1L << 31) / psb) - 8;
+    if (zc_max < 1) return hipErrorInvalidValue;
+    const int W = wx <= 2 ? 2 : 4;
+    const long ncg = (wx + W - 1) / W, nyt = (wy + 61) / 62;
+    int zc = wz;
+    while (zc > 8 && ncg * nyt * ((wz + zc - 1) / zc) < 1024) zc = (zc + 1) / 2;
+    if (zc > zc_max) zc = zc_max;
+    a.zc = zc;
+    const long nblk = (ncg * nyt * ((wz + zc - 1) / zc) + 3) / 4;
+    if (nblk > 0x7fffffffL || (norm && nblk > max_partials)) return hipErrorInvalidValue;
+    if (W == 2) {
+        if (norm) k_diff3_slab1<true, 2><<<(int)nblk, 256, 0, stream>>>(a);
+        else k_diff3_slab1<false, 2><<<(int)nblk, 256, 0, stream>>>(a);
+    } else {
+        if (norm) k_diff3_slab1<true, 4><<<(int)nblk, 256, 0, stream>>>(a);
+        else k_diff3_slab1<false, 4><<<(int)nblk, 256, 0, stream>>>(a);
+    }
+    *nparts = (int)nblk;
+    return hipGetLastError();
+}

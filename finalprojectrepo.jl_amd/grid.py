@@ -403,12 +403,13 @@ class GlobalGrid:
 
         if not part1.can_step_τ2(Ht, Hτ, Hτ2, Hout, dHdτ):
             return False
-        # multi-rank: z-slab decompositions only (the x / y faces of a slab are physical boundaries), and enough planes
-        return all((f >> 1) == 2 for f in self.neighbors) and (not self.neighbors or self.nz >= 8)
+        # between ranks every decomposed dimension needs room for the one-cell shell next to the halos plus an interior
+        n = (self.nx, self.ny, self.nz)
+        return all(n[f >> 1] >= 8 for f in self.neighbors)
 
     def step2(self, Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq2_dev):
         """TWO pseudo-iterations: Hout <- update(update(Hτ)), dHdτ <- residual of the second, halos of Hout refreshed.
-        Hτ2 plays the reference's second work buffer: only its boundary cells (and, between ranks, its z-halo planes)
+        Hτ2 plays the reference's second work buffer: only its boundary cells (and, between ranks, its halo planes)
         are used.  Hout must carry Hτ's physical-boundary values.  sq2_dev (2 doubles, or None) receives the LOCAL
         sums of (dHdτ*norm_scale)^2 of the first and second iteration.  Fields bit-identical to two calls of step(); the
         two sums equal step()'s to ~1e-13 relative (another summation order, see include/fpr.h)."""
@@ -422,54 +423,58 @@ class GlobalGrid:
         self.step2_middle(st)
         self.step2_end(st)
 
-    # z-slab choreography of two fused iterations (the level-1 field = state after the first iteration):
-    #   begin : single-step boxes on the planes next to a z-neighbour (level 1 there, into Hτ2) -> post their exchange;
-    #           fused launch on the lower half of the planes that need no neighbour data (overlaps the exchange)
-    #   middle: join; fused launches on the two planes next to the halos (their level-1 halo plane just arrived and is
-    #           read from Hτ2 like a physical boundary) -> post the exchange of the new field's halo planes
-    #   end   : fused launch on the upper half (overlaps that exchange); join
+    # Choreography of two fused iterations between ranks, any Cartesian decomposition (level 1 = the field after the
+    # first iteration, never written except where a neighbour needs it).  The SHELL is the one-cell layer of interior
+    # cells next to a face with a neighbour (boundary_boxes: disjoint thin boxes), the CORE everything inside it:
+    #   begin : single-step launches on the shell produce level 1 there (into Hτ2) -> post the exchange of Hτ2's
+    #           planes next to the halos; a fused launch on the lower half of the core overlaps it
+    #   middle: join; fused launches on the shell boxes -- their level-1 halo cells have just arrived in Hτ2 and are read
+    #           exactly like physical-boundary cells of level 1 -> post the exchange of the new field's planes
+    #   end   : fused launch on the upper half of the core (overlaps that exchange); join
+    # Two exchanges per two iterations, as with single steps.  z-faces travel in place, x / y faces through the pack
+    # kernels; one-cell-wide x-slabs run in the narrow-box kernel (k_diff3_slab2), y- and z-slabs in the wave-tile kernel.
     def step2_begin(self, Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq2_dev):
         from . import part1
 
-        nx, ny, nz = self.nx, self.ny, self.nz
-        has_lo, has_hi = 4 in self.neighbors, 5 in self.neighbors
         coef = (dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
         if sq2_dev is not None:
             sq2_dev.zero_()
-        for on, k in ((has_lo, 1), (has_hi, nz - 2)):
-            if on:
-                part1.diffusion_3D_step_τ_box(Ht, Hτ, Hτ2, dHdτ, *coef, (1, 1, k), (nx - 1, ny - 1, k + 1), 0.0, None, 0)
+        boxes, core = self.boundary_boxes()
+        for lo, hi in boxes:
+            part1.diffusion_3D_step_τ_box(Ht, Hτ, Hτ2, dHdτ, *coef, lo, hi, 0.0, None, 0)
+        mask = 0
+        for f in self.neighbors:
+            mask |= 1 << f
         tr = self.transport()
-        works = tr.begin(Hτ2, ZFACES)
-        zl, zh = (2 if has_lo else 1), (nz - 2 if has_hi else nz - 1)
-        zmid = (zl + zh) // 2
+        works = tr.begin(Hτ2, mask)
+        (cx0, cy0, cz0), (cx1, cy1, cz1) = core
+        zmid = (cz0 + cz1) // 2
         fused = (Ht, Hτ, Hτ2, Hout, dHdτ) + coef
-        part1.diffusion_3D_step_τ2_box(*fused, (1, 1, zl), (nx - 1, ny - 1, zmid), norm_scale, sq2_dev, 0)
-        return dict(fused=fused, scale=norm_scale, sq=sq2_dev, works=works, z=(zmid, zh), lo=has_lo, hi=has_hi, out=Hout,
-                    mid=Hτ2)
+        part1.diffusion_3D_step_τ2_box(*fused, (cx0, cy0, cz0), (cx1, cy1, zmid), norm_scale, sq2_dev, 0)
+        return dict(fused=fused, scale=norm_scale, sq=sq2_dev, works=works, boxes=boxes, core=core, zmid=zmid, out=Hout,
+                    mid=Hτ2, mask=mask)
 
     def step2_middle(self, st):
         from . import part1
 
-        nx, ny, nz = self.nx, self.ny, self.nz
         tr = self.transport()
-        tr.end(st["mid"], ZFACES, st["works"])
-        if st["lo"] and st["hi"]:   # both thin slabs in one launch
-            part1.diffusion_3D_step_τ2_box(*st["fused"], (1, 1, 1), (nx - 1, ny - 1, 2), st["scale"], st["sq"], 0,
-                                           z2=(nz - 2, nz - 1))
-        else:
-            for on, k in ((st["lo"], 1), (st["hi"], nz - 2)):
-                if on:
-                    part1.diffusion_3D_step_τ2_box(*st["fused"], (1, 1, k), (nx - 1, ny - 1, k + 1), st["scale"], st["sq"], 0)
-        st["works"] = tr.begin(st["out"], ZFACES)
+        tr.end(st["mid"], st["mask"], st["works"])
+        boxes = list(st["boxes"])
+        # the two z-slabs (peeled first, same x / y extent) share one launch
+        if 4 in self.neighbors and 5 in self.neighbors:
+            (lo0, hi0), (lo1, hi1) = boxes[0], boxes[1]
+            part1.diffusion_3D_step_τ2_box(*st["fused"], lo0, hi0, st["scale"], st["sq"], 0, z2=(lo1[2], hi1[2]))
+            boxes = boxes[2:]
+        for lo, hi in boxes:
+            part1.diffusion_3D_step_τ2_box(*st["fused"], lo, hi, st["scale"], st["sq"], 0)
+        st["works"] = tr.begin(st["out"], st["mask"])
 
     def step2_end(self, st):
         from . import part1
 
-        nx, ny = self.nx, self.ny
-        zmid, zh = st["z"]
-        part1.diffusion_3D_step_τ2_box(*st["fused"], (1, 1, zmid), (nx - 1, ny - 1, zh), st["scale"], st["sq"], 0)
-        self.transport().end(st["out"], ZFACES, st["works"])
+        (cx0, cy0, cz0), (cx1, cy1, cz1) = st["core"]
+        part1.diffusion_3D_step_τ2_box(*st["fused"], (cx0, cy0, st["zmid"]), (cx1, cy1, cz1), st["scale"], st["sq"], 0)
+        self.transport().end(st["out"], st["mask"], st["works"])
 
     def step_begin(self, Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq_dev):
         """Multi-rank step, first half: boundary slabs, then the exchange of the freshly written planes is posted

@@ -150,10 +150,13 @@ def _emulated_ranks(F, oracle, dims, n, mail):
     return ranks, ng, (dx, dy, dz), (lx, ly, lz)
 
 
-@pytest.mark.parametrize("dims,n", [((1, 1, 2), (128, 18, 10)), ((1, 1, 3), (130, 33, 9)), ((1, 1, 4), (128, 16, 8))], ids=str)
-def test_fused_pair_choreography_emulated_z_slabs(fpr, oracle, dims, n):
-    """GlobalGrid.step2 (two iterations per fused launch, level-1 halo planes exchanged in between) on emulated
-    z-slab ranks equals the single-domain oracle bit for bit, including both per-iteration norms."""
+@pytest.mark.parametrize("dims,n", [((1, 1, 2), (128, 18, 10)), ((1, 1, 3), (130, 33, 9)), ((1, 1, 4), (128, 16, 8)),
+                                     ((2, 1, 1), (128, 18, 10)), ((1, 2, 1), (128, 20, 9)), ((2, 2, 1), (130, 18, 9)),
+                                     ((2, 2, 2), (128, 18, 10)), ((3, 1, 2), (128, 16, 9)), ((1, 3, 1), (256, 34, 8))], ids=str)
+def test_fused_pair_choreography_emulated_ranks(fpr, oracle, dims, n):
+    """GlobalGrid.step2 (two iterations per fused launch, level-1 halo cells exchanged in between) on emulated ranks --
+    z-slabs and the reference's x / y / xyz decompositions (part1_scaling_experiments.jl:35-41) -- equals the
+    single-domain oracle bit for bit, including both per-iteration norms."""
     F = fpr
     mail = {}
     ranks, ng, (dx, dy, dz), (lx, ly, lz) = _emulated_ranks(F, oracle, dims, n, mail)

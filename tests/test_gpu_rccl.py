@@ -135,3 +135,42 @@ def test_step_and_fused_pair_over_rccl_periodic_z(fpr, oracle, periodic_grid, n)
         assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs))
         assert np.array_equal(F.tonumpy(gA)[1:-1, 1:-1, :], A[1:-1, 1:-1, :])
         assert np.array_equal(F.tonumpy(gR), R)
+
+
+def test_fused_pair_over_rccl_periodic_xyz(fpr, oracle, periodic_grid):
+    """The general fused-pair choreography (shell boxes on all six faces, x / y planes through the library's pack
+    kernels, one-cell x-slabs in the narrow-box kernel) over the library's RCCL transport: one rank, periodic in
+    x, y and z.  Interior cells, residuals and both norms against the oracle with wrapped halos."""
+    F = fpr
+    n = (128, 24, 16)
+    gg = periodic_grid(n, (1, 1, 1))
+    nx, ny, nz = n
+    dx, dy, dz = 10.0 / (nx - 2), 10.0 / (ny - 2), 10.0 / (nz - 2)
+    D, dt = 1.0, 0.2
+    dτ = min(dx, dy, dz) ** 2 / D / 8.1
+    coef = (dτ, 1 / dt, 1 / dx, 1 / dy, 1 / dz, D / dx, D / dy, D / dz)
+    Ht = wrap(rnd(n, 21))
+    A, B, R = Ht.copy(order="F"), farr(*n), farr(*n)
+    gHt, gA, gB, gR = F.asdevice(Ht), F.asdevice(A), F.fzeros(*n), F.fzeros(*n)
+    gC = gA.clone()
+    assert gg.can_step2(gHt, gA, gB, gC, gR)
+    sq2 = F.fzeros(2)
+    for it in range(3):
+        refs = []
+        for k in range(2):
+            oracle.diffusion3d_step(Ht, A, B, R, *coef)
+            wrap(B)
+            A, B = B, A
+            refs.append(oracle.sumsq_scaled(R, dt))
+        gg.step2(gHt, gA, gB, gC, gR, *coef, dt, sq2)
+        gA, gC = gC, gA
+        got = sq2.cpu().tolist()
+        assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs))
+        loc = F.tonumpy(gA)
+        assert np.array_equal(loc[1:-1, 1:-1, 1:-1], A[1:-1, 1:-1, 1:-1])
+        for d in range(3):   # halo faces (interiors of the faces; edges / corners are not refreshed by one exchange)
+            for side in (0, -1):
+                idx = [slice(1, -1)] * 3
+                idx[d] = side
+                assert np.array_equal(loc[tuple(idx)], A[tuple(idx)])
+        assert np.array_equal(F.tonumpy(gR)[1:-1, 1:-1, 1:-1], R[1:-1, 1:-1, 1:-1])

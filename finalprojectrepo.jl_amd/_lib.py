@@ -97,6 +97,8 @@ _SIG = {
     "fpr_compute_diffusion2d": [_vp, _dp, _d, _d, _d, _dp, _i, _i],
     "fpr_compute_advection2d_x": [_vp, _dp, _d, _dp, _dp, _i, _i],
     "fpr_compute_advection2d_y": [_vp, _dp, _d, _dp, _dp, _i, _i],
+    "fpr_ns_velocity_max2d": [_vp, _dp, _d, _d, _dp, _dp, _i, _i, C.POINTER(_d)],
+    "fpr_ns_rhs2d": [_vp, _dp, _dp, _dp, _d, _d, _i, _i, _d, _d, _d, _d, _d, _dp, _dp],
 }
 # every symbol include/fpr.h declares (checked by tests/test_abi.py)
 ALL_SYMBOLS = sorted(list(_SIG) + ["fpr_last_error", "fpr_version", "fpr_get_option", "fpr_last_coarse_iters",

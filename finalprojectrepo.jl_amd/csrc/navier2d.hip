@@ -86,3 +86,129 @@ extern "C" int fpr_compute_advection2d_y(fpr_ctx* ctx, const double* T, double h
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The step around the V-cycle in TWO passes.  The reference runs, per time step, seven pointwise kernels,
+// three whole-array maxima and four whole-array broadcasts (part2.jl:190-230): about 25 sweeps over (nx, ny) arrays.
+//   pass 1  fpr_ns_velocity_max2d : velocity from the stream function (:190) folded into the three maxima compute_dt
+//                                   needs (:193-196, :76-87); vx / vy are written only if the caller wants them
+//   (host: dt, part2.jl:76-87)
+//   pass 2  fpr_ns_rhs2d          : Ra dT/dx, both diffusion terms, the four upwind advection terms (velocity
+//                                   recomputed from S) and the right-hand sides of the two semi-implicit solves
+//                                   (:220, :225) or the explicit Euler update (:229-230), for every point of the arrays
+// Every expression keeps the reference's operand order (and the library is built without FMA contraction), so the
+// results are bit-identical to the kernel-by-kernel path; maxima are order-independent.
+__global__ __launch_bounds__(256) void k_ns_velocity_max(const double* __restrict__ S, double hx, double hy,
+                                                          double* __restrict__ vx_out, double* __restrict__ vy_out, int nx,
+                                                          int ny, double* __restrict__ partials, int nblk)
+{
+    __shared__ double red[16];
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    double mv = 0.0, mx = 0.0, my = 0.0;
+    if (i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1) {
+        const size_t id = (size_t)i + (size_t)nx * j;
+        const double vx = (S[id + nx] - S[id - nx]) / (2 * hy);   // part2.jl:92
+        const double vy = -(S[id + 1] - S[id - 1]) / (2 * hx);    // part2.jl:93
+        if (vx_out) vx_out[id] = vx;
+        if (vy_out) vy_out[id] = vy;
+        mv = sqrt(vx * vx + vy * vy);                             // part2.jl:193
+        mx = fabs(vx);
+        my = fabs(vy);
+    }
+    const int b = blockIdx.x + gridDim.x * blockIdx.y;
+    mv = fpr_block_max<256>(mv, red);
+    __syncthreads();
+    mx = fpr_block_max<256>(mx, red);
+    __syncthreads();
+    my = fpr_block_max<256>(my, red);
+    if (threadIdx.x == 0 && threadIdx.y == 0) { partials[b] = mv; partials[nblk + b] = mx; partials[2 * nblk + b] = my; }
+}
+
+__global__ __launch_bounds__(256) void k_ns_max3_finish(const double* __restrict__ partials, int nblk, double* __restrict__ out)
+{
+    __shared__ double red[16];
+    double m = 0.0;
+    const double* p = partials + (size_t)blockIdx.x * nblk;
+    for (int i = threadIdx.x; i < nblk; i += 256) m = fmax(m, p[i]);
+    m = fpr_block_max<256>(m, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = m;
+}
+
+template <bool IMPLICIT>
+__global__ __launch_bounds__(256) void k_ns_rhs(const double* __restrict__ T, const double* __restrict__ W,
+                                                 const double* __restrict__ S, double hx, double hy, int nx, int ny, double Ra,
+                                                 double Pr, double k, double beta, double dt, double cT, double cW,
+                                                 bool diffuse, double* __restrict__ T_out, double* __restrict__ W_out)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= nx || j >= ny) return;
+    const size_t id = (size_t)i + (size_t)nx * j;
+    const double t = T[id], w = W[id];
+    // the reference's term arrays are @zeros and written at interior points only (part2.jl:90-137)
+    double Rd = 0.0, dT2 = 0.0, dW2 = 0.0, dTx = 0.0, dTy = 0.0, dWx = 0.0, dWy = 0.0;
+    if (i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1) {
+        const double tE = T[id + 1], tW = T[id - 1], tN = T[id + nx], tS = T[id - nx];
+        const double wE = W[id + 1], wW = W[id - 1], wN = W[id + nx], wS = W[id - nx];
+        const double hx2 = hx * hx, hy2 = hy * hy;
+        const double vx = (S[id + nx] - S[id - nx]) / (2 * hy);   // :92
+        const double vy = -(S[id + 1] - S[id - 1]) / (2 * hx);    // :93
+        Rd = Ra * (tE - tW) / (2 * hx);                            // :101
+        if (diffuse) {                                             // :205-208 (opt.beta not approximately 1)
+            dT2 = k * (((tE - 2 * t) + tW) / hx2 + ((tN - 2 * t) + tS) / hy2);    // :109-110
+            dW2 = Pr * (((wE - 2 * w) + wW) / hx2 + ((wN - 2 * w) + wS) / hy2);
+        }
+        dTx = vx > 0 ? vx * (t - tW) / hx : vx * (tE - t) / hx;    // :118-122
+        dTy = vy > 0 ? vy * (t - tS) / hy : vy * (tN - t) / hy;    // :130-134
+        dWx = vx > 0 ? vx * (w - wW) / hx : vx * (wE - w) / hx;
+        dWy = vy > 0 ? vy * (w - wS) / hy : vy * (wN - w) / hy;
+    }
+    if constexpr (IMPLICIT) {
+        T_out[id] = -cT * (t + dt * (((1.0 - beta) * dT2 - dTx) - dTy));                    // :220
+        W_out[id] = -cW * (w + dt * ((((1.0 - beta) * dW2 - dWx) - dWy) - Pr * Rd));        // :225
+    } else {
+        T_out[id] = t + dt * ((dT2 - dTx) - dTy);                                           // :229
+        W_out[id] = w + dt * (((dW2 - dWx) - dWy) - Pr * Rd);                               // :230
+    }
+}
+
+// pass 1.  vmax_host[3] = maximum(v), maximum(abs.(vx)), maximum(abs.(vy)) (part2.jl:77,82); vx / vy may be NULL.
+// Synchronises the compute stream (the reference's maximum() does, too).
+extern "C" int fpr_ns_velocity_max2d(fpr_ctx* ctx, const double* S, double hx, double hy, double* vx, double* vy, int nx, int ny,
+                                     double* vmax_host)
+{
+    NS_CHECK(S && vmax_host)
+    const dim3 g = g2(nx, ny);
+    const int nblk = (int)(g.x * g.y);
+    FPR_REQUIRE(ctx, 3L * nblk <= FPR_MAX_PARTIALS, "grid too large for the partial buffer");
+    k_ns_velocity_max<<<g, dim3(64, 4), 0, ctx->stream[0]>>>(S, hx, hy, vx, vy, nx, ny, ctx->partials, nblk);
+    FPR_CHECK_LAUNCH(ctx);
+    k_ns_max3_finish<<<3, 256, 0, ctx->stream[0]>>>(ctx->partials, nblk, ctx->scalars + 8);
+    FPR_CHECK_LAUNCH(ctx);
+    FPR_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + 16, ctx->scalars + 8, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream[0]));
+    FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
+    for (int q = 0; q < 3; ++q) vmax_host[q] = ctx->host_scalars[16 + q];
+    return FPR_OK;
+}
+
+// pass 2.  beta > 0: T_out / W_out = right-hand sides of the semi-implicit solves with c = 1/(beta dt) and c/Pr
+// (part2.jl:219-225); beta == 0: the explicit Euler update (:229-230).  T must already carry its boundary conditions
+// (apply_boundary_conditions!, :199).  T_out / W_out must not alias T, W, S.
+extern "C" int fpr_ns_rhs2d(fpr_ctx* ctx, const double* T, const double* W, const double* S, double hx, double hy, int nx, int ny,
+                            double Ra, double Pr, double k, double beta, double dt, double* T_out, double* W_out)
+{
+    NS_CHECK(T && W && S && T_out && W_out)
+    FPR_REQUIRE(ctx, T_out != T && T_out != W && T_out != S && W_out != T && W_out != W && W_out != S && T_out != W_out,
+                "outputs must be buffers of their own");
+    // `opt.beta ≉ 1.0` (:205): Julia's isapprox, rtol = sqrt(eps)
+    const bool diffuse = !(fabs(beta - 1.0) <= 1.4901161193847656e-08 * fmax(fabs(beta), 1.0));
+    if (beta > 0.0) {
+        const double c = 1.0 / (beta * dt);   // :219
+        k_ns_rhs<true><<<g2(nx, ny), dim3(64, 4), 0, ctx->stream[0]>>>(T, W, S, hx, hy, nx, ny, Ra, Pr, k, beta, dt, c, c / Pr,
+                                                                          diffuse, T_out, W_out);
+    } else {
+        k_ns_rhs<false><<<g2(nx, ny), dim3(64, 4), 0, ctx->stream[0]>>>(T, W, S, hx, hy, nx, ny, Ra, Pr, k, beta, dt, 0.0, 0.0,
+                                                                           diffuse, T_out, W_out);
+    }
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}

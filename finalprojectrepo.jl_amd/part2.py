@@ -123,9 +123,30 @@ def compute_dt(v, vx, vy, dt_dif, a_dif, a_adv, h, beta):
     return dt_adv if beta >= 0.5 else min(dt_dif, dt_adv)
 
 
-def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_steps=None, trace=None):
+def velocity_and_maxima(S, hx, hy, vx=None, vy=None):
+    """Pass 1 of the fused step: compute_velocity! (part2.jl:190) folded into the three maxima compute_dt needs
+    (:193-196, :76-87).  Returns (maximum(v), maximum(abs.(vx)), maximum(abs.(vy))); vx / vy are written on request."""
+    out = (C.c_double * 3)()
+    _ctx().call("fpr_ns_velocity_max2d", fptr(S, 2), hx, hy, fptr(vx, 2) if vx is not None else None,
+                fptr(vy, 2) if vy is not None else None, *S.shape, out)
+    return out[0], out[1], out[2]
+
+
+def step_rhs_(T, W, S, hx, hy, Ra, Pr, k, beta, dt, T_out, W_out):
+    """Pass 2 of the fused step (part2.jl:202-230): all pointwise terms and the right-hand sides of the two semi-implicit
+    solves (beta > 0) or the explicit Euler update (beta == 0), bit-identical to the kernel-by-kernel path."""
+    _ctx().call("fpr_ns_rhs2d", fptr(T, 2), fptr(W, 2), fptr(S, 2), hx, hy, *T.shape, Ra, Pr, k, beta, dt, fptr(T_out, 2),
+                fptr(W_out, 2))
+
+
+def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_steps=None, trace=None, fused=True,
+                     timing=None):
     """part2.jl:140-262.  trace: optional list; one dict per time step is appended with the step's dt and the
-    residual histories of its multigrid solves (diagnostics for the parity tests; costs nothing when None)."""
+    residual histories of its multigrid solves (diagnostics for the parity tests; costs nothing when None).
+    fused (default): the step around the three multigrid solves runs as two passes (velocity_and_maxima, step_rhs_)
+    instead of the reference's seven kernels, three maxima and four broadcasts -- same numbers, bit for bit.
+    timing: optional dict; receives the seconds spent inside the multigrid solves ("mg_s") of the TIMED steps (from the
+    fourth on, :182-184), with a stream synchronisation around every solve (diagnostic mode, slightly slower)."""
     import torch
 
     opt = opt if opt is not None else SimIn_t()
@@ -133,9 +154,10 @@ def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_s
     h = 1.0 / (ny - 1.0)
     width = (nx - 1.0) / (ny - 1.0)
     dt_dif = (opt.a_dif * min(h, h) ** 2) / max(opt.k, opt.Pr)
-    names = "S vx vy v T dT2 dTx dTy T_rhs W dW2 dWx dWy W_rhs Ra_dTdx".split()
+    names = ("S T T_rhs W W_rhs" if fused else "S vx vy v T dT2 dTx dTy T_rhs W dW2 dWx dWy W_rhs Ra_dTdx").split()
     A = {n: fzeros(nx, ny) for n in names}
-    S, vx, vy, T, W = A["S"], A["vx"], A["vy"], A["T"], A["W"]
+    S, T, W = A["S"], A["T"], A["W"]
+    vx, vy = A.get("vx"), A.get("vy")
     init_array_(T, opt.T_init_strategy, h, width, opt)
     init_array_(W, opt.W_init_strategy, h, width, opt)
     prealloc = mg.preallocate_buffers(nx, ny)
@@ -155,6 +177,13 @@ def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_s
             rec = {} if trace is not None else None
 
             def solve(name, u, f, c, bcs):
+                if timing is not None and step >= 3:
+                    ctx.synchronize()
+                    t_s = time.time()
+                    mg.MGsolve_2DPoisson_(u, f, h, c, opt.tol, opt.niters, bcs, opt=mgopt, prealloc_dict=prealloc)
+                    ctx.synchronize()
+                    timing["mg_s"] = timing.get("mg_s", 0.0) + time.time() - t_s
+                    return
                 if rec is None:
                     mg.MGsolve_2DPoisson_(u, f, h, c, opt.tol, opt.niters, bcs, opt=mgopt, prealloc_dict=prealloc)
                 else:
@@ -163,28 +192,47 @@ def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_s
                     rec[name] = {"r_rms": r, "history": hist, "f_rms": frms, "coarse_iters": cit, "c": c}
 
             solve("S", S, W, 0.0, False)  # :187
-            compute_velocity_(S, hx, hy, vx, vy)  # :190
-            torch.sqrt(vx * vx + vy * vy, out=A["v"])  # :193
-            dt = compute_dt(A["v"], vx, vy, dt_dif, opt.a_dif, opt.a_adv, h, opt.beta)  # :196
-            mg.apply_boundary_conditions_(T)  # :199
-            compute_Ra_dTdx_(opt.Ra, hx, T, A["Ra_dTdx"])  # :202
-            if not math.isclose(opt.beta, 1.0):  # :205-208
-                compute_diffusion2d_(T, hx, hy, opt.k, A["dT2"])
-                compute_diffusion2d_(W, hx, hy, opt.Pr, A["dW2"])
-            compute_advection2d_x_(T, hx, vx, A["dTx"])  # :211-214
-            compute_advection2d_y_(T, hy, vy, A["dTy"])
-            compute_advection2d_x_(W, hx, vx, A["dWx"])
-            compute_advection2d_y_(W, hy, vy, A["dWy"])
-            if opt.beta > 0.0:  # :217-226
-                c = 1.0 / (opt.beta * dt)
-                A["T_rhs"].copy_(-c * (T + dt * ((1.0 - opt.beta) * A["dT2"] - A["dTx"] - A["dTy"])))
-                solve("T", T, A["T_rhs"], c, True)  # :221
-                c = c / opt.Pr
-                A["W_rhs"].copy_(-c * (W + dt * ((1.0 - opt.beta) * A["dW2"] - A["dWx"] - A["dWy"] - opt.Pr * A["Ra_dTdx"])))
-                solve("W", W, A["W_rhs"], c, False)  # :226
-            else:  # :229-230
-                T.copy_(T + dt * (A["dT2"] - A["dTx"] - A["dTy"]))
-                W.copy_(W + dt * (A["dW2"] - A["dWx"] - A["dWy"] - opt.Pr * A["Ra_dTdx"]))
+            if fused:
+                v_max, vx_max, vy_max = velocity_and_maxima(S, hx, hy)  # :190-193
+                if v_max == 0:  # compute_dt, :76-87
+                    dt = dt_dif
+                else:
+                    dt_adv = opt.a_adv * min(h / vx_max, h / vy_max)
+                    dt = dt_adv if opt.beta >= 0.5 else min(dt_dif, dt_adv)
+                mg.apply_boundary_conditions_(T)  # :199
+                step_rhs_(T, W, S, hx, hy, opt.Ra, opt.Pr, opt.k, opt.beta, dt, A["T_rhs"], A["W_rhs"])  # :202-230
+                if opt.beta > 0.0:
+                    c = 1.0 / (opt.beta * dt)
+                    solve("T", T, A["T_rhs"], c, True)  # :221
+                    c = c / opt.Pr
+                    solve("W", W, A["W_rhs"], c, False)  # :226
+                else:  # the explicit update landed in the spare buffers: they become T and W (:229-230)
+                    T, A["T_rhs"] = A["T_rhs"], T
+                    W, A["W_rhs"] = A["W_rhs"], W
+                    A["T"], A["W"] = T, W
+            else:
+                compute_velocity_(S, hx, hy, vx, vy)  # :190
+                torch.sqrt(vx * vx + vy * vy, out=A["v"])  # :193
+                dt = compute_dt(A["v"], vx, vy, dt_dif, opt.a_dif, opt.a_adv, h, opt.beta)  # :196
+                mg.apply_boundary_conditions_(T)  # :199
+                compute_Ra_dTdx_(opt.Ra, hx, T, A["Ra_dTdx"])  # :202
+                if not math.isclose(opt.beta, 1.0):  # :205-208
+                    compute_diffusion2d_(T, hx, hy, opt.k, A["dT2"])
+                    compute_diffusion2d_(W, hx, hy, opt.Pr, A["dW2"])
+                compute_advection2d_x_(T, hx, vx, A["dTx"])  # :211-214
+                compute_advection2d_y_(T, hy, vy, A["dTy"])
+                compute_advection2d_x_(W, hx, vx, A["dWx"])
+                compute_advection2d_y_(W, hy, vy, A["dWy"])
+                if opt.beta > 0.0:  # :217-226
+                    c = 1.0 / (opt.beta * dt)
+                    A["T_rhs"].copy_(-c * (T + dt * ((1.0 - opt.beta) * A["dT2"] - A["dTx"] - A["dTy"])))
+                    solve("T", T, A["T_rhs"], c, True)  # :221
+                    c = c / opt.Pr
+                    A["W_rhs"].copy_(-c * (W + dt * ((1.0 - opt.beta) * A["dW2"] - A["dWx"] - A["dWy"] - opt.Pr * A["Ra_dTdx"])))
+                    solve("W", W, A["W_rhs"], c, False)  # :226
+                else:  # :229-230
+                    T.copy_(T + dt * (A["dT2"] - A["dTx"] - A["dTy"]))
+                    W.copy_(W + dt * (A["dW2"] - A["dWx"] - A["dWy"] - opt.Pr * A["Ra_dTdx"]))
         if rec is not None:
             rec["dt"] = dt
             trace.append(rec)

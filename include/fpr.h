@@ -289,6 +289,16 @@ int fpr_compute_advection2d_x(fpr_ctx* ctx, const double* T, double hx, const do
 int fpr_compute_advection2d_y(fpr_ctx* ctx, const double* T, double hy, const double* vy, double* dTy, int nx, int ny);
 /* maximum(abs.(x)) -- part2.jl:77,82 */
 int fpr_absmax(fpr_ctx* ctx, const double* x, size_t n, double* out_host);
+/* The same step in two passes instead of 7 kernels + 3 maxima + 4 broadcasts (part2.jl:190-230), bit-identical:
+ * pass 1: velocity from S (:190) + maximum(v), maximum(abs.(vx)), maximum(abs.(vy)) (:193-196 via :76-87) into
+ * vmax_host[3]; vx / vy (nullable) are written only on request.  Synchronises like the reference's maximum().
+ * pass 2: Ra dT/dx, diffusion and upwind advection terms of T and W (velocity recomputed from S) and, for beta > 0, the
+ * right-hand sides of the two semi-implicit solves with c = 1/(beta dt) and c/Pr (:219-225), for beta == 0 the explicit
+ * Euler update (:229-230), at every point of the arrays.  T must carry its boundary conditions (:199) already. */
+int fpr_ns_velocity_max2d(fpr_ctx* ctx, const double* S, double hx, double hy, double* vx, double* vy, int nx, int ny,
+                          double* vmax_host);
+int fpr_ns_rhs2d(fpr_ctx* ctx, const double* T, const double* W, const double* S, double hx, double hy, int nx, int ny,
+                 double Ra, double Pr, double k, double beta, double dt, double* T_out, double* W_out);
 
 #ifdef __cplusplus
 }

@@ -528,4 +528,19 @@ compute_diffusion2d!(T::DA, hx, hy, k, dT2::DA) = check(ccall((:fpr_compute_diff
 compute_advection2d_x!(T::DA, hx, vx::DA, dTx::DA) = check(ccall((:fpr_compute_advection2d_x, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint), ctx(), p(T), hx, p(vx), p(dTx), size(T, 1), size(T, 2)))
 compute_advection2d_y!(T::DA, hy, vy::DA, dTy::DA) = check(ccall((:fpr_compute_advection2d_y, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint), ctx(), p(T), hy, p(vy), p(dTy), size(T, 1), size(T, 2)))
 
+"Pass 1 of the fused step around the V-cycle: velocity (part2.jl:190) + the three maxima of compute_dt (:76-87, :193-196)."
+function velocity_and_maxima!(S::DA, hx, hy; vx::Union{DA,Nothing} = nothing, vy::Union{DA,Nothing} = nothing)
+    m = zeros(Cdouble, 3)
+    check(ccall((:fpr_ns_velocity_max2d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}),
+                ctx(), p(S), hx, hy, vx === nothing ? Ptr{Cdouble}(C_NULL) : p(vx), vy === nothing ? Ptr{Cdouble}(C_NULL) : p(vy),
+                size(S, 1), size(S, 2), m))
+    return m[1], m[2], m[3]
+end
+"Pass 2: every pointwise term of part2.jl:202-214 and the right-hand sides of :220 / :225 (beta > 0) or the Euler update of :229-230."
+step_rhs!(T_out::DA, W_out::DA, T::DA, W::DA, S::DA, hx, hy, Ra, Pr, k, beta, dt) =
+    check(ccall((:fpr_ns_rhs2d, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Cint, Cint, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble,
+                 Ptr{Cdouble}, Ptr{Cdouble}),
+                ctx(), p(T), p(W), p(S), hx, hy, size(T, 1), size(T, 2), Ra, Pr, k, beta, dt, p(T_out), p(W_out)))
+
 end # module

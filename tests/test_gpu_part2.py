@@ -216,3 +216,38 @@ def test_config5_semi_implicit_2049sq(fpr, oracle):
     # Dirichlet columns of T (part2_utils.jl:28-29) are re-imposed before every V-cycle and never touched by it
     assert np.all(out.T[:, 0] == 1.0) and np.all(out.T[:, -1] == 0.0)
     assert np.all(out.S[0, :] == 0.0) and np.all(out.S[:, 0] == 0.0)   # S keeps its zero boundary (x = 0 start)
+
+
+@pytest.mark.parametrize("beta", [0.0, 0.5, 1.0])
+def test_fused_step_equals_kernel_by_kernel_step(fpr, oracle, beta):
+    """The two-pass step (fpr_ns_velocity_max2d + fpr_ns_rhs2d) against the reference's kernel-by-kernel sequence
+    (part2.jl:190-230 on the seven pointwise kernels): time steps and fields bit for bit over three steps, for the
+    explicit, the semi-implicit and the fully implicit (no diffusion terms, :205) branch."""
+    import warnings
+
+    F, p2 = fpr, fpr.part2
+    outs = []
+    for fused in (True, False):
+        opt = p2.SimIn_t()
+        opt.nx, opt.ny, opt.beta, opt.tol, opt.Pr, opt.niters, opt.ttot = 257, 65, beta, 1.0e-7, 1.0e-1, 20, 1e9
+        opt.W_init_strategy = p2.random
+        tr = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = p2.navier_stokes_2D(opt=opt, verbose=False, max_steps=3, trace=tr, fused=fused)
+        outs.append((out, [r["dt"] for r in tr]))
+    (a, dta), (b, dtb) = outs
+    assert dta == dtb
+    for name in ("T", "W", "S"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    # pass 1 alone: maxima and (optional) velocity arrays against the oracle
+    S = load_bin("S.bin")
+    nx, ny = S.shape
+    h = 1.0 / (ny - 1.0)
+    vx, vy = farr(nx, ny), farr(nx, ny)
+    oracle.compute_velocity(S, h, h, vx, vy)
+    gvx, gvy = F.fzeros(nx, ny), F.fzeros(nx, ny)
+    m = p2.velocity_and_maxima(F.asdevice(S), h, h, gvx, gvy)
+    assert np.array_equal(F.tonumpy(gvx), vx) and np.array_equal(F.tonumpy(gvy), vy)
+    assert m == (np.sqrt(vx * vx + vy * vy).max(), np.abs(vx).max(), np.abs(vy).max())
+    assert p2.velocity_and_maxima(F.asdevice(S), h, h) == m

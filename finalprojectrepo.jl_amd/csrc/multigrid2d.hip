@@ -1041,6 +1041,12 @@ __global__ __launch_bounds__(256) void k_cg_update_f(double* __restrict__ x, dou
     __shared__ double red[16];
     __shared__ double s_alpha;
     if (st->done) return;
+    // first element of this thread's grid-stride sequence: loaded before alpha is known (the loads overlap the reduction
+    // of the dot-product partials; coarse grids have at most one element per thread)
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    double x0 = 0.0, p0 = 0.0, r0 = 0.0, q0 = 0.0;
+    if (i0 < n) { x0 = x[i0]; p0 = p[i0]; r0 = r[i0]; q0 = ph[i0]; }
     const double pq = fpr_sum_partials_256(pq_partials, npq, red);
     if (threadIdx.x == 0) {
         const double alpha = st->rho2[it & 1] / pq;  // krylov.jl:69
@@ -1049,9 +1055,14 @@ __global__ __launch_bounds__(256) void k_cg_update_f(double* __restrict__ x, dou
     }
     __syncthreads();
     const double alpha = s_alpha;
-    const size_t stride = (size_t)gridDim.x * 256;
     double acc = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    if (i0 < n) {
+        x[i0] = x0 + alpha * p0;
+        const double rn = r0 - alpha * q0;
+        r[i0] = rn;
+        acc += rn * rn;
+    }
+    for (size_t i = i0 + stride; i < n; i += stride) {
         x[i] = x[i] + alpha * p[i];
         const double rn = r[i] - alpha * ph[i];
         r[i] = rn;
@@ -1090,6 +1101,104 @@ __global__ __launch_bounds__(256) void k_cg_p_f(double* __restrict__ p, const do
     const double beta = s_beta;
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = r[i] + beta * p[i];  // krylov.jl:85
+}
+
+// ---- CG iteration in TWO dependent launches ---------------------------------------------------------------
+// k_cg_pmv_f (this kernel) -> k_cg_update_f.  The direction update p = r + beta p of iteration it-1 (krylov.jl:85)
+// moves into the matvec of iteration it: every workgroup derives ||r||, the exit test and beta from the r.r partials
+// of the previous iteration (as k_cg_p_f does), forms the new p on its 32 x 8 tile plus a one-point ring (the ring is
+// recomputed, not communicated: p is double-buffered, nobody reads what a neighbour is writing), stores the tile,
+// applies the operator from the LDS image and reduces p .* p_hat.  Same operations on the same operands as the
+// three-launch form: x, r, p, the iteration count and the returned residual are bit-identical.
+constexpr int CGX = BX, CGY = BY;   // the tiles of k_cg_matvec_dot: identical dot-product partials, identical alpha
+__global__ __launch_bounds__(256) void k_cg_pmv_f(const double* __restrict__ p_old, double* __restrict__ p_new,
+                                                   const double* __restrict__ r, double* __restrict__ ph, int nx, int ny,
+                                                   double hx2, double hy2, double c, double* __restrict__ pq_partials,
+                                                   const double* __restrict__ rr_partials, int nrr,
+                                                   FprSolveState* __restrict__ st, int it, double N)
+{
+    __shared__ double red[16];
+    __shared__ double s_beta;
+    __shared__ int s_conv;
+    __shared__ double tile[CGY + 2][CGX + 2];
+    if (st->done) return;
+    const int tid = threadIdx.x + CGX * threadIdx.y;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int i0 = blockIdx.x * CGX, j0 = blockIdx.y * CGY;
+    // operands first: their loads do not depend on beta and overlap the reduction of the r.r partials below
+    const int i = i0 + tx, j = j0 + ty;
+    const bool own = i < nx && j < ny;
+    const size_t id = (size_t)(own ? i : 0) + (size_t)nx * (own ? j : 0);
+    const double p_own = p_old[id], r_own = it > 0 ? r[id] : 0.0;
+    constexpr int NRING = 2 * (CGX + 2) + 2 * CGY;   // bottom row, top row, left column, right column
+    int hx = 0, hy = 0;
+    if (tid < CGX + 2) { hx = tid; hy = 0; }
+    else if (tid < 2 * (CGX + 2)) { hx = tid - (CGX + 2); hy = CGY + 1; }
+    else if (tid < 2 * (CGX + 2) + CGY) { hx = 0; hy = tid - 2 * (CGX + 2) + 1; }
+    else if (tid < NRING) { hx = CGX + 1; hy = tid - 2 * (CGX + 2) - CGY + 1; }
+    const int ri = i0 + hx - 1, rj = j0 + hy - 1;
+    const bool ring = tid < NRING && ri >= 0 && rj >= 0 && ri < nx && rj < ny;
+    const size_t rid = (size_t)(ring ? ri : 0) + (size_t)nx * (ring ? rj : 0);
+    const double p_ring = p_old[rid], r_ring = it > 0 ? r[rid] : 0.0;
+    double beta = 0.0;
+    if (it > 0) {   // exit test and beta of iteration it-1 (krylov.jl:73-84)
+        double sacc = 0.0;   // fpr_sum_partials_256 for a 64 x 4 block: strided accumulation by linear thread id
+        for (int q = tid; q < nrr; q += 256) sacc += rr_partials[q];
+        const double rr = fpr_block_sum<256>(sacc, red);
+        if (tid == 0) {
+            const double normr = sqrt(rr);
+            const int conv = normr < st->thresh;              // krylov.jl:76
+            const double rho_old = st->rho2[(it - 1) & 1];
+            const double b = rr / rho_old;                    // krylov.jl:83-84
+            s_conv = conv;
+            s_beta = b;
+            if (blockIdx.x == 0 && blockIdx.y == 0) {
+                st->iters = it;
+                st->last_rms = sqrt(rr / N);                  // krylov.jl:90
+                if (conv) st->done = 1;
+                else { st->rho2[it & 1] = rr; st->rho_old = rho_old; st->rho = rr; st->beta = b; }
+            }
+        }
+        __syncthreads();
+        if (s_conv) return;
+        beta = s_beta;
+    }
+    // krylov.jl:85 (p = r = b before the first iteration)
+    tile[ty + 1][tx + 1] = own ? (it > 0 ? r_own + beta * p_own : p_own) : 0.0;
+    if (tid < NRING) tile[hy][hx] = ring ? (it > 0 ? r_ring + beta * p_ring : p_ring) : 0.0;
+    __syncthreads();
+    double acc = 0.0;
+    if (own) {
+        const double t = tile[ty + 1][tx + 1];
+        p_new[id] = t;
+        double q;
+        if (i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1) {
+            q = (((tile[ty + 1][tx + 2] - 2 * t) + tile[ty + 1][tx]) / hx2 + ((tile[ty + 2][tx + 1] - 2 * t) + tile[ty][tx + 1]) / hy2) - c * t;   // lap_at
+            ph[id] = q;
+        } else {
+            q = ph[id];   // boundary of p_hat keeps b's values (krylov.jl:61, 68)
+        }
+        acc = t * q;
+    }
+    const double sblk = fpr_block_sum<256>(acc, red);
+    if (tid == 0) pq_partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
+}
+
+// exit test of the LAST enqueued iteration (its successor's k_cg_pmv_f would have made it): one workgroup
+__global__ __launch_bounds__(256) void k_cg_tail_f(const double* __restrict__ rr_partials, int nrr, FprSolveState* __restrict__ st,
+                                                    int it, double N)
+{
+    __shared__ double red[16];
+    if (st->done) return;
+    const double rr = fpr_sum_partials_256(rr_partials, nrr, red);
+    if (threadIdx.x == 0) {
+        const double normr = sqrt(rr);
+        const double rho_old = st->rho2[(it - 1) & 1];
+        st->iters = it;
+        st->last_rms = sqrt(rr / N);
+        if (normr < st->thresh) st->done = 1;
+        else { st->rho2[it & 1] = rr; st->rho_old = rho_old; st->rho = rr; st->beta = rr / rho_old; }
+    }
 }
 
 // p .= r + beta p  (krylov.jl:85)
@@ -1452,23 +1561,23 @@ extern "C" int fpr_bc2d(fpr_ctx* ctx, double* T, int nx, int ny)
 }
 
 // ---- CG ---------------------------------------------------------------------------------------------
-struct CgWork { double *r, *p, *ph, *x; size_t n; };
+struct CgWork { double *r, *p, *ph, *x, *p2; size_t n; };
 
 static int cg_work(fpr_ctx* ctx, size_t n, CgWork* w)
 {
-    // four work vectors (krylov.jl:59-62), kept by the context and grown on demand
-    if (ctx->cg_cap < 4 * n) {
+    // four work vectors (krylov.jl:59-62) + the second p of the two-launch iteration, kept by the context
+    if (ctx->cg_cap < 5 * n) {
         if (ctx->cg_buf) {
             FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
             FPR_HIP(ctx, hipFree(ctx->cg_buf));
             ctx->cg_buf = nullptr;
             ctx->cg_cap = 0;
         }
-        FPR_HIP(ctx, hipMalloc(&ctx->cg_buf, 4 * n * sizeof(double)));
-        ctx->cg_cap = 4 * n;
+        FPR_HIP(ctx, hipMalloc(&ctx->cg_buf, 5 * n * sizeof(double)));
+        ctx->cg_cap = 5 * n;
     }
     double* b = ctx->cg_buf;
-    w->r = b; w->p = b + n; w->ph = b + 2 * n; w->x = b + 3 * n; w->n = n;
+    w->r = b; w->p = b + n; w->ph = b + 2 * n; w->x = b + 3 * n; w->p2 = b + 4 * n; w->n = n;
     return FPR_OK;
 }
 
@@ -1490,13 +1599,25 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
     k_state_init<<<1, 1, 0, s>>>(ctx->state, ctx->scalars + 2, tol, (double)N, 1);
     FPR_CHECK_LAUNCH(ctx);
     const int chunk = 64;
-    const bool fused = fpr_opt(ctx, "cg_fused", 1) != 0;
+    // cg_fused: 2 (default) = two dependent launches per iteration, 1 = three, 0 = five (one per operation)
+    const long fused = fpr_opt(ctx, "cg_fused", 2);
+    const dim3 gcg((nx + CGX - 1) / CGX, (ny + CGY - 1) / CGY);
+    const int npcg = (int)(gcg.x * gcg.y);
+    if (npcg > FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
     int done_iters = 0;
     ctx->state_h->done = 0; ctx->state_h->iters = 0; ctx->state_h->last_rms = 0.0;
     while (done_iters < Nmax) {
         const int m = (Nmax - done_iters < chunk) ? Nmax - done_iters : chunk;
         for (int i = 0; i < m; ++i) {
             const int it = done_iters + i;
+            if (fused == 2) {
+                const double* pin = (it & 1) ? w.p2 : w.p;
+                double* pout = (it & 1) ? w.p : w.p2;
+                k_cg_pmv_f<<<gcg, blk2, 0, s>>>(pin, pout, w.r, w.ph, nx, ny, hx * hx, hy * hy, c, ctx->partials, ctx->partials2, fg,
+                                               ctx->state, it, (double)N);
+                k_cg_update_f<<<fg, 256, 0, s>>>(w.x, w.r, pout, w.ph, N, ctx->partials, npcg, ctx->partials2, ctx->state, it);
+                continue;
+            }
             k_cg_matvec_dot<<<g2, blk2, 0, s>>>(w.p, w.ph, nx, ny, hx * hx, hy * hy, c, ctx->partials, ctx->state);
             if (fused) {
                 k_cg_update_f<<<fg, 256, 0, s>>>(w.x, w.r, w.p, w.ph, N, ctx->partials, np2, ctx->partials2, ctx->state, it);
@@ -1508,8 +1629,9 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
                 k_cg_p<<<fg, 256, 0, s>>>(w.p, w.r, N, ctx->state);
             }
         }
-        FPR_CHECK_LAUNCH(ctx);
         done_iters += m;
+        if (fused == 2) k_cg_tail_f<<<1, 256, 0, s>>>(ctx->partials2, fg, ctx->state, done_iters, (double)N);
+        FPR_CHECK_LAUNCH(ctx);
         if (int rc = read_state(ctx)) return rc;
         if (ctx->state_h->done) break;
     }

@@ -132,6 +132,33 @@ def test_cg_matches_oracle(fpr, oracle):
     assert np.abs(F.tonumpy(x) - xr).max() <= 1e-9 * np.abs(xr).max()
 
 
+@pytest.mark.parametrize("shape,nmax", [((257, 257), 700), ((66, 66), 1000), ((33, 17), 12), ((130, 35), 5), ((257, 65), 64),
+                                         ((65, 257), 65), ((40, 9), 129)], ids=str)
+def test_cg_launch_forms_agree_bit_for_bit(fpr, shape, nmax):
+    """cg! as two dependent launches per iteration (default: the direction update rides in the next matvec), three, or
+    five (one kernel per operation): the same operations on the same operands -- x, the returned residual and the
+    iteration count are identical, whether the solve converges, stops at Nmax, or crosses a host-poll boundary (64)."""
+    F, mg = fpr, fpr.multigrid
+    c = F.ctx()
+    b = rnd(shape, 77)
+    if nmax > 100:   # a consistent system that converges
+        b[0, :] = b[-1, :] = 0.0
+        b[:, 0] = b[:, -1] = 0.0
+    outs = []
+    try:
+        for form in (2, 1, 0):
+            c.set_option("cg_fused", form)
+            x = F.asdevice(np.full(shape, 3.0))
+            r, it = mg.cg_(x, F.asdevice(b), 0.05, 0.07, 0.9, 1e-7, nmax, return_iters=True)
+            outs.append((r, it, F.tonumpy(x)))
+    finally:
+        c.set_option("cg_fused", 2)
+    for r, it, x in outs[1:]:
+        assert it == outs[0][1] and r == outs[0][0]
+        assert np.array_equal(x, outs[0][2])
+    assert outs[0][1] <= nmax and np.isfinite(outs[0][2]).all()
+
+
 @pytest.mark.parametrize("solver", ["jacobi", "conjugate_gradient"])
 @pytest.mark.parametrize("bc,c", [(False, 0.0), (True, 78.66)])
 @pytest.mark.parametrize("shape,css", [((257, 65), 5), ((129, 129), 9), ((65, 65), 65)], ids=str)

@@ -491,6 +491,35 @@ def main():
         out["roofline_single"] = r2
         legs["single_steps"] = {"ms_per_step": e2 / K * 1e3, "value_GBs": A_EFF_BYTES * cells * K / e2 / 1e9,
                                 "kernel_ms": r2["kernel_ms"], "launches": r2["launches"]}
+        # third leg: fused pairs WITHOUT storing dHdtau -- what the native solver loop (fpr_diffusion3d_solve) runs: it needs
+        # the residual's norm every iteration and the residual array only when it returns.  24 B per cell and launch;
+        # not part of `value` (the step of the metric writes both outputs of the reference's kernel).
+        ctx.call("fpr_kernel_timer", 1)
+        import ctypes as C
+        state["cur"], state["parity"] = Hτ, 0
+        fp = F._lib.fptr
+        def pair_nores(nsteps):
+            for i in range(nsteps // 2):
+                outb = Hτ3 if state["cur"] is Hτ else Hτ
+                ctx.call("fpr_diffusion3d_step2", fp(Ht, 3), fp(state["cur"], 3), fp(Hτ2, 3), fp(outb, 3), None, n, n, n, *coef, dt,
+                         sq[2 * i:2 * i + 2].data_ptr())
+                state["cur"] = outb
+        pair_nores(W + (W & 1))
+        barrier()
+        ctx.call("fpr_kernel_timer", 1)
+        t0 = time.perf_counter()
+        pair_nores(K)
+        barrier()
+        e3 = time.perf_counter() - t0
+        ms3, cnt3 = timer_read(ctx, KT_STEP2)
+        ctx.call("fpr_kernel_timer", 0)
+        k3 = ms3 / max(cnt3, 1)
+        nb = 24.0 * cells
+        legs["fused_pairs_no_residual_store"] = {
+            "ms_per_step": e3 / max(2 * (K // 2), 1) * 1e3, "value_GBs": A_EFF_BYTES * cells * 2 * (K // 2) / e3 / 1e9,
+            "kernel_ms": k3, "launches": cnt3, "bytes_per_launch": nb,
+            "achieved": nb / (k3 * 1e-3) / 1e9 if k3 > 0 else 0.0, "frac": nb / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS if k3 > 0 else 0.0,
+            "note": "read Htau, read Ht, write the new field; both norms reduced; dHdtau not materialised (solver loop mode)"}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             try:

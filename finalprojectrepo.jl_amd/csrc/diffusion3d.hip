@@ -114,7 +114,7 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
                       int stream_sel, int zlo2 = 0, int zhi2 = 0)
 {
     if (!ctx) return FPR_ERR_INVALID;
-    FPR_REQUIRE(ctx, Ht && A && B && C && dH, "null field pointer");
+    FPR_REQUIRE(ctx, Ht && A && B && C, "null field pointer");   // dH may be null: residual not stored
     FPR_REQUIRE(ctx, A != C && B != C && A != B, "Htau, Hmid and Hout must be three distinct buffers");
     FPR_REQUIRE(ctx, stream_sel == 0 || stream_sel == 1, "stream_sel");
     FPR_REQUIRE(ctx, diff3_fuse2_ok(ctx, Ht, A, B, C, dH, nx, ny, nz), "problem not supported by the fused two-step kernel");
@@ -182,7 +182,7 @@ extern "C" int fpr_diffusion3d_can_step2(fpr_ctx* ctx, const double* Ht, const d
                                          const double* Hout, const double* dHdtau, int nx, int ny, int nz)
 {
     if (!ctx) return FPR_ERR_INVALID;
-    return (Ht && Htau && Hmid && Hout && dHdtau && Htau != Hout && Hmid != Hout && Htau != Hmid &&
+    return (Ht && Htau && Hmid && Hout && Htau != Hout && Hmid != Hout && Htau != Hmid &&   // dHdtau may be NULL
             diff3_fuse2_ok(ctx, Ht, Htau, Hmid, Hout, dHdtau, nx, ny, nz))
                ? 1
                : 0;
@@ -241,6 +241,14 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
     double* cur = Htau;   // current field
     int parity = 0;       // 0: cur is an even buffer (Htau or E1), 1: cur == Htau2
     long swaps = 0;
+    // The loop needs the residual's NORM every iteration, the residual ARRAY only when it returns (":191" reads it, nothing
+    // else does): fused pairs therefore run without storing dHdtau (24 instead of 32 bytes per cell and launch), and
+    // if the call ends on such a pair the pair is replayed once with the store -- from its still intact input, before
+    // the commit of Ht -- so that dHdtau holds what the reference's residual_H holds.  Option diff3_lazy_residual = 0:
+    // every launch stores it.
+    const bool lazy_res = fpr_opt(ctx, "diff3_lazy_residual", 1) != 0;
+    const double* stale_in = nullptr;   // input of the last fused pair if dHdtau has not been written since
+    double* stale_out = nullptr;
     for (int t = 0; t < nt; ++t) {
         long it = 0;
         double err = 2 * tol;  // :178
@@ -251,9 +259,11 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
             if (fuse && parity == 0 && left >= 2) {
                 double* out = (cur == Htau) ? E1 : Htau;
                 const bool n1 = want_norm(it + 1), n2 = want_norm(it + 2);
-                int rc = diff3_run2(ctx, Ht, cur, Htau2, out, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz,
-                                    nullptr, nullptr, dt, (n1 || n2) ? (double*)pinned : nullptr, false, 0);
+                int rc = diff3_run2(ctx, Ht, cur, Htau2, out, lazy_res ? nullptr : dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz,
+                                    D_dx, D_dy, D_dz, nullptr, nullptr, dt, (n1 || n2) ? (double*)pinned : nullptr, false, 0);
                 if (rc) return rc;
+                stale_in = lazy_res ? cur : nullptr;
+                stale_out = out;
                 if (n1 || n2) FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
                 if (n1 && fixed_iters <= 0) {
                     const double e1 = sqrt(pinned[0]) / sqrtN;  // :191 after the first of the two iterations
@@ -262,6 +272,7 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
                         rc = diff3_run(ctx, Ht, cur, Htau2, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz,
                                        nullptr, nullptr, false, 0.0, nullptr, false, 0);
                         if (rc) return rc;
+                        stale_in = nullptr;
                         cur = Htau2; parity = 1; ++swaps; ++it;
                         err = e1;
                         continue;
@@ -278,6 +289,7 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
             int rc = diff3_run(ctx, Ht, cur, out, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, nullptr,
                                nullptr, need_norm, dt, (double*)pinned, false, 0);
             if (rc) return rc;
+            stale_in = nullptr;
             cur = out; parity ^= 1;  // :190
             ++swaps;
             if (need_norm) {
@@ -288,6 +300,12 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
         }
         if (iters_host) iters_host[t] = it;
         if (err_host) err_host[t] = err;
+        if (t == nt - 1 && stale_in) {   // the call ends on a pair that did not store its residual: replay it with the store
+            int rc = diff3_run2(ctx, Ht, stale_in, Htau2, stale_out, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy,
+                                D_dz, nullptr, nullptr, dt, nullptr, false, 0);
+            if (rc) return rc;
+            stale_in = nullptr;
+        }
         int rc = fpr_copy(ctx, Ht, cur, N);  // Ht .= Htau  :203
         if (rc) return rc;
     }

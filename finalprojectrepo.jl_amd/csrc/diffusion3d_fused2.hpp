@@ -44,7 +44,7 @@ struct Diff3Args2 {
     const double* __restrict__ A;   // L0 (Htau)
     const double* __restrict__ B;   // boundary values of L1 (the reference's Htau2); interior never read
     double* __restrict__ C;         // L2 (interior of the box)
-    double* __restrict__ dH;        // residual of the second step
+    double* __restrict__ dH;        // residual of the second step (nullptr: not stored -- its norm is still reduced)
     int nx, ny, nz;
     int lo[3], hi[3];               // output box, clipped to the interior [1, n-1)
     double dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz;
@@ -155,7 +155,9 @@ __device__ __forceinline__ double diff3_block_sum_waves(double v, double* red, i
     return s;
 }
 
-template <bool NORM, int NW = 4>
+// WRES = false: the residual of the second step is not written to memory (a solver loop that only needs its norm:
+// 24 instead of 32 bytes per cell and launch, and two stores less per row)
+template <bool NORM, int NW = 4, bool WRES = true>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3Args2 a)
 {
     constexpr int VX = 2, RY = 4, TXW = 128, SYB = NW * RY - 2;
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
     const __amdgpu_buffer_rsrc_t rEB = rsrc_at(a.B, -1, j0);     // B x-boundary cells, plane m+1
     const __amdgpu_buffer_rsrc_t rH = rsrc_at(Hsrc, -1, hrow);   // halo row, plane m+1
     const __amdgpu_buffer_rsrc_t rC = rsrc_at(a.C, -NR, j0);     // L2 plane m-1
-    const __amdgpu_buffer_rsrc_t rD = rsrc_at(a.dH, -NR, j0);
+    const __amdgpu_buffer_rsrc_t rD = rsrc_at(WRES ? a.dH : a.C, -NR, j0);   // (unused without WRES)
 
     DVec<VX> P[NR][RY];       // L0 planes m-1, m, m+1; plane p lives in slot (p - m0 + 1) % NR
     DVec<VX> HT[NR][RY];      // Ht planes m-1, m, m+1 (in flight), same slot rule
@@ -427,9 +429,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
                 // lanes that own one cell of their pair (first / last owned cell of an odd-aligned range)
                 double r2 = res[0], g2 = h2[0];
                 if (has_split) { asm volatile("" ::: "memory"); r2 = cm[0] ? res[0] : res[1]; g2 = cm[0] ? h2[0] : h2[1]; }
-                diff3_bst2_nt(rD, sv4, sor, res[0], res[1]);
+                if constexpr (WRES) diff3_bst2_nt(rD, sv4, sor, res[0], res[1]);
                 diff3_bst2_nt(rC, sv4, sor, h2[0], h2[1]);
-                diff3_bst1(rD, sv2, sor, r2);
+                if constexpr (WRES) diff3_bst1(rD, sv2, sor, r2);
                 diff3_bst1(rC, sv2, sor, g2);
                 // Store-data hazard (gfx9 family, "VMEM store of more than 64 bits followed by a VALU write of its data
                 // VGPRs: 1 wait state -- not needed when the store takes its offset from an SGPR"): hipcc relies on the
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
 static inline bool diff3_can_fuse2(const double* Ht, const double* A, const double* B, const double* C, const double* dH,
                                    int nx, int ny, int nz)
 {
-    const uintptr_t al = (uintptr_t)Ht | (uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)dH;
+    const uintptr_t al = (uintptr_t)Ht | (uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)dH;   // dH may be null
     return (nx % 2 == 0) && nx >= 128 && ny >= 16 && nz >= 3 && (al & 15) == 0;
 }
 
@@ -558,12 +560,23 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
         if (xcd_opt == 0) xcd_opt = (nblk >= 64 && nblk <= 2 * slots) ? 1 : 3;
     }
     a.xcd_remap = (xcd_opt == 1 && nblk >= 64) ? 1 : ((xcd_opt == 2 && a.ntz % 8 == 0) ? 2 : 0);
+    const bool wres = a.dH != nullptr;
     if (a.nw == 8) {
-        if (norm) k_diff3_march2<true, 8><<<(int)nblk, 512, 0, stream>>>(a);
-        else k_diff3_march2<false, 8><<<(int)nblk, 512, 0, stream>>>(a);
+        if (wres) {
+            if (norm) k_diff3_march2<true, 8, true><<<(int)nblk, 512, 0, stream>>>(a);
+            else k_diff3_march2<false, 8, true><<<(int)nblk, 512, 0, stream>>>(a);
+        } else {
+            if (norm) k_diff3_march2<true, 8, false><<<(int)nblk, 512, 0, stream>>>(a);
+            else k_diff3_march2<false, 8, false><<<(int)nblk, 512, 0, stream>>>(a);
+        }
     } else {
-        if (norm) k_diff3_march2<true, 4><<<(int)nblk, 256, 0, stream>>>(a);
-        else k_diff3_march2<false, 4><<<(int)nblk, 256, 0, stream>>>(a);
+        if (wres) {
+            if (norm) k_diff3_march2<true, 4, true><<<(int)nblk, 256, 0, stream>>>(a);
+            else k_diff3_march2<false, 4, true><<<(int)nblk, 256, 0, stream>>>(a);
+        } else {
+            if (norm) k_diff3_march2<true, 4, false><<<(int)nblk, 256, 0, stream>>>(a);
+            else k_diff3_march2<false, 4, false><<<(int)nblk, 256, 0, stream>>>(a);
+        }
     }
     *nparts = (int)nblk;
     return hipGetLastError();

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void k_diff3_slab2(Diff3Args2 a)
             const long rem = array_bytes - pbase;
             return diff3_rsrc((uintptr_t)X + (uintptr_t)pbase, (unsigned)(rem > 0x7ffffff0L ? 0x7ffffff0L : rem));
         };
-        const __amdgpu_buffer_rsrc_t rA = mk(a.A), rHt = mk(a.Ht), rB = mk(a.B), rC = mk(a.C), rD = mk(a.dH);
+        const bool wres = a.dH != nullptr;   // uniform; the residual store is dropped (sentinel offset) without a buffer
+        const __amdgpu_buffer_rsrc_t rA = mk(a.A), rHt = mk(a.Ht), rB = mk(a.B), rC = mk(a.C), rD = mk(wres ? a.dH : a.C);
         // per-lane byte offset of (row, column xs-1) -- or the sentinel for rows outside the array (loads) / rows this
         // lane does not own (stores); columns add a compile-time constant, column and plane validity ride in the
         // scalar offset.  Column xs-2 (window index 0) gets an offset of its own: for xs = 1 it does not exist.
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void k_diff3_slab2(Diff3Args2 a)
                     double h2;
                     const double res = diff3_point(h, Qc[c], Qc[c + 2], ym, yp, Qm[c + 1], Qn[c + 1], HT[S % 3][c + 1], cf, h2);
                     const int soc = xs + c < xe ? so : (int)OOR;
-                    diff3_bst1(rD, vst + 8u * (c + 1), soc, res);
+                    diff3_bst1(rD, vst + 8u * (c + 1), wres ? soc : (int)OOR, res);
                     diff3_bst1(rC, vst + 8u * (c + 1), soc, h2);
                     if constexpr (NORM) {
                         if (row_own && xs + c < xe) { const double t = res * a.scale; acc2 += t * t; }

@@ -85,9 +85,10 @@ def diffusion_3D_step_τ2(Ht, Hτ, Hmid, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D
     """Two trips through the loop body of part1_kernel_programming.jl:179-192 in one pass over memory:
     step(Hτ -> Hmid); step(Hmid -> Hout) with Hmid never written (only its boundary cells are read).  Hout gets
     interior cells only and must already carry Hτ's boundary.  sumsq2_dev: 2 device doubles (norm sums of the
-    first / second iteration), or None."""
+    first / second iteration), or None.  dHdτ may be None: the residual of the second iteration is then not stored."""
     nx, ny, nz = Ht.shape
-    _ctx().call("fpr_diffusion3d_step2", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hmid, 3), fptr(Hout, 3), fptr(dHdτ, 3), nx, ny, nz,
+    _ctx().call("fpr_diffusion3d_step2", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hmid, 3), fptr(Hout, 3),
+                fptr(dHdτ, 3) if dHdτ is not None else None, nx, ny, nz,
                 dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale,
                 sumsq2_dev.data_ptr() if sumsq2_dev is not None else None)
 

@@ -99,7 +99,8 @@ int fpr_diffusion3d_step_norm_host(fpr_ctx* ctx, const double* Ht, const double*
  * kernel writes interior cells only, so the boundary cells of its second work buffer are what the intermediate field
  * carries there).  Hout receives interior cells only and must already hold Htau's boundary values to stand in for the
  * reference's first work buffer afterwards.  Htau, Hmid, Hout: three distinct buffers.  dHdtau = residual of the
- * second iteration.  sumsq2_dev (may be NULL): two device doubles, sum((r*scale)^2) of the first and of the second
+ * second iteration; it may be NULL, then the residual is not stored (its norm still lands in sumsq2_dev: a solver loop
+ * reads nothing else of it, and the launch moves 24 instead of 32 bytes per cell).  sumsq2_dev (may be NULL): two device doubles, sum((r*scale)^2) of the first and of the second
  * iteration (deterministic two-stage reductions).  "Bit for bit" is a statement about the FIELDS (Hout, dHdtau): the
  * two sums are accumulated as sum(r*r) per lane with scale^2 applied once at the end, the single-step kernel adds
  * (r*scale)^2 per cell -- both deterministic, equal to about 1e-13 relative, like any two summation orders.  Requirements: nx even and >= 128, ny >= 16, 16-byte aligned
@@ -131,7 +132,9 @@ int fpr_diffusion3d_step2_box2(fpr_ctx* ctx, const double* Ht, const double* Hta
  * Htau3 (nullable): a THIRD field-sized work buffer owned by the caller -- the library allocates no field memory.
  * With it, pairs of iterations run as one fused launch (fpr_diffusion3d_step2; an iteration whose norm ends the loop
  * is replayed alone, so fields, iteration counts and errors are those of the plain loop; option "diff3_fuse2" = 0
- * turns this off).  NULL: one iteration per launch.  Non-NULL for a problem the fused kernel cannot serve
+ * turns this off).  Inside the loop the pairs do not store dHdtau (the loop reads only its norm); a call that ends on
+ * a pair replays that pair once with the store, so dHdtau holds the reference's residual_H on return (option
+ * "diff3_lazy_residual" = 0: every launch stores it).  NULL: one iteration per launch.  Non-NULL for a problem the fused kernel cannot serve
  * (fpr_diffusion3d_can_step2 == 0) is FPR_ERR_INVALID, never a silent fallback. */
 int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, double* Htau2, double* Htau3, double* dHdtau, int nx, int ny, int nz,
                           double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy, double D_dz,

@@ -339,6 +339,12 @@ def test_fused_two_steps_bit_exact(fpr, oracle, shape, opts):
         assert np.array_equal(F.tonumpy(dC), C_ref) and np.array_equal(F.tonumpy(dD), dH_ref)
         g1, g2 = (float(x) for x in sq2.tolist())
         assert abs(g1 - s1) <= 1e-13 * s1 and abs(g2 - s2) <= 1e-13 * s2
+        # without a residual array (a solver loop reads only its norm): same field, same norms
+        dC.copy_(dA)
+        sq2.zero_()
+        F.part1.diffusion_3D_step_τ2(dHt, dA, dB, dC, None, *COEF.values(), 0.2, sq2)
+        assert np.array_equal(F.tonumpy(dC), C_ref)
+        assert [float(x) for x in sq2.tolist()] == [g1, g2]
     finally:
         for k in ("diff3_zc2", "diff3_xcd2", "diff3_nw2"):
             c.set_option(k, 0)
@@ -454,8 +460,10 @@ def test_solve_with_fused_pairs_equals_plain_loop(fpr, oracle, case):
     n = (128, 24, 20)
     Ht0 = oracle.init_gaussian(n, 10.0 / n[0], 10.0 / n[1], 10.0 / n[2], (5.0, 5.0, 5.0))
     out = []
-    for fuse in (0, 1):
+    # plain loop; fused pairs that store the residual every launch; fused pairs that store it only when the call returns
+    for fuse, lazy in ((0, 1), (1, 0), (1, 1)):
         c.set_option("diff3_fuse2", fuse)
+        c.set_option("diff3_lazy_residual", lazy)
         try:
             kw = dict(nx=n[0], ny=n[1], nz=n[2], ttot=0.6, Ht_init=F.asdevice(Ht0))
             kw.update(case)
@@ -463,10 +471,13 @@ def test_solve_with_fused_pairs_equals_plain_loop(fpr, oracle, case):
             out.append((H, info["iters"], info["err"], F.tonumpy(info["residual_H"])))
         finally:
             c.set_option("diff3_fuse2", 1)
-    (H0, it0, e0, r0), (H1, it1, e1, r1) = out
-    assert it0 == it1 and len(it0) == 3
-    assert np.array_equal(H0, H1) and np.array_equal(r0, r1)
-    assert np.allclose(e0, e1, rtol=1e-12, atol=0)
+            c.set_option("diff3_lazy_residual", 1)
+    (H0, it0, e0, r0) = out[0]
+    assert len(it0) == 3
+    for H1, it1, e1, r1 in out[1:]:
+        assert it0 == it1
+        assert np.array_equal(H0, H1) and np.array_equal(r0, r1)
+        assert np.allclose(e0, e1, rtol=1e-12, atol=0)
 
 
 def test_full_size_512_fused_equals_two_steps(fpr):

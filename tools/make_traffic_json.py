@@ -23,11 +23,11 @@ def mean(path, kernel, counter):
 
 
 entries = []
-for fused, kern in ((True, "k_diff3_march2<"), (False, "k_diff3_march<")):
+for fused, kern in ((True, "k_diff3_march2<true, 8, true>"), (False, "k_diff3_march<")):
     fe, nf = mean(os.path.join(root, "profiles", tag + "_pmc_fetch.txt"), kern, "FETCH_SIZE")
     wr, nw = mean(os.path.join(root, "profiles", tag + "_pmc_write.txt"), kern, "WRITE_SIZE")
     traffic = fe * 1024 * 2 + wr * 1024
-    entries.append({"n": n, "fuse2": fused, "kernel": kern.rstrip("<"), "FETCH_SIZE_KiB_mean": fe, "fetch_dispatches": nf,
+    entries.append({"n": n, "fuse2": fused, "kernel": kern.rstrip("<") if kern.endswith("<") else kern, "FETCH_SIZE_KiB_mean": fe, "fetch_dispatches": nf,
                     "WRITE_SIZE_KiB_mean": wr, "write_dispatches": nw, "fetch_correction": 2.0,
                     "traffic_bytes_per_launch": traffic, "min_bytes_per_launch": 32.0 * cells,
                     "traffic_over_min_bytes": traffic / (32.0 * cells),

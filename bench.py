@@ -382,10 +382,17 @@ def main():
     def timed_leg(fuse2, prewarm_ms):
         """W (+1 if needed to start from an even state) untimed warm-up steps, then EXACTLY K timed steps between
         barriers; returns max-over-ranks wall time and the per-kernel event times of the timed region."""
-        tpre = time.perf_counter()
-        while time.perf_counter() - tpre < prewarm_ms * 1e-3:   # clock ramp, RCCL channel set-up
-            run(8, 0, fuse2)
+        # clock ramp, RCCL channel set-up.  Between ranks the number of pre-warm steps must be the SAME everywhere (every
+        # step is a collective pattern): a fixed count there, a time budget on a single rank
+        if use_dist:
+            for _ in range(8 if prewarm_ms > 100 else 2):
+                run(8, 0, fuse2)
             torch.cuda.synchronize()
+        else:
+            tpre = time.perf_counter()
+            while time.perf_counter() - tpre < prewarm_ms * 1e-3:
+                run(8, 0, fuse2)
+                torch.cuda.synchronize()
         run(W, 0, fuse2)
         extra = 0
         if fuse2 and state["parity"] == 1:     # every timed launch of the fused leg must be the fused kernel

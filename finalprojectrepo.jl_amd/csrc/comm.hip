@@ -277,18 +277,20 @@ extern "C" int fpr_allreduce_sum_dev(fpr_ctx* ctx, double* x_dev, int count, int
 }
 
 // part1_utils.jl:38 as the reference calls it: one host Float64, summed over all ranks, back on the host.
-// Ordered on the compute stream behind everything enqueued so far; synchronises that stream.
+// Ordered behind everything enqueued so far on the compute stream; synchronises.
 extern "C" int fpr_allreduce_sum1(fpr_ctx* ctx, double* x_host_inout)
 {
     if (!ctx) return FPR_ERR_INVALID;
     FPR_REQUIRE(ctx, x_host_inout, "null pointer");
     if (!ctx->comm) return FPR_OK;   // single rank without a communicator
+    // like every RCCL operation of this communicator it runs on the comm stream, behind what the compute stream holds
     double* d = ctx->scalars + 48;
     ctx->host_scalars[48] = *x_host_inout;
-    FPR_HIP(ctx, hipMemcpyAsync(d, ctx->host_scalars + 48, sizeof(double), hipMemcpyHostToDevice, ctx->stream[0]));
-    FPR_NCCL(ctx, ncclAllReduce(d, d, 1, ncclDouble, ncclSum, comm_of(ctx), ctx->stream[0]));
-    FPR_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + 48, d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream[0]));
-    FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
+    if (int rc = fpr_stream_wait(ctx, 1, 0)) return rc;
+    FPR_HIP(ctx, hipMemcpyAsync(d, ctx->host_scalars + 48, sizeof(double), hipMemcpyHostToDevice, ctx->stream[1]));
+    FPR_NCCL(ctx, ncclAllReduce(d, d, 1, ncclDouble, ncclSum, comm_of(ctx), ctx->stream[1]));
+    FPR_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + 48, d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream[1]));
+    FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));
     *x_host_inout = ctx->host_scalars[48];
     return FPR_OK;
 }
@@ -303,9 +305,10 @@ extern "C" int fpr_gather3d(fpr_ctx* ctx, const double* A, int nx, int ny, int n
     FprGrid& g = ctx->grid;
     const size_t n = (size_t)nx * ny * nz;
     const int np = ctx->comm_size, me = ctx->comm_rank;
+    if (int rc = fpr_stream_wait(ctx, 1, 0)) return rc;   // comm stream (all RCCL calls), behind the producers of A
     if (me != 0) {
-        FPR_NCCL(ctx, ncclSend(A, n, ncclDouble, 0, comm_of(ctx), ctx->stream[0]));
-        FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
+        FPR_NCCL(ctx, ncclSend(A, n, ncclDouble, 0, comm_of(ctx), ctx->stream[1]));
+        FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));
         return FPR_OK;
     }
     FPR_REQUIRE(ctx, A_global_host, "rank 0 needs the global host array");
@@ -315,11 +318,11 @@ extern "C" int fpr_gather3d(fpr_ctx* ctx, const double* A, int nx, int ny, int n
     for (int r = 0; r < np; ++r) {
         const double* src = A;
         if (r != 0) {
-            FPR_NCCL(ctx, ncclRecv(g.stage, n, ncclDouble, r, comm_of(ctx), ctx->stream[0]));
+            FPR_NCCL(ctx, ncclRecv(g.stage, n, ncclDouble, r, comm_of(ctx), ctx->stream[1]));
             src = g.stage;
         }
-        FPR_HIP(ctx, hipMemcpyAsync(host.data(), src, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream[0]));
-        FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
+        FPR_HIP(ctx, hipMemcpyAsync(host.data(), src, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream[1]));
+        FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));
         const int c[3] = {r / (g.dims[1] * g.dims[2]), (r / g.dims[2]) % g.dims[1], r % g.dims[2]};
         for (int k = 0; k < nz; ++k)
             for (int j = 0; j < ny; ++j)

@@ -183,7 +183,11 @@ class _RcclTransport:
         self.c.call("fpr_halo_exchange3d", self.fptr(A, 3), *self.n)
 
     def allreduce_(self, t):
-        self.c.call("fpr_allreduce_sum_dev", t.data_ptr(), t.numel(), 0)
+        # every RCCL operation of this communicator runs on the comm stream, in program order (the same on all ranks):
+        # comm waits for the producers on the compute stream, the compute stream waits for the result
+        self.c.call("fpr_stream_wait", 1, 0)
+        self.c.call("fpr_allreduce_sum_dev", t.data_ptr(), t.numel(), 1)
+        self.c.call("fpr_stream_wait", 0, 1)
 
 
 def rccl_bootstrap(ctx, rank, world, dist=None, group=None):

@@ -226,8 +226,10 @@ int fpr_halo_exchange3d_begin(fpr_ctx* ctx, double* A, int nx, int ny, int nz, i
 int fpr_halo_exchange3d_end(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face_mask);
 
 /* MPI.Allreduce!(x, +, comm_cart) -- part1_utils.jl:38.  _dev: `count` device doubles in place on stream
- * stream_sel, no host sync (norms of several iterations can be reduced in one call).  _sum1: the reference's form,
- * one host double in / out, synchronises the compute stream.  Both are no-ops on a single rank. */
+ * stream_sel, no host sync (norms of several iterations can be reduced in one call).  All RCCL operations of a context
+ * should run on ONE stream in the same order on every rank: the halo exchanges use the comm stream (1), so pass 1 here
+ * as well and order it against the compute stream with fpr_stream_wait (grid.py _RcclTransport.allreduce_).  _sum1: the
+ * reference's form, one host double in / out, comm stream, synchronises.  No-ops without a communicator. */
 int fpr_allreduce_sum_dev(fpr_ctx* ctx, double* x_dev, int count, int stream_sel);
 int fpr_allreduce_sum1(fpr_ctx* ctx, double* x_host_inout);
 

@@ -287,8 +287,11 @@ function allreduce_sum1(x::Float64)
     return r[]
 end
 "In-place sum over all ranks of a small device vector (e.g. the norms of several iterations); no host sync."
-allreduce_sum!(x::DA; stream_sel = 0) =
-    check(ccall((:fpr_allreduce_sum_dev, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint), ctx(), p(x), length(x), stream_sel))
+function allreduce_sum!(x::DA)   # comm stream, ordered behind / ahead of the compute stream (all RCCL calls share one stream)
+    stream_wait(1, 0)
+    check(ccall((:fpr_allreduce_sum_dev, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint), ctx(), p(x), length(x), 1))
+    stream_wait(0, 1)
+end
 "part1_utils.jl:36-40 with the scale of its call site folded in: dist_norm_L2(residual_H*dt, comm) == dist_norm_L2(residual_H, comm; scale=dt)."
 function dist_norm_L2(Rh::DA, comm_cart; scale = 1.0)
     sq = sumsq_scaled(Rh, scale)                                  # part1_utils.jl:37

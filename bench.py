@@ -257,6 +257,59 @@ def ns_block(F):
                     "kernel_by_kernel = the reference's seven kernels + maxima + broadcasts, same results bit for bit"}
 
 
+def host_staged_p2p(torch, dist):
+    """--rehearse-shared-gpu: a torch.distributed look-alike for grid.HaloExchanger whose planes travel through host
+    memory over gloo.  For rehearsing N ranks on ONE card only -- the product transport is RCCL inside the library."""
+
+    class Work:
+        def __init__(self, w, host=None, dev=None):
+            self.w, self.host, self.dev = w, host, dev
+
+        def wait(self):
+            self.w.wait()
+            if self.dev is not None:
+                self.dev.copy_(self.host)      # on the caller's current stream (the comm stream)
+
+    class P2P:
+        ReduceOp = dist.ReduceOp
+
+        class P2POp:
+            def __init__(self, op, tensor, peer, group=None):
+                self.op, self.tensor, self.peer = op, tensor, peer
+
+        @staticmethod
+        def isend(*a, **k):
+            raise NotImplementedError
+
+        @staticmethod
+        def irecv(*a, **k):
+            raise NotImplementedError
+
+        def batch_isend_irecv(self, ops):
+            torch.cuda.current_stream().synchronize()     # the packed planes are complete
+            works = []
+            for o in ops:
+                if o.op is P2P.irecv:
+                    h = torch.empty(o.tensor.shape, dtype=o.tensor.dtype)
+                    works.append(Work(dist.irecv(h, o.peer), h, o.tensor))
+                else:
+                    works.append(Work(dist.isend(o.tensor.cpu().contiguous(), o.peer)))
+            return works
+
+        def all_reduce(self, t, op=None, group=None):
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+
+        def barrier(self, group=None):
+            dist.barrier()
+
+        def gather_object(self, *a, **k):
+            return dist.gather_object(*a, **k)
+
+    return P2P()
+
+
 # ------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -274,6 +327,10 @@ def main():
     ap.add_argument("--no-fuse2", action="store_true", help="main leg with one iteration per launch (k_diff3_march)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / control-plane rehearsal on CPU (gloo): no GPU, no compute, one JSON line")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="diagnostic for a 1-GPU box: every rank on cuda:0, halo planes and the norm's all-reduce staged "
+                         "through the host over gloo (RCCL refuses two ranks on one device).  Runs the N>1 control flow, the "
+                         "shell/core choreography and the HIP kernels between real processes; its rates are NOT measurements")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -311,10 +368,12 @@ def main():
             dist.destroy_process_group()
         return
 
-    torch.cuda.set_device(local_rank)
+    shared = args.rehearse_shared_gpu
+    device_index = 0 if shared else local_rank
+    torch.cuda.set_device(device_index)
     import fpr_amd
 
-    F = fpr_amd.load(local_rank)
+    F = fpr_amd.load(device_index)
     ctx = F.ctx()
     for kv in filter(None, args.variant.split(",")):
         k, v = kv.split("=")
@@ -322,7 +381,9 @@ def main():
 
     n = args.n
     dims = tuple(int(x) for x in args.dims.split(",")) if args.dims else (1, 1, world)
-    gg = F.grid.GlobalGrid(n, n, n, dims=dims, transport="rccl" if world > 1 else None)
+    gg = F.grid.GlobalGrid(n, n, n, dims=dims, transport=("dist" if shared else "rccl") if world > 1 else None)
+    if shared and world > 1:
+        gg.dist = host_staged_p2p(torch, dist)
     rccl_ranks = ctx.L.fpr_comm_size(ctx.h)
     # physics as diffusion_3D_kernel_programming with scale_physical_size=true (weak scaling keeps dx fixed)
     lx, ly, lz = (d * 10.0 for d in dims)
@@ -418,8 +479,13 @@ def main():
 
     def kernel_roofline(kind, kt, traffic_entry):
         ms_tot, cnt = kt[kind]
-        kms = ms_tot / cnt if cnt else 0.0
         ipl = 2 if kind == KT_STEP2 else 1
+        if world > 1:
+            # between ranks one pass over the local grid is SEVERAL launches (shell boxes, thin slabs, two core halves):
+            # price the pass, not the launch -- all diffusion launches of the timed region / passes in it
+            ms_tot = kt[KT_STEP][0] + kt[KT_STEP2][0]
+            cnt = max(K // ipl, 1)
+        kms = ms_tot / cnt if cnt else 0.0
         ach = min_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "kernel": "k_diff3_march2 (two iterations per launch)" if kind == KT_STEP2 else "k_diff3_march (one iteration per launch)",
@@ -430,6 +496,9 @@ def main():
              "effective_achieved": ach * ipl, "effective_frac": ach * ipl / HBM_PEAK_GBS,
              "effective_accounting": "SURVEY 8d: 32 B per interior cell per ITERATION x iterations per launch",
              "traffic": None, "traffic_source": None}
+        if world > 1:
+            r["kernel"] += "; between ranks: all launches of one pass over the local grid (shell, thin slabs, core halves)"
+            r["launches_by_kind"] = {"single_step_boxes": kt[KT_STEP][1], "fused_boxes": kt[KT_STEP2][1]}
         if traffic_entry:
             r["traffic"] = traffic_entry["traffic_bytes_per_launch"]
             r["traffic_source"] = traffic_entry.get("source")
@@ -488,6 +557,10 @@ def main():
         "roofline": roofline,
         "legs": legs,
     }
+    if shared:
+        out["rehearsal"] = ("%d ranks sharing one GPU, planes staged through the host over gloo: a control-flow and "
+                            "choreography rehearsal, not a measurement" % world)
+        out["config"]["halo"] = "REHEARSAL: host-staged gloo"
     # second leg: the one-iteration-per-launch kernel (north_star's ">= 60 % of HBM peak on the inner update" in
     # the one-pass accounting), with its own event timer; not part of `value`
     if world == 1 and main_fused and not args.no_single_leg:

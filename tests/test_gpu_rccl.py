@@ -174,3 +174,29 @@ def test_fused_pair_over_rccl_periodic_xyz(fpr, oracle, periodic_grid):
                 idx[d] = side
                 assert np.array_equal(loc[tuple(idx)], A[tuple(idx)])
         assert np.array_equal(F.tonumpy(gR)[1:-1, 1:-1, 1:-1], R[1:-1, 1:-1, 1:-1])
+
+
+def test_bench_two_ranks_rehearsal_on_one_card():
+    """bench.py's N>1 control flow between REAL processes on the one card a test box has: the self-launcher, the gloo
+    control plane, identical collective counts on every rank through pre-warm / warm-up / timed region, the shell/core
+    choreography of the fused pairs, one JSON line from rank 0.  Planes travel through the host (RCCL refuses two ranks
+    on one device), so the rate it prints is not a measurement; the norm it prints is checked against a 1-rank run of the
+    same global problem (run_all_benchmarks.sh:21-28 is the reference's multi-rank protocol)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "12", "--warmup", "4", "--no-cpu-baseline", "--no-secondary", "--no-single-leg", "--prewarm-ms", "0"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--n", "128"] + common,
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["process_grid"] == [1, 1, 2] and out["config"]["global_grid"] == [128, 128, 254]
+    assert "rehearsal" in out and out["legs"]["fused_pairs"]["launches"] == 6     # passes over the local grid, 12 steps
+    assert 0.0 < out["roofline"]["frac"] <= 1.0      # priced per pass: shell + thin slabs + core halves together
+    assert out["roofline"]["launches_by_kind"]["fused_boxes"] >= 3 * 6
+    assert out["config"]["last_err"] is not None and 0.0 < out["config"]["last_err"] < 1.0

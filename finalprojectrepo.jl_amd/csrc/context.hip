@@ -28,7 +28,9 @@ extern "C" int fpr_ctx_create(fpr_ctx** out, int device, void* compute_stream, v
               hipMalloc(&ctx->scalars, 64 * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->state, sizeof(FprSolveState)) == hipSuccess &&
               hipHostMalloc(&ctx->state_h, sizeof(FprSolveState)) == hipSuccess &&
-              hipHostMalloc(&ctx->host_scalars, 64 * sizeof(double)) == hipSuccess;
+              hipHostMalloc(&ctx->host_scalars, 64 * sizeof(double)) == hipSuccess &&
+              hipMalloc(&ctx->cyc, sizeof(FprCycleCtl)) == hipSuccess &&
+              hipHostMalloc(&ctx->cyc_h, FPR_CYC_SLOTS * sizeof(FprCycleCtl)) == hipSuccess;
     if (!ok) { fpr_ctx_destroy(ctx); return FPR_ERR_HIP; }
     hipMemset(ctx->scalars, 0, 64 * sizeof(double));
     hipMemset(ctx->state, 0, sizeof(FprSolveState));
@@ -48,6 +50,8 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
             if (L.tmp) hipFree(L.tmp);
             if (L.res_c) hipFree(L.res_c);
             if (L.corr_c) hipFree(L.corr_c);
+            if (L.tmp2) hipFree(L.tmp2);
+            if (L.corr_c2) hipFree(L.corr_c2);
         }
     for (auto& e : ctx->ktimer_ev) hipEventDestroy(e);
     if (ctx->cg_buf) hipFree(ctx->cg_buf);
@@ -57,6 +61,8 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
     if (ctx->state) hipFree(ctx->state);
     if (ctx->state_h) hipHostFree(ctx->state_h);
     if (ctx->host_scalars) hipHostFree(ctx->host_scalars);
+    if (ctx->cyc) hipFree(ctx->cyc);
+    if (ctx->cyc_h) hipHostFree(ctx->cyc_h);
     for (int s = 0; s < 2; ++s) {
         if (ctx->ev[s]) hipEventDestroy(ctx->ev[s]);
         if (ctx->own_stream[s] && ctx->stream[s]) hipStreamDestroy(ctx->stream[s]);
@@ -227,6 +233,86 @@ int fprx_finish_sum(fpr_ctx* ctx, const double* partials, int nparts, double* ou
     }
     if (accumulate) k_finish<1><<<1, 256, 0, ctx->stream[stream_sel]>>>(partials, nparts, out_dev);
     else k_finish<0><<<1, 256, 0, ctx->stream[stream_sel]>>>(partials, nparts, out_dev);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+// ---- cycles enqueued ahead (FprCycleCtl, fpr_internal.hpp) ------------------------------------------------
+__global__ void k_cycle_init(FprCycleCtl* ctl, FprSolveState* st, double tolf)
+{
+    ctl->stop = 0; ctl->ncycles = 0; ctl->coarse_iters = 0; ctl->seq = 0;
+    ctl->tolf = tolf; ctl->rms = 0.0;
+    st->acc_iters = 0;
+}
+
+// end of a V-cycle: sum(res.^2) of the last post-smoothing sweep exactly as k_finish<0> sums it, r_rms
+// (multigrid.jl:252) and the loop's exit test (:70) on the device
+__global__ __launch_bounds__(256) void k_cycle_finish(const double* __restrict__ partials, int n, double* __restrict__ out,
+                                                       double npoints, FprCycleCtl* ctl, const FprSolveState* st,
+                                                       FprCycleCtl* rec_host)
+{
+    __shared__ double red[16];
+    if (ctl->stop) return;
+    const double s = fpr_sum_partials_256(partials, n, red);
+    if (threadIdx.x == 0) {
+        out[0] = s;
+        const double r = sqrt(s / npoints);
+        FprCycleCtl c = *ctl;
+        c.rms = r;
+        c.ncycles += 1;
+        c.coarse_iters = st->acc_iters;
+        if (r < c.tolf) c.stop = 1;
+        *ctl = c;
+        // the record goes to pinned host memory straight from here (no copy command, no event between two cycles);
+        // the host polls `seq`, which is written last
+        rec_host->stop = c.stop; rec_host->ncycles = c.ncycles; rec_host->coarse_iters = c.coarse_iters;
+        rec_host->tolf = c.tolf; rec_host->rms = c.rms;
+        __threadfence_system();
+        __hip_atomic_store(&rec_host->seq, c.ncycles, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+int fprx_cycle_init(fpr_ctx* ctx, double tolf)
+{
+    k_cycle_init<<<1, 1, 0, ctx->stream[0]>>>(ctx->cyc, ctx->state, tolf);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+// Host side of the record: wait until the cycle with sequence number `seq` has reported into `slot`.  Polls the pinned
+// record; every now and then it asks the stream whether it has drained or failed, so that a launch that never ran
+// cannot make this spin for ever.
+int fprx_cycle_wait(fpr_ctx* ctx, int slot, int seq, FprCycleCtl* out)
+{
+    FprCycleCtl* rec = &ctx->cyc_h[slot];
+    unsigned long spins = 0;
+    while (__atomic_load_n(&rec->seq, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0xffff) == 0) {
+            const hipError_t q = hipStreamQuery(ctx->stream[0]);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(&rec->seq, __ATOMIC_ACQUIRE) == seq) break;
+                return fpr_fail(ctx, FPR_ERR_HIP, "V-cycle %d never reported (stream idle)", seq);
+            }
+            if (q != hipErrorNotReady) return fpr_fail(ctx, FPR_ERR_HIP, "HIP error while waiting for V-cycle %d: %s", seq, hipGetErrorString(q));
+        }
+    }
+    *out = *rec;
+    return FPR_OK;
+}
+
+int fprx_cycle_finish(fpr_ctx* ctx, const double* partials, int nparts, double* sumsq_out_dev, double npoints, int slot)
+{
+    __atomic_store_n(&ctx->cyc_h[slot].seq, 0, __ATOMIC_RELEASE);   // before the launch that will report into it
+    if (nparts > 2048) {   // as fprx_finish_sum; folding stale partials in a skipped cycle only touches scratch
+        const int nb = 128;
+        const int per = (nparts + nb - 1) / nb;
+        double* fold = ctx->partials + FPR_MAX_PARTIALS;
+        k_fold_partials<<<nb, 256, 0, ctx->stream[0]>>>(partials, nparts, per, fold);
+        partials = fold;
+        nparts = nb;
+    }
+    k_cycle_finish<<<1, 256, 0, ctx->stream[0]>>>(partials, nparts, sumsq_out_dev, npoints, ctx->cyc, ctx->state,
+                                                  &ctx->cyc_h[slot]);
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
 }

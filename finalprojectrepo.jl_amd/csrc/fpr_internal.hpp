@@ -29,11 +29,29 @@ struct FprSolveState {
     double rho2[2];  // CG: rho double-buffered by iteration parity (fused 3-launch iteration)
 };
 
+// MGsolve with cycles enqueued ahead of the host's convergence check (multigrid2d.hip, fpr_mgsolve2d): the decision
+// "r_rms < tol * f_rms" (multigrid.jl:70) is taken on the device when a cycle finishes, and every launch of a later cycle
+// returns at once when it finds `stop` set -- so a cycle enqueued before the host has seen the previous norm changes
+// nothing if the loop had already ended.
+struct FprCycleCtl {
+    int stop;          // 1 once a finished cycle met the criterion
+    int ncycles;       // cycles executed
+    int coarse_iters;  // coarse-solver iterations of all executed cycles
+    int seq;           // host record only: = ncycles, written LAST (the host polls it; 0 = not yet reported)
+    double tolf;       // tol * f_rms
+    double rms;        // r_rms of the last executed cycle
+};
+constexpr int FPR_CYC_SLOTS = 8;
+
 struct FprLevel {  // one multigrid level's scratch (role of prealloc_dict, multigrid.jl:25-38)
     int nx = 0, ny = 0;
     double* tmp = nullptr;    // ping-pong partner of u on this level
     double* res_c = nullptr;  // restricted residual = rhs of the next coarser level
     double* corr_c = nullptr; // coarse correction = u of the next coarser level
+    // finest level of fpr_mgsolve2d's seam passes only (allocated on first use): a second ping-pong partner, so that u itself
+    // is never scratch, and a second coarse correction, so that one pass can read cycle k's while it zeroes cycle k+1's
+    double* tmp2 = nullptr;
+    double* corr_c2 = nullptr;
 };
 
 struct FprGrid {  // implicit global grid of the decomposed diffusion path (role of ImplicitGlobalGrid's global state)
@@ -61,6 +79,10 @@ struct fpr_ctx {
     FprSolveState* state = nullptr; // device
     FprSolveState* state_h = nullptr;  // pinned host mirror
     double* host_scalars = nullptr;    // pinned, 64 doubles
+    FprCycleCtl* cyc = nullptr;        // device
+    FprCycleCtl* cyc_h = nullptr;      // pinned, FPR_CYC_SLOTS records (one per cycle in flight)
+    const int* cyc_skip = nullptr;     // &cyc->stop while fpr_mgsolve2d runs cycles ahead, else null (launches unconditional)
+    int cyc_slot = 0;                  // record slot (of cyc_h) the cycle being enqueued reports into
     std::map<std::pair<int, int>, std::vector<FprLevel>> arenas;  // keyed by finest (nx, ny)
     double* cg_buf = nullptr;          // CG work vectors (krylov.jl:59-62)
     size_t cg_cap = 0;                 // capacity of cg_buf in doubles
@@ -213,5 +235,8 @@ int fprx_sumsq_scaled_dev(fpr_ctx* ctx, const double* x, size_t n, double scale,
 int fprx_dot_dev(fpr_ctx* ctx, const double* x, const double* y, size_t n, double* out_dev);
 // finish a two-stage reduction: out_dev[0] (= or +=) sum(partials[0..nparts))
 int fprx_finish_sum(fpr_ctx* ctx, const double* partials, int nparts, double* out_dev, bool accumulate, int stream_sel);
+int fprx_cycle_init(fpr_ctx* ctx, double tolf);
+int fprx_cycle_finish(fpr_ctx* ctx, const double* partials, int nparts, double* sumsq_out_dev, double npoints, int slot);
+int fprx_cycle_wait(fpr_ctx* ctx, int slot, int seq, FprCycleCtl* out);
 int fprx_finish_sum2(fpr_ctx* ctx, const double* p0, const double* p1, int nparts, double* out2_dev, bool accumulate,
                      int stream_sel);

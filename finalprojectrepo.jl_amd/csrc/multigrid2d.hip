@@ -220,8 +220,9 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
                                                         double fac, int rows_per_chunk, int nstrips,
                                                         double* __restrict__ partials, const double* __restrict__ corr_c,
                                                         int apply_BCs, double* __restrict__ res_c_out,
-                                                        double* __restrict__ corr_c_out)
+                                                        double* __restrict__ corr_c_out, const int* __restrict__ skip)
 {
+    if (skip && *skip) return;   // a cycle enqueued ahead of the exit test that ended the loop (FprCycleCtl)
     __shared__ double red[16];
     constexpr int HX = RESTRICT ? 3 : 2;                     // feeder lanes on each side of a strip
     constexpr int SW = 64 - 2 * HX;                          // columns owned by a strip
@@ -369,6 +370,161 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
         const double sblk = fpr_block_sum<256>(acc, red);
         if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
     }
+}
+
+// ---- the seam between two V-cycles on the finest level: FOUR sweeps in one pass ------------------------------
+// MGsolve_2DPoisson! (multigrid.jl:57-71) runs V-cycle after V-cycle on the same arrays: the post-smoothing pair of
+// cycle k (:142-143, on the field corrected by the prolongated coarse solution, :136-139) is followed -- if the exit
+// test :70 does not end the loop -- by the pre-smoothing pair of cycle k+1 (:124-125) and its residual + injection
+// (:128-132).  k_seam_march does all of that in ONE pass over the finest grid: the same register-rolling march as
+// k_smooth2_march with five 3-row windows (the corrected input, the fields after sweeps 1..4) and a residual stage,
+//     read  uin (+ P(corr_c) on the fly), f                          (8 + 8 + 2 bytes per point)
+//     write the twice pre-smoothed field of cycle k+1, its restricted residual, the zero coarse guess   (8 + 2 + 2)
+// -- 30 bytes per point and cycle where the two separate passes move 26 + 28.  The field after sweep 2 is u at the end
+// of cycle k: it is not stored (its residual norm, the r_rms of :252, is summed exactly like k_smooth2_march<NORM>
+// does); if that norm ends the loop the host replays the plain post-smoothing pass from the untouched inputs
+// (fpr_mgsolve2d).  Same point arithmetic as k_sweep2d / prolong_bf: all fields bit-identical to the separate passes.
+// Strips overlap by 10 columns (54 owned of 64), chunks by 5 + 4 rows.  No boundary conditions between the cycles
+// (apply_BCs = 0 only: with them :60-62 changes boundary values between sweep 2 and sweep 3).
+__global__ __launch_bounds__(256) void k_seam_march(const double* __restrict__ uin, const double* __restrict__ f,
+                                                     double* __restrict__ uout, int nx, int ny, double C, double _h2,
+                                                     double fac, int rows_per_chunk, int nstrips,
+                                                     double* __restrict__ partials, const double* __restrict__ corr_c,
+                                                     double* __restrict__ res_c_out, double* __restrict__ corr_c_out,
+                                                     const int* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    __shared__ double red[16];
+    constexpr int HX = 5;                                    // feeder lanes on each side of a strip
+    constexpr int SW = 64 - 2 * HX;                          // columns owned by a strip
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + w;
+    const bool active = strip < nstrips;
+    const int gi = strip * SW - HX + lane;                   // global column of this lane
+    const bool col_ok = active && gi >= 0 && gi < nx;
+    const int gic = gi < 0 ? 0 : (gi > nx - 1 ? nx - 1 : gi);  // clamped for loads
+    const bool col_bnd = gi <= 0 || gi >= nx - 1;            // domain boundary column (or outside)
+    const bool owner = col_ok && lane >= HX && lane < 64 - HX;
+    const int y0 = blockIdx.y * rows_per_chunk;
+    const int y1 = (y0 + rows_per_chunk < ny) ? y0 + rows_per_chunk : ny;  // output rows [y0, y1)
+    const int rs = y0 - HX < 0 ? 0 : y0 - HX;
+    double acc = 0.0;
+    if (active) {
+        const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
+        // the two coarse columns this lane interpolates from, cached for coarse rows pj and pj+1 (see k_smooth2_march)
+        const int p_io = gic & 1, p_icl = gic >> 1, p_ich = (p_icl + 1 < nxc) ? p_icl + 1 : nxc - 1;
+        const bool p_sx0 = p_icl >= 1 && p_icl <= nxc - 2, p_sx1 = p_io && (p_icl + 1 <= nxc - 2);
+        const bool p_inx = gic >= 1 && gic <= nx - 2;
+        int pj = -2;
+        double pc00 = 0.0, pc10 = 0.0, pc01 = 0.0, pc11 = 0.0;
+        const int rowB = nx * 8;
+        const __amdgpu_buffer_rsrc_t rUin = fpr_rsrc(uin + (size_t)nx * rs), rF = fpr_rsrc(f + (size_t)nx * rs);
+        const __amdgpu_buffer_rsrc_t rUout = fpr_rsrc(uout + (size_t)nx * rs);
+        const unsigned vld = (unsigned)gic * 8u;
+        const unsigned vst = owner ? (unsigned)gi * 8u : FPR_OOR;   // lanes that own nothing store out of range
+        auto ldu = [&](int r) {
+            const int rc = r > ny - 1 ? ny - 1 : r;
+            const double v = fpr_bld(rUin, vld, (rc - rs) * rowB);
+            const int jo = rc & 1, jcl = rc >> 1;
+            if (jcl != pj) {
+                const int jch = (jcl + 1 < nyc) ? jcl + 1 : nyc - 1;
+                if (jcl == pj + 1) { pc00 = pc01; pc10 = pc11; }
+                else { pc00 = corr_c[(size_t)p_icl + (size_t)nxc * jcl]; pc10 = corr_c[(size_t)p_ich + (size_t)nxc * jcl]; }
+                pc01 = corr_c[(size_t)p_icl + (size_t)nxc * jch];
+                pc11 = corr_c[(size_t)p_ich + (size_t)nxc * jch];
+                pj = jcl;
+            }
+            // same value and accumulation order as prolong_bf
+            const bool in = p_inx && rc >= 1 && rc <= ny - 2;
+            const double wgt = (p_io | jo) ? ((p_io & jo) ? 0.25 : 0.5) : 1.0;
+            const bool sy0 = jcl >= 1 && jcl <= nyc - 2, sy1 = jo && (jcl + 1 <= nyc - 2);
+            double pv = 0.0;
+            pv = pv + ((in && p_sx0 && sy0) ? wgt * pc00 : 0.0);
+            pv = pv + ((in && p_sx1 && sy0) ? wgt * pc10 : 0.0);
+            pv = pv + ((in && p_sx0 && sy1) ? wgt * pc01 : 0.0);
+            pv = pv + ((in && p_sx1 && sy1) ? wgt * pc11 : 0.0);
+            return v - pv;
+        };
+        auto ldf = [&](int r) { const int rc = r > ny - 1 ? ny - 1 : r; return fpr_bld(rF, vld, (rc - rs) * rowB); };
+        // 3-row windows: w0 = corrected input rows r-2..r, wK = field after sweep K, rows r-K-2 .. r-K
+        double w0a = 0.0, w0b = 0.0, w0c = ldu(rs);
+        double w1a = 0.0, w1b = 0.0, w1c = 0.0;
+        double w2a = 0.0, w2b = 0.0, w2c = 0.0;
+        double w3a = 0.0, w3b = 0.0, w3c = 0.0;
+        double w4a = 0.0, w4b = 0.0, w4c = 0.0;
+        double f5 = 0.0, f4 = 0.0, f3 = 0.0, f2 = 0.0, f1 = 0.0, f0 = ldf(rs);   // f rows r-5 .. r
+        constexpr int PF = 4;
+        double pu[PF], pfv[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) { pu[q] = ldu(rs + 1 + q); pfv[q] = ldf(rs + 1 + q); }
+        const __amdgpu_buffer_rsrc_t rResC = fpr_rsrc(res_c_out), rCorC = fpr_rsrc(corr_c_out);
+        const unsigned vstc = (owner && !(gi & 1)) ? (unsigned)(gi >> 1) * 8u : FPR_OOR;
+        // one Jacobi sweep at row j of a field whose rows j-1, j, j+1 are (lo, mid, hi); rr = residual used by the update
+        auto sweep = [&](double lo, double mid, double hi, double fv, int j, double& rr) {
+            const double L = fpr_lane_up1(mid), R = fpr_lane_down1(mid);
+            rr = ((((R + L) + hi) + lo) - C * mid) * _h2 - fv;
+            const bool bnd = col_bnd || j <= 0 || j >= ny - 1;
+            return bnd ? mid : mid + fac * rr;
+        };
+        auto step = [&](auto Qc, int r) {
+            constexpr int Q = decltype(Qc)::value;
+            double an, fn;
+            asm volatile("v_mov_b64 %0, %1" : "=v"(an) : "v"(pu[Q]));
+            asm volatile("v_mov_b64 %0, %1" : "=v"(fn) : "v"(pfv[Q]));
+            pu[Q] = ldu(r + 1 + PF);                           // issue the loads of row r+1+PF
+            pfv[Q] = ldf(r + 1 + PF);
+            double rr;
+            // ---- cycle k, post-smoothing (:142-143): sweeps 1 and 2 at rows r-1, r-2 ----
+            const double u1 = sweep(w0a, w0b, w0c, f1, r - 1, rr);
+            w1a = w1b; w1b = w1c; w1c = u1;                    // rows r-3, r-2, r-1
+            const int j2 = r - 2;
+            const double u2 = sweep(w1a, w1b, w1c, f2, j2, rr);
+            {
+                const bool bnd = col_bnd || j2 <= 0 || j2 >= ny - 1;
+                const bool row_own = j2 >= y0 && j2 < y1;      // uniform
+                if (owner && row_own && !bnd) acc += rr * rr;  // r_rms of cycle k (:252)
+            }
+            w2a = w2b; w2b = w2c; w2c = u2;                    // rows r-4, r-3, r-2  (u at the end of cycle k)
+            // ---- cycle k+1, pre-smoothing (:124-125): sweeps 3 and 4 at rows r-3, r-4 ----
+            const double u3 = sweep(w2a, w2b, w2c, f3, r - 3, rr);
+            w3a = w3b; w3b = w3c; w3c = u3;                    // rows r-5, r-4, r-3
+            const int j4 = r - 4;
+            const double u4 = sweep(w3a, w3b, w3c, f4, j4, rr);
+            {
+                const bool row_own = j4 >= y0 && j4 < y1;      // uniform
+                fpr_bst(rUout, vst, row_own ? (j4 - rs) * rowB : (int)FPR_OOR, u4);   // unconditional (see FPR_OOR)
+            }
+            w4a = w4b; w4b = w4c; w4c = u4;                    // rows r-6, r-5, r-4
+            // ---- residual of the pre-smoothed field at row r-5, injected at even (row, column) (:128-132) ----
+            {
+                const int j5 = r - 5;
+                const double L = fpr_lane_up1(w4b), R = fpr_lane_down1(w4b);
+                const double rres = ((((R + L) + w4c) + w4a) - C * w4b) * _h2 - f5;
+                const int ic = gi >> 1, jc = j5 >> 1;
+                const bool cint = ic >= 1 && ic <= nxc - 2 && jc >= 1 && jc <= nyc - 2;
+                const bool row_inj = j5 >= y0 && j5 < y1 && !(j5 & 1);   // uniform
+                const int sc = row_inj ? jc * (nxc * 8) : (int)FPR_OOR;
+                fpr_bst(rResC, vstc, sc, cint ? rres : 0.0);
+                fpr_bst(rCorC, vstc, sc, 0.0);
+            }
+            w0a = w0b; w0b = w0c; w0c = an;
+            f5 = f4; f4 = f3; f3 = f2; f2 = f1; f1 = f0; f0 = fn;
+        };
+        const int rend = y1 + 4;
+        int r = rs;
+        static_assert(PF == 4, "the unrolled row loop below is written for PF = 4");
+        for (; r + PF - 1 <= rend; r += PF) {
+            step(std::integral_constant<int, 0>{}, r);
+            step(std::integral_constant<int, 1>{}, r + 1);
+            step(std::integral_constant<int, 2>{}, r + 2);
+            step(std::integral_constant<int, 3>{}, r + 3);
+        }
+        if (r <= rend) { step(std::integral_constant<int, 0>{}, r); ++r; }
+        if (r <= rend) { step(std::integral_constant<int, 1>{}, r); ++r; }
+        if (r <= rend) { step(std::integral_constant<int, 2>{}, r); ++r; }
+    }
+    const double sblk = fpr_block_sum<256>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
 }
 
 // ---- S fused Jacobi sweeps, register patches (coarse solve on grids too large for one workgroup) ------
@@ -544,8 +700,9 @@ __global__ __launch_bounds__(256) void k_smooth2_march2(const double* __restrict
                                                          double fac, int rows_per_chunk, int nstrips,
                                                          double* __restrict__ partials, const double* __restrict__ corr_c,
                                                          int apply_BCs, double* __restrict__ res_c_out,
-                                                         double* __restrict__ corr_c_out)
+                                                         double* __restrict__ corr_c_out, const int* __restrict__ skip)
 {
+    if (skip && *skip) return;   // a cycle enqueued ahead of the exit test that ended the loop (FprCycleCtl)
     __shared__ double red[16];
     // Feeder COLUMNS: HXL on the left, HXR on the right.  On rows whose start is only 8-byte aligned (odd rows of
     // an odd-width grid) the lane <-> column mapping is shifted by one column so that every 16-byte access stays
@@ -862,15 +1019,17 @@ __global__ __launch_bounds__(256) void k_laplace2d(const double* __restrict__ T,
 }
 
 // ---- B6: boundary conditions, part2_utils.jl:22-39 ------------------------------------------------
-__global__ __launch_bounds__(256) void k_bc_dirichlet(double* __restrict__ T, int nx, int ny)
+__global__ __launch_bounds__(256) void k_bc_dirichlet(double* __restrict__ T, int nx, int ny, const int* __restrict__ skip)
 {
+    if (skip && *skip) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nx) return;
     T[i] = 1.0;
     T[(size_t)i + (size_t)nx * (ny - 1)] = 0.0;
 }
-__global__ __launch_bounds__(256) void k_bc_neumann(double* __restrict__ T, int nx, int ny)
+__global__ __launch_bounds__(256) void k_bc_neumann(double* __restrict__ T, int nx, int ny, const int* __restrict__ skip)
 {
+    if (skip && *skip) return;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= ny) return;
     T[(size_t)nx * j] = T[(size_t)nx * j + 1];
@@ -1231,6 +1390,7 @@ struct MgSmallArgs {
     int css, apply_BCs, want_norm;
     double* out_sumsq;  // want_norm: sum(res.^2) of the last post-smoothing sweep of the top level
     FprSolveState* state;
+    const int* skip;    // cycles enqueued ahead: return at once if *skip (null = unconditional)
 };
 
 constexpr int MGS_NT = 1024;
@@ -1277,6 +1437,7 @@ __device__ __forceinline__ double mgs_sweep(const double* uin, const double* f, 
 __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (a.skip && *a.skip) return;
     double* red = sm;
     double* arena = sm + MGS_RED;
     const int tid = threadIdx.x;
@@ -1540,7 +1701,7 @@ extern "C" int fpr_bc_dirichlet2d(fpr_ctx* ctx, double* T, int nx, int ny)
 {
     if (!ctx) return FPR_ERR_INVALID;
     FPR_REQUIRE(ctx, T && nx >= 1 && ny >= 1, "bad array");
-    k_bc_dirichlet<<<(nx + 255) / 256, 256, 0, ctx->stream[0]>>>(T, nx, ny);
+    k_bc_dirichlet<<<(nx + 255) / 256, 256, 0, ctx->stream[0]>>>(T, nx, ny, ctx->cyc_skip);
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
 }
@@ -1549,7 +1710,7 @@ extern "C" int fpr_bc_neumann2d(fpr_ctx* ctx, double* T, int nx, int ny)
 {
     if (!ctx) return FPR_ERR_INVALID;
     FPR_REQUIRE(ctx, T && nx >= 2 && ny >= 1, "bad array");
-    k_bc_neumann<<<(ny + 255) / 256, 256, 0, ctx->stream[0]>>>(T, nx, ny);
+    k_bc_neumann<<<(ny + 255) / 256, 256, 0, ctx->stream[0]>>>(T, nx, ny, ctx->cyc_skip);
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
 }
@@ -1687,6 +1848,49 @@ static int get_arena(fpr_ctx* ctx, int nx, int ny, int css, std::vector<FprLevel
     return FPR_OK;
 }
 
+// Does the sub-hierarchy below an (nx, ny) level fit k_mg_small's LDS arena?  nlev = its levels, tot = doubles needed.
+static bool mgs_plan(int nx, int ny, int css, int* nlev_out, size_t* tot_out)
+{
+    int nlev = 1, lx = nx, ly = ny;
+    size_t tot = 3 * (size_t)lx * ly;
+    while ((lx < ly ? lx : ly) > css) {
+        if ((lx - 1) % 2 || (ly - 1) % 2) return false;
+        const int m = (lx < ly ? lx : ly) - 1;
+        if (m & (m - 1)) return false;
+        lx = 1 + (lx - 1) / 2;
+        ly = 1 + (ly - 1) / 2;
+        tot += 3 * (size_t)lx * ly;
+        ++nlev;
+        if (nlev > 16) return false;
+    }
+    *nlev_out = nlev;
+    *tot_out = tot;
+    return tot + MGS_RED <= 20000;
+}
+
+// True if every launch of a V-cycle on this hierarchy honours FprCycleCtl::stop (the marching passes with fused
+// restriction / prolongation down to an LDS-resident sub-hierarchy, Jacobi coarse solver): fpr_mgsolve2d may then
+// enqueue cycles ahead of the host's convergence check.  Anything else (CG, the per-operation kernels, levels the
+// march does not take, shapes that raise the reference's errors) runs the plain loop.
+static bool vcycle_streams(fpr_ctx* ctx, int nx, int ny, int css, int solver)
+{
+    if (solver != FPR_COARSE_JACOBI || !fpr_opt(ctx, "mg_small", 1) || fpr_opt(ctx, "mg_multi", 1) != 1) return false;
+    if (!fpr_opt(ctx, "mg_fuse_restrict", 1) || !fpr_opt(ctx, "mg_fuse_prolong", 1)) return false;
+    int lx = nx, ly = ny;
+    for (int depth = 0; depth < 32; ++depth) {
+        if ((lx - 1) % 2 || (ly - 1) % 2) return false;
+        const int m = (lx < ly ? lx : ly) - 1;
+        if (m <= 0 || (m & (m - 1))) return false;
+        int nlev;
+        size_t tot;
+        if (mgs_plan(lx, ly, css, &nlev, &tot)) return depth > 0;
+        if (!((lx < ly ? lx : ly) > css && lx >= 64 && ly >= 16)) return false;
+        lx = 1 + (lx - 1) / 2;
+        ly = 1 + (ly - 1) / 2;
+    }
+    return false;
+}
+
 // One level of Vcycle_2DPoisson! (multigrid.jl:91-170).  want_norm: top level only -- the r_rms of the
 // last post-smoothing sweep is left in ctx->scalars[0] (as sum of squares) for the caller.
 static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double* u, const double* rhs, double h, double c,
@@ -1695,6 +1899,7 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
     FprLevel& L = A[d];
     const int nx = L.nx, ny = L.ny;
     hipStream_t s = ctx->stream[0];
+    const int* skp = ctx->cyc_skip;
     if ((nx - 1) != 2 * ((nx - 1) / 2) || (ny - 1) != 2 * ((ny - 1) / 2))
         return fpr_fail(ctx, FPR_ERR_NOT_POW2, "ERROR:not a power of 2 (nx=%d, ny=%d)", nx, ny);  // multigrid.jl:95-97
     {
@@ -1711,20 +1916,10 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
 
     // ---- LDS-resident sub-hierarchy: this level and everything below it in one workgroup ----
     if (solver == FPR_COARSE_JACOBI && fpr_opt(ctx, "mg_small", 1)) {
-        int nlev = 1, lx = nx, ly = ny;
-        size_t tot = 3 * (size_t)lx * ly;
-        bool ok = true;
-        while ((lx < ly ? lx : ly) > css) {
-            if ((lx - 1) % 2 || (ly - 1) % 2) { ok = false; break; }
-            const int m = (lx < ly ? lx : ly) - 1;
-            if (m & (m - 1)) { ok = false; break; }
-            lx = 1 + (lx - 1) / 2;
-            ly = 1 + (ly - 1) / 2;
-            tot += 3 * (size_t)lx * ly;
-            ++nlev;
-            if (nlev > 16) { ok = false; break; }
-        }
-        if (ok && tot + MGS_RED <= 20000) {
+        int nlev = 1;
+        size_t tot = 0;
+        const bool ok = mgs_plan(nx, ny, css, &nlev, &tot);
+        if (ok) {
             static bool attr_set = false;
             if (!attr_set) {
                 FPR_HIP(ctx, hipFuncSetAttribute((const void*)k_mg_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1736,6 +1931,7 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             a.want_norm = (top && nlev > 1) ? 1 : 0;
             a.out_sumsq = ctx->scalars;
             a.state = ctx->state;
+            a.skip = ctx->cyc_skip;
             k_mg_small<<<1, MGS_NT, (tot + MGS_RED) * sizeof(double), s>>>(a);
             FPR_CHECK_LAUNCH(ctx);
             if (top) {
@@ -1773,11 +1969,11 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             if (fuse_r) {  // pre-smoothing pair + residual + injection + zero coarse guess in ONE pass (:124-132)
                 const dim3 gr((nstrips_r + 3) / 4, (ny + rpc - 1) / rpc);
                 const bool timed = top && fpr_ktimer_begin(ctx, FPR_KT_MG_PRE, s);
-                { if (vx2) k_smooth2_march2<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c); else k_smooth2_march<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c); }
+                { if (vx2) k_smooth2_march2<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c, skp); else k_smooth2_march<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c, skp); }
                 fpr_ktimer_end(ctx, timed, s);
-                if (apply_BCs) k_bc_neumann<<<(nyc + 255) / 256, 256, 0, s>>>(L.res_c, nxc, nyc);  // :355-357
+                if (apply_BCs) k_bc_neumann<<<(nyc + 255) / 256, 256, 0, s>>>(L.res_c, nxc, nyc, skp);  // :355-357
             } else {
-                { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr); else k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr); }  // :124-125
+                { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); else k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); }  // :124-125
                 k_restrict_residual2d<<<grid2(nxc, nyc), blk2, 0, s>>>(L.tmp, rhs, L.res_c, nx, ny, C, _h2, apply_BCs, L.corr_c);  // :128-132
             }
             FPR_CHECK_LAUNCH(ctx);
@@ -1788,15 +1984,16 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             // post-smoothing pair (:142-143); with fuse_p the correction u - P(corr_c) is applied while loading
             if (top) {
                 const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_POST, s);
-                if (fuse_p) { if (vx2) k_smooth2_march2<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs | ntf, nullptr, nullptr); else k_smooth2_march<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs | ntf, nullptr, nullptr); }
-                else { if (vx2) k_smooth2_march2<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, ntf, nullptr, nullptr); else k_smooth2_march<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, ntf, nullptr, nullptr); }
+                if (fuse_p) { if (vx2) k_smooth2_march2<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs | ntf, nullptr, nullptr, skp); else k_smooth2_march<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs | ntf, nullptr, nullptr, skp); }
+                else { if (vx2) k_smooth2_march2<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, ntf, nullptr, nullptr, skp); else k_smooth2_march<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, ntf, nullptr, nullptr, skp); }
                 fpr_ktimer_end(ctx, timed, s);
                 FPR_CHECK_LAUNCH(ctx);
-                if (int rc = fprx_finish_sum(ctx, ctx->partials, npm, ctx->scalars, false, 0)) return rc;
+                if (skp) { if (int rc = fprx_cycle_finish(ctx, ctx->partials, npm, ctx->scalars, (double)nx * (double)ny, ctx->cyc_slot)) return rc; }
+                else if (int rc = fprx_finish_sum(ctx, ctx->partials, npm, ctx->scalars, false, 0)) return rc;
                 *rms_is_host = false;
             } else {
-                if (fuse_p) { if (vx2) k_smooth2_march2<false, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs | ntf, nullptr, nullptr); else k_smooth2_march<false, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs | ntf, nullptr, nullptr); }
-                else { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr); else k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr); }
+                if (fuse_p) { if (vx2) k_smooth2_march2<false, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs | ntf, nullptr, nullptr, skp); else k_smooth2_march<false, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs | ntf, nullptr, nullptr, skp); }
+                else { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); else k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); }
                 FPR_CHECK_LAUNCH(ctx);
             }
             return FPR_OK;
@@ -1948,6 +2145,77 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
     return FPR_OK;
 }
 
+// ---- finest level of fpr_mgsolve2d when consecutive cycles share a pass (k_seam_march) -------------------------------
+struct TopGeom {
+    int nx, ny, rpc, rpc_s, nstrips, nstrips_r, nstrips_s, ntf;
+    dim3 gm, gr, gs;
+    double C, _h2, fac;
+};
+
+static TopGeom top_geom(fpr_ctx* ctx, int nx, int ny, double h, double c)
+{
+    TopGeom g;
+    g.nx = nx; g.ny = ny;
+    g.C = 4.0 + c * (h * h); g._h2 = 1 / (h * h);
+    g.fac = (4.0 / 5.0) * ((h * h) / (4.0 + c * (h * h)));
+    g.ntf = fpr_opt(ctx, "mg_nt", 0) ? 256 : 0;
+    g.nstrips = (nx + 59) / 60;      // as vcycle_level (one column per lane)
+    g.nstrips_r = (nx + 57) / 58;
+    g.nstrips_s = (nx + 53) / 54;    // k_seam_march: 54 owned columns per strip
+    int rpc = (int)fpr_opt(ctx, "mg_rows_per_chunk", 0);
+    if (rpc <= 0) {
+        const long target = fpr_opt(ctx, "mg_wave_target", 4096);
+        rpc = 64;
+        while (rpc > 16 && (long)g.nstrips * ((ny + rpc - 1) / rpc) < target) rpc >>= 1;
+    }
+    g.rpc = rpc;
+    int rs = (int)fpr_opt(ctx, "mg_seam_rows_per_chunk", 0);
+    g.rpc_s = rs > 0 ? rs : rpc;
+    g.gm = dim3((g.nstrips + 3) / 4, (ny + rpc - 1) / rpc);
+    g.gr = dim3((g.nstrips_r + 3) / 4, (ny + rpc - 1) / rpc);
+    g.gs = dim3((g.nstrips_s + 3) / 4, (ny + g.rpc_s - 1) / g.rpc_s);
+    return g;
+}
+
+// pre-smoothing pair + residual + injection + zero coarse guess (:124-132): uin -> out, L.res_c, corr_zero
+static int top_pre(fpr_ctx* ctx, const TopGeom& g, const double* uin, const double* rhs, double* out, double* res_c,
+                   double* corr_zero, const int* skp)
+{
+    hipStream_t s = ctx->stream[0];
+    const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_PRE, s);
+    k_smooth2_march<false, false, true><<<g.gr, 256, 0, s>>>(uin, rhs, out, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips_r, nullptr,
+                                                             nullptr, g.ntf, res_c, corr_zero, skp);
+    fpr_ktimer_end(ctx, timed, s);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+// prolongation + correction + post-smoothing pair (:136-143): X - P(corr) -> uout; norm: block sums into ctx->partials
+static int top_post(fpr_ctx* ctx, const TopGeom& g, const double* X, const double* rhs, const double* corr, double* uout,
+                    bool norm, const int* skp)
+{
+    hipStream_t s = ctx->stream[0];
+    const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_POST, s);
+    if (norm) k_smooth2_march<true, true, false><<<g.gm, 256, 0, s>>>(X, rhs, uout, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips, ctx->partials, corr, g.ntf, nullptr, nullptr, skp);
+    else k_smooth2_march<false, true, false><<<g.gm, 256, 0, s>>>(X, rhs, uout, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips, nullptr, corr, g.ntf, nullptr, nullptr, skp);
+    fpr_ktimer_end(ctx, timed, s);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+// the seam: post pair of cycle k (+ norm) and pre pair + residual + injection of cycle k+1: X - P(corr) -> Y, res_c, corr_zero
+static int top_seam(fpr_ctx* ctx, const TopGeom& g, const double* X, const double* rhs, const double* corr, double* Y,
+                    double* res_c, double* corr_zero, const int* skp)
+{
+    hipStream_t s = ctx->stream[0];
+    const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_SEAM, s);
+    k_seam_march<<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c,
+                                       corr_zero, skp);
+    fpr_ktimer_end(ctx, timed, s);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
 static int vcycle_run(fpr_ctx* ctx, double* u, const double* rhs, double h, double c, double tol, int css, int solver,
                       int apply_BCs, int nx, int ny, double* rms_host)
 {
@@ -1957,7 +2225,8 @@ static int vcycle_run(fpr_ctx* ctx, double* u, const double* rhs, double h, doub
     bool is_host = true;
     ctx->used_small = false;
     ctx->top_is_coarsest = false;
-    FPR_HIP(ctx, hipMemsetAsync(&ctx->state->acc_iters, 0, sizeof(int), ctx->stream[0]));
+    if (!ctx->cyc_skip)   // (cycles enqueued ahead accumulate over the whole solve: k_cycle_init zeroed it)
+        FPR_HIP(ctx, hipMemsetAsync(&ctx->state->acc_iters, 0, sizeof(int), ctx->stream[0]));
     if (int rc = vcycle_level(ctx, *A, 0, u, rhs, h, c, tol, css, solver, apply_BCs, true, &r, &is_host)) return rc;
     if (rms_host) {
         if (ctx->used_small)  // fetch the device-side iteration count / coarse rms with the same sync
@@ -2005,6 +2274,123 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
     double r_rms = 0.0;
     int n = 0;
     ctx->last_coarse_iters = 0;
+    int ahead = (int)fpr_opt(ctx, "mg_ahead", 1);
+    if (ahead > FPR_CYC_SLOTS - 2) ahead = FPR_CYC_SLOTS - 2;
+    if (ahead > 0 && niters > 1 && vcycle_streams(ctx, nx, ny, coarse_solve_size, coarse_solver)) {
+        // Cycles are enqueued `ahead` deep before the host waits for the norm of the oldest one: the exit test (:70) is
+        // evaluated on the device by k_cycle_finish, and all launches of a cycle that follows the one that met it return
+        // at once -- fields, norms and cycle count are those of the plain loop, without a host round trip per cycle.
+        struct Guard { fpr_ctx* c; ~Guard() { c->cyc_skip = nullptr; } } guard{ctx};
+        if (int rc = fprx_cycle_init(ctx, tolf)) return rc;
+        ctx->cyc_skip = &ctx->cyc->stop;
+        const int* skp = ctx->cyc_skip;
+        int enq = 0;
+        if (!apply_BCs && fpr_opt(ctx, "mg_seam", 1) && fpr_opt(ctx, "mg_vx", 1) != 2) {
+            // ---- consecutive cycles share their pass over the finest grid (k_seam_march) ----
+            // unit k = the end of cycle k: either the plain post-smoothing pass (k = niters, or the norms seen so far say
+            // that cycle k will meet the exit test) or a seam pass that also starts cycle k+1, followed by cycle k+1's
+            // coarser levels.  If a seam's norm ends the loop, everything enqueued behind it returns at once and the plain
+            // post-smoothing pass is replayed from the seam's inputs, which nothing has touched.
+            std::vector<FprLevel>* A;
+            if (int rc = get_arena(ctx, nx, ny, coarse_solve_size, &A)) return rc;
+            FprLevel& L = (*A)[0];
+            if (!L.res_c) return fpr_fail(ctx, FPR_ERR_INVALID, "level arena exhausted");
+            const size_t nc = (size_t)(1 + (nx - 1) / 2) * (size_t)(1 + (ny - 1) / 2);
+            if (!L.tmp2) FPR_HIP(ctx, hipMalloc(&L.tmp2, N * sizeof(double)));
+            if (!L.corr_c2) FPR_HIP(ctx, hipMalloc(&L.corr_c2, nc * sizeof(double)));
+            double* corr[2] = {L.corr_c, L.corr_c2};
+            const TopGeom g = top_geom(ctx, nx, ny, h, c);
+            const int npm = (int)(g.gm.x * g.gm.y), nps = (int)(g.gs.x * g.gs.y);
+            if (npm > FPR_MAX_PARTIALS || nps > FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
+            struct Unit { bool seam; const double* X; int p; } units[FPR_CYC_SLOTS];
+            double* X = nullptr;
+            int p = 0;
+            bool need_head = true;
+            double r_prev = 0.0, r_last = 0.0;   // the last two norms the host has seen
+            ctx->used_small = false;
+            auto lower = [&](int pp) -> int {
+                double dummy; bool dh;
+                return vcycle_level(ctx, *A, 1, corr[pp], L.res_c, h * 2, c, tol, coarse_solve_size, coarse_solver, 0, false, &dummy, &dh);
+            };
+            auto enqueue_unit = [&]() -> int {
+                const int k = enq + 1;
+                if (need_head) {   // first cycle, or the loop goes on after a plain post-smoothing pass
+                    if (int rc = top_pre(ctx, g, u, f, L.tmp, L.res_c, corr[0], skp)) return rc;
+                    if (int rc = lower(0)) return rc;
+                    X = L.tmp; p = 0; need_head = false;
+                }
+                bool last = (k == niters);
+                // mg_seam_predict: 1 = extrapolate (default); 0 = never (every cycle but the niters-th ends in a seam, the
+                // last one is replayed); 2 = odd cycles end in a plain pass (exercises the restart after a wrong guess)
+                const long predict = fpr_opt(ctx, "mg_seam_predict", 1);
+                if (predict == 2 && (k & 1)) last = true;
+                if (!last && predict == 1 && n >= 2 && r_last < r_prev && r_last > 0.0) {   // geometric extrapolation of the norm to cycle k
+                    double pred = r_last;
+                    const double rate = r_last / r_prev;
+                    for (int q = n; q < k; ++q) pred *= rate;
+                    last = pred < tolf;
+                }
+                const int slot = enq % FPR_CYC_SLOTS;
+                if (last) {
+                    if (int rc = top_post(ctx, g, X, f, corr[p], u, true, skp)) return rc;
+                    if (int rc = fprx_cycle_finish(ctx, ctx->partials, npm, ctx->scalars, (double)N, slot)) return rc;
+                    units[slot] = {false, X, p};
+                    need_head = true;
+                } else {
+                    double* Y = (X == L.tmp) ? L.tmp2 : L.tmp;
+                    if (int rc = top_seam(ctx, g, X, f, corr[p], Y, L.res_c, corr[1 - p], skp)) return rc;
+                    if (int rc = fprx_cycle_finish(ctx, ctx->partials, nps, ctx->scalars, (double)N, slot)) return rc;
+                    if (int rc = lower(1 - p)) return rc;   // cycle k+1 below the finest level
+                    units[slot] = {true, X, p};
+                    X = Y; p = 1 - p;
+                }
+                ++enq;
+                return FPR_OK;
+            };
+            while (true) {
+                // (nothing is enqueued behind a cycle that is expected to end the loop: if it does, nothing is skipped)
+                while (enq < niters && enq - n < 1 + ahead && !(need_head && enq > n))
+                    if (int rc = enqueue_unit()) return rc;
+                if (n >= enq) break;
+                const int slot = n % FPR_CYC_SLOTS;
+                FprCycleCtl rec;
+                if (int rc = fprx_cycle_wait(ctx, slot, n + 1, &rec)) return rc;
+                r_rms = rec.rms;
+                r_prev = r_last; r_last = r_rms;
+                ctx->last_coarse_iters = rec.coarse_iters;
+                if (history_host) history_host[n] = r_rms;
+                ++n;
+                if (rec.stop) {   // :70 (taken on the device)
+                    if (units[slot].seam)   // u at the end of this cycle was never stored: replay its post-smoothing pass
+                        if (int rc = top_post(ctx, g, units[slot].X, f, corr[units[slot].p], u, false, nullptr)) return rc;
+                    break;
+                }
+            }
+        } else {
+        auto enqueue_cycle = [&]() -> int {
+            if (apply_BCs)
+                if (int rc = fpr_bc2d(ctx, u, nx, ny)) return rc;  // :60-62
+            const int slot = enq % FPR_CYC_SLOTS;
+            ctx->cyc_slot = slot;   // k_cycle_finish writes the record of this cycle into pinned host memory itself
+            if (int rc = vcycle_run(ctx, u, f, h, c, tol, coarse_solve_size, coarse_solver, apply_BCs, nx, ny, nullptr)) return rc;
+            ++enq;
+            return FPR_OK;
+        };
+        while (true) {
+            while (enq < niters && enq - n < 1 + ahead)
+                if (int rc = enqueue_cycle()) return rc;
+            if (n >= enq) break;
+            const int slot = n % FPR_CYC_SLOTS;
+            FprCycleCtl rec;
+            if (int rc = fprx_cycle_wait(ctx, slot, n + 1, &rec)) return rc;
+            r_rms = rec.rms;
+            ctx->last_coarse_iters = rec.coarse_iters;
+            if (history_host) history_host[n] = r_rms;
+            ++n;
+            if (rec.stop) break;  // :70 (taken on the device)
+        }
+        }
+    } else
     for (int iter = 1; iter <= niters; ++iter) {
         if (apply_BCs)
             if (int rc = fpr_bc2d(ctx, u, nx, ny)) return rc;  // :60-62

@@ -64,7 +64,9 @@ enum {
     FPR_KT_DIFF3_STEP = 0,    /* k_diff3_march: one pseudo-iteration per launch                               */
     FPR_KT_DIFF3_STEP2 = 1,   /* k_diff3_march2: two pseudo-iterations per launch                             */
     FPR_KT_MG_PRE = 2,        /* finest level of a V-cycle: 2 sweeps + residual + injection in one pass       */
-    FPR_KT_MG_POST = 3        /* finest level of a V-cycle: prolongation + correction + 2 sweeps (+ norm)     */
+    FPR_KT_MG_POST = 3,       /* finest level of a V-cycle: prolongation + correction + 2 sweeps (+ norm)     */
+    FPR_KT_MG_SEAM = 4        /* finest level between two V-cycles of fpr_mgsolve2d: post pair of cycle k + norm +
+                                 pre pair + residual + injection of cycle k+1 in one pass (k_seam_march)         */
 };
 int fpr_kernel_timer(fpr_ctx* ctx, int enable);
 int fpr_kernel_timer_read(fpr_ctx* ctx, int kind, double* total_ms_host, long* count_host);

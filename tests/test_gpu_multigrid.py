@@ -432,3 +432,61 @@ def test_small_and_rectangular_hierarchies(fpr, oracle, shape, css, bc):
     assert np.allclose(hist, hist_ref, rtol=1e-10, atol=0)
     assert np.array_equal(F.tonumpy(gu), u_ref)
     assert cit == oracle.last_coarse_iters()
+
+
+@pytest.mark.parametrize("shape,css,bcs,tol,niters", [
+    ((257, 257), 5, False, 1e-6, 100),      # converges after several cycles
+    ((257, 257), 5, False, 1e-30, 4),       # never converges: stops at niters
+    ((513, 129), 9, True, 1e-5, 100),       # Neumann columns + Dirichlet rows re-applied every cycle (:60-62): no seam
+    ((1025, 1025), 5, False, 1e-1, 100),    # converges in the very first cycles: what was enqueued ahead must not run
+    ((2049, 2049), 17, True, 1e-7, 50),
+    ((2049, 1025), 17, False, 1e-9, 50),
+    ((129, 129), 5, False, 1e-6, 100),      # one marched level above the LDS-resident sub-hierarchy
+    ((4097, 4097), 5, False, 1e-6, 100),    # BASELINE config 3
+], ids=str)
+def test_cycles_enqueued_ahead_equal_the_plain_loop(fpr, shape, css, bcs, tol, niters):
+    """MGsolve_2DPoisson! (multigrid.jl:41-84) with its exit test (:70) taken on the device, 0..3 cycles enqueued before
+    the host has seen the previous norm (mg_ahead) and -- without boundary conditions -- consecutive cycles sharing one
+    pass over the finest grid (k_seam_march: post-smoothing of cycle k + pre-smoothing, residual, injection of cycle k+1),
+    against the plain loop that waits for every norm: the field is identical bit for bit, the cycle count and the
+    coarse-solver iteration count are identical, the residual history agrees to summation order (bit for bit where the
+    same kernels produce it).  Covers loops that end in their first cycles, at niters, on a seam (replay of the plain
+    post-smoothing pass), on a predicted last cycle, after a wrong prediction, and a second solve right behind the first."""
+    import warnings
+
+    F, mg = fpr, fpr.multigrid
+    c = F.ctx()
+    f = rnd(shape, 5)
+    if bcs:
+        f = f - 0.5
+    opt = mg.MGOpt()
+    opt.coarse_solve_size = css
+    h = 1.0 / (shape[0] - 1)
+    outs = []
+    variants = [(0, 0, 1), (1, 0, 1), (3, 0, 1), (0, 1, 1), (1, 1, 1), (3, 1, 1), (1, 1, 0), (2, 1, 2)]
+    try:
+        for ahead, seam, predict in variants:
+            c.set_option("mg_ahead", ahead)
+            c.set_option("mg_seam", seam)
+            c.set_option("mg_seam_predict", predict)
+            for rep in range(2):    # the second solve starts while the skipped launches of the first are still queued
+                u = F.asdevice(rnd(shape, 6) if bcs else np.zeros(shape))
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    r, hist, frms, cit = mg.MGsolve_2DPoisson_(u, F.asdevice(f), h, 0.0, tol, niters, bcs, opt=opt, return_history=True)
+            outs.append((r, hist, frms, cit, F.tonumpy(u)))
+    finally:
+        c.set_option("mg_ahead", 1)
+        c.set_option("mg_seam", 1)
+        c.set_option("mg_seam_predict", 1)
+    r0, h0, f0, c0, u0 = outs[0]
+    assert 1 <= len(h0) <= niters and np.isfinite(u0).all()
+    if tol == 1e-30:
+        assert len(h0) == niters
+    for (ahead, seam, predict), (r, hist, frms, cit, u) in zip(variants[1:], outs[1:]):
+        assert len(hist) == len(h0) and frms == f0 and cit == c0, (ahead, seam, predict)
+        if seam and not bcs:
+            assert np.allclose(hist, h0, rtol=1e-12, atol=0.0)
+        else:
+            assert np.array_equal(hist, h0) and r == r0
+        assert np.array_equal(u, u0), (ahead, seam, predict)

@@ -15,6 +15,9 @@ solver = sys.argv[3] if len(sys.argv) > 3 else "jacobi"
 rep = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 F = fpr_amd.load(0)
 mg = F.multigrid
+for kv in filter(None, os.environ.get("FPR_OPTS", "").split(",")):   # e.g. FPR_OPTS=mg_wave_target=2048,mg_ahead=0
+    k, v = kv.split("=")
+    F.ctx().set_option(k, int(v))
 b = F.asdevice(F.part2.splitmix64_uniform(n * n, 1).reshape((n, n), order="F"))
 x = F.fzeros(n, n)
 opt = mg.MGOpt()

@@ -3,6 +3,7 @@
 
     prof_summarize.py stats  <dir> <out.txt>        kernel_stats.csv -> per-kernel calls / avg / total
     prof_summarize.py pmc    <dir> <out.txt>        counter_collection.csv -> per-kernel mean counter value
+    prof_summarize.py timeline <dir> <out.txt> [n]  kernel_trace.csv -> the last n dispatches with durations and gaps
 """
 import csv
 import glob
@@ -27,6 +28,21 @@ def stats(d, out):
                                                   r.get("TotalDurationNs", r.get("Total(ns)", "?")), r.get("Percentage", "?")))
 
 
+def timeline(d, out, last=40):
+    """The last `last` dispatches of the trace in start order: duration and the idle gap since the previous one ended."""
+    f = find(d, "*kernel_trace.csv")
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))[-last:]
+    with open(out, "w") as o:
+        o.write("# rocprofv3 --kernel-trace timeline (%s): last %d dispatches\n" % (os.path.basename(f), len(rows)))
+        o.write("%-64s %12s %10s %10s\n" % ("kernel", "grid", "dur_us", "gap_us"))
+        prev = None
+        for r in rows:
+            st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            grid = "%sx%s" % (r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Grid_Size_Y", "?"))
+            o.write("%-64s %12s %10.2f %10.2f\n" % (r["Kernel_Name"][:64], grid, (en - st) / 1e3, (st - prev) / 1e3 if prev else 0.0))
+            prev = en
+
+
 def pmc(d, out):
     f = find(d, "*counter_collection.csv")
     acc = defaultdict(lambda: defaultdict(list))
@@ -41,4 +57,7 @@ def pmc(d, out):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    if sys.argv[1] == "timeline":
+        timeline(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 40)
+    else:
+        {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])

@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 A_EFF_BYTES = 32.0     # read Htau + read Ht + write Htau2 + write dHdtau, per interior cell
-KT_STEP, KT_STEP2, KT_MG_PRE, KT_MG_POST = 0, 1, 2, 3   # include/fpr.h FPR_KT_*
+KT_STEP, KT_STEP2, KT_MG_PRE, KT_MG_POST, KT_MG_SEAM = 0, 1, 2, 3, 4   # include/fpr.h FPR_KT_*
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -181,7 +181,7 @@ def vcycle_block(F, with_cpu=True, steps=5):
                 ts.append(time.perf_counter() - t0)
             ncyc = len(hist)
             if timed_kernels:
-                for name, kind in (("pre", KT_MG_PRE), ("post", KT_MG_POST)):
+                for name, kind in (("pre", KT_MG_PRE), ("post", KT_MG_POST), ("seam", KT_MG_SEAM)):
                     ms, cnt = timer_read(ctx, kind)
                     kern[name] = (ms / max(cnt, 1), cnt)
                 ctx.call("fpr_kernel_timer", 0)
@@ -191,32 +191,44 @@ def vcycle_block(F, with_cpu=True, steps=5):
     # --- byte accounting of one l = 2 V-cycle (11 grids): SURVEY 8d / DESIGN 4.2 ---
     pts = sum((2 ** k + 1) ** 2 for k in range(3, 13))            # smoothing levels k = 12 .. 3 (l = 2 is solved)
     acct_bytes = 132.0 * pts                                      # one pass per operation: 2.955 GB
-    phys_bytes = 54.0 * pts                                       # two passes per level: 28 B/pt + 26 B/pt
     spv = out["l2_jacobi"]["s_per_vcycle"]
+    ncyc = max(out["l2_jacobi"]["vcycles"], 1)
     N2 = float(n * n)
     pre_ms, pre_cnt = kern.get("pre", (0.0, 0))
     post_ms, post_cnt = kern.get("post", (0.0, 0))
-    pre_bytes, post_bytes = 28.0 * N2, 26.0 * N2
-    dom = ("post", post_ms, post_bytes) if post_ms >= pre_ms else ("pre", pre_ms, pre_bytes)
+    seam_ms, seam_cnt = kern.get("seam", (0.0, 0))
+    pre_bytes, post_bytes, seam_bytes = 28.0 * N2, 26.0 * N2, 30.0 * N2
+    # what this implementation must move per V-cycle: coarser levels two passes (28 + 26 B/pt), the finest level the passes
+    # that actually ran in the timed solve (launch counts from the event timer) spread over its cycles
+    phys_bytes = 54.0 * (pts - N2) + (pre_cnt * pre_bytes + post_cnt * post_bytes + seam_cnt * seam_bytes) / ncyc
+    cands = [("seam", seam_ms, seam_bytes, seam_cnt), ("post", post_ms, post_bytes, post_cnt), ("pre", pre_ms, pre_bytes, pre_cnt)]
+    dom = max(cands, key=lambda c: c[1] * c[3])                   # the finest-level kernel with the largest share of the time
     gbs = lambda byts, ms: byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    names = {"seam": "k_seam_march (finest level, between two cycles: correction + 2 post-smoothing sweeps + norm of cycle k, "
+                     "2 pre-smoothing sweeps + residual + injection of cycle k+1)",
+             "post": "k_smooth2_march<NORM,PROLONG> (finest level: prolongation + correction + 2 sweeps + norm)",
+             "pre": "k_smooth2_march<RESTRICT> (finest level: 2 sweeps + residual + injection)"}
     roof = {
         "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "kernel": "k_smooth2_march<NORM,PROLONG> (finest level: prolongation + correction + 2 sweeps + norm)" if dom[0] == "post"
-                  else "k_smooth2_march<RESTRICT> (finest level: 2 sweeps + residual + injection)",
+        "kernel": names[dom[0]],
         "achieved": gbs(dom[2], dom[1]), "frac": gbs(dom[2], dom[1]) / HBM_PEAK_GBS, "traffic": None,
         "kernel_ms": dom[1], "bytes_per_launch": dom[2],
         "kernels": {"finest_pre_pass": {"ms": pre_ms, "launches": pre_cnt, "bytes": pre_bytes, "GBs": gbs(pre_bytes, pre_ms),
-                                        "accounting": "read u, f; write u'' + res_c, corr_c (1/4 each): 28 B/pt"},
+                                        "accounting": "read u, f; write the smoothed field + res_c, corr_c (1/4 each): 28 B/pt"},
                     "finest_post_pass": {"ms": post_ms, "launches": post_cnt, "bytes": post_bytes, "GBs": gbs(post_bytes, post_ms),
-                                         "accounting": "read u, f, corr_c (1/4); write u'': 26 B/pt"}},
+                                         "accounting": "read u, f, corr_c (1/4); write the smoothed field: 26 B/pt"},
+                    "finest_seam_pass": {"ms": seam_ms, "launches": seam_cnt, "bytes": seam_bytes, "GBs": gbs(seam_bytes, seam_ms),
+                                         "accounting": "read u, f, corr_c (1/4); write the field after 4 sweeps + res_c, corr_c "
+                                                       "(1/4 each): 30 B/pt for what two passes (26 + 28 B/pt) do"}},
         "vcycle_physical_bytes": phys_bytes, "vcycle_physical_GBs": phys_bytes / spv / 1e9,
         "vcycle_physical_frac": phys_bytes / spv / 1e9 / HBM_PEAK_GBS,
         "vcycle_accounting_bytes": acct_bytes, "vcycle_effective_GBs": acct_bytes / spv / 1e9,
         "vcycle_effective_frac": acct_bytes / spv / 1e9 / HBM_PEAK_GBS,
-        "note": "frac: the dominant kernel's compulsory bytes / its hipEvent duration; vcycle_physical_*: the bytes a whole "
-                "V-cycle of this implementation must move (54 B/pt/level) / wall time per V-cycle (includes the "
-                "launch-latency-bound coarse levels); vcycle_effective_*: SURVEY 8d's one-pass-per-operation accounting "
-                "(132 B/pt/level = 2.955 GB) / the same time -- above what moves because two sweeps share a pass",
+        "note": "frac: the dominant finest-level kernel's compulsory bytes / its hipEvent duration; vcycle_physical_*: the bytes "
+                "a V-cycle of this implementation must move (coarser levels 54 B/pt, finest level the passes that ran) / wall "
+                "time per V-cycle (includes the launch-latency-bound coarse levels); vcycle_effective_*: SURVEY 8d's "
+                "one-pass-per-operation accounting (132 B/pt/level = 2.955 GB) / the same time -- above what moves because "
+                "sweeps share passes",
     }
     block = {"metric": "vcycle_wall_time_4097sq", "value": spv, "unit": "s", "higher_is_better": False, "dtype": "f64",
              "config": {"workload": "2D Poisson V-cycle 4097^2, 2+2 Jacobi smooths, 11 grids (l=2), Jacobi coarse solver; "

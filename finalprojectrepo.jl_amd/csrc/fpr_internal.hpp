@@ -167,6 +167,23 @@ __device__ __forceinline__ double fpr_lane_down1(double v)  // lane i <- lane i+
     return __hiloint2double(hi, lo);
 }
 
+// the same shifts with ZERO in the lane that has no source (lane 0 / lane 63) instead of the lane's own value: the
+// destination needs no copy of the source first (two v_mov less per shift).  For kernels whose outermost lanes only feed.
+__device__ __forceinline__ double fpr_lane_up1z(double v)  // lane i <- lane i-1, lane 0 <- 0
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double fpr_lane_down1z(double v)  // lane i <- lane i+1, lane 63 <- 0
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double fpr_wave_sum(double v)
 {
 #pragma unroll

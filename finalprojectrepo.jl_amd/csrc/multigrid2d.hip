@@ -384,8 +384,11 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
 // of cycle k: it is not stored (its residual norm, the r_rms of :252, is summed exactly like k_smooth2_march<NORM>
 // does); if that norm ends the loop the host replays the plain post-smoothing pass from the untouched inputs
 // (fpr_mgsolve2d).  Same point arithmetic as k_sweep2d / prolong_bf: all fields bit-identical to the separate passes.
-// Strips overlap by 10 columns (54 owned of 64), chunks by 5 + 4 rows.  No boundary conditions between the cycles
-// (apply_BCs = 0 only: with them :60-62 changes boundary values between sweep 2 and sweep 3).
+// Strips overlap by 10 columns (54 owned of 64), chunks by 5 + 4 rows.  BCS: the boundary conditions the loop re-applies
+// between two cycles (:60-62) act on the field between sweep 2 and sweep 3 (Neumann columns; see below), the correction
+// is prolongated with its Neumann rows, and the host copies the Neumann columns of the coarse residual afterwards
+// (k_bc_neumann, as behind the separate pre-smoothing pass).
+template <bool BCS>
 __global__ __launch_bounds__(256) void k_seam_march(const double* __restrict__ uin, const double* __restrict__ f,
                                                      double* __restrict__ uout, int nx, int ny, double C, double _h2,
                                                      double fac, int rows_per_chunk, int nstrips,
@@ -412,9 +415,11 @@ __global__ __launch_bounds__(256) void k_seam_march(const double* __restrict__ u
     if (active) {
         const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
         // the two coarse columns this lane interpolates from, cached for coarse rows pj and pj+1 (see k_smooth2_march)
-        const int p_io = gic & 1, p_icl = gic >> 1, p_ich = (p_icl + 1 < nxc) ? p_icl + 1 : nxc - 1;
+        int gis = gic;  // Neumann rows of the prolongated correction (part2_utils.jl:35-39)
+        if (BCS) gis = (gic == 0) ? 1 : (gic == nx - 1 ? nx - 2 : gic);
+        const int p_io = gis & 1, p_icl = gis >> 1, p_ich = (p_icl + 1 < nxc) ? p_icl + 1 : nxc - 1;
         const bool p_sx0 = p_icl >= 1 && p_icl <= nxc - 2, p_sx1 = p_io && (p_icl + 1 <= nxc - 2);
-        const bool p_inx = gic >= 1 && gic <= nx - 2;
+        const bool p_inx = gis >= 1 && gis <= nx - 2;
         int pj = -2;
         double pc00 = 0.0, pc10 = 0.0, pc01 = 0.0, pc11 = 0.0;
         const int rowB = nx * 8;
@@ -446,13 +451,14 @@ __global__ __launch_bounds__(256) void k_seam_march(const double* __restrict__ u
             return v - pv;
         };
         auto ldf = [&](int r) { const int rc = r > ny - 1 ? ny - 1 : r; return fpr_bld(rF, vld, (rc - rs) * rowB); };
-        // 3-row windows: w0 = corrected input rows r-2..r, wK = field after sweep K, rows r-K-2 .. r-K
-        double w0a = 0.0, w0b = 0.0, w0c = ldu(rs);
-        double w1a = 0.0, w1b = 0.0, w1c = 0.0;
-        double w2a = 0.0, w2b = 0.0, w2c = 0.0;
-        double w3a = 0.0, w3b = 0.0, w3c = 0.0;
-        double w4a = 0.0, w4b = 0.0, w4c = 0.0;
-        double f5 = 0.0, f4 = 0.0, f3 = 0.0, f2 = 0.0, f1 = 0.0, f0 = ldf(rs);   // f rows r-5 .. r
+        // 3-row windows with COMPILE-TIME slots: row j of every field lives in slot (j - rs) mod 3 (f: mod 6), and the row
+        // loop is unrolled by 12 = lcm(3, 4, 6) so that the slot of every operand is a constant: no register moves to
+        // shift fifteen window rows per step (the 2-sweep kernel shifts its windows; here that would be a fifth of the VALU work).
+        // w[0] = corrected input, w[K] = field after sweep K.
+        double w[5][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+        double fw[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        w[0][0] = ldu(rs);
+        fw[0] = ldf(rs);
         constexpr int PF = 4;
         double pu[PF], pfv[PF];
 #pragma unroll
@@ -461,13 +467,16 @@ __global__ __launch_bounds__(256) void k_seam_march(const double* __restrict__ u
         const unsigned vstc = (owner && !(gi & 1)) ? (unsigned)(gi >> 1) * 8u : FPR_OOR;
         // one Jacobi sweep at row j of a field whose rows j-1, j, j+1 are (lo, mid, hi); rr = residual used by the update
         auto sweep = [&](double lo, double mid, double hi, double fv, int j, double& rr) {
-            const double L = fpr_lane_up1(mid), R = fpr_lane_down1(mid);
+            const double L = fpr_lane_up1z(mid), R = fpr_lane_down1z(mid);
             rr = ((((R + L) + hi) + lo) - C * mid) * _h2 - fv;
             const bool bnd = col_bnd || j <= 0 || j >= ny - 1;
             return bnd ? mid : mid + fac * rr;
         };
-        auto step = [&](auto Qc, int r) {
-            constexpr int Q = decltype(Qc)::value;
+        auto step = [&](auto Tc, int r) {
+            constexpr int T = decltype(Tc)::value;               // (r - rs) mod 12
+            constexpr int Q = T % 4, M = T % 3, F = T % 6;
+            constexpr int M1 = (M + 1) % 3, M2 = (M + 2) % 3;    // slots of rows r-2 (= r+1) and r-1
+            auto fs = [](int k) { return (F - k + 6) % 6; };     // slot of f row r-k
             double an, fn;
             asm volatile("v_mov_b64 %0, %1" : "=v"(an) : "v"(pu[Q]));
             asm volatile("v_mov_b64 %0, %1" : "=v"(fn) : "v"(pfv[Q]));
@@ -475,31 +484,37 @@ __global__ __launch_bounds__(256) void k_seam_march(const double* __restrict__ u
             pfv[Q] = ldf(r + 1 + PF);
             double rr;
             // ---- cycle k, post-smoothing (:142-143): sweeps 1 and 2 at rows r-1, r-2 ----
-            const double u1 = sweep(w0a, w0b, w0c, f1, r - 1, rr);
-            w1a = w1b; w1b = w1c; w1c = u1;                    // rows r-3, r-2, r-1
+            w[1][M2] = sweep(w[0][M1], w[0][M2], w[0][M], fw[fs(1)], r - 1, rr);
             const int j2 = r - 2;
-            const double u2 = sweep(w1a, w1b, w1c, f2, j2, rr);
+            double u2 = sweep(w[1][M], w[1][M1], w[1][M2], fw[fs(2)], j2, rr);   // u at the end of cycle k (not stored)
+            if constexpr (BCS) {
+                // apply_boundary_conditions! between the cycles (multigrid.jl:60-62, part2_utils.jl:22-31): its Dirichlet
+                // rows hold their values already (set before the first cycle, never changed by a sweep or a correction);
+                // its Neumann columns copy their inner neighbour of THIS field
+                const double fromR = fpr_lane_down1z(u2), fromL = fpr_lane_up1z(u2);
+                u2 = (gi == 0) ? fromR : ((gi == nx - 1) ? fromL : u2);
+            }
+            w[2][M1] = u2;
             {
                 const bool bnd = col_bnd || j2 <= 0 || j2 >= ny - 1;
                 const bool row_own = j2 >= y0 && j2 < y1;      // uniform
-                if (owner && row_own && !bnd) acc += rr * rr;  // r_rms of cycle k (:252)
+                acc += (owner && row_own && !bnd) ? rr * rr : 0.0;  // r_rms of cycle k (:252); branch-free (+0.0 is exact)
             }
-            w2a = w2b; w2b = w2c; w2c = u2;                    // rows r-4, r-3, r-2  (u at the end of cycle k)
             // ---- cycle k+1, pre-smoothing (:124-125): sweeps 3 and 4 at rows r-3, r-4 ----
-            const double u3 = sweep(w2a, w2b, w2c, f3, r - 3, rr);
-            w3a = w3b; w3b = w3c; w3c = u3;                    // rows r-5, r-4, r-3
+            w[3][M] = sweep(w[2][M2], w[2][M], w[2][M1], fw[fs(3)], r - 3, rr);
             const int j4 = r - 4;
-            const double u4 = sweep(w3a, w3b, w3c, f4, j4, rr);
+            const double u4 = sweep(w[3][M1], w[3][M2], w[3][M], fw[fs(4)], j4, rr);
             {
                 const bool row_own = j4 >= y0 && j4 < y1;      // uniform
                 fpr_bst(rUout, vst, row_own ? (j4 - rs) * rowB : (int)FPR_OOR, u4);   // unconditional (see FPR_OOR)
             }
-            w4a = w4b; w4b = w4c; w4c = u4;                    // rows r-6, r-5, r-4
+            w[4][M2] = u4;
             // ---- residual of the pre-smoothed field at row r-5, injected at even (row, column) (:128-132) ----
             {
                 const int j5 = r - 5;
-                const double L = fpr_lane_up1(w4b), R = fpr_lane_down1(w4b);
-                const double rres = ((((R + L) + w4c) + w4a) - C * w4b) * _h2 - f5;
+                const double mid = w[4][M1];
+                const double L = fpr_lane_up1z(mid), R = fpr_lane_down1z(mid);
+                const double rres = ((((R + L) + w[4][M2]) + w[4][M]) - C * mid) * _h2 - fw[fs(5)];
                 const int ic = gi >> 1, jc = j5 >> 1;
                 const bool cint = ic >= 1 && ic <= nxc - 2 && jc >= 1 && jc <= nyc - 2;
                 const bool row_inj = j5 >= y0 && j5 < y1 && !(j5 & 1);   // uniform
@@ -507,21 +522,22 @@ __global__ __launch_bounds__(256) void k_seam_march(const double* __restrict__ u
                 fpr_bst(rResC, vstc, sc, cint ? rres : 0.0);
                 fpr_bst(rCorC, vstc, sc, 0.0);
             }
-            w0a = w0b; w0b = w0c; w0c = an;
-            f5 = f4; f4 = f3; f3 = f2; f2 = f1; f1 = f0; f0 = fn;
+            w[0][M1] = an;             // row r+1 takes the slot of row r-2
+            fw[(F + 1) % 6] = fn;      // row r+1 takes the slot of row r-5
         };
         const int rend = y1 + 4;
         int r = rs;
-        static_assert(PF == 4, "the unrolled row loop below is written for PF = 4");
-        for (; r + PF - 1 <= rend; r += PF) {
-            step(std::integral_constant<int, 0>{}, r);
-            step(std::integral_constant<int, 1>{}, r + 1);
-            step(std::integral_constant<int, 2>{}, r + 2);
-            step(std::integral_constant<int, 3>{}, r + 3);
+        static_assert(PF == 4, "the row loop below is unrolled by 12 = lcm(3 window slots, PF = 4, 6 rows of f)");
+#define FPR_SEAM_STEP(T) step(std::integral_constant<int, T>{}, r + T)
+        for (; r + 11 <= rend; r += 12) {
+            FPR_SEAM_STEP(0); FPR_SEAM_STEP(1); FPR_SEAM_STEP(2); FPR_SEAM_STEP(3); FPR_SEAM_STEP(4); FPR_SEAM_STEP(5);
+            FPR_SEAM_STEP(6); FPR_SEAM_STEP(7); FPR_SEAM_STEP(8); FPR_SEAM_STEP(9); FPR_SEAM_STEP(10); FPR_SEAM_STEP(11);
         }
-        if (r <= rend) { step(std::integral_constant<int, 0>{}, r); ++r; }
-        if (r <= rend) { step(std::integral_constant<int, 1>{}, r); ++r; }
-        if (r <= rend) { step(std::integral_constant<int, 2>{}, r); ++r; }
+#undef FPR_SEAM_STEP
+#define FPR_SEAM_TAIL(T) if (r <= rend) { step(std::integral_constant<int, T>{}, r); ++r; }
+        FPR_SEAM_TAIL(0) FPR_SEAM_TAIL(1) FPR_SEAM_TAIL(2) FPR_SEAM_TAIL(3) FPR_SEAM_TAIL(4) FPR_SEAM_TAIL(5)
+        FPR_SEAM_TAIL(6) FPR_SEAM_TAIL(7) FPR_SEAM_TAIL(8) FPR_SEAM_TAIL(9) FPR_SEAM_TAIL(10)
+#undef FPR_SEAM_TAIL
     }
     const double sblk = fpr_block_sum<256>(acc, red);
     if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
@@ -2169,8 +2185,27 @@ static TopGeom top_geom(fpr_ctx* ctx, int nx, int ny, double h, double c)
         while (rpc > 16 && (long)g.nstrips * ((ny + rpc - 1) / rpc) < target) rpc >>= 1;
     }
     g.rpc = rpc;
+    // k_seam_march holds 3 waves per SIMD (151 VGPRs) = 3 workgroups per CU, and a workgroup works for most of the pass:
+    // the chunks are made as tall as a single round allows (all workgroups resident at once, ~95 % of the slots) -- the
+    // 9 overlap rows weigh less and no second, half-empty round trails (4097^2: 38 chunks of 108 rows 127 us, 65 chunks of
+    // 64 rows 133 us, 52 of 80 rows 150 us)
     int rs = (int)fpr_opt(ctx, "mg_seam_rows_per_chunk", 0);
-    g.rpc_s = rs > 0 ? rs : rpc;
+    if (rs <= 0) {
+        if (ctx->ncu <= 0) {
+            int v = 0;
+            ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
+        }
+        const int gx = (g.nstrips_s + 3) / 4;
+        int chunks = (int)(0.95 * 3 * ctx->ncu) / gx;
+        if (chunks < 1) chunks = 1;
+        rs = (ny + chunks - 1) / chunks;
+        if (rs < 32) rs = 32;
+    }
+    {   // rows are addressed relative to the first row of a chunk with a 32-bit byte offset
+        const long cap = (long)(0x7fffffffL / ((long)nx * 8)) - 16;
+        if (rs > cap) rs = (int)(cap > 16 ? cap : 16);
+    }
+    g.rpc_s = rs;
     g.gm = dim3((g.nstrips + 3) / 4, (ny + rpc - 1) / rpc);
     g.gr = dim3((g.nstrips_r + 3) / 4, (ny + rpc - 1) / rpc);
     g.gs = dim3((g.nstrips_s + 3) / 4, (ny + g.rpc_s - 1) / g.rpc_s);
@@ -2179,25 +2214,26 @@ static TopGeom top_geom(fpr_ctx* ctx, int nx, int ny, double h, double c)
 
 // pre-smoothing pair + residual + injection + zero coarse guess (:124-132): uin -> out, L.res_c, corr_zero
 static int top_pre(fpr_ctx* ctx, const TopGeom& g, const double* uin, const double* rhs, double* out, double* res_c,
-                   double* corr_zero, const int* skp)
+                   double* corr_zero, int apply_BCs, const int* skp)
 {
     hipStream_t s = ctx->stream[0];
     const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_PRE, s);
     k_smooth2_march<false, false, true><<<g.gr, 256, 0, s>>>(uin, rhs, out, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips_r, nullptr,
                                                              nullptr, g.ntf, res_c, corr_zero, skp);
     fpr_ktimer_end(ctx, timed, s);
+    if (apply_BCs) k_bc_neumann<<<((1 + (g.ny - 1) / 2) + 255) / 256, 256, 0, s>>>(res_c, 1 + (g.nx - 1) / 2, 1 + (g.ny - 1) / 2, skp);  // :355-357
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
 }
 
 // prolongation + correction + post-smoothing pair (:136-143): X - P(corr) -> uout; norm: block sums into ctx->partials
 static int top_post(fpr_ctx* ctx, const TopGeom& g, const double* X, const double* rhs, const double* corr, double* uout,
-                    bool norm, const int* skp)
+                    bool norm, int apply_BCs, const int* skp)
 {
     hipStream_t s = ctx->stream[0];
     const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_POST, s);
-    if (norm) k_smooth2_march<true, true, false><<<g.gm, 256, 0, s>>>(X, rhs, uout, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips, ctx->partials, corr, g.ntf, nullptr, nullptr, skp);
-    else k_smooth2_march<false, true, false><<<g.gm, 256, 0, s>>>(X, rhs, uout, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips, nullptr, corr, g.ntf, nullptr, nullptr, skp);
+    if (norm) k_smooth2_march<true, true, false><<<g.gm, 256, 0, s>>>(X, rhs, uout, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips, ctx->partials, corr, apply_BCs | g.ntf, nullptr, nullptr, skp);
+    else k_smooth2_march<false, true, false><<<g.gm, 256, 0, s>>>(X, rhs, uout, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips, nullptr, corr, apply_BCs | g.ntf, nullptr, nullptr, skp);
     fpr_ktimer_end(ctx, timed, s);
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
@@ -2205,12 +2241,12 @@ static int top_post(fpr_ctx* ctx, const TopGeom& g, const double* X, const doubl
 
 // the seam: post pair of cycle k (+ norm) and pre pair + residual + injection of cycle k+1: X - P(corr) -> Y, res_c, corr_zero
 static int top_seam(fpr_ctx* ctx, const TopGeom& g, const double* X, const double* rhs, const double* corr, double* Y,
-                    double* res_c, double* corr_zero, const int* skp)
+                    double* res_c, double* corr_zero, int apply_BCs, const int* skp)
 {
     hipStream_t s = ctx->stream[0];
     const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_SEAM, s);
-    k_seam_march<<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c,
-                                       corr_zero, skp);
+    if (apply_BCs) k_seam_march<true><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
+    else k_seam_march<false><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
     fpr_ktimer_end(ctx, timed, s);
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
@@ -2285,7 +2321,7 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
         ctx->cyc_skip = &ctx->cyc->stop;
         const int* skp = ctx->cyc_skip;
         int enq = 0;
-        if (!apply_BCs && fpr_opt(ctx, "mg_seam", 1) && fpr_opt(ctx, "mg_vx", 1) != 2) {
+        if (fpr_opt(ctx, "mg_seam", 1) && fpr_opt(ctx, "mg_vx", 1) != 2) {
             // ---- consecutive cycles share their pass over the finest grid (k_seam_march) ----
             // unit k = the end of cycle k: either the plain post-smoothing pass (k = niters, or the norms seen so far say
             // that cycle k will meet the exit test) or a seam pass that also starts cycle k+1, followed by cycle k+1's
@@ -2310,12 +2346,14 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
             ctx->used_small = false;
             auto lower = [&](int pp) -> int {
                 double dummy; bool dh;
-                return vcycle_level(ctx, *A, 1, corr[pp], L.res_c, h * 2, c, tol, coarse_solve_size, coarse_solver, 0, false, &dummy, &dh);
+                return vcycle_level(ctx, *A, 1, corr[pp], L.res_c, h * 2, c, tol, coarse_solve_size, coarse_solver, apply_BCs, false, &dummy, &dh);
             };
             auto enqueue_unit = [&]() -> int {
                 const int k = enq + 1;
                 if (need_head) {   // first cycle, or the loop goes on after a plain post-smoothing pass
-                    if (int rc = top_pre(ctx, g, u, f, L.tmp, L.res_c, corr[0], skp)) return rc;
+                    if (apply_BCs)
+                        if (int rc = fpr_bc2d(ctx, u, nx, ny)) return rc;  // :60-62
+                    if (int rc = top_pre(ctx, g, u, f, L.tmp, L.res_c, corr[0], apply_BCs, skp)) return rc;
                     if (int rc = lower(0)) return rc;
                     X = L.tmp; p = 0; need_head = false;
                 }
@@ -2332,14 +2370,18 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
                 }
                 const int slot = enq % FPR_CYC_SLOTS;
                 if (last) {
-                    if (int rc = top_post(ctx, g, X, f, corr[p], u, true, skp)) return rc;
+                    if (int rc = top_post(ctx, g, X, f, corr[p], u, true, apply_BCs, skp)) return rc;
                     if (int rc = fprx_cycle_finish(ctx, ctx->partials, npm, ctx->scalars, (double)N, slot)) return rc;
                     units[slot] = {false, X, p};
                     need_head = true;
                 } else {
                     double* Y = (X == L.tmp) ? L.tmp2 : L.tmp;
-                    if (int rc = top_seam(ctx, g, X, f, corr[p], Y, L.res_c, corr[1 - p], skp)) return rc;
+                    if (int rc = top_seam(ctx, g, X, f, corr[p], Y, L.res_c, corr[1 - p], apply_BCs, skp)) return rc;
                     if (int rc = fprx_cycle_finish(ctx, ctx->partials, nps, ctx->scalars, (double)N, slot)) return rc;
+                    if (apply_BCs) {   // Neumann columns of the coarse residual (:355-357)
+                        k_bc_neumann<<<((1 + (ny - 1) / 2) + 255) / 256, 256, 0, ctx->stream[0]>>>(L.res_c, 1 + (nx - 1) / 2, 1 + (ny - 1) / 2, skp);
+                        FPR_CHECK_LAUNCH(ctx);
+                    }
                     if (int rc = lower(1 - p)) return rc;   // cycle k+1 below the finest level
                     units[slot] = {true, X, p};
                     X = Y; p = 1 - p;
@@ -2362,7 +2404,7 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
                 ++n;
                 if (rec.stop) {   // :70 (taken on the device)
                     if (units[slot].seam)   // u at the end of this cycle was never stored: replay its post-smoothing pass
-                        if (int rc = top_post(ctx, g, units[slot].X, f, corr[units[slot].p], u, false, nullptr)) return rc;
+                        if (int rc = top_post(ctx, g, units[slot].X, f, corr[units[slot].p], u, false, apply_BCs, nullptr)) return rc;
                     break;
                 }
             }

@@ -437,7 +437,7 @@ def test_small_and_rectangular_hierarchies(fpr, oracle, shape, css, bc):
 @pytest.mark.parametrize("shape,css,bcs,tol,niters", [
     ((257, 257), 5, False, 1e-6, 100),      # converges after several cycles
     ((257, 257), 5, False, 1e-30, 4),       # never converges: stops at niters
-    ((513, 129), 9, True, 1e-5, 100),       # Neumann columns + Dirichlet rows re-applied every cycle (:60-62): no seam
+    ((513, 129), 9, True, 1e-5, 100),       # Neumann columns + Dirichlet rows re-applied every cycle (:60-62)
     ((1025, 1025), 5, False, 1e-1, 100),    # converges in the very first cycles: what was enqueued ahead must not run
     ((2049, 2049), 17, True, 1e-7, 50),
     ((2049, 1025), 17, False, 1e-9, 50),
@@ -485,7 +485,7 @@ def test_cycles_enqueued_ahead_equal_the_plain_loop(fpr, shape, css, bcs, tol, n
         assert len(h0) == niters
     for (ahead, seam, predict), (r, hist, frms, cit, u) in zip(variants[1:], outs[1:]):
         assert len(hist) == len(h0) and frms == f0 and cit == c0, (ahead, seam, predict)
-        if seam and not bcs:
+        if seam:
             assert np.allclose(hist, h0, rtol=1e-12, atol=0.0)
         else:
             assert np.array_equal(hist, h0) and r == r0

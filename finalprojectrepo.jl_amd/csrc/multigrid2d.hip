@@ -1407,6 +1407,8 @@ struct MgSmallArgs {
     double* out_sumsq;  // want_norm: sum(res.^2) of the last post-smoothing sweep of the top level
     FprSolveState* state;
     const int* skip;    // cycles enqueued ahead: return at once if *skip (null = unconditional)
+    int row_solve;      // 1: coarsest grids with <= 16 interior points are solved inside one DPP row (option mg_small_row)
+    long long* prof;    // diagnostic (option mg_small_prof): wall_clock64 stamps (100 MHz) of thread 0 at the section borders
 };
 
 constexpr int MGS_NT = 1024;
@@ -1430,14 +1432,30 @@ __device__ __forceinline__ double mgs_block_sum(double v, double* red)
     return red[MGS_NT / 64];
 }
 
+// shifts inside a 16-lane DPP row (zero where no lane is the source); n is uniform, 1..15
+template <int CTRL>
+__device__ __forceinline__ double mgs_dpp(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int N> __device__ __forceinline__ double mgs_row_ror(double v) { return mgs_dpp<0x120 + N>(v); }
+// idx -> row j = idx / nx without an integer division: floor((idx + 0.5) * (1/nx)) in float is exact while
+// nx*ny*2.4e-7 < 0.5 (the rounding error of the product stays below the distance 0.5/nx of (idx + 0.5)/nx from an
+// integer); the LDS arena holds 20000 doubles, so N < 2^15 here.
+__device__ __forceinline__ int mgs_row(int idx, float rnx) { return (int)(((float)idx + 0.5f) * rnx); }
+
 // uout = uin + fac*res(uin) on the interior, boundary copied; returns this thread's sum of res^2
 __device__ __forceinline__ double mgs_sweep(const double* uin, const double* f, double* uout, int nx, int ny, double C,
                                             double _h2, double fac)
 {
     double acc = 0.0;
     const int N = nx * ny;
+    const float rnx = 1.0f / (float)nx;
     for (int idx = threadIdx.x; idx < N; idx += MGS_NT) {
-        const int j = idx / nx, i = idx - j * nx;
+        const int j = mgs_row(idx, rnx), i = idx - j * nx;
         const double uc = uin[idx];
         if (i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1) {
             const double r = ((((uin[idx + 1] + uin[idx - 1]) + uin[idx + nx]) + uin[idx - nx]) - C * uc) * _h2 - f[idx];
@@ -1457,6 +1475,9 @@ __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
     double* red = sm;
     double* arena = sm + MGS_RED;
     const int tid = threadIdx.x;
+    int pslot = 0;
+    auto stamp = [&]() { if (a.prof && tid == 0) a.prof[pslot++] = wall_clock64(); };
+    stamp();   // 0: start
 
     // level d: dims ((nx-1)>>d)+1, arrays u|f|t at arena + off(d)
     auto lnx = [&](int d) { return ((a.nx - 1) >> d) + 1; };
@@ -1482,6 +1503,7 @@ __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
         }
     }
     __syncthreads();
+    stamp();   // 1: top level loaded
 
     const int c_lev = a.nlev - 1;
     // ---- down sweep ----
@@ -1501,8 +1523,9 @@ __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
         const int nxc = lnx(d + 1), nyc = lny(d + 1), Nc = nxc * nyc;
         double* Uc = arena + off(d + 1);
         double* Fc = Uc + Nc;
+        const float rnxc = 1.0f / (float)nxc;
         for (int idx = tid; idx < Nc; idx += MGS_NT) {
-            const int jc = idx / nxc, ic = idx - jc * nxc;
+            const int jc = mgs_row(idx, rnxc), ic = idx - jc * nxc;
             int is = ic;
             if (a.apply_BCs) is = (ic == 0) ? 1 : (ic == nxc - 1 ? nxc - 2 : ic);
             double v = 0.0;
@@ -1514,6 +1537,7 @@ __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
             Uc[idx] = 0.0;
         }
         __syncthreads();
+        stamp();   // 2 .. 1+c_lev: level d went down
     }
 
     // ---- coarsest level: Jacobi with early exit (:147-159) ----
@@ -1534,6 +1558,78 @@ __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
         int it = 0;
         double* pin = U;
         double* pout = T;
+        const int nxi = nx - 2, nyi = ny - 2, ni = nxi * nyi;
+        if (N <= 64 && ni >= 1 && ni <= 16 && a.row_solve) {
+            // coarsest grid with at most 16 INTERIOR points (5x5 -> 3x3, the default coarse_solve_size): the interior lives in
+            // the first lanes of wave 0, one point per lane (lane = (i-1) + nxi*(j-1)), all of it inside one 16-lane DPP row:
+            // neighbours by row shifts (a boundary neighbour is a per-lane constant), the norm by four rotate-and-add steps
+            // (lane 0's order of summation; uniform through readfirstlane).  sqrt and the division of :157 are only evaluated
+            // when the exit test can possibly hold: sum > N * tol_rhs^2 * (1 + 1e-10) implies sqrt(sum/N) > tol_rhs.
+            if (tid < 64) {
+                const int lane = tid;
+                const bool in = lane < ni;
+                const int jj = in ? lane / nxi : 0, ii = in ? lane - jj * nxi : 0;   // interior coordinates, once
+                const int g = (ii + 1) + nx * (jj + 1);
+                const double fv = in ? F[g] : 0.0;
+                double uu = in ? U[g] : 0.0;
+                // boundary neighbours are constants (Dirichlet copy); interior ones come from the row shifts
+                const bool iE = in && ii + 1 < nxi, iW = in && ii > 0, iN = in && jj + 1 < nyi, iS = in && jj > 0;
+                const double cE = (in && !iE) ? U[g + 1] : 0.0, cW = (in && !iW) ? U[g - 1] : 0.0;
+                const double cN = (in && !iN) ? U[g + nx] : 0.0, cS = (in && !iS) ? U[g - nx] : 0.0;
+                const double hi_thr = ((double)N * (tol_rhs * tol_rhs)) * (1.0 + 1e-10);
+                double sq_last = 0.0;
+                bool have_rms = false;
+                // the DPP control is an immediate: the loop is instantiated per interior width (dispatch ONCE, outside it)
+                auto run = [&](auto NXIc) {
+                    constexpr int NXI = decltype(NXIc)::value;
+                    // The exit test of sweep k is evaluated while sweep k+1 is already in flight (its update is dropped if the
+                    // test holds): the dependent chain of a sweep is then its stencil alone, not stencil + reduction + test.
+                    double sq_vec = 0.0;     // per-lane total of sweep k-1 (every lane of row 0 holds a full sum)
+                    bool done = false;
+                    auto test = [&](int ksweep) {   // :157-158 for sweep `ksweep`, whose sum sits in sq_vec
+                        const double sq = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(sq_vec)),
+                                                           __builtin_amdgcn_readfirstlane(__double2loint(sq_vec)));
+                        it = ksweep;
+                        sq_last = sq;
+                        have_rms = false;
+                        if (sq > hi_thr) return false;      // cannot have converged
+                        res_rms = sqrt(sq / (double)N);     // :157
+                        have_rms = true;
+                        return res_rms < tol_rhs;
+                    };
+                    for (int k = 1; k <= iters; ++k) {
+                        const double sE = mgs_dpp<0x101>(uu), sW = mgs_dpp<0x111>(uu);                 // lanes i+1, i-1
+                        const double sN = mgs_dpp<0x100 + NXI>(uu), sS = mgs_dpp<0x110 + NXI>(uu);     // lanes i+nxi, i-nxi
+                        const double E = iE ? sE : cE, W = iW ? sW : cW, Nn = iN ? sN : cN, Ss = iS ? sS : cS;
+                        const double r = ((((E + W) + Nn) + Ss) - C * uu) * _h2 - fv;
+                        const double uu_new = in ? uu + fac * r : uu;
+                        double sq = in ? r * r : 0.0;
+                        sq += mgs_row_ror<8>(sq);
+                        sq += mgs_row_ror<4>(sq);
+                        sq += mgs_row_ror<2>(sq);
+                        sq += mgs_row_ror<1>(sq);
+                        if (k > 1 && test(k - 1)) { done = true; break; }   // uu is still the field after sweep k-1
+                        uu = uu_new;
+                        sq_vec = sq;
+                    }
+                    if (!done) test(iters);
+                };
+#define FPR_ROW_CASE(n) case n: run(std::integral_constant<int, n>{}); break;
+                switch (nxi) {
+                    FPR_ROW_CASE(1) FPR_ROW_CASE(2) FPR_ROW_CASE(3) FPR_ROW_CASE(4) FPR_ROW_CASE(5) FPR_ROW_CASE(6) FPR_ROW_CASE(7)
+                    FPR_ROW_CASE(8) FPR_ROW_CASE(9) FPR_ROW_CASE(10) FPR_ROW_CASE(11) FPR_ROW_CASE(12) FPR_ROW_CASE(13)
+                    FPR_ROW_CASE(14) FPR_ROW_CASE(15)
+                default: run(std::integral_constant<int, 15>{}); break;   // nxi = 16: one row of points, iN = iS = false everywhere
+                }
+#undef FPR_ROW_CASE
+                if (!have_rms) res_rms = sqrt(sq_last / (double)N);
+                if (in) U[g] = uu;
+                if (tid == 0) { red[MGS_RED - 1] = res_rms; red[MGS_RED - 2] = (double)it; }
+            }
+            __syncthreads();
+            res_rms = red[MGS_RED - 1];
+            it = (int)red[MGS_RED - 2];
+        } else
         if (N <= 64) {
             // tiny coarsest grid (5x5, 9x5, ...): one point per lane of wave 0, all in registers --
             // neighbours by wavefront shuffles, norm by a butterfly (every lane gets the same bits), no barrier
@@ -1576,6 +1672,7 @@ __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
             a.state->last_rms = res_rms;
         }
         __syncthreads();
+        stamp();   // coarsest level solved
     }
 
     // ---- up sweep ----
@@ -1589,11 +1686,12 @@ __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
         const double fac = (4.0 / 5.0) * ((h * h) / (4.0 + a.c * (h * h)));
         const int nxc = lnx(d + 1);
         const double* Uc = (d + 1 == c_lev) ? ucur : arena + off(d + 1);
+        const float rnx = 1.0f / (float)nx;
         for (int idx = tid; idx < N; idx += MGS_NT) {  // prolongation + correction (:136-139)
-            const int j = idx / nx, i = idx - j * nx;
+            const int j = mgs_row(idx, rnx), i = idx - j * nx;
             int is = i;
             if (a.apply_BCs) is = (i == 0) ? 1 : (i == nx - 1 ? nx - 2 : i);
-            U[idx] = U[idx] - prolong_at(Uc, is, j, nx, ny, nxc);
+            U[idx] = U[idx] - prolong_bf(Uc, is, j, nx, ny, nxc, lny(d + 1));   // branch-free form of prolong_at: same value
         }
         __syncthreads();
         mgs_sweep(U, F, T, nx, ny, C, _h2, fac);  // :142
@@ -1604,6 +1702,7 @@ __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
             if (tid == 0) a.out_sumsq[0] = s;
         }
         __syncthreads();
+        stamp();   // level d came up
     }
 
     {   // store the top level's solution
@@ -1611,6 +1710,7 @@ __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
         const double* U = (c_lev == 0) ? ucur : arena;
         for (int idx = tid; idx < N; idx += MGS_NT) a.u[idx] = U[idx];
     }
+    stamp();   // stored
 }
 
 // ================================================================================================
@@ -1948,6 +2048,8 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             a.out_sumsq = ctx->scalars;
             a.state = ctx->state;
             a.skip = ctx->cyc_skip;
+            a.row_solve = fpr_opt(ctx, "mg_small_row", 1) != 0;
+            a.prof = (long long*)(uintptr_t)fpr_opt(ctx, "mg_small_prof", 0);   // tools/exp_mg_small_prof.py: device address of 32 int64, or 0
             k_mg_small<<<1, MGS_NT, (tot + MGS_RED) * sizeof(double), s>>>(a);
             FPR_CHECK_LAUNCH(ctx);
             if (top) {

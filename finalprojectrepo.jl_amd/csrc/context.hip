@@ -238,10 +238,13 @@ int fprx_finish_sum(fpr_ctx* ctx, const double* partials, int nparts, double* ou
 }
 
 // ---- cycles enqueued ahead (FprCycleCtl, fpr_internal.hpp) ------------------------------------------------
-__global__ void k_cycle_init(FprCycleCtl* ctl, FprSolveState* st, double tolf)
+__global__ void k_cycle_init(FprCycleCtl* ctl, FprSolveState* st, double tol, double npoints, const double* sumsq_f)
 {
     ctl->stop = 0; ctl->ncycles = 0; ctl->coarse_iters = 0; ctl->seq = 0;
-    ctl->tolf = tolf; ctl->rms = 0.0;
+    const double frms = sqrt(sumsq_f[0] / npoints);   // multigrid.jl:53
+    ctl->frms = frms;
+    ctl->tolf = tol * frms;                            // :70
+    ctl->rms = 0.0;
     st->acc_iters = 0;
 }
 
@@ -266,15 +269,15 @@ __global__ __launch_bounds__(256) void k_cycle_finish(const double* __restrict__
         // the record goes to pinned host memory straight from here (no copy command, no event between two cycles);
         // the host polls `seq`, which is written last
         rec_host->stop = c.stop; rec_host->ncycles = c.ncycles; rec_host->coarse_iters = c.coarse_iters;
-        rec_host->tolf = c.tolf; rec_host->rms = c.rms;
+        rec_host->tolf = c.tolf; rec_host->rms = c.rms; rec_host->frms = c.frms;
         __threadfence_system();
         __hip_atomic_store(&rec_host->seq, c.ncycles, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-int fprx_cycle_init(fpr_ctx* ctx, double tolf)
+int fprx_cycle_init(fpr_ctx* ctx, double tol, double npoints, const double* sumsq_f_dev)
 {
-    k_cycle_init<<<1, 1, 0, ctx->stream[0]>>>(ctx->cyc, ctx->state, tolf);
+    k_cycle_init<<<1, 1, 0, ctx->stream[0]>>>(ctx->cyc, ctx->state, tol, npoints, sumsq_f_dev);
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
 }

@@ -2405,21 +2405,28 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
                             coarse_solve_size);
     }
     const size_t N = (size_t)nx * ny;
-    double fs;
-    if (int rc = fpr_sumsq_scaled(ctx, f, N, 1.0, &fs)) return rc;
-    const double f_rms = sqrt(fs / (double)N);  // :53
-    const double tolf = tol * f_rms;
+    double f_rms = 0.0, tolf = 0.0;   // :53, :70
     double r_rms = 0.0;
     int n = 0;
     ctx->last_coarse_iters = 0;
     int ahead = (int)fpr_opt(ctx, "mg_ahead", 1);
     if (ahead > FPR_CYC_SLOTS - 2) ahead = FPR_CYC_SLOTS - 2;
-    if (ahead > 0 && niters > 1 && vcycle_streams(ctx, nx, ny, coarse_solve_size, coarse_solver)) {
+    const bool streams = ahead > 0 && niters > 1 && vcycle_streams(ctx, nx, ny, coarse_solve_size, coarse_solver);
+    if (!streams) {
+        double fs;
+        if (int rc = fpr_sumsq_scaled(ctx, f, N, 1.0, &fs)) return rc;
+        f_rms = sqrt(fs / (double)N);
+        tolf = tol * f_rms;
+    }
+    if (streams) {
         // Cycles are enqueued `ahead` deep before the host waits for the norm of the oldest one: the exit test (:70) is
         // evaluated on the device by k_cycle_finish, and all launches of a cycle that follows the one that met it return
         // at once -- fields, norms and cycle count are those of the plain loop, without a host round trip per cycle.
         struct Guard { fpr_ctx* c; ~Guard() { c->cyc_skip = nullptr; } } guard{ctx};
-        if (int rc = fprx_cycle_init(ctx, tolf)) return rc;
+        // rms(f) and the threshold tol * rms(f) stay on the device too (same operations as on the host): no round trip
+        // before the first cycle; the host learns both from the first record
+        if (int rc = fprx_sumsq_scaled_dev(ctx, f, N, 1.0, ctx->scalars + 5, 0)) return rc;
+        if (int rc = fprx_cycle_init(ctx, tol, (double)N, ctx->scalars + 5)) return rc;
         ctx->cyc_skip = &ctx->cyc->stop;
         const int* skp = ctx->cyc_skip;
         int enq = 0;
@@ -2500,6 +2507,7 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
                 FprCycleCtl rec;
                 if (int rc = fprx_cycle_wait(ctx, slot, n + 1, &rec)) return rc;
                 r_rms = rec.rms;
+                f_rms = rec.frms; tolf = rec.tolf;
                 r_prev = r_last; r_last = r_rms;
                 ctx->last_coarse_iters = rec.coarse_iters;
                 if (history_host) history_host[n] = r_rms;
@@ -2528,6 +2536,7 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
             FprCycleCtl rec;
             if (int rc = fprx_cycle_wait(ctx, slot, n + 1, &rec)) return rc;
             r_rms = rec.rms;
+            f_rms = rec.frms; tolf = rec.tolf;
             ctx->last_coarse_iters = rec.coarse_iters;
             if (history_host) history_host[n] = r_rms;
             ++n;

@@ -442,6 +442,9 @@ def test_small_and_rectangular_hierarchies(fpr, oracle, shape, css, bc):
     ((2049, 2049), 17, True, 1e-7, 50),
     ((2049, 1025), 17, False, 1e-9, 50),
     ((129, 129), 5, False, 1e-6, 100),      # one marched level above the LDS-resident sub-hierarchy
+    ((1025, 65), 5, True, 1e-8, 100),       # a single row of seam chunks, 19 strips
+    ((65, 1025), 3, False, 1e-8, 100),      # two strips, 3x33 coarsest grid (one interior row inside the DPP row solve)
+    ((257, 129), 9, False, 1e-10, 30),
     ((4097, 4097), 5, False, 1e-6, 100),    # BASELINE config 3
 ], ids=str)
 def test_cycles_enqueued_ahead_equal_the_plain_loop(fpr, shape, css, bcs, tol, niters):

@@ -238,14 +238,20 @@ int fprx_finish_sum(fpr_ctx* ctx, const double* partials, int nparts, double* ou
 }
 
 // ---- cycles enqueued ahead (FprCycleCtl, fpr_internal.hpp) ------------------------------------------------
-__global__ void k_cycle_init(FprCycleCtl* ctl, FprSolveState* st, double tol, double npoints, const double* sumsq_f)
+// start of a solve: sum(f.^2) finished exactly as k_finish<0> does it, f_rms and the loop's threshold; the cycle state reset
+__global__ __launch_bounds__(256) void k_cycle_init(const double* __restrict__ partials, int n, FprCycleCtl* ctl,
+                                                     FprSolveState* st, double tol, double npoints)
 {
-    ctl->stop = 0; ctl->ncycles = 0; ctl->coarse_iters = 0; ctl->seq = 0;
-    const double frms = sqrt(sumsq_f[0] / npoints);   // multigrid.jl:53
-    ctl->frms = frms;
-    ctl->tolf = tol * frms;                            // :70
-    ctl->rms = 0.0;
-    st->acc_iters = 0;
+    __shared__ double red[16];
+    const double s = fpr_sum_partials_256(partials, n, red);
+    if (threadIdx.x == 0) {
+        ctl->stop = 0; ctl->ncycles = 0; ctl->coarse_iters = 0; ctl->seq = 0;
+        const double frms = sqrt(s / npoints);   // multigrid.jl:53
+        ctl->frms = frms;
+        ctl->tolf = tol * frms;                  // :70
+        ctl->rms = 0.0;
+        st->acc_iters = 0;
+    }
 }
 
 // end of a V-cycle: sum(res.^2) of the last post-smoothing sweep exactly as k_finish<0> sums it, r_rms
@@ -275,9 +281,22 @@ __global__ __launch_bounds__(256) void k_cycle_finish(const double* __restrict__
     }
 }
 
-int fprx_cycle_init(fpr_ctx* ctx, double tol, double npoints, const double* sumsq_f_dev)
+int fprx_cycle_init(fpr_ctx* ctx, const double* f, size_t n, double tol)
 {
-    k_cycle_init<<<1, 1, 0, ctx->stream[0]>>>(ctx->cyc, ctx->state, tol, npoints, sumsq_f_dev);
+    // as fprx_sumsq_scaled_dev(f) + the finishing launch, which here also sets up the cycle state (one launch less)
+    int g = flat_grid(n);
+    const double* partials = ctx->partials;
+    k_reduce<0><<<g, 256, 0, ctx->stream[0]>>>(f, nullptr, n, 1.0, ctx->partials);
+    FPR_CHECK_LAUNCH(ctx);
+    if (g > 2048) {
+        const int nb = 128;
+        const int per = (g + nb - 1) / nb;
+        double* fold = ctx->partials + FPR_MAX_PARTIALS;
+        k_fold_partials<<<nb, 256, 0, ctx->stream[0]>>>(partials, g, per, fold);
+        partials = fold;
+        g = nb;
+    }
+    k_cycle_init<<<1, 256, 0, ctx->stream[0]>>>(partials, g, ctx->cyc, ctx->state, tol, (double)n);
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
 }

@@ -253,7 +253,7 @@ int fprx_sumsq_scaled_dev(fpr_ctx* ctx, const double* x, size_t n, double scale,
 int fprx_dot_dev(fpr_ctx* ctx, const double* x, const double* y, size_t n, double* out_dev);
 // finish a two-stage reduction: out_dev[0] (= or +=) sum(partials[0..nparts))
 int fprx_finish_sum(fpr_ctx* ctx, const double* partials, int nparts, double* out_dev, bool accumulate, int stream_sel);
-int fprx_cycle_init(fpr_ctx* ctx, double tol, double npoints, const double* sumsq_f_dev);
+int fprx_cycle_init(fpr_ctx* ctx, const double* f, size_t n, double tol);
 int fprx_cycle_finish(fpr_ctx* ctx, const double* partials, int nparts, double* sumsq_out_dev, double npoints, int slot);
 int fprx_cycle_wait(fpr_ctx* ctx, int slot, int seq, FprCycleCtl* out);
 int fprx_finish_sum2(fpr_ctx* ctx, const double* p0, const double* p1, int nparts, double* out2_dev, bool accumulate,

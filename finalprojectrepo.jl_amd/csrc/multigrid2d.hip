@@ -297,6 +297,12 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
         // RESTRICT: coarse arrays (whole-array descriptors: nxc * nyc * 8 < 2^31), even owned columns only
         const __amdgpu_buffer_rsrc_t rResC = fpr_rsrc(res_c_out), rCorC = fpr_rsrc(corr_c_out);
         const unsigned vstc = (RESTRICT && owner && !(gi & 1)) ? (unsigned)(gi >> 1) * 8u : FPR_OOR;
+        // RESTRICT with apply_BCs: the coarse right-hand side gets its Neumann columns here (part2_utils.jl:35-39 as applied
+        // at multigrid.jl:355-357: column 0 = column 1, column nxc-1 = column nxc-2) -- the lanes of coarse columns 1 and
+        // nxc-2 store their value a second time, the lanes of columns 0 and nxc-1 do not store theirs
+        const bool nbc = RESTRICT && apply_BCs != 0;
+        const unsigned vstr = (nbc && (gi == 0 || gi == nx - 1)) ? FPR_OOR : vstc;
+        const unsigned vstn = (nbc && owner && (gi == 2 || gi == nx - 3)) ? (gi == 2 ? 0u : (unsigned)(nxc_r - 1) * 8u) : FPR_OOR;
         // The ring slot is a compile-time constant (the row loop is unrolled by PF): a slot is consumed and
         // refilled in place, so no register of an in-flight load is ever copied (a copy would make hipcc wait
         // for that load) and PF rows stay in flight per lane.
@@ -345,7 +351,8 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
                     const bool cint = ic >= 1 && ic <= nxc_r - 2 && jc >= 1 && jc <= nyc_r - 2;
                     const bool row_inj = j3 >= y0 && j3 < y1 && !(j3 & 1);   // uniform
                     const int sc = row_inj ? jc * (nxc_r * 8) : (int)FPR_OOR;
-                    fpr_bst(rResC, vstc, sc, cint ? rr : 0.0);
+                    fpr_bst(rResC, vstr, sc, cint ? rr : 0.0);
+                    fpr_bst(rResC, vstn, sc, cint ? rr : 0.0);
                     fpr_bst(rCorC, vstc, sc, 0.0);
                 }
                 fm = f0;                               // becomes f row (r+1)-3
@@ -465,6 +472,9 @@ __global__ __launch_bounds__(256) void k_seam_march(const double* __restrict__ u
         for (int q = 0; q < PF; ++q) { pu[q] = ldu(rs + 1 + q); pfv[q] = ldf(rs + 1 + q); }
         const __amdgpu_buffer_rsrc_t rResC = fpr_rsrc(res_c_out), rCorC = fpr_rsrc(corr_c_out);
         const unsigned vstc = (owner && !(gi & 1)) ? (unsigned)(gi >> 1) * 8u : FPR_OOR;
+        // BCS: Neumann columns of the coarse right-hand side (:355-357), see k_smooth2_march
+        const unsigned vstr = (BCS && (gi == 0 || gi == nx - 1)) ? FPR_OOR : vstc;
+        const unsigned vstn = (BCS && owner && (gi == 2 || gi == nx - 3)) ? (gi == 2 ? 0u : (unsigned)(nxc - 1) * 8u) : FPR_OOR;
         // one Jacobi sweep at row j of a field whose rows j-1, j, j+1 are (lo, mid, hi); rr = residual used by the update
         auto sweep = [&](double lo, double mid, double hi, double fv, int j, double& rr) {
             const double L = fpr_lane_up1z(mid), R = fpr_lane_down1z(mid);
@@ -519,7 +529,8 @@ __global__ __launch_bounds__(256) void k_seam_march(const double* __restrict__ u
                 const bool cint = ic >= 1 && ic <= nxc - 2 && jc >= 1 && jc <= nyc - 2;
                 const bool row_inj = j5 >= y0 && j5 < y1 && !(j5 & 1);   // uniform
                 const int sc = row_inj ? jc * (nxc * 8) : (int)FPR_OOR;
-                fpr_bst(rResC, vstc, sc, cint ? rres : 0.0);
+                fpr_bst(rResC, vstr, sc, cint ? rres : 0.0);
+                if constexpr (BCS) fpr_bst(rResC, vstn, sc, cint ? rres : 0.0);
                 fpr_bst(rCorC, vstc, sc, 0.0);
             }
             w[0][M1] = an;             // row r+1 takes the slot of row r-2
@@ -1831,10 +1842,34 @@ extern "C" int fpr_bc_neumann2d(fpr_ctx* ctx, double* T, int nx, int ny)
     return FPR_OK;
 }
 
+// apply_boundary_conditions! (part2_utils.jl:22-31) in one launch: Dirichlet rows, then Neumann columns.  The corner points
+// end up with the Dirichlet value of their row (their inner neighbour lies on that row), so every point has one writer.
+__global__ __launch_bounds__(256) void k_bc2d(double* __restrict__ T, int nx, int ny, const int* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < nx) {
+        T[t] = 1.0;
+        T[(size_t)t + (size_t)nx * (ny - 1)] = 0.0;
+    }
+    if (t >= 1 && t < ny - 1) {
+        T[(size_t)nx * t] = T[(size_t)nx * t + 1];
+        T[(size_t)nx * t + nx - 1] = T[(size_t)nx * t + nx - 2];
+    }
+}
+
 extern "C" int fpr_bc2d(fpr_ctx* ctx, double* T, int nx, int ny)
 {
-    if (int rc = fpr_bc_dirichlet2d(ctx, T, nx, ny)) return rc;
-    return fpr_bc_neumann2d(ctx, T, nx, ny);
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, T && nx >= 2 && ny >= 1, "bad array");
+    if (nx < 3 || ny < 2) {   // degenerate shapes: the two reference operations one after the other
+        if (int rc = fpr_bc_dirichlet2d(ctx, T, nx, ny)) return rc;
+        return fpr_bc_neumann2d(ctx, T, nx, ny);
+    }
+    const int m = nx > ny ? nx : ny;
+    k_bc2d<<<(m + 255) / 256, 256, 0, ctx->stream[0]>>>(T, nx, ny, ctx->cyc_skip);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
 }
 
 // ---- CG ---------------------------------------------------------------------------------------------
@@ -2087,9 +2122,9 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             if (fuse_r) {  // pre-smoothing pair + residual + injection + zero coarse guess in ONE pass (:124-132)
                 const dim3 gr((nstrips_r + 3) / 4, (ny + rpc - 1) / rpc);
                 const bool timed = top && fpr_ktimer_begin(ctx, FPR_KT_MG_PRE, s);
-                { if (vx2) k_smooth2_march2<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c, skp); else k_smooth2_march<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c, skp); }
+                { if (vx2) k_smooth2_march2<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c, skp); else k_smooth2_march<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, apply_BCs | ntf, L.res_c, L.corr_c, skp); }
                 fpr_ktimer_end(ctx, timed, s);
-                if (apply_BCs) k_bc_neumann<<<(nyc + 255) / 256, 256, 0, s>>>(L.res_c, nxc, nyc, skp);  // :355-357
+                if (apply_BCs && vx2) k_bc_neumann<<<(nyc + 255) / 256, 256, 0, s>>>(L.res_c, nxc, nyc, skp);  // :355-357 (k_smooth2_march does it itself)
             } else {
                 { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); else k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); }  // :124-125
                 k_restrict_residual2d<<<grid2(nxc, nyc), blk2, 0, s>>>(L.tmp, rhs, L.res_c, nx, ny, C, _h2, apply_BCs, L.corr_c);  // :128-132
@@ -2321,9 +2356,8 @@ static int top_pre(fpr_ctx* ctx, const TopGeom& g, const double* uin, const doub
     hipStream_t s = ctx->stream[0];
     const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_PRE, s);
     k_smooth2_march<false, false, true><<<g.gr, 256, 0, s>>>(uin, rhs, out, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips_r, nullptr,
-                                                             nullptr, g.ntf, res_c, corr_zero, skp);
+                                                             nullptr, apply_BCs | g.ntf, res_c, corr_zero, skp);   // (:355-357 included)
     fpr_ktimer_end(ctx, timed, s);
-    if (apply_BCs) k_bc_neumann<<<((1 + (g.ny - 1) / 2) + 255) / 256, 256, 0, s>>>(res_c, 1 + (g.nx - 1) / 2, 1 + (g.ny - 1) / 2, skp);  // :355-357
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
 }
@@ -2425,8 +2459,7 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
         struct Guard { fpr_ctx* c; ~Guard() { c->cyc_skip = nullptr; } } guard{ctx};
         // rms(f) and the threshold tol * rms(f) stay on the device too (same operations as on the host): no round trip
         // before the first cycle; the host learns both from the first record
-        if (int rc = fprx_sumsq_scaled_dev(ctx, f, N, 1.0, ctx->scalars + 5, 0)) return rc;
-        if (int rc = fprx_cycle_init(ctx, tol, (double)N, ctx->scalars + 5)) return rc;
+        if (int rc = fprx_cycle_init(ctx, f, N, tol)) return rc;
         ctx->cyc_skip = &ctx->cyc->stop;
         const int* skp = ctx->cyc_skip;
         int enq = 0;
@@ -2487,10 +2520,6 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
                     double* Y = (X == L.tmp) ? L.tmp2 : L.tmp;
                     if (int rc = top_seam(ctx, g, X, f, corr[p], Y, L.res_c, corr[1 - p], apply_BCs, skp)) return rc;
                     if (int rc = fprx_cycle_finish(ctx, ctx->partials, nps, ctx->scalars, (double)N, slot)) return rc;
-                    if (apply_BCs) {   // Neumann columns of the coarse residual (:355-357)
-                        k_bc_neumann<<<((1 + (ny - 1) / 2) + 255) / 256, 256, 0, ctx->stream[0]>>>(L.res_c, 1 + (nx - 1) / 2, 1 + (ny - 1) / 2, skp);
-                        FPR_CHECK_LAUNCH(ctx);
-                    }
                     if (int rc = lower(1 - p)) return rc;   // cycle k+1 below the finest level
                     units[slot] = {true, X, p};
                     X = Y; p = 1 - p;

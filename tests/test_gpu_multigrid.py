@@ -493,3 +493,42 @@ def test_cycles_enqueued_ahead_equal_the_plain_loop(fpr, shape, css, bcs, tol, n
         else:
             assert np.array_equal(hist, h0) and r == r0
         assert np.array_equal(u, u0), (ahead, seam, predict)
+
+
+@pytest.mark.parametrize("shape,css,bcs", [
+    ((1025, 1025), 5, False), ((1025, 1025), 5, True), ((513, 513), 5, False), ((2049, 2049), 17, True),
+    ((1025, 513), 9, False), ((513, 257), 5, True), ((2049, 1025), 5, False), ((4097, 4097), 5, False),
+    ((513, 1025), 3, True), ((1025, 129), 5, False),
+], ids=str)
+def test_three_levels_in_two_launches_equal_the_level_by_level_path(fpr, shape, css, bcs):
+    """k_mid_down / k_mid_up (the pre-smoothing passes of the three levels above the LDS-resident sub-hierarchy in one
+    launch, their post-smoothing passes in another; option mg_mid) against one marching pass per level and direction:
+    a single V-cycle (multigrid.jl:91-170) and a whole solve (:41-84) give the same field bit for bit, the same norms,
+    histories and coarse-solver iteration counts -- square and oblong grids, with and without boundary conditions."""
+    import warnings
+
+    F, mg = fpr, fpr.multigrid
+    c = F.ctx()
+    f = rnd(shape, 15) - (0.5 if bcs else 0.0)
+    u0 = rnd(shape, 16)
+    opt = mg.MGOpt()
+    opt.coarse_solve_size = css
+    h = 1.0 / (shape[0] - 1)
+    outs = []
+    try:
+        for mid in (0, 1):
+            c.set_option("mg_mid", mid)
+            u = F.asdevice(u0)
+            r1 = mg.Vcycle_2DPoisson_(u, F.asdevice(f), h, 0.3, 1e-6, css, mg.jacobi, mg.parallel, bcs)
+            v1 = F.tonumpy(u)
+            u = F.asdevice(u0)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                r, hist, frms, cit = mg.MGsolve_2DPoisson_(u, F.asdevice(f), h, 0.0, 1e-8, 12, bcs, opt=opt, return_history=True)
+            outs.append((r1, v1, r, hist, cit, F.tonumpy(u)))
+    finally:
+        c.set_option("mg_mid", 1)
+    a, b = outs
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    assert a[2] == b[2] and np.array_equal(a[3], b[3]) and a[4] == b[4]
+    assert np.array_equal(a[5], b[5]) and np.isfinite(b[5]).all()

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
             const int j1 = r - 1;
             double u1;
             {
-                const double L = fpr_lane_up1(a1), R = fpr_lane_down1(a1);
+                const double L = fpr_lane_up1z(a1), R = fpr_lane_down1z(a1);
                 const double rr = ((((R + L) + a2) + a0) - C * a1) * _h2 - f1;
                 const bool bnd = col_bnd || j1 <= 0 || j1 >= ny - 1;
                 u1 = bnd ? a1 : a1 + fac * rr;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
             // ---- sweep 2 at row r-2 (needs u1 rows r-3, r-2, r-1) ----
             const int j2 = r - 2;
             {
-                const double L = fpr_lane_up1(b1), R = fpr_lane_down1(b1);
+                const double L = fpr_lane_up1z(b1), R = fpr_lane_down1z(b1);
                 const double rr = ((((R + L) + b2) + b0) - C * b1) * _h2 - f0;
                 const bool bnd = col_bnd || j2 <= 0 || j2 >= ny - 1;
                 const double u2 = bnd ? b1 : b1 + fac * rr;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
             if constexpr (RESTRICT) {
                 // ---- residual of u2 at row r-3, injected at even (row, column) ----
                 const int j3 = r - 3;
-                const double L = fpr_lane_up1(c1), R = fpr_lane_down1(c1);
+                const double L = fpr_lane_up1z(c1), R = fpr_lane_down1z(c1);
                 const double rr = ((((R + L) + c2) + c0) - C * c1) * _h2 - fm;
                 {
                     const int ic = gi >> 1, jc = j3 >> 1;

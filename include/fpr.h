@@ -276,7 +276,13 @@ int fpr_vcycle2d(fpr_ctx* ctx, double* u_f, const double* rhs, double h, double 
 /* B8: MGsolve_2DPoisson!(u, f, h, c, tol, niters, apply_BCs; opt) -- multigrid.jl:41-84.
  * rms_host = returned r_rms; ncycles_host = V-cycles executed; history_host (nullable, >= niters
  * doubles) = r_rms after each cycle; frms_host (nullable) = rms(f); converged_host (nullable) = 0 when
- * the reference would emit its @warn (:78-80) -- not an error. */
+ * the reference would emit its @warn (:78-80) -- not an error.
+ * The loop runs as one stream of launches where every launch of a cycle can honour a device-side stop flag (Jacobi coarse
+ * solver on a hierarchy the marching passes take): the exit test :70 is evaluated on the device, cycles are enqueued
+ * ahead of the host's view of the norm, and two consecutive cycles share their pass over the finest grid -- u, the
+ * history, the cycle and coarse-iteration counts are those of the plain loop.  Tuning / A-B options
+ * (fpr_set_option, defaults in brackets): mg_ahead [1] cycles enqueued ahead (0 = plain loop), mg_seam [1] shared pass
+ * between cycles, mg_seam_predict [1], mg_mid [1] three launch-bound levels in two launches, mg_small_row [1]. */
 int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h, double c, double tol, int niters,
                   int apply_BCs, int coarse_solve_size, int coarse_solver, int nx, int ny, double* rms_host,
                   int* ncycles_host, double* history_host, double* frms_host, int* converged_host);

@@ -99,7 +99,7 @@ fpr_version() = unsafe_string(ccall((:fpr_version, libfpr), Cstring, ()))
 set_option(key::String, v::Integer) = check(ccall((:fpr_set_option, libfpr), Cint, (Ptr{Cvoid}, Cstring, Clong), ctx(), key, v))
 get_option(key::String) = ccall((:fpr_get_option, libfpr), Clong, (Ptr{Cvoid}, Cstring), ctx(), key)
 kernel_timer(on::Bool) = check(ccall((:fpr_kernel_timer, libfpr), Cint, (Ptr{Cvoid}, Cint), ctx(), on))
-function kernel_timer_read(kind::Integer = -1)   # FPR_KT_*: 0 step, 1 fused step pair, 2 / 3 finest MG passes, -1 all
+function kernel_timer_read(kind::Integer = -1)   # FPR_KT_*: 0 step, 1 fused step pair, 2 / 3 / 4 finest MG passes (pre, post, seam), -1 all
     ms = Ref{Cdouble}(0); n = Ref{Clong}(0)
     check(ccall((:fpr_kernel_timer_read, libfpr), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Clong}), ctx(), kind, ms, n))
     return ms[], n[]

@@ -31,9 +31,25 @@ def ctx():
     return _default_ctx
 
 
+_second_ctx = None
+
+
+def second_ctx():
+    """A second context on the default context's device (own streams and multigrid arena): part2 runs the W solve on it
+    beside the T solve of the same time step."""
+    global _second_ctx
+    c = ctx()
+    if _second_ctx is None or _second_ctx.device != c.device or _second_ctx._closed:
+        _second_ctx = Context(c.device, secondary=True)
+    return _second_ctx
+
+
 def reset():
     """@reset_parallel_stencil()"""
-    global _default_ctx
+    global _default_ctx, _second_ctx
+    if _second_ctx is not None:
+        _second_ctx.close()
+    _second_ctx = None
     if _default_ctx is not None:
         _default_ctx.close()
     _default_ctx = None

@@ -195,7 +195,9 @@ class Context:
     """fpr_ctx wrapper.  Two torch streams (compute, comm) are created and handed to the library so
     torch ops, torch.cuda.Event timing and the library's kernels share them."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, secondary=False):
+        """secondary: a further context on the same device (own streams, own multigrid arena) for work that runs beside the
+        default one; it does not become torch's current stream."""
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: the fpr hot path needs an MI355X (there is no CPU fallback)")
@@ -207,7 +209,8 @@ class Context:
         torch.cuda.synchronize(device)
         self.compute = torch.cuda.Stream(device=device)
         self.comm = torch.cuda.Stream(device=device)
-        torch.cuda.set_stream(self.compute)
+        if not secondary:
+            torch.cuda.set_stream(self.compute)
         h = _vp()
         rc = self.L.fpr_ctx_create(C.byref(h), device, _vp(self.compute.cuda_stream), _vp(self.comm.cuda_stream))
         if rc != 0:

@@ -1903,8 +1903,8 @@ static int cg_work(fpr_ctx* ctx, size_t n, CgWork* w)
 // workgroups are the tile-edge values of r (through the r array, coherent accesses) and one partial sum per workgroup and
 // dot product.  The ring of p is recomputed from the neighbour's r and the ring's own previous p (same operations as the
 // owner), so two barriers per iteration suffice: after the p.p_hat partials and after the r.r partials + r edges.
-// Launched with hipLaunchCooperativeKernel (the runtime guarantees that all 16 workgroups are resident); every spin is
-// bounded and raises an abort flag all workgroups honour, so a lost workgroup cannot hang the device.
+// 16 workgroups are resident together on every device this runs on; every spin is bounded and raises an abort flag all
+// workgroups honour, so a workgroup that does not arrive ends the solve with an error instead of hanging the device.
 // Same operations per point as k_cg_pmv_f / k_cg_update_f; the dot products are summed per workgroup and then over the 16
 // workgroups, i.e. in another order than the 64x4-tile partials of the other forms: results agree to rounding, not bit for
 // bit (cg_fused = 3; forms 0-2 remain bit-identical among themselves).
@@ -2194,8 +2194,12 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
             a.prof = (long long*)(uintptr_t)fpr_opt(ctx, "cg_prof", 0);
             FPR_HIP(ctx, hipMemsetAsync(a.ctr, 0, 2 * sizeof(unsigned), s));
             k_cgp_slots_init<<<1, 64, 0, s>>>(reinterpret_cast<unsigned long long*>(a.part));
-            void* args[] = {&a};
-            FPR_HIP(ctx, hipLaunchCooperativeKernel((const void*)k_cg_persistent, dim3(CGP_NB), dim3(CGP_NT), args, lds, s));
+            // An ordinary launch: 16 workgroups of 1024 threads are resident together on any device this library runs on
+            // (one per CU, 256 CUs), every wait is bounded, and a cooperative launch moves the process onto the runtime's
+            // cooperative queue -- after it, kernels of two streams no longer overlap (measured: the side-by-side T / W solves
+            // of the NS step 1.61 -> 1.96 ms, tools/exp_ns_only.py).
+            k_cg_persistent<<<dim3(CGP_NB), dim3(CGP_NT), lds, s>>>(a);
+            FPR_CHECK_LAUNCH(ctx);
             if (int rc = read_state(ctx)) return rc;
             if (ctx->state_h->done < 0) return fpr_fail(ctx, FPR_ERR_HIP, "cg!: a grid barrier of the persistent kernel timed out");
             return FPR_OK;   // x_in holds the solution (krylov.jl:88)

@@ -169,6 +169,17 @@ def Vcycle_2DPoisson_(u_f, rhs, h, c, tol, coarse_solve_size, coarse_solver, exe
     return out.value
 
 
+def mgsolve_raw(c_, u, f, h, c, tol, niters, apply_BCs, opt):
+    """fpr_mgsolve2d on the context c_ without the wrapper's printing and warnings (callable from a worker thread: ctypes
+    releases the GIL for the duration of the call).  Returns (r_rms, ncycles, f_rms, converged)."""
+    nx, ny = u.shape
+    rms, ncyc, frms, conv = C.c_double(0.0), C.c_int(0), C.c_double(0.0), C.c_int(0)
+    c_.call("fpr_mgsolve2d", fptr(u, 2), fptr(f, 2), h, c, tol, int(niters), int(bool(apply_BCs)),
+            int(opt.coarse_solve_size), CoarseSolver_t(opt.coarse_solver).value, nx, ny, C.byref(rms),
+            C.byref(ncyc), None, C.byref(frms), C.byref(conv))
+    return rms.value, ncyc.value, frms.value, bool(conv.value)
+
+
 def MGsolve_2DPoisson_(u, f, h, c, tol, niters, apply_BCs, opt=None, verbose=False, prealloc_dict=None,
                        return_history=False):
     """multigrid.jl:41-84; returns r_rms (and, with return_history, (r_rms, history, f_rms, coarse_iters))."""

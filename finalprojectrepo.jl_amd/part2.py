@@ -15,6 +15,12 @@ from . import multigrid as mg
 from ._lib import asdevice, fptr, fzeros, tonumpy
 
 
+def _second():
+    from . import second_ctx
+
+    return second_ctx()
+
+
 def _ctx():
     from . import ctx
 
@@ -140,13 +146,16 @@ def step_rhs_(T, W, S, hx, hy, Ra, Pr, k, beta, dt, T_out, W_out):
 
 
 def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_steps=None, trace=None, fused=True,
-                     timing=None):
+                     timing=None, concurrent_solves=True):
     """part2.jl:140-262.  trace: optional list; one dict per time step is appended with the step's dt and the
     residual histories of its multigrid solves (diagnostics for the parity tests; costs nothing when None).
     fused (default): the step around the three multigrid solves runs as two passes (velocity_and_maxima, step_rhs_)
     instead of the reference's seven kernels, three maxima and four broadcasts -- same numbers, bit for bit.
     timing: optional dict; receives the seconds spent inside the multigrid solves ("mg_s") of the TIMED steps (from the
-    fourth on, :182-184), with a stream synchronisation around every solve (diagnostic mode, slightly slower)."""
+    fourth on, :182-184), with a stream synchronisation around every solve (diagnostic mode, slightly slower).
+    concurrent_solves (default, fused path without trace / timing): the T solve (:221) and the W solve (:226) of a step do not
+    depend on each other; W runs on a second context (own streams, own arena) from a worker thread beside T -- these solves
+    are bound by launch latency, not by the GPU, so they overlap almost entirely.  Same results bit for bit."""
     import torch
 
     opt = opt if opt is not None else SimIn_t()
@@ -167,6 +176,8 @@ def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_s
     sim_time, step = 0.0, 0
     mgopt = mg.MGOpt()
     import warnings
+
+    pool, ctx2, ev_a, ev_b = None, None, None, None
 
     while sim_time < opt.ttot:
         if step == 3:
@@ -201,7 +212,25 @@ def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_s
                     dt = dt_adv if opt.beta >= 0.5 else min(dt_dif, dt_adv)
                 mg.apply_boundary_conditions_(T)  # :199
                 step_rhs_(T, W, S, hx, hy, opt.Ra, opt.Pr, opt.k, opt.beta, dt, A["T_rhs"], A["W_rhs"])  # :202-230
-                if opt.beta > 0.0:
+                if opt.beta > 0.0 and concurrent_solves and rec is None and timing is None:
+                    c = 1.0 / (opt.beta * dt)
+                    if pool is None:
+                        import concurrent.futures
+
+                        pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+                        ctx2 = _second()
+                        ev_a, ev_b = torch.cuda.Event(), torch.cuda.Event()
+                    ev_a.record(ctx.compute)          # W, W_rhs (and what they were computed from) are complete for the other stream
+                    ctx2.compute.wait_event(ev_a)
+                    fut = pool.submit(mg.mgsolve_raw, ctx2, W, A["W_rhs"], h, c / opt.Pr, opt.tol, opt.niters, False, mgopt)  # :226
+                    resT = mg.mgsolve_raw(ctx, T, A["T_rhs"], h, c, opt.tol, opt.niters, True, mgopt)                      # :221
+                    resW = fut.result()
+                    ev_b.record(ctx2.compute)         # the next step's kernels (default stream) read W
+                    ctx.compute.wait_event(ev_b)
+                    for nm, rs in (("T", resT), ("W", resW)):
+                        if not rs[3] and verbose:
+                            warnings.warn("V-cycle multigrid failed to converge within %d iterations." % opt.niters)  # multigrid.jl:78-80
+                elif opt.beta > 0.0:
                     c = 1.0 / (opt.beta * dt)
                     solve("T", T, A["T_rhs"], c, True)  # :221
                     c = c / opt.Pr
@@ -242,6 +271,8 @@ def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_s
             print("time, step: %g %d" % (sim_time, step))
         if testmode or (max_steps is not None and step >= max_steps):
             break
+    if pool is not None:
+        pool.shutdown(wait=True)
     ctx.synchronize()
     t_elapsed = time.time() - tic
     out = SimOut_t(tonumpy(T), tonumpy(W), tonumpy(S), t_elapsed, step - 3)

@@ -251,3 +251,28 @@ def test_fused_step_equals_kernel_by_kernel_step(fpr, oracle, beta):
     assert np.array_equal(F.tonumpy(gvx), vx) and np.array_equal(F.tonumpy(gvy), vy)
     assert m == (np.sqrt(vx * vx + vy * vy).max(), np.abs(vx).max(), np.abs(vy).max())
     assert p2.velocity_and_maxima(F.asdevice(S), h, h) == m
+
+
+@pytest.mark.parametrize("shape", [(513, 129), (1025, 1025)], ids=str)
+def test_t_and_w_solves_side_by_side_equal_the_sequence(fpr, shape):
+    """The T solve (part2.jl:221) and the W solve (:226) of a time step do not depend on each other: run side by side (W on a
+    second context from a worker thread, ordered against the default stream by events) they leave the same T, W, S and time
+    step as one after the other -- bit for bit, over several steps, so that each step consumes what the previous one's two
+    solves produced."""
+    import warnings
+
+    p2 = fpr.part2
+    outs = []
+    for conc in (False, True, True):
+        opt = p2.SimIn_t()
+        opt.nx, opt.ny, opt.beta, opt.tol, opt.Pr, opt.niters, opt.ttot = shape[0], shape[1], 0.5, 1.0e-7, 1.0, 30, 1e9
+        opt.W_init_strategy = p2.random
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            outs.append(p2.navier_stokes_2D(opt=opt, verbose=False, max_steps=5, fused=True, concurrent_solves=conc))
+    a = outs[0]
+    for b in outs[1:]:
+        assert a.dt_last == b.dt_last and a.steps == b.steps
+        for name in ("T", "W", "S"):
+            assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert np.isfinite(a.T).all() and np.isfinite(a.W).all()

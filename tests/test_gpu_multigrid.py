@@ -548,3 +548,53 @@ def test_three_levels_in_two_launches_equal_the_level_by_level_path(fpr, shape, 
     assert a[0] == b[0] and np.array_equal(a[1], b[1])
     assert a[2] == b[2] and np.array_equal(a[3], b[3]) and a[4] == b[4]
     assert np.array_equal(a[5], b[5]) and np.isfinite(b[5]).all()
+
+
+def test_stream_mode_equals_plain_loop_over_many_small_problems(fpr):
+    """A sweep over shapes, coarse_solve_size, boundary conditions, niters (including 1 and 2) and tolerances: fpr_mgsolve2d
+    in its default mode (device-side exit test, cycles ahead, seam pass, mid-level kernels, DPP-row coarse solve where each
+    applies) against the plain loop with the level-by-level kernels -- same field bit for bit, same cycle and coarse-iteration
+    counts, histories equal to summation order.  Errors the reference raises must come out the same in both modes."""
+    import itertools
+    import warnings
+
+    F, mg = fpr, fpr.multigrid
+    c = F.ctx()
+    shapes = [(65, 65), (129, 65), (65, 129), (257, 33), (129, 129), (513, 65), (257, 257), (513, 129), (1025, 257), (33, 33), (17, 257)]
+    combos = list(itertools.product(shapes, (3, 5, 9, 17), (False, True), (1, 2, 3, 9), (1e-2, 1e-7, 1e-13)))
+    rng = np.random.default_rng(11)
+    picks = [combos[i] for i in sorted(rng.choice(len(combos), size=90, replace=False))]
+    plain = {"mg_ahead": 0, "mg_seam": 0, "mg_mid": 0, "mg_small_row": 0}
+    checked = 0
+    for shape, css, bcs, niters, tol in picks:
+        f = rnd(shape, 31) - (0.5 if bcs else 0.0)
+        u0 = rnd(shape, 32) * 0.1
+        opt = mg.MGOpt()
+        opt.coarse_solve_size = css
+        h = 1.0 / (shape[0] - 1)
+        res = []
+        for mode in (plain, {}):
+            try:
+                for k in plain:
+                    c.set_option(k, mode.get(k, 1))
+                u = F.asdevice(u0)
+                try:
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        r, hist, frms, cit = mg.MGsolve_2DPoisson_(u, F.asdevice(f), h, 0.7, tol, niters, bcs, opt=opt, return_history=True)
+                    res.append(("ok", r, hist, frms, cit, F.tonumpy(u)))
+                except (AssertionError, RuntimeError) as e:
+                    res.append(("err", type(e).__name__))
+            finally:
+                for k in plain:
+                    c.set_option(k, 1)
+        a, b = res
+        assert a[0] == b[0], (shape, css, bcs, niters, tol)
+        if a[0] == "err":
+            assert a[1] == b[1]
+            continue
+        checked += 1
+        assert len(a[2]) == len(b[2]) and a[4] == b[4] and a[3] == b[3], (shape, css, bcs, niters, tol)
+        assert np.allclose(a[2], b[2], rtol=1e-12, atol=0.0), (shape, css, bcs, niters, tol)
+        assert np.array_equal(a[5], b[5]), (shape, css, bcs, niters, tol)
+    assert checked >= 60

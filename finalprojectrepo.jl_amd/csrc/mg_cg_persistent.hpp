@@ -1,0 +1,272 @@
+// mg_cg_persistent.hpp -- cg! (krylov.jl:55-91) as one persistent launch of 16 workgroups
+// Part of multigrid2d.hip (included there, in this order: mg_march.hpp, mg_cg.hpp, mg_small.hpp, mg_cg_persistent.hpp,
+// mg_mid.hpp); kernels only, the host side that launches them is in multigrid2d.hip.
+#pragma once
+
+// ---- cg! as ONE launch: a persistent 16-workgroup kernel with two grid barriers per iteration -----------------------------
+// The two-launch form spends ~5 us per launch boundary, 10 us per iteration, on a 257^2 problem whose arithmetic takes
+// well under 1 us.  tools/gridsync_probe.hip: a dependent launch costs 2.8 us (4.5 under rocprofv3), cooperative_groups'
+// grid.sync() 2.9 us for 16 workgroups and 32 us for 256 -- but a hand-written counter barrier between 16 workgroups costs
+// 1.1 us.  So: 4 x 4 workgroups of 1024 threads, every vector of the iteration (x, r, p, p_hat) in REGISTERS (<= 5 points per
+// thread), the direction p of the tile plus a one-point ring in LDS for the operator; the only data that travel between
+// workgroups are the tile-edge values of r (through the r array, coherent accesses) and one partial sum per workgroup and
+// dot product.  The ring of p is recomputed from the neighbour's r and the ring's own previous p (same operations as the
+// owner), so two barriers per iteration suffice: after the p.p_hat partials and after the r.r partials + r edges.
+// 16 workgroups are resident together on every device this runs on; every spin is bounded and raises an abort flag all
+// workgroups honour, so a workgroup that does not arrive ends the solve with an error instead of hanging the device.
+// Same operations per point as k_cg_pmv_f / k_cg_update_f; the dot products are summed per workgroup and then over the 16
+// workgroups, i.e. in another order than the 64x4-tile partials of the other forms: results agree to rounding, not bit for
+// bit (cg_fused = 3; forms 0-2 remain bit-identical among themselves).
+constexpr int CGP_NB = 16, CGP_NBX = 4, CGP_NT = 1024, CGP_PPT = 5, CGP_RPT = 1;   // workgroups, threads, tile / ring points per thread
+// (256 threads x 17 points: 9.0 us per iteration against 6.5 -- the two divisions per point of lap_at then weigh 2.8 us)
+struct CgpArgs {
+    const double* b;
+    double* x_out;         // solution (whole array written)
+    double* r_glob;        // N doubles: tile-edge values of r are exchanged through it
+    double* part;          // 4 x CGP_NB slots (8 bytes every 128: partial sum = arrival flag), all CGP_EMPTY before the launch
+    unsigned* ctr;         // [1] abort flag
+    FprSolveState* st;
+    int nx, ny, Nmax;
+    double hx2, hy2, c, tol, N;
+    long long* prof;       // diagnostic (option cg_prof = device address of 8 int64): ticks of workgroup 0 per section, summed
+};
+
+__device__ __forceinline__ double cgp_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cgp_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Grid barrier and all-reduce in ONE round trip: workgroup b stores its partial sum into its own slot of the set that belongs
+// to this barrier; lanes 0..15 of wave 0 of every workgroup each watch one slot until it no longer holds the EMPTY pattern (a
+// NaN payload no sum produces) -- the value itself is the arrival flag.  FOUR sets rotate: when a workgroup publishes for
+// barrier g it first empties its slot of set (g+2) mod 4, last used at barrier g-2 (everybody has read that one: they all
+// published g-1 since).  That slot is polled next at barrier g+2; between the emptying and that poll lie the owner's
+// publications g and g+1, and the barriers alternate between RELEASE (publishes the workgroup's earlier stores -- the tile-edge
+// values of r and the emptying -- acquired by the pollers) and relaxed (nothing but the sum travels), so one of the two orders
+// the emptying before the poll.  Returns the 16 partials summed in workgroup order in every thread; *ok = false if the wait
+// timed out (abort raised for everybody).
+constexpr unsigned long long CGP_EMPTY = 0x7ff8dead0badf00dull;
+constexpr int CGP_SLOT_STRIDE = 16;   // 8-byte words between two slots
+// sum over the 64 lanes of a wave by DPP row shifts (an inclusive scan inside each 16-lane row, then the four row totals):
+// ~25 instructions where the shuffle tree of fpr_wave_sum takes 12 LDS-crossbar round trips.  Result in every lane.
+__device__ __forceinline__ double cgp_wave_sum(double v)
+{
+    v += mgs_dpp<0x111>(v);
+    v += mgs_dpp<0x112>(v);
+    v += mgs_dpp<0x114>(v);
+    v += mgs_dpp<0x118>(v);   // lane 15 of every row: the row's total
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 47), __builtin_amdgcn_readlane(lo, 47));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
+    return ((r0 + r1) + r2) + r3;
+}
+
+template <bool RELEASE>
+__device__ __forceinline__ double cgp_allsum(unsigned long long* slots, unsigned* abort_flag, double v_thread, unsigned& gen, double* red,
+                                             double* gpart, int* s_abort, bool* ok)
+{
+    ++gen;
+    // (a slot per 128-byte line: the pollers of different slots do not queue at one memory channel)
+    unsigned long long* set = slots + (gen & 3u) * (CGP_NB * CGP_SLOT_STRIDE);
+    unsigned long long* nxt = slots + ((gen + 2u) & 3u) * (CGP_NB * CGP_SLOT_STRIDE);
+    const double v_wave = cgp_wave_sum(v_thread);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v_wave;
+    __syncthreads();                       // wave totals in LDS; the workgroup's earlier stores precede the publication below
+    if (threadIdx.x == 0) {
+        double v_blk = red[0];
+#pragma unroll
+        for (int w = 1; w < CGP_NT / 64; ++w) v_blk += red[w];
+        __hip_atomic_store(&nxt[blockIdx.x * CGP_SLOT_STRIDE], CGP_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long bits = (unsigned long long)__double_as_longlong(v_blk);
+        if (bits == CGP_EMPTY) bits ^= 1ull;   // (a sum that happens to be this very NaN stays a NaN)
+        if (RELEASE) __hip_atomic_store(&set[blockIdx.x * CGP_SLOT_STRIDE], bits, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(&set[blockIdx.x * CGP_SLOT_STRIDE], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x < 64) {                // wave 0: lane w < 16 waits for workgroup w
+        const int w = threadIdx.x;
+        int ab = 0;
+        if (w < CGP_NB) {
+            unsigned spins = 0;
+            unsigned long long bits;
+            while (true) {
+                bits = RELEASE ? __hip_atomic_load(&set[w * CGP_SLOT_STRIDE], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+                               : __hip_atomic_load(&set[w * CGP_SLOT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (bits != CGP_EMPTY) break;
+                if ((++spins & 0x3ff) == 0) {
+                    if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
+                    if (spins > (1u << 22)) {   // seconds, not minutes
+                        __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ab = 1;
+                        break;
+                    }
+                }
+            }
+            gpart[w] = __longlong_as_double((long long)bits);
+        }
+        ab = __any(ab);
+        if (threadIdx.x == 0) *s_abort = ab;
+    }
+    __syncthreads();
+    *ok = *s_abort == 0;
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < CGP_NB; ++w) s += gpart[w];
+    return s;
+}
+
+__global__ void k_cgp_slots_init(unsigned long long* slots)
+{
+    if (threadIdx.x < 4 * CGP_NB) slots[threadIdx.x * CGP_SLOT_STRIDE] = CGP_EMPTY;
+}
+
+__global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double red[CGP_NT / 64];
+    __shared__ double gpart[CGP_NB];
+    __shared__ int s_abort;
+    const int tid = threadIdx.x;
+    const int bx = blockIdx.x % CGP_NBX, by = blockIdx.x / CGP_NBX;
+    const int nx = a.nx, ny = a.ny;
+    const int twm = (nx + CGP_NBX - 1) / CGP_NBX, thm = (ny + CGP_NBX - 1) / CGP_NBX;   // nominal tile
+    const int i0 = bx * twm, j0 = by * thm;
+    int tw = nx - i0 < twm ? nx - i0 : twm, th = ny - j0 < thm ? ny - j0 : thm;
+    if (tw < 0) tw = 0;
+    if (th < 0) th = 0;
+    const int npt = tw * th;                       // points of this tile (0: the workgroup only takes part in the barriers)
+    const int lw = twm + 2;                        // LDS row length: tile + ring
+    double* P = sm;                                // (thm + 2) x lw image of p: tile cell (ti, tj) at (ti + 1) + lw * (tj + 1)
+    unsigned gen = 0;
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(a.part);   // 4 sets x 16 slots, all EMPTY at the start
+    bool ok = true;
+    if (tid == 0) s_abort = 0;
+    // this thread's points
+    int li[CGP_PPT], gi[CGP_PPT];                  // LDS index, global index (-1: none)
+    bool inter[CGP_PPT], edge[CGP_PPT];
+    double x[CGP_PPT], r[CGP_PPT], p[CGP_PPT], q[CGP_PPT];
+    const float rtw = tw > 0 ? 1.0f / (float)tw : 0.0f;
+#pragma unroll
+    for (int k = 0; k < CGP_PPT; ++k) {
+        const int idx = tid + k * CGP_NT;
+        gi[k] = -1; li[k] = 0; inter[k] = false; edge[k] = false;
+        x[k] = 0.0; r[k] = 0.0; p[k] = 0.0; q[k] = 0.0;
+        if (idx < npt) {
+            const int tj = mgs_row(idx, rtw), ti = idx - tj * tw;
+            const int i = i0 + ti, j = j0 + tj;
+            gi[k] = i + nx * j;
+            li[k] = (ti + 1) + lw * (tj + 1);
+            inter[k] = i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1;
+            edge[k] = ti == 0 || tj == 0 || ti == tw - 1 || tj == th - 1;
+            const double v = a.b[gi[k]];
+            r[k] = v; p[k] = v; q[k] = v;          // krylov.jl:61-66: r = p = b, p_hat starts as b (its boundary keeps b), x = 0
+        }
+    }
+    // ring cells of this thread (at most CGP_RPT): bottom row, top row, left column, right column of the (tw+2) x (th+2) frame
+    int rl[CGP_RPT], rg[CGP_RPT];
+    double p_ring[CGP_RPT];
+    {
+        const int nring = npt > 0 ? 2 * (tw + 2) + 2 * th : 0;
+#pragma unroll
+        for (int m = 0; m < CGP_RPT; ++m) {
+            const int t = tid + m * CGP_NT;
+            rl[m] = -1; rg[m] = -1;
+            if (t < nring) {
+                int hx, hy;
+                if (t < tw + 2) { hx = t; hy = 0; }
+                else if (t < 2 * (tw + 2)) { hx = t - (tw + 2); hy = th + 1; }
+                else if (t < 2 * (tw + 2) + th) { hx = 0; hy = t - 2 * (tw + 2) + 1; }
+                else { hx = tw + 1; hy = t - 2 * (tw + 2) - th + 1; }
+                const int ri = i0 + hx - 1, rj = j0 + hy - 1;
+                rl[m] = hx + lw * hy;
+                if (ri >= 0 && rj >= 0 && ri < nx && rj < ny) rg[m] = ri + nx * rj;
+            }
+            p_ring[m] = rg[m] >= 0 ? a.b[rg[m]] : 0.0;   // p = b before the first iteration
+        }
+    }
+    // rho = sum(r .* r) with r = b (krylov.jl:64), threshold tol * ||b|| (:57-58)
+    double rho = 0.0, rho_old = 0.0, rr = 0.0;
+    int it = 0;
+    bool conv = false, alive = true;
+    {
+        double acc0 = 0.0;
+#pragma unroll
+        for (int k = 0; k < CGP_PPT; ++k) acc0 += r[k] * r[k];
+        rho = cgp_allsum<false>(slots, &a.ctr[1], acc0, gen, red, gpart, &s_abort, &ok);
+        alive = ok;
+        rr = rho;
+    }
+    const double thresh = a.tol * sqrt(rho);
+    long long tsec[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool prof = a.prof != nullptr && blockIdx.x == 0 && tid == 0;
+    auto lap = [&](int k) { if (prof) { const long long t = wall_clock64(); tsec[k] += t - tprev; tprev = t; } };
+    if (prof) tprev = wall_clock64();
+    for (; alive && it < a.Nmax; ++it) {
+        // ---- exit test and beta of iteration it-1 (krylov.jl:73-84), new direction (:85), operator and p.p_hat (:68-69) ----
+        double beta = 0.0;
+        if (it > 0) {
+            if (sqrt(rr) < thresh) { conv = true; break; }      // :76 (every thread of every workgroup holds the same sum)
+            rho_old = rho;
+            beta = rr / rho_old;                                 // :83-84
+            rho = rr;
+#pragma unroll
+            for (int k = 0; k < CGP_PPT; ++k) p[k] = r[k] + beta * p[k];
+#pragma unroll
+            for (int m = 0; m < CGP_RPT; ++m)   // acquired at barrier 2 by wave 0 (cache invalidate), workgroup barrier since
+                if (rg[m] >= 0) p_ring[m] = a.r_glob[rg[m]] + beta * p_ring[m];
+        }
+#pragma unroll
+        for (int k = 0; k < CGP_PPT; ++k)
+            if (gi[k] >= 0) P[li[k]] = p[k];
+#pragma unroll
+        for (int m = 0; m < CGP_RPT; ++m)
+            if (rl[m] >= 0) P[rl[m]] = p_ring[m];
+        __syncthreads();
+        lap(0);   // beta, new p, ring loads, LDS image
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < CGP_PPT; ++k) {
+            if (inter[k]) {
+                const double t = p[k];
+                const int l = li[k];
+                q[k] = (((P[l + 1] - 2 * t) + P[l - 1]) / a.hx2 + ((P[l + lw] - 2 * t) + P[l - lw]) / a.hy2) - a.c * t;   // lap_at
+            }
+            if (gi[k] >= 0) acc += p[k] * q[k];
+        }
+        lap(1);   // operator
+        const double pq = cgp_allsum<false>(slots, &a.ctr[1], acc, gen, red, gpart, &s_abort, &ok);   // barrier 1 of the iteration
+        if (!ok) { alive = false; break; }
+        lap(3);   // barrier 1
+        // ---- alpha, x and r (krylov.jl:69-72), r.r; the tile-edge values of r go to the neighbours ----
+        const double alpha = rho / pq;
+        double acc2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < CGP_PPT; ++k) {
+            if (gi[k] >= 0) {
+                x[k] = x[k] + alpha * p[k];
+                const double rn = r[k] - alpha * q[k];
+                r[k] = rn;
+                acc2 += rn * rn;
+                if (edge[k]) a.r_glob[gi[k]] = rn;   // plain store: published by the RELEASE of barrier 2 (an atomic store each would be
+                                                     // issued behind an s_waitcnt of its own: five serial round trips)
+            }
+        }
+        lap(4);   // update
+        rr = cgp_allsum<true>(slots, &a.ctr[1], acc2, gen, red, gpart, &s_abort, &ok);        // barrier 2 (publishes the r edges)
+        if (!ok) { alive = false; break; }
+        lap(5);   // barrier 2
+    }
+    if (prof)
+        for (int k = 0; k < 6; ++k) a.prof[k] += tsec[k];
+    if (alive && !conv && it == a.Nmax && a.Nmax > 0) conv = sqrt(rr) < thresh;   // the loop ran out: the last norm (k_cg_tail_f)
+#pragma unroll
+    for (int k = 0; k < CGP_PPT; ++k)
+        if (gi[k] >= 0) a.x_out[gi[k]] = x[k];              // krylov.jl:88
+    if (blockIdx.x == 0 && tid == 0) {
+        a.st->iters = it;
+        a.st->last_rms = sqrt(rr / a.N);                   // :90 (r = b if the loop body never ran)
+        a.st->thresh = thresh;
+        a.st->done = alive ? (conv ? 1 : 0) : -1;          // -1: a barrier timed out
+        a.st->rho = rr;
+    }
+}
+

@@ -181,378 +181,7 @@ __device__ __forceinline__ double prolong_bf(const double* __restrict__ cc, int 
     return v;
 }
 
-// ---- buffer addressing helpers (descriptor base + per-lane byte offset + scalar byte offset) ---------------------
-// An offset of FPR_OOR is beyond every descriptor's num_records: the hardware drops the access (loads return 0).  The
-// marching kernels use it instead of branches around loads / stores: with conditional memory instructions hipcc cannot
-// count the operations younger than a prefetch and waits for more than it has to (finding 1).
-constexpr unsigned FPR_OOR = 0x7fffffffu;
-typedef unsigned fpr_u2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t fpr_rsrc(const void* p)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)FPR_OOR, 0x00020000);
-}
-__device__ __forceinline__ double fpr_bld(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
-{
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
-}
-__device__ __forceinline__ void fpr_bst(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, double x)
-{
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fpr_u2v, x), r, voff, soff, 0);
-}
-
-// ---- two fused Jacobi sweeps, register-rolling march in y (fine levels) ------------------------------
-// A wave owns a strip of 64 columns (one column per lane) and marches down a chunk of rows keeping a
-// 3-row window of u (sweep 0) and of the once-smoothed field (sweep 1) in registers; x-neighbours come
-// from wavefront shuffles, y-neighbours from the window.  Strips overlap by 4 columns (a wave loads 64
-// columns and owns the 60 in the middle: the two outer lanes on each side only feed the stencils), so
-// waves never communicate: no LDS, no barrier.  One pass reads u and f once and writes u once for TWO
-// sweeps (multigrid.jl:124-125 / :142-143).  Point arithmetic is that of k_sweep2d: bit-identical.
-// PROLONG: the input is corrected on the fly, u = uin - P(corr_c) (multigrid.jl:136-139 fused into the
-// post-smoothing pass: the prolongation/correction pass over the fine grid disappears).
-// RESTRICT: a third stage evaluates the residual of the twice-smoothed field at the injected points
-// (even row, even column) from a 3-row window of the output and writes the coarse right-hand side and
-// the zero initial coarse correction (multigrid.jl:128-132): the residual/restriction pass disappears
-// too.  Strips then overlap by 6 columns and chunks by 3+2 rows.  Coarse boundary points get 0; the
-// Neumann rows of apply_BCs are copied afterwards by k_bc_neumann on the (small) coarse array.
-template <bool NORM, bool PROLONG, bool RESTRICT>
-__global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict__ uin, const double* __restrict__ f,
-                                                        double* __restrict__ uout, int nx, int ny, double C, double _h2,
-                                                        double fac, int rows_per_chunk, int nstrips,
-                                                        double* __restrict__ partials, const double* __restrict__ corr_c,
-                                                        int apply_BCs, double* __restrict__ res_c_out,
-                                                        double* __restrict__ corr_c_out, const int* __restrict__ skip)
-{
-    if (skip && *skip) return;   // a cycle enqueued ahead of the exit test that ended the loop (FprCycleCtl)
-    __shared__ double red[16];
-    constexpr int HX = RESTRICT ? 3 : 2;                     // feeder lanes on each side of a strip
-    constexpr int SW = 64 - 2 * HX;                          // columns owned by a strip
-    apply_BCs &= 255;                                        // (bit 8, non-temporal stores, is ignored by this kernel)
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int strip = blockIdx.x * 4 + w;
-    const bool active = strip < nstrips;
-    const int gi = strip * SW - HX + lane;                   // global column of this lane
-    const bool col_ok = active && gi >= 0 && gi < nx;
-    const int gic = gi < 0 ? 0 : (gi > nx - 1 ? nx - 1 : gi);  // clamped for loads
-    const bool col_bnd = gi <= 0 || gi >= nx - 1;            // domain boundary column (or outside)
-    const bool owner = col_ok && lane >= HX && lane < 64 - HX;
-    const int y0 = blockIdx.y * rows_per_chunk;
-    const int y1 = (y0 + rows_per_chunk < ny) ? y0 + rows_per_chunk : ny;  // output rows [y0, y1)
-    const int rs = y0 - HX < 0 ? 0 : y0 - HX;
-    double acc = 0.0;
-    if (active) {
-        const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
-        int gis = gic;  // Neumann rows of the prolongated correction (part2_utils.jl:35-39)
-        if (PROLONG && apply_BCs) gis = (gic == 0) ? 1 : (gic == nx - 1 ? nx - 2 : gic);
-        // PROLONG: the two coarse columns this lane interpolates from, cached for coarse rows pj and pj+1
-        // (rows are visited in increasing order, so a coarse row is loaded once per two fine rows)
-        const int p_io = gis & 1, p_icl = gis >> 1, p_ich = (p_icl + 1 < nxc) ? p_icl + 1 : nxc - 1;
-        const bool p_sx0 = p_icl >= 1 && p_icl <= nxc - 2, p_sx1 = p_io && (p_icl + 1 <= nxc - 2);
-        const bool p_inx = gis >= 1 && gis <= nx - 2;
-        int pj = -2;
-        double pc00 = 0.0, pc10 = 0.0, pc01 = 0.0, pc11 = 0.0;
-        // rows are addressed relative to the first row of the chunk: (rows_per_chunk + 8) * nx * 8 < 2^31
-        const int rowB = nx * 8;
-        const __amdgpu_buffer_rsrc_t rUin = fpr_rsrc(uin + (size_t)nx * rs), rF = fpr_rsrc(f + (size_t)nx * rs);
-        const __amdgpu_buffer_rsrc_t rUout = fpr_rsrc(uout + (size_t)nx * rs);
-        const unsigned vld = (unsigned)gic * 8u;
-        const unsigned vst = owner ? (unsigned)gi * 8u : FPR_OOR;   // lanes that own nothing store out of range
-        auto ldu = [&](int r) {
-            const int rc = r > ny - 1 ? ny - 1 : r;
-            const double v = fpr_bld(rUin, vld, (rc - rs) * rowB);
-            if constexpr (PROLONG) {
-                const int jo = rc & 1, jcl = rc >> 1;
-                if (jcl != pj) {
-                    const int jch = (jcl + 1 < nyc) ? jcl + 1 : nyc - 1;
-                    if (jcl == pj + 1) { pc00 = pc01; pc10 = pc11; }
-                    else { pc00 = corr_c[(size_t)p_icl + (size_t)nxc * jcl]; pc10 = corr_c[(size_t)p_ich + (size_t)nxc * jcl]; }
-                    pc01 = corr_c[(size_t)p_icl + (size_t)nxc * jch];
-                    pc11 = corr_c[(size_t)p_ich + (size_t)nxc * jch];
-                    pj = jcl;
-                }
-                // same value and accumulation order as prolong_bf
-                const bool in = p_inx && rc >= 1 && rc <= ny - 2;
-                const double wgt = (p_io | jo) ? ((p_io & jo) ? 0.25 : 0.5) : 1.0;
-                const bool sy0 = jcl >= 1 && jcl <= nyc - 2, sy1 = jo && (jcl + 1 <= nyc - 2);
-                double pv = 0.0;
-                pv = pv + ((in && p_sx0 && sy0) ? wgt * pc00 : 0.0);
-                pv = pv + ((in && p_sx1 && sy0) ? wgt * pc10 : 0.0);
-                pv = pv + ((in && p_sx0 && sy1) ? wgt * pc01 : 0.0);
-                pv = pv + ((in && p_sx1 && sy1) ? wgt * pc11 : 0.0);
-                return v - pv;
-            } else {
-                return v;
-            }
-        };
-        auto ldf = [&](int r) { const int rc = r > ny - 1 ? ny - 1 : r; return fpr_bld(rF, vld, (rc - rs) * rowB); };
-        double a0 = 0.0, a1 = 0.0, a2 = ldu(rs);       // u   rows r-2, r-1, r
-        double b0 = 0.0, b1 = 0.0, b2 = 0.0;           // u1  rows r-3, r-2, r-1
-        double f0 = 0.0, f1 = 0.0, f2 = ldf(rs);       // f   rows r-2, r-1, r
-        double c0 = 0.0, c1 = 0.0, c2 = 0.0, fm = 0.0; // RESTRICT: u2 rows r-4, r-3, r-2 and f row r-3
-        // software pipeline: rows r+1 .. r+PF are in flight (PF loads of u and of f per lane)
-        constexpr int PF = 4;
-        double pu[PF], pfv[PF];
-#pragma unroll
-        for (int q = 0; q < PF; ++q) { pu[q] = ldu(rs + 1 + q); pfv[q] = ldf(rs + 1 + q); }
-        const int nxc_r = 1 + (nx - 1) / 2, nyc_r = 1 + (ny - 1) / 2;
-        // RESTRICT: coarse arrays (whole-array descriptors: nxc * nyc * 8 < 2^31), even owned columns only
-        const __amdgpu_buffer_rsrc_t rResC = fpr_rsrc(res_c_out), rCorC = fpr_rsrc(corr_c_out);
-        const unsigned vstc = (RESTRICT && owner && !(gi & 1)) ? (unsigned)(gi >> 1) * 8u : FPR_OOR;
-        // RESTRICT with apply_BCs: the coarse right-hand side gets its Neumann columns here (part2_utils.jl:35-39 as applied
-        // at multigrid.jl:355-357: column 0 = column 1, column nxc-1 = column nxc-2) -- the lanes of coarse columns 1 and
-        // nxc-2 store their value a second time, the lanes of columns 0 and nxc-1 do not store theirs
-        const bool nbc = RESTRICT && apply_BCs != 0;
-        const unsigned vstr = (nbc && (gi == 0 || gi == nx - 1)) ? FPR_OOR : vstc;
-        const unsigned vstn = (nbc && owner && (gi == 2 || gi == nx - 3)) ? (gi == 2 ? 0u : (unsigned)(nxc_r - 1) * 8u) : FPR_OOR;
-        // The ring slot is a compile-time constant (the row loop is unrolled by PF): a slot is consumed and
-        // refilled in place, so no register of an in-flight load is ever copied (a copy would make hipcc wait
-        // for that load) and PF rows stay in flight per lane.
-        auto step = [&](auto Qc, int r) {
-            constexpr int Q = decltype(Qc)::value;
-            // An explicit register copy of the (completed) row ends the live range of the slot, so the refill below
-            // can target the slot's own registers and nothing in flight has to be copied at the loop's back edge.
-            double an, fn;
-            asm volatile("v_mov_b64 %0, %1" : "=v"(an) : "v"(pu[Q]));
-            asm volatile("v_mov_b64 %0, %1" : "=v"(fn) : "v"(pfv[Q]));
-            pu[Q] = ldu(r + 1 + PF);                           // issue the loads of row r+1+PF
-            pfv[Q] = ldf(r + 1 + PF);
-            // ---- sweep 1 at row r-1 (needs u rows r-2, r-1, r) ----
-            const int j1 = r - 1;
-            double u1;
-            {
-                const double L = fpr_lane_up1z(a1), R = fpr_lane_down1z(a1);
-                const double rr = ((((R + L) + a2) + a0) - C * a1) * _h2 - f1;
-                const bool bnd = col_bnd || j1 <= 0 || j1 >= ny - 1;
-                u1 = bnd ? a1 : a1 + fac * rr;
-            }
-            b0 = b1; b1 = b2; b2 = u1;                 // u1 rows r-3, r-2, r-1
-            // ---- sweep 2 at row r-2 (needs u1 rows r-3, r-2, r-1) ----
-            const int j2 = r - 2;
-            {
-                const double L = fpr_lane_up1z(b1), R = fpr_lane_down1z(b1);
-                const double rr = ((((R + L) + b2) + b0) - C * b1) * _h2 - f0;
-                const bool bnd = col_bnd || j2 <= 0 || j2 >= ny - 1;
-                const double u2 = bnd ? b1 : b1 + fac * rr;
-                const bool row_own = j2 >= y0 && j2 < y1;        // uniform
-                fpr_bst(rUout, vst, row_own ? (j2 - rs) * rowB : (int)FPR_OOR, u2);   // unconditional (see FPR_OOR)
-                if constexpr (NORM) {
-                    if (owner && row_own && !bnd) acc += rr * rr;
-                }
-                if constexpr (RESTRICT) {
-                    c0 = c1; c1 = c2; c2 = u2;         // u2 rows r-4, r-3, r-2
-                }
-            }
-            if constexpr (RESTRICT) {
-                // ---- residual of u2 at row r-3, injected at even (row, column) ----
-                const int j3 = r - 3;
-                const double L = fpr_lane_up1z(c1), R = fpr_lane_down1z(c1);
-                const double rr = ((((R + L) + c2) + c0) - C * c1) * _h2 - fm;
-                {
-                    const int ic = gi >> 1, jc = j3 >> 1;
-                    const bool cint = ic >= 1 && ic <= nxc_r - 2 && jc >= 1 && jc <= nyc_r - 2;
-                    const bool row_inj = j3 >= y0 && j3 < y1 && !(j3 & 1);   // uniform
-                    const int sc = row_inj ? jc * (nxc_r * 8) : (int)FPR_OOR;
-                    fpr_bst(rResC, vstr, sc, cint ? rr : 0.0);
-                    fpr_bst(rResC, vstn, sc, cint ? rr : 0.0);
-                    fpr_bst(rCorC, vstc, sc, 0.0);
-                }
-                fm = f0;                               // becomes f row (r+1)-3
-            }
-            a0 = a1; a1 = a2; a2 = an;
-            f0 = f1; f1 = f2; f2 = fn;
-        };
-        const int rend = y1 + (RESTRICT ? 2 : 1);
-        int r = rs;
-        static_assert(PF == 4, "the unrolled row loop below is written for PF = 4 (PF = 8 measured 12 % slower)");
-        for (; r + PF - 1 <= rend; r += PF) {
-            step(std::integral_constant<int, 0>{}, r);
-            step(std::integral_constant<int, 1>{}, r + 1);
-            step(std::integral_constant<int, 2>{}, r + 2);
-            step(std::integral_constant<int, 3>{}, r + 3);
-        }
-        if (r <= rend) { step(std::integral_constant<int, 0>{}, r); ++r; }
-        if (r <= rend) { step(std::integral_constant<int, 1>{}, r); ++r; }
-        if (r <= rend) { step(std::integral_constant<int, 2>{}, r); ++r; }
-    }
-    if constexpr (NORM) {
-        const double sblk = fpr_block_sum<256>(acc, red);
-        if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
-    }
-}
-
-// ---- the seam between two V-cycles on the finest level: FOUR sweeps in one pass ------------------------------
-// MGsolve_2DPoisson! (multigrid.jl:57-71) runs V-cycle after V-cycle on the same arrays: the post-smoothing pair of
-// cycle k (:142-143, on the field corrected by the prolongated coarse solution, :136-139) is followed -- if the exit
-// test :70 does not end the loop -- by the pre-smoothing pair of cycle k+1 (:124-125) and its residual + injection
-// (:128-132).  k_seam_march does all of that in ONE pass over the finest grid: the same register-rolling march as
-// k_smooth2_march with five 3-row windows (the corrected input, the fields after sweeps 1..4) and a residual stage,
-//     read  uin (+ P(corr_c) on the fly), f                          (8 + 8 + 2 bytes per point)
-//     write the twice pre-smoothed field of cycle k+1, its restricted residual, the zero coarse guess   (8 + 2 + 2)
-// -- 30 bytes per point and cycle where the two separate passes move 26 + 28.  The field after sweep 2 is u at the end
-// of cycle k: it is not stored (its residual norm, the r_rms of :252, is summed exactly like k_smooth2_march<NORM>
-// does); if that norm ends the loop the host replays the plain post-smoothing pass from the untouched inputs
-// (fpr_mgsolve2d).  Same point arithmetic as k_sweep2d / prolong_bf: all fields bit-identical to the separate passes.
-// Strips overlap by 10 columns (54 owned of 64), chunks by 5 + 4 rows.  BCS: the boundary conditions the loop re-applies
-// between two cycles (:60-62) act on the field between sweep 2 and sweep 3 (Neumann columns; see below), the correction
-// is prolongated with its Neumann rows, and the host copies the Neumann columns of the coarse residual afterwards
-// (k_bc_neumann, as behind the separate pre-smoothing pass).
-template <bool BCS>
-__global__ __launch_bounds__(256) void k_seam_march(const double* __restrict__ uin, const double* __restrict__ f,
-                                                     double* __restrict__ uout, int nx, int ny, double C, double _h2,
-                                                     double fac, int rows_per_chunk, int nstrips,
-                                                     double* __restrict__ partials, const double* __restrict__ corr_c,
-                                                     double* __restrict__ res_c_out, double* __restrict__ corr_c_out,
-                                                     const int* __restrict__ skip)
-{
-    if (skip && *skip) return;
-    __shared__ double red[16];
-    constexpr int HX = 5;                                    // feeder lanes on each side of a strip
-    constexpr int SW = 64 - 2 * HX;                          // columns owned by a strip
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int strip = blockIdx.x * 4 + w;
-    const bool active = strip < nstrips;
-    const int gi = strip * SW - HX + lane;                   // global column of this lane
-    const bool col_ok = active && gi >= 0 && gi < nx;
-    const int gic = gi < 0 ? 0 : (gi > nx - 1 ? nx - 1 : gi);  // clamped for loads
-    const bool col_bnd = gi <= 0 || gi >= nx - 1;            // domain boundary column (or outside)
-    const bool owner = col_ok && lane >= HX && lane < 64 - HX;
-    const int y0 = blockIdx.y * rows_per_chunk;
-    const int y1 = (y0 + rows_per_chunk < ny) ? y0 + rows_per_chunk : ny;  // output rows [y0, y1)
-    const int rs = y0 - HX < 0 ? 0 : y0 - HX;
-    double acc = 0.0;
-    if (active) {
-        const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
-        // the two coarse columns this lane interpolates from, cached for coarse rows pj and pj+1 (see k_smooth2_march)
-        int gis = gic;  // Neumann rows of the prolongated correction (part2_utils.jl:35-39)
-        if (BCS) gis = (gic == 0) ? 1 : (gic == nx - 1 ? nx - 2 : gic);
-        const int p_io = gis & 1, p_icl = gis >> 1, p_ich = (p_icl + 1 < nxc) ? p_icl + 1 : nxc - 1;
-        const bool p_sx0 = p_icl >= 1 && p_icl <= nxc - 2, p_sx1 = p_io && (p_icl + 1 <= nxc - 2);
-        const bool p_inx = gis >= 1 && gis <= nx - 2;
-        int pj = -2;
-        double pc00 = 0.0, pc10 = 0.0, pc01 = 0.0, pc11 = 0.0;
-        const int rowB = nx * 8;
-        const __amdgpu_buffer_rsrc_t rUin = fpr_rsrc(uin + (size_t)nx * rs), rF = fpr_rsrc(f + (size_t)nx * rs);
-        const __amdgpu_buffer_rsrc_t rUout = fpr_rsrc(uout + (size_t)nx * rs);
-        const unsigned vld = (unsigned)gic * 8u;
-        const unsigned vst = owner ? (unsigned)gi * 8u : FPR_OOR;   // lanes that own nothing store out of range
-        auto ldu = [&](int r) {
-            const int rc = r > ny - 1 ? ny - 1 : r;
-            const double v = fpr_bld(rUin, vld, (rc - rs) * rowB);
-            const int jo = rc & 1, jcl = rc >> 1;
-            if (jcl != pj) {
-                const int jch = (jcl + 1 < nyc) ? jcl + 1 : nyc - 1;
-                if (jcl == pj + 1) { pc00 = pc01; pc10 = pc11; }
-                else { pc00 = corr_c[(size_t)p_icl + (size_t)nxc * jcl]; pc10 = corr_c[(size_t)p_ich + (size_t)nxc * jcl]; }
-                pc01 = corr_c[(size_t)p_icl + (size_t)nxc * jch];
-                pc11 = corr_c[(size_t)p_ich + (size_t)nxc * jch];
-                pj = jcl;
-            }
-            // same value and accumulation order as prolong_bf
-            const bool in = p_inx && rc >= 1 && rc <= ny - 2;
-            const double wgt = (p_io | jo) ? ((p_io & jo) ? 0.25 : 0.5) : 1.0;
-            const bool sy0 = jcl >= 1 && jcl <= nyc - 2, sy1 = jo && (jcl + 1 <= nyc - 2);
-            double pv = 0.0;
-            pv = pv + ((in && p_sx0 && sy0) ? wgt * pc00 : 0.0);
-            pv = pv + ((in && p_sx1 && sy0) ? wgt * pc10 : 0.0);
-            pv = pv + ((in && p_sx0 && sy1) ? wgt * pc01 : 0.0);
-            pv = pv + ((in && p_sx1 && sy1) ? wgt * pc11 : 0.0);
-            return v - pv;
-        };
-        auto ldf = [&](int r) { const int rc = r > ny - 1 ? ny - 1 : r; return fpr_bld(rF, vld, (rc - rs) * rowB); };
-        // 3-row windows with COMPILE-TIME slots: row j of every field lives in slot (j - rs) mod 3 (f: mod 6), and the row
-        // loop is unrolled by 12 = lcm(3, 4, 6) so that the slot of every operand is a constant: no register moves to
-        // shift fifteen window rows per step (the 2-sweep kernel shifts its windows; here that would be a fifth of the VALU work).
-        // w[0] = corrected input, w[K] = field after sweep K.
-        double w[5][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-        double fw[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        w[0][0] = ldu(rs);
-        fw[0] = ldf(rs);
-        constexpr int PF = 4;
-        double pu[PF], pfv[PF];
-#pragma unroll
-        for (int q = 0; q < PF; ++q) { pu[q] = ldu(rs + 1 + q); pfv[q] = ldf(rs + 1 + q); }
-        const __amdgpu_buffer_rsrc_t rResC = fpr_rsrc(res_c_out), rCorC = fpr_rsrc(corr_c_out);
-        const unsigned vstc = (owner && !(gi & 1)) ? (unsigned)(gi >> 1) * 8u : FPR_OOR;
-        // BCS: Neumann columns of the coarse right-hand side (:355-357), see k_smooth2_march
-        const unsigned vstr = (BCS && (gi == 0 || gi == nx - 1)) ? FPR_OOR : vstc;
-        const unsigned vstn = (BCS && owner && (gi == 2 || gi == nx - 3)) ? (gi == 2 ? 0u : (unsigned)(nxc - 1) * 8u) : FPR_OOR;
-        // one Jacobi sweep at row j of a field whose rows j-1, j, j+1 are (lo, mid, hi); rr = residual used by the update
-        auto sweep = [&](double lo, double mid, double hi, double fv, int j, double& rr) {
-            const double L = fpr_lane_up1z(mid), R = fpr_lane_down1z(mid);
-            rr = ((((R + L) + hi) + lo) - C * mid) * _h2 - fv;
-            const bool bnd = col_bnd || j <= 0 || j >= ny - 1;
-            return bnd ? mid : mid + fac * rr;
-        };
-        auto step = [&](auto Tc, int r) {
-            constexpr int T = decltype(Tc)::value;               // (r - rs) mod 12
-            constexpr int Q = T % 4, M = T % 3, F = T % 6;
-            constexpr int M1 = (M + 1) % 3, M2 = (M + 2) % 3;    // slots of rows r-2 (= r+1) and r-1
-            auto fs = [](int k) { return (F - k + 6) % 6; };     // slot of f row r-k
-            double an, fn;
-            asm volatile("v_mov_b64 %0, %1" : "=v"(an) : "v"(pu[Q]));
-            asm volatile("v_mov_b64 %0, %1" : "=v"(fn) : "v"(pfv[Q]));
-            pu[Q] = ldu(r + 1 + PF);                           // issue the loads of row r+1+PF
-            pfv[Q] = ldf(r + 1 + PF);
-            double rr;
-            // ---- cycle k, post-smoothing (:142-143): sweeps 1 and 2 at rows r-1, r-2 ----
-            w[1][M2] = sweep(w[0][M1], w[0][M2], w[0][M], fw[fs(1)], r - 1, rr);
-            const int j2 = r - 2;
-            double u2 = sweep(w[1][M], w[1][M1], w[1][M2], fw[fs(2)], j2, rr);   // u at the end of cycle k (not stored)
-            if constexpr (BCS) {
-                // apply_boundary_conditions! between the cycles (multigrid.jl:60-62, part2_utils.jl:22-31): its Dirichlet
-                // rows hold their values already (set before the first cycle, never changed by a sweep or a correction);
-                // its Neumann columns copy their inner neighbour of THIS field
-                const double fromR = fpr_lane_down1z(u2), fromL = fpr_lane_up1z(u2);
-                u2 = (gi == 0) ? fromR : ((gi == nx - 1) ? fromL : u2);
-            }
-            w[2][M1] = u2;
-            {
-                const bool bnd = col_bnd || j2 <= 0 || j2 >= ny - 1;
-                const bool row_own = j2 >= y0 && j2 < y1;      // uniform
-                acc += (owner && row_own && !bnd) ? rr * rr : 0.0;  // r_rms of cycle k (:252); branch-free (+0.0 is exact)
-            }
-            // ---- cycle k+1, pre-smoothing (:124-125): sweeps 3 and 4 at rows r-3, r-4 ----
-            w[3][M] = sweep(w[2][M2], w[2][M], w[2][M1], fw[fs(3)], r - 3, rr);
-            const int j4 = r - 4;
-            const double u4 = sweep(w[3][M1], w[3][M2], w[3][M], fw[fs(4)], j4, rr);
-            {
-                const bool row_own = j4 >= y0 && j4 < y1;      // uniform
-                fpr_bst(rUout, vst, row_own ? (j4 - rs) * rowB : (int)FPR_OOR, u4);   // unconditional (see FPR_OOR)
-            }
-            w[4][M2] = u4;
-            // ---- residual of the pre-smoothed field at row r-5, injected at even (row, column) (:128-132) ----
-            {
-                const int j5 = r - 5;
-                const double mid = w[4][M1];
-                const double L = fpr_lane_up1z(mid), R = fpr_lane_down1z(mid);
-                const double rres = ((((R + L) + w[4][M2]) + w[4][M]) - C * mid) * _h2 - fw[fs(5)];
-                const int ic = gi >> 1, jc = j5 >> 1;
-                const bool cint = ic >= 1 && ic <= nxc - 2 && jc >= 1 && jc <= nyc - 2;
-                const bool row_inj = j5 >= y0 && j5 < y1 && !(j5 & 1);   // uniform
-                const int sc = row_inj ? jc * (nxc * 8) : (int)FPR_OOR;
-                fpr_bst(rResC, vstr, sc, cint ? rres : 0.0);
-                if constexpr (BCS) fpr_bst(rResC, vstn, sc, cint ? rres : 0.0);
-                fpr_bst(rCorC, vstc, sc, 0.0);
-            }
-            w[0][M1] = an;             // row r+1 takes the slot of row r-2
-            fw[(F + 1) % 6] = fn;      // row r+1 takes the slot of row r-5
-        };
-        const int rend = y1 + 4;
-        int r = rs;
-        static_assert(PF == 4, "the row loop below is unrolled by 12 = lcm(3 window slots, PF = 4, 6 rows of f)");
-#define FPR_SEAM_STEP(T) step(std::integral_constant<int, T>{}, r + T)
-        for (; r + 11 <= rend; r += 12) {
-            FPR_SEAM_STEP(0); FPR_SEAM_STEP(1); FPR_SEAM_STEP(2); FPR_SEAM_STEP(3); FPR_SEAM_STEP(4); FPR_SEAM_STEP(5);
-            FPR_SEAM_STEP(6); FPR_SEAM_STEP(7); FPR_SEAM_STEP(8); FPR_SEAM_STEP(9); FPR_SEAM_STEP(10); FPR_SEAM_STEP(11);
-        }
-#undef FPR_SEAM_STEP
-#define FPR_SEAM_TAIL(T) if (r <= rend) { step(std::integral_constant<int, T>{}, r); ++r; }
-        FPR_SEAM_TAIL(0) FPR_SEAM_TAIL(1) FPR_SEAM_TAIL(2) FPR_SEAM_TAIL(3) FPR_SEAM_TAIL(4) FPR_SEAM_TAIL(5)
-        FPR_SEAM_TAIL(6) FPR_SEAM_TAIL(7) FPR_SEAM_TAIL(8) FPR_SEAM_TAIL(9) FPR_SEAM_TAIL(10)
-#undef FPR_SEAM_TAIL
-    }
-    const double sblk = fpr_block_sum<256>(acc, red);
-    if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
-}
+#include "mg_march.hpp"   // k_smooth2_march, k_seam_march, k_smooth2_march2: the register-rolling marches of the fine levels
 
 // ---- S fused Jacobi sweeps, register patches (coarse solve on grids too large for one workgroup) ------
 // The coarse-grid Jacobi solve of the "few levels" configurations (e.g. 257^2, 5140 sweeps per V-cycle)
@@ -711,241 +340,6 @@ __global__ __launch_bounds__(256) void k_jacobi_patch(const double* __restrict__
             const int blk = blockIdx.x + gridDim.x * blockIdx.y, nblk = gridDim.x * gridDim.y;
             partials[(size_t)tid * nblk + blk] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
         }
-    }
-}
-
-// ---- k_smooth2_march, two columns per lane (opt-in; measured slower, see vcycle_level) -------------------------------------------------
-// Same algorithm as k_smooth2_march with a strip of 128 columns per wave: a lane holds two adjacent
-// columns, loads/stores them with one 16-byte access (the hardware accepts the 8-byte alignment that
-// (2^k+1)-wide rows impose), needs a shuffle only for the outer neighbour of each pair, and halves the
-// loop and address arithmetic per point.
-struct __attribute__((aligned(8))) FprD2 { double x, y; };
-
-template <bool NORM, bool PROLONG, bool RESTRICT>
-__global__ __launch_bounds__(256) void k_smooth2_march2(const double* __restrict__ uin, const double* __restrict__ f,
-                                                         double* __restrict__ uout, int nx, int ny, double C, double _h2,
-                                                         double fac, int rows_per_chunk, int nstrips,
-                                                         double* __restrict__ partials, const double* __restrict__ corr_c,
-                                                         int apply_BCs, double* __restrict__ res_c_out,
-                                                         double* __restrict__ corr_c_out, const int* __restrict__ skip)
-{
-    if (skip && *skip) return;   // a cycle enqueued ahead of the exit test that ended the loop (FprCycleCtl)
-    __shared__ double red[16];
-    // Feeder COLUMNS: HXL on the left, HXR on the right.  On rows whose start is only 8-byte aligned (odd rows of
-    // an odd-width grid) the lane <-> column mapping is shifted by one column so that every 16-byte access stays
-    // 16-byte aligned; the wave then loses its last column on those rows, hence one more feeder on the right.
-    // All widths are even so that strips start on even columns.
-    constexpr int HX = RESTRICT ? 4 : 2;   // left feeders (3 needed with RESTRICT, rounded up to an even number)
-    constexpr int HXR = RESTRICT ? 4 : 4;  // right feeders: needed (2 or 3) + 1 lost column, rounded up to even
-    constexpr int SW = 128 - HX - HXR;     // columns owned by a strip
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int strip = blockIdx.x * 4 + w;
-    const bool active = strip < nstrips;
-    const int g0 = strip * SW - HX + 2 * lane;   // global column of element 0 (element 1 = g0 + 1)
-    const int y0 = blockIdx.y * rows_per_chunk;
-    const int y1 = (y0 + rows_per_chunk < ny) ? y0 + rows_per_chunk : ny;
-    const int rs = y0 - HX < 0 ? 0 : y0 - HX;
-    double acc = 0.0;
-    if (active) {
-        const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
-        int gi[2], gic[2], gis[2];
-        bool colbnd[2], owner[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            gi[e] = g0 + e;
-            gic[e] = gi[e] < 0 ? 0 : (gi[e] > nx - 1 ? nx - 1 : gi[e]);
-            colbnd[e] = gi[e] <= 0 || gi[e] >= nx - 1;
-            const int q = 2 * lane + e;
-            owner[e] = gi[e] >= 0 && gi[e] < nx && q >= HX && q < 128 - HXR;
-            gis[e] = gic[e];
-            if (PROLONG && apply_BCs) gis[e] = (gic[e] == 0) ? 1 : (gic[e] == nx - 1 ? nx - 2 : gic[e]);
-        }
-        const bool vec_ok = g0 >= 0 && g0 + 1 < nx;   // both columns exist: one 16-byte access (unshifted rows)
-        const bool vec_ok_s = g0 >= 1 && g0 < nx;     // columns g0-1, g0 exist (shifted rows)
-        const bool odd_pitch = (nx & 1) != 0;
-        // element 1 of the previous lane is owned / exists (needed for the shifted store)
-        const bool owner_prev = (2 * lane - 1 >= HX) && (2 * lane - 1 < 128 - HXR) && g0 - 1 >= 0 && g0 - 1 < nx;
-        // PROLONG: per element, the two coarse columns it interpolates from, cached for coarse rows pj, pj+1
-        int p_icl[2], p_ich[2], p_io[2];
-        bool p_sx0[2], p_sx1[2], p_inx[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            p_io[e] = gis[e] & 1;
-            p_icl[e] = gis[e] >> 1;
-            p_ich[e] = (p_icl[e] + 1 < nxc) ? p_icl[e] + 1 : nxc - 1;
-            p_sx0[e] = p_icl[e] >= 1 && p_icl[e] <= nxc - 2;
-            p_sx1[e] = p_io[e] && (p_icl[e] + 1 <= nxc - 2);
-            p_inx[e] = gis[e] >= 1 && gis[e] <= nx - 2;
-        }
-        int pj = -2;
-        double pc00[2] = {0.0, 0.0}, pc10[2] = {0.0, 0.0}, pc01[2] = {0.0, 0.0}, pc11[2] = {0.0, 0.0};
-        auto ld2 = [&](const double* __restrict__ p, int r, double& v0, double& v1) {
-            const int rc = r > ny - 1 ? ny - 1 : r;
-            const size_t row = (size_t)nx * rc;
-            if (odd_pitch && (rc & 1)) {
-                // shifted row: this lane fetches columns (g0-1, g0), 16-byte aligned; element 1 (column g0+1) is the
-                // first element of the next lane's pair
-                double s0, s1;
-                if (vec_ok_s) {
-                    const double2 t = *reinterpret_cast<const double2*>(p + row + (g0 - 1));
-                    s0 = t.x; s1 = t.y;
-                } else {
-                    const int c0 = g0 - 1 < 0 ? 0 : (g0 - 1 > nx - 1 ? nx - 1 : g0 - 1);
-                    s0 = p[row + c0]; s1 = p[row + gic[0]];
-                }
-                v0 = s1;
-                v1 = fpr_lane_down1(s0);
-            } else {
-                if (vec_ok) {
-                    const double2 t = *reinterpret_cast<const double2*>(p + row + g0);
-                    v0 = t.x; v1 = t.y;
-                } else {
-                    v0 = p[row + gic[0]]; v1 = p[row + gic[1]];
-                }
-            }
-        };
-        auto ldu = [&](int r, double& v0, double& v1) {
-            ld2(uin, r, v0, v1);
-            if constexpr (PROLONG) {
-                const int rc = r > ny - 1 ? ny - 1 : r;
-                const int jo = rc & 1, jcl = rc >> 1;
-                if (jcl != pj) {
-                    const int jch = (jcl + 1 < nyc) ? jcl + 1 : nyc - 1;
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        if (jcl == pj + 1) { pc00[e] = pc01[e]; pc10[e] = pc11[e]; }
-                        else { pc00[e] = corr_c[(size_t)p_icl[e] + (size_t)nxc * jcl]; pc10[e] = corr_c[(size_t)p_ich[e] + (size_t)nxc * jcl]; }
-                        pc01[e] = corr_c[(size_t)p_icl[e] + (size_t)nxc * jch];
-                        pc11[e] = corr_c[(size_t)p_ich[e] + (size_t)nxc * jch];
-                    }
-                    pj = jcl;
-                }
-                const bool sy0 = jcl >= 1 && jcl <= nyc - 2, sy1 = jo && (jcl + 1 <= nyc - 2);
-                const bool iny = rc >= 1 && rc <= ny - 2;
-                double pv[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {  // same value and accumulation order as prolong_bf
-                    const bool in = p_inx[e] && iny;
-                    const double wgt = (p_io[e] | jo) ? ((p_io[e] & jo) ? 0.25 : 0.5) : 1.0;
-                    double t = 0.0;
-                    t = t + ((in && p_sx0[e] && sy0) ? wgt * pc00[e] : 0.0);
-                    t = t + ((in && p_sx1[e] && sy0) ? wgt * pc10[e] : 0.0);
-                    t = t + ((in && p_sx0[e] && sy1) ? wgt * pc01[e] : 0.0);
-                    t = t + ((in && p_sx1[e] && sy1) ? wgt * pc11[e] : 0.0);
-                    pv[e] = t;
-                }
-                v0 = v0 - pv[0];
-                v1 = v1 - pv[1];
-            }
-        };
-        double a0[2] = {0, 0}, a1[2] = {0, 0}, a2[2], an[2];   // u  rows r-2, r-1, r, r+1
-        double b0[2] = {0, 0}, b1[2] = {0, 0}, b2[2] = {0, 0}; // u1 rows r-3, r-2, r-1
-        double c0[2] = {0, 0}, c1[2] = {0, 0}, c2[2] = {0, 0}; // u2 rows r-4, r-3, r-2 (RESTRICT)
-        double f0[2] = {0, 0}, f1[2] = {0, 0}, f2[2], fn[2], fm[2] = {0, 0};
-        ldu(rs, a2[0], a2[1]);
-        ld2(f, rs, f2[0], f2[1]);
-        // prefetch ring with compile-time slots (see k_smooth2_march): rows r+1 .. r+PF in flight
-        constexpr int PF = 4;
-        double pu[PF][2], pfv[PF][2];
-#pragma unroll
-        for (int q = 0; q < PF; ++q) { ldu(rs + 1 + q, pu[q][0], pu[q][1]); ld2(f, rs + 1 + q, pfv[q][0], pfv[q][1]); }
-        auto step = [&](auto Qc, int r) {
-            constexpr int Q = decltype(Qc)::value;
-            an[0] = pu[Q][0]; an[1] = pu[Q][1];
-            fn[0] = pfv[Q][0]; fn[1] = pfv[Q][1];
-            ldu(r + 1 + PF, pu[Q][0], pu[Q][1]);
-            ld2(f, r + 1 + PF, pfv[Q][0], pfv[Q][1]);
-            // ---- sweep 1 at row r-1 ----
-            const int j1 = r - 1;
-            double u1[2];
-            {
-                const double Lo = fpr_lane_up1(a1[1]), Ro = fpr_lane_down1(a1[0]);
-                const bool rowb = j1 <= 0 || j1 >= ny - 1;
-                const double rr0 = ((((a1[1] + Lo) + a2[0]) + a0[0]) - C * a1[0]) * _h2 - f1[0];
-                const double rr1 = ((((Ro + a1[0]) + a2[1]) + a0[1]) - C * a1[1]) * _h2 - f1[1];
-                u1[0] = (rowb || colbnd[0]) ? a1[0] : a1[0] + fac * rr0;
-                u1[1] = (rowb || colbnd[1]) ? a1[1] : a1[1] + fac * rr1;
-            }
-#pragma unroll
-            for (int e = 0; e < 2; ++e) { b0[e] = b1[e]; b1[e] = b2[e]; b2[e] = u1[e]; }
-            // ---- sweep 2 at row r-2 ----
-            const int j2 = r - 2;
-            {
-                const double Lo = fpr_lane_up1(b1[1]), Ro = fpr_lane_down1(b1[0]);
-                const bool rowb = j2 <= 0 || j2 >= ny - 1;
-                const double rr0 = ((((b1[1] + Lo) + b2[0]) + b0[0]) - C * b1[0]) * _h2 - f0[0];
-                const double rr1 = ((((Ro + b1[0]) + b2[1]) + b0[1]) - C * b1[1]) * _h2 - f0[1];
-                const bool bn0 = rowb || colbnd[0], bn1 = rowb || colbnd[1];
-                const double u20 = bn0 ? b1[0] : b1[0] + fac * rr0;
-                const double u21 = bn1 ? b1[1] : b1[1] + fac * rr1;
-                const bool shifted_row = odd_pitch && (j2 & 1) && j2 >= 0;
-                const double prev21 = fpr_lane_up1(u21);  // column g0-1 (element 1 of the previous lane)
-                if (j2 >= y0 && j2 < y1) {
-                    const size_t o = (size_t)nx * j2;
-                    if (shifted_row) {
-                        if (owner_prev && owner[0]) {
-                            *reinterpret_cast<double2*>(uout + o + (g0 - 1)) = make_double2(prev21, u20);
-                        } else {
-                            if (owner_prev) uout[o + g0 - 1] = prev21;
-                            if (owner[0]) uout[o + gi[0]] = u20;
-                        }
-                        // (this lane's element 1, column g0+1, is stored by the next lane as its `prev21`)
-                    } else if (owner[0] && owner[1]) {
-                        *reinterpret_cast<double2*>(uout + o + g0) = make_double2(u20, u21);
-                    } else {
-                        if (owner[0]) uout[o + gi[0]] = u20;
-                        if (owner[1]) uout[o + gi[1]] = u21;
-                    }
-                    if constexpr (NORM) {
-                        if (owner[0] && !bn0) acc += rr0 * rr0;
-                        if (owner[1] && !bn1) acc += rr1 * rr1;
-                    }
-                }
-                if constexpr (RESTRICT) {
-                    c0[0] = c1[0]; c1[0] = c2[0]; c2[0] = u20;
-                    c0[1] = c1[1]; c1[1] = c2[1]; c2[1] = u21;
-                }
-            }
-            if constexpr (RESTRICT) {
-                // ---- residual of u2 at row r-3, injected at even (row, column): one of the lane's two columns ----
-                const int j3 = r - 3;
-                const double Lo = fpr_lane_up1(c1[1]), Ro = fpr_lane_down1(c1[0]);
-                const double rr0 = ((((c1[1] + Lo) + c2[0]) + c0[0]) - C * c1[0]) * _h2 - fm[0];
-                const double rr1 = ((((Ro + c1[0]) + c2[1]) + c0[1]) - C * c1[1]) * _h2 - fm[1];
-                if (j3 >= y0 && j3 < y1 && !(j3 & 1)) {
-                    const int e = (gi[0] & 1) ? 1 : 0;  // the even column
-                    const double rr = e ? rr1 : rr0;
-                    if (e ? owner[1] : owner[0]) {
-                        const int ic = (e ? gi[1] : gi[0]) >> 1, jc = j3 >> 1;
-                        const bool cint = ic >= 1 && ic <= nxc - 2 && jc >= 1 && jc <= nyc - 2;
-                        const size_t cid = (size_t)ic + (size_t)nxc * jc;
-                        res_c_out[cid] = cint ? rr : 0.0;
-                        corr_c_out[cid] = 0.0;
-                    }
-                }
-                fm[0] = f0[0]; fm[1] = f0[1];
-            }
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                a0[e] = a1[e]; a1[e] = a2[e]; a2[e] = an[e];
-                f0[e] = f1[e]; f1[e] = f2[e]; f2[e] = fn[e];
-            }
-        };
-        const int rend = y1 + (RESTRICT ? 2 : 1);
-        int r = rs;
-        for (; r + PF - 1 <= rend; r += PF) {
-            step(std::integral_constant<int, 0>{}, r);
-            step(std::integral_constant<int, 1>{}, r + 1);
-            step(std::integral_constant<int, 2>{}, r + 2);
-            step(std::integral_constant<int, 3>{}, r + 3);
-        }
-        if (r <= rend) { step(std::integral_constant<int, 0>{}, r); ++r; }
-        if (r <= rend) { step(std::integral_constant<int, 1>{}, r); ++r; }
-        if (r <= rend) { step(std::integral_constant<int, 2>{}, r); ++r; }
-    }
-    if constexpr (NORM) {
-        const double sblk = fpr_block_sum<256>(acc, red);
-        if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
     }
 }
 
@@ -1129,600 +523,9 @@ __global__ __launch_bounds__(256) void k_jacobi_check_multi(FprSolveState* st, c
     }
 }
 
-// ---- CG kernels (krylov.jl:55-91) -------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cg_init(const double* __restrict__ b, double* __restrict__ r, double* __restrict__ p,
-                                                  double* __restrict__ ph, double* __restrict__ x, size_t n)
-{
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const double v = b[i];
-        r[i] = v; p[i] = v; ph[i] = v; x[i] = 0.0;
-    }
-}
+#include "mg_cg.hpp"      // cg! in five, three and two launches per iteration
 
-// p_hat = A p on the interior (boundary of p_hat keeps b's values), partial sums of p .* p_hat over
-// the WHOLE array (krylov.jl:68-69)
-__global__ __launch_bounds__(256) void k_cg_matvec_dot(const double* __restrict__ p, double* __restrict__ ph, int nx, int ny,
-                                                        double hx2, double hy2, double c, double* __restrict__ partials,
-                                                        const FprSolveState* __restrict__ st)
-{
-    __shared__ double red[16];
-    if (st->done) return;
-    const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
-    double acc = 0.0;
-    if (i < nx && j < ny) {
-        const size_t id = (size_t)i + (size_t)nx * j;
-        double q;
-        if (i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1) {
-            q = lap_at(p, id, nx, hx2, hy2, c);
-            ph[id] = q;
-        } else {
-            q = ph[id];
-        }
-        acc = p[id] * q;
-    }
-    const double s = fpr_block_sum<256>(acc, red);
-    if (threadIdx.x == 0 && threadIdx.y == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = s;
-}
-
-__global__ __launch_bounds__(256) void k_cg_alpha(FprSolveState* st, const double* __restrict__ partials, int nparts)
-{
-    __shared__ double red[16];
-    if (st->done) return;
-    const double s = fpr_sum_partials_256(partials, nparts, red);
-    if (threadIdx.x == 0) {
-        st->pq = s;
-        st->alpha = st->rho / s;  // krylov.jl:69
-    }
-}
-
-// x .+= alpha p ; r .-= alpha p_hat ; partial sums of r.^2   (krylov.jl:70-72)
-__global__ __launch_bounds__(256) void k_cg_update(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
-                                                    const double* __restrict__ ph, size_t n, double* __restrict__ partials,
-                                                    const FprSolveState* __restrict__ st)
-{
-    __shared__ double red[16];
-    if (st->done) return;
-    const double alpha = st->alpha;
-    const size_t stride = (size_t)gridDim.x * 256;
-    double acc = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        x[i] = x[i] + alpha * p[i];
-        const double rn = r[i] - alpha * ph[i];
-        r[i] = rn;
-        acc += rn * rn;
-    }
-    const double s = fpr_block_sum<256>(acc, red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = s;
-}
-
-__global__ __launch_bounds__(256) void k_cg_check(FprSolveState* st, const double* __restrict__ partials, int nparts, double N)
-{
-    __shared__ double red[16];
-    if (st->done) return;
-    const double s = fpr_sum_partials_256(partials, nparts, red);
-    if (threadIdx.x == 0) {
-        const double normr = sqrt(s);
-        st->iters += 1;
-        st->last_rms = sqrt(s / N);  // krylov.jl:90
-        if (normr < st->thresh) {
-            st->done = 1;  // krylov.jl:76-81
-        } else {
-            st->rho_old = st->rho;
-            st->rho = s;                      // krylov.jl:83
-            st->beta = st->rho / st->rho_old; // krylov.jl:84
-        }
-    }
-}
-
-// ---- fused CG iteration: 3 dependent launches instead of 5 ---------------------------------------------
-// k_cg_matvec_dot -> k_cg_update_f (every workgroup derives alpha from the dot partials) ->
-// k_cg_p_f (every workgroup derives ||r||, the exit test and beta from the r.r partials).
-// rho is double-buffered by iteration parity so that workgroup 0 can publish the new value while the
-// others still read the old one.  `it` = 0-based iteration index.
-__global__ __launch_bounds__(256) void k_cg_update_f(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
-                                                      const double* __restrict__ ph, size_t n, const double* __restrict__ pq_partials,
-                                                      int npq, double* __restrict__ partials, FprSolveState* __restrict__ st, int it)
-{
-    __shared__ double red[16];
-    __shared__ double s_alpha;
-    if (st->done) return;
-    // first element of this thread's grid-stride sequence: loaded before alpha is known (the loads overlap the reduction
-    // of the dot-product partials; coarse grids have at most one element per thread)
-    const size_t stride = (size_t)gridDim.x * 256;
-    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
-    double x0 = 0.0, p0 = 0.0, r0 = 0.0, q0 = 0.0;
-    if (i0 < n) { x0 = x[i0]; p0 = p[i0]; r0 = r[i0]; q0 = ph[i0]; }
-    const double pq = fpr_sum_partials_256(pq_partials, npq, red);
-    if (threadIdx.x == 0) {
-        const double alpha = st->rho2[it & 1] / pq;  // krylov.jl:69
-        s_alpha = alpha;
-        if (blockIdx.x == 0) { st->pq = pq; st->alpha = alpha; }
-    }
-    __syncthreads();
-    const double alpha = s_alpha;
-    double acc = 0.0;
-    if (i0 < n) {
-        x[i0] = x0 + alpha * p0;
-        const double rn = r0 - alpha * q0;
-        r[i0] = rn;
-        acc += rn * rn;
-    }
-    for (size_t i = i0 + stride; i < n; i += stride) {
-        x[i] = x[i] + alpha * p[i];
-        const double rn = r[i] - alpha * ph[i];
-        r[i] = rn;
-        acc += rn * rn;
-    }
-    __syncthreads();
-    const double sblk = fpr_block_sum<256>(acc, red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = sblk;
-}
-
-__global__ __launch_bounds__(256) void k_cg_p_f(double* __restrict__ p, const double* __restrict__ r, size_t n,
-                                                 const double* __restrict__ rr_partials, int nrr, FprSolveState* __restrict__ st,
-                                                 int it, double N)
-{
-    __shared__ double red[16];
-    __shared__ double s_beta;
-    __shared__ int s_conv;
-    if (st->done) return;
-    const double rr = fpr_sum_partials_256(rr_partials, nrr, red);
-    if (threadIdx.x == 0) {
-        const double normr = sqrt(rr);
-        const int conv = normr < st->thresh;          // krylov.jl:76
-        const double rho_old = st->rho2[it & 1];
-        const double beta = rr / rho_old;             // krylov.jl:83-84
-        s_conv = conv;
-        s_beta = beta;
-        if (blockIdx.x == 0) {
-            st->iters = it + 1;
-            st->last_rms = sqrt(rr / N);              // krylov.jl:90
-            if (conv) st->done = 1;
-            else { st->rho2[(it + 1) & 1] = rr; st->rho_old = rho_old; st->rho = rr; st->beta = beta; }
-        }
-    }
-    __syncthreads();
-    if (s_conv) return;
-    const double beta = s_beta;
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = r[i] + beta * p[i];  // krylov.jl:85
-}
-
-// ---- CG iteration in TWO dependent launches ---------------------------------------------------------------
-// k_cg_pmv_f (this kernel) -> k_cg_update_f.  The direction update p = r + beta p of iteration it-1 (krylov.jl:85)
-// moves into the matvec of iteration it: every workgroup derives ||r||, the exit test and beta from the r.r partials
-// of the previous iteration (as k_cg_p_f does), forms the new p on its 32 x 8 tile plus a one-point ring (the ring is
-// recomputed, not communicated: p is double-buffered, nobody reads what a neighbour is writing), stores the tile,
-// applies the operator from the LDS image and reduces p .* p_hat.  Same operations on the same operands as the
-// three-launch form: x, r, p, the iteration count and the returned residual are bit-identical.
-constexpr int CGX = BX, CGY = BY;   // the tiles of k_cg_matvec_dot: identical dot-product partials, identical alpha
-__global__ __launch_bounds__(256) void k_cg_pmv_f(const double* __restrict__ p_old, double* __restrict__ p_new,
-                                                   const double* __restrict__ r, double* __restrict__ ph, int nx, int ny,
-                                                   double hx2, double hy2, double c, double* __restrict__ pq_partials,
-                                                   const double* __restrict__ rr_partials, int nrr,
-                                                   FprSolveState* __restrict__ st, int it, double N)
-{
-    __shared__ double red[16];
-    __shared__ double s_beta;
-    __shared__ int s_conv;
-    __shared__ double tile[CGY + 2][CGX + 2];
-    if (st->done) return;
-    const int tid = threadIdx.x + CGX * threadIdx.y;
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int i0 = blockIdx.x * CGX, j0 = blockIdx.y * CGY;
-    // operands first: their loads do not depend on beta and overlap the reduction of the r.r partials below
-    const int i = i0 + tx, j = j0 + ty;
-    const bool own = i < nx && j < ny;
-    const size_t id = (size_t)(own ? i : 0) + (size_t)nx * (own ? j : 0);
-    const double p_own = p_old[id], r_own = it > 0 ? r[id] : 0.0;
-    constexpr int NRING = 2 * (CGX + 2) + 2 * CGY;   // bottom row, top row, left column, right column
-    int hx = 0, hy = 0;
-    if (tid < CGX + 2) { hx = tid; hy = 0; }
-    else if (tid < 2 * (CGX + 2)) { hx = tid - (CGX + 2); hy = CGY + 1; }
-    else if (tid < 2 * (CGX + 2) + CGY) { hx = 0; hy = tid - 2 * (CGX + 2) + 1; }
-    else if (tid < NRING) { hx = CGX + 1; hy = tid - 2 * (CGX + 2) - CGY + 1; }
-    const int ri = i0 + hx - 1, rj = j0 + hy - 1;
-    const bool ring = tid < NRING && ri >= 0 && rj >= 0 && ri < nx && rj < ny;
-    const size_t rid = (size_t)(ring ? ri : 0) + (size_t)nx * (ring ? rj : 0);
-    const double p_ring = p_old[rid], r_ring = it > 0 ? r[rid] : 0.0;
-    double beta = 0.0;
-    if (it > 0) {   // exit test and beta of iteration it-1 (krylov.jl:73-84)
-        double sacc = 0.0;   // fpr_sum_partials_256 for a 64 x 4 block: strided accumulation by linear thread id
-        for (int q = tid; q < nrr; q += 256) sacc += rr_partials[q];
-        const double rr = fpr_block_sum<256>(sacc, red);
-        if (tid == 0) {
-            const double normr = sqrt(rr);
-            const int conv = normr < st->thresh;              // krylov.jl:76
-            const double rho_old = st->rho2[(it - 1) & 1];
-            const double b = rr / rho_old;                    // krylov.jl:83-84
-            s_conv = conv;
-            s_beta = b;
-            if (blockIdx.x == 0 && blockIdx.y == 0) {
-                st->iters = it;
-                st->last_rms = sqrt(rr / N);                  // krylov.jl:90
-                if (conv) st->done = 1;
-                else { st->rho2[it & 1] = rr; st->rho_old = rho_old; st->rho = rr; st->beta = b; }
-            }
-        }
-        __syncthreads();
-        if (s_conv) return;
-        beta = s_beta;
-    }
-    // krylov.jl:85 (p = r = b before the first iteration)
-    tile[ty + 1][tx + 1] = own ? (it > 0 ? r_own + beta * p_own : p_own) : 0.0;
-    if (tid < NRING) tile[hy][hx] = ring ? (it > 0 ? r_ring + beta * p_ring : p_ring) : 0.0;
-    __syncthreads();
-    double acc = 0.0;
-    if (own) {
-        const double t = tile[ty + 1][tx + 1];
-        p_new[id] = t;
-        double q;
-        if (i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1) {
-            q = (((tile[ty + 1][tx + 2] - 2 * t) + tile[ty + 1][tx]) / hx2 + ((tile[ty + 2][tx + 1] - 2 * t) + tile[ty][tx + 1]) / hy2) - c * t;   // lap_at
-            ph[id] = q;
-        } else {
-            q = ph[id];   // boundary of p_hat keeps b's values (krylov.jl:61, 68)
-        }
-        acc = t * q;
-    }
-    const double sblk = fpr_block_sum<256>(acc, red);
-    if (tid == 0) pq_partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
-}
-
-// exit test of the LAST enqueued iteration (its successor's k_cg_pmv_f would have made it): one workgroup
-__global__ __launch_bounds__(256) void k_cg_tail_f(const double* __restrict__ rr_partials, int nrr, FprSolveState* __restrict__ st,
-                                                    int it, double N)
-{
-    __shared__ double red[16];
-    if (st->done) return;
-    const double rr = fpr_sum_partials_256(rr_partials, nrr, red);
-    if (threadIdx.x == 0) {
-        const double normr = sqrt(rr);
-        const double rho_old = st->rho2[(it - 1) & 1];
-        st->iters = it;
-        st->last_rms = sqrt(rr / N);
-        if (normr < st->thresh) st->done = 1;
-        else { st->rho2[it & 1] = rr; st->rho_old = rho_old; st->rho = rr; st->beta = rr / rho_old; }
-    }
-}
-
-// p .= r + beta p  (krylov.jl:85)
-__global__ __launch_bounds__(256) void k_cg_p(double* __restrict__ p, const double* __restrict__ r, size_t n,
-                                               const FprSolveState* __restrict__ st)
-{
-    if (st->done) return;
-    const double beta = st->beta;
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = r[i] + beta * p[i];
-}
-
-// ================================================================================================
-// k_mg_small: a whole sub-hierarchy of the V-cycle in ONE workgroup, resident in LDS.
-//
-// Coarse multigrid levels are launch-latency bound (a 65^2 level costs ~8 dependent launches of ~2 us
-// each for ~0.1 us of work, and the 5x5 Jacobi solve another ~130).  Once a level and everything below
-// it fit in the CU's 160 KiB LDS (3 arrays per level: u, rhs, ping-pong partner; sum over levels
-// <= 20 000 doubles, i.e. up to 65x65 or 129x33), one 1024-thread workgroup executes
-// Vcycle_2DPoisson! (multigrid.jl:91-170) for that level and all coarser ones with __syncthreads()
-// between the passes: pre-smoothing, residual+injection, the Jacobi coarse solve with its early exit
-// (:147-159), prolongation+correction, post-smoothing.  Same pointwise arithmetic as the per-level
-// kernels (bit-identical fields); norms are block-tree sums.
-// ================================================================================================
-struct MgSmallArgs {
-    double* u;          // top level of the sub-hierarchy, global memory, in/out
-    const double* rhs;  // its right-hand side
-    int nx, ny, nlev;   // nlev = levels including the coarsest one
-    double h, c, tol;
-    int css, apply_BCs, want_norm;
-    double* out_sumsq;  // want_norm: sum(res.^2) of the last post-smoothing sweep of the top level
-    FprSolveState* state;
-    const int* skip;    // cycles enqueued ahead: return at once if *skip (null = unconditional)
-    int row_solve;      // 1: coarsest grids with <= 16 interior points are solved inside one DPP row (option mg_small_row)
-    long long* prof;    // diagnostic (option mg_small_prof): wall_clock64 stamps (100 MHz) of thread 0 at the section borders
-};
-
-constexpr int MGS_NT = 1024;
-constexpr int MGS_RED = 32;  // doubles reserved for reductions / broadcasts
-
-__device__ __forceinline__ double mgs_block_sum(double v, double* red)
-{
-    // all MGS_NT threads call; returns the total in every thread
-    v = fpr_wave_sum(v);
-    const int tid = threadIdx.x;
-    __syncthreads();  // protect red[] from the previous use
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    if (tid == 0) {
-        double s = red[0];
-#pragma unroll
-        for (int w = 1; w < MGS_NT / 64; ++w) s += red[w];
-        red[MGS_NT / 64] = s;
-    }
-    __syncthreads();
-    return red[MGS_NT / 64];
-}
-
-// shifts inside a 16-lane DPP row (zero where no lane is the source); n is uniform, 1..15
-template <int CTRL>
-__device__ __forceinline__ double mgs_dpp(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-template <int N> __device__ __forceinline__ double mgs_row_ror(double v) { return mgs_dpp<0x120 + N>(v); }
-// idx -> row j = idx / nx without an integer division: floor((idx + 0.5) * (1/nx)) in float is exact while
-// nx*ny*2.4e-7 < 0.5 (the rounding error of the product stays below the distance 0.5/nx of (idx + 0.5)/nx from an
-// integer); the LDS arena holds 20000 doubles, so N < 2^15 here.
-__device__ __forceinline__ int mgs_row(int idx, float rnx) { return (int)(((float)idx + 0.5f) * rnx); }
-
-// uout = uin + fac*res(uin) on the interior, boundary copied; returns this thread's sum of res^2
-__device__ __forceinline__ double mgs_sweep(const double* uin, const double* f, double* uout, int nx, int ny, double C,
-                                            double _h2, double fac)
-{
-    double acc = 0.0;
-    const int N = nx * ny;
-    const float rnx = 1.0f / (float)nx;
-    for (int idx = threadIdx.x; idx < N; idx += MGS_NT) {
-        const int j = mgs_row(idx, rnx), i = idx - j * nx;
-        const double uc = uin[idx];
-        if (i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1) {
-            const double r = ((((uin[idx + 1] + uin[idx - 1]) + uin[idx + nx]) + uin[idx - nx]) - C * uc) * _h2 - f[idx];
-            uout[idx] = uc + fac * r;
-            acc += r * r;
-        } else {
-            uout[idx] = uc;
-        }
-    }
-    return acc;
-}
-
-__global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    if (a.skip && *a.skip) return;
-    double* red = sm;
-    double* arena = sm + MGS_RED;
-    const int tid = threadIdx.x;
-    int pslot = 0;
-    auto stamp = [&]() { if (a.prof && tid == 0) a.prof[pslot++] = wall_clock64(); };
-    stamp();   // 0: start
-
-    // level d: dims ((nx-1)>>d)+1, arrays u|f|t at arena + off(d)
-    auto lnx = [&](int d) { return ((a.nx - 1) >> d) + 1; };
-    auto lny = [&](int d) { return ((a.ny - 1) >> d) + 1; };
-    auto off = [&](int d) {
-        int o = 0;
-        for (int e = 0; e < d; ++e) o += 3 * lnx(e) * lny(e);
-        return o;
-    };
-    auto hlev = [&](int d) {
-        double h = a.h;
-        for (int e = 0; e < d; ++e) h = h * 2;  // the recursion passes h*2 (multigrid.jl:133)
-        return h;
-    };
-
-    {   // load the top level
-        const int N = a.nx * a.ny;
-        double* U = arena;
-        double* F = arena + N;
-        for (int idx = tid; idx < N; idx += MGS_NT) {
-            U[idx] = a.u[idx];
-            F[idx] = a.rhs[idx];
-        }
-    }
-    __syncthreads();
-    stamp();   // 1: top level loaded
-
-    const int c_lev = a.nlev - 1;
-    // ---- down sweep ----
-    for (int d = 0; d < c_lev; ++d) {
-        const int nx = lnx(d), ny = lny(d), N = nx * ny;
-        double* U = arena + off(d);
-        double* F = U + N;
-        double* T = F + N;
-        const double h = hlev(d);
-        const double C = 4.0 + a.c * (h * h), _h2 = 1 / (h * h);
-        const double fac = (4.0 / 5.0) * ((h * h) / (4.0 + a.c * (h * h)));
-        mgs_sweep(U, F, T, nx, ny, C, _h2, fac);  // :124
-        __syncthreads();
-        mgs_sweep(T, F, U, nx, ny, C, _h2, fac);  // :125
-        __syncthreads();
-        // residual + injection + Neumann rows into the next level's rhs; next level's u = 0 (:128-132)
-        const int nxc = lnx(d + 1), nyc = lny(d + 1), Nc = nxc * nyc;
-        double* Uc = arena + off(d + 1);
-        double* Fc = Uc + Nc;
-        const float rnxc = 1.0f / (float)nxc;
-        for (int idx = tid; idx < Nc; idx += MGS_NT) {
-            const int jc = mgs_row(idx, rnxc), ic = idx - jc * nxc;
-            int is = ic;
-            if (a.apply_BCs) is = (ic == 0) ? 1 : (ic == nxc - 1 ? nxc - 2 : ic);
-            double v = 0.0;
-            if (is >= 1 && is <= nxc - 2 && jc >= 1 && jc <= nyc - 2) {
-                const int id = 2 * is + nx * (2 * jc);
-                v = ((((U[id + 1] + U[id - 1]) + U[id + nx]) + U[id - nx]) - C * U[id]) * _h2 - F[id];
-            }
-            Fc[idx] = v;
-            Uc[idx] = 0.0;
-        }
-        __syncthreads();
-        stamp();   // 2 .. 1+c_lev: level d went down
-    }
-
-    // ---- coarsest level: Jacobi with early exit (:147-159) ----
-    double* ucur;  // where the coarse solution ends up
-    {
-        const int nx = lnx(c_lev), ny = lny(c_lev), N = nx * ny;
-        double* U = arena + off(c_lev);
-        double* F = U + N;
-        double* T = F + N;
-        const double h = hlev(c_lev);
-        const double C = 4.0 + a.c * (h * h), _h2 = 1 / (h * h);
-        const double fac = (4.0 / 5.0) * ((h * h) / (4.0 + a.c * (h * h)));
-        double acc = 0.0;
-        for (int idx = tid; idx < N; idx += MGS_NT) acc += F[idx] * F[idx];
-        const double tol_rhs = a.tol * sqrt(mgs_block_sum(acc, red) / (double)N);  // :150
-        const int iters = 20 * a.css;
-        double res_rms = 0.0;
-        int it = 0;
-        double* pin = U;
-        double* pout = T;
-        const int nxi = nx - 2, nyi = ny - 2, ni = nxi * nyi;
-        if (N <= 64 && ni >= 1 && ni <= 16 && a.row_solve) {
-            // coarsest grid with at most 16 INTERIOR points (5x5 -> 3x3, the default coarse_solve_size): the interior lives in
-            // the first lanes of wave 0, one point per lane (lane = (i-1) + nxi*(j-1)), all of it inside one 16-lane DPP row:
-            // neighbours by row shifts (a boundary neighbour is a per-lane constant), the norm by four rotate-and-add steps
-            // (lane 0's order of summation; uniform through readfirstlane).  sqrt and the division of :157 are only evaluated
-            // when the exit test can possibly hold: sum > N * tol_rhs^2 * (1 + 1e-10) implies sqrt(sum/N) > tol_rhs.
-            if (tid < 64) {
-                const int lane = tid;
-                const bool in = lane < ni;
-                const int jj = in ? lane / nxi : 0, ii = in ? lane - jj * nxi : 0;   // interior coordinates, once
-                const int g = (ii + 1) + nx * (jj + 1);
-                const double fv = in ? F[g] : 0.0;
-                double uu = in ? U[g] : 0.0;
-                // boundary neighbours are constants (Dirichlet copy); interior ones come from the row shifts
-                const bool iE = in && ii + 1 < nxi, iW = in && ii > 0, iN = in && jj + 1 < nyi, iS = in && jj > 0;
-                const double cE = (in && !iE) ? U[g + 1] : 0.0, cW = (in && !iW) ? U[g - 1] : 0.0;
-                const double cN = (in && !iN) ? U[g + nx] : 0.0, cS = (in && !iS) ? U[g - nx] : 0.0;
-                const double hi_thr = ((double)N * (tol_rhs * tol_rhs)) * (1.0 + 1e-10);
-                double sq_last = 0.0;
-                bool have_rms = false;
-                // the DPP control is an immediate: the loop is instantiated per interior width (dispatch ONCE, outside it)
-                auto run = [&](auto NXIc) {
-                    constexpr int NXI = decltype(NXIc)::value;
-                    // The exit test of sweep k is evaluated while sweep k+1 is already in flight (its update is dropped if the
-                    // test holds): the dependent chain of a sweep is then its stencil alone, not stencil + reduction + test.
-                    double sq_vec = 0.0;     // per-lane total of sweep k-1 (every lane of row 0 holds a full sum)
-                    bool done = false;
-                    auto test = [&](int ksweep) {   // :157-158 for sweep `ksweep`, whose sum sits in sq_vec
-                        const double sq = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(sq_vec)),
-                                                           __builtin_amdgcn_readfirstlane(__double2loint(sq_vec)));
-                        it = ksweep;
-                        sq_last = sq;
-                        have_rms = false;
-                        if (sq > hi_thr) return false;      // cannot have converged
-                        res_rms = sqrt(sq / (double)N);     // :157
-                        have_rms = true;
-                        return res_rms < tol_rhs;
-                    };
-                    for (int k = 1; k <= iters; ++k) {
-                        const double sE = mgs_dpp<0x101>(uu), sW = mgs_dpp<0x111>(uu);                 // lanes i+1, i-1
-                        const double sN = mgs_dpp<0x100 + NXI>(uu), sS = mgs_dpp<0x110 + NXI>(uu);     // lanes i+nxi, i-nxi
-                        const double E = iE ? sE : cE, W = iW ? sW : cW, Nn = iN ? sN : cN, Ss = iS ? sS : cS;
-                        const double r = ((((E + W) + Nn) + Ss) - C * uu) * _h2 - fv;
-                        const double uu_new = in ? uu + fac * r : uu;
-                        double sq = in ? r * r : 0.0;
-                        sq += mgs_row_ror<8>(sq);
-                        sq += mgs_row_ror<4>(sq);
-                        sq += mgs_row_ror<2>(sq);
-                        sq += mgs_row_ror<1>(sq);
-                        if (k > 1 && test(k - 1)) { done = true; break; }   // uu is still the field after sweep k-1
-                        uu = uu_new;
-                        sq_vec = sq;
-                    }
-                    if (!done) test(iters);
-                };
-#define FPR_ROW_CASE(n) case n: run(std::integral_constant<int, n>{}); break;
-                switch (nxi) {
-                    FPR_ROW_CASE(1) FPR_ROW_CASE(2) FPR_ROW_CASE(3) FPR_ROW_CASE(4) FPR_ROW_CASE(5) FPR_ROW_CASE(6) FPR_ROW_CASE(7)
-                    FPR_ROW_CASE(8) FPR_ROW_CASE(9) FPR_ROW_CASE(10) FPR_ROW_CASE(11) FPR_ROW_CASE(12) FPR_ROW_CASE(13)
-                    FPR_ROW_CASE(14) FPR_ROW_CASE(15)
-                default: run(std::integral_constant<int, 15>{}); break;   // nxi = 16: one row of points, iN = iS = false everywhere
-                }
-#undef FPR_ROW_CASE
-                if (!have_rms) res_rms = sqrt(sq_last / (double)N);
-                if (in) U[g] = uu;
-                if (tid == 0) { red[MGS_RED - 1] = res_rms; red[MGS_RED - 2] = (double)it; }
-            }
-            __syncthreads();
-            res_rms = red[MGS_RED - 1];
-            it = (int)red[MGS_RED - 2];
-        } else
-        if (N <= 64) {
-            // tiny coarsest grid (5x5, 9x5, ...): one point per lane of wave 0, all in registers --
-            // neighbours by wavefront shuffles, norm by a butterfly (every lane gets the same bits), no barrier
-            if (tid < 64) {
-                const int lane = tid;
-                const bool in = lane < N;
-                const int j = lane / nx, i = lane - j * nx;
-                const bool inter = in && i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1;
-                double uu = in ? U[lane] : 0.0;
-                const double fv = in ? F[lane] : 0.0;
-                for (int k = 1; k <= iters; ++k) {
-                    const double E = __shfl(uu, lane + 1, 64), W = __shfl(uu, lane - 1, 64);
-                    const double Nn = __shfl(uu, lane + nx, 64), Ss = __shfl(uu, lane - nx, 64);
-                    const double r = ((((E + W) + Nn) + Ss) - C * uu) * _h2 - fv;
-                    double sq = inter ? r * r : 0.0;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-                    res_rms = sqrt(sq / (double)N);
-                    if (inter) uu = uu + fac * r;
-                    it = k;
-                    if (res_rms < tol_rhs) break;
-                }
-                if (in) U[lane] = uu;
-                if (tid == 0) { red[MGS_RED - 1] = res_rms; red[MGS_RED - 2] = (double)it; }
-            }
-            __syncthreads();
-            res_rms = red[MGS_RED - 1];
-            it = (int)red[MGS_RED - 2];
-        } else
-        for (int i = 1; i <= iters; ++i) {
-            const double s = mgs_block_sum(mgs_sweep(pin, F, pout, nx, ny, C, _h2, fac), red);  // syncs inside
-            res_rms = sqrt(s / (double)N);
-            double* t = pin; pin = pout; pout = t;
-            it = i;
-            if (res_rms < tol_rhs) break;  // uniform: every thread holds the same value
-        }
-        ucur = pin;
-        if (tid == 0) {
-            a.state->acc_iters += it;
-            a.state->last_rms = res_rms;
-        }
-        __syncthreads();
-        stamp();   // coarsest level solved
-    }
-
-    // ---- up sweep ----
-    for (int d = c_lev - 1; d >= 0; --d) {
-        const int nx = lnx(d), ny = lny(d), N = nx * ny;
-        double* U = arena + off(d);
-        double* F = U + N;
-        double* T = F + N;
-        const double h = hlev(d);
-        const double C = 4.0 + a.c * (h * h), _h2 = 1 / (h * h);
-        const double fac = (4.0 / 5.0) * ((h * h) / (4.0 + a.c * (h * h)));
-        const int nxc = lnx(d + 1);
-        const double* Uc = (d + 1 == c_lev) ? ucur : arena + off(d + 1);
-        const float rnx = 1.0f / (float)nx;
-        for (int idx = tid; idx < N; idx += MGS_NT) {  // prolongation + correction (:136-139)
-            const int j = mgs_row(idx, rnx), i = idx - j * nx;
-            int is = i;
-            if (a.apply_BCs) is = (i == 0) ? 1 : (i == nx - 1 ? nx - 2 : i);
-            U[idx] = U[idx] - prolong_bf(Uc, is, j, nx, ny, nxc, lny(d + 1));   // branch-free form of prolong_at: same value
-        }
-        __syncthreads();
-        mgs_sweep(U, F, T, nx, ny, C, _h2, fac);  // :142
-        __syncthreads();
-        const double acc = mgs_sweep(T, F, U, nx, ny, C, _h2, fac);  // :143
-        if (d == 0 && a.want_norm) {
-            const double s = mgs_block_sum(acc, red);
-            if (tid == 0) a.out_sumsq[0] = s;
-        }
-        __syncthreads();
-        stamp();   // level d came up
-    }
-
-    {   // store the top level's solution
-        const int N = a.nx * a.ny;
-        const double* U = (c_lev == 0) ? ucur : arena;
-        for (int idx = tid; idx < N; idx += MGS_NT) a.u[idx] = U[idx];
-    }
-    stamp();   // stored
-}
+#include "mg_small.hpp"   // k_mg_small: the LDS-resident sub-hierarchy
 
 // ================================================================================================
 // host side
@@ -1893,274 +696,9 @@ static int cg_work(fpr_ctx* ctx, size_t n, CgWork* w)
     return FPR_OK;
 }
 
+#include "mg_cg_persistent.hpp"   // k_cg_persistent: cg! as one launch
+
 // runs cg! on the compute stream; leaves iters / last_rms in ctx->state_h (synchronises)
-// ---- cg! as ONE launch: a persistent 16-workgroup kernel with two grid barriers per iteration -----------------------------
-// The two-launch form spends ~5 us per launch boundary, 10 us per iteration, on a 257^2 problem whose arithmetic takes
-// well under 1 us.  tools/gridsync_probe.hip: a dependent launch costs 2.8 us (4.5 under rocprofv3), cooperative_groups'
-// grid.sync() 2.9 us for 16 workgroups and 32 us for 256 -- but a hand-written counter barrier between 16 workgroups costs
-// 1.1 us.  So: 4 x 4 workgroups of 1024 threads, every vector of the iteration (x, r, p, p_hat) in REGISTERS (<= 5 points per
-// thread), the direction p of the tile plus a one-point ring in LDS for the operator; the only data that travel between
-// workgroups are the tile-edge values of r (through the r array, coherent accesses) and one partial sum per workgroup and
-// dot product.  The ring of p is recomputed from the neighbour's r and the ring's own previous p (same operations as the
-// owner), so two barriers per iteration suffice: after the p.p_hat partials and after the r.r partials + r edges.
-// 16 workgroups are resident together on every device this runs on; every spin is bounded and raises an abort flag all
-// workgroups honour, so a workgroup that does not arrive ends the solve with an error instead of hanging the device.
-// Same operations per point as k_cg_pmv_f / k_cg_update_f; the dot products are summed per workgroup and then over the 16
-// workgroups, i.e. in another order than the 64x4-tile partials of the other forms: results agree to rounding, not bit for
-// bit (cg_fused = 3; forms 0-2 remain bit-identical among themselves).
-constexpr int CGP_NB = 16, CGP_NBX = 4, CGP_NT = 1024, CGP_PPT = 5, CGP_RPT = 1;   // workgroups, threads, tile / ring points per thread
-// (256 threads x 17 points: 9.0 us per iteration against 6.5 -- the two divisions per point of lap_at then weigh 2.8 us)
-struct CgpArgs {
-    const double* b;
-    double* x_out;         // solution (whole array written)
-    double* r_glob;        // N doubles: tile-edge values of r are exchanged through it
-    double* part;          // 4 x CGP_NB slots (8 bytes every 128: partial sum = arrival flag), all CGP_EMPTY before the launch
-    unsigned* ctr;         // [1] abort flag
-    FprSolveState* st;
-    int nx, ny, Nmax;
-    double hx2, hy2, c, tol, N;
-    long long* prof;       // diagnostic (option cg_prof = device address of 8 int64): ticks of workgroup 0 per section, summed
-};
-
-__device__ __forceinline__ double cgp_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void cgp_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// Grid barrier and all-reduce in ONE round trip: workgroup b stores its partial sum into its own slot of the set that belongs
-// to this barrier; lanes 0..15 of wave 0 of every workgroup each watch one slot until it no longer holds the EMPTY pattern (a
-// NaN payload no sum produces) -- the value itself is the arrival flag.  FOUR sets rotate: when a workgroup publishes for
-// barrier g it first empties its slot of set (g+2) mod 4, last used at barrier g-2 (everybody has read that one: they all
-// published g-1 since).  That slot is polled next at barrier g+2; between the emptying and that poll lie the owner's
-// publications g and g+1, and the barriers alternate between RELEASE (publishes the workgroup's earlier stores -- the tile-edge
-// values of r and the emptying -- acquired by the pollers) and relaxed (nothing but the sum travels), so one of the two orders
-// the emptying before the poll.  Returns the 16 partials summed in workgroup order in every thread; *ok = false if the wait
-// timed out (abort raised for everybody).
-constexpr unsigned long long CGP_EMPTY = 0x7ff8dead0badf00dull;
-constexpr int CGP_SLOT_STRIDE = 16;   // 8-byte words between two slots
-// sum over the 64 lanes of a wave by DPP row shifts (an inclusive scan inside each 16-lane row, then the four row totals):
-// ~25 instructions where the shuffle tree of fpr_wave_sum takes 12 LDS-crossbar round trips.  Result in every lane.
-__device__ __forceinline__ double cgp_wave_sum(double v)
-{
-    v += mgs_dpp<0x111>(v);
-    v += mgs_dpp<0x112>(v);
-    v += mgs_dpp<0x114>(v);
-    v += mgs_dpp<0x118>(v);   // lane 15 of every row: the row's total
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
-    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31));
-    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 47), __builtin_amdgcn_readlane(lo, 47));
-    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
-    return ((r0 + r1) + r2) + r3;
-}
-
-template <bool RELEASE>
-__device__ __forceinline__ double cgp_allsum(unsigned long long* slots, unsigned* abort_flag, double v_thread, unsigned& gen, double* red,
-                                             double* gpart, int* s_abort, bool* ok)
-{
-    ++gen;
-    // (a slot per 128-byte line: the pollers of different slots do not queue at one memory channel)
-    unsigned long long* set = slots + (gen & 3u) * (CGP_NB * CGP_SLOT_STRIDE);
-    unsigned long long* nxt = slots + ((gen + 2u) & 3u) * (CGP_NB * CGP_SLOT_STRIDE);
-    const double v_wave = cgp_wave_sum(v_thread);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v_wave;
-    __syncthreads();                       // wave totals in LDS; the workgroup's earlier stores precede the publication below
-    if (threadIdx.x == 0) {
-        double v_blk = red[0];
-#pragma unroll
-        for (int w = 1; w < CGP_NT / 64; ++w) v_blk += red[w];
-        __hip_atomic_store(&nxt[blockIdx.x * CGP_SLOT_STRIDE], CGP_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long bits = (unsigned long long)__double_as_longlong(v_blk);
-        if (bits == CGP_EMPTY) bits ^= 1ull;   // (a sum that happens to be this very NaN stays a NaN)
-        if (RELEASE) __hip_atomic_store(&set[blockIdx.x * CGP_SLOT_STRIDE], bits, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_store(&set[blockIdx.x * CGP_SLOT_STRIDE], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (threadIdx.x < 64) {                // wave 0: lane w < 16 waits for workgroup w
-        const int w = threadIdx.x;
-        int ab = 0;
-        if (w < CGP_NB) {
-            unsigned spins = 0;
-            unsigned long long bits;
-            while (true) {
-                bits = RELEASE ? __hip_atomic_load(&set[w * CGP_SLOT_STRIDE], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
-                               : __hip_atomic_load(&set[w * CGP_SLOT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (bits != CGP_EMPTY) break;
-                if ((++spins & 0x3ff) == 0) {
-                    if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
-                    if (spins > (1u << 22)) {   // seconds, not minutes
-                        __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ab = 1;
-                        break;
-                    }
-                }
-            }
-            gpart[w] = __longlong_as_double((long long)bits);
-        }
-        ab = __any(ab);
-        if (threadIdx.x == 0) *s_abort = ab;
-    }
-    __syncthreads();
-    *ok = *s_abort == 0;
-    double s = 0.0;
-#pragma unroll
-    for (int w = 0; w < CGP_NB; ++w) s += gpart[w];
-    return s;
-}
-
-__global__ void k_cgp_slots_init(unsigned long long* slots)
-{
-    if (threadIdx.x < 4 * CGP_NB) slots[threadIdx.x * CGP_SLOT_STRIDE] = CGP_EMPTY;
-}
-
-__global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    __shared__ double red[CGP_NT / 64];
-    __shared__ double gpart[CGP_NB];
-    __shared__ int s_abort;
-    const int tid = threadIdx.x;
-    const int bx = blockIdx.x % CGP_NBX, by = blockIdx.x / CGP_NBX;
-    const int nx = a.nx, ny = a.ny;
-    const int twm = (nx + CGP_NBX - 1) / CGP_NBX, thm = (ny + CGP_NBX - 1) / CGP_NBX;   // nominal tile
-    const int i0 = bx * twm, j0 = by * thm;
-    int tw = nx - i0 < twm ? nx - i0 : twm, th = ny - j0 < thm ? ny - j0 : thm;
-    if (tw < 0) tw = 0;
-    if (th < 0) th = 0;
-    const int npt = tw * th;                       // points of this tile (0: the workgroup only takes part in the barriers)
-    const int lw = twm + 2;                        // LDS row length: tile + ring
-    double* P = sm;                                // (thm + 2) x lw image of p: tile cell (ti, tj) at (ti + 1) + lw * (tj + 1)
-    unsigned gen = 0;
-    unsigned long long* slots = reinterpret_cast<unsigned long long*>(a.part);   // 4 sets x 16 slots, all EMPTY at the start
-    bool ok = true;
-    if (tid == 0) s_abort = 0;
-    // this thread's points
-    int li[CGP_PPT], gi[CGP_PPT];                  // LDS index, global index (-1: none)
-    bool inter[CGP_PPT], edge[CGP_PPT];
-    double x[CGP_PPT], r[CGP_PPT], p[CGP_PPT], q[CGP_PPT];
-    const float rtw = tw > 0 ? 1.0f / (float)tw : 0.0f;
-#pragma unroll
-    for (int k = 0; k < CGP_PPT; ++k) {
-        const int idx = tid + k * CGP_NT;
-        gi[k] = -1; li[k] = 0; inter[k] = false; edge[k] = false;
-        x[k] = 0.0; r[k] = 0.0; p[k] = 0.0; q[k] = 0.0;
-        if (idx < npt) {
-            const int tj = mgs_row(idx, rtw), ti = idx - tj * tw;
-            const int i = i0 + ti, j = j0 + tj;
-            gi[k] = i + nx * j;
-            li[k] = (ti + 1) + lw * (tj + 1);
-            inter[k] = i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1;
-            edge[k] = ti == 0 || tj == 0 || ti == tw - 1 || tj == th - 1;
-            const double v = a.b[gi[k]];
-            r[k] = v; p[k] = v; q[k] = v;          // krylov.jl:61-66: r = p = b, p_hat starts as b (its boundary keeps b), x = 0
-        }
-    }
-    // ring cells of this thread (at most CGP_RPT): bottom row, top row, left column, right column of the (tw+2) x (th+2) frame
-    int rl[CGP_RPT], rg[CGP_RPT];
-    double p_ring[CGP_RPT];
-    {
-        const int nring = npt > 0 ? 2 * (tw + 2) + 2 * th : 0;
-#pragma unroll
-        for (int m = 0; m < CGP_RPT; ++m) {
-            const int t = tid + m * CGP_NT;
-            rl[m] = -1; rg[m] = -1;
-            if (t < nring) {
-                int hx, hy;
-                if (t < tw + 2) { hx = t; hy = 0; }
-                else if (t < 2 * (tw + 2)) { hx = t - (tw + 2); hy = th + 1; }
-                else if (t < 2 * (tw + 2) + th) { hx = 0; hy = t - 2 * (tw + 2) + 1; }
-                else { hx = tw + 1; hy = t - 2 * (tw + 2) - th + 1; }
-                const int ri = i0 + hx - 1, rj = j0 + hy - 1;
-                rl[m] = hx + lw * hy;
-                if (ri >= 0 && rj >= 0 && ri < nx && rj < ny) rg[m] = ri + nx * rj;
-            }
-            p_ring[m] = rg[m] >= 0 ? a.b[rg[m]] : 0.0;   // p = b before the first iteration
-        }
-    }
-    // rho = sum(r .* r) with r = b (krylov.jl:64), threshold tol * ||b|| (:57-58)
-    double rho = 0.0, rho_old = 0.0, rr = 0.0;
-    int it = 0;
-    bool conv = false, alive = true;
-    {
-        double acc0 = 0.0;
-#pragma unroll
-        for (int k = 0; k < CGP_PPT; ++k) acc0 += r[k] * r[k];
-        rho = cgp_allsum<false>(slots, &a.ctr[1], acc0, gen, red, gpart, &s_abort, &ok);
-        alive = ok;
-        rr = rho;
-    }
-    const double thresh = a.tol * sqrt(rho);
-    long long tsec[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
-    const bool prof = a.prof != nullptr && blockIdx.x == 0 && tid == 0;
-    auto lap = [&](int k) { if (prof) { const long long t = wall_clock64(); tsec[k] += t - tprev; tprev = t; } };
-    if (prof) tprev = wall_clock64();
-    for (; alive && it < a.Nmax; ++it) {
-        // ---- exit test and beta of iteration it-1 (krylov.jl:73-84), new direction (:85), operator and p.p_hat (:68-69) ----
-        double beta = 0.0;
-        if (it > 0) {
-            if (sqrt(rr) < thresh) { conv = true; break; }      // :76 (every thread of every workgroup holds the same sum)
-            rho_old = rho;
-            beta = rr / rho_old;                                 // :83-84
-            rho = rr;
-#pragma unroll
-            for (int k = 0; k < CGP_PPT; ++k) p[k] = r[k] + beta * p[k];
-#pragma unroll
-            for (int m = 0; m < CGP_RPT; ++m)   // acquired at barrier 2 by wave 0 (cache invalidate), workgroup barrier since
-                if (rg[m] >= 0) p_ring[m] = a.r_glob[rg[m]] + beta * p_ring[m];
-        }
-#pragma unroll
-        for (int k = 0; k < CGP_PPT; ++k)
-            if (gi[k] >= 0) P[li[k]] = p[k];
-#pragma unroll
-        for (int m = 0; m < CGP_RPT; ++m)
-            if (rl[m] >= 0) P[rl[m]] = p_ring[m];
-        __syncthreads();
-        lap(0);   // beta, new p, ring loads, LDS image
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < CGP_PPT; ++k) {
-            if (inter[k]) {
-                const double t = p[k];
-                const int l = li[k];
-                q[k] = (((P[l + 1] - 2 * t) + P[l - 1]) / a.hx2 + ((P[l + lw] - 2 * t) + P[l - lw]) / a.hy2) - a.c * t;   // lap_at
-            }
-            if (gi[k] >= 0) acc += p[k] * q[k];
-        }
-        lap(1);   // operator
-        const double pq = cgp_allsum<false>(slots, &a.ctr[1], acc, gen, red, gpart, &s_abort, &ok);   // barrier 1 of the iteration
-        if (!ok) { alive = false; break; }
-        lap(3);   // barrier 1
-        // ---- alpha, x and r (krylov.jl:69-72), r.r; the tile-edge values of r go to the neighbours ----
-        const double alpha = rho / pq;
-        double acc2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < CGP_PPT; ++k) {
-            if (gi[k] >= 0) {
-                x[k] = x[k] + alpha * p[k];
-                const double rn = r[k] - alpha * q[k];
-                r[k] = rn;
-                acc2 += rn * rn;
-                if (edge[k]) a.r_glob[gi[k]] = rn;   // plain store: published by the RELEASE of barrier 2 (an atomic store each would be
-                                                     // issued behind an s_waitcnt of its own: five serial round trips)
-            }
-        }
-        lap(4);   // update
-        rr = cgp_allsum<true>(slots, &a.ctr[1], acc2, gen, red, gpart, &s_abort, &ok);        // barrier 2 (publishes the r edges)
-        if (!ok) { alive = false; break; }
-        lap(5);   // barrier 2
-    }
-    if (prof)
-        for (int k = 0; k < 6; ++k) a.prof[k] += tsec[k];
-    if (alive && !conv && it == a.Nmax && a.Nmax > 0) conv = sqrt(rr) < thresh;   // the loop ran out: the last norm (k_cg_tail_f)
-#pragma unroll
-    for (int k = 0; k < CGP_PPT; ++k)
-        if (gi[k] >= 0) a.x_out[gi[k]] = x[k];              // krylov.jl:88
-    if (blockIdx.x == 0 && tid == 0) {
-        a.st->iters = it;
-        a.st->last_rms = sqrt(rr / a.N);                   // :90 (r = b if the loop body never ran)
-        a.st->thresh = thresh;
-        a.st->done = alive ? (conv ? 1 : 0) : -1;          // -1: a barrier timed out
-        a.st->rho = rr;
-    }
-}
-
 static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, double hy, double c, double tol, int Nmax,
                     int nx, int ny)
 {
@@ -2292,299 +830,7 @@ static int get_arena(fpr_ctx* ctx, int nx, int ny, int css, std::vector<FprLevel
     return FPR_OK;
 }
 
-// ================================================================================================
-// k_mid_down / k_mid_up: the three levels right above the LDS-resident sub-hierarchy in TWO launches
-// ================================================================================================
-// Below the finest levels a V-cycle is bound by launches, not by bytes: rocprofv3 shows ~4.5 us from dispatch to completion
-// for a kernel that does nothing, and the marching passes of a 513^2, 257^2 or 129^2 level take 7-11 us each for 1-3 us
-// of work.  The pre-smoothing passes of three consecutive levels A > B > C (each: two sweeps from the ZERO initial guess
-// every level below the top starts from, multigrid.jl:132, + residual + injection) become ONE launch, and so do their three
-// post-smoothing passes (prolongation + correction + two sweeps each): a workgroup owns a tile of the coarsest output and
-// recomputes, in LDS, the halo it needs on the finer levels (pre: 53^2 points of A for 32^2 owned; post: 36^2 for 32^2),
-// so workgroups never communicate.  Same point arithmetic and the same prolongation order as the per-level kernels: all
-// arrays a later pass reads (tmp = the pre-smoothed field and res_c = the right-hand side of every level, the solution of
-// level A) are bit-identical; the solutions of B and C only ever exist in LDS.
-struct MidReg { int x0, x1, y0, y1; };   // inclusive index ranges at one level
-__device__ __forceinline__ MidReg mid_clip(int x0, int x1, int y0, int y1, int nx, int ny)
-{
-    MidReg r;
-    r.x0 = x0 < 0 ? 0 : x0; r.x1 = x1 > nx - 1 ? nx - 1 : x1;
-    r.y0 = y0 < 0 ? 0 : y0; r.y1 = y1 > ny - 1 ? ny - 1 : y1;
-    return r;
-}
-__device__ __forceinline__ MidReg mid_grow(MidReg r, int k, int nx, int ny) { return mid_clip(r.x0 - k, r.x1 + k, r.y0 - k, r.y1 + k, nx, ny); }
-__device__ __forceinline__ int mid_w(const MidReg& r) { return r.x1 - r.x0 + 1; }
-__device__ __forceinline__ int mid_h(const MidReg& r) { return r.y1 - r.y0 + 1; }
-__device__ __forceinline__ int mid_n(const MidReg& r) { return mid_w(r) * mid_h(r); }
-__device__ __forceinline__ int mid_at(const MidReg& r, int i, int j) { return (i - r.x0) + mid_w(r) * (j - r.y0); }
-
-struct MidLevel {
-    const double* f;     // right-hand side of the level (down: level A only is read, B and C are produced)
-    double* tmp;         // pre-smoothed field (down writes, up reads)
-    double* fout;        // down: right-hand side of the NEXT coarser level (res_c of this level)
-    int nx, ny;
-    double C, _h2, fac;
-};
-struct MidArgs {
-    MidLevel L[3];       // A, B, C
-    int nxD, nyD;        // the level below C (top of the LDS-resident sub-hierarchy)
-    double* uD;          // down: its zero initial guess is written; up: its solution is read
-    double* uA;          // up: solution of level A
-    int apply_BCs;
-    const int* skip;
-};
-
-constexpr int MID_TD = 4;     // k_mid_down: tile of the level-D right-hand side per workgroup
-constexpr int MID_TA = 32;    // k_mid_up: tile of the level-A solution per workgroup
-constexpr int MID_NT_DOWN = 1024, MID_NT_UP = 512;
-
-// out(p) = in(p) + fac*res(in)(p) on region `ro`, boundary points copied; `in` lives on region `ri` (ro grown by one,
-// clipped), f on region `rf`
-__device__ __forceinline__ void mid_sweep(const double* in, const MidReg& ri, const double* f, const MidReg& rf, double* out,
-                                          const MidReg& ro, int nx, int ny, double C, double _h2, double fac, int nt)
-{
-    const int w = mid_w(ro), n = mid_n(ro);
-    const float rw = 1.0f / (float)w;
-    const int wi = mid_w(ri);
-    for (int idx = threadIdx.x; idx < n; idx += nt) {
-        const int jj = mgs_row(idx, rw), ii = idx - jj * w;
-        const int i = ro.x0 + ii, j = ro.y0 + jj;
-        const int q = mid_at(ri, i, j);
-        const double uc = in[q];
-        double v = uc;
-        if (i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1) {
-            const double r = ((((in[q + 1] + in[q - 1]) + in[q + wi]) + in[q - wi]) - C * uc) * _h2 - f[mid_at(rf, i, j)];
-            v = uc + fac * r;
-        }
-        out[idx] = v;
-    }
-}
-
-// prolong_bf with the coarse field in an LDS region (indices clamped into it; a clamped value is never used)
-__device__ __forceinline__ double mid_prolong(const double* cc, const MidReg& rc, int i, int j, int nx, int ny, int nxc, int nyc)
-{
-    const bool in = i >= 1 && j >= 1 && i <= nx - 2 && j <= ny - 2;
-    const int io = i & 1, jo = j & 1;
-    int icl = i >> 1, jcl = j >> 1;
-    int ich = (icl + 1 < nxc) ? icl + 1 : nxc - 1, jch = (jcl + 1 < nyc) ? jcl + 1 : nyc - 1;
-    const double w = (io | jo) ? ((io & jo) ? 0.25 : 0.5) : 1.0;
-    const bool sx0 = icl >= 1 && icl <= nxc - 2, sx1 = io && (icl + 1 <= nxc - 2);
-    const bool sy0 = jcl >= 1 && jcl <= nyc - 2, sy1 = jo && (jcl + 1 <= nyc - 2);
-    icl = icl < rc.x0 ? rc.x0 : (icl > rc.x1 ? rc.x1 : icl); ich = ich < rc.x0 ? rc.x0 : (ich > rc.x1 ? rc.x1 : ich);
-    jcl = jcl < rc.y0 ? rc.y0 : (jcl > rc.y1 ? rc.y1 : jcl); jch = jch < rc.y0 ? rc.y0 : (jch > rc.y1 ? rc.y1 : jch);
-    const double c00 = cc[mid_at(rc, icl, jcl)], c10 = cc[mid_at(rc, ich, jcl)];
-    const double c01 = cc[mid_at(rc, icl, jch)], c11 = cc[mid_at(rc, ich, jch)];
-    double v = 0.0;
-    v = v + ((in && sx0 && sy0) ? w * c00 : 0.0);
-    v = v + ((in && sx1 && sy0) ? w * c10 : 0.0);
-    v = v + ((in && sx0 && sy1) ? w * c01 : 0.0);
-    v = v + ((in && sx1 && sy1) ? w * c11 : 0.0);
-    return v;
-}
-
-__global__ __launch_bounds__(MID_NT_DOWN) void k_mid_down(MidArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    if (a.skip && *a.skip) return;
-    constexpr int NT = MID_NT_DOWN;
-    const int tid = threadIdx.x;
-    const int ntx = (a.nxD - 1) / MID_TD > 0 ? (a.nxD - 1) / MID_TD : 1, nty = (a.nyD - 1) / MID_TD > 0 ? (a.nyD - 1) / MID_TD : 1;
-    const int bx = blockIdx.x, by = blockIdx.y;
-    // owned tile of the level-D right-hand side (the last tile of a dimension takes the remainder)
-    MidReg own;
-    own.x0 = bx * MID_TD; own.x1 = (bx == ntx - 1) ? a.nxD - 1 : own.x0 + MID_TD - 1;
-    own.y0 = by * MID_TD; own.y1 = (by == nty - 1) ? a.nyD - 1 : own.y0 + MID_TD - 1;
-    // regions, coarse to fine: rt[l] = where the pre-smoothed field of level l is needed, rf[l] = rt[l] grown by one
-    // (first sweep / right-hand side); the residual at coarse point c reads the fine field at 2c-1 .. 2c+1
-    MidReg rt[3], rf[3], rn = own;   // rn = region of the next coarser right-hand side
-    for (int l = 2; l >= 0; --l) {
-        rt[l] = mid_clip(2 * rn.x0 - 1, 2 * rn.x1 + 1, 2 * rn.y0 - 1, 2 * rn.y1 + 1, a.L[l].nx, a.L[l].ny);
-        rf[l] = mid_grow(rt[l], 1, a.L[l].nx, a.L[l].ny);
-        rn = rf[l];
-    }
-    // LDS: F | U1 (on rf) | U2 (on rt) of the current level, then the next level's F behind them
-    double* F = sm;
-    {   // right-hand side of level A from memory
-        const MidLevel& L = a.L[0];
-        const int w = mid_w(rf[0]), n = mid_n(rf[0]);
-        const float rw = 1.0f / (float)w;
-        for (int idx = tid; idx < n; idx += NT) {
-            const int jj = mgs_row(idx, rw), ii = idx - jj * w;
-            F[idx] = L.f[(size_t)(rf[0].x0 + ii) + (size_t)L.nx * (rf[0].y0 + jj)];
-        }
-    }
-    __syncthreads();
-    int scale = 8;   // level-l index = scale * level-D index
-    for (int l = 0; l < 3; ++l, scale >>= 1) {
-        const MidLevel& L = a.L[l];
-        const int nf = mid_n(rf[l]), ntm = mid_n(rt[l]);
-        double* U1 = F + nf;
-        double* U2 = U1 + nf;
-        double* Fn = U2 + ntm;   // next level's right-hand side
-        {   // first sweep from the zero initial guess (:124 with u = 0; the literal arithmetic on zeros, kept bit for bit)
-            const int w = mid_w(rf[l]);
-            const float rw = 1.0f / (float)w;
-            for (int idx = tid; idx < nf; idx += NT) {
-                const int jj = mgs_row(idx, rw), ii = idx - jj * w;
-                const int i = rf[l].x0 + ii, j = rf[l].y0 + jj;
-                double v = 0.0;
-                if (i >= 1 && j >= 1 && i < L.nx - 1 && j < L.ny - 1) {
-                    const double r = ((((0.0 + 0.0) + 0.0) + 0.0) - L.C * 0.0) * L._h2 - F[idx];
-                    v = 0.0 + L.fac * r;
-                }
-                U1[idx] = v;
-            }
-        }
-        __syncthreads();
-        mid_sweep(U1, rf[l], F, rf[l], U2, rt[l], L.nx, L.ny, L.C, L._h2, L.fac, NT);   // :125
-        __syncthreads();
-        {   // the owned part of the pre-smoothed field goes to memory (the post-smoothing pass reads it)
-            MidReg o;
-            o.x0 = scale * own.x0; o.x1 = (bx == ntx - 1) ? L.nx - 1 : scale * (own.x1 + 1) - 1;
-            o.y0 = scale * own.y0; o.y1 = (by == nty - 1) ? L.ny - 1 : scale * (own.y1 + 1) - 1;
-            const int w = mid_w(o), n = mid_n(o);
-            const float rw = 1.0f / (float)w;
-            for (int idx = tid; idx < n; idx += NT) {
-                const int jj = mgs_row(idx, rw), ii = idx - jj * w;
-                const int i = o.x0 + ii, j = o.y0 + jj;
-                L.tmp[(size_t)i + (size_t)L.nx * j] = U2[mid_at(rt[l], i, j)];
-            }
-        }
-        {   // residual at the injected points = right-hand side of the next level (:128-131; Neumann columns :355-357)
-            const MidReg rc = (l < 2) ? rf[l + 1] : own;
-            const int nxc = 1 + (L.nx - 1) / 2, nyc = 1 + (L.ny - 1) / 2;
-            const int half = scale >> 1;
-            MidReg o;   // owned part of that right-hand side
-            o.x0 = half * own.x0; o.x1 = (bx == ntx - 1) ? nxc - 1 : half * (own.x1 + 1) - 1;
-            o.y0 = half * own.y0; o.y1 = (by == nty - 1) ? nyc - 1 : half * (own.y1 + 1) - 1;
-            const int w = mid_w(rc), n = mid_n(rc), wt = mid_w(rt[l]);
-            const float rw = 1.0f / (float)w;
-            for (int idx = tid; idx < n; idx += NT) {
-                const int jj = mgs_row(idx, rw), ii = idx - jj * w;
-                const int ic = rc.x0 + ii, jc = rc.y0 + jj;
-                int is = ic;
-                if (a.apply_BCs) is = (ic == 0) ? 1 : (ic == nxc - 1 ? nxc - 2 : ic);
-                double v = 0.0;
-                if (is >= 1 && is <= nxc - 2 && jc >= 1 && jc <= nyc - 2) {
-                    const int q = mid_at(rt[l], 2 * is, 2 * jc);
-                    v = ((((U2[q + 1] + U2[q - 1]) + U2[q + wt]) + U2[q - wt]) - L.C * U2[q]) * L._h2 - F[mid_at(rf[l], 2 * is, 2 * jc)];
-                }
-                if (l < 2) Fn[idx] = v;
-                if (ic >= o.x0 && ic <= o.x1 && jc >= o.y0 && jc <= o.y1) {
-                    L.fout[(size_t)ic + (size_t)nxc * jc] = v;
-                    if (l == 2) a.uD[(size_t)ic + (size_t)nxc * jc] = 0.0;   // zero initial guess of level D (:132)
-                }
-            }
-        }
-        __syncthreads();
-        F = Fn;
-    }
-}
-
-__global__ __launch_bounds__(MID_NT_UP) void k_mid_up(MidArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    if (a.skip && *a.skip) return;
-    constexpr int NT = MID_NT_UP;
-    const int tid = threadIdx.x;
-    const MidLevel& LA = a.L[0];
-    const int ntx = (LA.nx - 1) / MID_TA > 0 ? (LA.nx - 1) / MID_TA : 1, nty = (LA.ny - 1) / MID_TA > 0 ? (LA.ny - 1) / MID_TA : 1;
-    const int bx = blockIdx.x, by = blockIdx.y;
-    MidReg own;   // owned tile of the level-A solution
-    own.x0 = bx * MID_TA; own.x1 = (bx == ntx - 1) ? LA.nx - 1 : own.x0 + MID_TA - 1;
-    own.y0 = by * MID_TA; own.y1 = (by == nty - 1) ? LA.ny - 1 : own.y0 + MID_TA - 1;
-    // regions, fine to coarse: r2[l] = where the solution of level l is needed, r1 = r2 grown by one (after the first
-    // sweep), rc = r2 grown by two (the corrected pre-smoothed field); the prolongation onto rc reads coarse points i>>1, (i>>1)+1
-    MidReg r2[3], r1[3], rc[3], rD;
-    r2[0] = own;
-    for (int l = 0; l < 3; ++l) {
-        r1[l] = mid_grow(r2[l], 1, a.L[l].nx, a.L[l].ny);
-        rc[l] = mid_grow(r2[l], 2, a.L[l].nx, a.L[l].ny);
-        const int nxc = 1 + (a.L[l].nx - 1) / 2, nyc = 1 + (a.L[l].ny - 1) / 2;
-        const MidReg rn = mid_clip(rc[l].x0 >> 1, (rc[l].x1 + 1) >> 1, rc[l].y0 >> 1, (rc[l].y1 + 1) >> 1, nxc, nyc);
-        if (l < 2) r2[l + 1] = rn; else rD = rn;
-    }
-    // LDS layout: per level X (on rc) | F (on r1) | U1 (on r1) | U2 (on r2; level A writes to memory instead), then D's field
-    double* X[3]; double* Fv[3]; double* U1[3]; double* U2[3];
-    double* p = sm;
-    for (int l = 0; l < 3; ++l) {
-        X[l] = p; p += mid_n(rc[l]);
-        Fv[l] = p; p += mid_n(r1[l]);
-        U1[l] = p; p += mid_n(r1[l]);
-        U2[l] = p; p += (l == 0) ? 0 : mid_n(r2[l]);
-    }
-    double* UD = p;
-    // every load the launch needs is issued up front: the pre-smoothed fields, the right-hand sides, the solution of level D
-    for (int l = 0; l < 3; ++l) {
-        const MidLevel& L = a.L[l];
-        {
-            const int w = mid_w(rc[l]), n = mid_n(rc[l]);
-            const float rw = 1.0f / (float)w;
-            for (int idx = tid; idx < n; idx += NT) {
-                const int jj = mgs_row(idx, rw), ii = idx - jj * w;
-                X[l][idx] = L.tmp[(size_t)(rc[l].x0 + ii) + (size_t)L.nx * (rc[l].y0 + jj)];
-            }
-        }
-        {
-            const int w = mid_w(r1[l]), n = mid_n(r1[l]);
-            const float rw = 1.0f / (float)w;
-            for (int idx = tid; idx < n; idx += NT) {
-                const int jj = mgs_row(idx, rw), ii = idx - jj * w;
-                Fv[l][idx] = L.f[(size_t)(r1[l].x0 + ii) + (size_t)L.nx * (r1[l].y0 + jj)];
-            }
-        }
-    }
-    {
-        const int w = mid_w(rD), n = mid_n(rD);
-        const float rw = 1.0f / (float)w;
-        for (int idx = tid; idx < n; idx += NT) {
-            const int jj = mgs_row(idx, rw), ii = idx - jj * w;
-            UD[idx] = a.uD[(size_t)(rD.x0 + ii) + (size_t)a.nxD * (rD.y0 + jj)];
-        }
-    }
-    __syncthreads();
-    const double* cc = UD;
-    MidReg rcc = rD;
-    for (int l = 2; l >= 0; --l) {
-        const MidLevel& L = a.L[l];
-        const int nxc = 1 + (L.nx - 1) / 2, nyc = 1 + (L.ny - 1) / 2;
-        {   // prolongation + correction (:136-139) of the pre-smoothed field, in place
-            const int w = mid_w(rc[l]), n = mid_n(rc[l]);
-            const float rw = 1.0f / (float)w;
-            for (int idx = tid; idx < n; idx += NT) {
-                const int jj = mgs_row(idx, rw), ii = idx - jj * w;
-                const int i = rc[l].x0 + ii, j = rc[l].y0 + jj;
-                int is = i;
-                if (a.apply_BCs) is = (i == 0) ? 1 : (i == L.nx - 1 ? L.nx - 2 : i);
-                X[l][idx] = X[l][idx] - mid_prolong(cc, rcc, is, j, L.nx, L.ny, nxc, nyc);
-            }
-        }
-        __syncthreads();
-        mid_sweep(X[l], rc[l], Fv[l], r1[l], U1[l], r1[l], L.nx, L.ny, L.C, L._h2, L.fac, NT);   // :142
-        __syncthreads();
-        if (l > 0) {
-            mid_sweep(U1[l], r1[l], Fv[l], r1[l], U2[l], r2[l], L.nx, L.ny, L.C, L._h2, L.fac, NT);   // :143
-            __syncthreads();
-            cc = U2[l];
-            rcc = r2[l];
-        } else {   // level A: the second sweep writes the owned tile of the solution to memory
-            const int w = mid_w(own), n = mid_n(own), wi = mid_w(r1[0]);
-            const float rw = 1.0f / (float)w;
-            for (int idx = tid; idx < n; idx += NT) {
-                const int jj = mgs_row(idx, rw), ii = idx - jj * w;
-                const int i = own.x0 + ii, j = own.y0 + jj;
-                const int q = mid_at(r1[0], i, j);
-                const double uc = U1[0][q];
-                double v = uc;
-                if (i >= 1 && j >= 1 && i < L.nx - 1 && j < L.ny - 1) {
-                    const double r = ((((U1[0][q + 1] + U1[0][q - 1]) + U1[0][q + wi]) + U1[0][q - wi]) - L.C * uc) * L._h2 - Fv[0][q];
-                    v = uc + L.fac * r;
-                }
-                a.uA[(size_t)i + (size_t)L.nx * j] = v;
-            }
-        }
-    }
-}
+#include "mg_mid.hpp"     // k_mid_down, k_mid_up: three launch-bound levels in two launches
 
 // Does the sub-hierarchy below an (nx, ny) level fit k_mg_small's LDS arena?  nlev = its levels, tot = doubles needed.
 static bool mgs_plan(int nx, int ny, int css, int* nlev_out, size_t* tot_out)

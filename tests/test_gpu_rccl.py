@@ -200,3 +200,31 @@ def test_bench_two_ranks_rehearsal_on_one_card():
     assert 0.0 < out["roofline"]["frac"] <= 1.0      # priced per pass: shell + thin slabs + core halves together
     assert out["roofline"]["launches_by_kind"]["fused_boxes"] >= 3 * 6
     assert out["config"]["last_err"] is not None and 0.0 < out["config"]["last_err"] < 1.0
+
+
+def test_bench_four_ranks_rehearsal_x_y_z_decompositions_agree():
+    """Four real processes on the one card (host-staged planes, see the two-rank test above) in the process grids (2,2,1),
+    (2,1,2) and (1,2,2): faces in x, y and z through the shell/core choreography of the fused pairs, the narrow-box kernels
+    and the pack kernels.  The three global problems are the same problem with its axes permuted (isotropic diffusion of a
+    centred Gaussian), so the norm rank 0 prints after 12 iterations must not depend on the decomposition."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--gpus", "4", "--rehearse-shared-gpu", "--n", "128", "--steps", "12", "--warmup", "4", "--no-cpu-baseline",
+              "--no-secondary", "--no-single-leg", "--prewarm-ms", "0"]
+    errs = []
+    for dims in ("2,2,1", "2,1,2", "1,2,2"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dims", dims] + common,
+                           capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 4 and out["config"]["process_grid"] == [int(x) for x in dims.split(",")]
+        assert out["legs"]["fused_pairs"]["launches"] == 6 and 0.0 < out["roofline"]["frac"] <= 1.0
+        errs.append(out["config"]["last_err"])
+    assert errs[0] is not None and 0.0 < errs[0] < 1.0
+    assert abs(errs[1] - errs[0]) <= 1e-12 * errs[0] and abs(errs[2] - errs[0]) <= 1e-12 * errs[0]

@@ -111,14 +111,16 @@ static bool diff3_fuse2_ok(fpr_ctx* ctx, const double* Ht, const double* A, cons
 static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const double* B, double* C, double* dH, int nx,
                       int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy,
                       double D_dz, const int* lo, const int* hi, double scale, double* sumsq2_dev, bool accumulate,
-                      int stream_sel, int zlo2 = 0, int zhi2 = 0)
-{
+                      int stream_sel, int zlo2 = 0, int zhi2 = 0, const int* skip = nullptr, int* nparts_only = nullptr)
+{   // nparts_only: the launch reduces both norms to per-workgroup partials (partials1 / partials2 of the stream's scratch) and
+    // leaves the finishing to the caller: *nparts_only = their number
     if (!ctx) return FPR_ERR_INVALID;
     FPR_REQUIRE(ctx, Ht && A && B && C, "null field pointer");   // dH may be null: residual not stored
     FPR_REQUIRE(ctx, A != C && B != C && A != B, "Htau, Hmid and Hout must be three distinct buffers");
     FPR_REQUIRE(ctx, stream_sel == 0 || stream_sel == 1, "stream_sel");
     FPR_REQUIRE(ctx, diff3_fuse2_ok(ctx, Ht, A, B, C, dH, nx, ny, nz), "problem not supported by the fused two-step kernel");
     Diff3Args2 a;
+    a.skip = skip;
     a.Ht = Ht; a.A = A; a.B = B; a.C = C; a.dH = dH;
     a.nx = nx; a.ny = ny; a.nz = nz;
     const int n[3] = {nx, ny, nz};
@@ -132,7 +134,7 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
     double* base = stream_sel ? ctx->partials2 : ctx->partials;
     a.partials1 = base;
     a.partials2 = base + FPR_MAX_PARTIALS / 2;
-    const bool norm = sumsq2_dev != nullptr;
+    const bool norm = sumsq2_dev != nullptr || nparts_only != nullptr;
     if (zlo2 < 1) zlo2 = 1;
     if (zhi2 > nz - 1) zhi2 = nz - 1;
     if (a.lo[2] >= a.hi[2] && zhi2 > zlo2) {   // empty first z-range: the second one takes its place
@@ -167,6 +169,10 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
                               (int)fpr_opt(ctx, "diff3_nw2", 0), ctx->ncu, zlo2, zhi2);
         fpr_ktimer_end(ctx, timed, ctx->stream[stream_sel]);
         if (e != hipSuccess) return fpr_fail(ctx, FPR_ERR_HIP, "fused diffusion3d launch: %s", hipGetErrorString(e));
+    }
+    if (nparts_only) {
+        *nparts_only = nparts;
+        return FPR_OK;
     }
     if (norm) {
         if (empty) {
@@ -205,6 +211,52 @@ extern "C" int fpr_diffusion3d_step2_box(fpr_ctx* ctx, const double* Ht, const d
     FPR_REQUIRE(ctx, lo && hi, "null box");
     return diff3_run2(ctx, Ht, Htau, Hmid, Hout, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo, hi,
                       scale, sumsq2_dev, true, stream_sel);
+}
+
+// ---- the solver's loop with its exit test on the device (pairs enqueued ahead of the host) ---------------------------
+// part1_kernel_programming.jl:179-192 is "iterate, read the norm on the host, compare, iterate".  At 128^3 a fused pair of
+// iterations takes ~15 us on the device and the host round trip behind it ~40 us.  As for MGsolve: the norms of
+// a pair stay on the device, k_diff3_check evaluates `err > tol` (:179) for the first and the second iteration of the pair and
+// raises a stop flag that every later pair (k_diff3_march2's `skip`) honours; the record of the pair goes to pinned host
+// memory from the kernel, sequence number last.  The FprCycleCtl fields are reused: ncycles = iterations executed,
+// coarse_iters = 1 if the loop ended on the FIRST iteration of the pair, tolf = tol, rms = err, frms = sqrt(N).
+__global__ void k_diff3_ctl_init(FprCycleCtl* ctl, double tol, double sqrtN)
+{
+    ctl->stop = 0; ctl->ncycles = 0; ctl->coarse_iters = 0; ctl->seq = 0;
+    ctl->tolf = tol; ctl->rms = 0.0; ctl->frms = sqrtN;
+}
+
+// finishes both norms of a pair exactly as k_finish2 does (same order of summation) and takes the loop's decision
+__global__ __launch_bounds__(256) void k_diff3_check(FprCycleCtl* ctl, const double* __restrict__ p1, const double* __restrict__ p2,
+                                                      int nparts, int n1, int n2, int it_base, int seq, FprCycleCtl* rec_host)
+{
+    __shared__ double red[16];
+    if (ctl->stop) return;
+    const double s1 = fpr_sum_partials_256(p1, nparts, red);
+    __syncthreads();
+    const double s2 = fpr_sum_partials_256(p2, nparts, red);
+    if (threadIdx.x != 0) return;
+    FprCycleCtl c = *ctl;
+    c.coarse_iters = 0;
+    bool done = false;
+    if (n1) {
+        const double e1 = sqrt(s1) / c.frms;   // :191 after the first iteration of the pair
+        c.rms = e1;
+        if (!(e1 > c.tolf)) { c.stop = 1; c.coarse_iters = 1; c.ncycles = it_base + 1; done = true; }
+    }
+    if (!done) {
+        c.ncycles = it_base + 2;
+        if (n2) {
+            const double e2 = sqrt(s2) / c.frms;
+            c.rms = e2;
+            if (!(e2 > c.tolf)) c.stop = 1;
+        }
+    }
+    *ctl = c;
+    rec_host->stop = c.stop; rec_host->ncycles = c.ncycles; rec_host->coarse_iters = c.coarse_iters;
+    rec_host->tolf = c.tolf; rec_host->rms = c.rms; rec_host->frms = c.frms;
+    __threadfence_system();
+    __hip_atomic_store(&rec_host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, double* Htau2, double* Htau3, double* dHdtau,
@@ -247,6 +299,8 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
     // the commit of Ht -- so that dHdtau holds what the reference's residual_H holds.  Option diff3_lazy_residual = 0:
     // every launch stores it.
     const bool lazy_res = fpr_opt(ctx, "diff3_lazy_residual", 1) != 0;
+    int ahead = (int)fpr_opt(ctx, "diff3_ahead", 2);   // fused pairs enqueued ahead of the host's view of the norm (0: wait for every norm)
+    if (ahead > FPR_CYC_SLOTS - 2) ahead = FPR_CYC_SLOTS - 2;
     const double* stale_in = nullptr;   // input of the last fused pair if dHdtau has not been written since
     double* stale_out = nullptr;
     for (int t = 0; t < nt; ++t) {
@@ -256,6 +310,68 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
         auto want_norm = [&](long j) { return fixed_iters > 0 ? (j == fixed_iters) : (j % check_every == 0); };
         while (more()) {
             const long left = fixed_iters > 0 ? fixed_iters - it : iter_max - it;
+            if (fuse && parity == 0 && left >= 2 && fixed_iters <= 0 && ahead > 0) {
+                // ---- a run of fused pairs enqueued `ahead` deep before the host looks at the norm of the oldest one ----
+                struct Pair { const double* in; double* out; long it_base; int slot, seq; bool rec; } ring[FPR_CYC_SLOTS];
+                hipStream_t s = ctx->stream[0];
+                k_diff3_ctl_init<<<1, 1, 0, s>>>(ctx->cyc, tol, sqrtN);
+                FPR_CHECK_LAUNCH(ctx);
+                long it_enq = it;
+                double* cur_enq = cur;
+                int enq = 0, seen = 0, nrec = 0;
+                bool stopped = false;
+                while (true) {
+                    while (enq - seen < 1 + ahead && iter_max - it_enq >= 2) {
+                        double* out = (cur_enq == Htau) ? E1 : Htau;
+                        const bool n1 = want_norm(it_enq + 1), n2 = want_norm(it_enq + 2);
+                        int nparts = 0;
+                        int rc = diff3_run2(ctx, Ht, cur_enq, Htau2, out, lazy_res ? nullptr : dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy,
+                                            _dz, D_dx, D_dy, D_dz, nullptr, nullptr, dt, nullptr, false, 0, 0, 0, &ctx->cyc->stop,
+                                            (n1 || n2) ? &nparts : nullptr);
+                        if (rc) return rc;
+                        Pair& p = ring[enq % FPR_CYC_SLOTS];
+                        p.in = cur_enq; p.out = out; p.it_base = it_enq; p.rec = n1 || n2; p.slot = 0; p.seq = 0;
+                        if (p.rec) {
+                            p.slot = nrec % FPR_CYC_SLOTS;
+                            p.seq = ++nrec;
+                            __atomic_store_n(&ctx->cyc_h[p.slot].seq, 0, __ATOMIC_RELEASE);
+                            k_diff3_check<<<1, 256, 0, s>>>(ctx->cyc, ctx->partials, ctx->partials + FPR_MAX_PARTIALS / 2, nparts,
+                                                            n1 ? 1 : 0, n2 ? 1 : 0, (int)it_enq, p.seq, &ctx->cyc_h[p.slot]);
+                            FPR_CHECK_LAUNCH(ctx);
+                        }
+                        cur_enq = out; it_enq += 2; ++enq;
+                    }
+                    if (seen == enq) break;   // iter_max is less than two iterations away: the single-iteration path finishes
+                    const Pair& p = ring[seen % FPR_CYC_SLOTS];
+                    ++seen;
+                    if (p.rec) {
+                        FprCycleCtl rec;
+                        if (int rc = fprx_cycle_wait(ctx, p.slot, p.seq, &rec)) return rc;
+                        err = rec.rms;
+                        if (rec.stop && rec.coarse_iters) {
+                            // the reference stops after the FIRST iteration of this pair: redo that one iteration from the pair's
+                            // input (intact: everything enqueued behind the pair has returned at once)
+                            int rc = diff3_run(ctx, Ht, p.in, Htau2, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz,
+                                               nullptr, nullptr, false, 0.0, nullptr, false, 0);
+                            if (rc) return rc;
+                            stale_in = nullptr;
+                            cur = Htau2; parity = 1; ++swaps; it = p.it_base + 1;
+                            stopped = true;
+                            break;
+                        }
+                        stale_in = lazy_res ? p.in : nullptr;
+                        stale_out = p.out;
+                        cur = p.out; swaps += 2; it = p.it_base + 2;
+                        if (rec.stop) { stopped = true; break; }
+                    } else {
+                        stale_in = lazy_res ? p.in : nullptr;
+                        stale_out = p.out;
+                        cur = p.out; swaps += 2; it = p.it_base + 2;
+                    }
+                }
+                (void)stopped;   // err <= tol ends the loop through more(); otherwise iter_max is near and the code below takes over
+                if (seen > 0) continue;
+            }
             if (fuse && parity == 0 && left >= 2) {
                 double* out = (cur == Htau) ? E1 : Htau;
                 const bool n1 = want_norm(it + 1), n2 = want_norm(it + 2);

@@ -56,6 +56,7 @@ struct Diff3Args2 {
     int xalign;                     // 1: x-tile cut points sit in the middle of 128-byte lines
     int zb_lo, zb_hi, ntz_a;        // optional second z-range [zb_lo, zb_hi) with the same x/y box: chunks tz >= ntz_a
     int xcd_remap;
+    const int* skip;                // fpr_diffusion3d_solve with pairs enqueued ahead of its exit test: return at once if *skip (nullptr = unconditional)
 #ifdef FPR_TUNE
     int dbg;                        // tuning harness only (tools/, -DFPR_TUNE): 1 = drop all stores, 2 = drop all loads of the z-loop
 #endif
@@ -168,6 +169,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
     // [parity][slot 0..5][row kind][TXW]; wave w owns slot w+1, slot 0 / 5 receive the global halo rows of
     // the bottom / top wave, so every wave reads "the slot below" and "the slot above" without a select
     __shared__ __attribute__((aligned(16))) double xrow[2 * (NW + 2) * SLOT];
+
+    if (a.skip && *a.skip) return;   // a pair enqueued behind the iteration that ended the solver's loop (diffusion3d.hip)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -510,34 +513,45 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
     a.sx = (span + a.ntx - 1) / a.ntx;
     a.sx += a.sx & 1;
     a.xalign = (a.sx >= 32 && a.sx <= 108 && a.nx % 16 == 0 && ((((uintptr_t)a.A | (uintptr_t)a.Ht)) & 127) == 0) ? 1 : 0;
-    // 8 waves per workgroup (32-row blocks, 30 owned: less redundant level-1 work and fewer re-read rows; one
-    // workgroup per CU) when the grid is tall enough, else 4 (16-row blocks, two workgroups per CU)
-    a.nw = (nw_opt == 4 || nw_opt == 8) ? nw_opt : ((a.ny >= 32 && wy >= 24) ? 8 : 4);
-    if (a.nw == 8 && a.ny < 32) a.nw = 4;
-    const int syb = a.nw * 4 - 2;
-    a.nby = (wy + syb - 1) / syb;
-    const long tiles_xy = (long)a.ntx * a.nby;
     // scalar byte offsets inside a chunk are 32-bit: (zc + 8) planes must stay below 2 GiB
     const long psb = (long)a.nx * a.ny * 8;
     if (psb * 12 >= (1L << 31)) return hipErrorInvalidValue;
     const int zc_max = (int)((1L << 31) / psb) - 8;
-    int zc = zc_opt;
-    if (zc <= 0) {
-        // chunking: workgroups run in rounds of `slots` (what the device holds at once); a chunk of zc planes costs
-        // zc + 6 plane-iterations (2 warm-up iterations, prologue / epilogue).  Pick the chunk count with the least
-        // rounds x cost; ties go to more workgroups.
-        const long slots = (long)(ncu > 0 ? ncu : 256) * (a.nw == 8 ? 1 : 2);
+    // chunking: workgroups run in rounds of `slots` (what the device holds at once); a chunk of zc planes costs
+    // zc + 6 plane-iterations (2 warm-up iterations, prologue / epilogue).  Pick the chunk count with the least
+    // rounds x cost; ties go to more workgroups.
+    auto plan = [&](int nw, int* zc_out) -> long {
+        const int syb_ = nw * 4 - 2;
+        const long tiles = (long)a.ntx * ((wy + syb_ - 1) / syb_);
+        const long slots = (long)(ncu > 0 ? ncu : 256) * (nw == 8 ? 1 : 2);
         long best = -1;
+        int zb = 0;
         for (int ntz = 1; ntz <= wz; ++ntz) {
             const int z = (wz + ntz - 1) / ntz;
             if (z > zc_max) continue;
             if (z < 4 && ntz > 1) break;
-            const long nb = tiles_xy * ((wz + z - 1) / z + (wzb + z - 1) / z);
+            const long nb = tiles * ((wz + z - 1) / z + (wzb + z - 1) / z);
             const long cost = ((nb + slots - 1) / slots) * (z + 6);
-            if (best < 0 || cost <= best) { best = cost; zc = z; }
+            if (best < 0 || cost <= best) { best = cost; zb = z; }
         }
-        if (zc <= 0) zc = wz < zc_max ? wz : zc_max;
-    }
+        if (zb <= 0) { zb = wz < zc_max ? wz : zc_max; best = zb + 6; }
+        *zc_out = zb;
+        return best;
+    };
+    // 8 waves per workgroup (32-row blocks, 30 owned: less redundant level-1 work and fewer re-read rows; one
+    // workgroup per CU) when the grid is tall enough, else 4 (16-row blocks, two workgroups per CU).  On small grids the
+    // 16-row blocks give twice as many (x, y) tiles and hence longer z-chunks for the same number of workgroups: they are
+    // taken when the plan with them is strictly cheaper (128^3: 11 against 12 plane-iterations, measured 15.6 against 17.5 us
+    // per iteration; 192^3: 17 = 17, measured equal; 256^3: 38 against 35, measured 59 against 56 us)
+    int zc = zc_opt, zc8 = 0, zc4 = 0;
+    const bool can8 = a.ny >= 32 && wy >= 24;
+    if (nw_opt == 4 || nw_opt == 8) a.nw = (nw_opt == 8 && a.ny < 32) ? 4 : nw_opt;
+    else if (!can8) a.nw = 4;
+    else a.nw = (zc_opt <= 0 && plan(4, &zc4) < plan(8, &zc8)) ? 4 : 8;
+    const int syb = a.nw * 4 - 2;
+    a.nby = (wy + syb - 1) / syb;
+    const long tiles_xy = (long)a.ntx * a.nby;
+    if (zc <= 0) plan(a.nw, &zc);
     if (zc > wz) zc = wz;
     if (zc > zc_max) zc = zc_max;
     a.zc = zc;

@@ -450,8 +450,9 @@ def test_fused_two_steps_box(fpr, oracle, box):
 
 
 @pytest.mark.parametrize("case", [dict(tol=1e-6, check_every=1), dict(tol=3e-5, check_every=1), dict(tol=1e-5, check_every=3),
-                                  dict(fixed_iters=51), dict(fixed_iters=50), dict(tol=1e-9, iter_max=77, check_every=1)],
-                         ids=["tol1e-6", "tol3e-5", "every3", "fixed51", "fixed50", "itermax77"])
+                                  dict(fixed_iters=51), dict(fixed_iters=50), dict(tol=1e-9, iter_max=77, check_every=1),
+                                  dict(tol=2e-5, check_every=2), dict(tol=1e-9, iter_max=78, check_every=5), dict(tol=1.0, check_every=1)],
+                         ids=["tol1e-6", "tol3e-5", "every3", "fixed51", "fixed50", "itermax77", "every2", "itermax78every5", "first_iteration"])
 def test_solve_with_fused_pairs_equals_plain_loop(fpr, oracle, case):
     """fpr_diffusion3d_solve runs pairs of iterations as fused launches; fields, iteration counts, errors and the
     final residual must be those of the plain one-iteration-per-launch loop (option diff3_fuse2 = 0)."""
@@ -460,10 +461,13 @@ def test_solve_with_fused_pairs_equals_plain_loop(fpr, oracle, case):
     n = (128, 24, 20)
     Ht0 = oracle.init_gaussian(n, 10.0 / n[0], 10.0 / n[1], 10.0 / n[2], (5.0, 5.0, 5.0))
     out = []
-    # plain loop; fused pairs that store the residual every launch; fused pairs that store it only when the call returns
-    for fuse, lazy in ((0, 1), (1, 0), (1, 1)):
+    # plain loop; fused pairs that store the residual every launch; fused pairs that store it only when the call returns -- each
+    # fused form with the host waiting for every norm (diff3_ahead = 0) and with the exit test on the device and 1, 2 (default)
+    # or 5 pairs enqueued ahead of the host (the pairs behind the one that ends the loop must not run)
+    for fuse, lazy, ahead in ((0, 1, 0), (1, 0, 0), (1, 1, 0), (1, 0, 2), (1, 1, 1), (1, 1, 2), (1, 1, 5)):
         c.set_option("diff3_fuse2", fuse)
         c.set_option("diff3_lazy_residual", lazy)
+        c.set_option("diff3_ahead", ahead)
         try:
             kw = dict(nx=n[0], ny=n[1], nz=n[2], ttot=0.6, Ht_init=F.asdevice(Ht0))
             kw.update(case)
@@ -472,6 +476,7 @@ def test_solve_with_fused_pairs_equals_plain_loop(fpr, oracle, case):
         finally:
             c.set_option("diff3_fuse2", 1)
             c.set_option("diff3_lazy_residual", 1)
+            c.set_option("diff3_ahead", 2)
     (H0, it0, e0, r0) = out[0]
     assert len(it0) == 3
     for H1, it1, e1, r1 in out[1:]:

@@ -170,6 +170,7 @@ int main(int argc, char** argv)
         CK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
         printf("# compute units: %d\n", ncu);
         Diff3Args2 f;
+        f.skip = nullptr;
         f.Ht = Ht; f.A = Htau; f.B = B; f.C = C; f.dH = dH;
         f.nx = f.ny = f.nz = n;
         for (int d = 0; d < 3; ++d) { f.lo[d] = 1; f.hi[d] = n - 1; }

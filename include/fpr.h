@@ -136,8 +136,11 @@ int fpr_diffusion3d_step2_box2(fpr_ctx* ctx, const double* Ht, const double* Hta
  * is replayed alone, so fields, iteration counts and errors are those of the plain loop; option "diff3_fuse2" = 0
  * turns this off).  Inside the loop the pairs do not store dHdtau (the loop reads only its norm); a call that ends on
  * a pair replays that pair once with the store, so dHdtau holds the reference's residual_H on return (option
- * "diff3_lazy_residual" = 0: every launch stores it).  NULL: one iteration per launch.  Non-NULL for a problem the fused kernel cannot serve
- * (fpr_diffusion3d_can_step2 == 0) is FPR_ERR_INVALID, never a silent fallback. */
+ * "diff3_lazy_residual" = 0: every launch stores it).  The loop's exit test (err > tol, :179) is evaluated on the device and
+ * up to "diff3_ahead" (default 2) pairs are enqueued before the host has seen the norm of the oldest; pairs behind the
+ * iteration that ends the loop return at once (0: the host waits for every norm).  NULL: one iteration per launch.
+ * Non-NULL for a problem the fused kernel cannot serve (fpr_diffusion3d_can_step2 == 0) is FPR_ERR_INVALID, never a
+ * silent fallback. */
 int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, double* Htau2, double* Htau3, double* dHdtau, int nx, int ny, int nz,
                           double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy, double D_dz,
                           double dt, double total_N, int nt, double tol, long iter_max, long fixed_iters, int check_every,

@@ -45,22 +45,6 @@ __device__ __forceinline__ void cgp_st(double* p, double v) { __hip_atomic_store
 // timed out (abort raised for everybody).
 constexpr unsigned long long CGP_EMPTY = 0x7ff8dead0badf00dull;
 constexpr int CGP_SLOT_STRIDE = 16;   // 8-byte words between two slots
-// sum over the 64 lanes of a wave by DPP row shifts (an inclusive scan inside each 16-lane row, then the four row totals):
-// ~25 instructions where the shuffle tree of fpr_wave_sum takes 12 LDS-crossbar round trips.  Result in every lane.
-__device__ __forceinline__ double cgp_wave_sum(double v)
-{
-    v += mgs_dpp<0x111>(v);
-    v += mgs_dpp<0x112>(v);
-    v += mgs_dpp<0x114>(v);
-    v += mgs_dpp<0x118>(v);   // lane 15 of every row: the row's total
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
-    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31));
-    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 47), __builtin_amdgcn_readlane(lo, 47));
-    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
-    return ((r0 + r1) + r2) + r3;
-}
-
 template <bool RELEASE>
 __device__ __forceinline__ double cgp_allsum(unsigned long long* slots, unsigned* abort_flag, double v_thread, unsigned& gen, double* red,
                                              double* gpart, int* s_abort, bool* ok)
@@ -69,7 +53,7 @@ __device__ __forceinline__ double cgp_allsum(unsigned long long* slots, unsigned
     // (a slot per 128-byte line: the pollers of different slots do not queue at one memory channel)
     unsigned long long* set = slots + (gen & 3u) * (CGP_NB * CGP_SLOT_STRIDE);
     unsigned long long* nxt = slots + ((gen + 2u) & 3u) * (CGP_NB * CGP_SLOT_STRIDE);
-    const double v_wave = cgp_wave_sum(v_thread);
+    const double v_wave = mgs_wave_sum(v_thread);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v_wave;
     __syncthreads();                       // wave totals in LDS; the workgroup's earlier stores precede the publication below
     if (threadIdx.x == 0) {

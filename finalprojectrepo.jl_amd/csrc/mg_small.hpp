@@ -30,24 +30,7 @@ struct MgSmallArgs {
 
 constexpr int MGS_NT = 1024;
 constexpr int MGS_RED = 32;  // doubles reserved for reductions / broadcasts
-
-__device__ __forceinline__ double mgs_block_sum(double v, double* red)
-{
-    // all MGS_NT threads call; returns the total in every thread
-    v = fpr_wave_sum(v);
-    const int tid = threadIdx.x;
-    __syncthreads();  // protect red[] from the previous use
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    if (tid == 0) {
-        double s = red[0];
-#pragma unroll
-        for (int w = 1; w < MGS_NT / 64; ++w) s += red[w];
-        red[MGS_NT / 64] = s;
-    }
-    __syncthreads();
-    return red[MGS_NT / 64];
-}
+constexpr int MGS_WPL = 5;   // single-wave coarse solve: points per lane (up to 320 points: 17 x 17)
 
 // shifts inside a 16-lane DPP row (zero where no lane is the source); n is uniform, 1..15
 template <int CTRL>
@@ -59,6 +42,37 @@ __device__ __forceinline__ double mgs_dpp(double v)
     return __hiloint2double(hi, lo);
 }
 template <int N> __device__ __forceinline__ double mgs_row_ror(double v) { return mgs_dpp<0x120 + N>(v); }
+// sum over the 64 lanes of a wave by DPP row shifts (an inclusive scan inside each 16-lane row, then the four row totals):
+// ~25 instructions where a shuffle tree takes 12 LDS-crossbar round trips.  The same value in every lane.
+__device__ __forceinline__ double mgs_wave_sum(double v)
+{
+    v += mgs_dpp<0x111>(v);
+    v += mgs_dpp<0x112>(v);
+    v += mgs_dpp<0x114>(v);
+    v += mgs_dpp<0x118>(v);   // lane 15 of every row: the row's total
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 47), __builtin_amdgcn_readlane(lo, 47));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
+    return ((r0 + r1) + r2) + r3;
+}
+
+__device__ __forceinline__ double mgs_block_sum(double v, double* red)
+{
+    // all MGS_NT threads call; returns the total in every thread (wave sums by DPP, then every thread adds the 16 wave
+    // totals in wave order from LDS: two barriers)
+    v = mgs_wave_sum(v);
+    const int tid = threadIdx.x;
+    __syncthreads();  // protect red[] from the previous use
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = red[0];
+#pragma unroll
+    for (int w = 1; w < MGS_NT / 64; ++w) s += red[w];
+    return s;
+}
+
 // idx -> row j = idx / nx without an integer division: floor((idx + 0.5) * (1/nx)) in float is exact while
 // nx*ny*2.4e-7 < 0.5 (the rounding error of the product stays below the distance 0.5/nx of (idx + 0.5)/nx from an
 // integer); the LDS arena holds 20000 doubles, so N < 2^15 here.
@@ -275,6 +289,65 @@ __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
             __syncthreads();
             res_rms = red[MGS_RED - 1];
             it = (int)red[MGS_RED - 2];
+        } else if (N <= 64 * MGS_WPL && a.row_solve) {
+            // small coarsest grid (9x9, 17x17, 17x9, ...): ONE wave sweeps it, up to MGS_WPL points per lane, the field
+            // ping-ponging between U and T in LDS.  The LDS operations of a wave execute in order and the wave sum is in
+            // registers, so a sweep needs no workgroup barrier (the block form: three per sweep, 16 waves).  sqrt and the
+            // division of :157 only when the exit test can possibly hold (see the DPP-row form above).
+            if (tid < 64) {
+                const int lane = tid;
+                int idx[MGS_WPL];
+                bool inter[MGS_WPL];
+                double fv[MGS_WPL];
+                const float rnx = 1.0f / (float)nx;
+#pragma unroll
+                for (int m = 0; m < MGS_WPL; ++m) {
+                    const int id = lane + 64 * m;
+                    const bool in = id < N;
+                    const int j = in ? mgs_row(id, rnx) : 0, i = id - j * nx;
+                    idx[m] = in ? id : -1;
+                    inter[m] = in && i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1;
+                    fv[m] = in ? F[id] : 0.0;
+                }
+                const double hi_thr = ((double)N * (tol_rhs * tol_rhs)) * (1.0 + 1e-10);
+                double sq_last = 0.0;
+                bool have_rms = false;
+                const double* pi = U;
+                double* po = T;
+                for (int k = 1; k <= iters; ++k) {
+                    double sq = 0.0;
+#pragma unroll
+                    for (int m = 0; m < MGS_WPL; ++m) {
+                        if (idx[m] >= 0) {
+                            const int id = idx[m];
+                            const double uc = pi[id];
+                            double v = uc;
+                            if (inter[m]) {
+                                const double r = ((((pi[id + 1] + pi[id - 1]) + pi[id + nx]) + pi[id - nx]) - C * uc) * _h2 - fv[m];
+                                v = uc + fac * r;
+                                sq += r * r;
+                            }
+                            po[id] = v;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this sweep's LDS traffic is done before the next one starts
+                    const double ssum = mgs_wave_sum(sq);
+                    const double* t = pi; pi = po; po = const_cast<double*>(t);
+                    it = k;
+                    sq_last = ssum;
+                    have_rms = false;
+                    if (ssum > hi_thr) continue;        // cannot have converged
+                    res_rms = sqrt(ssum / (double)N);   // :157
+                    have_rms = true;
+                    if (res_rms < tol_rhs) break;
+                }
+                if (!have_rms) res_rms = sqrt(sq_last / (double)N);
+                if (tid == 0) { red[MGS_RED - 1] = res_rms; red[MGS_RED - 2] = (double)it; }
+            }
+            __syncthreads();
+            res_rms = red[MGS_RED - 1];
+            it = (int)red[MGS_RED - 2];
+            pin = (it & 1) ? T : U;    // the solution sits in T after an odd number of sweeps
         } else
         for (int i = 1; i <= iters; ++i) {
             const double s = mgs_block_sum(mgs_sweep(pin, F, pout, nx, ny, C, _h2, fac), red);  // syncs inside

@@ -185,6 +185,32 @@ __device__ __forceinline__ double fpr_lane_down1z(double v)  // lane i <- lane i
     return __hiloint2double(hi, lo);
 }
 
+// shifts inside a 16-lane DPP row (zero where no lane is the source); n is uniform, 1..15
+template <int CTRL>
+__device__ __forceinline__ double fpr_dpp(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int N> __device__ __forceinline__ double fpr_row_ror(double v) { return fpr_dpp<0x120 + N>(v); }
+// sum over the 64 lanes of a wave by DPP row shifts (an inclusive scan inside each 16-lane row, then the four row totals):
+// ~25 instructions where a shuffle tree takes 12 LDS-crossbar round trips.  The same value in every lane.
+__device__ __forceinline__ double fpr_wave_sum_all(double v)
+{
+    v += fpr_dpp<0x111>(v);
+    v += fpr_dpp<0x112>(v);
+    v += fpr_dpp<0x114>(v);
+    v += fpr_dpp<0x118>(v);   // lane 15 of every row: the row's total
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 47), __builtin_amdgcn_readlane(lo, 47));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
+    return ((r0 + r1) + r2) + r3;
+}
+
 __device__ __forceinline__ double fpr_wave_sum(double v)
 {
 #pragma unroll

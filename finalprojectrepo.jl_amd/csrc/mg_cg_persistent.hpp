@@ -53,7 +53,7 @@ __device__ __forceinline__ double cgp_allsum(unsigned long long* slots, unsigned
     // (a slot per 128-byte line: the pollers of different slots do not queue at one memory channel)
     unsigned long long* set = slots + (gen & 3u) * (CGP_NB * CGP_SLOT_STRIDE);
     unsigned long long* nxt = slots + ((gen + 2u) & 3u) * (CGP_NB * CGP_SLOT_STRIDE);
-    const double v_wave = mgs_wave_sum(v_thread);
+    const double v_wave = fpr_wave_sum_all(v_thread);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v_wave;
     __syncthreads();                       // wave totals in LDS; the workgroup's earlier stores precede the publication below
     if (threadIdx.x == 0) {

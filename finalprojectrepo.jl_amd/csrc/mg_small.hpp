@@ -32,37 +32,11 @@ constexpr int MGS_NT = 1024;
 constexpr int MGS_RED = 32;  // doubles reserved for reductions / broadcasts
 constexpr int MGS_WPL = 5;   // single-wave coarse solve: points per lane (up to 320 points: 17 x 17)
 
-// shifts inside a 16-lane DPP row (zero where no lane is the source); n is uniform, 1..15
-template <int CTRL>
-__device__ __forceinline__ double mgs_dpp(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-template <int N> __device__ __forceinline__ double mgs_row_ror(double v) { return mgs_dpp<0x120 + N>(v); }
-// sum over the 64 lanes of a wave by DPP row shifts (an inclusive scan inside each 16-lane row, then the four row totals):
-// ~25 instructions where a shuffle tree takes 12 LDS-crossbar round trips.  The same value in every lane.
-__device__ __forceinline__ double mgs_wave_sum(double v)
-{
-    v += mgs_dpp<0x111>(v);
-    v += mgs_dpp<0x112>(v);
-    v += mgs_dpp<0x114>(v);
-    v += mgs_dpp<0x118>(v);   // lane 15 of every row: the row's total
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
-    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31));
-    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 47), __builtin_amdgcn_readlane(lo, 47));
-    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
-    return ((r0 + r1) + r2) + r3;
-}
-
 __device__ __forceinline__ double mgs_block_sum(double v, double* red)
 {
     // all MGS_NT threads call; returns the total in every thread (wave sums by DPP, then every thread adds the 16 wave
     // totals in wave order from LDS: two barriers)
-    v = mgs_wave_sum(v);
+    v = fpr_wave_sum_all(v);
     const int tid = threadIdx.x;
     __syncthreads();  // protect red[] from the previous use
     if ((tid & 63) == 0) red[tid >> 6] = v;
@@ -229,16 +203,16 @@ __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
                         return res_rms < tol_rhs;
                     };
                     for (int k = 1; k <= iters; ++k) {
-                        const double sE = mgs_dpp<0x101>(uu), sW = mgs_dpp<0x111>(uu);                 // lanes i+1, i-1
-                        const double sN = mgs_dpp<0x100 + NXI>(uu), sS = mgs_dpp<0x110 + NXI>(uu);     // lanes i+nxi, i-nxi
+                        const double sE = fpr_dpp<0x101>(uu), sW = fpr_dpp<0x111>(uu);                 // lanes i+1, i-1
+                        const double sN = fpr_dpp<0x100 + NXI>(uu), sS = fpr_dpp<0x110 + NXI>(uu);     // lanes i+nxi, i-nxi
                         const double E = iE ? sE : cE, W = iW ? sW : cW, Nn = iN ? sN : cN, Ss = iS ? sS : cS;
                         const double r = ((((E + W) + Nn) + Ss) - C * uu) * _h2 - fv;
                         const double uu_new = in ? uu + fac * r : uu;
                         double sq = in ? r * r : 0.0;
-                        sq += mgs_row_ror<8>(sq);
-                        sq += mgs_row_ror<4>(sq);
-                        sq += mgs_row_ror<2>(sq);
-                        sq += mgs_row_ror<1>(sq);
+                        sq += fpr_row_ror<8>(sq);
+                        sq += fpr_row_ror<4>(sq);
+                        sq += fpr_row_ror<2>(sq);
+                        sq += fpr_row_ror<1>(sq);
                         if (k > 1 && test(k - 1)) { done = true; break; }   // uu is still the field after sweep k-1
                         uu = uu_new;
                         sq_vec = sq;
@@ -331,7 +305,7 @@ __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this sweep's LDS traffic is done before the next one starts
-                    const double ssum = mgs_wave_sum(sq);
+                    const double ssum = fpr_wave_sum_all(sq);
                     const double* t = pi; pi = po; po = const_cast<double*>(t);
                     it = k;
                     sq_last = ssum;

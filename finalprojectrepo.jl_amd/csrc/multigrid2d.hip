@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void k_jacobi_patch(const double* __restrict__
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int sidx = wv + 4 * h;
-                const double a = fpr_wave_sum(part_acc[h]);
+                const double a = fpr_wave_sum_all(part_acc[h]);
                 if (lane == 0 && sidx < prev_nsw) red[0][sidx] = a;  // S >= prev_nsw
             }
             __syncthreads();
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void k_jacobi_patch(const double* __restrict__
         const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const double v = fpr_wave_sum(acc[s]);
+            const double v = fpr_wave_sum_all(acc[s]);
             if (lane == 0) red[wv][s] = v;
         }
         __syncthreads();
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void k_jacobi_check_multi(FprSolveState* st, c
     for (int s = wv; s < nsw; s += 4) {
         double a = 0.0;
         for (int i = lane; i < nblk; i += 64) a += partials[(size_t)s * nblk + i];
-        a = fpr_wave_sum(a);
+        a = fpr_wave_sum_all(a);   // (the same sum as the replay in the prologue of k_jacobi_patch)
         if (lane == 0) sums[s] = a;
     }
     __syncthreads();

@@ -30,7 +30,7 @@ extern "C" int fpr_ctx_create(fpr_ctx** out, int device, void* compute_stream, v
               hipHostMalloc(&ctx->state_h, sizeof(FprSolveState)) == hipSuccess &&
               hipHostMalloc(&ctx->host_scalars, 64 * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->cyc, sizeof(FprCycleCtl)) == hipSuccess &&
-              hipHostMalloc(&ctx->cyc_h, FPR_CYC_SLOTS * sizeof(FprCycleCtl)) == hipSuccess;
+              hipHostMalloc(&ctx->cyc_h, FPR_CYC_SLOTS * sizeof(FprCycleCtl), hipHostMallocCoherent) == hipSuccess;
     if (!ok) { fpr_ctx_destroy(ctx); return FPR_ERR_HIP; }
     hipMemset(ctx->scalars, 0, 64 * sizeof(double));
     hipMemset(ctx->state, 0, sizeof(FprSolveState));

@@ -194,22 +194,26 @@ __device__ __forceinline__ double prolong_bf(const double* __restrict__ cc, int 
 // prev_partials) -- every workgroup evaluates it redundantly and identically, workgroup 0 records it in
 // the solver state -- and does nothing once the criterion has been met.  This removes the separate
 // check launch from the dependent chain (one launch per 8 sweeps instead of two).
-template <int S, bool NORM, bool STATE>
-__global__ __launch_bounds__(256) void k_jacobi_patch(const double* __restrict__ uin, const double* __restrict__ f,
-                                                       double* __restrict__ uout, int nx, int ny, double C, double _h2,
-                                                       double fac, int nsw, double* __restrict__ partials,
-                                                       FprSolveState* __restrict__ state,
-                                                       const double* __restrict__ prev_partials, int prev_nsw,
-                                                       int prev_group, double Ntot)
+template <int S, int P, bool NORM, bool STATE>
+__global__ __launch_bounds__((P / 2) * (P / 2)) void k_jacobi_patch(const double* __restrict__ uin, const double* __restrict__ f,
+                                                                    double* __restrict__ uout, int nx, int ny, double C,
+                                                                    double _h2, double fac, int nsw, double* __restrict__ partials,
+                                                                    FprSolveState* __restrict__ state,
+                                                                    const double* __restrict__ prev_partials, int prev_nsw,
+                                                                    int prev_group, double Ntot)
 {
-    constexpr int P = 32;  // region = 32 x 32 points, own tile = inner 16 x 16
+    // region = P x P points, own tile = the inner T x T (S cells away from the region's edge); (P/2)^2 threads, 2x2 points each
     constexpr int T = P - 2 * S;
+    constexpr int HT = P / 2;                    // threads per side
+    constexpr int NT = HT * HT, NWV = (NT + 63) / 64;
+    constexpr int SPW = (S + NWV - 1) / NWV;     // sweeps whose partial lists one wave sums in the replay
+    static_assert(T > 0 && P % 2 == 0 && S <= 64, "patch geometry");
     __shared__ __attribute__((aligned(16))) double img[2][P * P];
-    __shared__ double red[4][S];
+    __shared__ double red[NWV][S];
     __shared__ int stop_flag;
     const int tid = threadIdx.x;
     // the field loads are issued first so that they overlap the replay of the previous group's exit test
-    const int tx = tid & 15, ty = tid >> 4;
+    const int ty = tid / HT, tx = tid - ty * HT;
     const int lx = 2 * tx, ly = 2 * ty;                      // patch origin inside the region
     const int x0 = blockIdx.x * T, y0 = blockIdx.y * T;      // own tile origin
     const int gx = x0 - S + lx, gy = y0 - S + ly;            // global coords of the patch origin
@@ -229,17 +233,19 @@ __global__ __launch_bounds__(256) void k_jacobi_patch(const double* __restrict__
         }
     if constexpr (STATE) {
         // Replay of the previous group's exit test.  All loads (flag, threshold, partial sums) are issued together;
-        // wave w sums the partials of sweeps w, w+4 (same order as k_jacobi_check_multi), lanes 0..prev_nsw-1 of
-        // wave 0 then evaluate sqrt(sum/N) < thresh in parallel and a ballot finds the first sweep that met it.
+        // wave w sums the partials of sweeps w, w+NWV, ... (per sweep the same strided sum as k_jacobi_check_multi), lanes
+        // 0..prev_nsw-1 of wave 0 then evaluate sqrt(sum/N) < thresh in parallel and a ballot finds the first sweep that met it.
         const int done0 = state->done;
         const double thresh = state->thresh;
         const int nblk = gridDim.x * gridDim.y;
         const int lane = tid & 63, wv = tid >> 6;
-        double part_acc[2] = {0.0, 0.0};
+        double part_acc[SPW];
+#pragma unroll
+        for (int h = 0; h < SPW; ++h) part_acc[h] = 0.0;
         if (prev_nsw > 0) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int sidx = wv + 4 * h;
+            for (int h = 0; h < SPW; ++h) {
+                const int sidx = wv + NWV * h;
                 if (sidx < prev_nsw)
                     for (int i = lane; i < nblk; i += 64) part_acc[h] += prev_partials[(size_t)sidx * nblk + i];
             }
@@ -247,8 +253,8 @@ __global__ __launch_bounds__(256) void k_jacobi_patch(const double* __restrict__
         if (done0) return;
         if (prev_nsw > 0) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int sidx = wv + 4 * h;
+            for (int h = 0; h < SPW; ++h) {
+                const int sidx = wv + NWV * h;
                 const double a = fpr_wave_sum_all(part_acc[h]);
                 if (lane == 0 && sidx < prev_nsw) red[0][sidx] = a;  // S >= prev_nsw
             }
@@ -338,7 +344,10 @@ __global__ __launch_bounds__(256) void k_jacobi_patch(const double* __restrict__
         __syncthreads();
         if (tid < S) {
             const int blk = blockIdx.x + gridDim.x * blockIdx.y, nblk = gridDim.x * gridDim.y;
-            partials[(size_t)tid * nblk + blk] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+            double v = red[0][tid];
+#pragma unroll
+            for (int w = 1; w < NWV; ++w) v += red[w][tid];
+            partials[(size_t)tid * nblk + blk] = v;
         }
     }
 }
@@ -1123,8 +1132,14 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
         ctx->state_h->done = 0; ctx->state_h->iters = 0; ctx->state_h->last_rms = 0.0;
         if (fpr_opt(ctx, "mg_multi", 1) && nx >= 32 && ny >= 32) {
             // groups of S fused sweeps per launch; the exit test is replayed per sweep on the device
-            constexpr int S = 8, TX = 16, TY = 16;
+            // k_jacobi_patch: 8 sweeps per launch on 32 x 32 regions (own tile 16 x 16, 256 threads), 1.25 us per sweep of the
+            // 257^2 grid (2.9 us launch boundary + loads + norms per launch, 0.5 us per sweep).  16 sweeps on 48 x 48 regions
+            // (576 threads) were measured at 1.40 us per sweep: a sweep of the larger region takes 1.0 us, twice as long.
+            constexpr int S8 = 8, TX = 16, TY = 16;
+            constexpr int PS = 8, PP = 32;
+            static_assert(PP - 2 * PS == TX, "both variants own 16 x 16 tiles");
             const bool patch = fpr_opt(ctx, "mg_patch", 1) != 0;
+            const int S = patch ? PS : S8;
             const dim3 gm((nx + TX - 1) / TX, (ny + TY - 1) / TY);
             const int nblk = (int)(gm.x * gm.y);
             if ((size_t)nblk * S > (size_t)FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
@@ -1147,12 +1162,12 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                         double* slot = ctx->partials + (size_t)(gi & 1) * S * nblk;
                         const double* pslot = ctx->partials + (size_t)((gi + 1) & 1) * S * nblk;
                         const bool pending = gi > gdone;  // the previous group of THIS chunk is still unchecked
-                        k_jacobi_patch<S, true, true><<<gm, 256, 0, s>>>(a, rhs, b, nx, ny, C, _h2, fac, nsw, slot, ctx->state,
-                                                                          pslot, pending ? Sg : 0, gi - 1, (double)N);
+                        k_jacobi_patch<PS, PP, true, true><<<gm, (PP / 2) * (PP / 2), 0, s>>>(a, rhs, b, nx, ny, C, _h2, fac, nsw, slot, ctx->state,
+                                                                                                pslot, pending ? Sg : 0, gi - 1, (double)N);
                         if (gi == gend - 1)  // last group of the chunk: stand-alone check before the host polls
                             k_jacobi_check_multi<<<1, 256, 0, s>>>(ctx->state, slot, nblk, nsw, (double)N, gi);
                     } else {
-                        k_sweep2d_multi<S, TX, TY, 2, true><<<gm, 256, 0, s>>>(a, rhs, b, nx, ny, C, _h2, fac, nsw, ctx->partials, ctx->state);
+                        k_sweep2d_multi<S8, TX, TY, 2, true><<<gm, 256, 0, s>>>(a, rhs, b, nx, ny, C, _h2, fac, nsw, ctx->partials, ctx->state);
                         k_jacobi_check_multi<<<1, 256, 0, s>>>(ctx->state, ctx->partials, nblk, nsw, (double)N, gi);
                     }
                     double* t = a; a = b; b = t;
@@ -1169,8 +1184,8 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                 double* out = (gs & 1) ? u : L.tmp;
                 const int nsw_g = (iters - gs * Sg < Sg) ? iters - gs * Sg : Sg;
                 if (redo < nsw_g) {  // the exit fell inside the group: recompute exactly `redo` sweeps from its input
-                    if (patch) k_jacobi_patch<S, false, false><<<gm, 256, 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, redo, nullptr, nullptr, nullptr, 0, 0, 0.0);
-                    else k_sweep2d_multi<S, TX, TY, 0, false><<<gm, 256, 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, redo, nullptr, nullptr);
+                    if (patch) k_jacobi_patch<PS, PP, false, false><<<gm, (PP / 2) * (PP / 2), 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, redo, nullptr, nullptr, nullptr, 0, 0, 0.0);
+                    else k_sweep2d_multi<S8, TX, TY, 0, false><<<gm, 256, 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, redo, nullptr, nullptr);
                 }
                 result = out;
             } else {

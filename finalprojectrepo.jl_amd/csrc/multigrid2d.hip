@@ -300,8 +300,16 @@ __global__ __launch_bounds__((P / 2) * (P / 2)) void k_jacobi_patch(const double
         if (s < nsw) {
             const double* cur = img[s & 1];
             double* nxt = img[(s + 1) & 1];
-            const double wl0 = cur[xl + P * ly], wl1 = cur[xl + P * (ly + 1)];
-            const double er0 = cur[xr + P * ly], er1 = cur[xr + P * (ly + 1)];
+            double wl0, wl1, er0, er1;
+            if constexpr (HT == 16) {
+                // a row of threads is one 16-lane DPP row: the x-neighbours of a patch come from the adjacent lanes' registers
+                // (zero beyond the region's edge: like the clamped reads, such garbage stays more than S cells from the own tile)
+                wl0 = fpr_dpp<0x111>(u[0][1]); wl1 = fpr_dpp<0x111>(u[1][1]);   // lane i <- lane i-1: its right column
+                er0 = fpr_dpp<0x101>(u[0][0]); er1 = fpr_dpp<0x101>(u[1][0]);   // lane i <- lane i+1: its left column
+            } else {
+                wl0 = cur[xl + P * ly]; wl1 = cur[xl + P * (ly + 1)];
+                er0 = cur[xr + P * ly]; er1 = cur[xr + P * (ly + 1)];
+            }
             const double2 dn = *reinterpret_cast<const double2*>(&cur[lx + P * yd]);
             const double2 up = *reinterpret_cast<const double2*>(&cur[lx + P * yu]);
             // E, W, N, S of each patch point

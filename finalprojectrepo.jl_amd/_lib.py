@@ -25,7 +25,8 @@ class FprError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libfpr_hip.so")
+    # FPR_LIB_PATH: another build of the same library (A/B runs of kernel variants from tools/); no fallback either way
+    return os.environ.get("FPR_LIB_PATH") or os.path.join(_HERE, "lib", "libfpr_hip.so")
 
 
 def build(verbose=False):

@@ -608,3 +608,42 @@ def test_fused_two_steps_two_z_ranges_in_one_launch(fpr, oracle, z2):
     assert (C == -3.0).all() and (D == -9.0).all()
     g1, g2 = (float(x) for x in sq2.tolist())
     assert abs(g1 - s1) <= 1e-13 * s1 and abs(g2 - s2) <= 1e-13 * s2
+
+
+def test_solver_loop_512_device_side_exit_test_equals_host_side(fpr):
+    """BASELINE config 2 size: fpr_diffusion3d_solve at 512^3 with its exit test on the device and pairs enqueued ahead
+    (default) against the loop that waits on the host for every norm -- same iteration counts, same errors, the same field
+    and residual bit for bit (compared on the device), for a tolerance the loop meets after a dozen iterations, for one it
+    meets on an odd iteration count and for an iter_max that cuts it off."""
+    import torch
+
+    F = fpr
+    c = F.ctx()
+    n = 512
+
+    def errs_after(k):   # the norm after k iterations (iter_max cuts the loop off)
+        _, H, _, info = F.part1.diffusion_3D_kernel_programming(nx=n, ny=n, nz=n, ttot=0.2, verbose=False, return_device=True,
+                                                                tol=1e-300, iter_max=k)
+        e = info["err"][0]
+        del H, info
+        return e
+
+    e11, e12 = errs_after(11), errs_after(12)
+    assert 0.0 < e12 < e11
+    # tolerances the loop meets exactly on its 12th (second of a pair) and on its 11th (first of a pair) iteration, and a cut-off
+    for kw in (dict(tol=e12 * (1 + 1e-9)), dict(tol=e11 * (1 + 1e-9)), dict(tol=1e-300, iter_max=9)):
+        outs = []
+        for ahead in (0, 2):
+            c.set_option("diff3_ahead", ahead)
+            try:
+                _, H, _, info = F.part1.diffusion_3D_kernel_programming(nx=n, ny=n, nz=n, ttot=0.2, verbose=False, return_device=True, **kw)
+                outs.append((H.clone(), list(info["iters"]), list(info["err"]), info["residual_H"].clone()))
+                del H, info
+            finally:
+                c.set_option("diff3_ahead", 2)
+        (H0, it0, e0, r0), (H1, it1, e1, r1) = outs
+        assert it0 == it1 and it0[0] in (9, 11, 12), (kw, it0, it1)
+        assert e0 == e1
+        assert torch.equal(H0, H1) and torch.equal(r0, r1)
+        del outs, H0, H1, r0, r1
+        torch.cuda.empty_cache()

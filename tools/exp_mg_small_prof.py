@@ -12,6 +12,7 @@ F = fpr_amd.load(0)
 mg = F.multigrid
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65
 css = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+cc = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0   # the c of (lap - c) u = f (NS solves: 1 / (beta dt) ~ 5e6)
 b = F.asdevice(F.part2.splitmix64_uniform(n * n, 1).reshape((n, n), order="F"))
 x = F.fzeros(n, n)
 opt = mg.MGOpt()
@@ -20,7 +21,7 @@ prof = torch.zeros(32, dtype=torch.int64, device=x.device)
 F.ctx().set_option("mg_small_prof", prof.data_ptr())
 for rep in range(3):
     x.zero_()
-    r = mg.Vcycle_2DPoisson_(x, b, 1.0 / (n - 1), 0.0, 1e-6, css, mg.jacobi, mg.parallel, False)
+    r = mg.Vcycle_2DPoisson_(x, b, 1.0 / (n - 1), cc, 1e-6, css, mg.jacobi, mg.parallel, False)
     F.synchronize()
     t = prof.cpu().numpy()
     k = int((t != 0).sum())

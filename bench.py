@@ -341,7 +341,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=512, help="local grid size per GPU (n^3)")
+    ap.add_argument("--n", "--local-n", dest="n", type=int, default=512,
+                    help="local grid size per GPU (n^3); under torch.distributed.run write --local-n (its parser takes --n for its own --nnodes)")
     ap.add_argument("--dims", type=str, default="", help="process grid, e.g. 2,2,2 (default: z-slabs 1,1,N)")
     ap.add_argument("--check-every", type=int, default=16, help="host convergence check every n iterations")
     ap.add_argument("--prewarm-ms", type=float, default=300.0, help="untimed pre-warm before the W warm-up steps")

@@ -158,5 +158,22 @@ int main()
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("dependent launches of an empty kernel: %.2f us per launch\n", ms * 1e3 / iters);
     }
+    {   // the same chain captured into a hipGraph and replayed
+        hipGraph_t graph; hipGraphExec_t exec;
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        for (int i = 0; i < iters; ++i) k_empty<<<64, 256, 0, s>>>(out);
+        CK(hipStreamEndCapture(s, &graph));
+        CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        float ms = 0.f;
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0, s));
+            CK(hipGraphLaunch(exec, s));
+            CK(hipEventRecord(e1, s));
+            CK(hipStreamSynchronize(s));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        printf("the same %d dependent launches replayed from a hipGraph: %.2f us per kernel node\n", iters, ms * 1e3 / iters);
+        CK(hipGraphExecDestroy(exec)); CK(hipGraphDestroy(graph));
+    }
     return 0;
 }

@@ -288,7 +288,7 @@ def host_staged_p2p(torch, dist):
 
     class Work:
         def __init__(self, w, host=None, dev=None):
-            self.w, self.host, self.dev = w, host, dev
+            self.w, self.host, self.dev = w, host, dev     # `host` also keeps a send's staging buffer alive until wait()
 
         def wait(self):
             self.w.wait()
@@ -318,7 +318,8 @@ def host_staged_p2p(torch, dist):
                     h = torch.empty(o.tensor.shape, dtype=o.tensor.dtype)
                     works.append(Work(dist.irecv(h, o.peer), h, o.tensor))
                 else:
-                    works.append(Work(dist.isend(o.tensor.cpu().contiguous(), o.peer)))
+                    h = o.tensor.cpu().contiguous()
+                    works.append(Work(dist.isend(h, o.peer), h))
             return works
 
         def all_reduce(self, t, op=None, group=None):

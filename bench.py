@@ -46,9 +46,12 @@ def self_launch(n):
     port = s.getsockname()[1]
     s.close()
     procs = []
+    # the control plane of self-launched ranks meets through a file (no window between probing a free port and its use);
+    # MASTER_ADDR / MASTER_PORT are still exported for anything that reads them
+    rdzv = os.path.join(os.environ.get("TMPDIR", "/tmp"), "fpr_bench_rdzv_%d_%d" % (os.getpid(), int(time.time() * 1e6)))
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FPR_BENCH_SELF_LAUNCHED="1")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FPR_BENCH_SELF_LAUNCHED="1", FPR_BENCH_RDZV_FILE=rdzv)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between processes)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
@@ -69,6 +72,10 @@ def self_launch(n):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+        try:
+            os.remove(rdzv)
+        except OSError:
+            pass
     sys.exit(rc)
 
 
@@ -373,7 +380,11 @@ def main():
     if use_dist:
         # control plane only (RCCL unique id, barriers, max over ranks): gloo on the host.  The data path -- halo planes
         # and the norm's all-reduce -- is RCCL inside libfpr_hip.so.
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        rdzv = os.environ.get("FPR_BENCH_RDZV_FILE")
+        if rdzv:
+            dist.init_process_group("gloo", init_method="file://" + rdzv, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
 

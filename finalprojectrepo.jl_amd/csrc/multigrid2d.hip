@@ -1369,6 +1369,7 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
 {
     if (!ctx) return FPR_ERR_INVALID;
     FPR_REQUIRE(ctx, u && f, "null pointer");
+    FPR_HIP(ctx, hipSetDevice(ctx->device));   // the calling thread may be a worker that has never selected the context's device
     if (int rc = check_dims(ctx, nx, ny)) return rc;
     {   // multigrid.jl:45-46
         const int m = coarse_solve_size - 1;

@@ -249,6 +249,9 @@ def vcycle_block(F, with_cpu=True, steps=5):
                                     "multigrid_bench.jl protocol (x=0, b~U[0,1), c=0, tol 1e-6)",
                         "mgsolve_s": out["l2_jacobi"]["mgsolve_s"], "vcycles": out["l2_jacobi"]["vcycles"]},
              "roofline": roof,
+             # BASELINE config 2 read literally ("4096^2, 5 levels"): coarse_solve_size = 257 (l = 8), the coarse 257^2 problem solved by
+             # 20 * 257 damped-Jacobi sweeps per cycle (the reference's default coarse solver) or by cg!
+             "five_levels_s_per_vcycle": {"jacobi": out["l8_jacobi"]["s_per_vcycle"], "conjugate_gradient": out["l8_cg"]["s_per_vcycle"]},
              "variants": {"five_levels_l8_cg": out["l8_cg"], "five_levels_l8_jacobi": out["l8_jacobi"]}}
     if with_cpu:
         try:

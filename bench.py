@@ -355,6 +355,10 @@ def main():
     ap.add_argument("--n", "--local-n", dest="n", type=int, default=512,
                     help="local grid size per GPU (n^3); under torch.distributed.run write --local-n (its parser takes --n for its own --nnodes)")
     ap.add_argument("--dims", type=str, default="", help="process grid, e.g. 2,2,2 (default: z-slabs 1,1,N)")
+    ap.add_argument("--as-one-rank-of", type=str, default="",
+                    help="a,b,c: run on ONE rank the global problem that a*b*c ranks with --n would run (local grid = "
+                         "dims*(n-2)+2, same physical size, same number of untimed steps) -- the control for the norm "
+                         "a decomposed run prints")
     ap.add_argument("--check-every", type=int, default=16, help="host convergence check every n iterations")
     ap.add_argument("--prewarm-ms", type=float, default=300.0, help="untimed pre-warm before the W warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -422,28 +426,37 @@ def main():
 
     n = args.n
     dims = tuple(int(x) for x in args.dims.split(",")) if args.dims else (1, 1, world)
-    gg = F.grid.GlobalGrid(n, n, n, dims=dims, transport=("dist" if shared else "rccl") if world > 1 else None)
+    as_one = tuple(int(x) for x in args.as_one_rank_of.split(",")) if args.as_one_rank_of else None
+    if as_one:
+        assert world == 1, "--as-one-rank-of is a single-rank control run"
+        nloc = tuple(d * (n - 2) + 2 for d in as_one)
+        phys = as_one
+    else:
+        nloc = (n, n, n)
+        phys = dims
+    gg = F.grid.GlobalGrid(*nloc, dims=dims, transport=("dist" if shared else "rccl") if world > 1 else None)
     if shared and world > 1:
         gg.dist = host_staged_p2p(torch, dist)
     rccl_ranks = ctx.L.fpr_comm_size(ctx.h)
     # physics as diffusion_3D_kernel_programming with scale_physical_size=true (weak scaling keeps dx fixed)
-    lx, ly, lz = (d * 10.0 for d in dims)
+    lx, ly, lz = (d * 10.0 for d in phys)
     dx, dy, dz = lx / gg.nx_g(), ly / gg.ny_g(), lz / gg.nz_g()
     D, dt = 1.0, 0.2
     dτ = min(dx, dy, dz) ** 2 / D / 8.1
     coef = (dτ, 1.0 / dt, 1.0 / dx, 1.0 / dy, 1.0 / dz, D / dx, D / dy, D / dz)
-    Ht = F.fzeros(n, n, n)
+    Ht = F.fzeros(*nloc)
     F.part1.init_local_gaussian((lx / 2, ly / 2, lz / 2), dx, dy, dz, Ht, gg.coords)
     Hτ = Ht.clone(memory_format=torch.preserve_format)
-    Hτ2 = F.fzeros(n, n, n)
-    res = F.fzeros(n, n, n)
+    Hτ2 = F.fzeros(*nloc)
+    res = F.fzeros(*nloc)
     # third work buffer for the fused pairs: carries Hτ's boundary; the field alternates between Hτ and Hτ3 while
     # Hτ2 keeps playing the reference's second buffer (its boundary cells / halo planes are all that is read)
     Hτ3 = Hτ.clone(memory_format=torch.preserve_format)
     can_fuse2 = gg.can_step2(Ht, Hτ, Hτ2, Hτ3, res)
     K, W, ce = args.steps, args.warmup, max(1, args.check_every)
     sq = torch.zeros(2 * (K + W + ce) + 64, dtype=torch.float64, device=Ht.device)
-    sqrtN = math.sqrt(world * n ** 3)
+    sqrtN = math.sqrt(world * nloc[0] * nloc[1] * nloc[2])
+    sums = []
 
     # field state: `cur` is the buffer holding the current field; parity 0 = an "even" buffer (Hτ or Hτ3, the
     # reference's first work buffer and its stand-in), parity 1 = Hτ2.  Fused pairs run even -> even.
@@ -464,7 +477,7 @@ def main():
             prev = i
             if fuse2 and state["parity"] == 0 and i + 1 < nsteps:
                 out = Hτ3 if state["cur"] is Hτ else Hτ
-                gg.step2(Ht, state["cur"], Hτ2, out, res, *coef, dt, sq[base + i:base + i + 2])
+                gg.step2(Ht, state["cur"], Hτ2, out, res, *coef, dt, sq[base + i:base + i + 2], join=False)
                 state["cur"] = out
                 i += 2
             else:
@@ -473,7 +486,8 @@ def main():
             if i // ce > prev // ce or i == nsteps:  # convergence check: all-reduce the chunk (RCCL), host reads it
                 chunk = sq[base + (prev // ce) * ce:base + i]
                 gg.allreduce_(chunk)
-                errs.append(math.sqrt(float(chunk[-1].item())) / sqrtN)
+                sums.append(float(chunk[-1].item()))
+                errs.append(math.sqrt(sums[-1]) / sqrtN)
 
     def barrier():
         torch.cuda.synchronize()
@@ -486,7 +500,7 @@ def main():
         barriers; returns max-over-ranks wall time and the per-kernel event times of the timed region."""
         # clock ramp, RCCL channel set-up.  Between ranks the number of pre-warm steps must be the SAME everywhere (every
         # step is a collective pattern): a fixed count there, a time budget on a single rank
-        if use_dist:
+        if use_dist or as_one:
             for _ in range(8 if prewarm_ms > 100 else 2):
                 run(8, 0, fuse2)
             torch.cuda.synchronize()
@@ -515,14 +529,14 @@ def main():
             elapsed = float(t.item())
         return elapsed, kt, extra
 
-    cells = (n - 2) ** 3
+    cells = (nloc[0] - 2) * (nloc[1] - 2) * (nloc[2] - 2)
     min_bytes = A_EFF_BYTES * cells     # what ONE launch must move at the very least, however many iterations it fuses
 
     def kernel_roofline(kind, kt, traffic_entry):
         ms_tot, cnt = kt[kind]
         ipl = 2 if kind == KT_STEP2 else 1
         if world > 1:
-            # between ranks one pass over the local grid is SEVERAL launches (shell boxes, thin slabs, two core halves):
+            # between ranks one pass over the local grid is SEVERAL launches (the core, and the shell boxes beside it):
             # price the pass, not the launch -- all diffusion launches of the timed region / passes in it
             ms_tot = kt[KT_STEP][0] + kt[KT_STEP2][0]
             cnt = max(K // ipl, 1)
@@ -538,7 +552,7 @@ def main():
              "effective_accounting": "SURVEY 8d: 32 B per interior cell per ITERATION x iterations per launch",
              "traffic": None, "traffic_source": None}
         if world > 1:
-            r["kernel"] += "; between ranks: all launches of one pass over the local grid (shell, thin slabs, core halves)"
+            r["kernel"] += "; between ranks: all launches of one pass over the local grid (core on the compute stream; shell boxes on the comm stream beside it)"
             r["launches_by_kind"] = {"single_step_boxes": kt[KT_STEP][1], "fused_boxes": kt[KT_STEP2][1]}
         if traffic_entry:
             r["traffic"] = traffic_entry["traffic_bytes_per_launch"]
@@ -551,7 +565,7 @@ def main():
         WRITE_SIZE, collected in separate passes -- tools/pmc_fused2.sh); recorded under profiles/, not measured live."""
         try:
             for tj in json.load(open(os.path.join(ROOT, "profiles", "diffusion_traffic.json")))["entries"]:
-                if tj.get("n") == n and world == 1 and tj.get("fuse2") == bool(fused):
+                if tj.get("n") == n and world == 1 and not as_one and tj.get("fuse2") == bool(fused):
                     return tj
         except Exception:
             pass
@@ -560,6 +574,7 @@ def main():
     main_fused = can_fuse2 and not args.no_fuse2
     elapsed, kt, extra = timed_leg(main_fused, args.prewarm_ms)
     last_err = errs[-1] if errs else None
+    last_sumsq = sums[-1] if sums else None
     value = A_EFF_BYTES * cells * world * K / elapsed / 1e9
     main_kind = KT_STEP2 if main_fused else KT_STEP
     roofline = kernel_roofline(main_kind, kt, traffic_for(main_fused))
@@ -585,7 +600,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "3D pseudo-transient diffusion, %d^3 cells per GPU, fused 7-pt update + fused norm%s"
                                % (n, ", two iterations per launch (temporal blocking)" if main_fused else ""),
-                   "local_grid": [n, n, n], "process_grid": list(dims), "global_grid": [gg.nx_g(), gg.ny_g(), gg.nz_g()],
+                   "local_grid": list(nloc), "process_grid": list(dims), "global_grid": [gg.nx_g(), gg.ny_g(), gg.nz_g()],
                    "bytes_per_cell_per_iteration": A_EFF_BYTES,
                    "norm": "fused every iteration; all-reduce + host check every %d" % ce,
                    "halo": ("RCCL ncclSend/ncclRecv groups inside libfpr_hip.so on the comm stream, overlapped with the "
@@ -594,7 +609,7 @@ def main():
                    "self_launched": os.environ.get("FPR_BENCH_SELF_LAUNCHED") == "1",
                    "pct_of_hbm_peak_effective_per_gpu": 100.0 * value / world / HBM_PEAK_GBS,
                    "pct_of_hbm_peak_physical_dominant_kernel": 100.0 * roofline["frac"],
-                   "last_err": last_err},
+                   "last_err": last_err, "last_sumsq": last_sumsq},
         "roofline": roofline,
         "legs": legs,
     }
@@ -622,7 +637,7 @@ def main():
         def pair_nores(nsteps):
             for i in range(nsteps // 2):
                 outb = Hτ3 if state["cur"] is Hτ else Hτ
-                ctx.call("fpr_diffusion3d_step2", fp(Ht, 3), fp(state["cur"], 3), fp(Hτ2, 3), fp(outb, 3), None, n, n, n, *coef, dt,
+                ctx.call("fpr_diffusion3d_step2", fp(Ht, 3), fp(state["cur"], 3), fp(Hτ2, 3), fp(outb, 3), None, *nloc, *coef, dt,
                          sq[2 * i:2 * i + 2].data_ptr())
                 state["cur"] = outb
         pair_nores(W + (W & 1))

@@ -46,6 +46,8 @@ _SIG = {
     "fpr_synchronize": [_vp],
     "fpr_set_option": [_vp, C.c_char_p, _l],
     "fpr_stream_wait": [_vp, _i, _i],
+    "fpr_reserve_comm_cus": [_vp, _i],
+    "fpr_stream_handle": [_vp, _i, C.POINTER(_vp)],
     "fpr_kernel_timer": [_vp, _i],
     "fpr_kernel_timer_read": [_vp, _i, C.POINTER(_d), C.POINTER(_l)],
     "fpr_diffusion3d_step": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8,
@@ -58,6 +60,7 @@ _SIG = {
     "fpr_diffusion3d_step2": [_vp] + [_dp] * 5 + [_i] * 3 + [_d] * 8 + [_d, _dp],
     "fpr_diffusion3d_step2_box": [_vp] + [_dp] * 5 + [_i] * 3 + [_d] * 8 + [C.POINTER(_i), C.POINTER(_i), _d, _dp, _i],
     "fpr_diffusion3d_step2_box2": [_vp] + [_dp] * 5 + [_i] * 3 + [_d] * 8 + [C.POINTER(_i), C.POINTER(_i), _i, _i, _d, _dp, _i],
+    "fpr_diffusion3d_step2_core": [_vp] + [_dp] * 5 + [_i] * 3 + [_d] * 8 + [C.POINTER(_i), C.POINTER(_i), _d, _dp, _i, _i, _i],
     "fpr_diffusion3d_flux": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 4,
     "fpr_diffusion3d_dHdtau": [_vp] + [_dp] * 6 + [_i] * 3 + [_d] * 4,
     "fpr_diffusion3d_update": [_vp] + [_dp] * 2 + [_i] * 3 + [_d],
@@ -67,6 +70,8 @@ _SIG = {
     "fpr_absmax": [_vp, _dp, _z, C.POINTER(_d)],
     "fpr_copy": [_vp, _dp, _dp, _z],
     "fpr_fill": [_vp, _dp, _d, _z],
+    "fpr_fill_on": [_vp, _dp, _d, _z, _i],
+    "fpr_add_on": [_vp, _dp, _dp, _z, _i],
     "fpr_init_gaussian3d": [_vp, _dp] + [_i] * 3 + [_d] * 6 + [_i] * 3,
     "fpr_halo_pack3d": [_vp, _dp, _i, _i, _i, _i, _dp, _i],
     "fpr_halo_unpack3d": [_vp, _dp, _i, _i, _i, _i, _dp, _i],
@@ -77,6 +82,7 @@ _SIG = {
     "fpr_halo_exchange3d": [_vp, _dp, _i, _i, _i],
     "fpr_halo_exchange3d_begin": [_vp, _dp, _i, _i, _i, _i],
     "fpr_halo_exchange3d_end": [_vp, _dp, _i, _i, _i, _i],
+    "fpr_halo_exchange3d_comm": [_vp, _dp, _i, _i, _i, _i],
     "fpr_allreduce_sum_dev": [_vp, _dp, _i, _i],
     "fpr_allreduce_sum1": [_vp, C.POINTER(_d)],
     "fpr_gather3d": [_vp, _dp, _i, _i, _i, _vp],
@@ -103,7 +109,7 @@ _SIG = {
 }
 # every symbol include/fpr.h declares (checked by tests/test_abi.py)
 ALL_SYMBOLS = sorted(list(_SIG) + ["fpr_last_error", "fpr_version", "fpr_get_option", "fpr_last_coarse_iters",
-                                   "fpr_comm_get_unique_id", "fpr_comm_rank", "fpr_comm_size"])
+                                   "fpr_comm_get_unique_id", "fpr_comm_rank", "fpr_comm_size", "fpr_comm_cus"])
 
 
 def load_library():
@@ -132,7 +138,7 @@ def load_library():
     L.fpr_last_coarse_iters.restype = _l
     L.fpr_comm_get_unique_id.argtypes = [_vp]
     L.fpr_comm_get_unique_id.restype = _i
-    for name in ("fpr_comm_rank", "fpr_comm_size"):
+    for name in ("fpr_comm_rank", "fpr_comm_size", "fpr_comm_cus"):
         getattr(L, name).argtypes = [_vp]
         getattr(L, name).restype = _i
     _LIB = L
@@ -210,6 +216,7 @@ class Context:
         torch.cuda.synchronize(device)
         self.compute = torch.cuda.Stream(device=device)
         self.comm = torch.cuda.Stream(device=device)
+        self._comm0 = self.comm
         if not secondary:
             torch.cuda.set_stream(self.compute)
         h = _vp()
@@ -227,6 +234,20 @@ class Context:
         if rc != 0:
             raise FprError(rc, self.L.fpr_last_error(self.h).decode())
         return rc
+
+    def reserve_comm_cus(self, k):
+        """fpr_reserve_comm_cus: the comm stream becomes a library-owned stream on k compute units (0: the torch stream
+        given at creation again); self.comm follows, so torch work placed on it lands on the same stream."""
+        torch = _torch()
+        if self.L.fpr_comm_cus(self.h) == int(k):
+            return
+        self.call("fpr_reserve_comm_cus", int(k))
+        if k > 0:
+            h = _vp()
+            self.call("fpr_stream_handle", 1, C.byref(h))
+            self.comm = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", self.device))
+        else:
+            self.comm = self._comm0
 
     def set_option(self, key, value):
         self.call("fpr_set_option", key.encode(), int(value))

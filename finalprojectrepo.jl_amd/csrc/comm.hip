@@ -196,21 +196,31 @@ static int post_group(fpr_ctx* ctx, double* A, int mask, hipStream_t s)
     for (int f = 0; f < 6; ++f) any |= ((mask >> f) & 1) && g.nb[f] >= 0;
     if (!any) return FPR_OK;
     FPR_NCCL(ctx, ncclGroupStart());
-    for (int d = 0; d < 3; ++d)
-        for (int side = 0; side < 2; ++side) {
+    // an error inside the group must not leave it open (later RCCL calls of this thread would be deferred for ever):
+    // remember the first failure, always close the group, then report
+    ncclResult_t first = ncclSuccess;
+    const char* what = "";
+    for (int d = 0; d < 3 && first == ncclSuccess; ++d)
+        for (int side = 0; side < 2 && first == ncclSuccess; ++side) {
             const int f = 2 * d + side;
             if (!((mask >> f) & 1) || g.nb[f] < 0) continue;
             double* dst = d == 2 ? A + (side ? (size_t)(nz - 1) * pz : 0) : g.recvbuf[f];
-            FPR_NCCL(ctx, ncclRecv(dst, count[d], ncclDouble, g.nb[f], comm_of(ctx), s));
+            first = ncclRecv(dst, count[d], ncclDouble, g.nb[f], comm_of(ctx), s);
+            what = "ncclRecv";
         }
-    for (int d = 0; d < 3; ++d)
-        for (int side = 1; side >= 0; --side) {
+    for (int d = 0; d < 3 && first == ncclSuccess; ++d)
+        for (int side = 1; side >= 0 && first == ncclSuccess; --side) {
             const int f = 2 * d + side;
             if (!((mask >> f) & 1) || g.nb[f] < 0) continue;
             const double* src = d == 2 ? A + (side ? (size_t)(nz - 2) * pz : pz) : g.sendbuf[f];
-            FPR_NCCL(ctx, ncclSend(src, count[d], ncclDouble, g.nb[f], comm_of(ctx), s));
+            first = ncclSend(src, count[d], ncclDouble, g.nb[f], comm_of(ctx), s);
+            what = "ncclSend";
         }
-    FPR_NCCL(ctx, ncclGroupEnd());
+    const ncclResult_t end = ncclGroupEnd();
+    if (first != ncclSuccess)
+        return fpr_fail(ctx, FPR_ERR_RCCL, "%s:%d %s -> %s (group closed: %s)", __FILE__, __LINE__, what, ncclGetErrorString(first),
+                        ncclGetErrorString(end));
+    if (end != ncclSuccess) return fpr_fail(ctx, FPR_ERR_RCCL, "%s:%d ncclGroupEnd -> %s", __FILE__, __LINE__, ncclGetErrorString(end));
     return FPR_OK;
 }
 
@@ -248,6 +258,30 @@ extern "C" int fpr_halo_exchange3d_end(fpr_ctx* ctx, double* A, int nx, int ny, 
     for (int f = 0; f < 4; ++f)
         if (((face_mask >> f) & 1) && g.nb[f] >= 0)
             if (int rc = fpr_halo_unpack3d(ctx, A, nx, ny, nz, f, g.recvbuf[f], 0)) return rc;
+    return FPR_OK;
+}
+
+// The whole exchange on the COMM stream, in stream order: pack the x / y planes, one group of sends / receives, unpack.
+// For callers that keep a chain of thin-box launches and exchanges on the comm stream beside one long launch on the
+// compute stream (the fused pairs of a decomposed run, GlobalGrid.step2): no event between the two streams per exchange.
+// As with _begin/_end all faces travel concurrently: edge and corner halo cells are not refreshed.
+extern "C" int fpr_halo_exchange3d_comm(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face_mask)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    if (int rc = check_grid(ctx, A, nx, ny, nz)) return rc;
+    const FprGrid& g = ctx->grid;
+    bool any = false;
+    for (int f = 0; f < 6; ++f) {
+        if (!((face_mask >> f) & 1) || g.nb[f] < 0) continue;
+        any = true;
+        if ((f >> 1) != 2)
+            if (int rc = fpr_halo_pack3d(ctx, A, nx, ny, nz, f, g.sendbuf[f], 1)) return rc;
+    }
+    if (!any) return FPR_OK;
+    if (int rc = post_group(ctx, A, face_mask, ctx->stream[1])) return rc;
+    for (int f = 0; f < 4; ++f)
+        if (((face_mask >> f) & 1) && g.nb[f] >= 0)
+            if (int rc = fpr_halo_unpack3d(ctx, A, nx, ny, nz, f, g.recvbuf[f], 1)) return rc;
     return FPR_OK;
 }
 

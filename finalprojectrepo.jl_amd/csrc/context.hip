@@ -23,6 +23,8 @@ extern "C" int fpr_ctx_create(fpr_ctx** out, int device, void* compute_stream, v
         }
         if (hipEventCreateWithFlags(&ctx->ev[s], hipEventDisableTiming) != hipSuccess) { delete ctx; return FPR_ERR_HIP; }
     }
+    ctx->stream[2] = ctx->stream[0];
+    if (hipEventCreateWithFlags(&ctx->ev[2], hipEventDisableTiming) != hipSuccess) { delete ctx; return FPR_ERR_HIP; }
     bool ok = hipMalloc(&ctx->partials, (FPR_MAX_PARTIALS + 256) * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->partials2, (FPR_MAX_PARTIALS + 256) * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->scalars, 64 * sizeof(double)) == hipSuccess &&
@@ -45,6 +47,7 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
     for (int s = 0; s < 2; ++s)
         if (ctx->stream[s]) hipStreamSynchronize(ctx->stream[s]);
     fpr_comm_finalize(ctx);
+    fpr_reserve_comm_cus(ctx, 0);
     for (auto& kv : ctx->arenas)
         for (auto& L : kv.second) {
             if (L.tmp) hipFree(L.tmp);
@@ -67,6 +70,7 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
         if (ctx->ev[s]) hipEventDestroy(ctx->ev[s]);
         if (ctx->own_stream[s] && ctx->stream[s]) hipStreamDestroy(ctx->stream[s]);
     }
+    if (ctx->ev[2]) hipEventDestroy(ctx->ev[2]);
     delete ctx;
     return FPR_OK;
 }
@@ -76,6 +80,61 @@ extern "C" int fpr_synchronize(fpr_ctx* ctx)
     if (!ctx) return FPR_ERR_INVALID;
     FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
     FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));
+    if (ctx->stream[2] != ctx->stream[0]) FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[2]));
+    return FPR_OK;
+}
+
+// Split the device between two library-owned streams (hipExtStreamCreateWithCUMask): stream 1 (comm) may use k compute
+// units, stream 2 (core) all the others.  Why masks and not just a smaller grid: a workgroup of a second queue is dealt
+// to a shader engine and WAITS there when that engine has no room, even with idle units elsewhere
+// (tools/cu_share_probe.hip, profiles/r3_cu_share_probe.txt: beside a launch that fills 244 of 256 units three quarters
+// of a 128-workgroup guest kernel started only when the launch ended; with masks every workgroup started at once).
+// The low k mask bits go to the comm stream: on gfx950 bit b is unit (b / 8 / 4) of shader engine (b / 8) % 4 of XCD b % 8,
+// so they spread over the XCDs first, then over the engines.  k = 0: back to the caller's streams (stream 2 = stream 0).
+extern "C" int fpr_reserve_comm_cus(fpr_ctx* ctx, int k)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    if (k == ctx->comm_cus) return FPR_OK;
+    FPR_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->ncu <= 0) {
+        int v = 0;
+        ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
+    }
+    FPR_REQUIRE(ctx, k >= 0 && k <= ctx->ncu / 2, "0 <= k <= half the compute units");
+    // the same number of units out of every shader engine (32 engines of 8 units on MI355X): a workgroup is dealt to an engine
+    // and waits THERE for room, so a lopsided split leaves one unit with two workgroups of a launch that has one per unit
+    FPR_REQUIRE(ctx, k % 32 == 0 || ctx->ncu != 256, "k must be a multiple of 32 (units per shader engine stay equal)");
+    if (ctx->comm_cus > 0) {   // drop the masked streams
+        for (int s = 0; s < 3; ++s) FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[s]));
+        ctx->stream[1] = ctx->caller_comm;
+        ctx->stream[2] = ctx->stream[0];
+        for (int m = 0; m < 2; ++m) {
+            if (ctx->masked[m]) hipStreamDestroy(ctx->masked[m]);
+            ctx->masked[m] = nullptr;
+        }
+        ctx->comm_cus = 0;
+    }
+    if (k == 0) return FPR_OK;
+    const int words = (ctx->ncu + 31) / 32;
+    std::vector<uint32_t> mc(words, 0u), mr(words, 0u);
+    for (int b = 0; b < ctx->ncu; ++b) (b < k ? mc : mr)[b / 32] |= 1u << (b % 32);
+    FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));
+    FPR_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->masked[0], (uint32_t)words, mc.data()));
+    FPR_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->masked[1], (uint32_t)words, mr.data()));
+    ctx->caller_comm = ctx->stream[1];
+    ctx->stream[1] = ctx->masked[0];
+    ctx->stream[2] = ctx->masked[1];
+    ctx->comm_cus = k;
+    return FPR_OK;
+}
+
+extern "C" int fpr_comm_cus(fpr_ctx* ctx) { return ctx ? ctx->comm_cus : -1; }
+
+// hipStream_t behind a selector (0 compute, 1 comm, 2 core), for host code that enqueues its own work on them
+extern "C" int fpr_stream_handle(fpr_ctx* ctx, int sel, void** out)
+{
+    if (!ctx || !out || sel < 0 || sel > 2) return FPR_ERR_INVALID;
+    *out = (void*)ctx->stream[sel];
     return FPR_OK;
 }
 
@@ -128,8 +187,8 @@ extern "C" int fpr_kernel_timer_read(fpr_ctx* ctx, int kind, double* total_ms_ho
 
 extern "C" int fpr_stream_wait(fpr_ctx* ctx, int waiter, int signaller)
 {
-    if (!ctx || waiter < 0 || waiter > 1 || signaller < 0 || signaller > 1) return FPR_ERR_INVALID;
-    if (waiter == signaller) return FPR_OK;
+    if (!ctx || waiter < 0 || waiter > 2 || signaller < 0 || signaller > 2) return FPR_ERR_INVALID;
+    if (ctx->stream[waiter] == ctx->stream[signaller]) return FPR_OK;
     FPR_HIP(ctx, hipEventRecord(ctx->ev[signaller], ctx->stream[signaller]));
     FPR_HIP(ctx, hipStreamWaitEvent(ctx->stream[waiter], ctx->ev[signaller], 0));
     return FPR_OK;
@@ -226,7 +285,7 @@ int fprx_finish_sum(fpr_ctx* ctx, const double* partials, int nparts, double* ou
         // The folded values live behind the partial list itself (the buffers hold FPR_MAX_PARTIALS + 256).
         const int nb = 128;
         const int per = (nparts + nb - 1) / nb;
-        double* fold = (stream_sel ? ctx->partials2 : ctx->partials) + FPR_MAX_PARTIALS;
+        double* fold = (stream_sel == 1 ? ctx->partials2 : ctx->partials) + FPR_MAX_PARTIALS;
         k_fold_partials<<<nb, 256, 0, ctx->stream[stream_sel]>>>(partials, nparts, per, fold);
         partials = fold;
         nparts = nb;
@@ -361,7 +420,7 @@ int fprx_finish_sum2(fpr_ctx* ctx, const double* p0, const double* p1, int npart
 int fprx_sumsq_scaled_dev(fpr_ctx* ctx, const double* x, size_t n, double scale, double* out_dev, int stream_sel)
 {
     const int g = flat_grid(n);
-    double* part = stream_sel ? ctx->partials2 : ctx->partials;
+    double* part = stream_sel == 1 ? ctx->partials2 : ctx->partials;
     k_reduce<0><<<g, 256, 0, ctx->stream[stream_sel]>>>(x, nullptr, n, scale, part);
     FPR_CHECK_LAUNCH(ctx);
     return fprx_finish_sum(ctx, part, g, out_dev, false, stream_sel);
@@ -436,6 +495,34 @@ extern "C" int fpr_fill(fpr_ctx* ctx, double* dst, double value, size_t n)
     FPR_REQUIRE(ctx, dst, "null pointer");
     if (n == 0) return FPR_OK;
     k_fill<<<flat_grid(n), 256, 0, ctx->stream[0]>>>(dst, value, n);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+__global__ __launch_bounds__(256) void k_addto(double* __restrict__ dst, const double* __restrict__ src, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = dst[i] + src[i];
+}
+
+// fill / dst += src on a chosen stream (0 compute, 1 comm, 2 core): the norm accumulators of a decomposed run's fused
+// pair live on the comm and core streams, and nothing of a pair should have to pass through the compute stream
+extern "C" int fpr_fill_on(fpr_ctx* ctx, double* dst, double value, size_t n, int stream_sel)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, dst && stream_sel >= 0 && stream_sel <= 2, "null pointer / stream_sel");
+    if (n == 0) return FPR_OK;
+    k_fill<<<flat_grid(n), 256, 0, ctx->stream[stream_sel]>>>(dst, value, n);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+extern "C" int fpr_add_on(fpr_ctx* ctx, double* dst, const double* src, size_t n, int stream_sel)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, dst && src && stream_sel >= 0 && stream_sel <= 2, "null pointer / stream_sel");
+    if (n == 0) return FPR_OK;
+    k_addto<<<flat_grid(n), 256, 0, ctx->stream[stream_sel]>>>(dst, src, n);
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
 }

@@ -111,13 +111,14 @@ static bool diff3_fuse2_ok(fpr_ctx* ctx, const double* Ht, const double* A, cons
 static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const double* B, double* C, double* dH, int nx,
                       int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy,
                       double D_dz, const int* lo, const int* hi, double scale, double* sumsq2_dev, bool accumulate,
-                      int stream_sel, int zlo2 = 0, int zhi2 = 0, const int* skip = nullptr, int* nparts_only = nullptr)
+                      int stream_sel, int zlo2 = 0, int zhi2 = 0, const int* skip = nullptr, int* nparts_only = nullptr,
+                      int reserve_cus = 0)
 {   // nparts_only: the launch reduces both norms to per-workgroup partials (partials1 / partials2 of the stream's scratch) and
     // leaves the finishing to the caller: *nparts_only = their number
     if (!ctx) return FPR_ERR_INVALID;
     FPR_REQUIRE(ctx, Ht && A && B && C, "null field pointer");   // dH may be null: residual not stored
     FPR_REQUIRE(ctx, A != C && B != C && A != B, "Htau, Hmid and Hout must be three distinct buffers");
-    FPR_REQUIRE(ctx, stream_sel == 0 || stream_sel == 1, "stream_sel");
+    FPR_REQUIRE(ctx, stream_sel >= 0 && stream_sel <= 2, "stream_sel");
     FPR_REQUIRE(ctx, diff3_fuse2_ok(ctx, Ht, A, B, C, dH, nx, ny, nz), "problem not supported by the fused two-step kernel");
     Diff3Args2 a;
     a.skip = skip;
@@ -131,7 +132,9 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
     a.dtau = dtau; a._dt = _dt; a._dx = _dx; a._dy = _dy; a._dz = _dz;
     a.D_dx = D_dx; a.D_dy = D_dy; a.D_dz = D_dz;
     a.scale = scale;
-    double* base = stream_sel ? ctx->partials2 : ctx->partials;
+    double* base = stream_sel == 1 ? ctx->partials2 : ctx->partials;
+    // a launch on the core stream of a split device (fpr_reserve_comm_cus) has that many units less, whatever the caller says
+    if (stream_sel == 2 && ctx->comm_cus > reserve_cus) reserve_cus = ctx->comm_cus;
     a.partials1 = base;
     a.partials2 = base + FPR_MAX_PARTIALS / 2;
     const bool norm = sumsq2_dev != nullptr || nparts_only != nullptr;
@@ -163,10 +166,14 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
                 e = diff3_launch_slab2(b, norm, ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2 - nparts, &np2);
                 nparts += np2;
             }
-        } else
+        } else {
+            if (reserve_cus > 0 && fpr_opt(ctx, "diff3_bal_g", 0) > 0) reserve_cus = -(int)fpr_opt(ctx, "diff3_bal_g", 0);   // tests
+            long bal_info = 0;
             e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), (int)fpr_opt(ctx, "diff3_xcd2", 0) & 3,
                               ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2, &nparts,
-                              (int)fpr_opt(ctx, "diff3_nw2", 0), ctx->ncu, zlo2, zhi2);
+                              (int)fpr_opt(ctx, "diff3_nw2", 0), ctx->ncu, zlo2, zhi2, reserve_cus, &bal_info);
+            if (reserve_cus != 0) ctx->options["diff3_last_bal"] = bal_info;   // diagnostic (fpr_get_option): which form ran
+        }
         fpr_ktimer_end(ctx, timed, ctx->stream[stream_sel]);
         if (e != hipSuccess) return fpr_fail(ctx, FPR_ERR_HIP, "fused diffusion3d launch: %s", hipGetErrorString(e));
     }
@@ -444,6 +451,21 @@ extern "C" int fpr_diffusion3d_step2_box2(fpr_ctx* ctx, const double* Ht, const 
     FPR_REQUIRE(ctx, zlo2 >= hi[2] || zhi2 <= lo[2] || zhi2 <= zlo2, "the two z-ranges must not overlap");
     return diff3_run2(ctx, Ht, Htau, Hmid, Hout, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo, hi,
                       scale, sumsq2_dev, true, stream_sel, zlo2, zhi2);
+}
+
+// The CORE box of a decomposed run's fused pair, launched so that `reserve_cus` compute units stay without a workgroup
+// of it: the shell launches and RCCL's send / receive kernels of the pair run beside it on the comm stream (role of
+// @hide_communication, part1_kernel_programming.jl:185-188, for two iterations at once).  Same results as _step2_box.
+extern "C" int fpr_diffusion3d_step2_core(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hmid,
+                                          double* Hout, double* dHdtau, int nx, int ny, int nz, double dtau, double _dt,
+                                          double _dx, double _dy, double _dz, double D_dx, double D_dy, double D_dz,
+                                          const int lo[3], const int hi[3], double scale, double* sumsq2_dev, int stream_sel,
+                                          int reserve_cus, int accumulate)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, lo && hi && reserve_cus >= 0, "null box / negative reserve");
+    return diff3_run2(ctx, Ht, Htau, Hmid, Hout, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo, hi,
+                      scale, sumsq2_dev, accumulate != 0, stream_sel, 0, 0, nullptr, nullptr, reserve_cus);
 }
 
 extern "C" int fpr_diffusion3d_step_box(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2,

@@ -56,6 +56,11 @@ struct Diff3Args2 {
     int xalign;                     // 1: x-tile cut points sit in the middle of 128-byte lines
     int zb_lo, zb_hi, ntz_a;        // optional second z-range [zb_lo, zb_hi) with the same x/y box: chunks tz >= ntz_a
     int xcd_remap;
+    // reserved form (k_diff3_march2<..., BAL = true>; decomposed runs that leave compute units to the halo exchange): the
+    // launch has G = gridDim.x workgroups where the plain grid has G + bal_r (tile, chunk) units.  Workgroup g first serves
+    // unit g like the plain grid (same tiles marching in lockstep, same block -> XCD mapping), then a slice of bal_q planes
+    // of one of the bal_r left-over units: unit G + g / bal_sp, slice g % bal_sp.
+    int bal_r, bal_sp, bal_q;
     const int* skip;                // fpr_diffusion3d_solve with pairs enqueued ahead of its exit test: return at once if *skip (nullptr = unconditional)
 #ifdef FPR_TUNE
     int dbg;                        // tuning harness only (tools/, -DFPR_TUNE): 1 = drop all stores, 2 = drop all loads of the z-loop
@@ -158,7 +163,10 @@ __device__ __forceinline__ double diff3_block_sum_waves(double v, double* red, i
 
 // WRES = false: the residual of the second step is not written to memory (a solver loop that only needs its norm:
 // 24 instead of 32 bytes per cell and launch, and two stores less per row)
-template <bool NORM, int NW = 4, bool WRES = true>
+// BAL = true: the grid is SHORT of the plain (tile, chunk) grid by a few units (device slots minus the compute units left
+// to RCCL and the shell launches of a decomposed run); every workgroup serves its own unit and then a thin slice of one of
+// the left-over units, so the launch still finishes in one balanced round and its tiles still march in lockstep.
+template <bool NORM, int NW = 4, bool WRES = true, bool BAL = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3Args2 a)
 {
     constexpr int VX = 2, RY = 4, TXW = 128, SYB = NW * RY - 2;
@@ -176,17 +184,31 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: rows, halo sources and row masks stay scalar
 
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
+    const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+    double tot1 = 0.0, tot2 = 0.0;   // per-lane sums over the owned cells of all chunks of this workgroup (NORM)
+
+    constexpr int NITEM = BAL ? 2 : 1;
+#pragma unroll 1
+    for (int item = 0; item < NITEM; ++item) {
+    int tx, by, k0, k1;
+    int slice = -1;
     int bid = blockIdx.x;
-    if (a.xcd_remap == 1) {
+    if (BAL && item == 1) {
+        const int j = bid / a.bal_sp;
+        if (j >= a.bal_r) break;                           // block-uniform: no left-over slice for this workgroup
+        slice = bid - j * a.bal_sp;
+        bid = gridDim.x + j;
+    } else if (a.xcd_remap == 1) {
         const int nblk = gridDim.x;
         const int q = nblk >> 3, rem = nblk & 7;
         const int xcd = bid & 7, slot = bid >> 3;
         bid = xcd * q + (xcd < rem ? xcd : rem) + slot;
     }
-    int tx = bid % a.ntx;
-    int by = (bid / a.ntx) % a.nby;
+    tx = bid % a.ntx;
+    by = (bid / a.ntx) % a.nby;
     int tz = bid / (a.ntx * a.nby);
-    if (a.xcd_remap == 2) {
+    if (!BAL && a.xcd_remap == 2) {
         // z-chunk ownership: XCD x (= blockIdx % 8, the hardware's round-robin) processes the chunks tz = x, x+8, ...
         // one after the other, so the workgroups resident on an XCD are x/y neighbours of ONE chunk (host: ntz % 8 == 0)
         const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
@@ -196,9 +218,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
         tx = rem % a.ntx;
         by = rem / a.ntx;
     }
-
-    const int nx = a.nx, ny = a.ny, nz = a.nz;
-    const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+    // z: owned planes [k0, k1)
+    const bool zsecond = tz >= a.ntz_a;          // chunk of the second z-range (two thin boxes in one launch)
+    const int zlo = zsecond ? a.zb_lo : a.lo[2], zhi = zsecond ? a.zb_hi : a.hi[2];
+    k0 = zlo + (zsecond ? tz - a.ntz_a : tz) * a.zc;
+    k1 = (k0 + a.zc < zhi) ? k0 + a.zc : zhi;
+    if (BAL && item == 1) {
+        k0 += slice * a.bal_q;
+        k1 = (k0 + a.bal_q < k1) ? k0 + a.bal_q : k1;
+        if (k1 <= k0) break;                               // block-uniform
+        __syncthreads();                                   // the first unit's last LDS rows are still being read
+    }
 
     // ---- x: owned output cells [ol, oh) (cut points between tiles are even); own cells [s, s+128) ----
     const int e0 = a.lo[0] & ~1;
@@ -244,11 +274,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
     const double* Hsrc = (w == 0) ? (bb ? a.B : a.A) : (bt ? a.B : a.A);
     const int hrow = (w == 0) ? jd : ju;
 
-    // ---- z: owned planes [k0, k1); iterations m0 .. m1 ----
-    const bool zsecond = tz >= a.ntz_a;          // chunk of the second z-range (two thin boxes in one launch)
-    const int zlo = zsecond ? a.zb_lo : a.lo[2], zhi = zsecond ? a.zb_hi : a.hi[2];
-    const int k0 = zlo + (zsecond ? tz - a.ntz_a : tz) * a.zc;
-    const int k1 = (k0 + a.zc < zhi) ? k0 + a.zc : zhi;
+    // ---- z: owned planes [k0, k1) (above); iterations m0 .. m1 ----
     const int m0 = k0 - 1, m1 = k1;
 
     bool cm[VX], rm[RY];
@@ -475,11 +501,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
     if (m <= m1) { step(std::integral_constant<int, 2>{}, T{}, m); ++m; }
     if (m <= m1) { step(std::integral_constant<int, 0>{}, T{}, m); ++m; }
 
+    // lanes accumulate every cell of the owned rows / planes; cells the lane does not own are dropped here
     if constexpr (NORM) {
-        // lanes accumulate every cell of the owned rows / planes; cells the lane does not own are dropped here
+        tot1 += (cm[0] ? acc1[0] : 0.0) + (cm[1] ? acc1[1] : 0.0);
+        tot2 += (cm[0] ? acc2[0] : 0.0) + (cm[1] ? acc2[1] : 0.0);
+    }
+    }   // item
+
+    if constexpr (NORM) {
         const double sc2 = a.scale * a.scale;
-        const double l1 = ((cm[0] ? acc1[0] : 0.0) + (cm[1] ? acc1[1] : 0.0)) * sc2;
-        const double l2 = ((cm[0] ? acc2[0] : 0.0) + (cm[1] ? acc2[1] : 0.0)) * sc2;
+        const double l1 = tot1 * sc2;
+        const double l2 = tot2 * sc2;
         const double s1 = diff3_block_sum_waves<NW>(l1, red, tid);
         const double s2 = diff3_block_sum_waves<NW>(l2, red + NW, tid);
         if (tid == 0) { a.partials1[blockIdx.x] = s1; a.partials2[blockIdx.x] = s2; }
@@ -497,13 +529,17 @@ static inline bool diff3_can_fuse2(const double* Ht, const double* A, const doub
 // Launch on `stream`; *nparts = number of per-block partials written to each of partials1/partials2 (norm only).
 // zc_opt: planes per z-chunk (0 = auto), nw_opt: waves per workgroup (0 = auto, 4 or 8), ncu: compute units of the
 // device (for the chunking heuristic).
+// reserve_cus > 0 (a halo exchange is in flight on the comm stream): the launch must leave that many compute units
+// without a workgroup, so that RCCL's send / receive kernel runs BESIDE it instead of draining behind a grid that fills
+// the device in one round -- the balanced form of the kernel (BAL) then serves the box with slots - reserve workgroups.
 static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int xcd_opt, hipStream_t stream,
                                        int max_partials, int* nparts, int nw_opt = 0, int ncu = 256, int zb_lo = 0,
-                                       int zb_hi = 0)
-{
+                                       int zb_hi = 0, int reserve_cus = 0, long* bal_info = nullptr)
+{   // *bal_info (diagnostic): 0 = the plain grid was launched, else left-over units * 1000000 + slices per unit * 1000 + planes per slice
     const int wx = a.hi[0] - a.lo[0], wy = a.hi[1] - a.lo[1], wz = a.hi[2] - a.lo[2];
     const int wzb = zb_hi > zb_lo ? zb_hi - zb_lo : 0;   // second z-range (same x/y box), may be empty
     *nparts = 0;
+    if (bal_info) *bal_info = 0;
     if (wx <= 0 || wy <= 0 || wz <= 0) return hipSuccess;
     if (!diff3_can_fuse2(a.Ht, a.A, a.B, a.C, a.dH, a.nx, a.ny, a.nz)) return hipErrorInvalidValue;
     // owned cells per x-tile: cut points at even cells e0 + t*sx; the tile's own cells [s, s+128) with
@@ -575,6 +611,43 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
     }
     a.xcd_remap = (xcd_opt == 1 && nblk >= 64) ? 1 : ((xcd_opt == 2 && a.ntz % 8 == 0) ? 2 : 0);
     const bool wres = a.dH != nullptr;
+    a.bal_r = a.bal_sp = a.bal_q = 0;
+    if (reserve_cus != 0 && wzb == 0) {   // < 0 (tests, option diff3_bal_g): the reserved form on exactly -reserve_cus workgroups
+        // The plain grid runs in rounds of `slots` workgroups.  A grid of several rounds frees units all the time and one
+        // that leaves `reserve_cus` units idle anyway needs no change; a grid that fills the device in ONE round is cut to
+        // G = slots - reserve workgroups: each serves its own (tile, chunk) unit, the r = nblk - G left-over units are
+        // sliced thinly over all of them (sp slices of q planes per unit; a slice costs q + 6 plane-iterations).
+        const int ncu_ = ncu > 0 ? ncu : 256, per_cu = a.nw == 8 ? 1 : 2;
+        const long slots = (long)ncu_ * per_cu;
+        const long G = reserve_cus < 0 ? -(long)reserve_cus : slots - (long)(reserve_cus < ncu_ / 2 ? reserve_cus : ncu_ / 2) * per_cu;
+        const long r = nblk - G;
+        if (r > 0 && r <= G && (reserve_cus < 0 || nblk <= slots) && (!norm || G <= max_partials)) {
+            a.bal_r = (int)r;
+            a.bal_sp = (int)(G / r);
+            a.bal_q = (zc + a.bal_sp - 1) / a.bal_sp;
+            if (a.xcd_remap == 2) a.xcd_remap = 0;
+            if (a.nw == 8) {
+                if (wres) {
+                    if (norm) k_diff3_march2<true, 8, true, true><<<(int)G, 512, 0, stream>>>(a);
+                    else k_diff3_march2<false, 8, true, true><<<(int)G, 512, 0, stream>>>(a);
+                } else {
+                    if (norm) k_diff3_march2<true, 8, false, true><<<(int)G, 512, 0, stream>>>(a);
+                    else k_diff3_march2<false, 8, false, true><<<(int)G, 512, 0, stream>>>(a);
+                }
+            } else {
+                if (wres) {
+                    if (norm) k_diff3_march2<true, 4, true, true><<<(int)G, 256, 0, stream>>>(a);
+                    else k_diff3_march2<false, 4, true, true><<<(int)G, 256, 0, stream>>>(a);
+                } else {
+                    if (norm) k_diff3_march2<true, 4, false, true><<<(int)G, 256, 0, stream>>>(a);
+                    else k_diff3_march2<false, 4, false, true><<<(int)G, 256, 0, stream>>>(a);
+                }
+            }
+            *nparts = (int)G;
+            if (bal_info) *bal_info = r * 1000000 + (long)a.bal_sp * 1000 + a.bal_q;
+            return hipGetLastError();
+        }
+    }
     if (a.nw == 8) {
         if (wres) {
             if (norm) k_diff3_march2<true, 8, true><<<(int)nblk, 512, 0, stream>>>(a);

@@ -70,9 +70,14 @@ struct fpr_ctx {
     void* comm = nullptr;        // ncclComm_t (comm.hip); nullptr = single rank
     int comm_rank = 0, comm_size = 1;
     FprGrid grid;
-    hipStream_t stream[2] = {nullptr, nullptr};  // 0 compute, 1 comm
+    // 0 compute, 1 comm, 2 core (= 0 unless fpr_reserve_comm_cus split the device: then 1 is a library-owned stream whose
+    // kernels run on `comm_cus` compute units only and 2 one whose kernels run on all the others)
+    hipStream_t stream[3] = {nullptr, nullptr, nullptr};
     bool own_stream[2] = {false, false};
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipStream_t caller_comm = nullptr;   // the comm stream given at creation, while a masked one stands in for it
+    hipStream_t masked[2] = {nullptr, nullptr};   // library-owned CU-masked streams (comm, core)
+    int comm_cus = 0;
     double* partials = nullptr;     // FPR_MAX_PARTIALS doubles: block partial sums (slot 0)
     double* partials2 = nullptr;    // second slot (comm stream / second reduction of a kernel)
     int ncu = 0;                       // compute units of the device (queried on first use)

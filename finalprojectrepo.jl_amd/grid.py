@@ -81,10 +81,10 @@ class HaloExchanger:
         # A has Julia shape (nx,ny,nz) with strides (1,nx,nx*ny): permute(2,1,0) is C-contiguous
         return A.permute(2, 1, 0)[k]
 
-    def pack_all(self, A, mask=63):
+    def pack_all(self, A, mask=63, stream_sel=0):
         for face in self.faces():
             if (face >> 1) != 2 and (mask >> face) & 1:
-                self.pack(A, face, self.sendbuf[face])
+                self.pack(A, face, self.sendbuf[face], stream_sel) if stream_sel else self.pack(A, face, self.sendbuf[face])
 
     def post(self, A, mask=63):
         """Post all sends/receives of already packed planes (z planes in place); returns work handles.
@@ -112,10 +112,10 @@ class HaloExchanger:
         for w in works:
             w.wait()
 
-    def unpack_all(self, A, mask=63):
+    def unpack_all(self, A, mask=63, stream_sel=0):
         for face in self.faces():
             if (face >> 1) != 2 and (mask >> face) & 1:
-                self.unpack(A, face, self.recvbuf[face])
+                self.unpack(A, face, self.recvbuf[face], stream_sel) if stream_sel else self.unpack(A, face, self.recvbuf[face])
 
     def update_halo_(self, A):
         """Blocking update_halo!(A)."""
@@ -153,6 +153,30 @@ class _DistTransport:
         c.compute.wait_stream(c.comm)
         ex.unpack_all(A, mask)
 
+    def prepare(self):
+        self.gg.exchanger()       # pack buffers are torch tensors zero-filled on the compute stream
+
+    def comm_post(self, A, mask=63):
+        """The exchange as a link of a chain on the COMM stream (fused pairs of a decomposed run): pack and post there."""
+        import torch
+        from . import ctx as _ctx
+
+        c = _ctx()
+        ex = self.gg.exchanger()
+        ex.pack_all(A, mask, 1)
+        with torch.cuda.stream(c.comm):
+            return ex.post(A, mask)
+
+    def comm_complete(self, A, mask, works):
+        import torch
+        from . import ctx as _ctx
+
+        c = _ctx()
+        ex = self.gg.exchanger()
+        with torch.cuda.stream(c.comm):
+            ex.wait(works)
+        ex.unpack_all(A, mask, 1)
+
     def update_halo_(self, A):
         self.gg.exchanger().update_halo_(A)
 
@@ -178,6 +202,17 @@ class _RcclTransport:
 
     def end(self, A, mask, token):
         self.c.call("fpr_halo_exchange3d_end", self.fptr(A, 3), *self.n, int(mask))
+
+    def prepare(self):
+        pass                      # the library owns its pack buffers (fpr_grid_init)
+
+    def comm_post(self, A, mask=63):
+        # pack, one RCCL group, unpack -- all in the comm stream's order: complete when the stream gets there
+        self.c.call("fpr_halo_exchange3d_comm", self.fptr(A, 3), *self.n, int(mask))
+        return None
+
+    def comm_complete(self, A, mask, token):
+        pass
 
     def update_halo_(self, A):
         self.c.call("fpr_halo_exchange3d", self.fptr(A, 3), *self.n)
@@ -220,7 +255,8 @@ class GlobalGrid:
 
     periods = (0, 0, 0)          # class defaults (a subclass may build the topology by hand)
     transport_kind = "dist"
-    _tr = _ex = _sq_host = None
+    _tr = _ex = _sq_host = _sq_shell = _reserve = None
+    _pending = False
 
     def __init__(self, nx, ny, nz, dims=None, group=None, use_dist=None, periods=(0, 0, 0), transport=None):
         self.nx, self.ny, self.nz = nx, ny, nz
@@ -270,6 +306,9 @@ class GlobalGrid:
         self._tr = None
         self._ex = None
         self._sq_host = None
+        self._sq_shell = None     # norm sums of the shell chain of a fused pair (comm stream)
+        self._reserve = None      # override of reserve_cus() (tools, tests)
+        self._pending = False     # a fused pair left on the core / comm streams (step2(join=False))
         if transport == "rccl":
             self._init_rccl()
 
@@ -326,12 +365,14 @@ class GlobalGrid:
     # ---- collectives ----
     def allreduce_sum(self, t):
         """MPI.Allreduce!(x, +, comm) of a 1-element tensor (part1_utils.jl:38); returns a float."""
+        self.join()
         if self.nprocs > 1:
             self.transport().allreduce_(t)
         return float(t[0].item()) if hasattr(t, "item") else float(t)
 
     def allreduce_(self, t):
         """In-place sum over all ranks of a small device tensor (several norms in one call); no host sync."""
+        self.join()
         if self.nprocs > 1:
             self.transport().allreduce_(t)
         return t
@@ -349,11 +390,11 @@ class GlobalGrid:
             c = _ctx()
             nx, ny, nz = self.nx, self.ny, self.nz
 
-            def pack(A, face, buf):
-                c.call("fpr_halo_pack3d", fptr(A, 3), nx, ny, nz, face, buf.data_ptr(), 0)
+            def pack(A, face, buf, stream_sel=0):
+                c.call("fpr_halo_pack3d", fptr(A, 3), nx, ny, nz, face, buf.data_ptr(), stream_sel)
 
-            def unpack(A, face, buf):
-                c.call("fpr_halo_unpack3d", fptr(A, 3), nx, ny, nz, face, buf.data_ptr(), 0)
+            def unpack(A, face, buf, stream_sel=0):
+                c.call("fpr_halo_unpack3d", fptr(A, 3), nx, ny, nz, face, buf.data_ptr(), stream_sel)
 
             self._ex = HaloExchanger((nx, ny, nz), self.neighbors, self.rank_of, pack, unpack,
                                      lambda n: fzeros(n), dist=self.dist, group=self.group)
@@ -361,6 +402,7 @@ class GlobalGrid:
 
     def update_halo_(self, A):
         """update_halo!(A) (part1_kernel_programming.jl:182,187): ordered on the compute stream."""
+        self.join()
         if self.neighbors:
             self.transport().update_halo_(A)
 
@@ -391,6 +433,7 @@ class GlobalGrid:
         sum((dHdτ*norm_scale)^2) (all-reduce it with allreduce_sum)."""
         from . import part1
 
+        self.join()
         if not self.neighbors:
             if sq_dev is None:
                 part1.diffusion_3D_step_τ(Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
@@ -411,12 +454,15 @@ class GlobalGrid:
         n = (self.nx, self.ny, self.nz)
         return all(n[f >> 1] >= 8 for f in self.neighbors)
 
-    def step2(self, Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq2_dev):
+    def step2(self, Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq2_dev, join=True):
         """TWO pseudo-iterations: Hout <- update(update(Hτ)), dHdτ <- residual of the second, halos of Hout refreshed.
         Hτ2 plays the reference's second work buffer: only its boundary cells (and, between ranks, its halo planes)
         are used.  Hout must carry Hτ's physical-boundary values.  sq2_dev (2 doubles, or None) receives the LOCAL
         sums of (dHdτ*norm_scale)^2 of the first and second iteration.  Fields bit-identical to two calls of step(); the
-        two sums equal step()'s to ~1e-13 relative (another summation order, see include/fpr.h)."""
+        two sums equal step()'s to ~1e-13 relative (another summation order, see include/fpr.h).
+        join=False (between ranks): the pair is left on the core / comm streams and the NEXT step2 continues from there
+        without passing through the compute stream; call join() (allreduce_ / step / update_halo_ do) before anything
+        else reads the fields or the sums."""
         from . import part1
 
         args = (Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
@@ -425,60 +471,107 @@ class GlobalGrid:
             return
         st = self.step2_begin(*args, norm_scale, sq2_dev)
         self.step2_middle(st)
-        self.step2_end(st)
+        self.step2_end(st, join)
+
+    def join(self):
+        """Order the compute stream behind a fused pair that step2(join=False) left on the core / comm streams."""
+        if self._pending:
+            from . import ctx as _ctx
+
+            _ctx().call("fpr_stream_wait", 0, 2)    # the core stream already waited for the pair's shell chain
+            self._pending = False
 
     # Choreography of two fused iterations between ranks, any Cartesian decomposition (level 1 = the field after the
     # first iteration, never written except where a neighbour needs it).  The SHELL is the one-cell layer of interior
-    # cells next to a face with a neighbour (boundary_boxes: disjoint thin boxes), the CORE everything inside it:
-    #   begin : single-step launches on the shell produce level 1 there (into Hτ2) -> post the exchange of Hτ2's
-    #           planes next to the halos; a fused launch on the lower half of the core overlaps it
-    #   middle: join; fused launches on the shell boxes -- their level-1 halo cells have just arrived in Hτ2 and are read
-    #           exactly like physical-boundary cells of level 1 -> post the exchange of the new field's planes
-    #   end   : fused launch on the upper half of the core (overlaps that exchange); join
-    # Two exchanges per two iterations, as with single steps.  z-faces travel in place, x / y faces through the pack
-    # kernels; one-cell-wide x-slabs run in the narrow-box kernel (k_diff3_slab2), y- and z-slabs in the wave-tile kernel.
-    def step2_begin(self, Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq2_dev):
-        from . import part1
+    # cells next to a face with a neighbour (boundary_boxes: disjoint thin boxes), the CORE everything inside it.
+    #
+    #   core stream :  CORE as ONE fused launch on the compute units the comm stream does not own ------------> join
+    #   comm stream :  shell, single steps -> level 1 in Hτ2 -> exchange(Hτ2) -> shell, fused launches (their level-1
+    #                  halo cells have just arrived and are read like physical-boundary cells) -> exchange(Hout) --^
+    #
+    # The device is SPLIT (fpr_reserve_comm_cus): the comm stream owns reserve_cus() compute units, the core stream all the
+    # others.  The whole shell chain -- thin launches, pack / unpack kernels, RCCL's send / receive kernels -- runs on its
+    # own units beside the core launch and ends long before it: both exchanges of the pair are hidden whatever the links
+    # take, and the core is never split.  The core launch serves the plain (tile, chunk) grid with that many workgroups
+    # less (fpr_diffusion3d_step2_core).  Round 2 ran the core as two half launches of 255 workgroups on 256 units: an
+    # exchange then started when the half beside it drained (tools/cu_share_probe.hip: a second queue's workgroups wait
+    # for room in the shader engine they were dealt to).
+    # z-faces travel in place, x / y faces through the pack kernels; one-cell-wide x-slabs run in the narrow-box kernel
+    # (k_diff3_slab2), y- and z-slabs in the wave-tile kernel.  The phases exist for emulated ranks in one process
+    # (tests): every rank posts before any rank completes.
+    def reserve_cus(self):
+        """Compute units of the comm stream during fused pairs: a multiple of 32 = the same number out of every shader
+        engine (a workgroup is dealt to an engine and waits there for room, so a lopsided split puts two workgroups of the
+        core launch on one unit: tools/cu_share_probe.hip).  z-faces only: 32 carry the pair's shell chain in well under
+        the core launch's time; x / y faces make the shell launches a multiple of that work: 64."""
+        if self._reserve is not None:
+            return self._reserve
+        return 64 if any((f >> 1) != 2 for f in self.neighbors) else 32
 
+    def step2_begin(self, Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq2_dev):
+        from . import ctx as _ctx
+        from . import part1
+        from ._lib import fzeros
+
+        c = _ctx()
         coef = (dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
+        sqs = None
         if sq2_dev is not None:
-            sq2_dev.zero_()
+            if self._sq_shell is None:
+                self._sq_shell = fzeros(2)
+            sqs = self._sq_shell
         boxes, core = self.boundary_boxes()
-        for lo, hi in boxes:
-            part1.diffusion_3D_step_τ_box(Ht, Hτ, Hτ2, dHdτ, *coef, lo, hi, 0.0, None, 0)
         mask = 0
         for f in self.neighbors:
             mask |= 1 << f
         tr = self.transport()
-        works = tr.begin(Hτ2, mask)
-        (cx0, cy0, cz0), (cx1, cy1, cz1) = core
-        zmid = (cz0 + cz1) // 2
         fused = (Ht, Hτ, Hτ2, Hout, dHdτ) + coef
-        part1.diffusion_3D_step_τ2_box(*fused, (cx0, cy0, cz0), (cx1, cy1, zmid), norm_scale, sq2_dev, 0)
-        return dict(fused=fused, scale=norm_scale, sq=sq2_dev, works=works, boxes=boxes, core=core, zmid=zmid, out=Hout,
+        k = self.reserve_cus()
+        c.reserve_comm_cus(k)                                 # split the device (no-op once done)
+        if self._pending:
+            # the previous pair was left on the core / comm streams: its core launch and the addition of its shell sums are
+            # in the core stream's order already; the shell chain of this pair has to see that core's output
+            c.call("fpr_stream_wait", 1, 2)
+        else:
+            tr.prepare()                                      # buffers a transport creates (and fills) on the compute stream: before the fork
+            c.call("fpr_stream_wait", 1, 0)                   # fork: the pair's inputs are ready
+            c.call("fpr_stream_wait", 2, 0)
+        # core stream first, so that its workgroups are placed before the thin launches ask for room; its sums are written
+        part1.diffusion_3D_step_τ2_core(*fused, core[0], core[1], norm_scale, sq2_dev, 2, k, accumulate=False)
+        if sqs is not None:
+            c.call("fpr_fill_on", sqs.data_ptr(), 0.0, 2, 1)
+        for lo, hi in boxes:                                  # comm stream: level 1 on the shell
+            part1.diffusion_3D_step_τ_box(Ht, Hτ, Hτ2, dHdτ, *coef, lo, hi, 0.0, None, 1)
+        works = tr.comm_post(Hτ2, mask)
+        return dict(fused=fused, scale=norm_scale, sq=sq2_dev, sqs=sqs, works=works, boxes=boxes, core=core, out=Hout,
                     mid=Hτ2, mask=mask)
 
     def step2_middle(self, st):
         from . import part1
 
         tr = self.transport()
-        tr.end(st["mid"], st["mask"], st["works"])
+        tr.comm_complete(st["mid"], st["mask"], st["works"])
         boxes = list(st["boxes"])
         # the two z-slabs (peeled first, same x / y extent) share one launch
         if 4 in self.neighbors and 5 in self.neighbors:
             (lo0, hi0), (lo1, hi1) = boxes[0], boxes[1]
-            part1.diffusion_3D_step_τ2_box(*st["fused"], lo0, hi0, st["scale"], st["sq"], 0, z2=(lo1[2], hi1[2]))
+            part1.diffusion_3D_step_τ2_box(*st["fused"], lo0, hi0, st["scale"], st["sqs"], 1, z2=(lo1[2], hi1[2]))
             boxes = boxes[2:]
         for lo, hi in boxes:
-            part1.diffusion_3D_step_τ2_box(*st["fused"], lo, hi, st["scale"], st["sq"], 0)
-        st["works"] = tr.begin(st["out"], st["mask"])
+            part1.diffusion_3D_step_τ2_box(*st["fused"], lo, hi, st["scale"], st["sqs"], 1)
+        st["works"] = tr.comm_post(st["out"], st["mask"])
 
-    def step2_end(self, st):
-        from . import part1
+    def step2_end(self, st, join=True):
+        from . import ctx as _ctx
 
-        (cx0, cy0, cz0), (cx1, cy1, cz1) = st["core"]
-        part1.diffusion_3D_step_τ2_box(*st["fused"], (cx0, cy0, st["zmid"]), (cx1, cy1, cz1), st["scale"], st["sq"], 0)
-        self.transport().end(st["out"], st["mask"], st["works"])
+        c = _ctx()
+        self.transport().comm_complete(st["out"], st["mask"], st["works"])
+        c.call("fpr_stream_wait", 2, 1)                       # the core stream takes in the shell chain ...
+        if st["sq"] is not None:
+            c.call("fpr_add_on", st["sq"].data_ptr(), st["sqs"].data_ptr(), 2, 2)    # ... and its sums
+        self._pending = True
+        if join:
+            self.join()
 
     def step_begin(self, Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq_dev):
         """Multi-rank step, first half: boundary slabs, then the exchange of the freshly written planes is posted

@@ -110,6 +110,19 @@ def diffusion_3D_step_τ2_box(Ht, Hτ, Hmid, Hout, dHdτ, dτ, _dt, _dx, _dy, _d
                 sumsq2_dev.data_ptr() if sumsq2_dev is not None else None, stream_sel)
 
 
+def diffusion_3D_step_τ2_core(Ht, Hτ, Hmid, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo, hi, scale=0.0,
+                              sumsq2_dev=None, stream_sel=0, reserve_cus=0, accumulate=True):
+    """The core box of a decomposed run's fused pair, leaving `reserve_cus` compute units to the shell launches and the
+    halo exchanges that run beside it on the comm stream (fpr_diffusion3d_step2_core; role of @hide_communication,
+    part1_kernel_programming.jl:185-188).  Results as diffusion_3D_step_τ2_box; accumulate=False writes the two sums."""
+    nx, ny, nz = Ht.shape
+    lo3 = (C.c_int * 3)(*lo)
+    hi3 = (C.c_int * 3)(*hi)
+    _ctx().call("fpr_diffusion3d_step2_core", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hmid, 3), fptr(Hout, 3), fptr(dHdτ, 3),
+                nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo3, hi3, scale,
+                sumsq2_dev.data_ptr() if sumsq2_dev is not None else None, stream_sel, int(reserve_cus), int(bool(accumulate)))
+
+
 def compute_flux_(qx, qy, qz, Hτ, D, dx, dy, dz):
     """part1_array_programming.jl:10-12 (north_star: compute_flux!)."""
     nx, ny, nz = Hτ.shape

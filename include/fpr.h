@@ -123,6 +123,17 @@ int fpr_diffusion3d_step2_box2(fpr_ctx* ctx, const double* Ht, const double* Hta
                                double* dHdtau, int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy,
                                double _dz, double D_dx, double D_dy, double D_dz, const int lo[3], const int hi[3],
                                int zlo2, int zhi2, double scale, double* sumsq2_dev, int stream_sel);
+/* _core: the CORE box of a decomposed run's pair (everything inside the one-cell shell next to the neighbours), launched
+ * so that `reserve_cus` compute units keep no workgroup of it: the shell launches and the RCCL send / receive kernels of
+ * the pair's two exchanges run BESIDE it on the comm stream instead of draining behind a grid that fills the device --
+ * the role of @hide_communication (part1_kernel_programming.jl:185-188) for two iterations at once.  The (tile, plane)
+ * space of the box is cut into (device slots - reserve) balanced ranges, one workgroup each (k_diff3_march2<.., BAL>);
+ * reserve_cus = 0 or a box whose plain grid leaves that many units idle anyway: exactly _step2_box.  Same results.
+ * accumulate = 0: the two sums are WRITTEN to sumsq2_dev (no zeroing launch in front of the pair's longest kernel). */
+int fpr_diffusion3d_step2_core(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hmid, double* Hout,
+                               double* dHdtau, int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy,
+                               double _dz, double D_dx, double D_dy, double D_dz, const int lo[3], const int hi[3],
+                               double scale, double* sumsq2_dev, int stream_sel, int reserve_cus, int accumulate);
 
 /* A5: the single-rank host loop of diffusion_3D_kernel_programming (part1_kernel_programming.jl:166-204) in
  * native code: for each of `nt` physical steps iterate the fused update until err <= tol (err =
@@ -176,6 +187,10 @@ int fpr_dot(fpr_ctx* ctx, const double* x, const double* y, size_t n, double* ou
 /* A5: `Ht .= Htau` -- part1_kernel_programming.jl:203 */
 int fpr_copy(fpr_ctx* ctx, double* dst, const double* src, size_t n);
 int fpr_fill(fpr_ctx* ctx, double* dst, double value, size_t n);
+/* the same, and dst += src, on a chosen stream (0 compute, 1 comm, 2 core): small device vectors such as the norm sums of
+ * a decomposed run's fused pair, which live on the comm and core streams (GlobalGrid.step2) */
+int fpr_fill_on(fpr_ctx* ctx, double* dst, double value, size_t n, int stream_sel);
+int fpr_add_on(fpr_ctx* ctx, double* dst, const double* src, size_t n, int stream_sel);
 
 /* A6: init_local_gaussian -- part1_utils.jl:1-12; coord* = 0-based Cartesian coordinates of the shard */
 int fpr_init_gaussian3d(fpr_ctx* ctx, double* H, int nx, int ny, int nz, double dx, double dy, double dz,
@@ -187,8 +202,18 @@ int fpr_init_gaussian3d(fpr_ctx* ctx, double* H, int nx, int ny, int nz, double 
  * halo plane (index 0 or n-1).  Plane sizes: ny*nz, nx*nz, nx*ny.  stream_sel as above. */
 int fpr_halo_pack3d(fpr_ctx* ctx, const double* A, int nx, int ny, int nz, int face, double* buf, int stream_sel);
 int fpr_halo_unpack3d(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face, const double* buf, int stream_sel);
-/* order stream `waiter` behind everything enqueued so far on stream `signaller` (0 compute, 1 comm) */
+/* order stream `waiter` behind everything enqueued so far on stream `signaller` (0 compute, 1 comm, 2 core) */
 int fpr_stream_wait(fpr_ctx* ctx, int waiter, int signaller);
+/* Split the device for a decomposed run (role of @hide_communication's boundary width, part1_kernel_programming.jl:185-188,
+ * in hardware terms): after fpr_reserve_comm_cus(ctx, k) stream 1 (comm) is a library-owned stream whose kernels -- the shell
+ * launches of a fused pair, the pack / unpack kernels, RCCL's send / receive kernels -- run on k compute units, and stream 2
+ * (core) one whose kernels run on all the others; before it, and after k = 0, stream 1 is the caller's comm stream and
+ * stream 2 is stream 0.  A second queue's workgroups wait for room in the shader engine they were dealt to even when
+ * other engines have idle units, so leaving units idle is not enough: the masks make the split explicit.
+ * fpr_comm_cus: the current k.  fpr_stream_handle: the hipStream_t behind a selector, for host code that enqueues on it. */
+int fpr_reserve_comm_cus(fpr_ctx* ctx, int k);
+int fpr_comm_cus(fpr_ctx* ctx);
+int fpr_stream_handle(fpr_ctx* ctx, int stream_sel, void** hip_stream_out);
 
 /* ---- process / device boundary of the decomposed diffusion path: RCCL over xGMI, one process per GPU ------
  * Replaces ImplicitGlobalGrid + MPI in the reference:
@@ -229,6 +254,10 @@ int fpr_halo_exchange3d(fpr_ctx* ctx, double* A, int nx, int ny, int nz);
  * faces).  All faces travel at once: edge / corner halo cells are not refreshed (a 7-point stencil reads none). */
 int fpr_halo_exchange3d_begin(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face_mask);
 int fpr_halo_exchange3d_end(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face_mask);
+/* _comm: the whole exchange (pack, one group of sends / receives, unpack) on the COMM stream in stream order -- for a
+ * chain of thin-box launches and exchanges kept on the comm stream beside one long launch on the compute stream
+ * (fpr_diffusion3d_step2_core); order it against the compute stream with fpr_stream_wait.  Faces as for _begin/_end. */
+int fpr_halo_exchange3d_comm(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face_mask);
 
 /* MPI.Allreduce!(x, +, comm_cart) -- part1_utils.jl:38.  _dev: `count` device doubles in place on stream
  * stream_sel, no host sync (norms of several iterations can be reduced in one call).  All RCCL operations of a context

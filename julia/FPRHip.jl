@@ -105,6 +105,14 @@ function kernel_timer_read(kind::Integer = -1)   # FPR_KT_*: 0 step, 1 fused ste
     return ms[], n[]
 end
 stream_wait(waiter::Integer, signaller::Integer) = check(ccall((:fpr_stream_wait, libfpr), Cint, (Ptr{Cvoid}, Cint, Cint), ctx(), waiter, signaller))
+"Split the device for a decomposed run: stream 1 (comm) on `k` compute units, stream 2 (core) on the others; 0 undoes it."
+reserve_comm_cus(k::Integer) = check(ccall((:fpr_reserve_comm_cus, libfpr), Cint, (Ptr{Cvoid}, Cint), ctx(), k))
+comm_cus() = ccall((:fpr_comm_cus, libfpr), Cint, (Ptr{Cvoid},), ctx())
+function stream_handle(sel::Integer)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:fpr_stream_handle, libfpr), Cint, (Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}), ctx(), sel, h))
+    return h[]
+end
 last_coarse_iters() = ccall((:fpr_last_coarse_iters, libfpr), Clong, (Ptr{Cvoid},), ctx())
 
 # ---- ParallelStencil surface ---------------------------------------------------------------------
@@ -238,6 +246,23 @@ function diffusion_3D_step_τ2_box2(Ht::DA, Hτ::DA, Hmid::DA, Hout::DA, dHdτ::
                 zlo2, zhi2, scale, sumsq2 === nothing ? Ptr{Cdouble}(C_NULL) : p(sumsq2), stream_sel))
 end
 
+"""
+The CORE box of a decomposed run's fused pair, leaving `reserve_cus` compute units without a workgroup of it: the shell
+launches and RCCL's send / receive kernels of the pair run beside it on the comm stream (`stream_sel = 1` launches,
+`halo_exchange_comm!`); role of `@hide_communication` (part1_kernel_programming.jl:185-188) for two iterations at once.
+"""
+function diffusion_3D_step_τ2_core(Ht::DA, Hτ::DA, Hmid::DA, Hout::DA, dHdτ::DA, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz,
+                                   lo::NTuple{3,Int}, hi::NTuple{3,Int}; scale = 0.0, sumsq2::Union{DA,Nothing} = nothing,
+                                   stream_sel = 0, reserve_cus = 32, accumulate = true)
+    nx, ny, nz = size(Ht)
+    lo3 = Cint[lo...]; hi3 = Cint[hi...]
+    check(ccall((:fpr_diffusion3d_step2_core, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint,
+                 Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cint}, Ptr{Cint}, Cdouble, Ptr{Cdouble}, Cint, Cint, Cint),
+                ctx(), p(Ht), p(Hτ), p(Hmid), p(Hout), p(dHdτ), nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo3, hi3, scale,
+                sumsq2 === nothing ? Ptr{Cdouble}(C_NULL) : p(sumsq2), stream_sel, reserve_cus, accumulate))
+end
+
 function compute_flux!(qx::DA, qy::DA, qz::DA, Hτ::DA, D, dx, dy, dz)        # part1_array_programming.jl:10-12
     nx, ny, nz = size(Hτ)
     check(ccall((:fpr_diffusion3d_flux, libfpr), Cint,
@@ -300,6 +325,8 @@ function dist_norm_L2(Rh::DA, comm_cart; scale = 1.0)
 end
 copy_device!(dst::DA, src::DA) = check(ccall((:fpr_copy, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Csize_t), ctx(), p(dst), p(src), length(dst)))
 fill_device!(dst::DA, v) = check(ccall((:fpr_fill, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Csize_t), ctx(), p(dst), v, length(dst)))
+fill_on!(dst::DA, v, stream_sel) = check(ccall((:fpr_fill_on, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Csize_t, Cint), ctx(), p(dst), v, length(dst), stream_sel))
+add_on!(dst::DA, src::DA, stream_sel) = check(ccall((:fpr_add_on, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Csize_t, Cint), ctx(), p(dst), p(src), length(dst), stream_sel))
 function init_local_gaussian_device!(H::DA, center, dx, dy, dz, coords)
     nx, ny, nz = size(H)
     check(ccall((:fpr_init_gaussian3d, libfpr), Cint,
@@ -398,6 +425,9 @@ halo_exchange_begin!(A::DA; faces = 63) = (n = size(A);
     check(ccall((:fpr_halo_exchange3d_begin, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint, Cint), ctx(), p(A), n[1], n[2], n[3], faces)))
 halo_exchange_end!(A::DA; faces = 63) = (n = size(A);
     check(ccall((:fpr_halo_exchange3d_end, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint, Cint), ctx(), p(A), n[1], n[2], n[3], faces)))
+"The whole exchange (pack, one RCCL group, unpack) in the COMM stream's order: a link of the shell chain of a fused pair."
+halo_exchange_comm!(A::DA; faces = 63) = (n = size(A);
+    check(ccall((:fpr_halo_exchange3d_comm, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint, Cint), ctx(), p(A), n[1], n[2], n[3], faces)))
 
 "`gather!(A, A_global)` (part1_kernel_programming.jl:223): A_global (host, rank 0; `nothing` elsewhere) receives all local arrays."
 function gather!(A::DA, A_global::Union{Array{Float64,3},Nothing})

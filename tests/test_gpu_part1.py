@@ -555,6 +555,86 @@ def test_fused_two_steps_random_shapes_and_boxes(fpr, oracle):
         c.set_option("diff3_nw2", 0)
 
 
+def test_fused_two_steps_reserved_form_random_shapes_and_boxes(fpr, oracle):
+    """fpr_diffusion3d_step2_core (k_diff3_march2<.., BAL>: a grid SHORT of the plain (tile, chunk) grid by r units, every
+    workgroup serving its own unit and then a slice of a left-over one) against two oracle steps: seeded sweep over grid
+    sizes, boxes, chunk sizes and workgroup counts; norms of both iterations, cells outside the box untouched.  Option
+    diff3_bal_g forces the form on grids that would not fill a device; fpr_get_option("diff3_last_bal") says which ran."""
+    F = fpr
+    c = F.ctx()
+    rng = np.random.RandomState(20261004)
+    ran_reserved = 0
+    try:
+        for trial in range(24):
+            nx = int(rng.randint(8, 40)) * 16 if trial % 2 else int(rng.randint(64, 300)) * 2
+            shape = (nx, int(rng.randint(16, 80)), int(rng.randint(6, 40)))
+            lo = tuple(int(rng.randint(1, max(2, n // 3))) if rng.rand() < 0.5 else 1 for n in shape)
+            hi = tuple(int(rng.randint(max(l + 1, 2 * n // 3), n)) if rng.rand() < 0.5 else n - 1 for l, n in zip(lo, shape))
+            c.set_option("diff3_nw2", int(rng.choice([0, 4, 8])))
+            zc = int(rng.choice([3, 4, 5, 7, 9]))
+            c.set_option("diff3_zc2", zc)
+            c.set_option("diff3_xcd2", int(rng.choice([0, 1, 3])))
+            # plain grid: tiles (>= ceil(span / 124) x-tiles, y-blocks of 30 or 14 owned rows) x chunks of zc planes;
+            # ask for a little less than a lower bound of that, so that mostly 1 .. a third of the units are left over
+            span = hi[0] - (lo[0] & ~1)
+            ntx = (span + 123) // 124
+            wy, wz = hi[1] - lo[1], hi[2] - lo[2]
+            units_lo = ntx * ((wy + 29) // 30) * ((wz + zc - 1) // zc)
+            G = max(1, int(units_lo * rng.choice([0.6, 0.75, 0.9, 0.97])))
+            c.set_option("diff3_bal_g", G)
+            Ht, A, B = rnd(shape, 500 + trial), rnd(shape, 600 + trial), rnd(shape, 700 + trial)
+            C_ref, dH_ref, _, _ = _two_oracle_steps(oracle, Ht, A, B)
+            Bp, dH1 = B.copy(order="F"), asf(np.zeros(shape))
+            oracle.diffusion3d_step(Ht, A, Bp, dH1, *COEF.values())
+            sl = tuple(slice(l, h) for l, h in zip(lo, hi))
+            dC, dD = F.asdevice(np.full(shape, -3.0)), F.asdevice(np.full(shape, -9.0))
+            sq2 = F.ctx().scal[:2]
+            sq2.zero_()
+            F.part1.diffusion_3D_step_τ2_core(F.asdevice(Ht), F.asdevice(A), F.asdevice(B), dC, dD, *COEF.values(), lo, hi,
+                                              0.2, sq2, 0, 8)
+            info = c.L.fpr_get_option(c.h, b"diff3_last_bal")
+            ran_reserved += info != 0
+            Cg, Dg = F.tonumpy(dC), F.tonumpy(dD)
+            assert np.array_equal(Cg[sl], C_ref[sl]) and np.array_equal(Dg[sl], dH_ref[sl]), (trial, shape, lo, hi, G, info)
+            r1 = float(((dH1[sl] * 0.2) ** 2).sum()); r2 = float(((dH_ref[sl] * 0.2) ** 2).sum())
+            got = sq2.cpu().tolist()
+            assert abs(got[0] - r1) <= 1e-12 * r1 and abs(got[1] - r2) <= 1e-12 * r2, (trial, got, r1, r2)
+            Cg[sl] = -3.0; Dg[sl] = -9.0
+            assert (Cg == -3.0).all() and (Dg == -9.0).all(), (trial, shape, lo, hi, G, info)
+    finally:
+        for k in ("diff3_bal_g", "diff3_nw2", "diff3_zc2", "diff3_xcd2"):
+            c.set_option(k, 0)
+    assert ran_reserved >= 12, ran_reserved     # the sweep must exercise the reserved form, not its fallback
+
+
+def test_full_size_512_core_launch_leaves_units_free_and_equals_the_plain_launch(fpr):
+    """BASELINE config 4's per-GPU size: the core box of a z-slab rank (planes 2 .. 509) as fpr_diffusion3d_step2_core with
+    12 compute units reserved equals fpr_diffusion3d_step2_box on the same box bit for bit; norms to 1e-13."""
+    import torch
+
+    F = fpr
+    n = 512
+    dx = 10.0 / n
+    coef = (dx * dx / 8.1, 5.0, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx)
+    Ht, A, B = F.fzeros(n, n, n), F.fzeros(n, n, n), F.fzeros(n, n, n)
+    F.part1.init_local_gaussian((5.0, 5.0, 5.0), dx, dx, dx, Ht)
+    A.copy_(Ht)
+    A.mul_(1.0 + 0.001 * torch.arange(n, device=A.device, dtype=torch.float64).reshape(n, 1, 1))
+    B.copy_(A).mul_(0.5)
+    lo, hi = (1, 1, 2), (n - 1, n - 1, n - 2)
+    C1, dH1, C2, dH2 = A.clone(), F.fzeros(n, n, n), A.clone(), F.fzeros(n, n, n)
+    sq = F.ctx().scal[:4]
+    sq.zero_()
+    F.part1.diffusion_3D_step_τ2_box(Ht, A, B, C1, dH1, *coef, lo, hi, 0.2, sq[0:2])
+    for reserve in (12, 40):
+        C2.copy_(A); dH2.zero_(); sq[2:4].zero_()
+        F.part1.diffusion_3D_step_τ2_core(Ht, A, B, C2, dH2, *coef, lo, hi, 0.2, sq[2:4], 0, reserve)
+        assert F.ctx().L.fpr_get_option(F.ctx().h, b"diff3_last_bal") != 0     # the reserved form ran
+        assert torch.equal(C1, C2) and torch.equal(dH1, dH2)
+        s = [float(x) for x in sq.tolist()]
+        assert abs(s[2] - s[0]) <= 1e-13 * s[0] and abs(s[3] - s[1]) <= 1e-13 * s[1]
+
+
 @pytest.mark.parametrize("case", [dict(tol=3e-5, check_every=1), dict(tol=1e-5, check_every=3), dict(fixed_iters=51)],
                          ids=["tol3e-5", "every3", "fixed51"])
 def test_python_loop_with_fused_pairs_equals_native_loop(fpr, oracle, case):

@@ -176,12 +176,79 @@ def test_fused_pair_over_rccl_periodic_xyz(fpr, oracle, periodic_grid):
         assert np.array_equal(F.tonumpy(gR)[1:-1, 1:-1, 1:-1], R[1:-1, 1:-1, 1:-1])
 
 
+@pytest.mark.parametrize("periods", [(0, 0, 1), (1, 1, 1)], ids=["z", "xyz"])
+def test_config4_512cubed_over_rccl_self_neighbour(fpr, oracle, periodic_grid, periods):
+    """BASELINE config 4's per-GPU workload (512^3 local array with neighbours) through the library's RCCL transport on
+    the one card a box has: one rank that is its own periodic neighbour (z = the native slab layout; xyz = every face
+    of a (2,2,2)-like rank), 4 single steps (GlobalGrid.step: boundary slabs, exchange beside the interior) and 2 fused
+    pairs (GlobalGrid.step2: the core as one balanced launch on the compute stream, shell launches and both exchanges
+    beside it on the comm stream) against the OpenMP oracle with wrapped halos: fields and residuals bit for bit, norms
+    to 1e-13.  What this cannot cover is the link transport between two devices (N > 1 needs N GPUs)."""
+    F = fpr
+    n = (512, 512, 512)
+    dims = tuple(d for d in range(3) if periods[d])
+    gg = periodic_grid(n, periods)
+    ext = [m - 2 if p else m for m, p in zip(n, periods)]
+    dx, dy, dz = 10.0 / ext[0], 10.0 / ext[1], 10.0 / ext[2]
+    D, dt = 1.0, 0.2
+    dτ = min(dx, dy, dz) ** 2 / D / 8.1
+    coef = (dτ, 1 / dt, 1 / dx, 1 / dy, 1 / dz, D / dx, D / dy, D / dz)
+    Ht = oracle.init_gaussian(n, dx, dy, dz, (4.0, 5.5, 6.0))
+    Ht *= 1.0 + 0.25 * rnd(n, 77)
+    wrap(Ht, dims=dims)
+    A, B, R = Ht.copy(order="F"), farr(*n), farr(*n)
+    gHt, gA, gB, gR = F.asdevice(Ht), F.asdevice(A), F.fzeros(*n), F.fzeros(*n)
+    inner = (slice(1, -1),) * 3
+
+    def faces_equal(loc, ref):
+        for d in dims:   # halo planes (face interiors; edges / corners are not refreshed by one all-faces exchange)
+            for side in (0, -1):
+                idx = [slice(1, -1)] * 3
+                idx[d] = side
+                if not np.array_equal(loc[tuple(idx)], ref[tuple(idx)]):
+                    return False
+        return True
+
+    sq = F.fzeros(1)
+    for it in range(4):
+        oracle.diffusion3d_step(Ht, A, B, R, *coef)
+        wrap(B, dims=dims)
+        A, B = B, A
+        gg.step(gHt, gA, gB, gR, *coef, dt, sq)
+        gA, gB = gB, gA
+        ref = oracle.sumsq_scaled(R, dt)
+        assert abs(float(sq.item()) - ref) <= 1e-13 * ref
+    loc = F.tonumpy(gA)
+    assert np.array_equal(loc[inner], A[inner]) and faces_equal(loc, A)
+    assert np.array_equal(F.tonumpy(gR)[inner], R[inner])
+    del loc
+    gC = gA.clone()
+    assert gg.can_step2(gHt, gA, gB, gC, gR)
+    assert gg.reserve_cus() >= 12
+    sq2 = F.fzeros(2)
+    for it in range(2):
+        refs = []
+        for k in range(2):
+            oracle.diffusion3d_step(Ht, A, B, R, *coef)
+            wrap(B, dims=dims)
+            A, B = B, A
+            refs.append(oracle.sumsq_scaled(R, dt))
+        gg.step2(gHt, gA, gB, gC, gR, *coef, dt, sq2)
+        gA, gC = gC, gA
+        got = sq2.cpu().tolist()
+        assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs)), (got, refs)
+        loc = F.tonumpy(gA)
+        assert np.array_equal(loc[inner], A[inner]) and faces_equal(loc, A)
+        del loc
+        assert np.array_equal(F.tonumpy(gR)[inner], R[inner])
+
+
 def test_bench_two_ranks_rehearsal_on_one_card():
     """bench.py's N>1 control flow between REAL processes on the one card a test box has: the self-launcher, the gloo
     control plane, identical collective counts on every rank through pre-warm / warm-up / timed region, the shell/core
     choreography of the fused pairs, one JSON line from rank 0.  Planes travel through the host (RCCL refuses two ranks
     on one device), so the rate it prints is not a measurement; the norm it prints is checked against a 1-rank run of the
-    same global problem (run_all_benchmarks.sh:21-28 is the reference's multi-rank protocol)."""
+    same global problem, `bench.py --as-one-rank-of 1,1,2` (run_all_benchmarks.sh:21-28 is the reference's multi-rank protocol)."""
     import json
     import os
     import subprocess
@@ -198,8 +265,17 @@ def test_bench_two_ranks_rehearsal_on_one_card():
     assert out["n_gpus"] == 2 and out["config"]["process_grid"] == [1, 1, 2] and out["config"]["global_grid"] == [128, 128, 254]
     assert "rehearsal" in out and out["legs"]["fused_pairs"]["launches"] == 6     # passes over the local grid, 12 steps
     assert 0.0 < out["roofline"]["frac"] <= 1.0      # priced per pass: shell + thin slabs + core halves together
-    assert out["roofline"]["launches_by_kind"]["fused_boxes"] >= 3 * 6
+    assert out["roofline"]["launches_by_kind"]["fused_boxes"] >= 2 * 6       # per pair: the core launch + the shell launch(es)
     assert out["config"]["last_err"] is not None and 0.0 < out["config"]["last_err"] < 1.0
+    # the same global problem (128 x 128 x 254, lz = 20) on ONE rank, same number of iterations: the sum of squares behind
+    # the norm rank 0 printed must be the single-domain one (summation order differs: 1e-12)
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--as-one-rank-of", "1,1,2", "--n", "128"] + common,
+                        capture_output=True, text=True, timeout=600, cwd=root)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    assert one["config"]["local_grid"] == [128, 128, 254] and one["config"]["global_grid"] == [128, 128, 254]
+    a, b = out["config"]["last_sumsq"], one["config"]["last_sumsq"]
+    assert a > 0 and abs(a - b) <= 1e-12 * b, (a, b)
 
 
 def test_bench_four_ranks_rehearsal_x_y_z_decompositions_agree():

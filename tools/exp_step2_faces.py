@@ -17,7 +17,7 @@ K = 40
 def run(gg, pairs):
     global A, C
     for _ in range(pairs):
-        gg.step2(Ht, A, O, C, R, *coef, 0.2, sq); A, C = C, A
+        gg.step2(Ht, A, O, C, R, *coef, 0.2, sq, join=False); A, C = C, A
 def run1(gg, its):
     global A, O
     for _ in range(its):

@@ -4,6 +4,7 @@
     prof_summarize.py stats  <dir> <out.txt>        kernel_stats.csv -> per-kernel calls / avg / total
     prof_summarize.py pmc    <dir> <out.txt>        counter_collection.csv -> per-kernel mean counter value
     prof_summarize.py timeline <dir> <out.txt> [n]  kernel_trace.csv -> the last n dispatches with durations and gaps
+    prof_summarize.py overlap  <dir> <out.txt> [n]  kernel_trace.csv -> the last n dispatches with absolute start / end, queue, grid
 """
 import csv
 import glob
@@ -43,6 +44,22 @@ def timeline(d, out, last=40):
             prev = en
 
 
+def overlap(d, out, last=40):
+    """The last `last` dispatches in start order with absolute start / end (us since the first of them), queue, grid,
+    workgroup size, VGPRs and LDS: shows which kernels ran side by side."""
+    f = find(d, "*kernel_trace.csv")
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))[-last:]
+    t0 = int(rows[0]["Start_Timestamp"])
+    with open(out, "w") as o:
+        o.write("# rocprofv3 --kernel-trace (%s): last %d dispatches, times in us since the first of them\n" % (os.path.basename(f), len(rows)))
+        o.write("%-56s %5s %9s %5s %5s %7s %10s %10s %9s\n" % ("kernel", "queue", "grid", "wg", "vgpr", "lds", "start", "end", "dur"))
+        for r in rows:
+            st, en = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+            o.write("%-56s %5s %9s %5s %5s %7s %10.1f %10.1f %9.1f\n" % (
+                r["Kernel_Name"][:56], r.get("Queue_Id", "?"), r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "?")),
+                r.get("VGPR_Count", "?"), r.get("LDS_Block_Size", "?"), st / 1e3, en / 1e3, (en - st) / 1e3))
+
+
 def pmc(d, out):
     f = find(d, "*counter_collection.csv")
     acc = defaultdict(lambda: defaultdict(list))
@@ -59,5 +76,7 @@ def pmc(d, out):
 if __name__ == "__main__":
     if sys.argv[1] == "timeline":
         timeline(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 40)
+    elif sys.argv[1] == "overlap":
+        overlap(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 40)
     else:
         {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])

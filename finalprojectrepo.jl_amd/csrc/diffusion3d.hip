@@ -19,7 +19,7 @@ static int diff3_run(fpr_ctx* ctx, const double* Ht, const double* Htau, double*
     FPR_REQUIRE(ctx, Ht && Htau && Htau2 && dHdtau, "null field pointer");
     FPR_REQUIRE(ctx, nx >= 3 && ny >= 3 && nz >= 3, "grid must be at least 3^3");
     FPR_REQUIRE(ctx, Htau != Htau2, "Htau and Htau2 must be distinct buffers (Jacobi ping-pong)");
-    FPR_REQUIRE(ctx, stream_sel == 0 || stream_sel == 1, "stream_sel");
+    FPR_REQUIRE(ctx, stream_sel >= 0 && stream_sel <= 2, "stream_sel");
     Diff3Args a;
     a.Ht = Ht; a.Htau = Htau; a.Htau2 = Htau2; a.dHdtau = dHdtau;
     a.nx = nx; a.ny = ny; a.nz = nz;
@@ -31,7 +31,7 @@ static int diff3_run(fpr_ctx* ctx, const double* Ht, const double* Htau, double*
     a.dtau = dtau; a._dt = _dt; a._dx = _dx; a._dy = _dy; a._dz = _dz;
     a.D_dx = D_dx; a.D_dy = D_dy; a.D_dz = D_dz;
     a.scale = scale;
-    a.partials = stream_sel ? ctx->partials2 : ctx->partials;
+    a.partials = stream_sel == 1 ? ctx->partials2 : ctx->partials;
     const bool empty = a.lo[0] >= a.hi[0] || a.lo[1] >= a.hi[1] || a.lo[2] >= a.hi[2];
     int nparts = 0;
     if (!empty) {

@@ -502,11 +502,14 @@ class GlobalGrid:
     def reserve_cus(self):
         """Compute units of the comm stream during fused pairs: a multiple of 32 = the same number out of every shader
         engine (a workgroup is dealt to an engine and waits there for room, so a lopsided split puts two workgroups of the
-        core launch on one unit: tools/cu_share_probe.hip).  z-faces only: 32 carry the pair's shell chain in well under
-        the core launch's time; x / y faces make the shell launches a multiple of that work: 64."""
+        core launch on one unit: tools/cu_share_probe.hip).  32 carry the shell chain of a rank with z-faces, y-faces or
+        one face per dimension in less than the core launch's time; x-faces cost about five z-faces each (lanes along y,
+        strided planes), so a rank with more shell work than that gets 64 (profiles/r3_step2_faces_overhead.txt: 512^3,
+        two faces per periodic dimension: z +9 %, y +13 % at 32 units; x +30 %, xy +39 %, xyz +49 % at 64)."""
         if self._reserve is not None:
             return self._reserve
-        return 64 if any((f >> 1) != 2 for f in self.neighbors) else 32
+        work = sum({0: 5, 1: 2, 2: 1}[f >> 1] for f in self.neighbors)
+        return 64 if work > 9 else 32
 
     def step2_begin(self, Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq2_dev):
         from . import ctx as _ctx
@@ -591,9 +594,18 @@ class GlobalGrid:
         """Second half: interior update (overlaps the transfers), join, unpack the received halos."""
         from . import part1
 
+        from . import ctx as _ctx
+
         args, inner, norm_scale, sq_dev, works = st
-        # 3. interior update overlaps the exchange
-        part1.diffusion_3D_step_τ_box(*args, inner[0], inner[1], norm_scale, sq_dev, 0)
+        # 3. interior update overlaps the exchange.  On a split device (fused pairs ran before: the comm stream owns a few
+        # compute units) it runs on the core stream, whose units the exchange does not compete for
+        c = _ctx()
+        if c.L.fpr_comm_cus(c.h) > 0:
+            c.call("fpr_stream_wait", 2, 0)
+            part1.diffusion_3D_step_τ_box(*args, inner[0], inner[1], norm_scale, sq_dev, 2)
+            c.call("fpr_stream_wait", 0, 2)
+        else:
+            part1.diffusion_3D_step_τ_box(*args, inner[0], inner[1], norm_scale, sq_dev, 0)
         # 4. join: the compute stream waits for the transfers, then unpacks the x/y halos
         self.transport().end(args[2], ALLFACES, works)
 

@@ -23,11 +23,14 @@ def run1(gg, its):
     for _ in range(its):
         gg.step(Ht, A, O, R, *coef, 0.2, sq[:1]); A, O = O, A
 res = {}
-for name, periods in (("none", (0, 0, 0)), ("z", (0, 0, 1)), ("yz", (0, 1, 1)), ("xyz", (1, 1, 1)), ("x", (1, 0, 0)), ("y", (0, 1, 0))):
+CASES = (("none", (0, 0, 0)), ("z", (0, 0, 1)), ("yz", (0, 1, 1)), ("xyz", (1, 1, 1)), ("x", (1, 0, 0)), ("y", (0, 1, 0)), ("xy", (1, 1, 0)))
+if len(sys.argv) > 2: CASES = tuple(c for c in CASES if c[0] in sys.argv[2].split(",") or c[0] == "none")
+for name, periods in CASES:
     if any(periods):
         gg = F.grid.GlobalGrid(n, n, n, dims=(1, 1, 1), periods=periods, transport="rccl", use_dist=False)
     else:
         gg = F.grid.GlobalGrid(n, n, n, dims=(1, 1, 1), use_dist=False)
+    if os.environ.get("FPR_RESERVE") and any(periods): gg._reserve = int(os.environ["FPR_RESERVE"])
     run(gg, 10); torch.cuda.synchronize(); t0 = time.perf_counter(); run(gg, K); th = time.perf_counter() - t0
     torch.cuda.synchronize(); t = time.perf_counter() - t0
     run1(gg, 10); torch.cuda.synchronize(); t0 = time.perf_counter(); run1(gg, 2 * K); torch.cuda.synchronize(); t1 = time.perf_counter() - t0

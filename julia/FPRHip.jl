@@ -16,16 +16,26 @@
 #     include("FPRHip.jl"); using .FPRHip
 #     @init_parallel_stencil(AMDGPU, Float64, 3)
 #
-# and keep the rest of the scripts unchanged: `@parallel [blocks threads shmem=...] kernel(args...)`
-# drops the launch geometry and calls the HIP kernel of the same name through `ccall`.
+# and keep the rest of the scripts unchanged:
+#   * `@parallel [blocks threads shmem=...] kernel(args...)` drops the launch geometry and calls the HIP kernel of the
+#     same name through `ccall`;
+#   * the kernel DEFINITIONS the solver files carry next to their host loops -- `@parallel_indices (ix, iy[, iz]) function
+#     kernel(...) ... end` (13 of them) and `@parallel function diffusion_3D_step_τ!(...) ... end` -- expand to nothing:
+#     this module already defines every one of those names (KERNELS below), an unknown name is an error.  Their bodies
+#     (`@sharedMem`, `@threadIdx`, `@blockDim`, `@sync_threads`, `CUDA.@atomic`, `@all`, `@inn`, `@d_xi` ...) are never
+#     expanded, so the solver files can be `include`d as they are once their `using` block is replaced;
+#   * `include_reference(@__MODULE__, "multigrid.jl")` goes one step further: it includes a reference file WITHOUT any
+#     edit, dropping its `using CUDA / ParallelStencil / ImplicitGlobalGrid` lines on the way (and, with `fast = true`,
+#     the host functions this module provides natively: the V-cycle as one stream of launches instead of one `ccall`
+#     per kernel).
 # AMDGPU.jl is used only for device-array allocation (ROCArray) and device selection.
 module FPRHip
 
 using AMDGPU
 import MPI      # bootstrap only: broadcast of the 128-byte RCCL unique id and the node-local rank (init_global_grid)
 
-export @init_parallel_stencil, @reset_parallel_stencil, @parallel, @zeros, @ones, @rand, @synchronize,
-       @hide_communication, Data,
+export @init_parallel_stencil, @reset_parallel_stencil, @parallel, @parallel_indices, @zeros, @ones, @rand, @synchronize,
+       @hide_communication, Data, include_reference,
        diffusion_3D_step_τ, diffusion_3D_step_τ_shared_memory, diffusion_3D_step_τ!,
        compute_flux!, compute_dHdτ!, update_H!, dist_norm_L2, init_local_gaussian_device!,
        residual_2DPoisson!, residual_2DPoisson_shmem!, residual_2DPoisson_wrapper!, iteration_2DPoisson!,
@@ -91,6 +101,7 @@ function destroy_context()
         ccall((:fpr_ctx_destroy, libfpr), Cint, (Ptr{Cvoid},), CTX[])
         CTX[] = C_NULL
         GRID[] = nothing
+        HAS_COMM[] = false
     end
     return nothing
 end
@@ -122,10 +133,125 @@ end
 macro reset_parallel_stencil()
     :(FPRHip.destroy_context())
 end
-"`@parallel [blocks threads shmem=n] f(args...)` -> `f(args...)` (launch geometry is the library's)."
+# Every kernel the reference defines with @parallel_indices / @parallel function (14 definitions: part1_kernel_programming.jl:46,75;
+# part1_array_programming.jl:9; multigrid.jl:173,191,330,403,427; krylov.jl:7,16; part2.jl:90,99,107,116,128) -- each is a function of
+# this module bound to one HIP kernel (or, for the array-programming step, to the three split kernels).
+const KERNELS = Set{Symbol}([
+    :diffusion_3D_step_τ, :diffusion_3D_step_τ_shared_memory, Symbol("diffusion_3D_step_τ!"),
+    Symbol("residual_2DPoisson!"), Symbol("residual_2DPoisson_shmem!"), Symbol("restrict!"), Symbol("prolongate_with_atomic!"),
+    Symbol("prolongate!"), Symbol("matrix_free_matvec_prod!"), Symbol("matrix_free_matvec_prod_shmem!"),
+    Symbol("compute_velocity!"), Symbol("compute_Ra_dTdx!"), Symbol("compute_diffusion2d!"), Symbol("compute_advection2d_x!"),
+    Symbol("compute_advection2d_y!")])
+
+"Name defined by a function-definition expression (long or short form, `where` / return-type annotations, macro prefixes), else `nothing`."
+function fdef_name(ex)
+    ex isa Expr || return nothing
+    ex.head === :macrocall && return fdef_name(ex.args[end])          # `@views function ...`, `@inline function ...`
+    if !(ex.head === :function || (ex.head === :(=) && ex.args[1] isa Expr && ex.args[1].head in (:call, :where, :(::))))
+        return nothing
+    end
+    sig = ex.args[1]
+    while sig isa Expr && sig.head in (:where, :(::))
+        sig = sig.args[1]
+    end
+    (sig isa Expr && sig.head === :call) || return nothing
+    f = sig.args[1]
+    if f isa Expr && f.head === :.                                     # `Mod.f(...) = ...`
+        f = f.args[end] isa QuoteNode ? f.args[end].value : f.args[end]
+    end
+    return f isa Symbol ? f : nothing
+end
+
+function swallow_kernel_definition(macroname, ex)
+    name = fdef_name(ex)
+    name === nothing && error("$macroname: expected a kernel definition (`function f(args...) ... end`)")
+    name in KERNELS || error("$macroname: FPRHip has no HIP kernel named `$name` -- the hot path it replaces is the set $(sort!(collect(KERNELS)))")
+    return nothing          # the definition is dropped: the module's function of that name stands in for it
+end
+
+"""
+`@parallel_indices (ix, iy[, iz]) function kernel(args...) ... end`: a ParallelStencil kernel DEFINITION.  The reference keeps
+its kernels in the same files as the host loops; here the definition expands to nothing -- `kernel` is this module's function
+of the same name (one `ccall` into libfpr_hip.so) -- and a kernel this module does not provide is an error.
+"""
+macro parallel_indices(args...)
+    swallow_kernel_definition("@parallel_indices", args[end])
+end
+
+"""
+`@parallel [blocks threads shmem=n | ranges] f(args...)` -> `f(args...)` (launch geometry is the library's);
+`@parallel function f(args...) ... end` (part1_array_programming.jl:9): a kernel definition, swallowed like `@parallel_indices`.
+"""
 macro parallel(args...)
+    fdef_name(args[end]) === nothing || return swallow_kernel_definition("@parallel", args[end])
     esc(args[end])
 end
+
+# ---- including the reference's solver files without editing them ------------------------------------------
+const ABSENT_PACKAGES = (:CUDA, :ParallelStencil, :ImplicitGlobalGrid)     # this module stands in for them
+# host functions / types of the solver files that this module provides natively (dropped with fast = true); functions as
+# (name, number of positional arguments) so that part1_utils.jl's 3-argument apply_boundary_conditions! survives
+const NATIVE_HOST = Set{Tuple{Symbol,Int}}([
+    (Symbol("MGsolve_2DPoisson!"), 7), (Symbol("Vcycle_2DPoisson!"), 9), (Symbol("iteration_2DPoisson!"), 6),
+    (Symbol("residual_2DPoisson_wrapper!"), 6), (Symbol("restrict_wrapper!"), 4), (Symbol("prolongate_wrapper!"), 4),
+    (Symbol("matrix_free_matvec_prod_wrapper!"), 5), (Symbol("cg!"), 7), (:preallocate_buffers, 2),
+    (Symbol("apply_boundary_conditions!"), 1), (Symbol("apply_boundary_conditions_dirichlet!"), 1),
+    (Symbol("apply_boundary_conditions_neumann!"), 1), (:dist_norm_L2, 2)])
+const NATIVE_TYPES = Set{Symbol}([:ExecutionPolicy_t, :CoarseSolver_t, :MGOpt])
+
+function positional_arity(ex)
+    ex isa Expr || return -1
+    ex.head === :macrocall && return positional_arity(ex.args[end])
+    sig = ex.args[1]
+    while sig isa Expr && sig.head in (:where, :(::))
+        sig = sig.args[1]
+    end
+    (sig isa Expr && sig.head === :call) || return -1
+    return count(a -> !(a isa Expr && a.head === :parameters), sig.args[2:end])
+end
+
+uses_absent_package(ex) = ex isa Expr && ex.head in (:using, :import) &&
+    any(a -> begin
+            path = a isa Expr && a.head === :(:) ? a.args[1] : a          # `using A: b, c`
+            path isa Expr && path.head === :. && !isempty(path.args) && path.args[1] in ABSENT_PACKAGES
+        end, ex.args)
+
+function native_type_definition(ex)
+    ex isa Expr || return false
+    ex.head === :struct && return (n = ex.args[2]; n = n isa Expr ? n.args[1] : n; n in NATIVE_TYPES)
+    if ex.head === :macrocall && ex.args[1] === Symbol("@enum")
+        n = ex.args[findfirst(a -> !(a isa LineNumberNode), ex.args[2:end]) + 1]
+        return n in NATIVE_TYPES
+    end
+    return false
+end
+
+"""
+    include_reference(mod, path; fast = true)
+
+`include` one of the reference's solver files (scripts-part1/part1_kernel_programming.jl, part1_array_programming.jl,
+scripts-part2/multigrid.jl, krylov.jl, part2.jl ...) into `mod` AS IT IS: `using` / `import` lines of CUDA, ParallelStencil and
+ImplicitGlobalGrid are dropped (this module stands in for them; `mod` must have done `using .FPRHip`), nested `include(...)`s go
+through the same filter, kernel definitions are swallowed by `@parallel_indices` / `@parallel`.  `fast = true` also drops the
+host functions, enums and `MGOpt` this module provides natively (NATIVE_HOST, NATIVE_TYPES), so that `MGsolve_2DPoisson!`,
+`Vcycle_2DPoisson!`, `cg!` ... are the library's fused paths instead of the reference's kernel-by-kernel loops.
+"""
+function include_reference(mod::Module, path::AbstractString; fast::Bool = true)
+    dir = dirname(abspath(path))
+    Base.include(mod, path) do ex
+        uses_absent_package(ex) && return nothing
+        if ex isa Expr && ex.head === :call && ex.args[1] === :include && length(ex.args) == 2
+            return :($(include_reference)($mod, joinpath($dir, $(ex.args[2])); fast = $fast))
+        end
+        if fast
+            native_type_definition(ex) && return nothing
+            name = fdef_name(ex)
+            name !== nothing && (name, positional_arity(ex)) in NATIVE_HOST && return nothing
+        end
+        return ex
+    end
+end
+
 "`@hide_communication (bx,by,bz) begin ... end`: the overlap is inside the multi-GPU step; run the body."
 macro hide_communication(args...)
     esc(args[end])
@@ -344,6 +470,7 @@ halo_unpack!(A::DA, buf::DA, face; stream_sel = 0) = (n = size(A);
 # One process per GPU.  MPI.jl is used for two bootstrap steps only (node-local rank, broadcast of the RCCL unique
 # id); every byte of the data path (halo planes, the norm's all-reduce, gather!) travels through the library.
 const GRID = Ref{Any}(nothing)   # (me, dims, nprocs, coords, n = (nx,ny,nz), periods, comm)
+const HAS_COMM = Ref(false)      # fpr_comm_init done on the current context
 grid() = (GRID[] === nothing && error("init_global_grid has not been called"); GRID[])
 
 "`select_device()`: bind this rank to GPU (node-local rank mod device count); returns the 0-based device id."
@@ -372,9 +499,12 @@ function init_global_grid(nx::Integer, ny::Integer, nz::Integer; dimx = 0, dimy 
     id = zeros(UInt8, 128)                                       # FPR_UNIQUE_ID_BYTES
     me == 0 && (ccall((:fpr_comm_get_unique_id, libfpr), Cint, (Ptr{UInt8},), id) == 0 || error("fpr_comm_get_unique_id failed"))
     MPI.Bcast!(id, 0, comm)
-    if ccall((:fpr_comm_size, libfpr), Cint, (Ptr{Cvoid},), ctx()) != np || ccall((:fpr_comm_rank, libfpr), Cint, (Ptr{Cvoid},), ctx()) != me || np > 1
+    # a communicator whenever this context has none yet (a single rank needs one too: a periodic dimension makes it its own
+    # neighbour, and the planes then travel through ncclSend / ncclRecv like between ranks), or when the world changed
+    if !HAS_COMM[] || ccall((:fpr_comm_size, libfpr), Cint, (Ptr{Cvoid},), ctx()) != np || ccall((:fpr_comm_rank, libfpr), Cint, (Ptr{Cvoid},), ctx()) != me
         check(ccall((:fpr_comm_finalize, libfpr), Cint, (Ptr{Cvoid},), ctx()))
         check(ccall((:fpr_comm_init, libfpr), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), ctx(), me, np, id))
+        HAS_COMM[] = true
     end
     me_o = Ref{Cint}(0); np_o = Ref{Cint}(0); dims = zeros(Cint, 3); coords = zeros(Cint, 3)
     check(ccall((:fpr_grid_init, libfpr), Cint,
@@ -390,6 +520,7 @@ end
 function finalize_global_grid(; finalize_MPI = true)
     CTX[] == C_NULL || check(ccall((:fpr_comm_finalize, libfpr), Cint, (Ptr{Cvoid},), CTX[]))
     GRID[] = nothing
+    HAS_COMM[] = false
     finalize_MPI && MPI.Initialized() && !MPI.Finalized() && MPI.Finalize()
     return nothing
 end
@@ -406,7 +537,16 @@ nz_g() = grid_sizes_g()[1][3]
 function coord_g(d::Int, i::Integer, dd::Real, A)
     g = grid(); n = g.n[d]
     x0 = 0.5 * (n - size(A, d)) * dd                       # staggered arrays sit half a cell in
-    return (g.coords[d] * (n - 2) + (i - 1)) * dd + x0
+    x = (g.coords[d] * (n - 2) + (i - 1)) * dd + x0
+    if g.periods[d] != 0
+        # ImplicitGlobalGrid, periodic dimension [3P-memory, SURVEY 8c]: the first cell of the global problem is a ghost
+        # cell, so everything shifts one cell to the left and wraps around the global extent n_g * dd
+        ng = grid_sizes_g()[1][d]
+        x -= dd
+        x > (ng - 1) * dd && (x -= ng * dd)
+        x < 0 && (x += ng * dd)
+    end
+    return x
 end
 x_g(ix::Integer, dx::Real, A) = coord_g(1, ix, dx, A)
 y_g(iy::Integer, dy::Real, A) = coord_g(2, iy, dy, A)
@@ -438,6 +578,21 @@ function gather!(A::DA, A_global::Union{Array{Float64,3},Nothing})
 end
 gather!(A::Array{Float64,3}, A_global) = gather!(ROCArray(A), grid().me == 0 ? A_global : nothing)   # the reference passes Array(Ht)
 
+"""
+`apply_boundary_conditions!(H, coords, dims)` (part1_utils.jl:14-34) as written: the 0-based Cartesian `coords` are compared
+with `1` and with `dims`, so on a single rank it does nothing and on rank coordinate 1 it zeroes the LOW plane -- an internal
+halo plane when dims > 1 (SURVEY 7 quirk; the Python mirror reproduces it on one rank and skips it between ranks).
+"""
+function apply_boundary_conditions!(H::ROCArray{Float64,3}, coords, dims)
+    coords[1] == 1 && (H[1, :, :] .= 0.0)
+    coords[2] == 1 && (H[:, 1, :] .= 0.0)
+    coords[3] == 1 && (H[:, :, 1] .= 0.0)
+    coords[1] == dims[1] && (H[end, :, :] .= 0.0)
+    coords[2] == dims[2] && (H[:, end, :] .= 0.0)
+    coords[3] == dims[3] && (H[:, :, end] .= 0.0)
+    return nothing
+end
+
 "part1_array_programming.jl:20-92 on the split kernels (BASELINE config 1); returns (X_g, H_g) like the reference."
 function diffusion_3D_array_programming(; nx, ny, nz, do_vis = false, verbose = true, init_and_finalize_MPI = !isinteractive())
     lx, ly, lz = 10.0, 10.0, 10.0; D = 1.0; ttot = 1.0
@@ -450,6 +605,7 @@ function diffusion_3D_array_programming(; nx, ny, nz, do_vis = false, verbose = 
     qz = AMDGPU.zeros(Float64, nx - 2, ny - 2, nz - 1)
     Ht = AMDGPU.zeros(Float64, nx, ny, nz)
     init_local_gaussian_device!(Ht, [lx / 2, ly / 2, lz / 2], dx, dy, dz, coords)
+    apply_boundary_conditions!(Ht, coords, dims)             # part1_array_programming.jl:53
     Hτ = copy(Ht); dHdt = AMDGPU.zeros(Float64, nx - 2, ny - 2, nz - 2)
     H_g = me == 0 ? zeros(nx * dims[1], ny * dims[2], nz * dims[3]) : nothing
     t = 0.0

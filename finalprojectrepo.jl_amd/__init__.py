@@ -41,6 +41,12 @@ def second_ctx():
     c = ctx()
     if _second_ctx is None or _second_ctx.device != c.device or _second_ctx._closed:
         _second_ctx = Context(c.device, secondary=True)
+        # the solve that runs beside another one must not depend on 16 workgroups being resident together: cg! in its
+        # two-launch form there (a switch set on the default context, cg_fused included, still wins: copied below)
+        _second_ctx.set_option("cg_fused", 2)
+        for k, v in c.opts.items():
+            _second_ctx.set_option(k, _lib.follower_value(k, v))
+        c.followers = [_second_ctx]
     return _second_ctx
 
 

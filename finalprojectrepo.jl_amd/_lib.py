@@ -198,6 +198,12 @@ def fptr(t, ndim=None):
     return t.data_ptr()
 
 
+def follower_value(key, value):
+    """... except that cg! never runs as the persistent kernel (cg_fused = 3, the default) on a context whose solves run
+    BESIDE another context's: its 16 workgroups synchronise through memory and must all be resident at once."""
+    return 2 if (key == "cg_fused" and int(value) == 3) else int(value)
+
+
 class Context:
     """fpr_ctx wrapper.  Two torch streams (compute, comm) are created and handed to the library so
     torch ops, torch.cuda.Event timing and the library's kernels share them."""
@@ -228,6 +234,8 @@ class Context:
         self.scal = torch.zeros(16, dtype=torch.float64, device=torch.device("cuda", device))
         self._closed = False
         self.comm_ready = False   # fpr_comm_init done (grid.rccl_bootstrap)
+        self.opts = {}            # options set through set_option (copied to contexts that follow this one)
+        self.followers = []
 
     def call(self, name, *args):
         rc = getattr(self.L, name)(self.h, *args)
@@ -251,6 +259,10 @@ class Context:
 
     def set_option(self, key, value):
         self.call("fpr_set_option", key.encode(), int(value))
+        self.opts[key] = int(value)
+        for follower in self.followers:      # a second context on the same device runs with the same switches ...
+            if not follower._closed:
+                follower.set_option(key, follower_value(key, value))
 
     def synchronize(self):
         self.call("fpr_synchronize")

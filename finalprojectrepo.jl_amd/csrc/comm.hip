@@ -347,7 +347,8 @@ extern "C" int fpr_gather3d(fpr_ctx* ctx, const double* A, int nx, int ny, int n
     }
     FPR_REQUIRE(ctx, A_global_host, "rank 0 needs the global host array");
     if (np > 1 && !g.stage) FPR_HIP(ctx, hipMalloc(&g.stage, n * sizeof(double)));
-    std::vector<double> host(n);
+    // every rank's block goes from device memory straight into its place in the (strided) global host array, one z-plane
+    // per 2-D copy: no field-sized host staging buffer (a 512^3 block is 1 GiB)
     const size_t gx = (size_t)nx * g.dims[0], gy = (size_t)ny * g.dims[1];
     for (int r = 0; r < np; ++r) {
         const double* src = A;
@@ -355,13 +356,13 @@ extern "C" int fpr_gather3d(fpr_ctx* ctx, const double* A, int nx, int ny, int n
             FPR_NCCL(ctx, ncclRecv(g.stage, n, ncclDouble, r, comm_of(ctx), ctx->stream[1]));
             src = g.stage;
         }
-        FPR_HIP(ctx, hipMemcpyAsync(host.data(), src, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream[1]));
-        FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));
         const int c[3] = {r / (g.dims[1] * g.dims[2]), (r / g.dims[2]) % g.dims[1], r % g.dims[2]};
-        for (int k = 0; k < nz; ++k)
-            for (int j = 0; j < ny; ++j)
-                memcpy(A_global_host + (size_t)c[0] * nx + gx * ((size_t)c[1] * ny + j + gy * ((size_t)c[2] * nz + k)),
-                       host.data() + (size_t)nx * (j + (size_t)ny * k), (size_t)nx * sizeof(double));
+        for (int k = 0; k < nz; ++k) {
+            double* dst = A_global_host + (size_t)c[0] * nx + gx * ((size_t)c[1] * ny + gy * ((size_t)c[2] * nz + k));
+            FPR_HIP(ctx, hipMemcpy2DAsync(dst, gx * sizeof(double), src + (size_t)nx * ny * k, (size_t)nx * sizeof(double),
+                                          (size_t)nx * sizeof(double), (size_t)ny, hipMemcpyDeviceToHost, ctx->stream[1]));
+        }
+        FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));   // the staging block is reused by the next rank
     }
     return FPR_OK;
 }

@@ -305,6 +305,13 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
     // if the call ends on such a pair the pair is replayed once with the store -- from its still intact input, before
     // the commit of Ht -- so that dHdtau holds what the reference's residual_H holds.  Option diff3_lazy_residual = 0:
     // every launch stores it.
+    // an error return in the middle of a run of pairs enqueued ahead of the host: drain them before the caller gets control
+    // back (they would otherwise still write the fields after the call has returned); outputs are undefined after an error
+    struct Drain {
+        fpr_ctx* c;
+        bool ok;
+        ~Drain() { if (!ok) hipStreamSynchronize(c->stream[0]); }
+    } drain{ctx, false};
     const bool lazy_res = fpr_opt(ctx, "diff3_lazy_residual", 1) != 0;
     int ahead = (int)fpr_opt(ctx, "diff3_ahead", 2);   // fused pairs enqueued ahead of the host's view of the norm (0: wait for every norm)
     if (ahead > FPR_CYC_SLOTS - 2) ahead = FPR_CYC_SLOTS - 2;
@@ -437,6 +444,7 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
         if (rc) return rc;
     }
     if (swapped_host) *swapped_host = (int)(swaps & 1);
+    drain.ok = true;
     return FPR_OK;
 }
 

@@ -55,7 +55,11 @@ __device__ __forceinline__ double cgp_allsum(unsigned long long* slots, unsigned
     unsigned long long* nxt = slots + ((gen + 2u) & 3u) * (CGP_NB * CGP_SLOT_STRIDE);
     const double v_wave = fpr_wave_sum_all(v_thread);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v_wave;
-    __syncthreads();                       // wave totals in LDS; the workgroup's earlier stores precede the publication below
+    // wave totals in LDS; the workgroup's earlier stores precede the publication below.  The tile-edge values of r were
+    // written with PLAIN stores by many threads; this barrier orders them before thread 0 at workgroup scope, and thread 0's
+    // agent-scope RELEASE store is cumulative over everything that happens-before it (the AMDGPU memory model composes
+    // scopes that include one another), so a poller's agent-scope acquire of the slot sees them: the usual grid-sync pattern
+    __syncthreads();
     if (threadIdx.x == 0) {
         double v_blk = red[0];
 #pragma unroll

@@ -727,11 +727,17 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
     const dim3 g2 = grid2(nx, ny);
     const int np2 = (int)(g2.x * g2.y);
     if (np2 > FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
-    k_cg_init<<<fg, 256, 0, s>>>(b, w.r, w.p, w.ph, w.x, N);
-    FPR_CHECK_LAUNCH(ctx);
-    if (int rc = fprx_dot_dev(ctx, b, b, N, ctx->scalars + 2)) return rc;
-    k_state_init<<<1, 1, 0, s>>>(ctx->state, ctx->scalars + 2, tol, (double)N, 1);
-    FPR_CHECK_LAUNCH(ctx);
+    // r = p = p_hat = b, x = 0, rho = b.b, state: what every form of the solve starts from (b itself is never written, so a
+    // form that gives up -- the persistent kernel on a barrier time-out -- can be followed by another from the start)
+    auto start = [&]() -> int {
+        k_cg_init<<<fg, 256, 0, s>>>(b, w.r, w.p, w.ph, w.x, N);
+        FPR_CHECK_LAUNCH(ctx);
+        if (int rc = fprx_dot_dev(ctx, b, b, N, ctx->scalars + 2)) return rc;
+        k_state_init<<<1, 1, 0, s>>>(ctx->state, ctx->scalars + 2, tol, (double)N, 1);
+        FPR_CHECK_LAUNCH(ctx);
+        return FPR_OK;
+    };
+    if (int rc = start()) return rc;
     const int chunk = 64;
     // cg_fused: 3 (default where it applies) = one persistent launch for the whole solve, 2 = two dependent launches per
     // iteration, 1 = three, 0 = five (one per operation)
@@ -739,7 +745,16 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
     if (fused == 3) {
         const int twm = (nx + CGP_NBX - 1) / CGP_NBX, thm = (ny + CGP_NBX - 1) / CGP_NBX;
         const size_t lds = (size_t)(twm + 2) * (thm + 2) * sizeof(double);
-        if (Nmax > 0 && (long)twm * thm <= (long)CGP_NT * CGP_PPT && 2L * (twm + 2) + 2L * thm <= (long)CGP_NT * CGP_RPT && lds <= 64 * 1024) {
+        // its 16 workgroups synchronise through memory, so all of them have to be resident at once: ask the runtime once
+        // whether a compute unit takes one (1024 threads, this much LDS) and whether the device has 16 units
+        if (ctx->cgp_resident < 0) {
+            int per_cu = 0, ncu = 0;
+            const bool ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_persistent, CGP_NT, 64 * 1024) == hipSuccess &&
+                            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess;
+            ctx->cgp_resident = (ok && (long)per_cu * ncu >= CGP_NB) ? 1 : 0;
+        }
+        if (ctx->cgp_resident == 1 && Nmax > 0 && (long)twm * thm <= (long)CGP_NT * CGP_PPT &&
+            2L * (twm + 2) + 2L * thm <= (long)CGP_NT * CGP_RPT && lds <= 64 * 1024) {
             CgpArgs a;
             a.b = b; a.x_out = x_in; a.r_glob = w.r; a.part = ctx->partials;
             a.ctr = (unsigned*)(ctx->scalars + 40);   // two words of the scalar block: barrier counter, abort flag
@@ -756,8 +771,11 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
             k_cg_persistent<<<dim3(CGP_NB), dim3(CGP_NT), lds, s>>>(a);
             FPR_CHECK_LAUNCH(ctx);
             if (int rc = read_state(ctx)) return rc;
-            if (ctx->state_h->done < 0) return fpr_fail(ctx, FPR_ERR_HIP, "cg!: a grid barrier of the persistent kernel timed out");
-            return FPR_OK;   // x_in holds the solution (krylov.jl:88)
+            if (ctx->state_h->done >= 0) return FPR_OK;   // x_in holds the solution (krylov.jl:88)
+            // A grid barrier timed out (a workgroup never became resident: the card is shared with other work): x_in is
+            // partly written, b is intact -- solve again from the start with the two-launch form, which needs no residency
+            ctx->options["cg_persistent_timeouts"] = fpr_opt(ctx, "cg_persistent_timeouts", 0) + 1;
+            if (int rc = start()) return rc;
         }
         fused = 2;
     }
@@ -1395,7 +1413,13 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
         // Cycles are enqueued `ahead` deep before the host waits for the norm of the oldest one: the exit test (:70) is
         // evaluated on the device by k_cycle_finish, and all launches of a cycle that follows the one that met it return
         // at once -- fields, norms and cycle count are those of the plain loop, without a host round trip per cycle.
-        struct Guard { fpr_ctx* c; ~Guard() { c->cyc_skip = nullptr; } } guard{ctx};
+        // an error return in the middle of the loop leaves launches enqueued AHEAD of the host: drain them before the caller
+        // gets control back (they would otherwise still write u after the call has returned); outputs are undefined then
+        struct Guard {
+            fpr_ctx* c;
+            bool ok;
+            ~Guard() { c->cyc_skip = nullptr; if (!ok) hipStreamSynchronize(c->stream[0]); }
+        } guard{ctx, false};
         // rms(f) and the threshold tol * rms(f) stay on the device too (same operations as on the host): no round trip
         // before the first cycle; the host learns both from the first record
         if (int rc = fprx_cycle_init(ctx, f, N, tol)) return rc;
@@ -1511,6 +1535,7 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
             if (rec.stop) break;  // :70 (taken on the device)
         }
         }
+        guard.ok = true;
     } else
     for (int iter = 1; iter <= niters; ++iter) {
         if (apply_BCs)

@@ -151,7 +151,8 @@ int fpr_diffusion3d_step2_core(fpr_ctx* ctx, const double* Ht, const double* Hta
  * up to "diff3_ahead" (default 2) pairs are enqueued before the host has seen the norm of the oldest; pairs behind the
  * iteration that ends the loop return at once (0: the host waits for every norm).  NULL: one iteration per launch.
  * Non-NULL for a problem the fused kernel cannot serve (fpr_diffusion3d_can_step2 == 0) is FPR_ERR_INVALID, never a
- * silent fallback. */
+ * silent fallback. After an error return the output arrays are UNDEFINED (launches enqueued ahead of the host's view of the norm
+ * are drained before the call returns, but they may have run). */
 int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, double* Htau2, double* Htau3, double* dHdtau, int nx, int ny, int nz,
                           double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy, double D_dz,
                           double dt, double total_N, int nt, double tol, long iter_max, long fixed_iters, int check_every,
@@ -314,7 +315,7 @@ int fpr_vcycle2d(fpr_ctx* ctx, double* u_f, const double* rhs, double h, double 
  * ahead of the host's view of the norm, and two consecutive cycles share their pass over the finest grid -- u, the
  * history, the cycle and coarse-iteration counts are those of the plain loop.  Tuning / A-B options
  * (fpr_set_option, defaults in brackets): mg_ahead [1] cycles enqueued ahead (0 = plain loop), mg_seam [1] shared pass
- * between cycles, mg_seam_predict [1], mg_mid [1] three launch-bound levels in two launches, mg_small_row [1]. */
+ * between cycles, mg_seam_predict [1], mg_mid [1] three launch-bound levels in two launches, mg_small_row [1]. After an error return u is UNDEFINED (cycles enqueued ahead of the host are drained first, but may have run). */
 int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h, double c, double tol, int niters,
                   int apply_BCs, int coarse_solve_size, int coarse_solver, int nx, int ny, double* rms_host,
                   int* ncycles_host, double* history_host, double* frms_host, int* converged_host);

@@ -306,7 +306,16 @@ def test_full_size_4097_properties(fpr):
     assert r5 < 1e-6 * frms and len(hist5) <= 12 and cit > 0
 
 
-CG_RTOL = 1e-4   # see the comment in test_config3_five_levels_4097
+# CG coarse solver on large coarse grids (documented exception, BASELINE.md 2 / DESIGN 2): the coarse problem is solved to
+# tol * ||b|| only, and where exactly the ~630 CG iterations of a solve land inside that tolerance depends on the summation
+# order of the dot products (krylov.jl:64,69,83) -- another order on the GPU than in the oracle, both deterministic.
+# Measured at 4097^2, l = 8 (tools/exp_cg_parity.py, profiles/r3_cg_parity.txt), all three launch forms: coarse iteration
+# counts EQUAL in every V-cycle (4397 in total), fields equal to 1e-12, residual history equal to 1e-10 through cycle 4 and
+# to 4.2e-7 at cycle 7 -- the residual itself has shrunk to 4e-7 of rms(f) by then, so in units of the first residual the
+# history agrees to 2e-13 throughout.  Asserted: counts ==, |d hist| <= 1e-10 * hist[0], per-entry 2e-6, field 1e-11.
+CG_HIST_RTOL_PER_ENTRY = 2e-6
+CG_HIST_ATOL_OF_FIRST = 1e-10
+CG_FIELD_RTOL = 1e-11
 
 
 def test_config3_known_answer_k10_l6_jacobi(fpr, oracle):
@@ -332,7 +341,8 @@ def test_config3_five_levels_4097(fpr, oracle):
     """BASELINE config 3 as named: 4097^2, 5 grids (l=8, coarse 257^2), 2+2 Jacobi smooths, multigrid_bench.jl
     protocol.  Jacobi coarse solver: 44 V-cycles / 226 160 coarse sweeps to tol 1e-6 (the coarse solve is capped at
     20*257 = 5140 sweeps and never converges), first three residuals and the field after three cycles equal to the
-    oracle's; CG coarse solver: 7 V-cycles, first three residuals equal to the oracle's."""
+    oracle's; CG coarse solver: 7 V-cycles and 4397 coarse iterations in every launch form of cg!, the whole residual history
+    against the oracle's (tolerances and their reason: CG_HIST_* above)."""
     F, mg = fpr, fpr.multigrid
     n = 4097
     h = 1.0 / (n - 1)
@@ -341,34 +351,46 @@ def test_config3_five_levels_4097(fpr, oracle):
     opt = mg.MGOpt()
     opt.coarse_solve_size = 257
     import warnings
-    for solver, ncyc, rtol in ((mg.jacobi, 44, 1e-10), (mg.conjugate_gradient, 7, CG_RTOL)):
-        opt.coarse_solver = solver
-        xo = farr(n, n)
-        _, hist_o, frms_o = oracle.mgsolve2d(xo, b, h, 0.0, 1e-6, 3, False, 257, solver.value)
-        cit_o = oracle.last_coarse_iters()
-        x = F.fzeros(n, n)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")   # 3 cycles do not converge: the reference's @warn (multigrid.jl:78-80)
-            _, hist3, frms, cit3 = mg.MGsolve_2DPoisson_(x, gb, h, 0.0, 1e-6, 3, False, opt=opt, return_history=True)
-        assert len(hist3) == len(hist_o) == 3
-        assert np.allclose(hist3, hist_o, rtol=rtol, atol=0), (hist3, hist_o)
-        assert abs(frms - frms_o) <= 1e-13 * frms_o
-        if solver is mg.jacobi:
-            assert cit3 == cit_o == 3 * 5140
-            assert np.array_equal(F.tonumpy(x), xo)
-        else:
-            # CG stops on ||r|| < tol*||b|| (krylov.jl:71): dot products differ by summation order between the two
-            # implementations, which ~600 iterations per solve amplify -- counts agree to a few iterations and the
-            # V-cycle residuals to the coarse tolerance (1e-6) times the cycle's contraction, not to rounding
-            print("config 3 l=8 CG: coarse iterations gpu/oracle", cit3, cit_o, "hist", hist3, hist_o)
-            assert abs(cit3 - cit_o) <= 0.02 * cit_o
-            assert np.abs(F.tonumpy(x) - xo).max() <= 1e-5 * np.abs(xo).max()
-        x.zero_()
-        r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, gb, h, 0.0, 1e-6, 100, False, opt=opt, return_history=True)
-        assert len(hist) == ncyc and r < 1e-6 * frms
-        assert np.allclose(hist[:3], hist_o, rtol=rtol, atol=0)
-        if solver is mg.jacobi:
-            assert cit == 44 * 5140 == 226160
+    # ---- Jacobi coarse solver: three cycles against the oracle (a full oracle solve would be 44 cycles of 5140 sweeps) ----
+    opt.coarse_solver = mg.jacobi
+    xo = farr(n, n)
+    _, hist_o, frms_o = oracle.mgsolve2d(xo, b, h, 0.0, 1e-6, 3, False, 257, mg.jacobi.value)
+    cit_o = oracle.last_coarse_iters()
+    x = F.fzeros(n, n)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")   # 3 cycles do not converge: the reference's @warn (multigrid.jl:78-80)
+        _, hist3, frms, cit3 = mg.MGsolve_2DPoisson_(x, gb, h, 0.0, 1e-6, 3, False, opt=opt, return_history=True)
+    assert len(hist3) == len(hist_o) == 3
+    assert np.allclose(hist3, hist_o, rtol=1e-10, atol=0), (hist3, hist_o)
+    assert abs(frms - frms_o) <= 1e-13 * frms_o
+    assert cit3 == cit_o == 3 * 5140
+    assert np.array_equal(F.tonumpy(x), xo)
+    x.zero_()
+    r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, gb, h, 0.0, 1e-6, 100, False, opt=opt, return_history=True)
+    assert len(hist) == 44 and r < 1e-6 * frms
+    assert np.allclose(hist[:3], hist_o, rtol=1e-10, atol=0)
+    assert cit == 44 * 5140 == 226160
+    # ---- CG coarse solver: the whole solve against the oracle, in every launch form of cg! ----
+    opt.coarse_solver = mg.conjugate_gradient
+    xo = farr(n, n)
+    _, hist_o, frms_o = oracle.mgsolve2d(xo, b, h, 0.0, 1e-6, 100, False, 257, mg.conjugate_gradient.value)
+    cit_o = oracle.last_coarse_iters()
+    assert len(hist_o) == 7
+    c = F.ctx()
+    try:
+        for form in (3, 2, 1):     # persistent kernel, two launches per iteration, three
+            c.set_option("cg_fused", form)
+            x = F.fzeros(n, n)
+            r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, gb, h, 0.0, 1e-6, 100, False, opt=opt, return_history=True)
+            assert len(hist) == 7 and r < 1e-6 * frms and abs(frms - frms_o) <= 1e-13 * frms_o
+            assert cit == cit_o, (form, cit, cit_o)        # the stop decision (krylov.jl:71) falls in the same iteration of every solve
+            d = np.abs(np.asarray(hist) - np.asarray(hist_o))
+            assert d.max() <= CG_HIST_ATOL_OF_FIRST * hist_o[0], (form, d.tolist())
+            assert (d <= CG_HIST_RTOL_PER_ENTRY * np.asarray(hist_o)).all(), (form, (d / np.asarray(hist_o)).tolist())
+            assert (d[:3] <= 1e-10 * np.asarray(hist_o)[:3]).all()      # north_star's figure holds while the residual is not yet small
+            assert np.abs(F.tonumpy(x) - xo).max() <= CG_FIELD_RTOL * np.abs(xo).max()
+    finally:
+        c.set_option("cg_fused", 3)
 
 
 @pytest.mark.parametrize("tol", [0.9, 0.7, 0.5, 0.4, 0.3, 0.25, 0.2, 0.15, 1e-9])

@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 A_EFF_BYTES = 32.0     # read Htau + read Ht + write Htau2 + write dHdtau, per interior cell
-KT_STEP, KT_STEP2, KT_MG_PRE, KT_MG_POST, KT_MG_SEAM = 0, 1, 2, 3, 4   # include/fpr.h FPR_KT_*
+KT_STEP, KT_STEP2, KT_MG_PRE, KT_MG_POST, KT_MG_SEAM, KT_MG_CG, KT_MG_PATCH = 0, 1, 2, 3, 4, 5, 6   # include/fpr.h FPR_KT_*
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -117,9 +117,9 @@ def cpu_baseline_diffusion(n, budget_s=10.0):
     }
 
 
-def cpu_baseline_vcycle(n, b_host):
-    """One V-cycle of the oracle's MGsolve (multigrid_bench.jl:27-42 protocol: x = 0, b ~ U[0,1), c = 0, l = 2, Jacobi
-    coarse solver) at n^2 on the host cores."""
+def cpu_baseline_vcycle(n, b_host, css=5, solver=0):
+    """One V-cycle of the oracle's MGsolve (multigrid_bench.jl:27-42 protocol: x = 0, b ~ U[0,1), c = 0; coarse grid css^2,
+    coarse solver 0 = Jacobi / 1 = cg!) at n^2 on the host cores."""
     import numpy as np
 
     threads = min(os.cpu_count() or 1, 16)
@@ -128,17 +128,20 @@ def cpu_baseline_vcycle(n, b_host):
 
     orc = Oracle(openmp=True)
     x = farr(n, n)
-    orc.mgsolve2d(x, b_host, 1.0 / (n - 1), 0.0, 1e-6, 1)   # warm-up / page touch (one V-cycle)
+    reps = 3 if css == 5 else 1          # a five-level cycle with the Jacobi coarse solver is 5140 sweeps of 257^2: seconds
+    if reps > 1:
+        orc.mgsolve2d(x, b_host, 1.0 / (n - 1), 0.0, 1e-6, 1, False, css, solver)   # warm-up / page touch (one V-cycle)
     ts = []
-    for _ in range(3):
+    for _ in range(reps):
         x[:] = 0.0
         t0 = time.time()
-        orc.mgsolve2d(x, b_host, 1.0 / (n - 1), 0.0, 1e-6, 1)
+        orc.mgsolve2d(x, b_host, 1.0 / (n - 1), 0.0, 1e-6, 1, False, css, solver)
         ts.append(time.time() - t0)
-    t = sorted(ts)[1]
+    t = sorted(ts)[len(ts) // 2]
     return {"value": t, "unit": "s", "cores": threads, "kind": "port",
-            "sample": "one V-cycle (MGsolve with niters = 1: rms(f) + V-cycle) of the C port at %d^2, l = 2, Jacobi coarse "
-                      "solver, OpenMP %d threads, median of 3" % (n, threads)}
+            "sample": "one V-cycle (MGsolve with niters = 1: rms(f) + V-cycle) of the C port at %d^2, coarse grid %d^2, %s coarse "
+                      "solver, OpenMP %d threads, %s" % (n, css, "cg!" if solver else "Jacobi", threads,
+                                                         "median of 3" if reps > 1 else "one run")}
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -172,11 +175,11 @@ def vcycle_block(F, with_cpu=True, steps=5):
         opt.coarse_solve_size, opt.coarse_solver = css, solver
         ts = []
         ncyc = 0
-        reps = steps if label == "l2_jacobi" else (3 if label == "l8_cg" else 1)
+        reps = steps if label == "l2_jacobi" else (3 if label == "l8_cg" else 2)
         for i in range(reps + 1):
             x.zero_()
             F.synchronize()
-            timed_kernels = label == "l2_jacobi" and i == reps   # last repetition: events around the finest passes
+            timed_kernels = i == reps   # last repetition: events around the finest passes / the coarse-solver launches
             if timed_kernels:
                 ctx.call("fpr_kernel_timer", 1)
             t0 = time.perf_counter()
@@ -184,13 +187,17 @@ def vcycle_block(F, with_cpu=True, steps=5):
                 warnings.simplefilter("ignore")
                 r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, b, h, 0.0, 1e-6, 100, False, opt=opt, return_history=True)
             F.synchronize()
-            if i > 0 or reps == 0:
-                ts.append(time.perf_counter() - t0)
+            if (i > 0 and not (timed_kernels and label != "l2_jacobi" and reps > 1)) or reps == 0:
+                ts.append(time.perf_counter() - t0)     # (event pairs around 28 000 small launches would show in the wall time)
             ncyc = len(hist)
             if timed_kernels:
-                for name, kind in (("pre", KT_MG_PRE), ("post", KT_MG_POST), ("seam", KT_MG_SEAM)):
-                    ms, cnt = timer_read(ctx, kind)
-                    kern[name] = (ms / max(cnt, 1), cnt)
+                if label == "l2_jacobi":
+                    for name, kind in (("pre", KT_MG_PRE), ("post", KT_MG_POST), ("seam", KT_MG_SEAM)):
+                        ms, cnt = timer_read(ctx, kind)
+                        kern[name] = (ms / max(cnt, 1), cnt)
+                else:
+                    ms, cnt = timer_read(ctx, KT_MG_CG if label == "l8_cg" else KT_MG_PATCH)
+                    kern[label] = (ms, cnt)
                 ctx.call("fpr_kernel_timer", 0)
         t = sorted(ts)[len(ts) // 2]
         out[label] = {"mgsolve_s": t, "vcycles": ncyc, "s_per_vcycle": t / max(ncyc, 1), "coarse_iters": int(cit),
@@ -258,6 +265,55 @@ def vcycle_block(F, with_cpu=True, steps=5):
             block["cpu_baseline"] = cpu_baseline_vcycle(n, b_host)
         except Exception as e:
             block["cpu_baseline"] = {"value": None, "unit": "s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    # ---- BASELINE config 3 read literally: "4096^2, 5 levels" = grids 4097^2 ... 257^2 (multigrid_bench.jl:27 sweeps l = 2:8; this is
+    # l = 8), typed like the block above.  The cycle is bound by its COARSE solve, and that by latency, not bytes: the 257^2 problem
+    # (0.5 MB per array) lives in the L2 / in registers, so the roofline of the dominant kernel is a time floor per iteration.
+    cg_ms, cg_solves = kern.get("l8_cg", (0.0, 0))
+    cg_its = max(out["l8_cg"]["coarse_iters"], 1)
+    us_per_cg_it = cg_ms * 1e3 / cg_its if cg_ms > 0 else None
+    CG_FLOOR_US = 4.2      # two grid barriers of 16 workgroups per iteration, 2.1 us each (profiles/r2_cg_persistent_sections.txt)
+    pt_ms, pt_launches = kern.get("l8_jacobi", (0.0, 0))
+    us_per_launch = pt_ms * 1e3 / pt_launches if pt_launches else None
+    PATCH_FIXED_US, PATCH_SWEEP_US = 4.5, 0.70     # a launch of 8 sweeps = 4.5 us fixed + 0.70 us per sweep
+    five = {"metric": "vcycle_wall_time_4097sq_5levels", "unit": "s", "higher_is_better": False, "dtype": "f64",
+            "config": {"workload": "2D Poisson V-cycle 4097^2, 5 grids (4097^2 ... 257^2, l = 8), 2+2 Jacobi smooths; "
+                                   "multigrid_bench.jl protocol (x=0, b~U[0,1), c=0, tol 1e-6); coarse solve = cg! or 20*257 "
+                                   "damped-Jacobi sweeps (the reference's default coarse solver)"},
+            "value": out["l8_cg"]["s_per_vcycle"], "value_is": "conjugate_gradient (the faster coarse solver, as in the reference's table)",
+            "conjugate_gradient": {
+                "value": out["l8_cg"]["s_per_vcycle"], "unit": "s", "mgsolve_s": out["l8_cg"]["mgsolve_s"], "vcycles": out["l8_cg"]["vcycles"],
+                "coarse_iters": out["l8_cg"]["coarse_iters"],
+                "roofline": {"bound": "latency", "kernel": "k_cg_persistent (one launch per coarse solve: 16 workgroups, x / r / p / p_hat in "
+                                                           "registers, two grid barriers per CG iteration)",
+                             "achieved": us_per_cg_it, "peak": CG_FLOOR_US, "unit": "us per CG iteration",
+                             "frac": (CG_FLOOR_US / us_per_cg_it) if us_per_cg_it else None,
+                             "launches": cg_solves, "kernel_ms_total": cg_ms,
+                             "share_of_solve": cg_ms * 1e-3 / out["l8_cg"]["mgsolve_s"] if out["l8_cg"]["mgsolve_s"] > 0 else None,
+                             "traffic": None,
+                             "note": "achieved = hipEvent time of all k_cg_persistent launches of one solve / CG iterations; peak = the floor "
+                                     "of two barrier round trips per iteration (krylov.jl's recurrence needs p.p_hat before alpha and "
+                                     "r.r before beta); frac = floor / achieved"}},
+            "jacobi": {
+                "value": out["l8_jacobi"]["s_per_vcycle"], "unit": "s", "mgsolve_s": out["l8_jacobi"]["mgsolve_s"], "vcycles": out["l8_jacobi"]["vcycles"],
+                "coarse_iters": out["l8_jacobi"]["coarse_iters"],
+                "roofline": {"bound": "latency", "kernel": "k_jacobi_patch (8 sweeps of the 257^2 grid per launch: 32x32 regions as 2x2 register "
+                                                           "patches, edges through LDS, exit test replayed in the next launch)",
+                             "achieved": us_per_launch / 8.0 if us_per_launch else None, "peak": PATCH_SWEEP_US, "unit": "us per sweep",
+                             "frac": (PATCH_SWEEP_US / (us_per_launch / 8.0)) if us_per_launch else None,
+                             "us_per_launch_of_8_sweeps": us_per_launch, "launches_timed": pt_launches,
+                             "fixed_us_per_launch": PATCH_FIXED_US, "traffic": None,
+                             "note": "achieved = hipEvent time per 8-sweep launch / 8; peak = the per-sweep cost inside a launch "
+                                     "(measured with 2 / 4 / 8 sweeps per launch: 4.5 us fixed + 0.70 us per sweep); frac = how much of a "
+                                     "launch is sweeps rather than launch boundary"}}}
+    if with_cpu:
+        for key, solver in (("conjugate_gradient", 1), ("jacobi", 0)):
+            try:
+                five[key]["cpu_baseline"] = cpu_baseline_vcycle(n, b_host, 257, solver)
+            except Exception as e:
+                five[key]["cpu_baseline"] = {"value": None, "unit": "s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        five["cpu_baseline"] = five["conjugate_gradient"]["cpu_baseline"]
+    five["roofline"] = five["conjugate_gradient"]["roofline"]
+    block["vcycle_5levels"] = five
     return block
 
 
@@ -668,6 +724,7 @@ def main():
             torch.cuda.empty_cache()
             try:
                 out["vcycle"] = vcycle_block(F, with_cpu=not args.no_cpu_baseline)
+                out["vcycle_5levels"] = out["vcycle"].pop("vcycle_5levels")
             except Exception as e:
                 out["vcycle"] = {"error": repr(e)}
             try:

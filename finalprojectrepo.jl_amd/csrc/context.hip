@@ -171,6 +171,7 @@ extern "C" int fpr_kernel_timer_read(fpr_ctx* ctx, int kind, double* total_ms_ho
     if (!ctx || !total_ms_host || !count_host) return FPR_ERR_INVALID;
     FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
     FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));
+    if (ctx->stream[2] != ctx->stream[0]) FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[2]));
     double tot = 0.0;
     long cnt = 0;
     for (size_t i = 0; i + 1 < ctx->ktimer_used; i += 2) {

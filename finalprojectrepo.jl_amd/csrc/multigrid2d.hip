@@ -768,7 +768,9 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
             // (one per CU, 256 CUs), every wait is bounded, and a cooperative launch moves the process onto the runtime's
             // cooperative queue -- after it, kernels of two streams no longer overlap (measured: the side-by-side T / W solves
             // of the NS step 1.61 -> 1.96 ms, tools/exp_ns_only.py).
+            const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_CG, s);
             k_cg_persistent<<<dim3(CGP_NB), dim3(CGP_NT), lds, s>>>(a);
+            fpr_ktimer_end(ctx, timed, s);
             FPR_CHECK_LAUNCH(ctx);
             if (int rc = read_state(ctx)) return rc;
             if (ctx->state_h->done >= 0) return FPR_OK;   // x_in holds the solution (krylov.jl:88)
@@ -1188,8 +1190,10 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                         double* slot = ctx->partials + (size_t)(gi & 1) * S * nblk;
                         const double* pslot = ctx->partials + (size_t)((gi + 1) & 1) * S * nblk;
                         const bool pending = gi > gdone;  // the previous group of THIS chunk is still unchecked
+                        const bool timed = nsw == Sg && fpr_ktimer_begin(ctx, FPR_KT_MG_PATCH, s);
                         k_jacobi_patch<PS, PP, true, true><<<gm, (PP / 2) * (PP / 2), 0, s>>>(a, rhs, b, nx, ny, C, _h2, fac, nsw, slot, ctx->state,
                                                                                                 pslot, pending ? Sg : 0, gi - 1, (double)N);
+                        fpr_ktimer_end(ctx, timed, s);
                         if (gi == gend - 1)  // last group of the chunk: stand-alone check before the host polls
                             k_jacobi_check_multi<<<1, 256, 0, s>>>(ctx->state, slot, nblk, nsw, (double)N, gi);
                     } else {

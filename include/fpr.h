@@ -65,8 +65,10 @@ enum {
     FPR_KT_DIFF3_STEP2 = 1,   /* k_diff3_march2: two pseudo-iterations per launch                             */
     FPR_KT_MG_PRE = 2,        /* finest level of a V-cycle: 2 sweeps + residual + injection in one pass       */
     FPR_KT_MG_POST = 3,       /* finest level of a V-cycle: prolongation + correction + 2 sweeps (+ norm)     */
-    FPR_KT_MG_SEAM = 4        /* finest level between two V-cycles of fpr_mgsolve2d: post pair of cycle k + norm +
+    FPR_KT_MG_SEAM = 4,       /* finest level between two V-cycles of fpr_mgsolve2d: post pair of cycle k + norm +
                                  pre pair + residual + injection of cycle k+1 in one pass (k_seam_march)         */
+    FPR_KT_MG_CG = 5,         /* coarse solve by cg! as ONE persistent launch (k_cg_persistent): a launch = a solve      */
+    FPR_KT_MG_PATCH = 6       /* coarse solve by damped Jacobi on a large coarse grid: one launch = 8 sweeps (k_jacobi_patch) */
 };
 int fpr_kernel_timer(fpr_ctx* ctx, int enable);
 int fpr_kernel_timer_read(fpr_ctx* ctx, int kind, double* total_ms_host, long* count_host);

@@ -376,6 +376,366 @@ __global__ __launch_bounds__(256) void k_seam_march(const double* __restrict__ u
     if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
 }
 
+// ---- k_seam_march, second version: the same pass with ~half the vector instructions per row (round 3) -----------------------
+// Counters of the first version (profiles/r2_mg_seam_pmc.txt): 49.8 M vector instructions per launch at 4097^2 = 138 per
+// wave-row = a VALU floor of 81-91 us beside a memory floor of 91 us for a pass that takes 130 us -- as much VALU-bound as
+// memory-bound.  What changed, results unchanged (same operations on the same operands in the same order per point):
+//   * chunks start on an EVEN row (one more row of overlap), so the parity of every row of the unrolled loop is a
+//     compile-time constant: the prolongation of an even row has two terms, of an odd row four -- no per-row branch on
+//     "did the coarse row change", no per-term selects;
+//   * the coarse correction is fetched through a buffer descriptor with the per-lane column masks (interior coarse column,
+//     odd fine column) folded into the lane's byte offset and the per-row masks (interior coarse row) into the scalar
+//     offset: an excluded term is a load that returns 0 (w * 0 added is what the first version's `cond ? w*c : 0.0` adds),
+//     and the coarse rows sit in a ring of three register pairs with compile-time slots, loaded three rows before use
+//     (the first version loaded them in the row that used them: every other row waited for its newest load);
+//   * boundary COLUMNS keep their value by a per-lane factor (fac or 0) instead of a select per sweep, boundary ROWS (first
+//     / last row of the grid: first / last chunk only) by a uniform branch;
+//   * the residual stage and its stores run in the rows that are injected (every other one), the norm is accumulated
+//     unmasked under a uniform row test and masked per lane once at the end.
+template <bool BCS>
+__global__ __launch_bounds__(256) void k_seam_march_v2(const double* __restrict__ uin, const double* __restrict__ f,
+                                                        double* __restrict__ uout, int nx, int ny, double C, double _h2,
+                                                        double fac, int rows_per_chunk, int nstrips,
+                                                        double* __restrict__ partials, const double* __restrict__ corr_c,
+                                                        double* __restrict__ res_c_out, double* __restrict__ corr_c_out,
+                                                        const int* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    __shared__ double red[16];
+    constexpr int HX = 5;                                    // feeder lanes on each side of a strip
+    constexpr int SW = 64 - 2 * HX;                          // columns owned by a strip
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + w;
+    const bool active = strip < nstrips;
+    const int gi = strip * SW - HX + lane;                   // global column of this lane
+    const bool col_ok = active && gi >= 0 && gi < nx;
+    const int gic = gi < 0 ? 0 : (gi > nx - 1 ? nx - 1 : gi);  // clamped for loads
+    const bool col_bnd = gi <= 0 || gi >= nx - 1;            // domain boundary column (or outside)
+    const bool owner = col_ok && lane >= HX && lane < 64 - HX;
+    const int y0 = blockIdx.y * rows_per_chunk;              // host: rows_per_chunk is even
+    const int y1 = (y0 + rows_per_chunk < ny) ? y0 + rows_per_chunk : ny;  // output rows [y0, y1)
+    const int rs = y0 - 6 < 0 ? 0 : y0 - 6;                  // EVEN: row rs + T has the parity of T
+    double acc = 0.0;
+    if (active) {
+        const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
+        int gis = gic;  // Neumann columns of the prolongated correction (part2_utils.jl:35-39)
+        if (BCS) gis = (gic == 0) ? 1 : (gic == nx - 1 ? nx - 2 : gic);
+        const int p_io = gis & 1, p_icl = gis >> 1, p_ich = (p_icl + 1 < nxc) ? p_icl + 1 : nxc - 1;
+        const bool p_sx0 = p_icl >= 1 && p_icl <= nxc - 2, p_sx1 = p_io && (p_icl + 1 <= nxc - 2);
+        const bool p_inx = gis >= 1 && gis <= nx - 2;
+        const double wE = p_io ? 0.5 : 1.0, wO = p_io ? 0.25 : 0.5;   // prolong_bf's weight in an even / odd fine row
+        const unsigned vcl = (p_inx && p_sx0) ? (unsigned)p_icl * 8u : FPR_OOR;   // excluded terms read 0
+        const unsigned vch = (p_inx && p_sx1) ? (unsigned)p_ich * 8u : FPR_OOR;
+        const __amdgpu_buffer_rsrc_t rCor = fpr_rsrc(corr_c);
+        const int crow = nxc * 8;
+        double cs[3][2];                                     // coarse rows j, j+1, j+2 (slot = (j - rs/2) mod 3): columns icl, ich
+        auto ldc = [&](int slot, int j) {
+            const int so = (j >= 1 && j <= nyc - 2) ? j * crow : (int)FPR_OOR;   // a boundary coarse row contributes nothing
+            cs[slot][0] = fpr_bld(rCor, vcl, so);
+            cs[slot][1] = fpr_bld(rCor, vch, so);
+        };
+        const int rowB = nx * 8;
+        const __amdgpu_buffer_rsrc_t rUin = fpr_rsrc(uin + (size_t)nx * rs), rF = fpr_rsrc(f + (size_t)nx * rs);
+        const __amdgpu_buffer_rsrc_t rUout = fpr_rsrc(uout + (size_t)nx * rs);
+        const unsigned vld = (unsigned)gic * 8u;
+        const unsigned vst = owner ? (unsigned)gi * 8u : FPR_OOR;   // lanes that own nothing store out of range
+        // corrected input of row `row` = rs + LR (mod 12): u - P(corr), terms and order of prolong_bf
+        auto ldu = [&](auto LRc, int row) {
+            constexpr int LR = decltype(LRc)::value;
+            constexpr int JR = LR >> 1;
+            constexpr int SA = JR % 3, SB = (JR + 1) % 3, SN = (JR + 2) % 3;
+            const int rc = row > ny - 1 ? ny - 1 : row;
+            const double v = fpr_bld(rUin, vld, (rc - rs) * rowB);
+            double pv;
+            if constexpr ((LR & 1) == 0) {
+                ldc(SN, (row >> 1) + 2);           // used three rows from now; its slot held the row last used one row ago
+                pv = wE * cs[SA][0];
+                pv = pv + wE * cs[SA][1];
+            } else {
+                pv = wO * cs[SA][0];
+                pv = pv + wO * cs[SA][1];
+                pv = pv + wO * cs[SB][0];
+                pv = pv + wO * cs[SB][1];
+            }
+            return v - pv;
+        };
+        auto ldf = [&](int r) { const int rc = r > ny - 1 ? ny - 1 : r; return fpr_bld(rF, vld, (rc - rs) * rowB); };
+        double wv[5][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+        double fw[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        using I0 = std::integral_constant<int, 0>;
+        ldc(0, rs >> 1);
+        ldc(1, (rs >> 1) + 1);
+        wv[0][0] = ldu(I0{}, rs);
+        fw[0] = ldf(rs);
+        constexpr int PF = 4;
+        double pu[PF], pfv[PF];
+        pu[0] = ldu(std::integral_constant<int, 1>{}, rs + 1); pfv[0] = ldf(rs + 1);
+        pu[1] = ldu(std::integral_constant<int, 2>{}, rs + 2); pfv[1] = ldf(rs + 2);
+        pu[2] = ldu(std::integral_constant<int, 3>{}, rs + 3); pfv[2] = ldf(rs + 3);
+        pu[3] = ldu(std::integral_constant<int, 4>{}, rs + 4); pfv[3] = ldf(rs + 4);
+        const __amdgpu_buffer_rsrc_t rResC = fpr_rsrc(res_c_out), rCorC = fpr_rsrc(corr_c_out);
+        const unsigned vstc = (owner && !(gi & 1)) ? (unsigned)(gi >> 1) * 8u : FPR_OOR;
+        // BCS: Neumann columns of the coarse right-hand side (:355-357), see k_smooth2_march
+        const unsigned vstr = (BCS && (gi == 0 || gi == nx - 1)) ? FPR_OOR : vstc;
+        const unsigned vstn = (BCS && owner && (gi == 2 || gi == nx - 3)) ? (gi == 2 ? 0u : (unsigned)(nxc - 1) * 8u) : FPR_OOR;
+        const double facL = col_bnd ? 0.0 : fac;             // a boundary column keeps its value: mid + 0 * rr
+        const bool cint_col = (gi >> 1) >= 1 && (gi >> 1) <= nxc - 2;
+        // one Jacobi sweep at row j of a field whose rows j-1, j, j+1 are (lo, mid, hi); rr = residual used by the update
+        auto sweep = [&](double lo, double mid, double hi, double fv, int j, double& rr) {
+            const double L = fpr_lane_up1z(mid), R = fpr_lane_down1z(mid);
+            rr = ((((R + L) + hi) + lo) - C * mid) * _h2 - fv;
+            double un = mid + facL * rr;
+            if (j <= 0 || j >= ny - 1) { asm volatile("" ::: "memory"); un = mid; }   // uniform: first / last row of the grid
+            return un;
+        };
+        auto step = [&](auto Tc, int r) {
+            constexpr int T = decltype(Tc)::value;               // (r - rs) mod 12
+            constexpr int Q = T % 4, M = T % 3, F = T % 6;
+            constexpr int M1 = (M + 1) % 3, M2 = (M + 2) % 3;    // slots of rows r-2 (= r+1) and r-1
+            auto fs = [](int k) { return (F - k + 6) % 6; };     // slot of f row r-k
+            double an, fn;
+            asm volatile("v_mov_b64 %0, %1" : "=v"(an) : "v"(pu[Q]));
+            asm volatile("v_mov_b64 %0, %1" : "=v"(fn) : "v"(pfv[Q]));
+            pu[Q] = ldu(std::integral_constant<int, T + 1 + PF>{}, r + 1 + PF);   // issue the loads of row r+1+PF
+            pfv[Q] = ldf(r + 1 + PF);
+            double rr;
+            // ---- cycle k, post-smoothing (:142-143): sweeps 1 and 2 at rows r-1, r-2 ----
+            wv[1][M2] = sweep(wv[0][M1], wv[0][M2], wv[0][M], fw[fs(1)], r - 1, rr);
+            const int j2 = r - 2;
+            double u2 = sweep(wv[1][M], wv[1][M1], wv[1][M2], fw[fs(2)], j2, rr);   // u at the end of cycle k (not stored)
+            if constexpr (BCS) {
+                // apply_boundary_conditions! between the cycles (multigrid.jl:60-62): Neumann columns copy their inner neighbour
+                const double fromR = fpr_lane_down1z(u2), fromL = fpr_lane_up1z(u2);
+                u2 = (gi == 0) ? fromR : ((gi == nx - 1) ? fromL : u2);
+            }
+            wv[2][M1] = u2;
+            if (j2 >= y0 && j2 < y1 && j2 > 0 && j2 < ny - 1) {   // uniform; lanes that own nothing are dropped at the end
+                asm volatile("" ::: "memory");
+                acc = acc + rr * rr;                              // r_rms of cycle k (:252)
+            }
+            // ---- cycle k+1, pre-smoothing (:124-125): sweeps 3 and 4 at rows r-3, r-4 ----
+            wv[3][M] = sweep(wv[2][M2], wv[2][M], wv[2][M1], fw[fs(3)], r - 3, rr);
+            const int j4 = r - 4;
+            const double u4 = sweep(wv[3][M1], wv[3][M2], wv[3][M], fw[fs(4)], j4, rr);
+            {
+                const bool row_own = j4 >= y0 && j4 < y1;      // uniform
+                fpr_bst(rUout, vst, row_own ? (j4 - rs) * rowB : (int)FPR_OOR, u4);   // unconditional (see FPR_OOR)
+            }
+            wv[4][M2] = u4;
+            // ---- residual of the pre-smoothed field at row r-5 (even in every odd step), injected at even columns (:128-132) ----
+            if constexpr ((T & 1) == 1) {
+                const int j5 = r - 5;
+                const double mid = wv[4][M1];
+                const double L = fpr_lane_up1z(mid), R = fpr_lane_down1z(mid);
+                const double rres = ((((R + L) + wv[4][M2]) + wv[4][M]) - C * mid) * _h2 - fw[fs(5)];
+                const int jc = j5 >> 1;
+                const bool cint = cint_col && jc >= 1 && jc <= nyc - 2;
+                const bool row_inj = j5 >= y0 && j5 < y1;       // uniform
+                const int sc = row_inj ? jc * crow : (int)FPR_OOR;
+                fpr_bst(rResC, vstr, sc, cint ? rres : 0.0);
+                if constexpr (BCS) fpr_bst(rResC, vstn, sc, cint ? rres : 0.0);
+                fpr_bst(rCorC, vstc, sc, 0.0);
+            }
+            wv[0][M1] = an;            // row r+1 takes the slot of row r-2
+            fw[(F + 1) % 6] = fn;      // row r+1 takes the slot of row r-5
+        };
+        const int rend = y1 + 4;
+        int r = rs;
+#define FPR_SEAM_STEP(T) step(std::integral_constant<int, T>{}, r + T)
+        for (; r + 11 <= rend; r += 12) {
+            FPR_SEAM_STEP(0); FPR_SEAM_STEP(1); FPR_SEAM_STEP(2); FPR_SEAM_STEP(3); FPR_SEAM_STEP(4); FPR_SEAM_STEP(5);
+            FPR_SEAM_STEP(6); FPR_SEAM_STEP(7); FPR_SEAM_STEP(8); FPR_SEAM_STEP(9); FPR_SEAM_STEP(10); FPR_SEAM_STEP(11);
+        }
+#undef FPR_SEAM_STEP
+#define FPR_SEAM_TAIL(T) if (r <= rend) { step(std::integral_constant<int, T>{}, r); ++r; }
+        FPR_SEAM_TAIL(0) FPR_SEAM_TAIL(1) FPR_SEAM_TAIL(2) FPR_SEAM_TAIL(3) FPR_SEAM_TAIL(4) FPR_SEAM_TAIL(5)
+        FPR_SEAM_TAIL(6) FPR_SEAM_TAIL(7) FPR_SEAM_TAIL(8) FPR_SEAM_TAIL(9) FPR_SEAM_TAIL(10)
+#undef FPR_SEAM_TAIL
+        acc = (owner && !col_bnd) ? acc : 0.0;
+    }
+    const double sblk = fpr_block_sum<256>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
+}
+
+// ---- k_smooth2_march, second version (round 3): what k_seam_march_v2 does for the seam, for the two-sweep passes ------------
+// Same fields as k_smooth2_march (same operations on the same operands per point).  Chunks start on an even row, so row
+// parity is a compile-time constant of the loop unrolled by 12: the prolongation has two terms in even rows and four in odd
+// ones, its coarse rows come through a buffer descriptor with the exclusion masks folded into the offsets (an excluded term
+// reads 0) into a ring of three register pairs three rows ahead of their use; windows live in compile-time slots (no
+// shifting of nine window rows per step); boundary columns keep their value through a per-lane factor, boundary rows
+// through a uniform branch; the residual stage runs in the injected rows only; the norm is masked per lane once at the end.
+template <bool NORM, bool PROLONG, bool RESTRICT>
+__global__ __launch_bounds__(256) void k_smooth2_march_v2(const double* __restrict__ uin, const double* __restrict__ f,
+                                                           double* __restrict__ uout, int nx, int ny, double C, double _h2,
+                                                           double fac, int rows_per_chunk, int nstrips,
+                                                           double* __restrict__ partials, const double* __restrict__ corr_c,
+                                                           int apply_BCs, double* __restrict__ res_c_out,
+                                                           double* __restrict__ corr_c_out, const int* __restrict__ skip)
+{
+    if (skip && *skip) return;   // a cycle enqueued ahead of the exit test that ended the loop (FprCycleCtl)
+    __shared__ double red[16];
+    constexpr int HX = RESTRICT ? 3 : 2;                     // feeder lanes on each side of a strip
+    constexpr int SW = 64 - 2 * HX;                          // columns owned by a strip
+    apply_BCs &= 255;                                        // (bit 8, non-temporal stores, is ignored by this kernel)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + w;
+    const bool active = strip < nstrips;
+    const int gi = strip * SW - HX + lane;                   // global column of this lane
+    const bool col_ok = active && gi >= 0 && gi < nx;
+    const int gic = gi < 0 ? 0 : (gi > nx - 1 ? nx - 1 : gi);  // clamped for loads
+    const bool col_bnd = gi <= 0 || gi >= nx - 1;            // domain boundary column (or outside)
+    const bool owner = col_ok && lane >= HX && lane < 64 - HX;
+    const int y0 = blockIdx.y * rows_per_chunk;              // host: rows_per_chunk is even
+    const int y1 = (y0 + rows_per_chunk < ny) ? y0 + rows_per_chunk : ny;  // output rows [y0, y1)
+    constexpr int HY = RESTRICT ? 4 : 2;                     // rows above the chunk (even: row rs + T has the parity of T)
+    const int rs = y0 - HY < 0 ? 0 : y0 - HY;
+    double acc = 0.0;
+    if (active) {
+        const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
+        int gis = gic;  // Neumann columns of the prolongated correction (part2_utils.jl:35-39)
+        if (PROLONG && apply_BCs) gis = (gic == 0) ? 1 : (gic == nx - 1 ? nx - 2 : gic);
+        const int p_io = gis & 1, p_icl = gis >> 1, p_ich = (p_icl + 1 < nxc) ? p_icl + 1 : nxc - 1;
+        const bool p_sx0 = p_icl >= 1 && p_icl <= nxc - 2, p_sx1 = p_io && (p_icl + 1 <= nxc - 2);
+        const bool p_inx = gis >= 1 && gis <= nx - 2;
+        const double wE = p_io ? 0.5 : 1.0, wO = p_io ? 0.25 : 0.5;   // prolong_bf's weight in an even / odd fine row
+        const unsigned vcl = (PROLONG && p_inx && p_sx0) ? (unsigned)p_icl * 8u : FPR_OOR;   // excluded terms read 0
+        const unsigned vch = (PROLONG && p_inx && p_sx1) ? (unsigned)p_ich * 8u : FPR_OOR;
+        const __amdgpu_buffer_rsrc_t rCor = fpr_rsrc(PROLONG ? (const void*)corr_c : (const void*)uin);
+        const int crow = nxc * 8;
+        double cs[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};   // coarse rows j, j+1, j+2 (slot = (j - rs/2) mod 3): columns icl, ich
+        auto ldc = [&](int slot, int j) {
+            if constexpr (PROLONG) {
+                const int so = (j >= 1 && j <= nyc - 2) ? j * crow : (int)FPR_OOR;   // a boundary coarse row contributes nothing
+                cs[slot][0] = fpr_bld(rCor, vcl, so);
+                cs[slot][1] = fpr_bld(rCor, vch, so);
+            }
+        };
+        // rows are addressed relative to the first row of the chunk: (rows_per_chunk + 8) * nx * 8 < 2^31
+        const int rowB = nx * 8;
+        const __amdgpu_buffer_rsrc_t rUin = fpr_rsrc(uin + (size_t)nx * rs), rF = fpr_rsrc(f + (size_t)nx * rs);
+        const __amdgpu_buffer_rsrc_t rUout = fpr_rsrc(uout + (size_t)nx * rs);
+        const unsigned vld = (unsigned)gic * 8u;
+        const unsigned vst = owner ? (unsigned)gi * 8u : FPR_OOR;   // lanes that own nothing store out of range
+        auto ldu = [&](auto LRc, int row) {
+            constexpr int LR = decltype(LRc)::value;             // (row - rs) mod 12
+            constexpr int JR = LR >> 1;
+            constexpr int SA = JR % 3, SB = (JR + 1) % 3, SN = (JR + 2) % 3;
+            const int rc = row > ny - 1 ? ny - 1 : row;
+            const double v = fpr_bld(rUin, vld, (rc - rs) * rowB);
+            if constexpr (PROLONG) {
+                double pv;
+                if constexpr ((LR & 1) == 0) {
+                    ldc(SN, (row >> 1) + 2);       // used three rows from now; its slot held the row last used one row ago
+                    pv = wE * cs[SA][0];
+                    pv = pv + wE * cs[SA][1];
+                } else {
+                    pv = wO * cs[SA][0];
+                    pv = pv + wO * cs[SA][1];
+                    pv = pv + wO * cs[SB][0];
+                    pv = pv + wO * cs[SB][1];
+                }
+                return v - pv;
+            } else {
+                return v;
+            }
+        };
+        auto ldf = [&](int r) { const int rc = r > ny - 1 ? ny - 1 : r; return fpr_bld(rF, vld, (rc - rs) * rowB); };
+        // windows in compile-time slots: row j of u (wa), of the once-smoothed field (wb), of the twice-smoothed field (wc,
+        // RESTRICT) lives in slot (j - rs) mod 3, row j of f in slot (j - rs) mod 4
+        double wa[3] = {0.0, 0.0, 0.0}, wb[3] = {0.0, 0.0, 0.0}, wc[3] = {0.0, 0.0, 0.0}, fw[4] = {0.0, 0.0, 0.0, 0.0};
+        ldc(0, rs >> 1);
+        ldc(1, (rs >> 1) + 1);
+        wa[0] = ldu(std::integral_constant<int, 0>{}, rs);
+        fw[0] = ldf(rs);
+        constexpr int PF = 4;
+        double pu[PF], pfv[PF];
+        pu[0] = ldu(std::integral_constant<int, 1>{}, rs + 1); pfv[0] = ldf(rs + 1);
+        pu[1] = ldu(std::integral_constant<int, 2>{}, rs + 2); pfv[1] = ldf(rs + 2);
+        pu[2] = ldu(std::integral_constant<int, 3>{}, rs + 3); pfv[2] = ldf(rs + 3);
+        pu[3] = ldu(std::integral_constant<int, 4>{}, rs + 4); pfv[3] = ldf(rs + 4);
+        // RESTRICT: coarse arrays (whole-array descriptors: nxc * nyc * 8 < 2^31), even owned columns only
+        const __amdgpu_buffer_rsrc_t rResC = fpr_rsrc(RESTRICT ? (const void*)res_c_out : (const void*)uout);
+        const __amdgpu_buffer_rsrc_t rCorC = fpr_rsrc(RESTRICT ? (const void*)corr_c_out : (const void*)uout);
+        const unsigned vstc = (RESTRICT && owner && !(gi & 1)) ? (unsigned)(gi >> 1) * 8u : FPR_OOR;
+        // RESTRICT with apply_BCs: Neumann columns of the coarse right-hand side (:355-357), see k_smooth2_march
+        const bool nbc = RESTRICT && apply_BCs != 0;
+        const unsigned vstr = (nbc && (gi == 0 || gi == nx - 1)) ? FPR_OOR : vstc;
+        const unsigned vstn = (nbc && owner && (gi == 2 || gi == nx - 3)) ? (gi == 2 ? 0u : (unsigned)(nxc - 1) * 8u) : FPR_OOR;
+        const double facL = col_bnd ? 0.0 : fac;             // a boundary column keeps its value: mid + 0 * rr
+        const bool cint_col = (gi >> 1) >= 1 && (gi >> 1) <= nxc - 2;
+        auto sweep = [&](double lo, double mid, double hi, double fv, int j, double& rr) {
+            const double L = fpr_lane_up1z(mid), R = fpr_lane_down1z(mid);
+            rr = ((((R + L) + hi) + lo) - C * mid) * _h2 - fv;
+            double un = mid + facL * rr;
+            if (j <= 0 || j >= ny - 1) { asm volatile("" ::: "memory"); un = mid; }   // uniform: first / last row of the grid
+            return un;
+        };
+        auto step = [&](auto Tc, int r) {
+            constexpr int T = decltype(Tc)::value;               // (r - rs) mod 12
+            constexpr int Q = T % 4, M = T % 3, F = T % 4;
+            constexpr int M1 = (M + 1) % 3, M2 = (M + 2) % 3;    // slots of rows r-2 (= r+1) and r-1
+            auto fs = [](int k) { return (F - k + 4) % 4; };     // slot of f row r-k
+            double an, fn;
+            asm volatile("v_mov_b64 %0, %1" : "=v"(an) : "v"(pu[Q]));
+            asm volatile("v_mov_b64 %0, %1" : "=v"(fn) : "v"(pfv[Q]));
+            pu[Q] = ldu(std::integral_constant<int, T + 1 + PF>{}, r + 1 + PF);   // issue the loads of row r+1+PF
+            pfv[Q] = ldf(r + 1 + PF);
+            double rr;
+            // ---- sweep 1 at row r-1 (u rows r-2, r-1, r) ----
+            wb[M2] = sweep(wa[M1], wa[M2], wa[M], fw[fs(1)], r - 1, rr);
+            // ---- sweep 2 at row r-2 (once-smoothed rows r-3, r-2, r-1) ----
+            const int j2 = r - 2;
+            const double u2 = sweep(wb[M], wb[M1], wb[M2], fw[fs(2)], j2, rr);
+            {
+                const bool row_own = j2 >= y0 && j2 < y1;        // uniform
+                fpr_bst(rUout, vst, row_own ? (j2 - rs) * rowB : (int)FPR_OOR, u2);   // unconditional (see FPR_OOR)
+            }
+            if constexpr (NORM) {
+                if (j2 >= y0 && j2 < y1 && j2 > 0 && j2 < ny - 1) {   // uniform; lanes that own nothing are dropped at the end
+                    asm volatile("" ::: "memory");
+                    acc = acc + rr * rr;
+                }
+            }
+            if constexpr (RESTRICT) {
+                wc[M1] = u2;
+                // ---- residual of the twice-smoothed field at row r-3 (even in every odd step), injected at even columns ----
+                if constexpr ((T & 1) == 1) {
+                    const int j3 = r - 3;
+                    const double mid = wc[M];
+                    const double L = fpr_lane_up1z(mid), R = fpr_lane_down1z(mid);
+                    const double rres = ((((R + L) + wc[M1]) + wc[M2]) - C * mid) * _h2 - fw[fs(3)];
+                    const int jc = j3 >> 1;
+                    const bool cint = cint_col && jc >= 1 && jc <= nyc - 2;
+                    const bool row_inj = j3 >= y0 && j3 < y1;   // uniform
+                    const int sc = row_inj ? jc * crow : (int)FPR_OOR;
+                    fpr_bst(rResC, vstr, sc, cint ? rres : 0.0);
+                    fpr_bst(rResC, vstn, sc, cint ? rres : 0.0);
+                    fpr_bst(rCorC, vstc, sc, 0.0);
+                }
+            }
+            wa[M1] = an;               // row r+1 takes the slot of row r-2
+            fw[(F + 1) % 4] = fn;      // row r+1 takes the slot of row r-3
+        };
+        const int rend = y1 + (RESTRICT ? 2 : 1);
+        int r = rs;
+#define FPR_M2_STEP(T) step(std::integral_constant<int, T>{}, r + T)
+        for (; r + 11 <= rend; r += 12) {
+            FPR_M2_STEP(0); FPR_M2_STEP(1); FPR_M2_STEP(2); FPR_M2_STEP(3); FPR_M2_STEP(4); FPR_M2_STEP(5);
+            FPR_M2_STEP(6); FPR_M2_STEP(7); FPR_M2_STEP(8); FPR_M2_STEP(9); FPR_M2_STEP(10); FPR_M2_STEP(11);
+        }
+#undef FPR_M2_STEP
+#define FPR_M2_TAIL(T) if (r <= rend) { step(std::integral_constant<int, T>{}, r); ++r; }
+        FPR_M2_TAIL(0) FPR_M2_TAIL(1) FPR_M2_TAIL(2) FPR_M2_TAIL(3) FPR_M2_TAIL(4) FPR_M2_TAIL(5)
+        FPR_M2_TAIL(6) FPR_M2_TAIL(7) FPR_M2_TAIL(8) FPR_M2_TAIL(9) FPR_M2_TAIL(10)
+#undef FPR_M2_TAIL
+        acc = (owner && !col_bnd) ? acc : 0.0;
+    }
+    if constexpr (NORM) {
+        const double sblk = fpr_block_sum<256>(acc, red);
+        if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
+    }
+}
+
 // ---- k_smooth2_march, two columns per lane (opt-in; measured slower, see vcycle_level) -------------------------------------------------
 // Same algorithm as k_smooth2_march with a strip of 128 columns per wave: a lane holds two adjacent
 // columns, loads/stores them with one 16-byte access (the hardware accepts the 8-byte alignment that

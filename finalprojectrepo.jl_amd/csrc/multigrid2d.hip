@@ -183,6 +183,14 @@ __device__ __forceinline__ double prolong_bf(const double* __restrict__ cc, int 
 
 #include "mg_march.hpp"   // k_smooth2_march, k_seam_march, k_smooth2_march2: the register-rolling marches of the fine levels
 
+// the two-sweep pass in its first or second version ("mg_march_v", default 2; same fields)
+template <bool N, bool P, bool R, class... A>
+static inline void march_go(fpr_ctx* ctx, dim3 g, hipStream_t s, A... a)
+{
+    if (fpr_opt(ctx, "mg_march_v", 2) == 1) k_smooth2_march<N, P, R><<<g, 256, 0, s>>>(a...);
+    else k_smooth2_march_v2<N, P, R><<<g, 256, 0, s>>>(a...);
+}
+
 // ---- S fused Jacobi sweeps, register patches (coarse solve on grids too large for one workgroup) ------
 // The coarse-grid Jacobi solve of the "few levels" configurations (e.g. 257^2, 5140 sweeps per V-cycle)
 // is latency bound: ~1 MFLOP per sweep.  A workgroup of 16x16 threads holds a 32x32 region in
@@ -1068,17 +1076,18 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                 rpc = 64;
                 while (rpc > 16 && (long)nstrips * ((ny + rpc - 1) / rpc) < target) rpc >>= 1;
             }
+            rpc += rpc & 1;   // chunks start on even rows (k_smooth2_march_v2)
             const dim3 gm((nstrips + 3) / 4, (ny + rpc - 1) / rpc);
             const int npm = (int)(gm.x * gm.y);
             const bool fuse_p = fpr_opt(ctx, "mg_fuse_prolong", 1) != 0;
             if (fuse_r) {  // pre-smoothing pair + residual + injection + zero coarse guess in ONE pass (:124-132)
                 const dim3 gr((nstrips_r + 3) / 4, (ny + rpc - 1) / rpc);
                 const bool timed = top && fpr_ktimer_begin(ctx, FPR_KT_MG_PRE, s);
-                { if (vx2) k_smooth2_march2<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c, skp); else k_smooth2_march<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, apply_BCs | ntf, L.res_c, L.corr_c, skp); }
+                { if (vx2) k_smooth2_march2<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c, skp); else march_go<false, false, true>(ctx, gr, s, u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, apply_BCs | ntf, L.res_c, L.corr_c, skp); }
                 fpr_ktimer_end(ctx, timed, s);
                 if (apply_BCs && vx2) k_bc_neumann<<<(nyc + 255) / 256, 256, 0, s>>>(L.res_c, nxc, nyc, skp);  // :355-357 (k_smooth2_march does it itself)
             } else {
-                { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); else k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); }  // :124-125
+                { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); else march_go<false, false, false>(ctx, gm, s, u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); }  // :124-125
                 k_restrict_residual2d<<<grid2(nxc, nyc), blk2, 0, s>>>(L.tmp, rhs, L.res_c, nx, ny, C, _h2, apply_BCs, L.corr_c);  // :128-132
             }
             FPR_CHECK_LAUNCH(ctx);
@@ -1089,16 +1098,16 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             // post-smoothing pair (:142-143); with fuse_p the correction u - P(corr_c) is applied while loading
             if (top) {
                 const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_POST, s);
-                if (fuse_p) { if (vx2) k_smooth2_march2<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs | ntf, nullptr, nullptr, skp); else k_smooth2_march<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs | ntf, nullptr, nullptr, skp); }
-                else { if (vx2) k_smooth2_march2<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, ntf, nullptr, nullptr, skp); else k_smooth2_march<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, ntf, nullptr, nullptr, skp); }
+                if (fuse_p) { if (vx2) k_smooth2_march2<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs | ntf, nullptr, nullptr, skp); else march_go<true, true, false>(ctx, gm, s, L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs | ntf, nullptr, nullptr, skp); }
+                else { if (vx2) k_smooth2_march2<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, ntf, nullptr, nullptr, skp); else march_go<true, false, false>(ctx, gm, s, L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, ntf, nullptr, nullptr, skp); }
                 fpr_ktimer_end(ctx, timed, s);
                 FPR_CHECK_LAUNCH(ctx);
                 if (skp) { if (int rc = fprx_cycle_finish(ctx, ctx->partials, npm, ctx->scalars, (double)nx * (double)ny, ctx->cyc_slot)) return rc; }
                 else if (int rc = fprx_finish_sum(ctx, ctx->partials, npm, ctx->scalars, false, 0)) return rc;
                 *rms_is_host = false;
             } else {
-                if (fuse_p) { if (vx2) k_smooth2_march2<false, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs | ntf, nullptr, nullptr, skp); else k_smooth2_march<false, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs | ntf, nullptr, nullptr, skp); }
-                else { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); else k_smooth2_march<false, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); }
+                if (fuse_p) { if (vx2) k_smooth2_march2<false, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs | ntf, nullptr, nullptr, skp); else march_go<false, true, false>(ctx, gm, s, L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs | ntf, nullptr, nullptr, skp); }
+                else { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); else march_go<false, false, false>(ctx, gm, s, L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); }
                 FPR_CHECK_LAUNCH(ctx);
             }
             return FPR_OK;
@@ -1281,6 +1290,7 @@ static TopGeom top_geom(fpr_ctx* ctx, int nx, int ny, double h, double c)
         rpc = 64;
         while (rpc > 16 && (long)g.nstrips * ((ny + rpc - 1) / rpc) < target) rpc >>= 1;
     }
+    rpc += rpc & 1;   // chunks start on even rows (k_smooth2_march_v2)
     g.rpc = rpc;
     // k_seam_march holds 3 waves per SIMD (151 VGPRs) = 3 workgroups per CU, and a workgroup works for most of the pass:
     // the chunks are made as tall as a single round allows (all workgroups resident at once, ~95 % of the slots) -- the
@@ -1293,11 +1303,13 @@ static TopGeom top_geom(fpr_ctx* ctx, int nx, int ny, double h, double c)
             ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
         }
         const int gx = (g.nstrips_s + 3) / 4;
-        int chunks = (int)(0.95 * 3 * ctx->ncu) / gx;
+        const int wg_per_cu = fpr_opt(ctx, "mg_seam_v", 2) == 1 ? 3 : 4;   // 151 VGPRs: three waves per SIMD; second version 108: four
+        int chunks = (int)(0.95 * wg_per_cu * ctx->ncu) / gx;
         if (chunks < 1) chunks = 1;
         rs = (ny + chunks - 1) / chunks;
         if (rs < 32) rs = 32;
     }
+    rs += rs & 1;   // k_seam_march_v2: chunks start on even rows (the parity of a row of its unrolled loop is a constant)
     {   // rows are addressed relative to the first row of a chunk with a 32-bit byte offset
         const long cap = (long)(0x7fffffffL / ((long)nx * 8)) - 16;
         if (rs > cap) rs = (int)(cap > 16 ? cap : 16);
@@ -1315,7 +1327,7 @@ static int top_pre(fpr_ctx* ctx, const TopGeom& g, const double* uin, const doub
 {
     hipStream_t s = ctx->stream[0];
     const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_PRE, s);
-    k_smooth2_march<false, false, true><<<g.gr, 256, 0, s>>>(uin, rhs, out, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips_r, nullptr,
+    march_go<false, false, true>(ctx, g.gr, s, uin, rhs, out, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips_r, nullptr,
                                                              nullptr, apply_BCs | g.ntf, res_c, corr_zero, skp);   // (:355-357 included)
     fpr_ktimer_end(ctx, timed, s);
     FPR_CHECK_LAUNCH(ctx);
@@ -1328,8 +1340,8 @@ static int top_post(fpr_ctx* ctx, const TopGeom& g, const double* X, const doubl
 {
     hipStream_t s = ctx->stream[0];
     const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_POST, s);
-    if (norm) k_smooth2_march<true, true, false><<<g.gm, 256, 0, s>>>(X, rhs, uout, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips, ctx->partials, corr, apply_BCs | g.ntf, nullptr, nullptr, skp);
-    else k_smooth2_march<false, true, false><<<g.gm, 256, 0, s>>>(X, rhs, uout, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips, nullptr, corr, apply_BCs | g.ntf, nullptr, nullptr, skp);
+    if (norm) march_go<true, true, false>(ctx, g.gm, s, X, rhs, uout, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips, ctx->partials, corr, apply_BCs | g.ntf, nullptr, nullptr, skp);
+    else march_go<false, true, false>(ctx, g.gm, s, X, rhs, uout, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips, nullptr, corr, apply_BCs | g.ntf, nullptr, nullptr, skp);
     fpr_ktimer_end(ctx, timed, s);
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
@@ -1341,8 +1353,13 @@ static int top_seam(fpr_ctx* ctx, const TopGeom& g, const double* X, const doubl
 {
     hipStream_t s = ctx->stream[0];
     const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_SEAM, s);
-    if (apply_BCs) k_seam_march<true><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
-    else k_seam_march<false><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
+    if (fpr_opt(ctx, "mg_seam_v", 2) == 1) {   // the first version of the pass (A/B; same fields)
+        if (apply_BCs) k_seam_march<true><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
+        else k_seam_march<false><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
+    } else {
+        if (apply_BCs) k_seam_march_v2<true><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
+        else k_seam_march_v2<false><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
+    }
     fpr_ktimer_end(ctx, timed, s);
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;

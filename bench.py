@@ -218,10 +218,10 @@ def vcycle_block(F, with_cpu=True, steps=5):
     cands = [("seam", seam_ms, seam_bytes, seam_cnt), ("post", post_ms, post_bytes, post_cnt), ("pre", pre_ms, pre_bytes, pre_cnt)]
     dom = max(cands, key=lambda c: c[1] * c[3])                   # the finest-level kernel with the largest share of the time
     gbs = lambda byts, ms: byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    names = {"seam": "k_seam_march (finest level, between two cycles: correction + 2 post-smoothing sweeps + norm of cycle k, "
+    names = {"seam": "k_seam_march_v2 (finest level, between two cycles: correction + 2 post-smoothing sweeps + norm of cycle k, "
                      "2 pre-smoothing sweeps + residual + injection of cycle k+1)",
-             "post": "k_smooth2_march<NORM,PROLONG> (finest level: prolongation + correction + 2 sweeps + norm)",
-             "pre": "k_smooth2_march<RESTRICT> (finest level: 2 sweeps + residual + injection)"}
+             "post": "k_smooth2_march_v2<NORM,PROLONG> (finest level: prolongation + correction + 2 sweeps + norm)",
+             "pre": "k_smooth2_march_v2<RESTRICT> (finest level: 2 sweeps + residual + injection)"}
     traffic, traffic_src = None, None
     try:   # HBM-side bytes of the dominant pass from the committed rocprofv3 --pmc passes (tools/profile_mg.sh), not measured live
         for tj in json.load(open(os.path.join(ROOT, "profiles", "mg_traffic.json")))["entries"]:

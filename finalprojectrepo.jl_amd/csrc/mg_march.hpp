@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void k_seam_march(const double* __restrict__ u
 //     / last row of the grid: first / last chunk only) by a uniform branch;
 //   * the residual stage and its stores run in the rows that are injected (every other one), the norm is accumulated
 //     unmasked under a uniform row test and masked per lane once at the end.
-template <bool BCS>
+template <bool BCS, int PF = 4>   // PF rows of u and f in flight per lane (4 or 6: the loop is unrolled by 12)
 __global__ __launch_bounds__(256) void k_seam_march_v2(const double* __restrict__ uin, const double* __restrict__ f,
                                                         double* __restrict__ uout, int nx, int ny, double C, double _h2,
                                                         double fac, int rows_per_chunk, int nstrips,
@@ -467,12 +467,16 @@ __global__ __launch_bounds__(256) void k_seam_march_v2(const double* __restrict_
         ldc(1, (rs >> 1) + 1);
         wv[0][0] = ldu(I0{}, rs);
         fw[0] = ldf(rs);
-        constexpr int PF = 4;
+        static_assert(PF == 4 || PF == 6, "ring slots are compile-time constants of a loop unrolled by 12");
         double pu[PF], pfv[PF];
         pu[0] = ldu(std::integral_constant<int, 1>{}, rs + 1); pfv[0] = ldf(rs + 1);
         pu[1] = ldu(std::integral_constant<int, 2>{}, rs + 2); pfv[1] = ldf(rs + 2);
         pu[2] = ldu(std::integral_constant<int, 3>{}, rs + 3); pfv[2] = ldf(rs + 3);
         pu[3] = ldu(std::integral_constant<int, 4>{}, rs + 4); pfv[3] = ldf(rs + 4);
+        if constexpr (PF == 6) {
+            pu[4] = ldu(std::integral_constant<int, 5>{}, rs + 5); pfv[4] = ldf(rs + 5);
+            pu[5] = ldu(std::integral_constant<int, 6>{}, rs + 6); pfv[5] = ldf(rs + 6);
+        }
         const __amdgpu_buffer_rsrc_t rResC = fpr_rsrc(res_c_out), rCorC = fpr_rsrc(corr_c_out);
         const unsigned vstc = (owner && !(gi & 1)) ? (unsigned)(gi >> 1) * 8u : FPR_OOR;
         // BCS: Neumann columns of the coarse right-hand side (:355-357), see k_smooth2_march
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(256) void k_seam_march_v2(const double* __restrict_
         };
         auto step = [&](auto Tc, int r) {
             constexpr int T = decltype(Tc)::value;               // (r - rs) mod 12
-            constexpr int Q = T % 4, M = T % 3, F = T % 6;
+            constexpr int Q = T % PF, M = T % 3, F = T % 6;
             constexpr int M1 = (M + 1) % 3, M2 = (M + 2) % 3;    // slots of rows r-2 (= r+1) and r-1
             auto fs = [](int k) { return (F - k + 6) % 6; };     // slot of f row r-k
             double an, fn;

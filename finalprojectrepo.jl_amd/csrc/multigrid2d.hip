@@ -1358,6 +1358,7 @@ static int top_seam(fpr_ctx* ctx, const TopGeom& g, const double* X, const doubl
         else k_seam_march<false><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
     } else {
         if (apply_BCs) k_seam_march_v2<true><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
+        else if (fpr_opt(ctx, "mg_seam_pf", 4) == 6) k_seam_march_v2<false, 6><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
         else k_seam_march_v2<false><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
     }
     fpr_ktimer_end(ctx, timed, s);

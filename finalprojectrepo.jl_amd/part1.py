@@ -273,7 +273,7 @@ def diffusion_3D_kernel_programming(*, nx, ny, nz, ttot=1.0, tol=1e-8, use_share
     if gg.nprocs == 1:
         apply_boundary_conditions_(Ht, coords, dims)  # :139 -- a no-op on one rank (0-based coords vs 1, part1_utils.jl:14-34)
     # On several ranks the same comparison would zero an INTERNAL halo plane of the rank with coordinate 1 (and
-    # never the physical boundary); it is skipped so that an N-shard run equals the single-domain run.
+    # never the physical boundary); it is skipped so that an N-shard run equals the single-domain run (EXPERIMENTS.md section 5).
     Hτ = Ht.clone(memory_format=torch.preserve_format)  # :140
     Hτ2 = fzeros(nx, ny, nz)  # :141
     residual_H = fzeros(nx, ny, nz)  # :142

@@ -141,6 +141,9 @@ extern "C" int fpr_grid_init(fpr_ctx* ctx, int nx, int ny, int nz, int dimx, int
                 c[d] = (c[d] + g.dims[d]) % g.dims[d];
                 nb = (c[0] * g.dims[1] + c[1]) * g.dims[2] + c[2];
             }
+            // measurement aid ("grid_drop_faces", bit 2*dim+side): a periodic single rank has two faces per dimension; dropping
+            // one of each gives the face set of a corner rank of a (2,2,2) decomposition (tools/exp_step2_faces.py)
+            if ((fpr_opt(ctx, "grid_drop_faces", 0) >> (2 * d + side)) & 1) nb = -1;
             g.nb[2 * d + side] = nb;
             if (nb >= 0 && d != 2) {
                 FPR_HIP(ctx, hipMalloc(&g.sendbuf[2 * d + side], plane[d] * sizeof(double)));

@@ -169,9 +169,11 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
         } else {
             if (reserve_cus > 0 && fpr_opt(ctx, "diff3_bal_g", 0) > 0) reserve_cus = -(int)fpr_opt(ctx, "diff3_bal_g", 0);   // tests
             long bal_info = 0;
+            // a launch on the comm stream of a split device has that stream's compute units only: chunk it for them
+            const int ncu_plan = (stream_sel == 1 && ctx->comm_cus > 0) ? ctx->comm_cus : ctx->ncu;
             e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), (int)fpr_opt(ctx, "diff3_xcd2", 0) & 3,
                               ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2, &nparts,
-                              (int)fpr_opt(ctx, "diff3_nw2", 0), ctx->ncu, zlo2, zhi2, reserve_cus, &bal_info);
+                              (int)fpr_opt(ctx, "diff3_nw2", 0), ncu_plan, zlo2, zhi2, reserve_cus, &bal_info);
             if (reserve_cus != 0) ctx->options["diff3_last_bal"] = bal_info;   // diagnostic (fpr_get_option): which form ran
         }
         fpr_ktimer_end(ctx, timed, ctx->stream[stream_sel]);

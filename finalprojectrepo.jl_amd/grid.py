@@ -258,7 +258,9 @@ class GlobalGrid:
     _tr = _ex = _sq_host = _sq_shell = _reserve = None
     _pending = False
 
-    def __init__(self, nx, ny, nz, dims=None, group=None, use_dist=None, periods=(0, 0, 0), transport=None):
+    def __init__(self, nx, ny, nz, dims=None, group=None, use_dist=None, periods=(0, 0, 0), transport=None, drop_faces=0):
+        """drop_faces (bit 2*dim+side; measurement aid): faces that get no neighbour although the topology has one -- a
+        periodic single rank minus its three low faces has the face set of a corner rank of a (2,2,2) decomposition."""
         self.nx, self.ny, self.nz = nx, ny, nz
         dist = None
         if use_dist is None or use_dist:
@@ -290,6 +292,10 @@ class GlobalGrid:
                 elif self.periods[d]:
                     c[d] %= dims[d]
                     self.neighbors[2 * d + side] = tuple(c)
+        for f in range(6):
+            if (drop_faces >> f) & 1:
+                self.neighbors.pop(f, None)
+        self.drop_faces = int(drop_faces)
         if transport is None:
             transport = "dist"
             if self.neighbors and dist is not None:
@@ -319,6 +325,7 @@ class GlobalGrid:
 
         c = _ctx()
         rccl_bootstrap(c, self.me, self.nprocs, self.dist, self.group)
+        c.set_option("grid_drop_faces", getattr(self, "drop_faces", 0))
         me, npr = C.c_int(0), C.c_int(0)
         dims_o, coords_o = (C.c_int * 3)(), (C.c_int * 3)()
         c.call("fpr_grid_init", self.nx, self.ny, self.nz, *self.dims, *self.periods, C.byref(me), dims_o, C.byref(npr), coords_o)

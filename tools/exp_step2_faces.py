@@ -23,11 +23,13 @@ def run1(gg, its):
     for _ in range(its):
         gg.step(Ht, A, O, R, *coef, 0.2, sq[:1]); A, O = O, A
 res = {}
-CASES = (("none", (0, 0, 0)), ("z", (0, 0, 1)), ("yz", (0, 1, 1)), ("xyz", (1, 1, 1)), ("x", (1, 0, 0)), ("y", (0, 1, 0)), ("xy", (1, 1, 0)))
+# name, periodic dimensions, dropped faces (bit 2*dim+side): "corner" = one face per dimension, the face set of a rank of (2,2,2)
+CASES = (("none", (0, 0, 0), 0), ("z", (0, 0, 1), 0), ("yz", (0, 1, 1), 0), ("xyz", (1, 1, 1), 0), ("x", (1, 0, 0), 0), ("y", (0, 1, 0), 0),
+         ("xy", (1, 1, 0), 0), ("corner", (1, 1, 1), 0b010101), ("z1", (0, 0, 1), 0b010000))
 if len(sys.argv) > 2: CASES = tuple(c for c in CASES if c[0] in sys.argv[2].split(",") or c[0] == "none")
-for name, periods in CASES:
+for name, periods, drop in CASES:
     if any(periods):
-        gg = F.grid.GlobalGrid(n, n, n, dims=(1, 1, 1), periods=periods, transport="rccl", use_dist=False)
+        gg = F.grid.GlobalGrid(n, n, n, dims=(1, 1, 1), periods=periods, transport="rccl", use_dist=False, drop_faces=drop)
     else:
         gg = F.grid.GlobalGrid(n, n, n, dims=(1, 1, 1), use_dist=False)
     if os.environ.get("FPR_RESERVE") and any(periods): gg._reserve = int(os.environ["FPR_RESERVE"])

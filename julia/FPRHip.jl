@@ -47,7 +47,8 @@ export @init_parallel_stencil, @reset_parallel_stencil, @parallel, @parallel_ind
        compute_velocity!, compute_Ra_dTdx!, compute_diffusion2d!, compute_advection2d_x!, compute_advection2d_y!,
        halo_pack!, halo_unpack!, fpr_version,
        init_global_grid, finalize_global_grid, select_device, update_halo!, gather!, nx_g, ny_g, nz_g, x_g, y_g, z_g,
-       halo_exchange_begin!, halo_exchange_end!, allreduce_sum!, diffusion_3D_array_programming
+       halo_exchange_begin!, halo_exchange_end!, halo_exchange_comm!, allreduce_sum!, diffusion_3D_array_programming,
+       diffusion_3D_step_τ2_halo!, join_pair!
 
 const libfpr = get(ENV, "FPR_HIP_LIB", joinpath(@__DIR__, "..", "finalprojectrepo.jl_amd", "lib", "libfpr_hip.so"))
 
@@ -102,6 +103,8 @@ function destroy_context()
         CTX[] = C_NULL
         GRID[] = nothing
         HAS_COMM[] = false
+        SQ_SHELL[] = nothing
+        PAIR_PENDING[] = false
     end
     return nothing
 end
@@ -439,6 +442,7 @@ function allreduce_sum1(x::Float64)
 end
 "In-place sum over all ranks of a small device vector (e.g. the norms of several iterations); no host sync."
 function allreduce_sum!(x::DA)   # comm stream, ordered behind / ahead of the compute stream (all RCCL calls share one stream)
+    join_pair!()
     stream_wait(1, 0)
     check(ccall((:fpr_allreduce_sum_dev, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint), ctx(), p(x), length(x), 1))
     stream_wait(0, 1)
@@ -554,6 +558,7 @@ z_g(iz::Integer, dz::Real, A) = coord_g(3, iz, dz, A)
 
 "`update_halo!(A...)` (part1_kernel_programming.jl:182,187): ordered on the compute stream, no host synchronisation."
 function update_halo!(As::DA...)
+    join_pair!()
     for A in As
         n = size(A)
         check(ccall((:fpr_halo_exchange3d, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint), ctx(), p(A), n[1], n[2], n[3]))
@@ -568,6 +573,100 @@ halo_exchange_end!(A::DA; faces = 63) = (n = size(A);
 "The whole exchange (pack, one RCCL group, unpack) in the COMM stream's order: a link of the shell chain of a fused pair."
 halo_exchange_comm!(A::DA; faces = 63) = (n = size(A);
     check(ccall((:fpr_halo_exchange3d_comm, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint, Cint), ctx(), p(A), n[1], n[2], n[3], faces)))
+
+# ---- two iterations per launch BETWEEN ranks (mirror of GlobalGrid.step2 in finalprojectrepo.jl_amd/grid.py) ------------
+"Faces (0-based, 2*dim + side) of this rank that have a neighbour."
+neighbour_faces() = [f for f in 0:5 if grid_sizes_g()[2][f + 1] >= 0]
+
+"""
+Thin boxes (0-based `[lo, hi)`) of the interior cells next to faces with a neighbour -- z faces peeled first, then y, then
+x, so the boxes are disjoint -- and the remaining core box.
+"""
+function boundary_boxes(n::NTuple{3,Int}, faces)
+    lo = [1, 1, 1]; hi = [n[1] - 1, n[2] - 1, n[3] - 1]
+    boxes = Tuple{NTuple{3,Int},NTuple{3,Int}}[]
+    for d in (3, 2, 1), side in (0, 1)
+        f = 2 * (d - 1) + side
+        (f in faces && hi[d] - lo[d] >= 1) || continue
+        blo = copy(lo); bhi = copy(hi)
+        if side == 0
+            bhi[d] = lo[d] + 1; lo[d] += 1
+        else
+            blo[d] = hi[d] - 1; hi[d] -= 1
+        end
+        push!(boxes, (Tuple(blo), Tuple(bhi)))
+    end
+    return boxes, (Tuple(lo), Tuple(hi))
+end
+
+"Compute units of the comm stream during fused pairs (a multiple of 32: the same number out of every shader engine)."
+comm_units(faces) = sum((5, 5, 2, 2, 1, 1)[f + 1] for f in faces; init = 0) > 9 ? 64 : 32
+
+const SQ_SHELL = Ref{Any}(nothing)
+const PAIR_PENDING = Ref(false)
+
+"""
+    diffusion_3D_step_τ2_halo!(Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz; scale, sumsq2, join)
+
+Two trips through the loop body of part1_kernel_programming.jl:179-192 on a rank WITH neighbours, halos of `Hout` refreshed --
+what `@hide_communication` + `update_halo!` do there for one iteration.  The device is split (`reserve_comm_cus`): the core of
+the local grid runs as ONE fused launch on the core stream; on the comm stream, beside it, run the single steps on the
+one-cell shell (level 1 into `Hτ2`), the exchange of `Hτ2`'s planes, the fused launches on the shell boxes and the exchange of
+the new field.  `join = false` leaves the pair on those two streams (the next pair continues from there); call
+`join_pair!()` before anything else reads the fields or `sumsq2`.  Same results as two single steps with `update_halo!`
+of the new buffer after each.
+"""
+function diffusion_3D_step_τ2_halo!(Ht::DA, Hτ::DA, Hτ2::DA, Hout::DA, dHdτ::DA, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz;
+                                    scale = 0.0, sumsq2::Union{DA,Nothing} = nothing, join::Bool = true)
+    faces = neighbour_faces()
+    if isempty(faces)
+        return diffusion_3D_step_τ2(Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz; scale = scale, sumsq2 = sumsq2)
+    end
+    coef = (dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
+    boxes, core = boundary_boxes(size(Ht), faces)
+    mask = sum(1 << f for f in faces)
+    k = comm_units(faces)
+    reserve_comm_cus(k)
+    sqs = nothing
+    if sumsq2 !== nothing
+        SQ_SHELL[] === nothing && (SQ_SHELL[] = AMDGPU.zeros(Float64, 2))
+        sqs = SQ_SHELL[]
+    end
+    if PAIR_PENDING[]
+        stream_wait(1, 2)                        # the shell chain of this pair sees the previous pair's core
+    else
+        stream_wait(1, 0); stream_wait(2, 0)     # fork: the pair's inputs are ready
+    end
+    diffusion_3D_step_τ2_core(Ht, Hτ, Hτ2, Hout, dHdτ, coef..., core[1], core[2]; scale = scale, sumsq2 = sumsq2, stream_sel = 2,
+                              reserve_cus = k, accumulate = false)
+    sqs === nothing || fill_on!(sqs, 0.0, 1)
+    for (lo, hi) in boxes                        # comm stream: level 1 on the shell
+        diffusion_3D_step_τ_box(Ht, Hτ, Hτ2, dHdτ, coef..., lo, hi; stream_sel = 1)
+    end
+    halo_exchange_comm!(Hτ2; faces = mask)
+    rest = boxes
+    if 4 in faces && 5 in faces                  # the two z-slabs (peeled first, same x / y extent) share one launch
+        (lo0, hi0), (lo1, hi1) = boxes[1], boxes[2]
+        diffusion_3D_step_τ2_box2(Ht, Hτ, Hτ2, Hout, dHdτ, coef..., lo0, hi0, lo1[3], hi1[3]; scale = scale, sumsq2 = sqs, stream_sel = 1)
+        rest = boxes[3:end]
+    end
+    for (lo, hi) in rest
+        diffusion_3D_step_τ2_box(Ht, Hτ, Hτ2, Hout, dHdτ, coef..., lo, hi; scale = scale, sumsq2 = sqs, stream_sel = 1)
+    end
+    halo_exchange_comm!(Hout; faces = mask)
+    stream_wait(2, 1)                            # the core stream takes in the shell chain and its sums
+    sumsq2 === nothing || add_on!(sumsq2, sqs, 2)
+    PAIR_PENDING[] = true
+    join && join_pair!()
+    return nothing
+end
+
+"Order the compute stream behind a pair that `diffusion_3D_step_τ2_halo!(...; join = false)` left on the core / comm streams."
+function join_pair!()
+    PAIR_PENDING[] && stream_wait(0, 2)
+    PAIR_PENDING[] = false
+    return nothing
+end
 
 "`gather!(A, A_global)` (part1_kernel_programming.jl:223): A_global (host, rank 0; `nothing` elsewhere) receives all local arrays."
 function gather!(A::DA, A_global::Union{Array{Float64,3},Nothing})

@@ -22,13 +22,17 @@ def mean(path, kernel, counter):
     raise SystemExit("no %s for %s in %s" % (counter, kernel, path))
 
 
+try:
+    box = " | ".join(l.strip() for l in open(os.path.join(root, "profiles", tag + "_box.txt")) if l.strip())
+except OSError:
+    box = None
 entries = []
-for fused, kern in ((True, "k_diff3_march2<true, 8, true>"), (False, "k_diff3_march<")):
+for fused, kern in ((True, "k_diff3_march2<true, 8, true, false>"), (False, "k_diff3_march<")):
     fe, nf = mean(os.path.join(root, "profiles", tag + "_pmc_fetch.txt"), kern, "FETCH_SIZE")
     wr, nw = mean(os.path.join(root, "profiles", tag + "_pmc_write.txt"), kern, "WRITE_SIZE")
     traffic = fe * 1024 * 2 + wr * 1024
     entries.append({"n": n, "fuse2": fused, "kernel": kern.rstrip("<") if kern.endswith("<") else kern, "FETCH_SIZE_KiB_mean": fe, "fetch_dispatches": nf,
-                    "WRITE_SIZE_KiB_mean": wr, "write_dispatches": nw, "fetch_correction": 2.0,
+                    "WRITE_SIZE_KiB_mean": wr, "write_dispatches": nw, "fetch_correction": 2.0, "box": box,
                     "traffic_bytes_per_launch": traffic, "min_bytes_per_launch": 32.0 * cells,
                     "traffic_over_min_bytes": traffic / (32.0 * cells),
                     "source": "profiles/%s_pmc_fetch.txt, profiles/%s_pmc_write.txt: separate rocprofv3 --pmc passes of "

@@ -8,6 +8,8 @@
 R=$GRAFT_REPO_ROOT; TAG=${1:-prof}; shift
 ARGS="--no-secondary --no-cpu-baseline --steps 200 --warmup 20 $*"
 mkdir -p $R/gpurun_out
+# the box all passes of this call run on (kernel statistics and counters come from ONE lease)
+{ echo "host $(hostname)"; (rocm-smi --showuniqueid 2>/dev/null | grep -i "unique" | head -2) ; date -u +"utc %Y-%m-%dT%H:%M:%SZ"; } > $R/gpurun_out/${TAG}_box.txt
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pb_stats /tmp/pb_fetch /tmp/pb_write
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_stats -- python3 $R/bench.py $ARGS > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> /tmp/pb1.err

@@ -5,6 +5,8 @@
 # usage: tools/profile_mg.sh <tag> [n] [coarse_solve_size] [jacobi|cg]
 R=$GRAFT_REPO_ROOT; TAG=${1:-prof}; N=${2:-4097}; CSS=${3:-5}; SOLVER=${4:-jacobi}
 mkdir -p $R/gpurun_out
+# the box all passes of this call run on (kernel statistics and counters come from ONE lease)
+{ echo "host $(hostname)"; (rocm-smi --showuniqueid 2>/dev/null | grep -i "unique" | head -2) ; date -u +"utc %Y-%m-%dT%H:%M:%SZ"; } > $R/gpurun_out/${TAG}_mg_box.txt
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pm_stats /tmp/pm_fetch /tmp/pm_write
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pm_stats -- python3 $R/tools/prof_mg.py $N $CSS $SOLVER 5 > $R/gpurun_out/${TAG}_mg_run.txt 2> /tmp/pm1.err

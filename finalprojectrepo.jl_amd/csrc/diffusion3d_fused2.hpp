@@ -167,8 +167,13 @@ __device__ __forceinline__ double diff3_block_sum_waves(double v, double* red, i
 // to RCCL and the shell launches of a decomposed run); every workgroup serves its own unit and then a thin slice of one of
 // the left-over units, so the launch still finishes in one balanced round and its tiles still march in lockstep.
 template <bool NORM, int NW = 4, bool WRES = true, bool BAL = false>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3Args2 a)
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_diff3_march2(Diff3Args2 a)
 {
+    // NW = 1: ONE wave per workgroup, a 128 x 4 tile whose first or last row is a y-boundary (or y-halo) row -- the
+    // one-row shell next to a y-neighbour of a decomposed run.  Level 1 of the row next to the boundary needs level 0 of
+    // rows inside the tile only, and the owned row is that one: the wave needs a single global halo row (the boundary row
+    // of level 1, from B); the level-0 halo on the far side is never read into anything that is stored.  A 16-row block
+    // (NW = 4) for one owned row did four times the work.
     constexpr int VX = 2, RY = 4, TXW = 128, SYB = NW * RY - 2;
     constexpr int NR = 3;                         // ring length = loop unroll: <= 256 registers, two workgroups per CU
     constexpr int SLOT = 4 * TXW;                 // doubles per wave slot: L0 first row, L0 last row, L1 first row, L1 last row
@@ -271,8 +276,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
     const int jd = bb ? 0 : (j0 > 0 ? j0 - 1 : 0);
     const int ju = bt ? ny - 1 : (j0 + RY < ny - 1 ? j0 + RY : ny - 1);
     const bool hwave = (w == 0) || (w == NW - 1);             // waves that own a global halo row
-    const double* Hsrc = (w == 0) ? (bb ? a.B : a.A) : (bt ? a.B : a.A);
-    const int hrow = (w == 0) ? jd : ju;
+    // (NW = 1: the wave is bottom and top wave at once and owns ONE halo row: the y-boundary row of level 1 on the side
+    // of the tile that touches the boundary -- host: the tile touches one)
+    const bool top1 = NW == 1 && bt && !bb;
+    const double* Hsrc = (w == 0 && !top1) ? (bb ? a.B : a.A) : (bt ? a.B : a.A);
+    const int hrow = (w == 0 && !top1) ? jd : ju;
 
     // ---- z: owned planes [k0, k1) (above); iterations m0 .. m1 ----
     const int m0 = k0 - 1, m1 = k1;
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_diff3_march2(Diff3
             t.x = Qc[RY - 1].v[0]; t.y = Qc[RY - 1].v[1]; *reinterpret_cast<d2l*>(mine + 3 * TXW) = t;
             if (hwave) {   // bottom wave: slot 0 "last row"; top wave: slot NW+1 "first row"
                 t.x = YH.v[0]; t.y = YH.v[1];
-                *reinterpret_cast<d2l*>(buf + (w == 0 ? TXW : (NW + 1) * SLOT) + lane * VX) = t;
+                *reinterpret_cast<d2l*>(buf + ((w == 0 && !top1) ? TXW : (NW + 1) * SLOT) + lane * VX) = t;
             }
         }
         diff3_lds_barrier();
@@ -559,7 +567,7 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
     auto plan = [&](int nw, int* zc_out) -> long {
         const int syb_ = nw * 4 - 2;
         const long tiles = (long)a.ntx * ((wy + syb_ - 1) / syb_);
-        const long slots = (long)(ncu > 0 ? ncu : 256) * (nw == 8 ? 1 : 2);
+        const long slots = (long)(ncu > 0 ? ncu : 256) * (nw == 8 ? 1 : (nw == 1 ? 6 : 2));   // nw = 1: 24.5 KB of LDS per workgroup
         long best = -1;
         int zb = 0;
         for (int ntz = 1; ntz <= wz; ++ntz) {
@@ -581,7 +589,11 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
     // per iteration; 192^3: 17 = 17, measured equal; 256^3: 38 against 35, measured 59 against 56 us)
     int zc = zc_opt, zc8 = 0, zc4 = 0;
     const bool can8 = a.ny >= 32 && wy >= 24;
+    // one-row shells next to a y-neighbour (rows 1 / ny-2, possibly both rows of a 2-row box at the boundary): one wave per
+    // workgroup; needs the tile of 4 rows to touch the y-boundary and its far row to feed nothing that is owned
+    const bool can1 = wzb == 0 && a.ny >= 8 && ((a.lo[1] == 1 && wy <= 1) || (a.hi[1] == a.ny - 1 && wy <= 1));
     if (nw_opt == 4 || nw_opt == 8) a.nw = (nw_opt == 8 && a.ny < 32) ? 4 : nw_opt;
+    else if (nw_opt == 1 ? can1 : (can1 && nw_opt == 0)) a.nw = 1;
     else if (!can8) a.nw = 4;
     else a.nw = (zc_opt <= 0 && plan(4, &zc4) < plan(8, &zc8)) ? 4 : 8;
     const int syb = a.nw * 4 - 2;
@@ -606,12 +618,23 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
     // one L2 while they march in lockstep: measured -5..7 % time and -14 % read traffic at 512^3; with many rounds it
     // was slower than the hardware's round-robin.
     {
-        const long slots = (long)(ncu > 0 ? ncu : 256) * (a.nw == 8 ? 1 : 2);
+        const long slots = (long)(ncu > 0 ? ncu : 256) * (a.nw == 8 ? 1 : (a.nw == 1 ? 6 : 2));
         if (xcd_opt == 0) xcd_opt = (nblk >= 64 && nblk <= 2 * slots) ? 1 : 3;
     }
     a.xcd_remap = (xcd_opt == 1 && nblk >= 64) ? 1 : ((xcd_opt == 2 && a.ntz % 8 == 0) ? 2 : 0);
     const bool wres = a.dH != nullptr;
     a.bal_r = a.bal_sp = a.bal_q = 0;
+    if (a.nw == 1) {
+        if (wres) {
+            if (norm) k_diff3_march2<true, 1, true><<<(int)nblk, 64, 0, stream>>>(a);
+            else k_diff3_march2<false, 1, true><<<(int)nblk, 64, 0, stream>>>(a);
+        } else {
+            if (norm) k_diff3_march2<true, 1, false><<<(int)nblk, 64, 0, stream>>>(a);
+            else k_diff3_march2<false, 1, false><<<(int)nblk, 64, 0, stream>>>(a);
+        }
+        *nparts = (int)nblk;
+        return hipGetLastError();
+    }
     if (reserve_cus != 0 && wzb == 0) {   // < 0 (tests, option diff3_bal_g): the reserved form on exactly -reserve_cus workgroups
         // The plain grid runs in rounds of `slots` workgroups.  A grid of several rounds frees units all the time and one
         // that leaves `reserve_cus` units idle anyway needs no change; a grid that fills the device in ONE round is cut to

@@ -1,7 +1,7 @@
 """Fused-pair choreography with neighbours at n^3 on ONE GPU (one rank, periodic = its own neighbour through the
 library's RCCL transport), a few pairs, for a dispatch timeline under rocprofv3 --kernel-trace: does the RCCL kernel
 of an exchange finish inside the core launch beside it, or drain behind it?
-usage: exp_overlap.py <n> <periods e.g. 001> <pairs> [k=v,k=v library options]"""
+usage: exp_overlap.py <n> <periods e.g. 001> <pairs> [k=v,k=v library options]     (FPR_DROP_FACES=21: corner rank of (2,2,2))"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,7 +17,9 @@ coef = (dx * dx / 8.1, 5.0, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx)
 Ht = F.fzeros(n, n, n); F.part1.init_local_gaussian((5., 5., 5.), dx, dx, dx, Ht)
 A, O, C, R, sq = Ht.clone(), F.fzeros(n, n, n), Ht.clone(), F.fzeros(n, n, n), F.fzeros(2)
 if any(periods):
-    gg = F.grid.GlobalGrid(n, n, n, dims=(1, 1, 1), periods=periods, transport="rccl", use_dist=False)
+    gg = F.grid.GlobalGrid(n, n, n, dims=(1, 1, 1), periods=periods, transport="rccl", use_dist=False,
+                           drop_faces=int(os.environ.get("FPR_DROP_FACES", "0")))
+    if os.environ.get("FPR_RESERVE"): gg._reserve = int(os.environ["FPR_RESERVE"])
 else:
     gg = F.grid.GlobalGrid(n, n, n, dims=(1, 1, 1), use_dist=False)
 def run(pairs):

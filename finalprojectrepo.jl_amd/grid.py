@@ -546,11 +546,20 @@ class GlobalGrid:
             tr.prepare()                                      # buffers a transport creates (and fills) on the compute stream: before the fork
             c.call("fpr_stream_wait", 1, 0)                   # fork: the pair's inputs are ready
             c.call("fpr_stream_wait", 2, 0)
-        # core stream first, so that its workgroups are placed before the thin launches ask for room; its sums are written
+        # Level 1 on the shell.  The x-slabs (one column wide, lanes along y: every access a cache line of its own) crawl beside
+        # a launch that saturates the memory system -- 180 us where they take 25 us alone -- so they run on the CORE stream
+        # AHEAD of the core launch; the z- and y-slabs run on the comm stream beside it.  (boundary_boxes peels x last.)
+        nxf = sum(1 for f in (0, 1) if f in self.neighbors)
+        xboxes = boxes[len(boxes) - nxf:] if nxf else []
+        for lo, hi in xboxes:
+            part1.diffusion_3D_step_τ_box(Ht, Hτ, Hτ2, dHdτ, *coef, lo, hi, 0.0, None, 2)
+        if xboxes:
+            c.call("fpr_stream_wait", 1, 2)                   # the comm stream's chain follows them (not the core launch below)
+        # the core launch before the thin launches of the comm stream, so that its workgroups are placed first; its sums are written
         part1.diffusion_3D_step_τ2_core(*fused, core[0], core[1], norm_scale, sq2_dev, 2, k, accumulate=False)
         if sqs is not None:
             c.call("fpr_fill_on", sqs.data_ptr(), 0.0, 2, 1)
-        for lo, hi in boxes:                                  # comm stream: level 1 on the shell
+        for lo, hi in boxes[:len(boxes) - nxf]:               # comm stream: level 1 on the z- and y-slabs
             part1.diffusion_3D_step_τ_box(Ht, Hτ, Hτ2, dHdτ, *coef, lo, hi, 0.0, None, 1)
         works = tr.comm_post(Hτ2, mask)
         return dict(fused=fused, scale=norm_scale, sq=sq2_dev, sqs=sqs, works=works, boxes=boxes, core=core, out=Hout,

@@ -511,12 +511,13 @@ class GlobalGrid:
         engine (a workgroup is dealt to an engine and waits there for room, so a lopsided split puts two workgroups of the
         core launch on one unit: tools/cu_share_probe.hip).  32 carry the shell chain of a rank with z-faces, y-faces or
         one face per dimension in less than the core launch's time; x-faces cost about five z-faces each (lanes along y,
-        strided planes), so a rank with more shell work than that gets 64 (profiles/r3_step2_faces_overhead.txt: 512^3,
-        two faces per periodic dimension: z +9 %, y +13 % at 32 units; x +30 %, xy +39 %, xyz +49 % at 64)."""
+        strided planes), so a rank with more shell work than two of those gets 64 (profiles/r3_step2_faces_overhead.txt: 512^3,
+        two faces per periodic dimension: z +9 %, y +11 %, x +27 % at 32 units; xy +38 %, xyz +40 % at 64; one face per
+        dimension, a corner rank of (2,2,2): +19 % at 32)."""
         if self._reserve is not None:
             return self._reserve
         work = sum({0: 5, 1: 2, 2: 1}[f >> 1] for f in self.neighbors)
-        return 64 if work > 9 else 32
+        return 64 if work > 10 else 32
 
     def step2_begin(self, Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq2_dev):
         from . import ctx as _ctx

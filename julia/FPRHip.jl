@@ -600,7 +600,7 @@ function boundary_boxes(n::NTuple{3,Int}, faces)
 end
 
 "Compute units of the comm stream during fused pairs (a multiple of 32: the same number out of every shader engine)."
-comm_units(faces) = sum((5, 5, 2, 2, 1, 1)[f + 1] for f in faces; init = 0) > 9 ? 64 : 32
+comm_units(faces) = sum((5, 5, 2, 2, 1, 1)[f + 1] for f in faces; init = 0) > 10 ? 64 : 32
 
 const SQ_SHELL = Ref{Any}(nothing)
 const PAIR_PENDING = Ref(false)

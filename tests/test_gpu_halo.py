@@ -197,3 +197,41 @@ def test_fused_pair_choreography_emulated_ranks(fpr, oracle, dims, n):
             idx = [slice(1, -1)] * 3
             idx[d] = -1 if side else 0
             assert np.array_equal(loc[tuple(idx)], glob[tuple(idx)])
+
+
+def test_device_split_streams_and_small_ops(fpr):
+    """fpr_reserve_comm_cus / fpr_comm_cus / fpr_stream_handle / fpr_fill_on / fpr_add_on: the comm and core streams of a split
+    device are library-owned, ordered against the compute stream by fpr_stream_wait, and a lopsided split is refused (a
+    workgroup is dealt to a shader engine and waits there: tools/cu_share_probe.hip)."""
+    import ctypes as C
+    import torch
+
+    F = fpr
+    c = F.ctx()
+    c.reserve_comm_cus(0)                    # (earlier tests with fused pairs between ranks leave the device split)
+    try:
+        with pytest.raises(F.FprError):
+            c.reserve_comm_cus(8)            # not the same number of units out of every shader engine
+        assert c.L.fpr_comm_cus(c.h) == 0
+        h0 = [C.c_void_p() for _ in range(3)]
+        for s in range(3):
+            c.call("fpr_stream_handle", s, C.byref(h0[s]))
+        assert h0[2].value == h0[0].value and h0[1].value != h0[0].value      # unsplit: the core stream IS the compute stream
+        c.reserve_comm_cus(32)
+        assert c.L.fpr_comm_cus(c.h) == 32
+        h = [C.c_void_p() for _ in range(3)]
+        for s in range(3):
+            c.call("fpr_stream_handle", s, C.byref(h[s]))
+        assert h[0].value == h0[0].value and len({h[0].value, h[1].value, h[2].value}) == 3
+        a, b = F.fzeros(6), F.fzeros(6)
+        a.fill_(2.0)                                     # compute stream
+        c.call("fpr_stream_wait", 1, 0)
+        c.call("fpr_fill_on", b.data_ptr(), 1.5, 6, 1)   # comm stream
+        c.call("fpr_add_on", b.data_ptr(), a.data_ptr(), 6, 1)
+        c.call("fpr_stream_wait", 2, 1)
+        c.call("fpr_add_on", a.data_ptr(), b.data_ptr(), 6, 2)   # core stream: 2 + 3.5
+        c.call("fpr_stream_wait", 0, 2)
+        assert torch.equal(a.cpu(), torch.full((6,), 5.5, dtype=torch.float64)) and torch.equal(b.cpu(), torch.full((6,), 3.5, dtype=torch.float64))
+    finally:
+        c.reserve_comm_cus(0)
+    assert c.L.fpr_comm_cus(c.h) == 0

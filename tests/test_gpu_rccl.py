@@ -176,6 +176,65 @@ def test_fused_pair_over_rccl_periodic_xyz(fpr, oracle, periodic_grid):
         assert np.array_equal(F.tonumpy(gR)[1:-1, 1:-1, 1:-1], R[1:-1, 1:-1, 1:-1])
 
 
+@pytest.mark.parametrize("periods,n", [((0, 0, 1), (128, 40, 36)), ((1, 1, 1), (256, 36, 20)), ((1, 0, 1), (128, 24, 16))], ids=["z", "xyz", "xz"])
+def test_pairs_chained_on_core_and_comm_streams(fpr, oracle, periodic_grid, periods, n):
+    """step2(join=False): consecutive fused pairs chain on the core / comm streams of the split device without passing through
+    the compute stream (what bench.py runs between ranks); join() -- or allreduce_ / step / update_halo_ -- orders the compute
+    stream behind them.  Twelve pairs, every pair's two norms kept in their own slots; then a pair left pending and two single
+    steps (GlobalGrid.step on the split device): fields and residual bit for bit, all norms to 1e-13, against the oracle with
+    wrapped halos."""
+    F = fpr
+    dims = tuple(d for d in range(3) if periods[d])
+    gg = periodic_grid(n, periods)
+    ext = [m - 2 if p else m for m, p in zip(n, periods)]
+    dx, dy, dz = 10.0 / ext[0], 10.0 / ext[1], 10.0 / ext[2]
+    D, dt = 1.0, 0.2
+    dτ = min(dx, dy, dz) ** 2 / D / 8.1
+    coef = (dτ, 1 / dt, 1 / dx, 1 / dy, 1 / dz, D / dx, D / dy, D / dz)
+    Ht = wrap(rnd(n, 31), dims=dims)
+    A, B, R = Ht.copy(order="F"), farr(*n), farr(*n)
+    gHt, gA, gB, gR = F.asdevice(Ht), F.asdevice(A), F.fzeros(*n), F.fzeros(*n)
+    gC = gA.clone()
+    assert gg.can_step2(gHt, gA, gB, gC, gR)
+    npairs = 12
+    sq = F.fzeros(2 * npairs + 2)
+    refs = []
+    for p in range(npairs):
+        for k in range(2):
+            oracle.diffusion3d_step(Ht, A, B, R, *coef)
+            wrap(B, dims=dims)
+            A, B = B, A
+            refs.append(oracle.sumsq_scaled(R, dt))
+        gg.step2(gHt, gA, gB, gC, gR, *coef, dt, sq[2 * p:2 * p + 2], join=False)
+        gA, gC = gC, gA
+    assert gg._pending
+    gg.allreduce_(sq)          # joins (a single rank: nothing else happens)
+    assert not gg._pending
+    got = sq.cpu().tolist()[:2 * npairs]
+    assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs)), (got, refs)
+    inner = (slice(1, -1),) * 3
+    assert np.array_equal(F.tonumpy(gA)[inner], A[inner]) and np.array_equal(F.tonumpy(gR)[inner], R[inner])
+    # one more pair left pending, then two single steps on the split device (the first one joins): the field is back in the
+    # first work buffer after an even number of steps, as a fused pair needs it
+    gg.step2(gHt, gA, gB, gC, gR, *coef, dt, sq[0:2], join=False)
+    gA, gC = gC, gA
+    for k in range(2):
+        oracle.diffusion3d_step(Ht, A, B, R, *coef)
+        wrap(B, dims=dims)
+        A, B = B, A
+    assert gg._pending
+    for it in range(2):
+        oracle.diffusion3d_step(Ht, A, B, R, *coef)
+        wrap(B, dims=dims)
+        A, B = B, A
+        gg.step(gHt, gA, gB, gR, *coef, dt, sq[2:3])
+        gA, gB = gB, gA
+        assert not gg._pending
+        ref = oracle.sumsq_scaled(R, dt)
+        assert abs(float(sq[2].item()) - ref) <= 1e-13 * ref
+        assert np.array_equal(F.tonumpy(gA)[inner], A[inner]) and np.array_equal(F.tonumpy(gR)[inner], R[inner])
+
+
 @pytest.mark.parametrize("periods", [(0, 0, 1), (1, 1, 1)], ids=["z", "xyz"])
 def test_config4_512cubed_over_rccl_self_neighbour(fpr, oracle, periodic_grid, periods):
     """BASELINE config 4's per-GPU workload (512^3 local array with neighbours) through the library's RCCL transport on

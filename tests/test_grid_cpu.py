@@ -199,3 +199,30 @@ def test_bench_self_launcher_dry_run_world2():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-such-flag"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
+
+
+def test_comm_share_and_box_order_of_fused_pairs():
+    """GlobalGrid.reserve_cus: the comm stream of a fused pair gets a multiple of 32 compute units (the same number out of
+    every shader engine), 64 only above two x-faces' worth of shell work; boundary_boxes peels the x-slabs last (step2 runs
+    their first iteration on the core stream ahead of the core launch and takes them off the end of the list)."""
+    class Fake(grid.GlobalGrid):
+        def __init__(self, n, faces):
+            self.nx, self.ny, self.nz = n
+            self.neighbors = {f: (0, 0, 0) for f in faces}
+
+    n = (64, 48, 40)
+    for faces, want in (((4, 5), 32), ((4,), 32), ((2, 3), 32), ((2, 3, 4, 5), 32), ((1, 3, 5), 32), ((0, 1), 32),
+                        ((0, 1, 2, 3), 64), ((0, 1, 2, 3, 4, 5), 64), ((0, 1, 4), 64)):
+        g = Fake(n, faces)
+        k = g.reserve_cus()
+        assert k == want and k % 32 == 0, (faces, k)
+        boxes, core = g.boundary_boxes()
+        nxf = sum(1 for f in (0, 1) if f in faces)
+        assert len(boxes) == len(faces)
+        for lo, hi in boxes[len(boxes) - nxf:]:
+            assert hi[0] - lo[0] == 1 and (lo[0] == 1 or hi[0] == n[0] - 1)
+        for lo, hi in boxes[:len(boxes) - nxf]:
+            assert hi[0] - lo[0] > 1
+        # boxes and core are disjoint and cover the interior
+        vol = sum((hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]) for lo, hi in boxes + [core])
+        assert vol == (n[0] - 2) * (n[1] - 2) * (n[2] - 2)

@@ -257,6 +257,7 @@ class GlobalGrid:
     transport_kind = "dist"
     _tr = _ex = _sq_host = _sq_shell = _reserve = None
     _pending = False
+    _singles = 0
 
     def __init__(self, nx, ny, nz, dims=None, group=None, use_dist=None, periods=(0, 0, 0), transport=None, drop_faces=0):
         """drop_faces (bit 2*dim+side; measurement aid): faces that get no neighbour although the topology has one -- a
@@ -441,6 +442,13 @@ class GlobalGrid:
         from . import part1
 
         self.join()
+        # a run of single steps (a loop that cannot fuse pairs, a leg of one-iteration launches) undoes the split of the device
+        # that fused pairs left behind: unsplit, the interior launch has every compute unit and the exchange runs beside it
+        self._singles += 1
+        if self._singles == 3 and self.neighbors:
+            from . import ctx as _ctx
+
+            _ctx().reserve_comm_cus(0)
         if not self.neighbors:
             if sq_dev is None:
                 part1.diffusion_3D_step_τ(Ht, Hτ, Hτ2, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
@@ -525,6 +533,7 @@ class GlobalGrid:
         from ._lib import fzeros
 
         c = _ctx()
+        self._singles = 0
         coef = (dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
         sqs = None
         if sq2_dev is not None:

@@ -2,7 +2,7 @@
 // Builds with -DDIFF3_STORE_NOP=<n> (wait states after the 16-byte stores of a row; -1 = none).  Runs `launches`
 // fused launches at nx x ny x nz and compares EVERY cell of both outputs, bit for bit, with two single-iteration
 // launches computed once; a second stream keeps copying a 1 GiB buffer meanwhile (whatever of it the fused kernel's
-// one-workgroup-per-CU grid lets in).  usage: hazard_soak nx ny nz launches
+// one-workgroup-per-CU grid lets in).  usage: hazard_soak nx ny nz launches [reserve_cus: the reserved form of the launch, 0 = plain grid]
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -76,6 +76,7 @@ int main(int argc, char** argv)
         CK(diff3_launch(a, false, t, s, 1 << 22, &np));
         CK(hipStreamSynchronize(s));
     }
+    const int reserve = argc > 5 ? atoi(argv[5]) : 0;
     int ncu = 256;
     CK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
     Diff3Args2 f;
@@ -93,7 +94,7 @@ int main(int argc, char** argv)
     unsigned long long bad_launches = 0, prev = 0;
     for (int i = 0; i < launches; ++i) {
         for (int k = 0; k < 3; ++k) k_copy16<<<1024, 256, 0, s2>>>((double2*)(k & 1 ? bg0 : bg1), (const double2*)(k & 1 ? bg1 : bg0), NB / 2);
-        CK(diff3_launch2(f, true, 0, 0, s, 1 << 21, &np, 0, ncu));
+        CK(diff3_launch2(f, true, 0, 0, s, 1 << 21, &np, 0, ncu, 0, 0, reserve));
         k_count_diff<<<2048, 256, 0, s>>>(C, Cref, N, cnt);
         k_count_diff<<<2048, 256, 0, s>>>(dH, dHref, N, cnt);
         if ((i & 15) == 15 || i == launches - 1) {

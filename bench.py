@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 A_EFF_BYTES = 32.0     # read Htau + read Ht + write Htau2 + write dHdtau, per interior cell
-KT_STEP, KT_STEP2, KT_MG_PRE, KT_MG_POST, KT_MG_SEAM, KT_MG_CG, KT_MG_PATCH = 0, 1, 2, 3, 4, 5, 6   # include/fpr.h FPR_KT_*
+KT_STEP, KT_STEP2, KT_MG_PRE, KT_MG_POST, KT_MG_SEAM, KT_MG_CG, KT_MG_PATCH, KT_CORE = 0, 1, 2, 3, 4, 5, 6, 7   # include/fpr.h FPR_KT_*
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -577,7 +577,7 @@ def main():
         run(K, W + extra, fuse2)
         barrier()
         elapsed = time.perf_counter() - t0
-        kt = {kind: timer_read(ctx, kind) for kind in (KT_STEP, KT_STEP2)}
+        kt = {kind: timer_read(ctx, kind) for kind in (KT_STEP, KT_STEP2, KT_CORE)}
         ctx.call("fpr_kernel_timer", 0)
         if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64)
@@ -586,30 +586,39 @@ def main():
         return elapsed, kt, extra
 
     cells = (nloc[0] - 2) * (nloc[1] - 2) * (nloc[2] - 2)
+    _cb = gg.boundary_boxes()[1] if world > 1 else ((1, 1, 1), tuple(m - 1 for m in nloc))
+    core_cells = (_cb[1][0] - _cb[0][0]) * (_cb[1][1] - _cb[0][1]) * (_cb[1][2] - _cb[0][2])
     min_bytes = A_EFF_BYTES * cells     # what ONE launch must move at the very least, however many iterations it fuses
 
     def kernel_roofline(kind, kt, traffic_entry):
         ms_tot, cnt = kt[kind]
         ipl = 2 if kind == KT_STEP2 else 1
-        if world > 1:
-            # between ranks one pass over the local grid is SEVERAL launches (the core, and the shell boxes beside it):
-            # price the pass, not the launch -- all diffusion launches of the timed region / passes in it
+        nbytes = min_bytes
+        if world > 1 and kind == KT_STEP2 and kt[KT_CORE][1]:
+            # between ranks a fused pair is ONE core launch on the core stream (the dominant kernel, priced here: 32 B per
+            # core cell) and thin shell launches BESIDE it on the comm stream (reported below; they overlap it in time)
+            ms_tot, cnt = kt[KT_CORE]
+            nbytes = A_EFF_BYTES * core_cells
+        elif world > 1:
+            # single steps between ranks: boundary slabs, then the interior beside the exchange -- price the pass
             ms_tot = kt[KT_STEP][0] + kt[KT_STEP2][0]
             cnt = max(K // ipl, 1)
         kms = ms_tot / cnt if cnt else 0.0
-        ach = min_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        ach = nbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "kernel": "k_diff3_march2 (two iterations per launch)" if kind == KT_STEP2 else "k_diff3_march (one iteration per launch)",
              "achieved": ach, "frac": ach / HBM_PEAK_GBS, "kernel_ms": kms, "launches": cnt,
-             "bytes_per_launch": min_bytes, "iterations_per_launch": ipl,
+             "bytes_per_launch": nbytes, "iterations_per_launch": ipl,
              "accounting": "32 B per interior cell per LAUNCH: read Htau, read Ht, write the new field, write dHdtau (the "
                            "field between two fused iterations never leaves the chip)",
              "effective_achieved": ach * ipl, "effective_frac": ach * ipl / HBM_PEAK_GBS,
              "effective_accounting": "SURVEY 8d: 32 B per interior cell per ITERATION x iterations per launch",
              "traffic": None, "traffic_source": None}
         if world > 1:
-            r["kernel"] += "; between ranks: all launches of one pass over the local grid (core on the compute stream; shell boxes on the comm stream beside it)"
-            r["launches_by_kind"] = {"single_step_boxes": kt[KT_STEP][1], "fused_boxes": kt[KT_STEP2][1]}
+            r["kernel"] += ("; between ranks: the CORE launch of the local grid (one per pair, on the core stream of the split device); the "
+                            "shell launches run beside it on the comm stream") if kt[KT_CORE][1] else "; between ranks: all launches of one pass"
+            r["launches_by_kind"] = {"single_step_boxes": kt[KT_STEP][1], "fused_boxes": kt[KT_STEP2][1] + kt[KT_CORE][1], "core": kt[KT_CORE][1]}
+            r["shell_launches_ms_total"] = kt[KT_STEP][0] + kt[KT_STEP2][0]
         if traffic_entry:
             r["traffic"] = traffic_entry["traffic_bytes_per_launch"]
             r["traffic_source"] = traffic_entry.get("source")

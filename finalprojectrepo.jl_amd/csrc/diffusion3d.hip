@@ -133,6 +133,7 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
     a.D_dx = D_dx; a.D_dy = D_dy; a.D_dz = D_dz;
     a.scale = scale;
     double* base = stream_sel == 1 ? ctx->partials2 : ctx->partials;
+    const bool is_core = reserve_cus > 0 || stream_sel == 2;   // fpr_diffusion3d_step2_core (kernel timer kind)
     // a launch on the core stream of a split device (fpr_reserve_comm_cus) has that many units less, whatever the caller says
     if (stream_sel == 2 && ctx->comm_cus > reserve_cus) reserve_cus = ctx->comm_cus;
     a.partials1 = base;
@@ -154,7 +155,7 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
         // boxes up to 12 cells wide in x (the slab next to an x-neighbour of a decomposed run) go to the kernel whose
         // lanes run along y; everything else to the wave-tile kernel.  A second z-range rides along in either case.
         const bool narrow = (a.hi[0] - a.lo[0]) <= (int)fpr_opt(ctx, "diff3_slab_max", 12);
-        const bool timed = fpr_ktimer_begin(ctx, FPR_KT_DIFF3_STEP2, ctx->stream[stream_sel]);
+        const bool timed = fpr_ktimer_begin(ctx, is_core ? FPR_KT_DIFF3_CORE : FPR_KT_DIFF3_STEP2, ctx->stream[stream_sel]);
         hipError_t e;
         if (narrow) {
             e = diff3_launch_slab2(a, norm, ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2, &nparts);

@@ -235,6 +235,7 @@ static int post_group(fpr_ctx* ctx, double* A, int mask, hipStream_t s)
 extern "C" int fpr_halo_exchange3d_begin(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face_mask)
 {
     if (!ctx) return FPR_ERR_INVALID;
+    if (int rc = fpr_diffusion3d_join(ctx)) return rc;   // a fused pair left on the core / comm streams (fpr_diffusion3d_step2_halo)
     if (int rc = check_grid(ctx, A, nx, ny, nz)) return rc;
     const FprGrid& g = ctx->grid;
     bool any = false;
@@ -308,6 +309,7 @@ extern "C" int fpr_allreduce_sum_dev(fpr_ctx* ctx, double* x_dev, int count, int
 {
     if (!ctx) return FPR_ERR_INVALID;
     FPR_REQUIRE(ctx, x_dev && count >= 1 && (stream_sel == 0 || stream_sel == 1), "pointer / count / stream");
+    if (int rc = fpr_diffusion3d_join(ctx)) return rc;
     if (!ctx->comm) return FPR_OK;   // single rank without a communicator
     FPR_NCCL(ctx, ncclAllReduce(x_dev, x_dev, (size_t)count, ncclDouble, ncclSum, comm_of(ctx), ctx->stream[stream_sel]));
     return FPR_OK;
@@ -319,6 +321,7 @@ extern "C" int fpr_allreduce_sum1(fpr_ctx* ctx, double* x_host_inout)
 {
     if (!ctx) return FPR_ERR_INVALID;
     FPR_REQUIRE(ctx, x_host_inout, "null pointer");
+    if (int rc = fpr_diffusion3d_join(ctx)) return rc;
     if (!ctx->comm) return FPR_OK;   // single rank without a communicator
     // like every RCCL operation of this communicator it runs on the comm stream, behind what the compute stream holds
     double* d = ctx->scalars + 48;
@@ -339,6 +342,7 @@ extern "C" int fpr_gather3d(fpr_ctx* ctx, const double* A, int nx, int ny, int n
 {
     if (!ctx) return FPR_ERR_INVALID;
     if (int rc = check_grid(ctx, A, nx, ny, nz)) return rc;
+    if (int rc = fpr_diffusion3d_join(ctx)) return rc;
     FprGrid& g = ctx->grid;
     const size_t n = (size_t)nx * ny * nz;
     const int np = ctx->comm_size, me = ctx->comm_rank;

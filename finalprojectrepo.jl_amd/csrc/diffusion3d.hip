@@ -479,6 +479,106 @@ extern "C" int fpr_diffusion3d_step2_core(fpr_ctx* ctx, const double* Ht, const 
                       scale, sumsq2_dev, accumulate != 0, stream_sel, 0, 0, nullptr, nullptr, reserve_cus);
 }
 
+// ---- two iterations per launch BETWEEN ranks: the whole choreography of a fused pair in one call ---------------------------
+// (GlobalGrid.step2 in finalprojectrepo.jl_amd/grid.py and diffusion_3D_step_τ2_halo! in julia/FPRHip.jl are its twins; the phased
+// Python form stays for emulated ranks.)  SHELL = the one-cell layer of interior cells next to a face with a neighbour (disjoint
+// thin boxes: z faces peeled first, then y, then x), CORE = the rest.  The device is split (fpr_reserve_comm_cus):
+//   core stream : [x-slabs' first iteration] CORE as one fused launch ---------------------------------------------> (+ shell sums)
+//   comm stream : z / y slabs' first iteration -> exchange(level 1 in Hmid) -> fused launches on the shell -> exchange(Hout) --^
+// join = 0 leaves the pair on those two streams; the next pair continues from there, fpr_diffusion3d_join (or any entry point of
+// the grid: fpr_halo_exchange3d*, fpr_allreduce_sum*) orders the compute stream behind it.
+static int diff3_comm_units(const FprGrid& g)
+{
+    int work = 0;
+    const int w[3] = {5, 2, 1};   // an x-slab costs about five z-slabs (lanes along y, one cache line per access), a y-slab two
+    for (int f = 0; f < 6; ++f)
+        if (g.nb[f] >= 0) work += w[f >> 1];
+    return work > 10 ? 64 : 32;   // multiples of 32: the same number of units out of every shader engine (fpr_reserve_comm_cus)
+}
+
+extern "C" int fpr_diffusion3d_join(fpr_ctx* ctx)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    if (!ctx->pair_pending) return FPR_OK;
+    ctx->pair_pending = false;
+    return fpr_stream_wait(ctx, 0, 2);   // the core stream has taken in the shell chain already
+}
+
+extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Hmid, double* Hout,
+                                          double* dHdtau, int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy,
+                                          double _dz, double D_dx, double D_dy, double D_dz, double scale, double* sumsq2_dev,
+                                          int join)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, ctx->grid.on && nx == ctx->grid.n[0] && ny == ctx->grid.n[1] && nz == ctx->grid.n[2],
+                "fpr_grid_init has not been called for arrays of this size");
+    const FprGrid& g = ctx->grid;
+    int mask = 0;
+    for (int f = 0; f < 6; ++f)
+        if (g.nb[f] >= 0) mask |= 1 << f;
+    if (!mask) {   // no neighbour: the plain fused launch on the compute stream
+        if (int rc = fpr_diffusion3d_join(ctx)) return rc;
+        return diff3_run2(ctx, Ht, Htau, Hmid, Hout, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, nullptr, nullptr,
+                          scale, sumsq2_dev, false, 0);
+    }
+    const int n[3] = {nx, ny, nz};
+    for (int f = 0; f < 6; ++f)
+        FPR_REQUIRE(ctx, g.nb[f] < 0 || n[f >> 1] >= 8, "a decomposed dimension needs at least 8 cells for shell + core");
+    // boundary boxes (0-based [lo, hi)) and the core
+    int lo[3] = {1, 1, 1}, hi[3] = {nx - 1, ny - 1, nz - 1};
+    int blo[6][3], bhi[6][3], bdim[6], nbx = 0;
+    for (int d = 2; d >= 0; --d)
+        for (int side = 0; side < 2; ++side) {
+            if (g.nb[2 * d + side] < 0 || hi[d] - lo[d] < 1) continue;
+            for (int e = 0; e < 3; ++e) { blo[nbx][e] = lo[e]; bhi[nbx][e] = hi[e]; }
+            if (side == 0) { bhi[nbx][d] = lo[d] + 1; lo[d] += 1; }
+            else { blo[nbx][d] = hi[d] - 1; hi[d] -= 1; }
+            bdim[nbx++] = d;
+        }
+    const int k = diff3_comm_units(g);
+    if (int rc = fpr_reserve_comm_cus(ctx, k)) return rc;
+    double* sqs = ctx->scalars + 46;   // the shell chain's two sums (comm stream)
+    if (ctx->pair_pending) {
+        if (int rc = fpr_stream_wait(ctx, 1, 2)) return rc;   // this pair's shell chain sees the previous pair's core
+    } else {
+        if (int rc = fpr_stream_wait(ctx, 1, 0)) return rc;   // fork: the pair's inputs are ready
+        if (int rc = fpr_stream_wait(ctx, 2, 0)) return rc;
+    }
+#define D3ARGS nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz
+    // the x-slabs' first iteration on the core stream AHEAD of the core launch (25 us there, 180 us beside it)
+    bool anyx = false;
+    for (int b = 0; b < nbx; ++b)
+        if (bdim[b] == 0) {
+            if (int rc = diff3_run(ctx, Ht, Htau, Hmid, dHdtau, D3ARGS, blo[b], bhi[b], false, 0.0, nullptr, true, 2)) return rc;
+            anyx = true;
+        }
+    if (anyx)
+        if (int rc = fpr_stream_wait(ctx, 1, 2)) return rc;   // the chain follows them (recorded before the core launch)
+    if (int rc = diff3_run2(ctx, Ht, Htau, Hmid, Hout, dHdtau, D3ARGS, lo, hi, scale, sumsq2_dev, false, 2, 0, 0, nullptr, nullptr, k)) return rc;
+    if (sumsq2_dev)
+        if (int rc = fpr_fill_on(ctx, sqs, 0.0, 2, 1)) return rc;
+    for (int b = 0; b < nbx; ++b)
+        if (bdim[b] != 0)
+            if (int rc = diff3_run(ctx, Ht, Htau, Hmid, dHdtau, D3ARGS, blo[b], bhi[b], false, 0.0, nullptr, true, 1)) return rc;
+    if (int rc = fpr_halo_exchange3d_comm(ctx, Hmid, nx, ny, nz, mask)) return rc;
+    // fused launches on the shell boxes: their level-1 halo cells have just arrived in Hmid
+    int b0 = 0;
+    if (g.nb[4] >= 0 && g.nb[5] >= 0) {   // the two z-slabs (peeled first, same x / y extent) share one launch
+        if (int rc = diff3_run2(ctx, Ht, Htau, Hmid, Hout, dHdtau, D3ARGS, blo[0], bhi[0], scale, sumsq2_dev ? sqs : nullptr, true, 1,
+                                blo[1][2], bhi[1][2])) return rc;
+        b0 = 2;
+    }
+    for (int b = b0; b < nbx; ++b)
+        if (int rc = diff3_run2(ctx, Ht, Htau, Hmid, Hout, dHdtau, D3ARGS, blo[b], bhi[b], scale, sumsq2_dev ? sqs : nullptr, true, 1)) return rc;
+#undef D3ARGS
+    if (int rc = fpr_halo_exchange3d_comm(ctx, Hout, nx, ny, nz, mask)) return rc;
+    if (int rc = fpr_stream_wait(ctx, 2, 1)) return rc;       // the core stream takes in the shell chain ...
+    if (sumsq2_dev)
+        if (int rc = fpr_add_on(ctx, sumsq2_dev, sqs, 2, 2)) return rc;   // ... and its sums
+    ctx->pair_pending = true;
+    return join ? fpr_diffusion3d_join(ctx) : FPR_OK;
+}
+
 extern "C" int fpr_diffusion3d_step_box(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2,
                                         double* dHdtau, int nx, int ny, int nz, double dtau, double _dt, double _dx,
                                         double _dy, double _dz, double D_dx, double D_dy, double D_dz, const int lo[3],

@@ -78,6 +78,7 @@ struct fpr_ctx {
     hipStream_t caller_comm = nullptr;   // the comm stream given at creation, while a masked one stands in for it
     hipStream_t masked[2] = {nullptr, nullptr};   // library-owned CU-masked streams (comm, core)
     int comm_cus = 0;
+    bool pair_pending = false;         // a fused pair of fpr_diffusion3d_step2_halo left on the core / comm streams (join = 0)
     int cgp_resident = -1;             // k_cg_persistent: 16 workgroups of 1024 threads resident together? (-1 = not asked yet)
     double* partials = nullptr;     // FPR_MAX_PARTIALS doubles: block partial sums (slot 0)
     double* partials2 = nullptr;    // second slot (comm stream / second reduction of a kernel)

@@ -257,6 +257,7 @@ class GlobalGrid:
     transport_kind = "dist"
     _tr = _ex = _sq_host = _sq_shell = _reserve = None
     _pending = False
+    _native_pending = False
     _singles = 0
 
     def __init__(self, nx, ny, nz, dims=None, group=None, use_dist=None, periods=(0, 0, 0), transport=None, drop_faces=0):
@@ -484,12 +485,34 @@ class GlobalGrid:
         if not self.neighbors:
             part1.diffusion_3D_step_τ2(*args, norm_scale, sq2_dev)
             return
+        if self.transport_kind == "rccl" and self._reserve is None and not self._pending:
+            # the product path: the whole choreography in ONE call of the library (fpr_diffusion3d_step2_halo); the phased
+            # Python form below is its twin for emulated ranks / the gloo transport and for experiments with the comm share
+            from . import ctx as _ctx
+            from ._lib import fptr
+
+            self._singles = 0
+            _ctx().call("fpr_diffusion3d_step2_halo", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hτ2, 3), fptr(Hout, 3), fptr(dHdτ, 3),
+                        self.nx, self.ny, self.nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, float(norm_scale),
+                        sq2_dev.data_ptr() if sq2_dev is not None else None, 1 if join else 0)
+            self._native_pending = not join
+            return
         st = self.step2_begin(*args, norm_scale, sq2_dev)
         self.step2_middle(st)
         self.step2_end(st, join)
 
+    @property
+    def pending(self):
+        """True while a fused pair of step2(join=False) sits on the core / comm streams, not yet joined."""
+        return self._pending or self._native_pending
+
     def join(self):
         """Order the compute stream behind a fused pair that step2(join=False) left on the core / comm streams."""
+        if self._native_pending:
+            from . import ctx as _ctx
+
+            _ctx().call("fpr_diffusion3d_join")
+            self._native_pending = False
         if self._pending:
             from . import ctx as _ctx
 
@@ -534,6 +557,8 @@ class GlobalGrid:
 
         c = _ctx()
         self._singles = 0
+        if self._native_pending:      # a pair left pending by the one-call form: the phased form starts from the compute stream
+            self.join()
         coef = (dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
         sqs = None
         if sq2_dev is not None:

@@ -138,6 +138,19 @@ int fpr_diffusion3d_step2_core(fpr_ctx* ctx, const double* Ht, const double* Hta
                                double* dHdtau, int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy,
                                double _dz, double D_dx, double D_dy, double D_dz, const int lo[3], const int hi[3],
                                double scale, double* sumsq2_dev, int stream_sel, int reserve_cus, int accumulate);
+/* _halo: TWO iterations on a rank WITH neighbours (fpr_grid_init), halos of Hout refreshed -- what `@hide_communication` + `update_halo!`
+ * (part1_kernel_programming.jl:185-190) do for one iteration, for two: the device is split (fpr_reserve_comm_cus, 32 or 64 units for
+ * the comm stream by the rank's faces), the core of the local grid runs as ONE fused launch on the core stream, and beside it on the
+ * comm stream run the first iteration on the one-cell shell (level 1 into Hmid), the exchange of Hmid's planes, the fused launches on
+ * the shell and the exchange of Hout's planes (the x-slabs' first iteration runs on the core stream ahead of the core launch).  Same
+ * results as two fpr_diffusion3d_step calls each followed by fpr_halo_exchange3d of the written buffer; Hout must carry Htau's
+ * physical-boundary values; sumsq2_dev (nullable) receives the LOCAL sums of both iterations.  join = 0 leaves the pair on the core /
+ * comm streams: the next _halo call continues from there; fpr_diffusion3d_join orders the compute stream behind it (call it before
+ * anything else reads the fields or the sums).  Without neighbours: fpr_diffusion3d_step2. */
+int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Hmid, double* Hout, double* dHdtau,
+                               int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx,
+                               double D_dy, double D_dz, double scale, double* sumsq2_dev, int join);
+int fpr_diffusion3d_join(fpr_ctx* ctx);
 
 /* A5: the single-rank host loop of diffusion_3D_kernel_programming (part1_kernel_programming.jl:166-204) in
  * native code: for each of `nt` physical steps iterate the fused update until err <= tol (err =

@@ -103,8 +103,6 @@ function destroy_context()
         CTX[] = C_NULL
         GRID[] = nothing
         HAS_COMM[] = false
-        SQ_SHELL[] = nothing
-        PAIR_PENDING[] = false
     end
     return nothing
 end
@@ -615,7 +613,7 @@ halo_exchange_end!(A::DA; faces = 63) = (n = size(A);
 halo_exchange_comm!(A::DA; faces = 63) = (n = size(A);
     check(ccall((:fpr_halo_exchange3d_comm, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint, Cint), ctx(), p(A), n[1], n[2], n[3], faces)))
 
-# ---- two iterations per launch BETWEEN ranks (mirror of GlobalGrid.step2 in finalprojectrepo.jl_amd/grid.py) ------------
+# ---- iterations BETWEEN ranks: the overlapped single step (@hide_communication) and the fused pair (one library call) ------
 "Faces (0-based, 2*dim + side) of this rank that have a neighbour."
 neighbour_faces() = [f for f in 0:5 if grid_sizes_g()[2][f + 1] >= 0]
 
@@ -640,17 +638,14 @@ function boundary_boxes(n::NTuple{3,Int}, faces)
     return boxes, (Tuple(lo), Tuple(hi))
 end
 
-"Compute units of the comm stream during fused pairs (a multiple of 32: the same number out of every shader engine)."
-comm_units(faces) = sum((5, 5, 2, 2, 1, 1)[f + 1] for f in faces; init = 0) > 10 ? 64 : 32
-
-const SQ_SHELL = Ref{Any}(nothing)
-const PAIR_PENDING = Ref(false)
 
 """
     diffusion_3D_step_τ2_halo!(Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz; scale, sumsq2, join)
 
 Two trips through the loop body of part1_kernel_programming.jl:179-192 on a rank WITH neighbours, halos of `Hout` refreshed --
-what `@hide_communication` + `update_halo!` do there for one iteration.  The device is split (`reserve_comm_cus`): the core of
+what `@hide_communication` + `update_halo!` do there for one iteration; ONE call of the library (`fpr_diffusion3d_step2_halo`;
+`GlobalGrid.step2_begin/middle/end` in finalprojectrepo.jl_amd/grid.py is the same choreography in phases).  The device is split
+(`reserve_comm_cus`): the core of
 the local grid runs as ONE fused launch on the core stream; on the comm stream, beside it, run the single steps on the
 one-cell shell (level 1 into `Hτ2`), the exchange of `Hτ2`'s planes, the fused launches on the shell boxes and the exchange of
 the new field.  `join = false` leaves the pair on those two streams (the next pair continues from there); call
@@ -659,55 +654,17 @@ of the new buffer after each.
 """
 function diffusion_3D_step_τ2_halo!(Ht::DA, Hτ::DA, Hτ2::DA, Hout::DA, dHdτ::DA, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz;
                                     scale = 0.0, sumsq2::Union{DA,Nothing} = nothing, join::Bool = true)
-    faces = neighbour_faces()
-    if isempty(faces)
-        return diffusion_3D_step_τ2(Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz; scale = scale, sumsq2 = sumsq2)
-    end
-    coef = (dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
-    boxes, core = boundary_boxes(size(Ht), faces)
-    mask = sum(1 << f for f in faces)
-    k = comm_units(faces)
-    reserve_comm_cus(k)
-    sqs = nothing
-    if sumsq2 !== nothing
-        SQ_SHELL[] === nothing && (SQ_SHELL[] = AMDGPU.zeros(Float64, 2))
-        sqs = SQ_SHELL[]
-    end
-    if PAIR_PENDING[]
-        stream_wait(1, 2)                        # the shell chain of this pair sees the previous pair's core
-    else
-        stream_wait(1, 0); stream_wait(2, 0)     # fork: the pair's inputs are ready
-    end
-    diffusion_3D_step_τ2_core(Ht, Hτ, Hτ2, Hout, dHdτ, coef..., core[1], core[2]; scale = scale, sumsq2 = sumsq2, stream_sel = 2,
-                              reserve_cus = k, accumulate = false)
-    sqs === nothing || fill_on!(sqs, 0.0, 1)
-    for (lo, hi) in boxes                        # comm stream: level 1 on the shell
-        diffusion_3D_step_τ_box(Ht, Hτ, Hτ2, dHdτ, coef..., lo, hi; stream_sel = 1)
-    end
-    halo_exchange_comm!(Hτ2; faces = mask)
-    rest = boxes
-    if 4 in faces && 5 in faces                  # the two z-slabs (peeled first, same x / y extent) share one launch
-        (lo0, hi0), (lo1, hi1) = boxes[1], boxes[2]
-        diffusion_3D_step_τ2_box2(Ht, Hτ, Hτ2, Hout, dHdτ, coef..., lo0, hi0, lo1[3], hi1[3]; scale = scale, sumsq2 = sqs, stream_sel = 1)
-        rest = boxes[3:end]
-    end
-    for (lo, hi) in rest
-        diffusion_3D_step_τ2_box(Ht, Hτ, Hτ2, Hout, dHdτ, coef..., lo, hi; scale = scale, sumsq2 = sqs, stream_sel = 1)
-    end
-    halo_exchange_comm!(Hout; faces = mask)
-    stream_wait(2, 1)                            # the core stream takes in the shell chain and its sums
-    sumsq2 === nothing || add_on!(sumsq2, sqs, 2)
-    PAIR_PENDING[] = true
-    join && join_pair!()
+    nx, ny, nz = size(Ht)
+    check(ccall((:fpr_diffusion3d_step2_halo, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint,
+                 Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cdouble}, Cint),
+                ctx(), p(Ht), p(Hτ), p(Hτ2), p(Hout), p(dHdτ), nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale,
+                sumsq2 === nothing ? Ptr{Cdouble}(C_NULL) : p(sumsq2), join ? 1 : 0))
     return nothing
 end
 
 "Order the compute stream behind a pair that `diffusion_3D_step_τ2_halo!(...; join = false)` left on the core / comm streams."
-function join_pair!()
-    PAIR_PENDING[] && stream_wait(0, 2)
-    PAIR_PENDING[] = false
-    return nothing
-end
+join_pair!() = CTX[] == C_NULL ? nothing : (check(ccall((:fpr_diffusion3d_join, libfpr), Cint, (Ptr{Cvoid},), CTX[])); nothing)
 
 "`gather!(A, A_global)` (part1_kernel_programming.jl:223): A_global (host, rank 0; `nothing` elsewhere) receives all local arrays."
 function gather!(A::DA, A_global::Union{Array{Float64,3},Nothing})

@@ -207,9 +207,9 @@ def test_pairs_chained_on_core_and_comm_streams(fpr, oracle, periodic_grid, peri
             refs.append(oracle.sumsq_scaled(R, dt))
         gg.step2(gHt, gA, gB, gC, gR, *coef, dt, sq[2 * p:2 * p + 2], join=False)
         gA, gC = gC, gA
-    assert gg._pending
+    assert gg.pending
     gg.allreduce_(sq)          # joins (a single rank: nothing else happens)
-    assert not gg._pending
+    assert not gg.pending
     got = sq.cpu().tolist()[:2 * npairs]
     assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs)), (got, refs)
     inner = (slice(1, -1),) * 3
@@ -222,14 +222,14 @@ def test_pairs_chained_on_core_and_comm_streams(fpr, oracle, periodic_grid, peri
         oracle.diffusion3d_step(Ht, A, B, R, *coef)
         wrap(B, dims=dims)
         A, B = B, A
-    assert gg._pending
+    assert gg.pending
     for it in range(2):
         oracle.diffusion3d_step(Ht, A, B, R, *coef)
         wrap(B, dims=dims)
         A, B = B, A
         gg.step(gHt, gA, gB, gR, *coef, dt, sq[2:3])
         gA, gB = gB, gA
-        assert not gg._pending
+        assert not gg.pending
         ref = oracle.sumsq_scaled(R, dt)
         assert abs(float(sq[2].item()) - ref) <= 1e-13 * ref
         assert np.array_equal(F.tonumpy(gA)[inner], A[inner]) and np.array_equal(F.tonumpy(gR)[inner], R[inner])

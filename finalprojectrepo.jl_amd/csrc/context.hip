@@ -60,6 +60,7 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
     if (ctx->cg_buf) hipFree(ctx->cg_buf);
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->partials2) hipFree(ctx->partials2);
+    if (ctx->core_partials) hipFree(ctx->core_partials);
     if (ctx->scalars) hipFree(ctx->scalars);
     if (ctx->state) hipFree(ctx->state);
     if (ctx->state_h) hipHostFree(ctx->state_h);
@@ -407,6 +408,23 @@ __global__ __launch_bounds__(256) void k_finish2(const double* __restrict__ p0, 
     __shared__ double red[16];
     const double s = fpr_sum_partials_256(blockIdx.x ? p1 : p0, n, red);
     if (threadIdx.x == 0) out[blockIdx.x] = ACC ? out[blockIdx.x] + s : s;
+}
+
+// out[b] = (sum of list b, fixed order) + add[b]: what k_finish2<0> followed by out += add gives, in one launch
+__global__ __launch_bounds__(256) void k_finish2_plus(const double* __restrict__ p0, const double* __restrict__ p1, int n,
+                                                       const double* __restrict__ add, double* __restrict__ out)
+{
+    __shared__ double red[16];
+    const double s = fpr_sum_partials_256(blockIdx.x ? p1 : p0, n, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s + add[blockIdx.x];
+}
+
+int fprx_finish_sum2_plus(fpr_ctx* ctx, const double* p0, const double* p1, int nparts, const double* add2_dev, double* out2_dev,
+                          int stream_sel)
+{
+    k_finish2_plus<<<2, 256, 0, ctx->stream[stream_sel]>>>(p0, p1, nparts, add2_dev, out2_dev);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
 }
 
 int fprx_finish_sum2(fpr_ctx* ctx, const double* p0, const double* p1, int nparts, double* out2_dev, bool accumulate,

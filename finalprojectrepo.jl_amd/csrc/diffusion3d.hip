@@ -3,6 +3,7 @@
 // Reference: scripts-part1/part1_kernel_programming.jl, part1_array_programming.jl, part1_utils.jl.
 #include "diffusion3d_kernels.hpp"
 #include "fpr_internal.hpp"
+#include <cstring>
 
 // defined in diffusion3d_launch.hpp (shared with tools/diffusion_tune.hip)
 #include "diffusion3d_launch.hpp"
@@ -112,8 +113,9 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
                       int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy,
                       double D_dz, const int* lo, const int* hi, double scale, double* sumsq2_dev, bool accumulate,
                       int stream_sel, int zlo2 = 0, int zhi2 = 0, const int* skip = nullptr, int* nparts_only = nullptr,
-                      int reserve_cus = 0)
-{   // nparts_only: the launch reduces both norms to per-workgroup partials (partials1 / partials2 of the stream's scratch) and
+                      int reserve_cus = 0, double* partial_base = nullptr, int partial_cap = 0)
+{   // partial_base / partial_cap: two lists of partial_cap doubles for the partials instead of the stream's scratch
+    // nparts_only: the launch reduces both norms to per-workgroup partials (partials1 / partials2 of the stream's scratch) and
     // leaves the finishing to the caller: *nparts_only = their number
     if (!ctx) return FPR_ERR_INVALID;
     FPR_REQUIRE(ctx, Ht && A && B && C, "null field pointer");   // dH may be null: residual not stored
@@ -136,8 +138,9 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
     const bool is_core = reserve_cus > 0 || stream_sel == 2;   // fpr_diffusion3d_step2_core (kernel timer kind)
     // a launch on the core stream of a split device (fpr_reserve_comm_cus) has that many units less, whatever the caller says
     if (stream_sel == 2 && ctx->comm_cus > reserve_cus) reserve_cus = ctx->comm_cus;
-    a.partials1 = base;
-    a.partials2 = base + FPR_MAX_PARTIALS / 2;
+    const int pcap = partial_base ? partial_cap : FPR_MAX_PARTIALS / 2;
+    a.partials1 = partial_base ? partial_base : base;
+    a.partials2 = a.partials1 + pcap;
     const bool norm = sumsq2_dev != nullptr || nparts_only != nullptr;
     if (zlo2 < 1) zlo2 = 1;
     if (zhi2 > nz - 1) zhi2 = nz - 1;
@@ -158,13 +161,13 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
         const bool timed = fpr_ktimer_begin(ctx, is_core ? FPR_KT_DIFF3_CORE : FPR_KT_DIFF3_STEP2, ctx->stream[stream_sel]);
         hipError_t e;
         if (narrow) {
-            e = diff3_launch_slab2(a, norm, ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2, &nparts);
+            e = diff3_launch_slab2(a, norm, ctx->stream[stream_sel], pcap, &nparts);
             if (e == hipSuccess && zhi2 > zlo2) {
                 Diff3Args2 b = a;
                 b.lo[2] = zlo2; b.hi[2] = zhi2;
                 b.partials1 = a.partials1 + nparts; b.partials2 = a.partials2 + nparts;
                 int np2 = 0;
-                e = diff3_launch_slab2(b, norm, ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2 - nparts, &np2);
+                e = diff3_launch_slab2(b, norm, ctx->stream[stream_sel], pcap - nparts, &np2);
                 nparts += np2;
             }
         } else {
@@ -173,7 +176,7 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
             // a launch on the comm stream of a split device has that stream's compute units only: chunk it for them
             const int ncu_plan = (stream_sel == 1 && ctx->comm_cus > 0) ? ctx->comm_cus : ctx->ncu;
             e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), (int)fpr_opt(ctx, "diff3_xcd2", 0) & 3,
-                              ctx->stream[stream_sel], FPR_MAX_PARTIALS / 2, &nparts,
+                              ctx->stream[stream_sel], pcap, &nparts,
                               (int)fpr_opt(ctx, "diff3_nw2", 0), ncu_plan, zlo2, zhi2, reserve_cus, &bal_info);
             if (reserve_cus != 0) ctx->options["diff3_last_bal"] = bal_info;   // diagnostic (fpr_get_option): which form ran
         }
@@ -501,7 +504,8 @@ extern "C" int fpr_diffusion3d_join(fpr_ctx* ctx)
     if (!ctx) return FPR_ERR_INVALID;
     if (!ctx->pair_pending) return FPR_OK;
     ctx->pair_pending = false;
-    return fpr_stream_wait(ctx, 0, 2);   // the core stream has taken in the shell chain already
+    if (int rc = fpr_stream_wait(ctx, 0, 2)) return rc;   // the core launch (which has taken in the shell chain's exchanges)
+    return fpr_stream_wait(ctx, 0, 1);                    // the pair's sums, finished on the comm stream
 }
 
 extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Hmid, double* Hout,
@@ -538,9 +542,13 @@ extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const 
     const int k = diff3_comm_units(g);
     if (int rc = fpr_reserve_comm_cus(ctx, k)) return rc;
     double* sqs = ctx->scalars + 46;   // the shell chain's two sums (comm stream)
-    if (ctx->pair_pending) {
-        if (int rc = fpr_stream_wait(ctx, 1, 2)) return rc;   // this pair's shell chain sees the previous pair's core
-    } else {
+    // an error half way leaves launches on the core / comm streams: the compute stream is ordered behind both before the call
+    // returns, so that nothing the caller enqueues next overtakes them (the outputs are undefined after an error, fpr.h)
+    struct Rejoin {
+        fpr_ctx* c; bool armed;
+        ~Rejoin() { if (armed) { char msg[sizeof(c->err)]; memcpy(msg, c->err, sizeof(msg)); fpr_stream_wait(c, 0, 1); fpr_stream_wait(c, 0, 2); c->pair_pending = false; memcpy(c->err, msg, sizeof(msg)); } }
+    } rejoin{ctx, true};
+    if (!ctx->pair_pending) {   // (a pending pair left the comm stream behind its core launch and the core stream behind its chain)
         if (int rc = fpr_stream_wait(ctx, 1, 0)) return rc;   // fork: the pair's inputs are ready
         if (int rc = fpr_stream_wait(ctx, 2, 0)) return rc;
     }
@@ -554,7 +562,16 @@ extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const 
         }
     if (anyx)
         if (int rc = fpr_stream_wait(ctx, 1, 2)) return rc;   // the chain follows them (recorded before the core launch)
-    if (int rc = diff3_run2(ctx, Ht, Htau, Hmid, Hout, dHdtau, D3ARGS, lo, hi, scale, sumsq2_dev, false, 2, 0, 0, nullptr, nullptr, k)) return rc;
+    // The core launch leaves per-workgroup partials of its two sums in a buffer of its own (one per pair parity); they are
+    // finished on the COMM stream once the core has ended -- on the core stream nothing stands between this core launch and the
+    // next pair's (a finish and an add there cost 26 us per pair, profiles/r3_overlap_timeline_native.txt)
+    if (sumsq2_dev && !ctx->core_partials)
+        FPR_HIP(ctx, hipMalloc(&ctx->core_partials, (size_t)4 * FPR_CORE_PARTIALS * sizeof(double)));
+    double* cpart = sumsq2_dev ? ctx->core_partials + (size_t)(ctx->pair_parity & 1) * 2 * FPR_CORE_PARTIALS : nullptr;
+    ctx->pair_parity ^= 1;
+    int core_nparts = 0;
+    if (int rc = diff3_run2(ctx, Ht, Htau, Hmid, Hout, dHdtau, D3ARGS, lo, hi, scale, nullptr, false, 2, 0, 0, nullptr,
+                            sumsq2_dev ? &core_nparts : nullptr, k, cpart, FPR_CORE_PARTIALS)) return rc;
     if (sumsq2_dev)
         if (int rc = fpr_fill_on(ctx, sqs, 0.0, 2, 1)) return rc;
     for (int b = 0; b < nbx; ++b)
@@ -572,9 +589,18 @@ extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const 
         if (int rc = diff3_run2(ctx, Ht, Htau, Hmid, Hout, dHdtau, D3ARGS, blo[b], bhi[b], scale, sumsq2_dev ? sqs : nullptr, true, 1)) return rc;
 #undef D3ARGS
     if (int rc = fpr_halo_exchange3d_comm(ctx, Hout, nx, ny, nz, mask)) return rc;
-    if (int rc = fpr_stream_wait(ctx, 2, 1)) return rc;       // the core stream takes in the shell chain ...
-    if (sumsq2_dev)
-        if (int rc = fpr_add_on(ctx, sumsq2_dev, sqs, 2, 2)) return rc;   // ... and its sums
+    // Every stream wait between two core launches costs 5-8 us of the core stream's time (tools/attic/dbg_faces.py: with none
+    // of them a z pair is +3.7 % over the plain launch, with these two +5.3 %, with a third at the top of the next call +5.9 %)
+    if (int rc = fpr_stream_wait(ctx, 2, 1)) return rc;       // the core stream takes in the shell chain
+    if (int rc = fpr_stream_wait(ctx, 1, 2)) return rc;       // the comm stream goes on behind the core launch: the next chain ...
+    if (sumsq2_dev) {   // ... and the pair's sums = core partials + the shell chain's sums
+        if (core_nparts > 0) {
+            if (int rc = fprx_finish_sum2_plus(ctx, cpart, cpart + FPR_CORE_PARTIALS, core_nparts, sqs, sumsq2_dev, 1)) return rc;
+        } else {   // empty core: the shell chain's sums are the pair's
+            FPR_HIP(ctx, hipMemcpyAsync(sumsq2_dev, sqs, 2 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream[1]));
+        }
+    }
+    rejoin.armed = false;
     ctx->pair_pending = true;
     return join ? fpr_diffusion3d_join(ctx) : FPR_OK;
 }

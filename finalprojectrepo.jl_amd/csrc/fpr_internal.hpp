@@ -14,6 +14,7 @@
 
 constexpr int FPR_WAVE = 64;            // gfx950 wavefront
 constexpr int FPR_MAX_PARTIALS = 1 << 19;  // per-slot block partials (doubles)
+constexpr int FPR_CORE_PARTIALS = 1 << 14; // per list of a core launch between ranks (fpr_diffusion3d_step2_halo)
 
 // device-side solver state shared by the coarse Jacobi / CG kernels (one per context)
 struct FprSolveState {
@@ -79,6 +80,8 @@ struct fpr_ctx {
     hipStream_t masked[2] = {nullptr, nullptr};   // library-owned CU-masked streams (comm, core)
     int comm_cus = 0;
     bool pair_pending = false;         // a fused pair of fpr_diffusion3d_step2_halo left on the core / comm streams (join = 0)
+    double* core_partials = nullptr;   // 2 pairs x 2 lists x FPR_CORE_PARTIALS: the core launch's partials, finished on the comm stream
+    int pair_parity = 0;
     int cgp_resident = -1;             // k_cg_persistent: 16 workgroups of 1024 threads resident together? (-1 = not asked yet)
     double* partials = nullptr;     // FPR_MAX_PARTIALS doubles: block partial sums (slot 0)
     double* partials2 = nullptr;    // second slot (comm stream / second reduction of a kernel)
@@ -289,5 +292,7 @@ int fprx_finish_sum(fpr_ctx* ctx, const double* partials, int nparts, double* ou
 int fprx_cycle_init(fpr_ctx* ctx, const double* f, size_t n, double tol);
 int fprx_cycle_finish(fpr_ctx* ctx, const double* partials, int nparts, double* sumsq_out_dev, double npoints, int slot);
 int fprx_cycle_wait(fpr_ctx* ctx, int slot, int seq, FprCycleCtl* out);
+int fprx_finish_sum2_plus(fpr_ctx* ctx, const double* p0, const double* p1, int nparts, const double* add2_dev, double* out2_dev,
+                          int stream_sel);   // out[b] = sum(list b) + add[b]
 int fprx_finish_sum2(fpr_ctx* ctx, const double* p0, const double* p1, int nparts, double* out2_dev, bool accumulate,
                      int stream_sel);

@@ -235,6 +235,40 @@ def test_pairs_chained_on_core_and_comm_streams(fpr, oracle, periodic_grid, peri
         assert np.array_equal(F.tonumpy(gA)[inner], A[inner]) and np.array_equal(F.tonumpy(gR)[inner], R[inner])
 
 
+def test_one_call_pair_without_sums_and_after_an_error(fpr, periodic_grid):
+    """fpr_diffusion3d_step2_halo with sumsq2_dev = NULL (no norm is computed anywhere in the choreography) and joined at once gives the
+    fields of the call that computes the sums; a call the library refuses (arrays of another size than fpr_grid_init's) raises, leaves
+    no pair pending, and the next valid calls give the same result again."""
+    F = fpr
+    n, periods = (128, 24, 20), (1, 0, 1)
+    gg = periodic_grid(n, periods)
+    dx = 10.0 / 126
+    coef = (dx * dx / 8.1, 5.0, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx)
+    Ht = wrap(rnd(n, 77), dims=(0, 2))
+
+    def pairs(with_sums, join):
+        gHt, gA, gB, gR = F.asdevice(Ht), F.asdevice(Ht), F.fzeros(*n), F.fzeros(*n)
+        gC = gA.clone()
+        sq = F.fzeros(2) if with_sums else None
+        for _ in range(3):
+            gg.step2(gHt, gA, gB, gC, gR, *coef, 0.2, sq, join=join)
+            gA, gC = gC, gA
+        gg.join()
+        return F.tonumpy(gA), F.tonumpy(gR), (sq.cpu().tolist() if with_sums else None)
+
+    a_f, a_r, a_s = pairs(True, False)
+    b_f, b_r, _ = pairs(False, True)
+    assert np.array_equal(a_f, b_f) and np.array_equal(a_r, b_r) and all(v > 0 for v in a_s)
+    m = (64, 24, 20)
+    small = [F.fzeros(*m) for _ in range(5)]
+    gg_pending_before = gg.pending
+    with pytest.raises(F.FprError):
+        F.ctx().call("fpr_diffusion3d_step2_halo", *[F._lib.fptr(x, 3) for x in small], *m, *coef, 0.2, None, 0)
+    assert not gg_pending_before and not gg.pending
+    c_f, c_r, c_s = pairs(True, False)
+    assert np.array_equal(a_f, c_f) and np.array_equal(a_r, c_r) and a_s == c_s
+
+
 @pytest.mark.parametrize("periods", [(0, 0, 1), (1, 1, 1)], ids=["z", "xyz"])
 def test_config4_512cubed_over_rccl_self_neighbour(fpr, oracle, periodic_grid, periods):
     """BASELINE config 4's per-GPU workload (512^3 local array with neighbours) through the library's RCCL transport on

@@ -266,6 +266,10 @@ class Context:
             if not follower._closed:
                 follower.set_option(key, follower_value(key, value))
 
+    def get_option(self, key):
+        """fpr_get_option: a switch set by set_option, or a diagnostic the library recorded (e.g. diff3_last_bal, comm_units_found)."""
+        return int(self.L.fpr_get_option(self.h, key.encode()))
+
     def synchronize(self):
         self.call("fpr_synchronize")
 

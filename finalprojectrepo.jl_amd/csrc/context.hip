@@ -61,6 +61,8 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->partials2) hipFree(ctx->partials2);
     if (ctx->core_partials) hipFree(ctx->core_partials);
+    if (ctx->tickets) hipFree(ctx->tickets);
+    if (ctx->reserved_map) hipFree(ctx->reserved_map);
     if (ctx->scalars) hipFree(ctx->scalars);
     if (ctx->state) hipFree(ctx->state);
     if (ctx->state_h) hipHostFree(ctx->state_h);
@@ -92,20 +94,29 @@ extern "C" int fpr_synchronize(fpr_ctx* ctx)
 // of a 128-workgroup guest kernel started only when the launch ended; with masks every workgroup started at once).
 // The low k mask bits go to the comm stream: on gfx950 bit b is unit (b / 8 / 4) of shader engine (b / 8) % 4 of XCD b % 8,
 // so they spread over the XCDs first, then over the engines.  k = 0: back to the caller's streams (stream 2 = stream 0).
+// marks the compute unit every workgroup runs on (key of fpr_cu_key) and stays for a few microseconds, so that a launch of many
+// workgroups visits every unit of its stream's mask
+__global__ __launch_bounds__(64) void k_cu_probe(unsigned* __restrict__ map)
+{
+    if (threadIdx.x == 0) {
+        const unsigned key = fpr_cu_key();
+        atomicOr(map + (key >> 5), 1u << (key & 31));
+        for (int i = 0; i < 40; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+}
+
 extern "C" int fpr_reserve_comm_cus(fpr_ctx* ctx, int k)
 {
     if (!ctx) return FPR_ERR_INVALID;
-    if (k == ctx->comm_cus) return FPR_OK;
+    if (k == ctx->comm_cus || (k > 0 && k == ctx->comm_cus_asked)) return FPR_OK;
     FPR_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->ncu <= 0) {
         int v = 0;
         ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
     }
     FPR_REQUIRE(ctx, k >= 0 && k <= ctx->ncu / 2, "0 <= k <= half the compute units");
-    // the same number of units out of every shader engine (32 engines of 8 units on MI355X): a workgroup is dealt to an engine
-    // and waits THERE for room, so a lopsided split leaves one unit with two workgroups of a launch that has one per unit
-    FPR_REQUIRE(ctx, k % 32 == 0 || ctx->ncu != 256, "k must be a multiple of 32 (units per shader engine stay equal)");
-    if (ctx->comm_cus > 0) {   // drop the masked streams
+    FPR_REQUIRE(ctx, k % 8 == 0 || ctx->ncu != 256, "k must be a multiple of 8 (the same number of units out of every XCD)");
+    if (ctx->comm_cus > 0) {   // drop the library's streams
         for (int s = 0; s < 3; ++s) FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[s]));
         ctx->stream[1] = ctx->caller_comm;
         ctx->stream[2] = ctx->stream[0];
@@ -113,15 +124,59 @@ extern "C" int fpr_reserve_comm_cus(fpr_ctx* ctx, int k)
             if (ctx->masked[m]) hipStreamDestroy(ctx->masked[m]);
             ctx->masked[m] = nullptr;
         }
-        ctx->comm_cus = 0;
+        ctx->comm_cus = ctx->comm_cus_asked = 0;
+        ctx->core_unmasked = false;
     }
     if (k == 0) return FPR_OK;
-    const int words = (ctx->ncu + 31) / 32;
-    std::vector<uint32_t> mc(words, 0u), mr(words, 0u);
-    for (int b = 0; b < ctx->ncu; ++b) (b < k ? mc : mr)[b / 32] |= 1u << (b % 32);
     FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));
-    FPR_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->masked[0], (uint32_t)words, mc.data()));
-    FPR_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->masked[1], (uint32_t)words, mr.data()));
+    // Two forms of the split.  A workgroup is dealt to a shader engine and waits THERE for room, so a core stream whose mask takes
+    // different numbers of units out of the engines (32 engines of 8 units on MI355X) leaves working units without a workgroup
+    // of a launch that has one per unit while workgroups wait elsewhere (profiles/r3_cu_share_probe.txt).
+    //  (a) k a multiple of 32: the comm stream gets the low k mask bits (bit b = unit b / 32 of engine (b / 8) % 4 of XCD b % 8:
+    //      one unit of every engine per 32), the core stream all the others.
+    //  (b) any other multiple of 8 (16 for a rank with z-faces only): the comm stream as in (a), the core stream EVERY unit; a
+    //      probe launch on the comm stream records which units that stream really has (key XCC_ID | HW_ID[15:8]), and the
+    //      workgroups of a core launch that find themselves on one of them leave at once (Diff3Args2::reserved).  If the probe
+    //      does not find exactly k units, k is rounded up to the next multiple of 32 and form (a) is used.
+    const int words = (ctx->ncu + 31) / 32;
+    const int asked = k;
+    const long force = fpr_opt(ctx, "core_unmasked", -1);    // experiments: 0 = never (b), 1 = (b) for every k
+    bool unmasked = force == 1 || (force != 0 && k % 32 != 0);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        std::vector<uint32_t> mc(words, 0u), mr(words, 0u);
+        for (int b = 0; b < ctx->ncu; ++b) (b < k ? mc : mr)[b / 32] |= 1u << (b % 32);
+        FPR_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->masked[0], (uint32_t)words, mc.data()));
+        if (unmasked) {
+            if (!ctx->reserved_map) FPR_HIP(ctx, hipMalloc(&ctx->reserved_map, 64 * sizeof(unsigned)));
+            unsigned host[64];
+            int found = 0;
+            for (int probe = 0; probe < 3 && found != k; ++probe) {
+                FPR_HIP(ctx, hipMemsetAsync(ctx->reserved_map, 0, sizeof(host), ctx->masked[0]));
+                k_cu_probe<<<64 * k, 64, 0, ctx->masked[0]>>>(ctx->reserved_map);
+                FPR_HIP(ctx, hipMemcpyAsync(host, ctx->reserved_map, sizeof(host), hipMemcpyDeviceToHost, ctx->masked[0]));
+                FPR_HIP(ctx, hipStreamSynchronize(ctx->masked[0]));
+                found = 0;
+                for (unsigned w : host) found += __builtin_popcount(w);
+            }
+            ctx->options["comm_units_found"] = found;
+            if (found == k) {
+                FPR_HIP(ctx, hipStreamCreateWithFlags(&ctx->masked[1], hipStreamNonBlocking));
+                ctx->core_unmasked = true;
+                break;
+            }
+            hipStreamDestroy(ctx->masked[0]);      // form (a) with the next multiple of 32
+            ctx->masked[0] = nullptr;
+            unmasked = false;
+            k = (k + 31) / 32 * 32;
+            if (k > ctx->ncu / 2) return fpr_fail(ctx, FPR_ERR_INVALID, "the comm stream's units could not be identified and k cannot be rounded up");
+            continue;
+        }
+        FPR_REQUIRE(ctx, k % 32 == 0 || ctx->ncu != 256, "k must be a multiple of 32 for a masked core stream");
+        FPR_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->masked[1], (uint32_t)words, mr.data()));
+        ctx->core_unmasked = false;
+        break;
+    }
+    ctx->comm_cus_asked = asked;
     ctx->caller_comm = ctx->stream[1];
     ctx->stream[1] = ctx->masked[0];
     ctx->stream[2] = ctx->masked[1];

@@ -175,9 +175,17 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
             long bal_info = 0;
             // a launch on the comm stream of a split device has that stream's compute units only: chunk it for them
             const int ncu_plan = (stream_sel == 1 && ctx->comm_cus > 0) ? ctx->comm_cus : ctx->ncu;
+            // the reserved form of a core launch takes tickets: one workgroup per device slot, the ones the split leaves no slot for find no work
+            const bool tickets = reserve_cus != 0 && stream_sel != 1 && fpr_opt(ctx, "diff3_tickets", 1) != 0;   // (one ticketed launch at a time: the core / compute stream's)
+            if (tickets && !ctx->tickets) {
+                FPR_HIP(ctx, hipMalloc(&ctx->tickets, 16 * sizeof(int)));
+                FPR_HIP(ctx, hipMemsetAsync(ctx->tickets, 0, 16 * sizeof(int), ctx->stream[stream_sel]));
+            }
             e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), (int)fpr_opt(ctx, "diff3_xcd2", 0) & 3,
                               ctx->stream[stream_sel], pcap, &nparts,
-                              (int)fpr_opt(ctx, "diff3_nw2", 0), ncu_plan, zlo2, zhi2, reserve_cus, &bal_info);
+                              (int)fpr_opt(ctx, "diff3_nw2", 0), ncu_plan, zlo2, zhi2, reserve_cus, &bal_info,
+                              tickets ? ctx->tickets : nullptr,
+                              (tickets && ctx->core_unmasked && stream_sel == 2) ? ctx->reserved_map : nullptr);
             if (reserve_cus != 0) ctx->options["diff3_last_bal"] = bal_info;   // diagnostic (fpr_get_option): which form ran
         }
         fpr_ktimer_end(ctx, timed, ctx->stream[stream_sel]);
@@ -496,7 +504,9 @@ static int diff3_comm_units(const FprGrid& g)
     const int w[3] = {5, 2, 1};   // an x-slab costs about five z-slabs (lanes along y, one cache line per access), a y-slab two
     for (int f = 0; f < 6; ++f)
         if (g.nb[f] >= 0) work += w[f >> 1];
-    return work > 10 ? 64 : 32;   // multiples of 32: the same number of units out of every shader engine (fpr_reserve_comm_cus)
+    // z-faces alone: 16 units carry the chain (two thin single steps, the fused shell launch, two RCCL kernels) in about half a
+    // core launch; the core launch takes tickets, so the split need not be the same in every shader engine (fpr_reserve_comm_cus)
+    return work > 10 ? 64 : (work > 2 ? 32 : 16);
 }
 
 extern "C" int fpr_diffusion3d_join(fpr_ctx* ctx)
@@ -539,7 +549,8 @@ extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const 
             else { blo[nbx][d] = hi[d] - 1; hi[d] -= 1; }
             bdim[nbx++] = d;
         }
-    const int k = diff3_comm_units(g);
+    const long k_opt = fpr_opt(ctx, "diff3_comm_units", 0);   // experiments: 8, 16, 32, 64
+    const int k = k_opt > 0 ? (int)k_opt : diff3_comm_units(g);
     if (int rc = fpr_reserve_comm_cus(ctx, k)) return rc;
     double* sqs = ctx->scalars + 46;   // the shell chain's two sums (comm stream)
     // an error half way leaves launches on the core / comm streams: the compute stream is ordered behind both before the call

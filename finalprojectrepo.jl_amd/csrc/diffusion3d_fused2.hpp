@@ -39,6 +39,26 @@
 #define DIFF3_STORE_NOP 1
 #endif
 
+// Every workgroup of a ticketed launch passes here once, behind its other counter updates; the last one leaves the counters at zero
+// for the next launch.
+__device__ __forceinline__ void diff3_ticket_leave(int* ticket, int nwg)
+{
+    if (atomicAdd(ticket + 8, 1) == nwg - 1)
+        for (int i = 0; i < 11; ++i) __hip_atomic_store(ticket + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#ifndef FPR_CU_KEY_DEFINED
+#define FPR_CU_KEY_DEFINED
+// key of the compute unit the calling wave runs on: XCC_ID (3 bits) | HW_ID[15:8] = SE_ID, SH_ID, CU_ID
+__device__ __forceinline__ unsigned fpr_cu_key()
+{
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return ((xcc & 7u) << 8) | ((hw >> 8) & 0xffu);
+}
+#endif
+
 struct Diff3Args2 {
     const double* __restrict__ Ht;
     const double* __restrict__ A;   // L0 (Htau)
@@ -61,6 +81,18 @@ struct Diff3Args2 {
     // unit g like the plain grid (same tiles marching in lockstep, same block -> XCD mapping), then a slice of bal_q planes
     // of one of the bal_r left-over units: unit G + g / bal_sp, slice g % bal_sp.
     int bal_r, bal_sp, bal_q;
+    // Tickets (reserved form on a device whose compute units are split between streams, fpr_reserve_comm_cus): the launch has one
+    // workgroup per device slot, MORE than its bal_g units; a workgroup takes a ticket from the counter of the XCD it runs on
+    // (then, if that XCD's share of the units is taken, from the others') and the ones that find none leave at once.
+    // Whichever slots the stream's CU mask takes away -- the dispatcher deals a workgroup to a shader engine and lets it wait
+    // THERE -- the workgroups that cannot be placed are then the ones without work, so the mask needs no symmetry (8 or 16
+    // units instead of 32), and every unit is served whatever the placement.  The last workgroup to leave zeroes the counters.
+    int* ticket;                    // 8 unit counters + 1 exit counter, all zero between launches; nullptr: unit = blockIdx.x, bal_g = gridDim.x
+    int bal_g;                      // units served by the launch's workgroups (G)
+    // On a device split by fpr_reserve_comm_cus the core stream has EVERY unit and the launch one workgroup per unit: the ones that
+    // land on a unit of the comm stream (bit fpr_cu_key() of this map, found by a probe launch) leave at once and keep it free.
+    // Placement then cannot leave a working unit without a workgroup, whatever share the comm stream has (8, 16, ... units).
+    const unsigned* reserved;
     const int* skip;                // fpr_diffusion3d_solve with pairs enqueued ahead of its exit test: return at once if *skip (nullptr = unconditional)
 #ifdef FPR_TUNE
     int dbg;                        // tuning harness only (tools/, -DFPR_TUNE): 1 = drop all stores, 2 = drop all loads of the z-loop
@@ -193,19 +225,59 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_diff3_march2(Diff3
     const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
     double tot1 = 0.0, tot2 = 0.0;   // per-lane sums over the owned cells of all chunks of this workgroup (NORM)
 
+    // unit of this workgroup and number of units the launch's workgroups serve
+    int unit = blockIdx.x, nunits = gridDim.x;
+    if (BAL && a.ticket) {
+        // counters: [0, 8) units taken per XCD group, [8] workgroups that are through, [9] units taken, [10] workgroups that have
+        // started and -- unless they sit on a unit of the comm stream -- made their claim
+        __shared__ int tk;
+        nunits = a.bal_g;
+        if (tid == 0) {
+            const int q = nunits >> 3, rem = nunits & 7;
+            const unsigned key = fpr_cu_key(), xcc = key >> 8;
+            const bool comm_unit = a.reserved && ((a.reserved[key >> 5] >> (key & 31)) & 1u);
+            auto ld = [&](int i) { return __hip_atomic_load(a.ticket + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            if (comm_unit) {
+                // A workgroup on a unit of the comm stream leaves as soon as every unit of work has an owner (a few microseconds
+                // into the launch).  It takes one itself only if every workgroup has started and claimed and work is still left
+                // (the dispatcher placed two workgroups on one unit one after the other), or after ~50 us without either.
+                atomicAdd(a.ticket + 10, 1);
+                for (int spin = 0; spin < 48; ++spin) {
+                    if (ld(9) >= nunits || ld(10) >= (int)gridDim.x) break;
+                    __builtin_amdgcn_s_sleep(32);
+                }
+            }
+            int u = -1;
+            if (!comm_unit || ld(9) < nunits)
+                for (int t = 0; t < 8 && u < 0; ++t) {      // own XCD first: its units are x/y neighbours marching in lockstep on one L2
+                    const int g = (int)((xcc + t) & 7), share = q + (g < rem ? 1 : 0);
+                    if ((t > 0 || comm_unit) && ld(g) >= share) continue;   // (the own group's counter is not asked first: one round trip)
+                    const int k = atomicAdd(a.ticket + g, 1);
+                    if (k < share) u = g + 8 * k;           // the position blockIdx has in a grid of nunits workgroups
+                }
+            // (results not used: the wave does not wait for these two)
+            if (u >= 0) __hip_atomic_fetch_add(a.ticket + 9, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!comm_unit) __hip_atomic_fetch_add(a.ticket + 10, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (u < 0) diff3_ticket_leave(a.ticket, (int)gridDim.x);   // (a workgroup with work does this at its end)
+            tk = u;
+        }
+        __syncthreads();
+        unit = __builtin_amdgcn_readfirstlane(tk);          // (block-uniform: keep it scalar)
+        if (unit < 0) return;                               // no work left for this workgroup
+    }
     constexpr int NITEM = BAL ? 2 : 1;
 #pragma unroll 1
     for (int item = 0; item < NITEM; ++item) {
     int tx, by, k0, k1;
     int slice = -1;
-    int bid = blockIdx.x;
+    int bid = unit;
     if (BAL && item == 1) {
         const int j = bid / a.bal_sp;
         if (j >= a.bal_r) break;                           // block-uniform: no left-over slice for this workgroup
         slice = bid - j * a.bal_sp;
-        bid = gridDim.x + j;
+        bid = nunits + j;
     } else if (a.xcd_remap == 1) {
-        const int nblk = gridDim.x;
+        const int nblk = nunits;
         const int q = nblk >> 3, rem = nblk & 7;
         const int xcd = bid & 7, slot = bid >> 3;
         bid = xcd * q + (xcd < rem ? xcd : rem) + slot;
@@ -516,13 +588,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_diff3_march2(Diff3
     }
     }   // item
 
+    if (BAL && a.ticket && tid == 0) diff3_ticket_leave(a.ticket, (int)gridDim.x);
     if constexpr (NORM) {
         const double sc2 = a.scale * a.scale;
         const double l1 = tot1 * sc2;
         const double l2 = tot2 * sc2;
         const double s1 = diff3_block_sum_waves<NW>(l1, red, tid);
         const double s2 = diff3_block_sum_waves<NW>(l2, red + NW, tid);
-        if (tid == 0) { a.partials1[blockIdx.x] = s1; a.partials2[blockIdx.x] = s2; }
+        if (tid == 0) { a.partials1[unit] = s1; a.partials2[unit] = s2; }
     }
 }
 
@@ -542,8 +615,9 @@ static inline bool diff3_can_fuse2(const double* Ht, const double* A, const doub
 // the device in one round -- the balanced form of the kernel (BAL) then serves the box with slots - reserve workgroups.
 static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int xcd_opt, hipStream_t stream,
                                        int max_partials, int* nparts, int nw_opt = 0, int ncu = 256, int zb_lo = 0,
-                                       int zb_hi = 0, int reserve_cus = 0, long* bal_info = nullptr)
-{   // *bal_info (diagnostic): 0 = the plain grid was launched, else left-over units * 1000000 + slices per unit * 1000 + planes per slice
+                                       int zb_hi = 0, int reserve_cus = 0, long* bal_info = nullptr, int* ticket = nullptr,
+                                       const unsigned* reserved = nullptr)
+{   // ticket (9 zeroed ints): the reserved form as ONE workgroup per device slot that take tickets (Diff3Args2::ticket)   // *bal_info (diagnostic): 0 = the plain grid was launched, else left-over units * 1000000 + slices per unit * 1000 + planes per slice
     const int wx = a.hi[0] - a.lo[0], wy = a.hi[1] - a.lo[1], wz = a.hi[2] - a.lo[2];
     const int wzb = zb_hi > zb_lo ? zb_hi - zb_lo : 0;   // second z-range (same x/y box), may be empty
     *nparts = 0;
@@ -624,6 +698,8 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
     a.xcd_remap = (xcd_opt == 1 && nblk >= 64) ? 1 : ((xcd_opt == 2 && a.ntz % 8 == 0) ? 2 : 0);
     const bool wres = a.dH != nullptr;
     a.bal_r = a.bal_sp = a.bal_q = 0;
+    a.ticket = nullptr; a.bal_g = 0;
+    a.reserved = nullptr;
     if (a.nw == 1) {
         if (wres) {
             if (norm) k_diff3_march2<true, 1, true><<<(int)nblk, 64, 0, stream>>>(a);
@@ -649,21 +725,28 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
             a.bal_sp = (int)(G / r);
             a.bal_q = (zc + a.bal_sp - 1) / a.bal_sp;
             if (a.xcd_remap == 2) a.xcd_remap = 0;
+            a.bal_g = (int)G;
+            long grid = G;
+            if (ticket && G <= slots) {
+                a.ticket = ticket;
+                a.reserved = reserved;
+                grid = slots;
+            }
             if (a.nw == 8) {
                 if (wres) {
-                    if (norm) k_diff3_march2<true, 8, true, true><<<(int)G, 512, 0, stream>>>(a);
-                    else k_diff3_march2<false, 8, true, true><<<(int)G, 512, 0, stream>>>(a);
+                    if (norm) k_diff3_march2<true, 8, true, true><<<(int)grid, 512, 0, stream>>>(a);
+                    else k_diff3_march2<false, 8, true, true><<<(int)grid, 512, 0, stream>>>(a);
                 } else {
-                    if (norm) k_diff3_march2<true, 8, false, true><<<(int)G, 512, 0, stream>>>(a);
-                    else k_diff3_march2<false, 8, false, true><<<(int)G, 512, 0, stream>>>(a);
+                    if (norm) k_diff3_march2<true, 8, false, true><<<(int)grid, 512, 0, stream>>>(a);
+                    else k_diff3_march2<false, 8, false, true><<<(int)grid, 512, 0, stream>>>(a);
                 }
             } else {
                 if (wres) {
-                    if (norm) k_diff3_march2<true, 4, true, true><<<(int)G, 256, 0, stream>>>(a);
-                    else k_diff3_march2<false, 4, true, true><<<(int)G, 256, 0, stream>>>(a);
+                    if (norm) k_diff3_march2<true, 4, true, true><<<(int)grid, 256, 0, stream>>>(a);
+                    else k_diff3_march2<false, 4, true, true><<<(int)grid, 256, 0, stream>>>(a);
                 } else {
-                    if (norm) k_diff3_march2<true, 4, false, true><<<(int)G, 256, 0, stream>>>(a);
-                    else k_diff3_march2<false, 4, false, true><<<(int)G, 256, 0, stream>>>(a);
+                    if (norm) k_diff3_march2<true, 4, false, true><<<(int)grid, 256, 0, stream>>>(a);
+                    else k_diff3_march2<false, 4, false, true><<<(int)grid, 256, 0, stream>>>(a);
                 }
             }
             *nparts = (int)G;

@@ -78,10 +78,14 @@ struct fpr_ctx {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     hipStream_t caller_comm = nullptr;   // the comm stream given at creation, while a masked one stands in for it
     hipStream_t masked[2] = {nullptr, nullptr};   // library-owned CU-masked streams (comm, core)
-    int comm_cus = 0;
+    int comm_cus = 0;                  // units of the comm stream (0: device not split)
+    int comm_cus_asked = 0;            // what fpr_reserve_comm_cus was asked for (it may round up)
     bool pair_pending = false;         // a fused pair of fpr_diffusion3d_step2_halo left on the core / comm streams (join = 0)
     double* core_partials = nullptr;   // 2 pairs x 2 lists x FPR_CORE_PARTIALS: the core launch's partials, finished on the comm stream
     int pair_parity = 0;
+    int* tickets = nullptr;            // 9 counters of the ticketed reserved form (Diff3Args2::ticket), zero between launches
+    unsigned* reserved_map = nullptr;  // 2048 bits, one per (XCC, SE, SH, CU) key: the comm stream's compute units (fpr_reserve_comm_cus), found by a probe launch
+    bool core_unmasked = false;        // the core stream has every unit; workgroups of a core launch that land on a comm unit leave at once
     int cgp_resident = -1;             // k_cg_persistent: 16 workgroups of 1024 threads resident together? (-1 = not asked yet)
     double* partials = nullptr;     // FPR_MAX_PARTIALS doubles: block partial sums (slot 0)
     double* partials2 = nullptr;    // second slot (comm stream / second reduction of a kernel)
@@ -107,6 +111,18 @@ struct fpr_ctx {
     size_t ktimer_used = 0;
     char err[512] = {0};
 };
+
+#ifndef FPR_CU_KEY_DEFINED
+#define FPR_CU_KEY_DEFINED
+// key of the compute unit the calling wave runs on: XCC_ID (3 bits) | HW_ID[15:8] = SE_ID, SH_ID, CU_ID
+__device__ __forceinline__ unsigned fpr_cu_key()
+{
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return ((xcc & 7u) << 8) | ((hw >> 8) & 0xffu);
+}
+#endif
 
 inline int fpr_fail(fpr_ctx* ctx, int code, const char* fmt, ...)
 {

@@ -548,7 +548,8 @@ class GlobalGrid:
         if self._reserve is not None:
             return self._reserve
         work = sum({0: 5, 1: 2, 2: 1}[f >> 1] for f in self.neighbors)
-        return 64 if work > 10 else 32
+        # z-faces alone: 16 (the core launch takes tickets -- Diff3Args2::ticket -- so the split need not be the same in every engine)
+        return 64 if work > 10 else (32 if work > 2 else 16)
 
     def step2_begin(self, Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq2_dev):
         from . import ctx as _ctx

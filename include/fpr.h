@@ -139,7 +139,7 @@ int fpr_diffusion3d_step2_core(fpr_ctx* ctx, const double* Ht, const double* Hta
                                double _dz, double D_dx, double D_dy, double D_dz, const int lo[3], const int hi[3],
                                double scale, double* sumsq2_dev, int stream_sel, int reserve_cus, int accumulate);
 /* _halo: TWO iterations on a rank WITH neighbours (fpr_grid_init), halos of Hout refreshed -- what `@hide_communication` + `update_halo!`
- * (part1_kernel_programming.jl:185-190) do for one iteration, for two: the device is split (fpr_reserve_comm_cus, 32 or 64 units for
+ * (part1_kernel_programming.jl:185-190) do for one iteration, for two: the device is split (fpr_reserve_comm_cus, 16, 32 or 64 units for
  * the comm stream by the rank's faces), the core of the local grid runs as ONE fused launch on the core stream, and beside it on the
  * comm stream run the first iteration on the one-cell shell (level 1 into Hmid), the exchange of Hmid's planes, the fused launches on
  * the shell and the exchange of Hout's planes (the x-slabs' first iteration runs on the core stream ahead of the core launch).  Same
@@ -228,6 +228,9 @@ int fpr_stream_wait(fpr_ctx* ctx, int waiter, int signaller);
  * (core) one whose kernels run on all the others; before it, and after k = 0, stream 1 is the caller's comm stream and
  * stream 2 is stream 0.  A second queue's workgroups wait for room in the shader engine they were dealt to even when
  * other engines have idle units, so leaving units idle is not enough: the masks make the split explicit.
+ * k: a multiple of 8.  For a multiple of 32 the core stream is masked to the other units.  Otherwise (16 for a rank with z-faces
+ * only) the core stream keeps every unit and the one-workgroup-per-unit core launch of a fused pair lets the workgroups that land
+ * on a comm unit leave at once (the comm stream's units are found by a probe launch; if that fails k is rounded up to 32).
  * fpr_comm_cus: the current k.  fpr_stream_handle: the hipStream_t behind a selector, for host code that enqueues on it. */
 int fpr_reserve_comm_cus(fpr_ctx* ctx, int k);
 int fpr_comm_cus(fpr_ctx* ctx);

@@ -201,8 +201,8 @@ def test_fused_pair_choreography_emulated_ranks(fpr, oracle, dims, n):
 
 def test_device_split_streams_and_small_ops(fpr):
     """fpr_reserve_comm_cus / fpr_comm_cus / fpr_stream_handle / fpr_fill_on / fpr_add_on: the comm and core streams of a split
-    device are library-owned, ordered against the compute stream by fpr_stream_wait, and a lopsided split is refused (a
-    workgroup is dealt to a shader engine and waits there: tools/cu_share_probe.hip)."""
+    device are library-owned, ordered against the compute stream by fpr_stream_wait, and a split that is not the same share of every XCD is
+    refused (k must be a multiple of 8; within an XCD the core launch of a pair copes with any split: it takes tickets)."""
     import ctypes as C
     import torch
 
@@ -211,12 +211,16 @@ def test_device_split_streams_and_small_ops(fpr):
     c.reserve_comm_cus(0)                    # (earlier tests with fused pairs between ranks leave the device split)
     try:
         with pytest.raises(F.FprError):
-            c.reserve_comm_cus(8)            # not the same number of units out of every shader engine
+            c.reserve_comm_cus(12)           # not the same number of units out of every XCD
         assert c.L.fpr_comm_cus(c.h) == 0
         h0 = [C.c_void_p() for _ in range(3)]
         for s in range(3):
             c.call("fpr_stream_handle", s, C.byref(h0[s]))
         assert h0[2].value == h0[0].value and h0[1].value != h0[0].value      # unsplit: the core stream IS the compute stream
+        c.reserve_comm_cus(16)                   # core stream on every unit; the comm stream's 16 units found by a probe launch
+        assert c.L.fpr_comm_cus(c.h) in (16, 32)  # (32: the probe did not find them, masked core stream instead)
+        if c.L.fpr_comm_cus(c.h) == 16:
+            assert c.get_option("comm_units_found") == 16
         c.reserve_comm_cus(32)
         assert c.L.fpr_comm_cus(c.h) == 32
         h = [C.c_void_p() for _ in range(3)]

@@ -1,3 +1,5 @@
+"""z-slab pair at 512^3 on a periodic self-neighbour for comm shares of 8 / 16 / 32 units (option diff3_comm_units), with and without
+tickets in the core launch (option diff3_tickets), against the plain fused launch."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, fpr_amd
@@ -20,8 +22,10 @@ def t(gg, K=40):
 g0 = F.grid.GlobalGrid(n, n, n, dims=(1, 1, 1), periods=(0, 0, 0), transport="rccl", use_dist=False)
 base = t(g0)
 print("plain %.1f us" % base)
-gz = F.grid.GlobalGrid(n, n, n, dims=(1, 1, 1), periods=(0, 0, 1), transport="rccl", use_dist=False)
-for dbg in (0, 1, 2, 4, 6, 7, 0):
-    F.ctx().set_option("diff3_halo_dbg", dbg)
+per = tuple(int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "001"))
+gz = F.grid.GlobalGrid(n, n, n, dims=(1, 1, 1), periods=per, transport="rccl", use_dist=False)
+for unm, k in ((0, 32), (-1, 16), (1, 32), (-1, 16), (0, 32)):
+    F.ctx().reserve_comm_cus(0)
+    F.ctx().set_option("core_unmasked", unm); F.ctx().set_option("diff3_comm_units", k)
     us = t(gz)
-    print("z dbg=%d: %.1f us (+%.1f %%)" % (dbg, us, 100 * (us / base - 1)), flush=True)
+    print("periods %s core_unmasked=%d units=%d: %.1f us (+%.1f %%)" % (per, unm, k, us, 100 * (us / base - 1)), flush=True)

@@ -202,8 +202,8 @@ def test_bench_self_launcher_dry_run_world2():
 
 
 def test_comm_share_and_box_order_of_fused_pairs():
-    """GlobalGrid.reserve_cus: the comm stream of a fused pair gets a multiple of 32 compute units (the same number out of
-    every shader engine), 64 only above two x-faces' worth of shell work; boundary_boxes peels the x-slabs last (step2 runs
+    """GlobalGrid.reserve_cus: the comm stream of a fused pair gets 16 compute units for z-faces alone, else a multiple of 32 (the
+    same number out of every shader engine), 64 only above two x-faces' worth of shell work; boundary_boxes peels the x-slabs last (step2 runs
     their first iteration on the core stream ahead of the core launch and takes them off the end of the list)."""
     class Fake(grid.GlobalGrid):
         def __init__(self, n, faces):
@@ -211,11 +211,11 @@ def test_comm_share_and_box_order_of_fused_pairs():
             self.neighbors = {f: (0, 0, 0) for f in faces}
 
     n = (64, 48, 40)
-    for faces, want in (((4, 5), 32), ((4,), 32), ((2, 3), 32), ((2, 3, 4, 5), 32), ((1, 3, 5), 32), ((0, 1), 32),
+    for faces, want in (((4, 5), 16), ((4,), 16), ((2, 3), 32), ((2, 3, 4, 5), 32), ((1, 3, 5), 32), ((0, 1), 32),
                         ((0, 1, 2, 3), 64), ((0, 1, 2, 3, 4, 5), 64), ((0, 1, 4), 64)):
         g = Fake(n, faces)
         k = g.reserve_cus()
-        assert k == want and k % 32 == 0, (faces, k)
+        assert k == want and k % 8 == 0, (faces, k)
         boxes, core = g.boundary_boxes()
         nxf = sum(1 for f in (0, 1) if f in faces)
         assert len(boxes) == len(faces)

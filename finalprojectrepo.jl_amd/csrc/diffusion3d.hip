@@ -509,14 +509,26 @@ static int diff3_comm_units(const FprGrid& g)
     return work > 10 ? 64 : (work > 2 ? 32 : 16);
 }
 
-extern "C" int fpr_diffusion3d_join(fpr_ctx* ctx)
+static int diff3_join(fpr_ctx* ctx, bool async)
 {
     if (!ctx) return FPR_ERR_INVALID;
     if (!ctx->pair_pending) return FPR_OK;
     ctx->pair_pending = false;
-    if (int rc = fpr_stream_wait(ctx, 0, 2)) return rc;   // the core launch (which has taken in the shell chain's exchanges)
-    return fpr_stream_wait(ctx, 0, 1);                    // the pair's sums, finished on the comm stream
+    if (async || fpr_opt(ctx, "diff3_join_async", 0)) {
+        if (int rc = fpr_stream_wait(ctx, 0, 2)) return rc;   // the core launch (which has taken in the shell chain's exchanges)
+        return fpr_stream_wait(ctx, 0, 1);                    // the pair's sums, finished on the comm stream
+    }
+    // The host waits for the two streams; the compute stream then needs no wait at all.  A wait parked on the compute stream while
+    // pairs are still in flight is a third busy queue with a blocked barrier packet: every stream wait INSIDE the pairs then takes
+    // longer, and a rank whose shell chain is nearly as long as its core launch (x-faces) ran its pairs 30 % slower for as long as
+    // the wait was pending (tools/attic/dbg3.py: 942 -> 1207-1279 us per pair at 512^3, corner rank of (2,2,2)).  Callers of a join
+    // read the sums or exchange halos next, i.e. wait for the pairs anyway.
+    FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[2]));
+    FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));
+    return FPR_OK;
 }
+
+extern "C" int fpr_diffusion3d_join(fpr_ctx* ctx) { return diff3_join(ctx, false); }
 
 extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Hmid, double* Hout,
                                           double* dHdtau, int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy,
@@ -613,7 +625,7 @@ extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const 
     }
     rejoin.armed = false;
     ctx->pair_pending = true;
-    return join ? fpr_diffusion3d_join(ctx) : FPR_OK;
+    return join ? diff3_join(ctx, true) : FPR_OK;   // join = 1: the compute stream is ordered behind this pair (stream waits; the host goes on)
 }
 
 extern "C" int fpr_diffusion3d_step_box(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2,

@@ -516,7 +516,9 @@ class GlobalGrid:
         if self._pending:
             from . import ctx as _ctx
 
-            _ctx().call("fpr_stream_wait", 0, 2)    # the core stream already waited for the pair's shell chain
+            # the host waits (a wait parked on the compute stream while pairs are in flight slows the stream waits inside them:
+            # fpr_diffusion3d_join); the core stream already waited for the pair's shell chain
+            _ctx().synchronize()
             self._pending = False
 
     # Choreography of two fused iterations between ranks, any Cartesian decomposition (level 1 = the field after the

@@ -145,8 +145,9 @@ int fpr_diffusion3d_step2_core(fpr_ctx* ctx, const double* Ht, const double* Hta
  * the shell and the exchange of Hout's planes (the x-slabs' first iteration runs on the core stream ahead of the core launch).  Same
  * results as two fpr_diffusion3d_step calls each followed by fpr_halo_exchange3d of the written buffer; Hout must carry Htau's
  * physical-boundary values; sumsq2_dev (nullable) receives the LOCAL sums of both iterations.  join = 0 leaves the pair on the core /
- * comm streams: the next _halo call continues from there; fpr_diffusion3d_join orders the compute stream behind it (call it before
- * anything else reads the fields or the sums).  Without neighbours: fpr_diffusion3d_step2. */
+ * comm streams: the next _halo call continues from there; fpr_diffusion3d_join waits for it (the HOST waits for the core and comm
+ * streams: a wait parked on the compute stream while pairs are in flight slows them; option diff3_join_async = 1 for stream waits
+ * instead); call it before anything else reads the fields or the sums.  Without neighbours: fpr_diffusion3d_step2. */
 int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Hmid, double* Hout, double* dHdtau,
                                int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx,
                                double D_dy, double D_dz, double scale, double* sumsq2_dev, int join);

@@ -504,9 +504,12 @@ static int diff3_comm_units(const FprGrid& g)
     const int w[3] = {5, 2, 1};   // an x-slab costs about five z-slabs (lanes along y, one cache line per access), a y-slab two
     for (int f = 0; f < 6; ++f)
         if (g.nb[f] >= 0) work += w[f >> 1];
-    // z-faces alone: 16 units carry the chain (two thin single steps, the fused shell launch, two RCCL kernels) in about half a
-    // core launch; the core launch takes tickets, so the split need not be the same in every shader engine (fpr_reserve_comm_cus)
-    return work > 10 ? 64 : (work > 2 ? 32 : 16);
+    // Measured at 512^3 (tools/attic/dbg_faces2.py, two faces per dimension): z 16 units +7 %, 32 +9-11 %; y 16 +9.1 %, 24 +10.9 %,
+    // 32 +12.2 %; yz 24 +12 %, 16 +12.6 %, 32 +14.2 %; with x-faces the chain is nearly as long as the core launch and 32 (64 above
+    // two x-faces' worth of work) stays the best.  Shares that are no multiple of 32 use the unmasked core stream (fpr_reserve_comm_cus).
+    bool anyx = g.nb[0] >= 0 || g.nb[1] >= 0;
+    if (!anyx) return work > 4 ? 24 : 16;
+    return work > 10 ? 64 : 32;
 }
 
 static int diff3_join(fpr_ctx* ctx, bool async)

@@ -550,8 +550,11 @@ class GlobalGrid:
         if self._reserve is not None:
             return self._reserve
         work = sum({0: 5, 1: 2, 2: 1}[f >> 1] for f in self.neighbors)
-        # z-faces alone: 16 (the core launch takes tickets -- Diff3Args2::ticket -- so the split need not be the same in every engine)
-        return 64 if work > 10 else (32 if work > 2 else 16)
+        # no x-faces: 16 (24 for y- and z-faces together) -- shares that are no multiple of 32 use the unmasked core stream, whose core
+        # launch lets the workgroups on comm units leave (fpr_reserve_comm_cus); same rule as diff3_comm_units in the library
+        if not any(f < 2 for f in self.neighbors):
+            return 24 if work > 4 else 16
+        return 64 if work > 10 else 32
 
     def step2_begin(self, Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq2_dev):
         from . import ctx as _ctx

@@ -202,7 +202,7 @@ def test_bench_self_launcher_dry_run_world2():
 
 
 def test_comm_share_and_box_order_of_fused_pairs():
-    """GlobalGrid.reserve_cus: the comm stream of a fused pair gets 16 compute units for z-faces alone, else a multiple of 32 (the
+    """GlobalGrid.reserve_cus: the comm stream of a fused pair gets 16 or 24 compute units without x-faces, else a multiple of 32 (the
     same number out of every shader engine), 64 only above two x-faces' worth of shell work; boundary_boxes peels the x-slabs last (step2 runs
     their first iteration on the core stream ahead of the core launch and takes them off the end of the list)."""
     class Fake(grid.GlobalGrid):
@@ -211,7 +211,7 @@ def test_comm_share_and_box_order_of_fused_pairs():
             self.neighbors = {f: (0, 0, 0) for f in faces}
 
     n = (64, 48, 40)
-    for faces, want in (((4, 5), 16), ((4,), 16), ((2, 3), 32), ((2, 3, 4, 5), 32), ((1, 3, 5), 32), ((0, 1), 32),
+    for faces, want in (((4, 5), 16), ((4,), 16), ((2, 3), 16), ((2, 3, 4, 5), 24), ((1, 3, 5), 32), ((0, 1), 32),
                         ((0, 1, 2, 3), 64), ((0, 1, 2, 3, 4, 5), 64), ((0, 1, 4), 64)):
         g = Fake(n, faces)
         k = g.reserve_cus()

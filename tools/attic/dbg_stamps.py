@@ -1,3 +1,5 @@
+"""Per-workgroup start / end stamps of the ticketed core launch (EXPERIMENTS 10.1-12).  Needs the temporary hook Diff3Args2::stamps
+(option diff3_dbg_stamps) that existed while the split forms were compared; kept for the record of how the placement was read."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, fpr_amd, numpy as np

@@ -14,7 +14,7 @@
 
 constexpr int FPR_WAVE = 64;            // gfx950 wavefront
 constexpr int FPR_MAX_PARTIALS = 1 << 19;  // per-slot block partials (doubles)
-constexpr int FPR_CORE_PARTIALS = 1 << 14; // per list of a core launch between ranks (fpr_diffusion3d_step2_halo)
+constexpr int FPR_CORE_PARTIALS = 1 << 16; // per list of a core launch between ranks (fpr_diffusion3d_step2_halo)
 
 // device-side solver state shared by the coarse Jacobi / CG kernels (one per context)
 struct FprSolveState {

@@ -421,6 +421,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the V-cycle / NS blocks")
     ap.add_argument("--no-single-leg", action="store_true", help="skip the one-iteration-per-launch leg")
     ap.add_argument("--variant", type=str, default="", help="k=v,... diffusion kernel options (diff3_*)")
+    ap.add_argument("--no-neighbour-leg", action="store_true", help="skip the leg that runs the pair as an interior z-slab rank (self-neighbour over RCCL)")
     ap.add_argument("--no-fuse2", action="store_true", help="main leg with one iteration per launch (k_diff3_march)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / control-plane rehearsal on CPU (gloo): no GPU, no compute, one JSON line")
@@ -726,6 +727,8 @@ def main():
         # comm stream of the split device).  Links excluded; they are hidden by construction (the chain with both exchanges
         # ends after about a quarter of the core launch).  Not part of `value`.
         try:
+            if args.no_neighbour_leg:
+                raise RuntimeError("skipped (--no-neighbour-leg)")
             gp = F.grid.GlobalGrid(*nloc, dims=(1, 1, 1), periods=(0, 0, 1), transport="rccl", use_dist=False)
             state["cur"] = Hτ
             def pair_z(nsteps):

@@ -6,7 +6,7 @@
 # Raw traces stay in /tmp; summaries land in gpurun_out/<tag>_*.txt (copy them to profiles/).
 # usage: tools/profile_bench.sh <tag> [bench.py args...]
 R=$GRAFT_REPO_ROOT; TAG=${1:-prof}; shift
-ARGS="--no-secondary --no-cpu-baseline --steps 200 --warmup 20 $*"
+ARGS="--no-secondary --no-cpu-baseline --no-neighbour-leg --steps 200 --warmup 20 $*"
 mkdir -p $R/gpurun_out
 # the box all passes of this call run on (kernel statistics and counters come from ONE lease)
 { echo "host $(hostname)"; (rocm-smi --showuniqueid 2>/dev/null | grep -i "unique" | head -2) ; date -u +"utc %Y-%m-%dT%H:%M:%SZ"; } > $R/gpurun_out/${TAG}_box.txt

@@ -147,7 +147,7 @@ extern "C" int fpr_reserve_comm_cus(fpr_ctx* ctx, int k)
         for (int b = 0; b < ctx->ncu; ++b) (b < k ? mc : mr)[b / 32] |= 1u << (b % 32);
         FPR_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->masked[0], (uint32_t)words, mc.data()));
         if (unmasked) {
-            if (!ctx->reserved_map) FPR_HIP(ctx, hipMalloc(&ctx->reserved_map, 64 * sizeof(unsigned)));
+            if (!ctx->reserved_map) FPR_HIP(ctx, hipMalloc(&ctx->reserved_map, 128 * sizeof(unsigned)));   // [64, 128): scratch of the tests
             unsigned host[64];
             int found = 0;
             for (int probe = 0; probe < 3 && found != k; ++probe) {

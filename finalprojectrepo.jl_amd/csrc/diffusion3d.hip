@@ -181,11 +181,18 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
                 FPR_HIP(ctx, hipMalloc(&ctx->tickets, 16 * sizeof(int)));
                 FPR_HIP(ctx, hipMemsetAsync(ctx->tickets, 0, 16 * sizeof(int), ctx->stream[stream_sel]));
             }
+            const unsigned* rmap = (tickets && ctx->core_unmasked && stream_sel == 2) ? ctx->reserved_map : nullptr;
+            if (rmap && fpr_opt(ctx, "diff3_reserved_test", 0)) {
+                // tests: a WRONG map (1: every unit marked as a comm unit, 2: every other key) -- the claim protocol must still serve every
+                // unit of work (workgroups on 'comm units' take work once every workgroup has started), only later
+                FPR_HIP(ctx, hipMemsetAsync(ctx->reserved_map + 64, fpr_opt(ctx, "diff3_reserved_test", 0) == 1 ? 0xFF : 0xAA, 64 * sizeof(unsigned),
+                                            ctx->stream[stream_sel]));
+                rmap = ctx->reserved_map + 64;
+            }
             e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), (int)fpr_opt(ctx, "diff3_xcd2", 0) & 3,
                               ctx->stream[stream_sel], pcap, &nparts,
                               (int)fpr_opt(ctx, "diff3_nw2", 0), ncu_plan, zlo2, zhi2, reserve_cus, &bal_info,
-                              tickets ? ctx->tickets : nullptr,
-                              (tickets && ctx->core_unmasked && stream_sel == 2) ? ctx->reserved_map : nullptr);
+                              tickets ? ctx->tickets : nullptr, rmap);
             if (reserve_cus != 0) ctx->options["diff3_last_bal"] = bal_info;   // diagnostic (fpr_get_option): which form ran
         }
         fpr_ktimer_end(ctx, timed, ctx->stream[stream_sel]);

@@ -235,6 +235,42 @@ def test_pairs_chained_on_core_and_comm_streams(fpr, oracle, periodic_grid, peri
         assert np.array_equal(F.tonumpy(gA)[inner], A[inner]) and np.array_equal(F.tonumpy(gR)[inner], R[inner])
 
 
+def test_core_launch_serves_every_unit_whatever_the_comm_unit_map_says(fpr, periodic_grid):
+    """The core launch of a z-slab rank's pair has one workgroup per compute unit; the ones on a comm unit (a map a probe launch
+    filled) leave, the others claim the (tile, chunk) units by tickets.  With a WRONG map -- every unit marked, or every other key --
+    the workgroups on 'comm units' take the work that is left once every workgroup has started: same fields, residual and norms
+    bit for bit (512 x 512 x 66: 255 (tile, chunk) units for 240 workgroups, the reserved form with left-over slices)."""
+    F = fpr
+    n, periods = (512, 512, 66), (0, 0, 1)
+    gg = periodic_grid(n, periods)
+    dx = 10.0 / 510
+    coef = (dx * dx / 8.1, 5.0, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx)
+    Ht = wrap(rnd(n, 91), dims=(2,))
+    c = F.ctx()
+
+    def pairs():
+        gHt, gA, gB, gR = F.asdevice(Ht), F.asdevice(Ht), F.fzeros(*n), F.fzeros(*n)
+        gC = gA.clone()
+        sq = F.fzeros(6)
+        for p in range(3):
+            gg.step2(gHt, gA, gB, gC, gR, *coef, 0.2, sq[2 * p:2 * p + 2], join=False)
+            gA, gC = gC, gA
+        gg.join()
+        return F.tonumpy(gA), F.tonumpy(gR), sq.cpu().tolist(), c.get_option("diff3_last_bal")
+
+    ref = pairs()
+    if c.L.fpr_comm_cus(c.h) % 32 == 0:
+        pytest.skip("the probe launch did not identify the comm stream's units on this device: masked core stream, no map")
+    assert ref[3] > 0          # the reserved form ran
+    try:
+        for mode in (1, 2):
+            c.set_option("diff3_reserved_test", mode)
+            got = pairs()
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2] and got[3] == ref[3], mode
+    finally:
+        c.set_option("diff3_reserved_test", 0)
+
+
 def test_one_call_pair_without_sums_and_after_an_error(fpr, periodic_grid):
     """fpr_diffusion3d_step2_halo with sumsq2_dev = NULL (no norm is computed anywhere in the choreography) and joined at once gives the
     fields of the call that computes the sums; a call the library refuses (arrays of another size than fpr_grid_init's) raises, leaves

@@ -22,6 +22,9 @@ import argparse
 import json
 import math
 import os
+import re
+import shutil
+import signal
 import socket
 import subprocess
 import sys
@@ -40,18 +43,16 @@ KT_STEP, KT_STEP2, KT_MG_PRE, KT_MG_POST, KT_MG_SEAM, KT_MG_CG, KT_MG_PATCH, KT_
 # ------------------------------------------------------------------------------------------------------------
 def self_launch(n):
     """Start n ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), wait for them and
-    exit with the first non-zero exit code.  Runs before torch or HIP is imported: nothing here touches a GPU."""
+    exit with the first non-zero exit code.  Runs before torch or HIP is imported: nothing here touches a GPU.  Every rank
+    it starts supervises its own worker (supervise() below), exactly as a rank started by torch.distributed.run does."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     procs = []
-    # the control plane of self-launched ranks meets through a file (no window between probing a free port and its use);
-    # MASTER_ADDR / MASTER_PORT are still exported for anything that reads them
-    rdzv = os.path.join(os.environ.get("TMPDIR", "/tmp"), "fpr_bench_rdzv_%d_%d" % (os.getpid(), int(time.time() * 1e6)))
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FPR_BENCH_SELF_LAUNCHED="1", FPR_BENCH_RDZV_FILE=rdzv)
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FPR_BENCH_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between processes)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
@@ -72,10 +73,147 @@ def self_launch(n):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    sys.exit(rc)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# watchdog: between ranks every step is a collective pattern, and a collective that deadlocks waits for ever.  Each rank
+# process (started by torch.distributed.run or by self_launch) therefore does NOT touch a GPU itself: it starts its worker
+# as a child and watches the worker's heartbeat file.  No progress for --watchdog-s seconds, or a worker that dies,
+# fails the ATTEMPT for every rank (a marker file in the directory all ranks of the job share); the supervisors then
+# start FRESH workers once with --choreography plain (single steps: boundary slabs -> exchange || interior, no split
+# of the device, no chained pairs).  A second failure exits non-zero on every rank.
+# ------------------------------------------------------------------------------------------------------------
+HB_PHASES_QUIET = ("start",)       # phases that may be silent for --watchdog-import-s (the first `import torch` on a fresh box pages the image in)
+
+
+def job_dir():
+    """Directory shared by the ranks of ONE job on this node: keyed by the parent process (the torchrun agent or
+    self_launch, the same for every rank) and the rendezvous port."""
+    key = "%s_%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"))
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "fpr_bench_job_" + re.sub(r"[^A-Za-z0-9_.-]", "_", key))
+
+
+def hb(phase, **extra):
+    """Worker side: record progress (phase name + time) for the supervisor.  No-op without a supervisor."""
+    path = os.environ.get("FPR_BENCH_HB_FILE")
+    if not path:
+        return
+    tmp = path + ".tmp"
+    with open(tmp, "w") as f:
+        json.dump(dict(phase=phase, t=time.time(), **extra), f)
+    os.replace(tmp, path)
+
+
+def _read_json(path):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def _kill_tree(p, grace=3.0):
+    """End one worker (exact pid; its own process group so that helpers it started go with it)."""
+    if p.poll() is not None:
+        return
+    try:
+        os.killpg(p.pid, signal.SIGTERM)
+    except OSError:
+        pass
+    t0 = time.time()
+    while p.poll() is None and time.time() - t0 < grace:
+        time.sleep(0.05)
+    if p.poll() is None:
         try:
-            os.remove(rdzv)
+            os.killpg(p.pid, signal.SIGKILL)
         except OSError:
             pass
+        p.wait()
+
+
+def supervise(args):
+    """Rank process of an N > 1 run: start the worker, watch it, fall back once.  Never returns."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    jd = job_dir()
+    os.makedirs(jd, exist_ok=True)
+    first_failure = None
+    rc = 1
+    for attempt in (1, 2):
+        choreo = args.choreography if attempt == 1 else "plain"
+        hbf = os.path.join(jd, "hb_%d_%d.json" % (attempt, rank))
+        fail_marker = os.path.join(jd, "fail_%d" % attempt)
+        env = dict(os.environ, FPR_BENCH_WORKER="1", FPR_BENCH_ATTEMPT=str(attempt), FPR_BENCH_HB_FILE=hbf,
+                   FPR_BENCH_RDZV_FILE=os.path.join(jd, "rdzv_%d" % attempt), FPR_BENCH_CHOREOGRAPHY=choreo)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("NCCL_DEBUG", "WARN")
+        env.setdefault("NCCL_DEBUG_FILE", os.path.join(jd, "rccl_%d_%d.log" % (attempt, rank)))   # read back on failure
+        if first_failure is not None:
+            env["FPR_BENCH_FIRST_FAILURE"] = json.dumps(first_failure)
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True)
+        t_start = time.time()
+        reason, detail = None, None
+        while True:
+            r = p.poll()
+            h = _read_json(hbf) or {"phase": "start", "t": t_start}
+            if r is not None:
+                if r == 0 or h.get("phase") == "done":
+                    rc = 0           # the job's result is out (rank 0 prints after the last collective); teardown noise is not a failure
+                else:
+                    reason = "worker of rank %d exited with code %d in phase %r" % (rank, r, h.get("phase"))
+                    detail = {k: v for k, v in h.items() if k not in ("phase", "t")} or None
+                break
+            if os.path.exists(fail_marker):
+                reason = (_read_json(fail_marker) or {}).get("reason", "another rank failed the attempt")
+                break
+            quiet = time.time() - max(h.get("t", t_start), t_start)
+            limit = args.watchdog_import_s if h.get("phase") in HB_PHASES_QUIET else args.watchdog_s
+            if h.get("phase") == "done":
+                if quiet > 30.0:     # result printed, a rank hangs in teardown: end it
+                    _kill_tree(p)
+                    rc = 0
+                    break
+            elif quiet > limit:
+                reason = "no progress of rank %d for %.0f s in phase %r" % (rank, quiet, h.get("phase"))
+                break
+            time.sleep(0.1)
+        if reason is None:
+            break
+        # the attempt failed: tell every rank (first writer wins), end the worker, collect what RCCL said
+        try:
+            fd = os.open(fail_marker, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+            os.write(fd, json.dumps({"reason": reason, "detail": detail, "rank": rank, "t": time.time()}).encode())
+            os.close(fd)
+        except OSError:
+            fm = _read_json(fail_marker) or {}
+            reason, detail = fm.get("reason", reason), fm.get("detail", detail)
+        _kill_tree(p)
+        log = ""
+        try:
+            with open(os.path.join(jd, "rccl_%d_%d.log" % (attempt, 0))) as f:
+                log = f.read()[-2000:]
+        except OSError:
+            pass
+        phases = {}
+        for r_ in range(world):
+            hh = _read_json(os.path.join(jd, "hb_%d_%d.json" % (attempt, r_)))
+            phases[str(r_)] = hh.get("phase") if hh else None
+        failure = {"attempt": attempt, "choreography": choreo, "reason": reason, "detail": detail, "phase_by_rank": phases,
+                   "rccl_rank0_log_tail": log}
+        print("bench.py watchdog (rank %d): attempt %d (%s) failed: %s" % (rank, attempt, choreo, reason), file=sys.stderr)
+        if attempt == 1:
+            first_failure = failure
+            time.sleep(1.0)          # every supervisor has seen the marker and ended its worker before fresh ones meet
+            continue
+        if rank == 0:
+            print(json.dumps({"metric": "diffusion3d_effective_memory_throughput", "value": None, "unit": "GB/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "error": "both attempts failed",
+                              "attempts": [first_failure, failure]}))
+            sys.stdout.flush()
+        rc = 1
+    if rank == 0:
+        time.sleep(0.5)
+        shutil.rmtree(jd, ignore_errors=True)
     sys.exit(rc)
 
 
@@ -403,6 +541,70 @@ def host_staged_p2p(torch, dist):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# the norm of a decomposed run against the single-domain control (tests/golden/scale_norms.json)
+# ------------------------------------------------------------------------------------------------------------
+NORM_RTOL = 1.0e-12      # fields are bit-identical to the single-domain run; the sums differ by their order only
+GOLDEN_NORMS = os.path.join(ROOT, "tests", "golden", "scale_norms.json")
+
+
+def norm_check(n, dims, iters, got, path=None):
+    """Compare the sum of squares behind the norm after `iters` pseudo-iterations with the one the same GLOBAL problem gave
+    on ONE rank (control runs: bench.py --golden-norms, tools/make_scale_norms.sh).  The reference never asserts a multi-rank
+    result (test/part1.jl:22 runs one rank); this does."""
+    key = "n%d_dims%d,%d,%d" % ((n,) + tuple(dims))
+    g = _read_json(path or GOLDEN_NORMS) or {}
+    ent = (g.get("entries") or {}).get(key)
+    if ent is None or got is None or not (1 <= iters <= len(ent["sumsq"])):
+        return {"ok": None, "key": key, "iterations": iters, "got": got,
+                "note": "no control value for this problem / iteration count in tests/golden/scale_norms.json"}
+    exp = ent["sumsq"][iters - 1]
+    rel = abs(got - exp) / abs(exp)
+    return {"ok": bool(rel <= NORM_RTOL), "key": key, "iterations": iters, "expected": exp, "got": got, "rel": rel, "rtol": NORM_RTOL,
+            "control": "one rank, global grid %s (%s)" % (ent.get("global_grid"), g.get("source"))}
+
+
+def golden_norms(F, torch, args):
+    """Control runs for norm_check: for every process grid in --golden-dims the global problem that grid solves with
+    --n cells per rank, on ONE rank, --golden-iters pseudo-iterations as fused pairs; the local sum of squares behind the
+    norm after every iteration goes to --golden-norms (merged into an existing file)."""
+    ctx = F.ctx()
+    n, T = args.n, args.golden_iters + (args.golden_iters & 1)
+    data = _read_json(args.golden_norms) or {}
+    data.setdefault("entries", {})
+    data["source"] = ("bench.py --golden-norms: single-rank control runs of the global problems (as --as-one-rank-of), fused pairs, "
+                      "sum((dHdtau*dt)^2) over the interior after every pseudo-iteration since the Gaussian initial state")
+    for spec in filter(None, args.golden_dims.split(";")):
+        d = tuple(int(x) for x in spec.split(","))
+        nloc = tuple(k * (n - 2) + 2 for k in d)
+        gg = F.grid.GlobalGrid(*nloc, dims=(1, 1, 1), transport=None)
+        lx, ly, lz = (k * 10.0 for k in d)
+        dx, dy, dz = lx / gg.nx_g(), ly / gg.ny_g(), lz / gg.nz_g()
+        D, dt = 1.0, 0.2
+        coef = (min(dx, dy, dz) ** 2 / D / 8.1, 1.0 / dt, 1.0 / dx, 1.0 / dy, 1.0 / dz, D / dx, D / dy, D / dz)
+        Ht = F.fzeros(*nloc)
+        F.part1.init_local_gaussian((lx / 2, ly / 2, lz / 2), dx, dy, dz, Ht, gg.coords)
+        A = Ht.clone(memory_format=torch.preserve_format)
+        B = F.fzeros(*nloc)
+        C_ = A.clone(memory_format=torch.preserve_format)
+        res = F.fzeros(*nloc)
+        assert gg.can_step2(Ht, A, B, C_, res), nloc
+        sq = torch.zeros(T, dtype=torch.float64, device=Ht.device)
+        for i in range(0, T, 2):
+            gg.step2(Ht, A, B, C_, res, *coef, dt, sq[i:i + 2])
+            A, C_ = C_, A
+        torch.cuda.synchronize()
+        data["entries"]["n%d_dims%d,%d,%d" % ((n,) + d)] = {"n": n, "dims": list(d), "global_grid": list(nloc),
+                                                           "sumsq": [float(v) for v in sq.cpu().tolist()]}
+        print("golden norms: n=%d dims=%s global %s, %d iterations, last sumsq %.17g" % (n, d, nloc, T, float(sq[-1].item())),
+              file=sys.stderr)
+        del Ht, A, B, C_, res, sq, gg
+        torch.cuda.empty_cache()
+    with open(args.golden_norms, "w") as f:
+        json.dump(data, f, indent=0)
+        f.write("\n")
+
+
+# ------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -425,6 +627,20 @@ def main():
     ap.add_argument("--no-fuse2", action="store_true", help="main leg with one iteration per launch (k_diff3_march)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / control-plane rehearsal on CPU (gloo): no GPU, no compute, one JSON line")
+    ap.add_argument("--choreography", choices=("pairs", "plain"), default="pairs",
+                    help="between ranks: pairs = fused pairs (shell chain + both exchanges on the comm stream of the CU-split device "
+                         "beside ONE core launch); plain = single steps (boundary slabs -> exchange || interior), no split -- the "
+                         "watchdog's fallback")
+    ap.add_argument("--watchdog-s", type=float, default=120.0, help="N > 1: seconds without progress of a rank before the attempt is failed")
+    ap.add_argument("--watchdog-import-s", type=float, default=420.0, help="the same before the worker has imported torch (fresh box)")
+    ap.add_argument("--no-norm-check", action="store_true", help="N > 1: do not compare the norm with tests/golden/scale_norms.json")
+    ap.add_argument("--golden-norms", type=str, default="",
+                    help="FILE: control runs on ONE rank (as --as-one-rank-of) of the global problems the decomposed runs solve; "
+                         "writes the sum of squares behind the norm after every iteration (tools/make_scale_norms.sh)")
+    ap.add_argument("--golden-dims", type=str, default="1,1,2;1,1,4;1,1,8;2,1,1;2,2,1;2,2,2")
+    ap.add_argument("--golden-iters", type=int, default=320)
+    ap.add_argument("--dry-run-hang", type=int, default=-1, help="(test) --dry-run: this rank stops making progress in the first attempt")
+    ap.add_argument("--dry-run-hang-always", action="store_true", help="(test) ... and in the fallback attempt too")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="diagnostic for a 1-GPU box: every rank on cuda:0, halo planes and the norm's all-reduce staged "
                          "through the host over gloo (RCCL refuses two ranks on one device).  Runs the N>1 control flow, the "
@@ -433,14 +649,21 @@ def main():
 
     if args.gpus > 1 and "RANK" not in os.environ:
         self_launch(args.gpus)   # never returns
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ and os.environ.get("FPR_BENCH_WORKER") != "1":
+        supervise(args)          # never returns: this process only watches its worker (and never touches a GPU)
 
+    hb("start")
     import torch
     import torch.distributed as dist
 
+    hb("imported")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = "RANK" in os.environ and world > 1
+    attempt = int(os.environ.get("FPR_BENCH_ATTEMPT", "1"))
+    choreography = os.environ.get("FPR_BENCH_CHOREOGRAPHY", args.choreography)
+    first_failure = json.loads(os.environ["FPR_BENCH_FIRST_FAILURE"]) if os.environ.get("FPR_BENCH_FIRST_FAILURE") else None
     if use_dist:
         # control plane only (RCCL unique id, barriers, max over ranks): gloo on the host.  The data path -- halo planes
         # and the norm's all-reduce -- is RCCL inside libfpr_hip.so.
@@ -451,22 +674,28 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    hb("process_group")
 
     if args.dry_run:
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         seen = torch.ones(1, dtype=torch.float64)
+        if rank == args.dry_run_hang and (attempt == 1 or args.dry_run_hang_always):
+            time.sleep(1.0e6)        # (test) a rank that deadlocked: the others wait for it in the barrier below
         if use_dist:
             dist.barrier()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(seen)
+            dist.barrier()
+        hb("done")
         if rank == 0:
             print(json.dumps({"metric": "diffusion3d_effective_memory_throughput", "value": None, "unit": "GB/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
                               "ranks_seen": int(seen.item()), "max_over_ranks": float(t.item()),
                               "self_launched": os.environ.get("FPR_BENCH_SELF_LAUNCHED") == "1",
-                              "control_plane": "gloo" if use_dist else "none"}))
+                              "control_plane": "gloo" if use_dist else "none",
+                              "choreography": choreography, "attempt": attempt, "first_attempt": first_failure}))
+            sys.stdout.flush()
         if use_dist:
-            dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -482,6 +711,10 @@ def main():
         ctx.set_option(k, int(v))
 
     n = args.n
+    if args.golden_norms:
+        assert world == 1, "--golden-norms is a series of single-rank control runs"
+        golden_norms(F, torch, args)
+        return
     dims = tuple(int(x) for x in args.dims.split(",")) if args.dims else (1, 1, world)
     as_one = tuple(int(x) for x in args.as_one_rank_of.split(",")) if args.as_one_rank_of else None
     if as_one:
@@ -495,6 +728,9 @@ def main():
     if shared and world > 1:
         gg.dist = host_staged_p2p(torch, dist)
     rccl_ranks = ctx.L.fpr_comm_size(ctx.h)
+    if world > 1 and not shared and rccl_ranks != world:
+        raise RuntimeError("the library's RCCL communicator has %d ranks, the job %d" % (rccl_ranks, world))
+    hb("rccl_init")
     # physics as diffusion_3D_kernel_programming with scale_physical_size=true (weak scaling keeps dx fixed)
     lx, ly, lz = (d * 10.0 for d in phys)
     dx, dy, dz = lx / gg.nx_g(), ly / gg.ny_g(), lz / gg.nz_g()
@@ -510,6 +746,8 @@ def main():
     # Hτ2 keeps playing the reference's second buffer (its boundary cells / halo planes are all that is read)
     Hτ3 = Hτ.clone(memory_format=torch.preserve_format)
     can_fuse2 = gg.can_step2(Ht, Hτ, Hτ2, Hτ3, res)
+    hb("fields")
+    iters_done = [0]          # pseudo-iterations since the initial state (what tests/golden/scale_norms.json is indexed by)
     K, W, ce = args.steps, args.warmup, max(1, args.check_every)
     sq = torch.zeros(2 * (K + W + ce) + 64, dtype=torch.float64, device=Ht.device)
     sqrtN = math.sqrt(world * nloc[0] * nloc[1] * nloc[2])
@@ -540,6 +778,7 @@ def main():
             else:
                 one_step(sq[base + i:base + i + 1])
                 i += 1
+            iters_done[0] += i - prev
             if i // ce > prev // ce or i == nsteps:  # convergence check: all-reduce the chunk (RCCL), host reads it
                 chunk = sq[base + (prev // ce) * ce:base + i]
                 gg.allreduce_(chunk)
@@ -560,6 +799,9 @@ def main():
         if use_dist or as_one:
             for _ in range(8 if prewarm_ms > 100 else 2):
                 run(8, 0, fuse2)
+                if use_dist:
+                    torch.cuda.synchronize()
+                    hb("prewarm")
             torch.cuda.synchronize()
         else:
             tpre = time.perf_counter()
@@ -567,6 +809,9 @@ def main():
                 run(8, 0, fuse2)
                 torch.cuda.synchronize()
         run(W, 0, fuse2)
+        if use_dist:
+            torch.cuda.synchronize()
+            hb("warmup")
         extra = 0
         if fuse2 and state["parity"] == 1:     # every timed launch of the fused leg must be the fused kernel
             run(1, W, False)
@@ -580,6 +825,7 @@ def main():
         elapsed = time.perf_counter() - t0
         kt = {kind: timer_read(ctx, kind) for kind in (KT_STEP, KT_STEP2, KT_CORE)}
         ctx.call("fpr_kernel_timer", 0)
+        hb("timed")
         if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -637,7 +883,7 @@ def main():
             pass
         return None
 
-    main_fused = can_fuse2 and not args.no_fuse2
+    main_fused = can_fuse2 and not args.no_fuse2 and not (world > 1 and choreography == "plain")
     elapsed, kt, extra = timed_leg(main_fused, args.prewarm_ms)
     last_err = errs[-1] if errs else None
     last_sumsq = sums[-1] if sums else None
@@ -675,10 +921,17 @@ def main():
                    "self_launched": os.environ.get("FPR_BENCH_SELF_LAUNCHED") == "1",
                    "pct_of_hbm_peak_effective_per_gpu": 100.0 * value / world / HBM_PEAK_GBS,
                    "pct_of_hbm_peak_physical_dominant_kernel": 100.0 * roofline["frac"],
-                   "last_err": last_err, "last_sumsq": last_sumsq},
+                   "last_err": last_err, "last_sumsq": last_sumsq, "iterations_since_start": iters_done[0],
+                   "choreography": ("pairs" if main_fused else "plain") if world > 1 else "none (1 rank)", "attempt": attempt},
         "roofline": roofline,
         "legs": legs,
     }
+    if first_failure is not None:
+        out["first_attempt"] = first_failure      # the watchdog failed the first attempt; this line comes from the fallback
+    norm_failed = False
+    if (world > 1 or as_one) and not args.no_norm_check:
+        out["norm_check"] = norm_check(n, as_one or dims, iters_done[0], last_sumsq)
+        norm_failed = out["norm_check"].get("ok") is False
     if shared:
         out["rehearsal"] = ("%d ranks sharing one GPU, planes staged through the host over gloo: a control-flow and "
                             "choreography rehearsal, not a measurement" % world)
@@ -785,12 +1038,24 @@ def main():
                 out["ns_step"] = ns_block(F)
             except Exception as e:
                 out["ns_step"] = {"error": repr(e)}
+    if use_dist:
+        dist.barrier()                  # the last collective: every rank got through the whole run
+        F.grid.finalize_global_grid()
+    if norm_failed and os.environ.get("FPR_BENCH_WORKER") == "1" and attempt == 1:
+        # every rank holds the same all-reduced sum and takes this exit: the supervisors fail the attempt and start the
+        # fallback, whose line carries this record as `first_attempt`
+        hb("norm_failed", norm_check=out["norm_check"])
+        dist.destroy_process_group()
+        sys.exit(3)
+    hb("done" if not norm_failed else "norm_failed", **({"norm_check": out["norm_check"]} if norm_failed else {}))
+    if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
     if use_dist:
-        dist.barrier()
-        F.grid.finalize_global_grid()
         dist.destroy_process_group()
+    if norm_failed:
+        print("bench.py: norm check FAILED: %r" % (out["norm_check"],), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

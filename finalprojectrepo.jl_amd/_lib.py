@@ -249,9 +249,12 @@ class Context:
         """fpr_reserve_comm_cus: the comm stream becomes a library-owned stream on k compute units (0: the torch stream
         given at creation again); self.comm follows, so torch work placed on it lands on the same stream."""
         torch = _torch()
-        if self.L.fpr_comm_cus(self.h) == int(k):
+        # the library may round a share up (asked 16, the probe found other units: 32): remember what was ASKED, or every pair
+        # would call in again and wrap the stream once more
+        if self.L.fpr_comm_cus(self.h) == int(k) or (k > 0 and getattr(self, "_comm_asked", 0) == int(k) and self.L.fpr_comm_cus(self.h) > 0):
             return
         self.call("fpr_reserve_comm_cus", int(k))
+        self._comm_asked = int(k)
         if k > 0:
             h = _vp()
             self.call("fpr_stream_handle", 1, C.byref(h))

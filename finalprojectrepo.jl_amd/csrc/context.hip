@@ -84,6 +84,9 @@ extern "C" int fpr_synchronize(fpr_ctx* ctx)
     FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
     FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));
     if (ctx->stream[2] != ctx->stream[0]) FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[2]));
+    // all three streams are drained: a fused pair that fpr_diffusion3d_step2_halo(join = 0) left on the core / comm streams is joined
+    // (the next pair must fork from the compute stream again, behind whatever the caller enqueues there in between)
+    ctx->pair_pending = false;
     return FPR_OK;
 }
 
@@ -126,6 +129,7 @@ extern "C" int fpr_reserve_comm_cus(fpr_ctx* ctx, int k)
         }
         ctx->comm_cus = ctx->comm_cus_asked = 0;
         ctx->core_unmasked = false;
+        ctx->pair_pending = false;   // drained above: nothing is left on the streams that have just been destroyed
     }
     if (k == 0) return FPR_OK;
     FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));
@@ -142,25 +146,39 @@ extern "C" int fpr_reserve_comm_cus(fpr_ctx* ctx, int k)
     const int asked = k;
     const long force = fpr_opt(ctx, "core_unmasked", -1);    // experiments: 0 = never (b), 1 = (b) for every k
     bool unmasked = force == 1 || (force != 0 && k % 32 != 0);
+    // every failure below leaves the context unsplit and owns no stream (comm_cus stays 0)
+    auto undo = [&](hipError_t e, const char* what) {
+        for (int m = 0; m < 2; ++m) {
+            if (ctx->masked[m]) hipStreamDestroy(ctx->masked[m]);
+            ctx->masked[m] = nullptr;
+        }
+        return fpr_fail(ctx, FPR_ERR_HIP, "fpr_reserve_comm_cus: %s: %s", what, hipGetErrorString(e));
+    };
+#define FPR_SPLIT(call)                                  \
+    do {                                                 \
+        hipError_t e_ = (call);                          \
+        if (e_ != hipSuccess) return undo(e_, #call);    \
+    } while (0)
     for (int attempt = 0; attempt < 2; ++attempt) {
         std::vector<uint32_t> mc(words, 0u), mr(words, 0u);
         for (int b = 0; b < ctx->ncu; ++b) (b < k ? mc : mr)[b / 32] |= 1u << (b % 32);
-        FPR_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->masked[0], (uint32_t)words, mc.data()));
+        FPR_SPLIT(hipExtStreamCreateWithCUMask(&ctx->masked[0], (uint32_t)words, mc.data()));
         if (unmasked) {
-            if (!ctx->reserved_map) FPR_HIP(ctx, hipMalloc(&ctx->reserved_map, 128 * sizeof(unsigned)));   // [64, 128): scratch of the tests
+            if (!ctx->reserved_map) FPR_SPLIT(hipMalloc(&ctx->reserved_map, 128 * sizeof(unsigned)));   // [64, 128): scratch of the tests
             unsigned host[64];
             int found = 0;
             for (int probe = 0; probe < 3 && found != k; ++probe) {
-                FPR_HIP(ctx, hipMemsetAsync(ctx->reserved_map, 0, sizeof(host), ctx->masked[0]));
+                FPR_SPLIT(hipMemsetAsync(ctx->reserved_map, 0, sizeof(host), ctx->masked[0]));
                 k_cu_probe<<<64 * k, 64, 0, ctx->masked[0]>>>(ctx->reserved_map);
-                FPR_HIP(ctx, hipMemcpyAsync(host, ctx->reserved_map, sizeof(host), hipMemcpyDeviceToHost, ctx->masked[0]));
-                FPR_HIP(ctx, hipStreamSynchronize(ctx->masked[0]));
+                FPR_SPLIT(hipGetLastError());
+                FPR_SPLIT(hipMemcpyAsync(host, ctx->reserved_map, sizeof(host), hipMemcpyDeviceToHost, ctx->masked[0]));
+                FPR_SPLIT(hipStreamSynchronize(ctx->masked[0]));
                 found = 0;
                 for (unsigned w : host) found += __builtin_popcount(w);
             }
             ctx->options["comm_units_found"] = found;
             if (found == k) {
-                FPR_HIP(ctx, hipStreamCreateWithFlags(&ctx->masked[1], hipStreamNonBlocking));
+                FPR_SPLIT(hipStreamCreateWithFlags(&ctx->masked[1], hipStreamNonBlocking));
                 ctx->core_unmasked = true;
                 break;
             }
@@ -171,11 +189,15 @@ extern "C" int fpr_reserve_comm_cus(fpr_ctx* ctx, int k)
             if (k > ctx->ncu / 2) return fpr_fail(ctx, FPR_ERR_INVALID, "the comm stream's units could not be identified and k cannot be rounded up");
             continue;
         }
-        FPR_REQUIRE(ctx, k % 32 == 0 || ctx->ncu != 256, "k must be a multiple of 32 for a masked core stream");
-        FPR_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->masked[1], (uint32_t)words, mr.data()));
+        if (!(k % 32 == 0 || ctx->ncu != 256)) {
+            undo(hipSuccess, "mask");
+            return fpr_fail(ctx, FPR_ERR_INVALID, "k must be a multiple of 32 for a masked core stream");
+        }
+        FPR_SPLIT(hipExtStreamCreateWithCUMask(&ctx->masked[1], (uint32_t)words, mr.data()));
         ctx->core_unmasked = false;
         break;
     }
+#undef FPR_SPLIT
     ctx->comm_cus_asked = asked;
     ctx->caller_comm = ctx->stream[1];
     ctx->stream[1] = ctx->masked[0];

@@ -176,10 +176,12 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
             // a launch on the comm stream of a split device has that stream's compute units only: chunk it for them
             const int ncu_plan = (stream_sel == 1 && ctx->comm_cus > 0) ? ctx->comm_cus : ctx->ncu;
             // the reserved form of a core launch takes tickets: one workgroup per device slot, the ones the split leaves no slot for find no work
-            const bool tickets = reserve_cus != 0 && stream_sel != 1 && fpr_opt(ctx, "diff3_tickets", 1) != 0;   // (one ticketed launch at a time: the core / compute stream's)
+            // (a launch leaves its counters zeroed; launches of ONE stream follow each other, and every stream selector has a block of
+            // its own, so a ticketed launch on the compute stream cannot meet a pending pair's core launch in the same counters)
+            const bool tickets = reserve_cus != 0 && stream_sel != 1 && fpr_opt(ctx, "diff3_tickets", 1) != 0;
             if (tickets && !ctx->tickets) {
-                FPR_HIP(ctx, hipMalloc(&ctx->tickets, 16 * sizeof(int)));
-                FPR_HIP(ctx, hipMemsetAsync(ctx->tickets, 0, 16 * sizeof(int), ctx->stream[stream_sel]));
+                FPR_HIP(ctx, hipMalloc(&ctx->tickets, 3 * 16 * sizeof(int)));
+                FPR_HIP(ctx, hipMemset(ctx->tickets, 0, 3 * 16 * sizeof(int)));   // once, complete before any stream goes on
             }
             const unsigned* rmap = (tickets && ctx->core_unmasked && stream_sel == 2) ? ctx->reserved_map : nullptr;
             if (rmap && fpr_opt(ctx, "diff3_reserved_test", 0)) {
@@ -192,7 +194,7 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
             e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), (int)fpr_opt(ctx, "diff3_xcd2", 0) & 3,
                               ctx->stream[stream_sel], pcap, &nparts,
                               (int)fpr_opt(ctx, "diff3_nw2", 0), ncu_plan, zlo2, zhi2, reserve_cus, &bal_info,
-                              tickets ? ctx->tickets : nullptr, rmap);
+                              tickets ? ctx->tickets + 16 * stream_sel : nullptr, rmap);
             if (reserve_cus != 0) ctx->options["diff3_last_bal"] = bal_info;   // diagnostic (fpr_get_option): which form ran
         }
         fpr_ktimer_end(ctx, timed, ctx->stream[stream_sel]);

@@ -1309,11 +1309,12 @@ static TopGeom top_geom(fpr_ctx* ctx, int nx, int ny, double h, double c)
         rs = (ny + chunks - 1) / chunks;
         if (rs < 32) rs = 32;
     }
-    rs += rs & 1;   // k_seam_march_v2: chunks start on even rows (the parity of a row of its unrolled loop is a constant)
     {   // rows are addressed relative to the first row of a chunk with a 32-bit byte offset
         const long cap = (long)(0x7fffffffL / ((long)nx * 8)) - 16;
         if (rs > cap) rs = (int)(cap > 16 ? cap : 16);
     }
+    rs += rs & 1;   // k_seam_march_v2: chunks start on even rows (the parity of a row of its unrolled loop is a constant) --
+                    // after the cap, which may be odd (one row more than the cap stays far inside the 16 rows of slack)
     g.rpc_s = rs;
     g.gm = dim3((g.nstrips + 3) / 4, (ny + rpc - 1) / rpc);
     g.gr = dim3((g.nstrips_r + 3) / 4, (ny + rpc - 1) / rpc);

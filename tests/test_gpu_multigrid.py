@@ -337,6 +337,28 @@ def test_config3_known_answer_k10_l6_jacobi(fpr, oracle):
     assert np.array_equal(F.tonumpy(x), xo)
 
 
+def test_bench_vcycle_config_4097_l2_full_solve_against_the_oracle(fpr, oracle):
+    """The configuration bench.py's `vcycle` block times -- 4097^2, 11 grids (l = 2, coarse 5^2), Jacobi coarse solver,
+    multigrid_bench.jl:27-42 protocol (x = 0, b ~ U[0,1) over the whole array, c = 0, tol 1e-6) -- as a FULL solve against the
+    oracle at its own size: 7 V-cycles, residual history to 1e-10, the field bit for bit.  This runs the 11-level
+    path (finest marches, seam passes between cycles, k_mid_down/up, the LDS-resident k_mg_small) under a 4097^2 finest level."""
+    F, mg = fpr, fpr.multigrid
+    n = 4097
+    h = 1.0 / (n - 1)
+    b = asf(splitmix64_uniform(n * n, 1).reshape((n, n), order="F"))
+    xo = farr(n, n)
+    r_o, hist_o, frms_o = oracle.mgsolve2d(xo, b, h, 0.0, 1e-6, 100, False, 5, 0)
+    x = F.fzeros(n, n)
+    opt = mg.MGOpt()
+    opt.coarse_solve_size, opt.coarse_solver = 5, mg.jacobi
+    r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, F.asdevice(b), h, 0.0, 1e-6, 100, False, opt=opt, return_history=True)
+    assert len(hist) == len(hist_o) == 7
+    assert abs(frms - frms_o) <= 1e-13 * frms_o
+    assert np.allclose(hist, hist_o, rtol=1e-10, atol=0), (hist, hist_o)
+    assert cit == oracle.last_coarse_iters()
+    assert np.array_equal(F.tonumpy(x), xo)
+
+
 def test_config3_five_levels_4097(fpr, oracle):
     """BASELINE config 3 as named: 4097^2, 5 grids (l=8, coarse 257^2), 2+2 Jacobi smooths, multigrid_bench.jl
     protocol.  Jacobi coarse solver: 44 V-cycles / 226 160 coarse sweeps to tol 1e-6 (the coarse solve is capped at

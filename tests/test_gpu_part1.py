@@ -485,6 +485,51 @@ def test_solve_with_fused_pairs_equals_plain_loop(fpr, oracle, case):
         assert np.allclose(e0, e1, rtol=1e-12, atol=0)
 
 
+def test_full_size_512_single_and_fused_launches_against_the_oracle(fpr):
+    """BASELINE config 2 at its own size against the oracle (OpenMP build of the same C restatement of
+    part1_kernel_programming.jl:46-58): a plain, non-periodic 512^3 grid, bench.py's physics, an input without symmetries;
+    2 single launches then 1 fused pair (4 iterations).  Fields and residuals bit for bit, norms to 1e-13."""
+    import os
+
+    from fixtures_io import splitmix64_uniform
+    from oracle.oracle import Oracle, asf, farr
+
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
+    orc = Oracle(openmp=True)
+    F = fpr
+    n = 512
+    dx = 10.0 / n
+    dt = 0.2
+    coef = (dx * dx / 8.1, 1 / dt, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx)
+    Ht = orc.init_gaussian((n, n, n), dx, dx, dx, (4.0, 5.5, 6.0))
+    Ht *= 1.0 + 0.25 * asf(splitmix64_uniform(n ** 3, 77).reshape((n, n, n), order="F"))
+    A, B, R = Ht.copy(order="F"), farr(n, n, n), farr(n, n, n)
+    gHt, gA, gB, gR = F.asdevice(Ht), F.asdevice(A), F.fzeros(n, n, n), F.fzeros(n, n, n)
+    sq = F.ctx().scal[:2]
+    for it in range(2):
+        orc.diffusion3d_step(Ht, A, B, R, *coef)
+        A, B = B, A
+        F.part1.diffusion_3D_step_τ_norm(gHt, gA, gB, gR, *coef, dt, sq[0:1])
+        gA, gB = gB, gA
+        ref = orc.sumsq_scaled(R, dt)
+        assert abs(float(sq[0].item()) - ref) <= 1e-13 * ref
+    assert np.array_equal(F.tonumpy(gA), A) and np.array_equal(F.tonumpy(gR), R)
+    # the fused pair: gB plays the reference's second buffer (its boundary cells are read), gC receives the field after two
+    # iterations and must carry gA's boundary values
+    gC = gA.clone()
+    assert F.part1.can_step_τ2(gHt, gA, gB, gC, gR)
+    refs = []
+    for k in range(2):
+        orc.diffusion3d_step(Ht, A, B, R, *coef)
+        A, B = B, A
+        refs.append(orc.sumsq_scaled(R, dt))
+    F.part1.diffusion_3D_step_τ2(gHt, gA, gB, gC, gR, *coef, dt, sq)
+    got = [float(v) for v in sq.tolist()]
+    assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs)), (got, refs)
+    assert np.array_equal(F.tonumpy(gC), A)
+    assert np.array_equal(F.tonumpy(gR), R)
+
+
 def test_full_size_512_fused_equals_two_steps(fpr):
     """BASELINE config 2 size: the fused launch equals two single launches bit for bit at 512^3 (norms to 1e-13)."""
     import torch

@@ -305,6 +305,47 @@ def test_one_call_pair_without_sums_and_after_an_error(fpr, periodic_grid):
     assert np.array_equal(a_f, c_f) and np.array_equal(a_r, c_r) and a_s == c_s
 
 
+def test_synchronize_joins_a_pending_pair(fpr, periodic_grid):
+    """fpr_synchronize drains all three streams, so it IS a join: a pair left pending (join = 0), then fpr_synchronize, then
+    work on the compute stream that rewrites the pair's inputs (`Ht .= Hτ`, part1_kernel_programming.jl:203), then the next
+    pair -- which must fork from the compute stream again, behind that work.  (Round 3 left `pair_pending` set: the second
+    pair skipped the fork and could read Ht / Hτ while they were still being written.)  Compared with the same sequence
+    joined explicitly; the heavy copies are repeated so that an unordered pair would start long before they end."""
+    import torch
+
+    F = fpr
+    n = (256, 192, 160)
+    gg = periodic_grid(n, (0, 0, 1))
+    dx = 10.0 / 126
+    coef = (dx * dx / 8.1, 5.0, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx)
+    H0 = wrap(rnd(n, 91), dims=(2,))
+    big = [F.fzeros(*n) for _ in range(2)]
+
+    def run(use_synchronize):
+        gHt, gA, gB, gR = F.asdevice(H0), F.asdevice(H0), F.fzeros(*n), F.fzeros(*n)
+        gC = gA.clone()
+        c = F.ctx()
+        c.call("fpr_diffusion3d_step2_halo", *[F._lib.fptr(x, 3) for x in (gHt, gA, gB, gC, gR)], *n, *coef, 0.2, None, 0)
+        if use_synchronize:
+            c.synchronize()
+        else:
+            c.call("fpr_diffusion3d_join")
+            torch.cuda.synchronize()
+        for _ in range(24):                      # compute-stream work ahead of the commit (keeps the stream busy for a while)
+            big[0].copy_(big[1])
+        gHt.copy_(gC)                            # Ht .= Hτ on the compute stream
+        gA.copy_(gC)
+        c.call("fpr_diffusion3d_step2_halo", *[F._lib.fptr(x, 3) for x in (gHt, gA, gB, gC, gR)], *n, *coef, 0.2, None, 0)
+        c.call("fpr_diffusion3d_join")
+        torch.cuda.synchronize()
+        return F.tonumpy(gC), F.tonumpy(gR)
+
+    ref_f, ref_r = run(False)
+    for _ in range(3):
+        f, r = run(True)
+        assert np.array_equal(f, ref_f) and np.array_equal(r, ref_r)
+
+
 @pytest.mark.parametrize("periods", [(0, 0, 1), (1, 1, 1)], ids=["z", "xyz"])
 def test_config4_512cubed_over_rccl_self_neighbour(fpr, oracle, periodic_grid, periods):
     """BASELINE config 4's per-GPU workload (512^3 local array with neighbours) through the library's RCCL transport on
@@ -405,6 +446,19 @@ def test_bench_two_ranks_rehearsal_on_one_card():
     assert one["config"]["local_grid"] == [128, 128, 254] and one["config"]["global_grid"] == [128, 128, 254]
     a, b = out["config"]["last_sumsq"], one["config"]["last_sumsq"]
     assert a > 0 and abs(a - b) <= 1e-12 * b, (a, b)
+    # ... and bench.py checked both itself against the committed control runs (tests/golden/scale_norms.json: the check the
+    # driver's N > 1 runs carry in their line)
+    for o in (out, one):
+        nc = o["norm_check"]
+        assert nc["ok"] is True and nc["key"] == "n128_dims1,1,2" and nc["iterations"] == o["config"]["iterations_since_start"] == 32
+    assert out["config"]["choreography"] == "pairs" and out["config"]["attempt"] == 1 and "first_attempt" not in out
+    # the watchdog's fallback choreography (single steps, no split of the device) on the same problem: same norm
+    rp = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--n", "128",
+                         "--choreography", "plain"] + common, capture_output=True, text=True, timeout=600, cwd=root)
+    assert rp.returncode == 0, rp.stderr[-2000:]
+    plain = json.loads([l for l in rp.stdout.splitlines() if l.startswith("{")][0])
+    assert plain["config"]["choreography"] == "plain" and plain["norm_check"]["ok"] is True
+    assert plain["roofline"]["launches_by_kind"]["core"] == 0
 
 
 def test_bench_four_ranks_rehearsal_x_y_z_decompositions_agree():
@@ -430,6 +484,7 @@ def test_bench_four_ranks_rehearsal_x_y_z_decompositions_agree():
         out = json.loads(lines[0])
         assert out["n_gpus"] == 4 and out["config"]["process_grid"] == [int(x) for x in dims.split(",")]
         assert out["legs"]["fused_pairs"]["launches"] == 6 and 0.0 < out["roofline"]["frac"] <= 1.0
+        assert out["norm_check"]["ok"] is True and out["norm_check"]["key"] == "n128_dims" + dims
         errs.append(out["config"]["last_err"])
     assert errs[0] is not None and 0.0 < errs[0] < 1.0
     assert abs(errs[1] - errs[0]) <= 1e-12 * errs[0] and abs(errs[2] - errs[0]) <= 1e-12 * errs[0]

@@ -201,6 +201,107 @@ def test_bench_self_launcher_dry_run_world2():
     assert p.returncode != 0
 
 
+def _bench(argv, timeout=300):
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_watchdog_fails_a_stalled_attempt_and_falls_back_to_the_plain_choreography():
+    """A rank that stops making progress (a deadlocked collective) must not hang the N > 1 bench: every rank process
+    supervises its worker through a heartbeat file; the stalled attempt is failed for ALL ranks, fresh workers run once with
+    --choreography plain, and the one JSON line says which choreography produced it and why the first attempt failed."""
+    import json
+    import time
+
+    t0 = time.time()
+    p = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--dry-run-hang", "1", "--watchdog-s", "3"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert time.time() - t0 < 120
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["attempt"] == 2 and d["choreography"] == "plain" and d["ranks_seen"] == 2
+    fa = d["first_attempt"]
+    assert fa["attempt"] == 1 and fa["choreography"] == "pairs" and "no progress" in fa["reason"]
+    assert set(fa["phase_by_rank"]) == {"0", "1"}
+    assert "watchdog" in p.stderr
+
+
+def test_bench_watchdog_second_failure_exits_nonzero_within_bounds():
+    """When the fallback stalls too the launch fails loudly (non-zero exit, an error line naming both attempts) instead of
+    waiting for ever."""
+    import json
+    import time
+
+    t0 = time.time()
+    p = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--dry-run-hang", "0", "--dry-run-hang-always",
+                "--watchdog-s", "3"])
+    assert p.returncode != 0
+    assert time.time() - t0 < 120
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["error"] == "both attempts failed"
+    assert [a["choreography"] for a in d["attempts"]] == ["pairs", "plain"]
+
+
+def test_bench_watchdog_under_torch_distributed_run():
+    """The driver starts N > 1 as `python -m torch.distributed.run ... bench.py --gpus N`: the ranks it starts supervise their
+    workers the same way (the fallback's workers meet through a fresh rendezvous file, not the agent's store)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--dry-run", "--dry-run-hang", "1", "--watchdog-s", "3"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["attempt"] == 2 and d["choreography"] == "plain" and d["self_launched"] is False and d["ranks_seen"] == 2
+
+
+def test_bench_norm_check_against_the_control_runs(tmp_path):
+    """norm_check: the sum of squares a decomposed run prints against the single-rank control of the same global problem
+    after the same number of iterations (tests/golden/scale_norms.json): 1e-12, and `ok: None` when there is no control."""
+    import importlib.util
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    g = tmp_path / "norms.json"
+    g.write_text(json.dumps({"source": "test", "entries": {"n128_dims1,1,2": {"n": 128, "dims": [1, 1, 2], "global_grid": [128, 128, 254],
+                                                                               "sumsq": [4.0, 3.0, 2.0]}}}))
+    ok = bench.norm_check(128, (1, 1, 2), 2, 3.0 * (1 + 5e-13), str(g))
+    assert ok["ok"] is True and ok["expected"] == 3.0 and ok["rel"] < 1e-12
+    bad = bench.norm_check(128, (1, 1, 2), 3, 2.0 * (1 + 1e-9), str(g))
+    assert bad["ok"] is False and bad["expected"] == 2.0
+    assert bench.norm_check(128, (1, 1, 2), 4, 1.0, str(g))["ok"] is None        # beyond the recorded iterations
+    assert bench.norm_check(128, (2, 2, 2), 1, 1.0, str(g))["ok"] is None        # no control for this process grid
+    # the committed file: the process grids of run_all_benchmarks.sh:21-28 / part1_scaling_experiments.jl:35-41 and the z-slabs
+    # bench.py runs by default, at the bench's local size, far enough for the driver's flags and the defaults
+    committed = json.load(open(os.path.join(root, "tests", "golden", "scale_norms.json")))
+    for dims in ("1,1,2", "1,1,4", "1,1,8", "2,1,1", "2,2,1", "2,2,2"):
+        ent = committed["entries"]["n512_dims" + dims]
+        assert len(ent["sumsq"]) >= 64 + 20 + 200 and all(v > 0 for v in ent["sumsq"])
+        assert ent["global_grid"] == [int(d) * 510 + 2 for d in dims.split(",")]
+
+
 def test_comm_share_and_box_order_of_fused_pairs():
     """GlobalGrid.reserve_cus: the comm stream of a fused pair gets 16 or 24 compute units without x-faces, else a multiple of 32 (the
     same number out of every shader engine), 64 only above two x-faces' worth of shell work; boundary_boxes peels the x-slabs last (step2 runs

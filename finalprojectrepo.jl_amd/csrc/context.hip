@@ -328,6 +328,26 @@ __global__ __launch_bounds__(256) void k_reduce(const double* __restrict__ x, co
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 
+// Dot2 (fpr_internal.hpp): block partials as (s, e) pairs, then one block sums the pairs and rounds s + e once
+__global__ __launch_bounds__(256) void k_dot2(const double* __restrict__ x, const double* __restrict__ y, size_t n,
+                                               double* __restrict__ partials)
+{
+    __shared__ double red[32];
+    const size_t stride = (size_t)gridDim.x * 256;
+    double s = 0.0, e = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) fpr_s2_add_prod(s, e, x[i], y[i]);
+    fpr_block_sum_s2<256>(s, e, red);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s; partials[2 * blockIdx.x + 1] = e; }
+}
+
+__global__ __launch_bounds__(256) void k_finish_s2(const double* __restrict__ partials, int n, double* __restrict__ out)
+{
+    __shared__ double red[32];
+    double s, e;
+    fpr_sum_partials_256_s2(partials, n, red, s, e);
+    if (threadIdx.x == 0) out[0] = s + e;
+}
+
 template <int MODE>  // 0 store sum, 1 accumulate sum, 2 store max
 __global__ __launch_bounds__(256) void k_finish(const double* __restrict__ partials, int n, double* __restrict__ out)
 {
@@ -528,6 +548,16 @@ int fprx_dot_dev(fpr_ctx* ctx, const double* x, const double* y, size_t n, doubl
     k_reduce<1><<<g, 256, 0, ctx->stream[0]>>>(x, y, n, 1.0, ctx->partials);
     FPR_CHECK_LAUNCH(ctx);
     return fprx_finish_sum(ctx, ctx->partials, g, out_dev, false, 0);
+}
+
+int fprx_dot2_dev(fpr_ctx* ctx, const double* x, const double* y, size_t n, double* out_dev)
+{
+    const int g = flat_grid(n);
+    k_dot2<<<g, 256, 0, ctx->stream[0]>>>(x, y, n, ctx->partials);
+    FPR_CHECK_LAUNCH(ctx);
+    k_finish_s2<<<1, 256, 0, ctx->stream[0]>>>(ctx->partials, g, out_dev);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
 }
 
 static int read_scalar(fpr_ctx* ctx, const double* dev, double* out_host)

@@ -298,11 +298,96 @@ __device__ __forceinline__ double fpr_sum_partials_256(const double* __restrict_
     return fpr_block_sum<256>(s, red);
 }
 
+// ---- twofold-precision sums (Ogita / Rump / Oishi: Sum2, Dot2) ---------------------------------------------------------------
+// A sum is carried as (s, e): s the running floating-point sum, e the plain sum of the rounding errors of every addition
+// (TwoSum) and product (an explicit fma -- not a contraction: the library is built with -ffp-contract=off) made on the way.
+// fl(s + e) is the exact sum rounded once, up to a relative (depth * eps)^2 -- whatever the order of the additions.  cg!'s three
+// dot products (krylov.jl:64,69,83) are formed this way here AND in the oracle, so that both round the same near-exact numbers
+// and the iteration no longer depends on the summation order (the reference's own order is unspecified: Julia's pairwise
+// `sum` on the CPU, CUDA.jl's tree on the GPU).  Only s is on the critical path of a reduction tree; e trails it.
+__device__ __forceinline__ void fpr_two_sum(double a, double b, double& s, double& err)
+{
+    const double t = a + b;
+    const double bb = t - a;
+    err = (a - (t - bb)) + (b - bb);
+    s = t;
+}
+__device__ __forceinline__ void fpr_s2_add(double& s, double& e, double v)           // (s, e) += v
+{
+    double t, d;
+    fpr_two_sum(s, v, t, d);
+    s = t;
+    e += d;
+}
+__device__ __forceinline__ void fpr_s2_merge(double& s, double& e, double s2, double e2)   // (s, e) += (s2, e2)
+{
+    double t, d;
+    fpr_two_sum(s, s2, t, d);
+    s = t;
+    e = (e + e2) + d;
+}
+__device__ __forceinline__ void fpr_s2_add_prod(double& s, double& e, double a, double b)   // (s, e) += a * b, exactly
+{
+    const double p = a * b;
+    const double pe = __builtin_fma(a, b, -p);
+    double t, d;
+    fpr_two_sum(s, p, t, d);
+    s = t;
+    e += d + pe;
+}
+// over the 64 lanes of a wave (DPP row shifts as fpr_wave_sum_all); the same (s, e) in every lane
+__device__ __forceinline__ void fpr_wave_sum_all_s2(double& s, double& e)
+{
+    fpr_s2_merge(s, e, fpr_dpp<0x111>(s), fpr_dpp<0x111>(e));
+    fpr_s2_merge(s, e, fpr_dpp<0x112>(s), fpr_dpp<0x112>(e));
+    fpr_s2_merge(s, e, fpr_dpp<0x114>(s), fpr_dpp<0x114>(e));
+    fpr_s2_merge(s, e, fpr_dpp<0x118>(s), fpr_dpp<0x118>(e));
+    auto lane = [](double v, int l) {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        return __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l));
+    };
+    double rs = lane(s, 15), re = lane(e, 15);
+    fpr_s2_merge(rs, re, lane(s, 31), lane(e, 31));
+    fpr_s2_merge(rs, re, lane(s, 47), lane(e, 47));
+    fpr_s2_merge(rs, re, lane(s, 63), lane(e, 63));
+    s = rs;
+    e = re;
+}
+// Block-wide, fixed order; result valid in thread 0.  `red` = __shared__ double[32].
+template <int NT>
+__device__ __forceinline__ void fpr_block_sum_s2(double& s, double& e, double* red)
+{
+    const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    fpr_wave_sum_all_s2(s, e);
+    if constexpr (NT > FPR_WAVE) {
+        if ((tid & (FPR_WAVE - 1)) == 0) { red[tid / FPR_WAVE] = s; red[16 + tid / FPR_WAVE] = e; }
+        __syncthreads();
+        if (tid == 0) {
+            double ts = red[0], te = red[16];
+#pragma unroll
+            for (int w = 1; w < NT / FPR_WAVE; ++w) fpr_s2_merge(ts, te, red[w], red[16 + w]);
+            s = ts;
+            e = te;
+        }
+    }
+}
+// n block partials stored as pairs (part[2 i] = s, part[2 i + 1] = e) summed by ONE block of 256 threads; valid in thread 0
+__device__ __forceinline__ void fpr_sum_partials_256_s2(const double* __restrict__ part, int n, double* red, double& s, double& e)
+{
+    const int tid = threadIdx.x + blockDim.x * threadIdx.y;
+    double ts = 0.0, te = 0.0;
+    for (int i = tid; i < n; i += 256) fpr_s2_merge(ts, te, part[2 * i], part[2 * i + 1]);
+    fpr_block_sum_s2<256>(ts, te, red);
+    s = ts;
+    e = te;
+}
+
 #endif  // __HIPCC__
 
 // cross-TU internal entry points (implemented in reduce.hip)
 int fprx_sumsq_scaled_dev(fpr_ctx* ctx, const double* x, size_t n, double scale, double* out_dev, int stream_sel);
 int fprx_dot_dev(fpr_ctx* ctx, const double* x, const double* y, size_t n, double* out_dev);
+int fprx_dot2_dev(fpr_ctx* ctx, const double* x, const double* y, size_t n, double* out_dev);   // twofold-precision dot (Dot2), rounded once
 // finish a two-stage reduction: out_dev[0] (= or +=) sum(partials[0..nparts))
 int fprx_finish_sum(fpr_ctx* ctx, const double* partials, int nparts, double* out_dev, bool accumulate, int stream_sel);
 int fprx_cycle_init(fpr_ctx* ctx, const double* f, size_t n, double tol);

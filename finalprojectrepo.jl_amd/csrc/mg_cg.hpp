@@ -4,6 +4,9 @@
 #pragma once
 
 // ---- CG kernels (krylov.jl:55-91) -------------------------------------------------------------------
+// The three dot products of an iteration (:64, :69, :83) are Dot2 sums (fpr_internal.hpp: twofold precision, rounded once): block
+// partials travel as (s, e) pairs, every consumer rounds s + e.  All launch forms and the oracle (orc_cg2d) then hold the same
+// alpha / beta / exit test in every iteration, whatever their summation order.
 __global__ __launch_bounds__(256) void k_cg_init(const double* __restrict__ b, double* __restrict__ r, double* __restrict__ p,
                                                   double* __restrict__ ph, double* __restrict__ x, size_t n)
 {
@@ -20,10 +23,10 @@ __global__ __launch_bounds__(256) void k_cg_matvec_dot(const double* __restrict_
                                                         double hx2, double hy2, double c, double* __restrict__ partials,
                                                         const FprSolveState* __restrict__ st)
 {
-    __shared__ double red[16];
+    __shared__ double red[32];
     if (st->done) return;
     const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
-    double acc = 0.0;
+    double s = 0.0, e = 0.0;
     if (i < nx && j < ny) {
         const size_t id = (size_t)i + (size_t)nx * j;
         double q;
@@ -33,18 +36,23 @@ __global__ __launch_bounds__(256) void k_cg_matvec_dot(const double* __restrict_
         } else {
             q = ph[id];
         }
-        acc = p[id] * q;
+        fpr_s2_add_prod(s, e, p[id], q);
     }
-    const double s = fpr_block_sum<256>(acc, red);
-    if (threadIdx.x == 0 && threadIdx.y == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = s;
+    fpr_block_sum_s2<256>(s, e, red);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const int b = blockIdx.x + gridDim.x * blockIdx.y;
+        partials[2 * b] = s; partials[2 * b + 1] = e;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_cg_alpha(FprSolveState* st, const double* __restrict__ partials, int nparts)
 {
-    __shared__ double red[16];
+    __shared__ double red[32];
     if (st->done) return;
-    const double s = fpr_sum_partials_256(partials, nparts, red);
+    double ss, se;
+    fpr_sum_partials_256_s2(partials, nparts, red, ss, se);
     if (threadIdx.x == 0) {
+        const double s = ss + se;
         st->pq = s;
         st->alpha = st->rho / s;  // krylov.jl:69
     }
@@ -55,27 +63,29 @@ __global__ __launch_bounds__(256) void k_cg_update(double* __restrict__ x, doubl
                                                     const double* __restrict__ ph, size_t n, double* __restrict__ partials,
                                                     const FprSolveState* __restrict__ st)
 {
-    __shared__ double red[16];
+    __shared__ double red[32];
     if (st->done) return;
     const double alpha = st->alpha;
     const size_t stride = (size_t)gridDim.x * 256;
-    double acc = 0.0;
+    double s = 0.0, e = 0.0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         x[i] = x[i] + alpha * p[i];
         const double rn = r[i] - alpha * ph[i];
         r[i] = rn;
-        acc += rn * rn;
+        fpr_s2_add_prod(s, e, rn, rn);
     }
-    const double s = fpr_block_sum<256>(acc, red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    fpr_block_sum_s2<256>(s, e, red);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s; partials[2 * blockIdx.x + 1] = e; }
 }
 
 __global__ __launch_bounds__(256) void k_cg_check(FprSolveState* st, const double* __restrict__ partials, int nparts, double N)
 {
-    __shared__ double red[16];
+    __shared__ double red[32];
     if (st->done) return;
-    const double s = fpr_sum_partials_256(partials, nparts, red);
+    double ss, se;
+    fpr_sum_partials_256_s2(partials, nparts, red, ss, se);
     if (threadIdx.x == 0) {
+        const double s = ss + se;
         const double normr = sqrt(s);
         st->iters += 1;
         st->last_rms = sqrt(s / N);  // krylov.jl:90
@@ -98,7 +108,7 @@ __global__ __launch_bounds__(256) void k_cg_update_f(double* __restrict__ x, dou
                                                       const double* __restrict__ ph, size_t n, const double* __restrict__ pq_partials,
                                                       int npq, double* __restrict__ partials, FprSolveState* __restrict__ st, int it)
 {
-    __shared__ double red[16];
+    __shared__ double red[32];
     __shared__ double s_alpha;
     if (st->done) return;
     // first element of this thread's grid-stride sequence: loaded before alpha is known (the loads overlap the reduction
@@ -107,42 +117,46 @@ __global__ __launch_bounds__(256) void k_cg_update_f(double* __restrict__ x, dou
     const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
     double x0 = 0.0, p0 = 0.0, r0 = 0.0, q0 = 0.0;
     if (i0 < n) { x0 = x[i0]; p0 = p[i0]; r0 = r[i0]; q0 = ph[i0]; }
-    const double pq = fpr_sum_partials_256(pq_partials, npq, red);
+    double pqs, pqe;
+    fpr_sum_partials_256_s2(pq_partials, npq, red, pqs, pqe);
     if (threadIdx.x == 0) {
+        const double pq = pqs + pqe;
         const double alpha = st->rho2[it & 1] / pq;  // krylov.jl:69
         s_alpha = alpha;
         if (blockIdx.x == 0) { st->pq = pq; st->alpha = alpha; }
     }
     __syncthreads();
     const double alpha = s_alpha;
-    double acc = 0.0;
+    double s = 0.0, e = 0.0;
     if (i0 < n) {
         x[i0] = x0 + alpha * p0;
         const double rn = r0 - alpha * q0;
         r[i0] = rn;
-        acc += rn * rn;
+        fpr_s2_add_prod(s, e, rn, rn);
     }
     for (size_t i = i0 + stride; i < n; i += stride) {
         x[i] = x[i] + alpha * p[i];
         const double rn = r[i] - alpha * ph[i];
         r[i] = rn;
-        acc += rn * rn;
+        fpr_s2_add_prod(s, e, rn, rn);
     }
     __syncthreads();
-    const double sblk = fpr_block_sum<256>(acc, red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = sblk;
+    fpr_block_sum_s2<256>(s, e, red);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s; partials[2 * blockIdx.x + 1] = e; }
 }
 
 __global__ __launch_bounds__(256) void k_cg_p_f(double* __restrict__ p, const double* __restrict__ r, size_t n,
                                                  const double* __restrict__ rr_partials, int nrr, FprSolveState* __restrict__ st,
                                                  int it, double N)
 {
-    __shared__ double red[16];
+    __shared__ double red[32];
     __shared__ double s_beta;
     __shared__ int s_conv;
     if (st->done) return;
-    const double rr = fpr_sum_partials_256(rr_partials, nrr, red);
+    double rrs, rre;
+    fpr_sum_partials_256_s2(rr_partials, nrr, red, rrs, rre);
     if (threadIdx.x == 0) {
+        const double rr = rrs + rre;
         const double normr = sqrt(rr);
         const int conv = normr < st->thresh;          // krylov.jl:76
         const double rho_old = st->rho2[it & 1];
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(256) void k_cg_pmv_f(const double* __restrict__ p_o
                                                    const double* __restrict__ rr_partials, int nrr,
                                                    FprSolveState* __restrict__ st, int it, double N)
 {
-    __shared__ double red[16];
+    __shared__ double red[32];
     __shared__ double s_beta;
     __shared__ int s_conv;
     __shared__ double tile[CGY + 2][CGX + 2];
@@ -202,10 +216,10 @@ __global__ __launch_bounds__(256) void k_cg_pmv_f(const double* __restrict__ p_o
     const double p_ring = p_old[rid], r_ring = it > 0 ? r[rid] : 0.0;
     double beta = 0.0;
     if (it > 0) {   // exit test and beta of iteration it-1 (krylov.jl:73-84)
-        double sacc = 0.0;   // fpr_sum_partials_256 for a 64 x 4 block: strided accumulation by linear thread id
-        for (int q = tid; q < nrr; q += 256) sacc += rr_partials[q];
-        const double rr = fpr_block_sum<256>(sacc, red);
+        double rrs, rre;
+        fpr_sum_partials_256_s2(rr_partials, nrr, red, rrs, rre);
         if (tid == 0) {
+            const double rr = rrs + rre;
             const double normr = sqrt(rr);
             const int conv = normr < st->thresh;              // krylov.jl:76
             const double rho_old = st->rho2[(it - 1) & 1];
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(256) void k_cg_pmv_f(const double* __restrict__ p_o
     tile[ty + 1][tx + 1] = own ? (it > 0 ? r_own + beta * p_own : p_own) : 0.0;
     if (tid < NRING) tile[hy][hx] = ring ? (it > 0 ? r_ring + beta * p_ring : p_ring) : 0.0;
     __syncthreads();
-    double acc = 0.0;
+    double accs = 0.0, acce = 0.0;
     if (own) {
         const double t = tile[ty + 1][tx + 1];
         p_new[id] = t;
@@ -238,20 +252,26 @@ __global__ __launch_bounds__(256) void k_cg_pmv_f(const double* __restrict__ p_o
         } else {
             q = ph[id];   // boundary of p_hat keeps b's values (krylov.jl:61, 68)
         }
-        acc = t * q;
+        fpr_s2_add_prod(accs, acce, t, q);
     }
-    const double sblk = fpr_block_sum<256>(acc, red);
-    if (tid == 0) pq_partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
+    __syncthreads();   // (red was read by thread 0 above)
+    fpr_block_sum_s2<256>(accs, acce, red);
+    if (tid == 0) {
+        const int b = blockIdx.x + gridDim.x * blockIdx.y;
+        pq_partials[2 * b] = accs; pq_partials[2 * b + 1] = acce;
+    }
 }
 
 // exit test of the LAST enqueued iteration (its successor's k_cg_pmv_f would have made it): one workgroup
 __global__ __launch_bounds__(256) void k_cg_tail_f(const double* __restrict__ rr_partials, int nrr, FprSolveState* __restrict__ st,
                                                     int it, double N)
 {
-    __shared__ double red[16];
+    __shared__ double red[32];
     if (st->done) return;
-    const double rr = fpr_sum_partials_256(rr_partials, nrr, red);
+    double rrs, rre;
+    fpr_sum_partials_256_s2(rr_partials, nrr, red, rrs, rre);
     if (threadIdx.x == 0) {
+        const double rr = rrs + rre;
         const double normr = sqrt(rr);
         const double rho_old = st->rho2[(it - 1) & 1];
         st->iters = it;

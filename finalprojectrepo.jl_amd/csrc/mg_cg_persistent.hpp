@@ -14,16 +14,17 @@
 // owner), so two barriers per iteration suffice: after the p.p_hat partials and after the r.r partials + r edges.
 // 16 workgroups are resident together on every device this runs on; every spin is bounded and raises an abort flag all
 // workgroups honour, so a workgroup that does not arrive ends the solve with an error instead of hanging the device.
-// Same operations per point as k_cg_pmv_f / k_cg_update_f; the dot products are summed per workgroup and then over the 16
-// workgroups, i.e. in another order than the 64x4-tile partials of the other forms: results agree to rounding, not bit for
-// bit (cg_fused = 3; forms 0-2 remain bit-identical among themselves).
+// Same operations per point as k_cg_pmv_f / k_cg_update_f; the dot products are Dot2 sums (fpr_internal.hpp: every addition's
+// and product's rounding error is carried along and the total rounded once), summed per workgroup and then over the 16
+// workgroups -- another order than the 64x4-tile partials of the other forms, the same value: all forms and the oracle agree
+// bit for bit.
 constexpr int CGP_NB = 16, CGP_NBX = 4, CGP_NT = 1024, CGP_PPT = 5, CGP_RPT = 1;   // workgroups, threads, tile / ring points per thread
 // (256 threads x 17 points: 9.0 us per iteration against 6.5 -- the two divisions per point of lap_at then weigh 2.8 us)
 struct CgpArgs {
     const double* b;
     double* x_out;         // solution (whole array written)
     double* r_glob;        // N doubles: tile-edge values of r are exchanged through it
-    double* part;          // 4 x CGP_NB slots (8 bytes every 128: partial sum = arrival flag), all CGP_EMPTY before the launch
+    double* part;          // 4 x 2 CGP_NB slots (8 bytes every 128: a workgroup's (s, e) pair, each word its own arrival flag), all CGP_EMPTY before the launch
     unsigned* ctr;         // [1] abort flag
     FprSolveState* st;
     int nx, ny, Nmax;
@@ -34,46 +35,79 @@ struct CgpArgs {
 __device__ __forceinline__ double cgp_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void cgp_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Grid barrier and all-reduce in ONE round trip: workgroup b stores its partial sum into its own slot of the set that belongs
-// to this barrier; lanes 0..15 of wave 0 of every workgroup each watch one slot until it no longer holds the EMPTY pattern (a
-// NaN payload no sum produces) -- the value itself is the arrival flag.  FOUR sets rotate: when a workgroup publishes for
+// Grid barrier and all-reduce in ONE round trip: workgroup b stores its partial sum -- a Dot2 pair (s, e), two words -- into its own
+// two slots of the set that belongs to this barrier; lanes 0..31 of wave 0 of every workgroup each watch one slot until it no longer
+// holds the EMPTY pattern (a NaN payload no sum produces) -- every word is its own arrival flag, so the two need no order.  FOUR sets rotate: when a workgroup publishes for
 // barrier g it first empties its slot of set (g+2) mod 4, last used at barrier g-2 (everybody has read that one: they all
 // published g-1 since).  That slot is polled next at barrier g+2; between the emptying and that poll lie the owner's
 // publications g and g+1, and the barriers alternate between RELEASE (publishes the workgroup's earlier stores -- the tile-edge
 // values of r and the emptying -- acquired by the pollers) and relaxed (nothing but the sum travels), so one of the two orders
-// the emptying before the poll.  Returns the 16 partials summed in workgroup order in every thread; *ok = false if the wait
-// timed out (abort raised for everybody).
+// the emptying before the poll.  Returns the 16 pairs summed in workgroup order and rounded once (s + e), in every thread;
+// *ok = false if the wait timed out (abort raised for everybody).
 constexpr unsigned long long CGP_EMPTY = 0x7ff8dead0badf00dull;
 constexpr int CGP_SLOT_STRIDE = 16;   // 8-byte words between two slots
+// 16 Dot2 pairs held one word per lane by lanes 0..31 of a wave (lane 2 b = s of pair b, lane 2 b + 1 = its e; lanes >= 32 hold
+// zeros) -> their sum as one pair, the same in every lane: the e words move to the even lanes, three DPP row shifts merge the
+// eight pairs of each 16-lane row, the two row totals are merged last.  A fixed tree -- four merges deep, a handful of registers
+// (summing 32 words one after the other out of LDS in every thread cost 67 spilled VGPRs and 4 us per iteration).
+__device__ __forceinline__ void cgp_merge16(double val, double& s_out, double& e_out)
+{
+    const bool even = (threadIdx.x & 1) == 0;
+    const double up = fpr_dpp<0x101>(val);          // row_shl:1: lane i <- lane i + 1
+    double s = even ? val : 0.0, e = even ? up : 0.0;
+    fpr_s2_merge(s, e, fpr_dpp<0x112>(s), fpr_dpp<0x112>(e));
+    fpr_s2_merge(s, e, fpr_dpp<0x114>(s), fpr_dpp<0x114>(e));
+    fpr_s2_merge(s, e, fpr_dpp<0x118>(s), fpr_dpp<0x118>(e));   // lane 14 of a row: the row's eight pairs
+    auto lane = [](double v, int l) {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        return __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l));
+    };
+    double rs = lane(s, 14), re = lane(e, 14);
+    fpr_s2_merge(rs, re, lane(s, 30), lane(e, 30));
+    s_out = rs;
+    e_out = re;
+}
 template <bool RELEASE>
-__device__ __forceinline__ double cgp_allsum(unsigned long long* slots, unsigned* abort_flag, double v_thread, unsigned& gen, double* red,
-                                             double* gpart, int* s_abort, bool* ok)
+__device__ __forceinline__ double cgp_allsum(unsigned long long* slots, unsigned* abort_flag, double vs, double ve, unsigned& gen, double* red,
+                                             double* fold, double* gsum, int* s_abort, bool* ok)
 {
     ++gen;
     // (a slot per 128-byte line: the pollers of different slots do not queue at one memory channel)
-    unsigned long long* set = slots + (gen & 3u) * (CGP_NB * CGP_SLOT_STRIDE);
-    unsigned long long* nxt = slots + ((gen + 2u) & 3u) * (CGP_NB * CGP_SLOT_STRIDE);
-    const double v_wave = fpr_wave_sum_all(v_thread);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v_wave;
+    unsigned long long* set = slots + (gen & 3u) * (2 * CGP_NB * CGP_SLOT_STRIDE);
+    unsigned long long* nxt = slots + ((gen + 2u) & 3u) * (2 * CGP_NB * CGP_SLOT_STRIDE);
+    // The workgroup's 1024 pairs: folded 4 -> 1 through LDS by the first four waves (one per SIMD), whose DPP wave sums then run
+    // without a neighbour on their SIMD (all 16 waves summing their own lanes -- 7 merges of ~14 instructions, four waves per
+    // SIMD -- cost 0.5 us per barrier more), four wave totals to LDS.
+    fold[threadIdx.x] = vs;
+    fold[CGP_NT + threadIdx.x] = ve;
+    __syncthreads();
+    if (threadIdx.x < CGP_NT / 4) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) fpr_s2_merge(vs, ve, fold[threadIdx.x + k * (CGP_NT / 4)], fold[CGP_NT + threadIdx.x + k * (CGP_NT / 4)]);
+        fpr_wave_sum_all_s2(vs, ve);
+        if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = vs; red[2 * (threadIdx.x >> 6) + 1] = ve; }
+    }
     // wave totals in LDS; the workgroup's earlier stores precede the publication below.  The tile-edge values of r were
-    // written with PLAIN stores by many threads; this barrier orders them before thread 0 at workgroup scope, and thread 0's
-    // agent-scope RELEASE store is cumulative over everything that happens-before it (the AMDGPU memory model composes
+    // written with PLAIN stores by many threads; this barrier orders them before threads 0 / 1 at workgroup scope, and their
+    // agent-scope RELEASE stores are cumulative over everything that happens-before them (the AMDGPU memory model composes
     // scopes that include one another), so a poller's agent-scope acquire of the slot sees them: the usual grid-sync pattern
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double v_blk = red[0];
-#pragma unroll
-        for (int w = 1; w < CGP_NT / 64; ++w) v_blk += red[w];
-        __hip_atomic_store(&nxt[blockIdx.x * CGP_SLOT_STRIDE], CGP_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long bits = (unsigned long long)__double_as_longlong(v_blk);
-        if (bits == CGP_EMPTY) bits ^= 1ull;   // (a sum that happens to be this very NaN stays a NaN)
-        if (RELEASE) __hip_atomic_store(&set[blockIdx.x * CGP_SLOT_STRIDE], bits, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_store(&set[blockIdx.x * CGP_SLOT_STRIDE], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (threadIdx.x < 64) {                // wave 0: lane w < 16 waits for workgroup w
+    if (threadIdx.x < 64) {                // wave 0 sums the workgroup, publishes, polls and sums the grid
         const int w = threadIdx.x;
+        static_assert(CGP_NT / 256 <= 16 && CGP_NB == 16, "cgp_merge16 sums up to 16 pairs");
+        double bs, be;
+        cgp_merge16(w < 2 * (CGP_NT / 256) ? red[w] : 0.0, bs, be);
+        if (w < 2) {                       // thread 0 publishes s, thread 1 e
+            const int slot = (2 * blockIdx.x + w) * CGP_SLOT_STRIDE;
+            __hip_atomic_store(&nxt[slot], CGP_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long bits = (unsigned long long)__double_as_longlong(w == 0 ? bs : be);
+            if (bits == CGP_EMPTY) bits ^= 1ull;   // (a sum that happens to be this very NaN stays a NaN)
+            if (RELEASE) __hip_atomic_store(&set[slot], bits, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_store(&set[slot], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         int ab = 0;
-        if (w < CGP_NB) {
+        double val = 0.0;
+        if (w < 2 * CGP_NB) {              // lane w waits for word w & 1 of workgroup w >> 1
             unsigned spins = 0;
             unsigned long long bits;
             while (true) {
@@ -89,29 +123,29 @@ __device__ __forceinline__ double cgp_allsum(unsigned long long* slots, unsigned
                     }
                 }
             }
-            gpart[w] = __longlong_as_double((long long)bits);
+            val = __longlong_as_double((long long)bits);
         }
         ab = __any(ab);
-        if (threadIdx.x == 0) *s_abort = ab;
+        double gs, ge;
+        cgp_merge16(val, gs, ge);
+        if (threadIdx.x == 0) { *s_abort = ab; *gsum = gs + ge; }
     }
     __syncthreads();
     *ok = *s_abort == 0;
-    double s = 0.0;
-#pragma unroll
-    for (int w = 0; w < CGP_NB; ++w) s += gpart[w];
-    return s;
+    return *gsum;
 }
 
 __global__ void k_cgp_slots_init(unsigned long long* slots)
 {
-    if (threadIdx.x < 4 * CGP_NB) slots[threadIdx.x * CGP_SLOT_STRIDE] = CGP_EMPTY;
+    for (int t = threadIdx.x; t < 4 * 2 * CGP_NB; t += blockDim.x) slots[t * CGP_SLOT_STRIDE] = CGP_EMPTY;
 }
 
 __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    __shared__ double red[CGP_NT / 64];
-    __shared__ double gpart[CGP_NB];
+    __shared__ double red[2 * (CGP_NT / 64)];
+    __shared__ double fold[2 * CGP_NT];
+    __shared__ double gsum;
     __shared__ int s_abort;
     const int tid = threadIdx.x;
     const int bx = blockIdx.x % CGP_NBX, by = blockIdx.x / CGP_NBX;
@@ -176,10 +210,10 @@ __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
     int it = 0;
     bool conv = false, alive = true;
     {
-        double acc0 = 0.0;
+        double acc0 = 0.0, err0 = 0.0;
 #pragma unroll
-        for (int k = 0; k < CGP_PPT; ++k) acc0 += r[k] * r[k];
-        rho = cgp_allsum<false>(slots, &a.ctr[1], acc0, gen, red, gpart, &s_abort, &ok);
+        for (int k = 0; k < CGP_PPT; ++k) fpr_s2_add_prod(acc0, err0, r[k], r[k]);
+        rho = cgp_allsum<false>(slots, &a.ctr[1], acc0, err0, gen, red, fold, &gsum, &s_abort, &ok);
         alive = ok;
         rr = rho;
     }
@@ -210,7 +244,7 @@ __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
             if (rl[m] >= 0) P[rl[m]] = p_ring[m];
         __syncthreads();
         lap(0);   // beta, new p, ring loads, LDS image
-        double acc = 0.0;
+        double acc = 0.0, acce = 0.0;
 #pragma unroll
         for (int k = 0; k < CGP_PPT; ++k) {
             if (inter[k]) {
@@ -218,28 +252,28 @@ __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
                 const int l = li[k];
                 q[k] = (((P[l + 1] - 2 * t) + P[l - 1]) / a.hx2 + ((P[l + lw] - 2 * t) + P[l - lw]) / a.hy2) - a.c * t;   // lap_at
             }
-            if (gi[k] >= 0) acc += p[k] * q[k];
+            if (gi[k] >= 0) fpr_s2_add_prod(acc, acce, p[k], q[k]);
         }
         lap(1);   // operator
-        const double pq = cgp_allsum<false>(slots, &a.ctr[1], acc, gen, red, gpart, &s_abort, &ok);   // barrier 1 of the iteration
+        const double pq = cgp_allsum<false>(slots, &a.ctr[1], acc, acce, gen, red, fold, &gsum, &s_abort, &ok);   // barrier 1 of the iteration
         if (!ok) { alive = false; break; }
         lap(3);   // barrier 1
         // ---- alpha, x and r (krylov.jl:69-72), r.r; the tile-edge values of r go to the neighbours ----
         const double alpha = rho / pq;
-        double acc2 = 0.0;
+        double acc2 = 0.0, acc2e = 0.0;
 #pragma unroll
         for (int k = 0; k < CGP_PPT; ++k) {
             if (gi[k] >= 0) {
                 x[k] = x[k] + alpha * p[k];
                 const double rn = r[k] - alpha * q[k];
                 r[k] = rn;
-                acc2 += rn * rn;
+                fpr_s2_add_prod(acc2, acc2e, rn, rn);
                 if (edge[k]) a.r_glob[gi[k]] = rn;   // plain store: published by the RELEASE of barrier 2 (an atomic store each would be
                                                      // issued behind an s_waitcnt of its own: five serial round trips)
             }
         }
         lap(4);   // update
-        rr = cgp_allsum<true>(slots, &a.ctr[1], acc2, gen, red, gpart, &s_abort, &ok);        // barrier 2 (publishes the r edges)
+        rr = cgp_allsum<true>(slots, &a.ctr[1], acc2, acc2e, gen, red, fold, &gsum, &s_abort, &ok);        // barrier 2 (publishes the r edges)
         if (!ok) { alive = false; break; }
         lap(5);   // barrier 2
     }

@@ -734,13 +734,13 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
     const int fg = flat_grid(N);
     const dim3 g2 = grid2(nx, ny);
     const int np2 = (int)(g2.x * g2.y);
-    if (np2 > FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
+    if (2L * np2 > FPR_MAX_PARTIALS || 2L * fg > FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");   // (s, e) pairs
     // r = p = p_hat = b, x = 0, rho = b.b, state: what every form of the solve starts from (b itself is never written, so a
     // form that gives up -- the persistent kernel on a barrier time-out -- can be followed by another from the start)
     auto start = [&]() -> int {
         k_cg_init<<<fg, 256, 0, s>>>(b, w.r, w.p, w.ph, w.x, N);
         FPR_CHECK_LAUNCH(ctx);
-        if (int rc = fprx_dot_dev(ctx, b, b, N, ctx->scalars + 2)) return rc;
+        if (int rc = fprx_dot2_dev(ctx, b, b, N, ctx->scalars + 2)) return rc;   // krylov.jl:57,64 as a Dot2 sum, like every dot product of cg!
         k_state_init<<<1, 1, 0, s>>>(ctx->state, ctx->scalars + 2, tol, (double)N, 1);
         FPR_CHECK_LAUNCH(ctx);
         return FPR_OK;
@@ -791,7 +791,7 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
     }
     const dim3 gcg((nx + CGX - 1) / CGX, (ny + CGY - 1) / CGY);
     const int npcg = (int)(gcg.x * gcg.y);
-    if (npcg > FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
+    if (2L * npcg > FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
     int done_iters = 0;
     ctx->state_h->done = 0; ctx->state_h->iters = 0; ctx->state_h->last_rms = 0.0;
     while (done_iters < Nmax) {

@@ -105,6 +105,79 @@ static double sumsq_scaled(const double *x, size_t n, double scale) { return pw_
 static double dot(const double *x, const double *y, size_t n) { return pw_dot(x, y, n); }
 #endif
 
+/* Dot2 (Ogita / Rump / Oishi): x.y as if computed in twice the working precision and rounded once.  Every product's
+ * rounding error (an explicit fma: exact, not a contraction) and every addition's (TwoSum) are summed beside the
+ * running sum; fl(s + e) is the exact dot product rounded once up to a relative (depth * eps)^2 -- whatever the
+ * order of the additions.  Used for cg!'s three dot products (krylov.jl:57,64,69,72,83,90), whose summation order the
+ * reference leaves unspecified (Julia's pairwise `sum` on the CPU, CUDA.jl's reduction tree on the GPU): the HIP
+ * kernels form the same sums in their own order and arrive at the same rounded values, so the whole iteration --
+ * alpha, beta, the exit test -- is the same on both sides.  Eight independent lanes so that gcc vectorises. */
+static inline void two_sum(double a, double b, double *s, double *e)
+{
+    const double t = a + b;
+    const double bb = t - a;
+    *e = (a - (t - bb)) + (b - bb);
+    *s = t;
+}
+static void dot2_range(const double *x, const double *y, size_t n, double *s_out, double *e_out)
+{
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8)
+        for (int k = 0; k < 8; ++k) {
+            const double p = x[i + k] * y[i + k];
+            const double pe = fma(x[i + k], y[i + k], -p);
+            double t, d;
+            two_sum(s[k], p, &t, &d);
+            s[k] = t;
+            e[k] += d + pe;
+        }
+    for (; i < n; ++i) {
+        const double p = x[i] * y[i];
+        const double pe = fma(x[i], y[i], -p);
+        double t, d;
+        two_sum(s[0], p, &t, &d);
+        s[0] = t;
+        e[0] += d + pe;
+    }
+    double ts = s[0], te = e[0];
+    for (int k = 1; k < 8; ++k) {
+        double t, d;
+        two_sum(ts, s[k], &t, &d);
+        ts = t;
+        te = (te + e[k]) + d;
+    }
+    *s_out = ts;
+    *e_out = te;
+}
+static double dot2(const double *x, const double *y, size_t n)
+{
+#ifdef _OPENMP
+    int nt = omp_get_max_threads();
+    double ps[256], pe[256];
+    if (nt > 256) nt = 256;
+#pragma omp parallel num_threads(nt)
+    {
+        int t = omp_get_thread_num();
+        size_t lo = n * (size_t)t / (size_t)nt, hi = n * (size_t)(t + 1) / (size_t)nt;
+        dot2_range(x + lo, y + lo, hi - lo, &ps[t], &pe[t]);
+    }
+    double ts = ps[0], te = pe[0];
+    for (int t = 1; t < nt; ++t) {
+        double u, d;
+        two_sum(ts, ps[t], &u, &d);
+        ts = u;
+        te = (te + pe[t]) + d;
+    }
+    return ts + te;
+#else
+    double ts, te;
+    dot2_range(x, y, n, &ts, &te);
+    return ts + te;
+#endif
+}
+double orc_dot2(const double *x, const double *y, size_t n) { return dot2(x, y, n); }
+
 /* sum(x.^2) */
 double orc_sumsq(const double *x, size_t n) { return sumsq_scaled(x, n, 1.0); }
 double orc_dot(const double *x, const double *y, size_t n) { return dot(x, y, n); }
@@ -438,12 +511,13 @@ void orc_laplace_apply2d(const double *T, double hx, double hy, double c, double
 }
 
 /* B9: cg! -- krylov.jl:55-91.  Starts from x=0 and overwrites x_in; p_hat = copy(r) so its boundary
- * keeps b's boundary values for the whole solve (the matvec only writes the interior). */
+ * keeps b's boundary values for the whole solve (the matvec only writes the interior).  `norm` / `sum(a .* b)` are
+ * Dot2 sums (above): the reference does not specify their order, and in twofold precision the order no longer matters. */
 double orc_cg2d(double *x_in, const double *b, double hx, double hy, double c, double tol, int Nmax,
                 int nx, int ny, int *iters_out)
 {
     const size_t N = (size_t)nx * ny;
-    const double normb = sqrt(dot(b, b, N)); /* :57 */
+    const double normb = sqrt(dot2(b, b, N)); /* :57 */
     const double tolb = tol * normb;
     double *r = (double *)malloc(N * sizeof(double));
     double *p = (double *)malloc(N * sizeof(double));
@@ -453,23 +527,23 @@ double orc_cg2d(double *x_in, const double *b, double hx, double hy, double c, d
     memcpy(p, r, N * sizeof(double));
     memcpy(p_hat, r, N * sizeof(double));
     double normr = INFINITY;
-    double rho = dot(r, r, N); /* :64 */
+    double rho = dot2(r, r, N); /* :64 */
     int it = 0;
     for (int i = 1; i <= Nmax; ++i) {
         it = i;
         orc_laplace_apply2d(p, hx, hy, c, p_hat, nx, ny);      /* :68 */
-        const double alpha = rho / dot(p, p_hat, N);            /* :69 */
+        const double alpha = rho / dot2(p, p_hat, N);            /* :69 */
         for (size_t n = 0; n < N; ++n) x[n] = x[n] + alpha * p[n];     /* :70 */
         for (size_t n = 0; n < N; ++n) r[n] = r[n] - alpha * p_hat[n]; /* :71 */
-        normr = sqrt(dot(r, r, N));                              /* :72 */
+        normr = sqrt(dot2(r, r, N));                              /* :72 */
         if (normr < tolb) break;                                 /* :76 */
         const double rho_old = rho;
-        rho = dot(r, r, N);                                      /* :83 */
+        rho = dot2(r, r, N);                                      /* :83 */
         const double beta = rho / rho_old;
         for (size_t n = 0; n < N; ++n) p[n] = r[n] + beta * p[n]; /* :85 */
     }
     memcpy(x_in, x, N * sizeof(double)); /* :88 */
-    const double out = sqrt(dot(r, r, N) / (double)N); /* :90 */
+    const double out = sqrt(dot2(r, r, N) / (double)N); /* :90 */
     if (iters_out) *iters_out = it;
     free(r); free(p); free(p_hat); free(x);
     return out;

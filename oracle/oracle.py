@@ -44,6 +44,7 @@ class Oracle:
         sig = {
             "orc_sumsq": (d, [_dp, z]),
             "orc_dot": (d, [_dp, _dp, z]),
+            "orc_dot2": (d, [_dp, _dp, z]),
             "orc_has_openmp": (i, []),
             "orc_diffusion3d_step": (None, [_dp] * 4 + [i] * 3 + [d] * 8),
             "orc_diffusion3d_flux": (None, [_dp] * 4 + [i] * 3 + [d] * 4),

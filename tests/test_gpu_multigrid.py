@@ -118,9 +118,11 @@ def test_cg_matches_oracle(fpr, oracle):
     x = F.asdevice(np.full((n, n), 5.0))  # cg! starts from zero and overwrites x_in
     r, it = mg.cg_(x, F.asdevice(b), h, h, 3.14, 1e-6, 1000, return_iters=True)
     assert r < 1e-6 * math.sqrt((b ** 2).sum() / n ** 2)
+    # cg!'s dot products are Dot2 sums on both sides (twofold precision, rounded once: order-independent), everything else is
+    # pointwise: the same iterates bit for bit
     assert it == it_ref
-    assert abs(r - r_ref) <= 1e-8 * r_ref
-    assert np.abs(F.tonumpy(x) - xr).max() <= 1e-10 * np.abs(xr).max()
+    assert r == r_ref
+    assert np.array_equal(F.tonumpy(x), xr)
     # rhs with non-zero boundary (as the Neumann rows of a restricted residual): p_hat keeps b's boundary
     b2 = rnd((33, 17), 9)
     xr = farr(33, 17)
@@ -128,16 +130,17 @@ def test_cg_matches_oracle(fpr, oracle):
     r_ref, it_ref = oracle.cg2d(xr, b2, 0.1, 0.1, 1.0, 1e-8, 12)
     x = F.fzeros(33, 17)
     r, it = mg.cg_(x, F.asdevice(b2), 0.1, 0.1, 1.0, 1e-8, 12, return_iters=True)
-    assert it == it_ref == 12 and abs(r - r_ref) <= 1e-9 * abs(r_ref)
-    assert np.abs(F.tonumpy(x) - xr).max() <= 1e-9 * np.abs(xr).max()
+    assert it == it_ref == 12 and r == r_ref
+    assert np.array_equal(F.tonumpy(x), xr)
 
 
 @pytest.mark.parametrize("shape,nmax", [((257, 257), 700), ((66, 66), 1000), ((33, 17), 12), ((130, 35), 5), ((257, 65), 64),
                                          ((65, 257), 65), ((40, 9), 129)], ids=str)
-def test_cg_launch_forms_agree_bit_for_bit(fpr, shape, nmax):
-    """cg! as two dependent launches per iteration (default: the direction update rides in the next matvec), three, or
-    five (one kernel per operation): the same operations on the same operands -- x, the returned residual and the
-    iteration count are identical, whether the solve converges, stops at Nmax, or crosses a host-poll boundary (64)."""
+def test_cg_launch_forms_agree_bit_for_bit(fpr, oracle, shape, nmax):
+    """cg! as ONE persistent launch (default where the grid fits 16 workgroups), as two dependent launches per iteration (the
+    direction update rides in the next matvec), three, or five (one kernel per operation): the same operations on the same
+    operands, dot products as Dot2 sums (order-independent) -- x, the returned residual and the iteration count are identical
+    among all four AND equal to the oracle's, whether the solve converges, stops at Nmax, or crosses a host-poll boundary (64)."""
     F, mg = fpr, fpr.multigrid
     c = F.ctx()
     b = rnd(shape, 77)
@@ -146,33 +149,21 @@ def test_cg_launch_forms_agree_bit_for_bit(fpr, shape, nmax):
         b[:, 0] = b[:, -1] = 0.0
     outs = []
     try:
-        for form in (2, 1, 0):
+        for form in (3, 2, 1, 0):
             c.set_option("cg_fused", form)
             x = F.asdevice(np.full(shape, 3.0))
             r, it = mg.cg_(x, F.asdevice(b), 0.05, 0.07, 0.9, 1e-7, nmax, return_iters=True)
             outs.append((r, it, F.tonumpy(x)))
-        # the persistent single-launch form (default where the grid fits 16 workgroups): the same iteration with the dot
-        # products summed in another order -- agrees to rounding; the iteration count may move by a few where the
-        # residual norm crosses the threshold on a plateau
-        c.set_option("cg_fused", 3)
-        x = F.asdevice(np.full(shape, 3.0))
-        r3, it3 = mg.cg_(x, F.asdevice(b), 0.05, 0.07, 0.9, 1e-7, nmax, return_iters=True)
-        x3 = F.tonumpy(x)
     finally:
         c.set_option("cg_fused", 3)
     for r, it, x in outs[1:]:
         assert it == outs[0][1] and r == outs[0][0]
         assert np.array_equal(x, outs[0][2])
     assert outs[0][1] <= nmax and np.isfinite(outs[0][2]).all()
-    r0, it0, x0 = outs[0]
-    assert np.isfinite(x3).all() and it3 <= nmax
-    if it0 < nmax:    # converged: same solution to the solver's tolerance, iteration counts within a few
-        assert abs(it3 - it0) <= max(3, it0 // 50)
-        assert np.abs(x3 - x0).max() <= 1e-6 * max(np.abs(x0).max(), 1e-300)
-    else:             # stopped at Nmax: the same iterates up to rounding growth
-        assert it3 == nmax
-        assert np.abs(x3 - x0).max() <= 1e-7 * max(np.abs(x0).max(), 1e-300)
-        assert abs(r3 - r0) <= 1e-6 * abs(r0)
+    xr = farr(*shape)
+    r_ref, it_ref = oracle.cg2d(xr, b, 0.05, 0.07, 0.9, 1e-7, nmax)
+    assert it_ref == outs[0][1] and r_ref == outs[0][0]
+    assert np.array_equal(xr, outs[0][2])
 
 
 @pytest.mark.parametrize("solver", ["jacobi", "conjugate_gradient"])
@@ -181,25 +172,27 @@ def test_cg_launch_forms_agree_bit_for_bit(fpr, shape, nmax):
 def test_single_vcycle_matches_oracle(fpr, oracle, shape, css, bc, c, solver):
     F, mg = fpr, fpr.multigrid
     u0, f = rnd(shape, 21), rnd(shape, 22)
-    if solver == "conjugate_gradient":
-        # cg! keeps b's boundary inside p_hat (krylov.jl:59-61): with a non-zero boundary on the coarse rhs
-        # (random f, or the Neumann rows of apply_BCs) the iteration is inconsistent and blows up to
-        # 1e10..NaN in the oracle as well -- chaotic, so parity is only meaningful on well-posed input.
-        if bc:
-            pytest.skip("CG coarse solve with Neumann rows on the coarse rhs diverges in the reference algorithm")
+    if solver == "conjugate_gradient" and not bc:
+        # cg! keeps b's boundary inside p_hat (krylov.jl:59-61): with a non-zero boundary on the coarse rhs (random f, or the
+        # Neumann rows of apply_BCs) the iteration is inconsistent and grows to 1e10..NaN in the oracle as well.  The well-posed
+        # case gets a zero boundary; the Neumann case (bc) runs as it is -- through round 3 it was skipped as chaotic, but with
+        # Dot2 dot products both sides walk through the same iterates bit for bit, wherever they lead.
         f[0, :] = f[-1, :] = 0.0
         f[:, 0] = f[:, -1] = 0.0
     h = 1.0 / (shape[1] - 1)
     sv = getattr(mg, solver)
     u_ref = u0.copy(order="F")
-    r_ref = oracle.vcycle2d(u_ref, f, h, c, 1e-7, css, sv.value, bc)
-    it_ref = None
+    with np.errstate(all="ignore"):
+        r_ref = oracle.vcycle2d(u_ref, f, h, c, 1e-7, css, sv.value, bc)
+    if solver == "conjugate_gradient" and bc and not (abs(r_ref) < 1e3 * np.abs(f).max()):
+        # the inconsistent coarse system let CG run away (residual 1e12 and beyond): sums that cancel to nothing are beyond
+        # twofold precision too, and what comes out is rounding noise on both sides
+        pytest.skip("CG coarse solve with Neumann rows on the coarse rhs diverges in the reference algorithm (oracle residual %.3g)" % r_ref)
     gu = F.asdevice(u0)
     r = mg.Vcycle_2DPoisson_(gu, F.asdevice(f), h, c, 1e-7, css, sv, mg.parallel_shmem, bc)
-    assert abs(r - r_ref) <= 1e-10 * abs(r_ref)
-    got = F.tonumpy(gu)
-    tol = 0.0 if solver == "jacobi" else 1e-9 * np.abs(u_ref).max()
-    assert np.abs(got - u_ref).max() <= tol  # Jacobi coarse solve: same sweep count => bit-exact
+    assert (math.isnan(r) and math.isnan(r_ref)) or abs(r - r_ref) <= 1e-10 * abs(r_ref)
+    # same sweep / iteration counts, pointwise kernels and order-independent dot products: bit-exact with either coarse solver
+    assert np.array_equal(F.tonumpy(gu), u_ref, equal_nan=True)
 
 
 def test_vcycle_errors(fpr):
@@ -306,16 +299,10 @@ def test_full_size_4097_properties(fpr):
     assert r5 < 1e-6 * frms and len(hist5) <= 12 and cit > 0
 
 
-# CG coarse solver on large coarse grids (documented exception, BASELINE.md 2 / DESIGN 2): the coarse problem is solved to
-# tol * ||b|| only, and where exactly the ~630 CG iterations of a solve land inside that tolerance depends on the summation
-# order of the dot products (krylov.jl:64,69,83) -- another order on the GPU than in the oracle, both deterministic.
-# Measured at 4097^2, l = 8 (tools/exp_cg_parity.py, profiles/r3_cg_parity.txt), all three launch forms: coarse iteration
-# counts EQUAL in every V-cycle (4397 in total), fields equal to 1e-12, residual history equal to 1e-10 through cycle 4 and
-# to 4.2e-7 at cycle 7 -- the residual itself has shrunk to 4e-7 of rms(f) by then, so in units of the first residual the
-# history agrees to 2e-13 throughout.  Asserted: counts ==, |d hist| <= 1e-10 * hist[0], per-entry 2e-6, field 1e-11.
-CG_HIST_RTOL_PER_ENTRY = 2e-6
-CG_HIST_ATOL_OF_FIRST = 1e-10
-CG_FIELD_RTOL = 1e-11
+# CG coarse solver on large coarse grids: through round 3 a documented exception (the ~630 CG iterations of a coarse solve
+# amplified the different summation orders of the dot products krylov.jl:64,69,83 to 4e-7 in the last residuals of a solve,
+# profiles/r3_cg_parity.txt).  The dot products are now Dot2 sums on both sides (twofold precision, rounded once: the order no
+# longer matters), so a V-cycle with cg! is as exact as one with the Jacobi coarse solver: fields bit for bit, history 1e-10.
 
 
 def test_config3_known_answer_k10_l6_jacobi(fpr, oracle):
@@ -364,7 +351,7 @@ def test_config3_five_levels_4097(fpr, oracle):
     protocol.  Jacobi coarse solver: 44 V-cycles / 226 160 coarse sweeps to tol 1e-6 (the coarse solve is capped at
     20*257 = 5140 sweeps and never converges), first three residuals and the field after three cycles equal to the
     oracle's; CG coarse solver: 7 V-cycles and 4397 coarse iterations in every launch form of cg!, the whole residual history
-    against the oracle's (tolerances and their reason: CG_HIST_* above)."""
+    to north_star's 1e-10 per entry and the field bit for bit against the oracle's."""
     F, mg = fpr, fpr.multigrid
     n = 4097
     h = 1.0 / (n - 1)
@@ -407,10 +394,8 @@ def test_config3_five_levels_4097(fpr, oracle):
             assert len(hist) == 7 and r < 1e-6 * frms and abs(frms - frms_o) <= 1e-13 * frms_o
             assert cit == cit_o, (form, cit, cit_o)        # the stop decision (krylov.jl:71) falls in the same iteration of every solve
             d = np.abs(np.asarray(hist) - np.asarray(hist_o))
-            assert d.max() <= CG_HIST_ATOL_OF_FIRST * hist_o[0], (form, d.tolist())
-            assert (d <= CG_HIST_RTOL_PER_ENTRY * np.asarray(hist_o)).all(), (form, (d / np.asarray(hist_o)).tolist())
-            assert (d[:3] <= 1e-10 * np.asarray(hist_o)[:3]).all()      # north_star's figure holds while the residual is not yet small
-            assert np.abs(F.tonumpy(x) - xo).max() <= CG_FIELD_RTOL * np.abs(xo).max()
+            assert (d <= 1e-10 * np.asarray(hist_o)).all(), (form, (d / np.asarray(hist_o)).tolist())     # north_star's figure, every entry
+            assert np.array_equal(F.tonumpy(x), xo)
     finally:
         c.set_option("cg_fused", 3)
 

@@ -328,3 +328,31 @@ def test_assemble_global_layout():
     G = fpr_amd.pkg.grid.assemble_global(parts, dims)
     assert G.shape == (6, 2, 4)
     assert G[0, 0, 0] == 0 and G[0, 0, 2] == 1 and G[3, 0, 0] == 2 and G[5, 1, 3] == 3
+
+
+def test_dot2_is_the_exactly_rounded_dot_product_in_any_order(oracle):
+    """orc_dot2 (cg!'s dot products, krylov.jl:64,69,83): the exact dot product rounded once, whatever the order of the
+    operands -- checked against rational arithmetic on ill-conditioned data (condition number ~1e7, where the plain pairwise
+    dot loses 7 digits; Dot2's error bound eps + (n eps)^2 cond stays far below one ulp there) and on a positive sum, forwards,
+    reversed and shuffled.  (cg!'s own sums -- r.r, p.Ap of a definite operator -- have condition numbers near 1.)"""
+    import ctypes as C
+    from fractions import Fraction
+
+    rng = np.random.default_rng(5)
+    n = 4099
+    x = rng.standard_normal(n) * 10.0 ** rng.integers(-2, 2, n)
+    y = rng.standard_normal(n) * 10.0 ** rng.integers(-2, 2, n)
+    # append the negated head so that most of the sum cancels
+    x2 = np.concatenate([x, -x[: n - 7]])
+    y2 = np.concatenate([y, y[: n - 7]])
+    dp = C.POINTER(C.c_double)
+    for a, b in ((x, x), (x, y), (x2, y2)):
+        exact = float(sum(Fraction(float(u)) * Fraction(float(v)) for u, v in zip(a, b)))
+        perm = rng.permutation(len(a))
+        for aa, bb in ((a, b), (a[::-1].copy(), b[::-1].copy()), (a[perm], b[perm])):
+            aa, bb = np.ascontiguousarray(aa), np.ascontiguousarray(bb)
+            got = oracle.lib.orc_dot2(aa.ctypes.data_as(dp), bb.ctypes.data_as(dp), len(aa))
+            assert got == exact, (got, exact)
+    plain = oracle.lib.orc_dot(np.ascontiguousarray(x2).ctypes.data_as(dp), np.ascontiguousarray(y2).ctypes.data_as(dp), len(x2))
+    exact = float(sum(Fraction(float(u)) * Fraction(float(v)) for u, v in zip(x2, y2)))
+    assert plain != exact            # (what Dot2 buys on this input)

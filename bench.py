@@ -540,6 +540,59 @@ def host_staged_p2p(torch, dist):
     return P2P()
 
 
+def device_state(index=0):
+    """Clocks, power and the power cap of the card, read IN PROCESS from librocm_smi64 (what `rocm-smi --showclocks --showpower`
+    prints) -- one call, outside every timed region -- so that a reader can tell a slow box from a slow kernel (the same binary
+    ran the dominant kernel in 0.796-0.856 ms on four boxes).  No child process: a process that has initialised the GPU must not
+    fork + exec on this pool, and rocm-smi itself is a python script."""
+    import ctypes as C
+
+    try:
+        L = C.CDLL("librocm_smi64.so")
+    except OSError:
+        try:
+            L = C.CDLL("/opt/rocm/lib/librocm_smi64.so")
+        except OSError as e:
+            return {"error": repr(e)}
+
+    class Freqs(C.Structure):
+        _fields_ = [("has_deep_sleep", C.c_bool), ("num_supported", C.c_uint32), ("current", C.c_uint32), ("frequency", C.c_uint64 * 33)]
+
+    out = {}
+    try:
+        if L.rsmi_init(C.c_uint64(0)) != 0:
+            return {"error": "rsmi_init failed"}
+        n = C.c_uint32(0)
+        L.rsmi_num_monitor_devices(C.byref(n))
+        out["rsmi_devices"] = n.value
+        dv = C.c_uint32(index if index < n.value else 0)
+        for name, kind in (("sclk_MHz", 0), ("fclk_MHz", 1), ("socclk_MHz", 3), ("mclk_MHz", 4)):
+            f = Freqs()
+            if L.rsmi_dev_gpu_clk_freq_get(dv, C.c_int(kind), C.byref(f)) == 0 and f.num_supported > 0 and f.current < 33:
+                out[name] = f.frequency[f.current] / 1e6
+                out[name + "_levels"] = [f.frequency[i] / 1e6 for i in range(min(f.num_supported, 33))]
+        v = C.c_uint64(0)
+        t = C.c_int(0)
+        if L.rsmi_dev_power_get(dv, C.byref(v), C.byref(t)) == 0:
+            out["power_W"] = v.value / 1e6
+            out["power_kind"] = {0: "average", 1: "current socket"}.get(t.value, str(t.value))
+        if L.rsmi_dev_power_cap_get(dv, C.c_uint32(0), C.byref(v)) == 0:
+            out["power_cap_W"] = v.value / 1e6
+        tv = C.c_int64(0)
+        for name, sensor in (("temp_edge_C", 0), ("temp_junction_C", 1), ("temp_memory_C", 2)):
+            if L.rsmi_dev_temp_metric_get(dv, C.c_uint32(sensor), C.c_int(0), C.byref(tv)) == 0:
+                out[name] = tv.value / 1e3
+        uid = C.c_uint64(0)
+        if L.rsmi_dev_unique_id_get(dv, C.byref(uid)) == 0:
+            out["unique_id"] = "0x%x" % uid.value
+        lvl = C.c_int(0)
+        if L.rsmi_dev_perf_level_get(dv, C.byref(lvl)) == 0:
+            out["perf_level"] = {0: "auto", 1: "low", 2: "high", 3: "manual"}.get(lvl.value, str(lvl.value))
+    except Exception as e:
+        out["error"] = repr(e)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------
 # the norm of a decomposed run against the single-domain control (tests/golden/scale_norms.json)
 # ------------------------------------------------------------------------------------------------------------
@@ -633,6 +686,7 @@ def main():
                          "watchdog's fallback")
     ap.add_argument("--watchdog-s", type=float, default=120.0, help="N > 1: seconds without progress of a rank before the attempt is failed")
     ap.add_argument("--watchdog-import-s", type=float, default=420.0, help="the same before the worker has imported torch (fresh box)")
+    ap.add_argument("--no-power-probe", action="store_true", help="skip the clocks / power diagnostic (about 2 s, outside the timed regions)")
     ap.add_argument("--no-norm-check", action="store_true", help="N > 1: do not compare the norm with tests/golden/scale_norms.json")
     ap.add_argument("--golden-norms", type=str, default="",
                     help="FILE: control runs on ONE rank (as --as-one-rank-of) of the global problems the decomposed runs solve; "
@@ -867,9 +921,12 @@ def main():
             r["launches_by_kind"] = {"single_step_boxes": kt[KT_STEP][1], "fused_boxes": kt[KT_STEP2][1] + kt[KT_CORE][1], "core": kt[KT_CORE][1]}
             r["shell_launches_ms_total"] = kt[KT_STEP][0] + kt[KT_STEP2][0]
         if traffic_entry:
+            # counters come from a committed rocprofv3 --pmc run on ANOTHER box (its id in traffic_source): a property of the
+            # kernel (bytes per launch), not divided by this box's kernel time
             r["traffic"] = traffic_entry["traffic_bytes_per_launch"]
             r["traffic_source"] = traffic_entry.get("source")
-            r["achieved_traffic"] = r["traffic"] / (kms * 1e-3) / 1e9 if kms > 0 else None
+            r["traffic_box"] = traffic_entry.get("box")
+            r["traffic_over_algorithmic"] = r["traffic"] / nbytes if nbytes else None
         return r
 
     def traffic_for(fused):
@@ -884,6 +941,7 @@ def main():
         return None
 
     main_fused = can_fuse2 and not args.no_fuse2 and not (world > 1 and choreography == "plain")
+    dev_before = device_state(device_index) if rank == 0 else None
     elapsed, kt, extra = timed_leg(main_fused, args.prewarm_ms)
     last_err = errs[-1] if errs else None
     last_sumsq = sums[-1] if sums else None
@@ -926,6 +984,9 @@ def main():
         "roofline": roofline,
         "legs": legs,
     }
+    if rank == 0:
+        out["device_state"] = {"before_timed_region": dev_before, "after_timed_region": device_state(device_index),
+                               "host": socket.gethostname(), "note": "rocm-smi, one call each, outside the timed region"}
     if first_failure is not None:
         out["first_attempt"] = first_failure      # the watchdog failed the first attempt; this line comes from the fallback
     norm_failed = False
@@ -982,6 +1043,7 @@ def main():
         try:
             if args.no_neighbour_leg:
                 raise RuntimeError("skipped (--no-neighbour-leg)")
+            gp = None
             gp = F.grid.GlobalGrid(*nloc, dims=(1, 1, 1), periods=(0, 0, 1), transport="rccl", use_dist=False)
             state["cur"] = Hτ
             def pair_z(nsteps):
@@ -1015,10 +1077,68 @@ def main():
                 "note": "one rank, periodic in z = its own neighbour over ncclSend / ncclRecv (RCCL, comm stream of the CU-split "
                         "device); two faces with a neighbour like an interior rank of (1,1,N); a projection from one card, link "
                         "time not included (hidden behind the core launch by construction)"}
-            F.grid.finalize_global_grid()
-            ctx.reserve_comm_cus(0)
         except Exception as e:   # a projection, never required for the GPU number
             legs["fused_pairs_as_interior_rank_of_z_slabs"] = {"error": repr(e)}
+        finally:
+            # whatever happened in the leg: no pair left pending, the single-rank RCCL grid gone, the device unsplit -- the blocks
+            # that follow (and the second context) run in the state they expect; a failure here must not mask the leg's own
+            for undo in (lambda: gp.join(), F.grid.finalize_global_grid, lambda: ctx.reserve_comm_cus(0), ctx.synchronize):
+                try:
+                    undo()
+                except Exception:
+                    pass
+    # Clocks and power UNDER each kernel (a diagnostic outside every timed region): the same launches for about a second each while a
+    # host thread reads librocm_smi64 every 20 ms.  The fused kernel does twice the FP64 work per byte of the one-iteration kernel;
+    # whether the card holds its clocks under that load is what separates a slow box from a slow kernel.
+    if rank == 0 and world == 1 and main_fused and not args.no_power_probe and not as_one:
+        try:
+            import threading
+
+            def probe(fn, seconds):
+                samples, stop = [], threading.Event()
+
+                def sampler():
+                    while not stop.is_set():
+                        d = device_state(device_index)
+                        samples.append((d.get("sclk_MHz"), d.get("power_W"), d.get("fclk_MHz"), d.get("mclk_MHz"), d.get("temp_junction_C")))
+                        stop.wait(0.02)
+
+                fn(16)
+                torch.cuda.synchronize()
+                th = threading.Thread(target=sampler, daemon=True)
+                t0 = time.perf_counter()
+                th.start()
+                n = 0
+                while time.perf_counter() - t0 < seconds:
+                    fn(32)
+                    torch.cuda.synchronize()
+                    n += 32
+                dt = time.perf_counter() - t0
+                stop.set()
+                th.join(2.0)
+                late = samples[len(samples) // 3:] or samples     # the first third is the ramp
+                avg = lambda k: (sum(x[k] for x in late if x[k] is not None) / max(sum(1 for x in late if x[k] is not None), 1)) if late else None
+                mn = lambda k: min((x[k] for x in late if x[k] is not None), default=None)
+                return {"ms_per_iteration": dt / n * 1e3, "iterations": n, "samples": len(samples), "sclk_MHz_avg": avg(0), "sclk_MHz_min": mn(0),
+                        "power_W_avg": avg(1), "fclk_MHz_avg": avg(2), "mclk_MHz_avg": avg(3), "temp_junction_C_avg": avg(4)}
+
+            state["cur"], state["parity"] = Hτ, 0
+
+            def fused_n(k):
+                run(k, 0, True)
+
+            def single_n(k):
+                run(k, 0, False)
+
+            pp = {"fused_pairs": probe(fused_n, 1.0)}
+            state["cur"], state["parity"] = Hτ, 0
+            pp["single_steps"] = probe(single_n, 1.0)
+            pp["idle"] = device_state(device_index)
+            pp["note"] = ("about one second of back-to-back launches per kernel, librocm_smi64 read every 20 ms by a host thread (first third dropped); "
+                          "not part of any timed region")
+            out["power_probe"] = pp
+        except Exception as e:
+            out["power_probe"] = {"error": repr(e)}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             try:

@@ -409,7 +409,10 @@ def vcycle_block(F, with_cpu=True, steps=5):
     cg_ms, cg_solves = kern.get("l8_cg", (0.0, 0))
     cg_its = max(out["l8_cg"]["coarse_iters"], 1)
     us_per_cg_it = cg_ms * 1e3 / cg_its if cg_ms > 0 else None
-    CG_FLOOR_US = 4.2      # two grid barriers of 16 workgroups per iteration, 2.1 us each (profiles/r2_cg_persistent_sections.txt)
+    # krylov.jl's recurrence needs p.p_hat before alpha and r.r before beta: two all-to-all hand-offs per iteration that nothing can hide.
+    # Floor = two device-scope store -> poll hand-offs at the idle price MI355X_MICROARCH.md lists (1.0 us cross-XCD, 8 bytes); the sums
+    # in front of and behind each hand-off, the operator and the updates are what the kernel adds (profiles/r4_cg_persistent_sections.txt)
+    CG_FLOOR_US = 2.0
     pt_ms, pt_launches = kern.get("l8_jacobi", (0.0, 0))
     us_per_launch = pt_ms * 1e3 / pt_launches if pt_launches else None
     PATCH_FIXED_US, PATCH_SWEEP_US = 4.5, 0.70     # a launch of 8 sweeps = 4.5 us fixed + 0.70 us per sweep
@@ -421,16 +424,17 @@ def vcycle_block(F, with_cpu=True, steps=5):
             "conjugate_gradient": {
                 "value": out["l8_cg"]["s_per_vcycle"], "unit": "s", "mgsolve_s": out["l8_cg"]["mgsolve_s"], "vcycles": out["l8_cg"]["vcycles"],
                 "coarse_iters": out["l8_cg"]["coarse_iters"],
-                "roofline": {"bound": "latency", "kernel": "k_cg_persistent (one launch per coarse solve: 16 workgroups, x / r / p / p_hat in "
-                                                           "registers, two grid barriers per CG iteration)",
+                "roofline": {"bound": "latency", "kernel": "k_cg_persistent (one launch per coarse solve: 64 workgroups of 256 threads, x / r / p / "
+                                                           "p_hat in registers, Dot2 dot products, two grid barriers per CG iteration)",
                              "achieved": us_per_cg_it, "peak": CG_FLOOR_US, "unit": "us per CG iteration",
                              "frac": (CG_FLOOR_US / us_per_cg_it) if us_per_cg_it else None,
                              "launches": cg_solves, "kernel_ms_total": cg_ms,
                              "share_of_solve": cg_ms * 1e-3 / out["l8_cg"]["mgsolve_s"] if out["l8_cg"]["mgsolve_s"] > 0 else None,
                              "traffic": None,
-                             "note": "achieved = hipEvent time of all k_cg_persistent launches of one solve / CG iterations; peak = the floor "
-                                     "of two barrier round trips per iteration (krylov.jl's recurrence needs p.p_hat before alpha and "
-                                     "r.r before beta); frac = floor / achieved"}},
+                             "note": "achieved = hipEvent time of all k_cg_persistent launches of one solve / CG iterations; peak = two "
+                                     "device-scope store -> poll hand-offs per iteration at 1.0 us each (krylov.jl's recurrence needs p.p_hat "
+                                     "before alpha and r.r before beta; rounds 2-3 quoted the measured cost of two whole barriers, 4.2 us, as the "
+                                     "floor and ran at 6.75 us); frac = floor / achieved"}},
             "jacobi": {
                 "value": out["l8_jacobi"]["s_per_vcycle"], "unit": "s", "mgsolve_s": out["l8_jacobi"]["mgsolve_s"], "vcycles": out["l8_jacobi"]["vcycles"],
                 "coarse_iters": out["l8_jacobi"]["coarse_iters"],

@@ -18,8 +18,14 @@
 // and product's rounding error is carried along and the total rounded once), summed per workgroup and then over the 16
 // workgroups -- another order than the 64x4-tile partials of the other forms, the same value: all forms and the oracle agree
 // bit for bit.
-constexpr int CGP_NB = 16, CGP_NBX = 4, CGP_NT = 1024, CGP_PPT = 5, CGP_RPT = 1;   // workgroups, threads, tile / ring points per thread
-// (256 threads x 17 points: 9.0 us per iteration against 6.5 -- the two divisions per point of lap_at then weigh 2.8 us)
+// Two geometries (template parameters NB workgroups as NBX x NBX tiles, NT threads each; <= 5 points per thread either way):
+//   16 x 1024 threads (rounds 2-3): one workgroup per CU on 16 CUs -- four waves per SIMD, so every per-thread instruction costs four
+//             issue slots: 2.4 us of an iteration were arithmetic (7.5 us per iteration with the Dot2 sums of round 4);
+//   64 x 256 threads (round 4 default): the same points on 64 CUs with ONE wave per SIMD.  A barrier is bounded by one store -> poll
+//             hand-off whatever the number of slots a wave polls (64 lanes, one or two words each), so the arithmetic between the
+//             barriers shrinks fourfold at the price of 64 instead of 16 arrivals per barrier.
+constexpr int CGP_PPT = 5, CGP_RPT = 1;   // tile / ring points per thread
+// (16 x 256 threads x 17 points: 9.0 us per iteration against 6.5 -- the two divisions per point of lap_at then weigh 2.8 us)
 struct CgpArgs {
     const double* b;
     double* x_out;         // solution (whole array written)
@@ -29,91 +35,90 @@ struct CgpArgs {
     FprSolveState* st;
     int nx, ny, Nmax;
     double hx2, hy2, c, tol, N;
+    double ihx2, ihy2;     // pow2: 1 / hx2, 1 / hy2 (exact)
+    int pow2;              // hx2 and hy2 are powers of two (every grid of the multigrid hierarchy: h = 2^-k): x / hx2 == x * (1 / hx2) bit for
+                           // bit -- an exact scaling either way -- and the operator needs no division (two per point: ~0.4 us per iteration)
     long long* prof;       // diagnostic (option cg_prof = device address of 8 int64): ticks of workgroup 0 per section, summed
 };
 
-__device__ __forceinline__ double cgp_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void cgp_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The tile-edge values of r travel between workgroups as `sc1` (write-through / L1-bypassing) stores and loads through a raw buffer
+// descriptor: every byte handed over is stored sc1 and loaded sc1, every storing wave drains its stores (s_waitcnt vmcnt(0)) before
+// the workgroup barrier that precedes the publication of the barrier word, and the readers load after the barrier that follows
+// their poll -- the hand-off form MI355X_MICROARCH.md lists as valid WITHOUT an agent-scope release (buffer_wbl2: 1.7-6.5 us) and
+// acquire (buffer_inv); with both in barrier 2 that barrier cost 3.2 us on 64 workgroups against 2.0 us for barrier 1.
+constexpr int CGP_SC1 = 16;   // cache-policy bit of the raw buffer intrinsics on gfx94x / gfx950: sc1
+__device__ __forceinline__ double cgp_ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, CGP_SC1));
+}
+__device__ __forceinline__ void cgp_st_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff, double v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fpr_u2v, v), r, voff, 0, CGP_SC1);
+}
 
 // Grid barrier and all-reduce in ONE round trip: workgroup b stores its partial sum -- a Dot2 pair (s, e), two words -- into its own
 // two slots of the set that belongs to this barrier; lanes 0..31 of wave 0 of every workgroup each watch one slot until it no longer
 // holds the EMPTY pattern (a NaN payload no sum produces) -- every word is its own arrival flag, so the two need no order.  FOUR sets rotate: when a workgroup publishes for
 // barrier g it first empties its slot of set (g+2) mod 4, last used at barrier g-2 (everybody has read that one: they all
 // published g-1 since).  That slot is polled next at barrier g+2; between the emptying and that poll lie the owner's
-// publications g and g+1, and the barriers alternate between RELEASE (publishes the workgroup's earlier stores -- the tile-edge
-// values of r and the emptying -- acquired by the pollers) and relaxed (nothing but the sum travels), so one of the two orders
-// the emptying before the poll.  Returns the 16 pairs summed in workgroup order and rounded once (s + e), in every thread;
+// publications g and g+1 (stores of one lane to the same cache-line-sized slots, issued in order behind an s_waitcnt).  DRAIN:
+// the barrier that hands over the tile-edge values of r -- every wave waits for its (sc1) stores before the workgroup barrier.  Returns the 16 pairs summed in workgroup order and rounded once (s + e), in every thread;
 // *ok = false if the wait timed out (abort raised for everybody).
 constexpr unsigned long long CGP_EMPTY = 0x7ff8dead0badf00dull;
 constexpr int CGP_SLOT_STRIDE = 16;   // 8-byte words between two slots
-// 16 Dot2 pairs held one word per lane by lanes 0..31 of a wave (lane 2 b = s of pair b, lane 2 b + 1 = its e; lanes >= 32 hold
-// zeros) -> their sum as one pair, the same in every lane: the e words move to the even lanes, three DPP row shifts merge the
-// eight pairs of each 16-lane row, the two row totals are merged last.  A fixed tree -- four merges deep, a handful of registers
-// (summing 32 words one after the other out of LDS in every thread cost 67 spilled VGPRs and 4 us per iteration).
-__device__ __forceinline__ void cgp_merge16(double val, double& s_out, double& e_out)
-{
-    const bool even = (threadIdx.x & 1) == 0;
-    const double up = fpr_dpp<0x101>(val);          // row_shl:1: lane i <- lane i + 1
-    double s = even ? val : 0.0, e = even ? up : 0.0;
-    fpr_s2_merge(s, e, fpr_dpp<0x112>(s), fpr_dpp<0x112>(e));
-    fpr_s2_merge(s, e, fpr_dpp<0x114>(s), fpr_dpp<0x114>(e));
-    fpr_s2_merge(s, e, fpr_dpp<0x118>(s), fpr_dpp<0x118>(e));   // lane 14 of a row: the row's eight pairs
-    auto lane = [](double v, int l) {
-        const int lo = __double2loint(v), hi = __double2hiint(v);
-        return __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l));
-    };
-    double rs = lane(s, 14), re = lane(e, 14);
-    fpr_s2_merge(rs, re, lane(s, 30), lane(e, 30));
-    s_out = rs;
-    e_out = re;
-}
-template <bool RELEASE>
+// Grid barrier + all-reduce.  Inside the workgroup: NT = 1024: the 1024 pairs are folded 4 -> 1 through LDS by the first four waves
+// (one per SIMD) before the DPP wave sums (all 16 waves summing their own lanes, four per SIMD, cost 0.5 us per barrier more);
+// NT = 256: every wave has its SIMD to itself and sums its lanes at once.  The <= 4 wave totals are merged by thread 0 / 1, which
+// publish s / e.  Across workgroups: lane w < NB of wave 0 polls the two words of workgroup w; the NB pairs are summed by one DPP
+// wave sum (lanes >= NB hold zeros): a fixed tree, a handful of registers (summing 32 words one after the other out of LDS in
+// every thread cost 67 spilled VGPRs and 4 us per iteration).
+template <bool DRAIN, int NB, int NT>
 __device__ __forceinline__ double cgp_allsum(unsigned long long* slots, unsigned* abort_flag, double vs, double ve, unsigned& gen, double* red,
                                              double* fold, double* gsum, int* s_abort, bool* ok)
 {
+    static_assert(NB <= 64 && (NT == 256 || NT == 1024), "one polling lane per workgroup; four summing waves per workgroup");
     ++gen;
     // (a slot per 128-byte line: the pollers of different slots do not queue at one memory channel)
-    unsigned long long* set = slots + (gen & 3u) * (2 * CGP_NB * CGP_SLOT_STRIDE);
-    unsigned long long* nxt = slots + ((gen + 2u) & 3u) * (2 * CGP_NB * CGP_SLOT_STRIDE);
-    // The workgroup's 1024 pairs: folded 4 -> 1 through LDS by the first four waves (one per SIMD), whose DPP wave sums then run
-    // without a neighbour on their SIMD (all 16 waves summing their own lanes -- 7 merges of ~14 instructions, four waves per
-    // SIMD -- cost 0.5 us per barrier more), four wave totals to LDS.
-    fold[threadIdx.x] = vs;
-    fold[CGP_NT + threadIdx.x] = ve;
-    __syncthreads();
-    if (threadIdx.x < CGP_NT / 4) {
+    unsigned long long* set = slots + (gen & 3u) * (2 * NB * CGP_SLOT_STRIDE);
+    unsigned long long* nxt = slots + ((gen + 2u) & 3u) * (2 * NB * CGP_SLOT_STRIDE);
+    if constexpr (NT == 1024) {
+        fold[threadIdx.x] = vs;
+        fold[NT + threadIdx.x] = ve;
+        __syncthreads();
+        if (threadIdx.x < NT / 4) {
 #pragma unroll
-        for (int k = 1; k < 4; ++k) fpr_s2_merge(vs, ve, fold[threadIdx.x + k * (CGP_NT / 4)], fold[CGP_NT + threadIdx.x + k * (CGP_NT / 4)]);
+            for (int k = 1; k < 4; ++k) fpr_s2_merge(vs, ve, fold[threadIdx.x + k * (NT / 4)], fold[NT + threadIdx.x + k * (NT / 4)]);
+        }
+    }
+    if (threadIdx.x < 256) {
         fpr_wave_sum_all_s2(vs, ve);
         if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = vs; red[2 * (threadIdx.x >> 6) + 1] = ve; }
     }
-    // wave totals in LDS; the workgroup's earlier stores precede the publication below.  The tile-edge values of r were
-    // written with PLAIN stores by many threads; this barrier orders them before threads 0 / 1 at workgroup scope, and their
-    // agent-scope RELEASE stores are cumulative over everything that happens-before them (the AMDGPU memory model composes
-    // scopes that include one another), so a poller's agent-scope acquire of the slot sees them: the usual grid-sync pattern
+    // wave totals in LDS; the workgroup's earlier sc1 stores (tile-edge values of r) have left every wave before the barrier, the
+    // barrier words are published behind it
+    if constexpr (DRAIN) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
     if (threadIdx.x < 64) {                // wave 0 sums the workgroup, publishes, polls and sums the grid
         const int w = threadIdx.x;
-        static_assert(CGP_NT / 256 <= 16 && CGP_NB == 16, "cgp_merge16 sums up to 16 pairs");
-        double bs, be;
-        cgp_merge16(w < 2 * (CGP_NT / 256) ? red[w] : 0.0, bs, be);
         if (w < 2) {                       // thread 0 publishes s, thread 1 e
+            double bs = red[0], be = red[1];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) fpr_s2_merge(bs, be, red[2 * k], red[2 * k + 1]);
             const int slot = (2 * blockIdx.x + w) * CGP_SLOT_STRIDE;
             __hip_atomic_store(&nxt[slot], CGP_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned long long bits = (unsigned long long)__double_as_longlong(w == 0 ? bs : be);
             if (bits == CGP_EMPTY) bits ^= 1ull;   // (a sum that happens to be this very NaN stays a NaN)
-            if (RELEASE) __hip_atomic_store(&set[slot], bits, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            else __hip_atomic_store(&set[slot], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&set[slot], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         int ab = 0;
-        double val = 0.0;
-        if (w < 2 * CGP_NB) {              // lane w waits for word w & 1 of workgroup w >> 1
+        double gs = 0.0, ge = 0.0;
+        if (w < NB) {                      // lane w waits for the two words of workgroup w (each its own arrival flag)
             unsigned spins = 0;
-            unsigned long long bits;
+            unsigned long long b0 = CGP_EMPTY, b1 = CGP_EMPTY;
             while (true) {
-                bits = RELEASE ? __hip_atomic_load(&set[w * CGP_SLOT_STRIDE], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
-                               : __hip_atomic_load(&set[w * CGP_SLOT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (bits != CGP_EMPTY) break;
+                if (b0 == CGP_EMPTY) b0 = __hip_atomic_load(&set[(2 * w) * CGP_SLOT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (b1 == CGP_EMPTY) b1 = __hip_atomic_load(&set[(2 * w + 1) * CGP_SLOT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (b0 != CGP_EMPTY && b1 != CGP_EMPTY) break;
                 if ((++spins & 0x3ff) == 0) {
                     if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
                     if (spins > (1u << 22)) {   // seconds, not minutes
@@ -123,11 +128,11 @@ __device__ __forceinline__ double cgp_allsum(unsigned long long* slots, unsigned
                     }
                 }
             }
-            val = __longlong_as_double((long long)bits);
+            gs = __longlong_as_double((long long)b0);
+            ge = __longlong_as_double((long long)b1);
         }
         ab = __any(ab);
-        double gs, ge;
-        cgp_merge16(val, gs, ge);
+        fpr_wave_sum_all_s2(gs, ge);
         if (threadIdx.x == 0) { *s_abort = ab; *gsum = gs + ge; }
     }
     __syncthreads();
@@ -135,16 +140,18 @@ __device__ __forceinline__ double cgp_allsum(unsigned long long* slots, unsigned
     return *gsum;
 }
 
-__global__ void k_cgp_slots_init(unsigned long long* slots)
+__global__ void k_cgp_slots_init(unsigned long long* slots, int nb)
 {
-    for (int t = threadIdx.x; t < 4 * 2 * CGP_NB; t += blockDim.x) slots[t * CGP_SLOT_STRIDE] = CGP_EMPTY;
+    for (int t = threadIdx.x; t < 4 * 2 * nb; t += blockDim.x) slots[t * CGP_SLOT_STRIDE] = CGP_EMPTY;
 }
 
+template <int CGP_NB, int CGP_NBX, int CGP_NT>
 __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
 {
+    static_assert(CGP_NBX * CGP_NBX == CGP_NB, "square arrangement of tiles");
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    __shared__ double red[2 * (CGP_NT / 64)];
-    __shared__ double fold[2 * CGP_NT];
+    __shared__ double red[8];
+    __shared__ double fold[CGP_NT == 1024 ? 2 * CGP_NT : 2];
     __shared__ double gsum;
     __shared__ int s_abort;
     const int tid = threadIdx.x;
@@ -158,6 +165,7 @@ __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
     const int npt = tw * th;                       // points of this tile (0: the workgroup only takes part in the barriers)
     const int lw = twm + 2;                        // LDS row length: tile + ring
     double* P = sm;                                // (thm + 2) x lw image of p: tile cell (ti, tj) at (ti + 1) + lw * (tj + 1)
+    const __amdgpu_buffer_rsrc_t rR = fpr_rsrc(a.r_glob);   // tile-edge values of r (sc1 stores / loads)
     unsigned gen = 0;
     unsigned long long* slots = reinterpret_cast<unsigned long long*>(a.part);   // 4 sets x 16 slots, all EMPTY at the start
     bool ok = true;
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
         double acc0 = 0.0, err0 = 0.0;
 #pragma unroll
         for (int k = 0; k < CGP_PPT; ++k) fpr_s2_add_prod(acc0, err0, r[k], r[k]);
-        rho = cgp_allsum<false>(slots, &a.ctr[1], acc0, err0, gen, red, fold, &gsum, &s_abort, &ok);
+        rho = cgp_allsum<false, CGP_NB, CGP_NT>(slots, &a.ctr[1], acc0, err0, gen, red, fold, &gsum, &s_abort, &ok);
         alive = ok;
         rr = rho;
     }
@@ -233,8 +241,8 @@ __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
 #pragma unroll
             for (int k = 0; k < CGP_PPT; ++k) p[k] = r[k] + beta * p[k];
 #pragma unroll
-            for (int m = 0; m < CGP_RPT; ++m)   // acquired at barrier 2 by wave 0 (cache invalidate), workgroup barrier since
-                if (rg[m] >= 0) p_ring[m] = a.r_glob[rg[m]] + beta * p_ring[m];
+            for (int m = 0; m < CGP_RPT; ++m)   // sc1 loads behind barrier 2 (its poll, then the workgroup barrier)
+                if (rg[m] >= 0) p_ring[m] = cgp_ld_sc1(rR, (unsigned)rg[m] * 8u) + beta * p_ring[m];
         }
 #pragma unroll
         for (int k = 0; k < CGP_PPT; ++k)
@@ -250,12 +258,13 @@ __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
             if (inter[k]) {
                 const double t = p[k];
                 const int l = li[k];
-                q[k] = (((P[l + 1] - 2 * t) + P[l - 1]) / a.hx2 + ((P[l + lw] - 2 * t) + P[l - lw]) / a.hy2) - a.c * t;   // lap_at
+                const double dxx = (P[l + 1] - 2 * t) + P[l - 1], dyy = (P[l + lw] - 2 * t) + P[l - lw];
+                q[k] = a.pow2 ? (dxx * a.ihx2 + dyy * a.ihy2) - a.c * t : (dxx / a.hx2 + dyy / a.hy2) - a.c * t;   // lap_at
             }
             if (gi[k] >= 0) fpr_s2_add_prod(acc, acce, p[k], q[k]);
         }
         lap(1);   // operator
-        const double pq = cgp_allsum<false>(slots, &a.ctr[1], acc, acce, gen, red, fold, &gsum, &s_abort, &ok);   // barrier 1 of the iteration
+        const double pq = cgp_allsum<false, CGP_NB, CGP_NT>(slots, &a.ctr[1], acc, acce, gen, red, fold, &gsum, &s_abort, &ok);   // barrier 1 of the iteration
         if (!ok) { alive = false; break; }
         lap(3);   // barrier 1
         // ---- alpha, x and r (krylov.jl:69-72), r.r; the tile-edge values of r go to the neighbours ----
@@ -268,12 +277,12 @@ __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
                 const double rn = r[k] - alpha * q[k];
                 r[k] = rn;
                 fpr_s2_add_prod(acc2, acc2e, rn, rn);
-                if (edge[k]) a.r_glob[gi[k]] = rn;   // plain store: published by the RELEASE of barrier 2 (an atomic store each would be
-                                                     // issued behind an s_waitcnt of its own: five serial round trips)
+                if (edge[k]) cgp_st_sc1(rR, (unsigned)gi[k] * 8u, rn);   // write-through; drained before barrier 2 publishes (an atomic
+                                                                         // store each would be issued behind an s_waitcnt of its own)
             }
         }
         lap(4);   // update
-        rr = cgp_allsum<true>(slots, &a.ctr[1], acc2, acc2e, gen, red, fold, &gsum, &s_abort, &ok);        // barrier 2 (publishes the r edges)
+        rr = cgp_allsum<true, CGP_NB, CGP_NT>(slots, &a.ctr[1], acc2, acc2e, gen, red, fold, &gsum, &s_abort, &ok);        // barrier 2 (publishes the r edges)
         if (!ok) { alive = false; break; }
         lap(5);   // barrier 2
     }

@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "fpr_internal.hpp"
+#include <cmath>
 
 #define BX 64
 #define BY 4
@@ -751,33 +752,47 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
     // iteration, 1 = three, 0 = five (one per operation)
     long fused = fpr_opt(ctx, "cg_fused", 3);
     if (fused == 3) {
-        const int twm = (nx + CGP_NBX - 1) / CGP_NBX, thm = (ny + CGP_NBX - 1) / CGP_NBX;
+        // geometry: 64 workgroups of 256 threads (default) or 16 of 1024 (option cg_persistent_wgs = 16; rounds 2-3)
+        const bool g64 = fpr_opt(ctx, "cg_persistent_wgs", 64) != 16;
+        const int nbx = g64 ? 8 : 4, nb = nbx * nbx, nt = g64 ? 256 : 1024;
+        const int twm = (nx + nbx - 1) / nbx, thm = (ny + nbx - 1) / nbx;
         const size_t lds = (size_t)(twm + 2) * (thm + 2) * sizeof(double);
-        // its 16 workgroups synchronise through memory, so all of them have to be resident at once: ask the runtime once
-        // whether a compute unit takes one (1024 threads, this much LDS) and whether the device has 16 units
-        if (ctx->cgp_resident < 0) {
+        // its workgroups synchronise through memory, so all of them have to be resident at once: ask the runtime once
+        // whether a compute unit takes one (this many threads, this much LDS) and whether the device has enough units
+        int& resident = g64 ? ctx->cgp_resident64 : ctx->cgp_resident;
+        if (resident < 0) {
             int per_cu = 0, ncu = 0;
-            const bool ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_persistent, CGP_NT, 64 * 1024) == hipSuccess &&
-                            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess;
-            ctx->cgp_resident = (ok && (long)per_cu * ncu >= CGP_NB) ? 1 : 0;
+            const hipError_t eo = g64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_persistent<64, 8, 256>, nt, 64 * 1024)
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_persistent<16, 4, 1024>, nt, 64 * 1024);
+            const bool ok = eo == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess;
+            resident = (ok && per_cu >= 1 && ncu >= nb) ? 1 : 0;    // one workgroup per unit: a unit of its own for every workgroup
         }
-        if (ctx->cgp_resident == 1 && Nmax > 0 && (long)twm * thm <= (long)CGP_NT * CGP_PPT &&
-            2L * (twm + 2) + 2L * thm <= (long)CGP_NT * CGP_RPT && lds <= 64 * 1024) {
+        if (resident == 1 && Nmax > 0 && (long)twm * thm <= (long)nt * CGP_PPT &&
+            2L * (twm + 2) + 2L * thm <= (long)nt * CGP_RPT && lds <= 64 * 1024) {
             CgpArgs a;
             a.b = b; a.x_out = x_in; a.r_glob = w.r; a.part = ctx->partials;
             a.ctr = (unsigned*)(ctx->scalars + 40);   // two words of the scalar block: barrier counter, abort flag
             a.st = ctx->state;
             a.nx = nx; a.ny = ny; a.Nmax = Nmax;
             a.hx2 = hx * hx; a.hy2 = hy * hy; a.c = c; a.tol = tol; a.N = (double)N;
+            {   // a division by a power of two is an exact scaling, and so is the multiplication by its (exact) reciprocal
+                int ex = 0, ey = 0;
+                const bool px = std::frexp(a.hx2, &ex) == 0.5 && ex > -1000 && ex < 1000;
+                const bool py = std::frexp(a.hy2, &ey) == 0.5 && ey > -1000 && ey < 1000;
+                a.pow2 = (px && py && fpr_opt(ctx, "cg_pow2", 1) != 0) ? 1 : 0;
+                a.ihx2 = a.pow2 ? 1.0 / a.hx2 : 0.0;
+                a.ihy2 = a.pow2 ? 1.0 / a.hy2 : 0.0;
+            }
             a.prof = (long long*)(uintptr_t)fpr_opt(ctx, "cg_prof", 0);
             FPR_HIP(ctx, hipMemsetAsync(a.ctr, 0, 2 * sizeof(unsigned), s));
-            k_cgp_slots_init<<<1, 64, 0, s>>>(reinterpret_cast<unsigned long long*>(a.part));
-            // An ordinary launch: 16 workgroups of 1024 threads are resident together on any device this library runs on
-            // (one per CU, 256 CUs), every wait is bounded, and a cooperative launch moves the process onto the runtime's
-            // cooperative queue -- after it, kernels of two streams no longer overlap (measured: the side-by-side T / W solves
-            // of the NS step 1.61 -> 1.96 ms, tools/exp_ns_only.py).
+            k_cgp_slots_init<<<1, 64, 0, s>>>(reinterpret_cast<unsigned long long*>(a.part), nb);
+            // An ordinary launch: the workgroups are resident together on any device this library runs on (one per CU, 256 CUs),
+            // every wait is bounded, and a cooperative launch moves the process onto the runtime's cooperative queue -- after it,
+            // kernels of two streams no longer overlap (measured: the side-by-side T / W solves of the NS step 1.61 -> 1.96 ms,
+            // tools/exp_ns_only.py).
             const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_CG, s);
-            k_cg_persistent<<<dim3(CGP_NB), dim3(CGP_NT), lds, s>>>(a);
+            if (g64) k_cg_persistent<64, 8, 256><<<dim3(nb), dim3(nt), lds, s>>>(a);
+            else k_cg_persistent<16, 4, 1024><<<dim3(nb), dim3(nt), lds, s>>>(a);
             fpr_ktimer_end(ctx, timed, s);
             FPR_CHECK_LAUNCH(ctx);
             if (int rc = read_state(ctx)) return rc;

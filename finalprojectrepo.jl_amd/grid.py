@@ -244,7 +244,19 @@ def rccl_bootstrap(ctx, rank, world, dist=None, group=None):
         src = 0 if group is None else dist.get_global_rank(group, 0)
         dist.broadcast_object_list(box, src=src, group=group)
         buf = C.create_string_buffer(box[0], 128)
-    ctx.call("fpr_comm_init", int(rank), int(world), buf)
+    # this RCCL build prints a five-line version banner on stdout when a communicator is created: send it to stderr, stdout belongs
+    # to the caller (bench.py prints ONE JSON line there)
+    import os
+    import sys
+
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        ctx.call("fpr_comm_init", int(rank), int(world), buf)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
     ctx.comm_ready = True
 
 

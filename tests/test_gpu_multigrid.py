@@ -149,13 +149,16 @@ def test_cg_launch_forms_agree_bit_for_bit(fpr, oracle, shape, nmax):
         b[:, 0] = b[:, -1] = 0.0
     outs = []
     try:
-        for form in (3, 2, 1, 0):
+        for form, wgs in ((3, 64), (3, 16), (2, 64), (1, 64), (0, 64)):   # the persistent kernel in both geometries (64 x 256 and 16 x 1024 threads)
             c.set_option("cg_fused", form)
+            c.set_option("cg_persistent_wgs", wgs)
             x = F.asdevice(np.full(shape, 3.0))
             r, it = mg.cg_(x, F.asdevice(b), 0.05, 0.07, 0.9, 1e-7, nmax, return_iters=True)
             outs.append((r, it, F.tonumpy(x)))
+        assert c.get_option("cg_persistent_timeouts") == 0
     finally:
         c.set_option("cg_fused", 3)
+        c.set_option("cg_persistent_wgs", 64)
     for r, it, x in outs[1:]:
         assert it == outs[0][1] and r == outs[0][0]
         assert np.array_equal(x, outs[0][2])

@@ -19,7 +19,10 @@ b[:, 0] = b[:, -1] = 0.0
 prof = torch.zeros(8, dtype=torch.int64, device="cuda")
 F.ctx().set_option("cg_prof", prof.data_ptr())
 names = ["beta/p/ring/LDS", "operator", "-", "sum+barrier 1", "update", "sum+barrier 2"]
-for rep in range(3):
+for rep in range(6):
+    F.ctx().set_option("cg_persistent_wgs", 64 if rep < 3 else 16)
+    if rep in (0, 3):
+        print("--- %d workgroups ---" % (64 if rep < 3 else 16))
     prof.zero_()
     x = F.fzeros(n, n)
     r, it = mg.cg_(x, F.asdevice(b), 1.0 / (n - 1), 1.0 / (n - 1), 0.0, 1e-12, nmax, return_iters=True)
@@ -27,3 +30,4 @@ for rep in range(3):
     t = prof.cpu().numpy()[:6] / 100.0
     print("n=%d: %d iterations, %.2f us per iteration: %s" % (n, it, t.sum() / max(it, 1), ", ".join("%s %.2f" % (a, v / max(it, 1)) for a, v in zip(names, t))))
 F.ctx().set_option("cg_prof", 0)
+F.ctx().set_option("cg_persistent_wgs", 64)

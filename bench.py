@@ -690,6 +690,7 @@ def main():
                          "watchdog's fallback")
     ap.add_argument("--watchdog-s", type=float, default=120.0, help="N > 1: seconds without progress of a rank before the attempt is failed")
     ap.add_argument("--watchdog-import-s", type=float, default=420.0, help="the same before the worker has imported torch (fresh box)")
+    ap.add_argument("--no-placement", action="store_true", help="allocate the field arrays plainly (no pool of candidates timed pairwise)")
     ap.add_argument("--no-power-probe", action="store_true", help="skip the clocks / power diagnostic (about 2 s, outside the timed regions)")
     ap.add_argument("--no-norm-check", action="store_true", help="N > 1: do not compare the norm with tests/golden/scale_norms.json")
     ap.add_argument("--golden-norms", type=str, default="",
@@ -795,14 +796,40 @@ def main():
     D, dt = 1.0, 0.2
     dτ = min(dx, dy, dz) ** 2 / D / 8.1
     coef = (dτ, 1.0 / dt, 1.0 / dx, 1.0 / dy, 1.0 / dz, D / dx, D / dy, D / dz)
-    Ht = F.fzeros(*nloc)
+    # The five field arrays, placed for the streaming kernels (finalprojectrepo.jl_amd/placement.py: which physical pages an
+    # allocation receives decides whether two arrays streamed at equal offsets get in each other's way -- 0.775 against 0.85-0.91 ms
+    # for the same launch; a pool of candidates is timed pairwise once, outside every timed region, and the best-matched five stay).
+    # Every rank does the same thing for itself; --no-placement allocates plainly.
+    placement = {}
+    if args.no_placement or as_one:
+        Ht, Hτ, Hτ3, res, Hτ2 = (F.fzeros(*nloc) for _ in range(5))
+        placement["selected"] = False
+    else:
+        # streamed together at equal offsets: (Ht, field read), (field written, residual) -- the field alternates between Hτ and Hτ3.
+        # A trial = a few fused pairs on the candidate arrays (zeros: the arithmetic does not depend on the values), timed by events.
+        def trial(arrs):
+            tHt, tA, tC, tR, tB = arrs
+            if not F.part1.can_step_τ2(tHt, tA, tB, tC, tR):
+                return 0.0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            sq2 = ctx.scal[:2]
+            for i in range(3):
+                if i == 1:
+                    e0.record()
+                for _ in range(3 if i else 2):
+                    F.part1.diffusion_3D_step_τ2(tHt, tA, tB, tC, tR, *coef, dt, sq2)
+                    F.part1.diffusion_3D_step_τ2(tHt, tC, tB, tA, tR, *coef, dt, sq2)
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / 12.0
+
+        Ht, Hτ, Hτ3, res, Hτ2 = F.placement.alloc_fields(5, *nloc, report=placement, pairs=[(0, 1), (0, 2), (2, 3), (1, 3), (1, 2)],
+                                                      trial=trial)
     F.part1.init_local_gaussian((lx / 2, ly / 2, lz / 2), dx, dy, dz, Ht, gg.coords)
-    Hτ = Ht.clone(memory_format=torch.preserve_format)
-    Hτ2 = F.fzeros(*nloc)
-    res = F.fzeros(*nloc)
-    # third work buffer for the fused pairs: carries Hτ's boundary; the field alternates between Hτ and Hτ3 while
+    Hτ.copy_(Ht)
+    # Hτ3: third work buffer for the fused pairs: carries Hτ's boundary; the field alternates between Hτ and Hτ3 while
     # Hτ2 keeps playing the reference's second buffer (its boundary cells / halo planes are all that is read)
-    Hτ3 = Hτ.clone(memory_format=torch.preserve_format)
+    Hτ3.copy_(Ht)
     can_fuse2 = gg.can_step2(Ht, Hτ, Hτ2, Hτ3, res)
     hb("fields")
     iters_done = [0]          # pseudo-iterations since the initial state (what tests/golden/scale_norms.json is indexed by)
@@ -984,7 +1011,8 @@ def main():
                    "pct_of_hbm_peak_effective_per_gpu": 100.0 * value / world / HBM_PEAK_GBS,
                    "pct_of_hbm_peak_physical_dominant_kernel": 100.0 * roofline["frac"],
                    "last_err": last_err, "last_sumsq": last_sumsq, "iterations_since_start": iters_done[0],
-                   "choreography": ("pairs" if main_fused else "plain") if world > 1 else "none (1 rank)", "attempt": attempt},
+                   "choreography": ("pairs" if main_fused else "plain") if world > 1 else "none (1 rank)", "attempt": attempt,
+                   "field_placement": placement},
         "roofline": roofline,
         "legs": legs,
     }

@@ -12,6 +12,7 @@ Julia's `f!` is spelled `f_` here; Unicode names (Hτ, dτ, diffusion_3D_step_τ
 There is NO CPU fallback: every compute entry point calls the HIP library and raises if it is missing.
 """
 from . import _lib
+from . import placement  # noqa: F401
 from ._lib import Context, FprError, asdevice, fzeros, fones, tonumpy, lib_path  # noqa: F401
 
 _default_ctx = None

@@ -124,6 +124,7 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
     FPR_REQUIRE(ctx, diff3_fuse2_ok(ctx, Ht, A, B, C, dH, nx, ny, nz), "problem not supported by the fused two-step kernel");
     Diff3Args2 a;
     a.skip = skip;
+    a.lane_off = fpr_opt(ctx, "diff3_lane_off", 1) != 0;
     a.Ht = Ht; a.A = A; a.B = B; a.C = C; a.dH = dH;
     a.nx = nx; a.ny = ny; a.nz = nz;
     const int n[3] = {nx, ny, nz};

@@ -45,6 +45,13 @@
 #ifndef DIFF3_P2P_SYNC
 #define DIFF3_P2P_SYNC 0
 #endif
+// 1: lanes whose pair of cells lies outside what the tile needs (level 0 on [ol - 2, oh + 1]) are switched OFF for the whole march
+// (EXEC) instead of re-reading the nearest needed pair and computing on it: 5 x-tiles of 128 cells cover a 510-cell line, so about
+// a sixth of the lanes of every vector instruction works on nothing -- at the same issue rate, but the kernel runs at the card's
+// power cap (profiles/r4_power_probe.json) and idle lanes draw less.  (Diff3Args2::lane_off selects it at run time.)
+#ifndef DIFF3_LANE_OFF
+#define DIFF3_LANE_OFF 1
+#endif
 
 // Every workgroup of a ticketed launch passes here once, behind its other counter updates; the last one leaves the counters at zero
 // for the next launch.
@@ -101,6 +108,7 @@ struct Diff3Args2 {
     // Placement then cannot leave a working unit without a workgroup, whatever share the comm stream has (8, 16, ... units).
     const unsigned* reserved;
     const int* skip;                // fpr_diffusion3d_solve with pairs enqueued ahead of its exit test: return at once if *skip (nullptr = unconditional)
+    int lane_off;                   // 1: lanes outside the cells the tile needs are switched off for the whole march (DIFF3_LANE_OFF)
 #ifdef FPR_TUNE
     int dbg;                        // tuning harness only (tools/, -DFPR_TUNE): 1 = drop all stores, 2 = drop all loads of the z-loop
 #endif
@@ -387,6 +395,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_diff3_march2(Diff3
     const Diff3Coef cf{a.dtau, a._dt, a._dx, a._dy, a._dz, a.D_dx, a.D_dy, a.D_dz};
     auto kcl = [&](int k) { return k < 0 ? 0 : (k > nz - 1 ? nz - 1 : k); };
 
+#if DIFF3_LANE_OFF
+    // (all waves of a workgroup share the tile's x-range, so every wave keeps the same lanes -- at least one -- and still arrives
+    // at every barrier; a neighbour value that DPP would take from a switched-off lane only feeds level 1 at the cells ifirst /
+    // ilast + 1, which nothing owned depends on)
+    if (!a.lane_off || (ib >= ifirst && ib <= ilast)) {
+#endif
     // ---- buffer descriptors: base = array + (pbA + plane shift) planes + first row; every access of iteration m
     //      uses the scalar offsets so + r * rs with so = (m + 2 - pbA) * ps (see the shifts below) ----
     const int ps = (int)(sz * 8), rs = (int)(sy * 8);   // plane / row stride in bytes (host: (zc + 8) * ps < 2^31)
@@ -619,6 +633,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_diff3_march2(Diff3
         tot1 += (cm[0] ? acc1[0] : 0.0) + (cm[1] ? acc1[1] : 0.0);
         tot2 += (cm[0] ? acc2[0] : 0.0) + (cm[1] ? acc2[1] : 0.0);
     }
+#if DIFF3_LANE_OFF
+    }
+#endif
     }   // item
 
     if (BAL && a.ticket && tid == 0) diff3_ticket_leave(a.ticket, (int)gridDim.x);

@@ -49,6 +49,12 @@ __global__ void k_find_diff(const double* a, const double* b, size_t n, unsigned
         }
 }
 
+typedef double tune_d2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_copy_nt(const tune_d2* __restrict__ a, tune_d2* __restrict__ b, size_t n2)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) __builtin_nontemporal_store(a[i], &b[i]);
+}
+
 int main(int argc, char** argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 512;
@@ -171,21 +177,162 @@ int main(int argc, char** argv)
         printf("# compute units: %d\n", ncu);
         Diff3Args2 f;
         f.skip = nullptr;
+        f.lane_off = getenv("DIFF3_LANE_OFF") ? atoi(getenv("DIFF3_LANE_OFF")) : 1;
         f.Ht = Ht; f.A = Htau; f.B = B; f.C = C; f.dH = dH;
         f.nx = f.ny = f.nz = n;
         for (int d = 0; d < 3; ++d) { f.lo[d] = 1; f.hi[d] = n - 1; }
         f.dtau = a.dtau; f._dt = a._dt; f._dx = a._dx; f._dy = a._dy; f._dz = a._dz;
         f.D_dx = a.D_dx; f.D_dy = a.D_dy; f.D_dz = a.D_dz; f.scale = a.scale;
         f.partials1 = parts; f.partials2 = parts2;
+        if (strstr(filter, "f2class")) {
+            // Allocations fall into two classes: a copy between two arrays of the SAME class runs at ~4950 GB/s, between classes at ~5400
+            // (tools/place_probe.hip).  Which assignment of classes to the fused kernel's four streams (Ht, A read; C, dH written) is the fast one?
+            const size_t AB = N * 8;
+            const int K = 12;
+            double* arr[K];
+            int cls[K];
+            for (int k = 0; k < K; ++k) { CK(hipMalloc(&arr[k], AB)); CK(hipMemsetAsync(arr[k], 0, AB, s)); }
+            auto copy_ms = [&](int i, int j) {
+                for (int w = 0; w < 2; ++w) k_copy_nt<<<2048, 256, 0, s>>>((const tune_d2*)arr[i], (tune_d2*)arr[j], AB / 16);
+                CK(hipEventRecord(e0, s));
+                for (int r = 0; r < 6; ++r) k_copy_nt<<<2048, 256, 0, s>>>((const tune_d2*)arr[i], (tune_d2*)arr[j], AB / 16);
+                CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                return ms / 6;
+            };
+            float t[K];
+            t[0] = 0.f;
+            float lo = 1e9f, hi = 0.f;
+            for (int k = 1; k < K; ++k) { t[k] = copy_ms(0, k); lo = t[k] < lo ? t[k] : lo; hi = t[k] > hi ? t[k] : hi; }
+            const float mid = 0.5f * (lo + hi);
+            cls[0] = 0;
+            printf("f2class copy 0 -> k [GB/s]:");
+            for (int k = 1; k < K; ++k) { cls[k] = t[k] > mid ? 0 : 1; printf(" %.0f(%d)", 2.0 * AB / (t[k] * 1e-3) / 1e9, cls[k]); }
+            printf("   (class 0 = like array 0: slow copy)\n");
+            if (hi < 1.04f * lo) printf("f2class: all candidates look alike (spread %.1f %%)\n", 100.0 * (hi / lo - 1.0));
+            // members of each class
+            std::vector<int> m[2];
+            for (int k = 0; k < K; ++k) m[cls[k]].push_back(k);
+            printf("f2class: %zu arrays of class 0, %zu of class 1\n", m[0].size(), m[1].size());
+            for (int pat = 0; pat < 16; ++pat) {
+                const int want[4] = {pat & 1, (pat >> 1) & 1, (pat >> 2) & 1, (pat >> 3) & 1};   // Ht, A, C, dH
+                int used[2] = {0, 0}, pick[4];
+                bool ok = true;
+                for (int q = 0; q < 4; ++q) {
+                    if (used[want[q]] >= (int)m[want[q]].size()) { ok = false; break; }
+                    pick[q] = m[want[q]][used[want[q]]++];
+                }
+                if (!ok) { printf("f2class pattern Ht%d A%d C%d dH%d: not enough arrays of a class\n", want[0], want[1], want[2], want[3]); continue; }
+                CK(hipMemcpyAsync(arr[pick[0]], Ht, AB, hipMemcpyDeviceToDevice, s));
+                CK(hipMemcpyAsync(arr[pick[1]], Htau, AB, hipMemcpyDeviceToDevice, s));
+                Diff3Args2 g = f;
+                g.Ht = arr[pick[0]]; g.A = arr[pick[1]]; g.C = arr[pick[2]]; g.dH = arr[pick[3]];
+                for (int w = 0; w < 30; ++w) CK(diff3_launch2(g, true, 0, 0, s, 1 << 22, &np, 0, ncu));
+                float best = 1e9f;
+                for (int round = 0; round < 3; ++round) {
+                    CK(hipEventRecord(e0, s));
+                    for (int i = 0; i < 20; ++i) CK(diff3_launch2(g, true, 0, 0, s, 1 << 22, &np, 0, ncu));
+                    CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
+                    best = ms < best ? ms : best;
+                }
+                Diff3Args a1 = a; Diff3Tuning t1;
+                a1.Ht = g.Ht; a1.Htau = g.A; a1.Htau2 = g.C; a1.dHdtau = g.dH;
+                for (int w = 0; w < 10; ++w) CK(diff3_launch(a1, true, t1, s, 1 << 22, &np));
+                CK(hipEventRecord(e0, s));
+                for (int i = 0; i < 20; ++i) CK(diff3_launch(a1, true, t1, s, 1 << 22, &np));
+                CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                float ms1; CK(hipEventElapsedTime(&ms1, e0, e1)); ms1 /= 20;
+                printf("f2class pattern Ht%d A%d C%d dH%d: fused %.4f ms/launch, one-iteration kernel %.4f ms\n", want[0], want[1], want[2], want[3], best, ms1);
+                fflush(stdout);
+            }
+            return 0;
+        }
+        if (strstr(filter, "f2place")) {
+            // Does the time of a launch depend on WHERE its five arrays lie?  (Between two processes the same launch took 0.75-0.89 ms on
+            // one box; inside a process it repeats to 0.1 %.)  Arrays carved out of ONE slab at base + k * (array size + delta) for several
+            // delta, then out of separate allocations made in a fresh order; 3 x 20 launches each.
+            const size_t AB = N * 8;
+            const size_t deltas[] = {0, 4096, 64 << 10, 256 << 10, (1 << 20) + (64 << 10), (2 << 20), (3 << 20) + (192 << 10), (17 << 20) + (320 << 10)};
+            for (int rep = 0; rep < 2; ++rep)
+            for (size_t dlt : deltas) {
+                char* slab;
+                CK(hipMalloc(&slab, 5 * (AB + dlt) + (64 << 20)));
+                double* arr[5];
+                for (int k = 0; k < 5; ++k) arr[k] = (double*)(slab + (size_t)k * (AB + dlt));
+                CK(hipMemcpyAsync(arr[0], Ht, AB, hipMemcpyDeviceToDevice, s));
+                CK(hipMemcpyAsync(arr[1], Htau, AB, hipMemcpyDeviceToDevice, s));
+                CK(hipMemcpyAsync(arr[2], B, AB, hipMemcpyDeviceToDevice, s));
+                CK(hipMemsetAsync(arr[3], 0, AB, s)); CK(hipMemsetAsync(arr[4], 0, AB, s));
+                Diff3Args2 g = f;
+                g.Ht = arr[0]; g.A = arr[1]; g.B = arr[2]; g.C = arr[3]; g.dH = arr[4];
+                for (int w = 0; w < 40; ++w) CK(diff3_launch2(g, true, 0, 0, s, 1 << 22, &np, 0, ncu));
+                float best = 1e9f, worst = 0.f;
+                for (int round = 0; round < 3; ++round) {
+                    CK(hipEventRecord(e0, s));
+                    for (int i = 0; i < 20; ++i) CK(diff3_launch2(g, true, 0, 0, s, 1 << 22, &np, 0, ncu));
+                    CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
+                    best = ms < best ? ms : best; worst = ms > worst ? ms : worst;
+                }
+                CK(hipMemsetAsync(cnt, 0, 8, s));
+                k_count_diff<<<2048, 256, 0, s>>>(arr[3], Cref, N, cnt);
+                unsigned long long bad = 0;
+                CK(hipMemcpyAsync(&bad, cnt, 8, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s));
+                float ms1 = 0.f;
+                {   // the one-iteration kernel on the same arrays (Ht, A -> C, dH) and a plain copy A -> C: slow placement or slow pattern?
+                    Diff3Args a1 = a; Diff3Tuning t1;
+                    a1.Ht = arr[0]; a1.Htau = arr[1]; a1.Htau2 = arr[3]; a1.dHdtau = arr[4];
+                    for (int w = 0; w < 10; ++w) CK(diff3_launch(a1, true, t1, s, 1 << 22, &np));
+                    CK(hipEventRecord(e0, s));
+                    for (int i = 0; i < 20; ++i) CK(diff3_launch(a1, true, t1, s, 1 << 22, &np));
+                    CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&ms1, e0, e1)); ms1 /= 20;
+                }
+                float msc = 0.f;
+                {
+                    CK(hipEventRecord(e0, s));
+                    for (int i = 0; i < 10; ++i) CK(hipMemcpyAsync(arr[3], arr[1], AB, hipMemcpyDeviceToDevice, s));
+                    CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&msc, e0, e1)); msc /= 10;
+                }
+                printf("f2place slab delta %9zu B: fused %.4f .. %.4f ms/launch  %s | one-iteration kernel %.4f ms | copy 1 GiB %.4f ms  (slab %p)\n", dlt, best, worst,
+                       bad ? "MISMATCH" : "ok", ms1, msc, (void*)slab);
+                fflush(stdout);
+                CK(hipFree(slab));
+            }
+            for (int rep = 0; rep < 4; ++rep) {   // separate allocations, with a spacer of another size before each round
+                void* spacer; CK(hipMalloc(&spacer, (size_t)(37 + 101 * rep) << 20));
+                double* arr[5];
+                for (int k = 0; k < 5; ++k) CK(hipMalloc(&arr[k], AB));
+                CK(hipMemcpyAsync(arr[0], Ht, AB, hipMemcpyDeviceToDevice, s));
+                CK(hipMemcpyAsync(arr[1], Htau, AB, hipMemcpyDeviceToDevice, s));
+                CK(hipMemcpyAsync(arr[2], B, AB, hipMemcpyDeviceToDevice, s));
+                CK(hipMemsetAsync(arr[3], 0, AB, s)); CK(hipMemsetAsync(arr[4], 0, AB, s));
+                Diff3Args2 g = f;
+                g.Ht = arr[0]; g.A = arr[1]; g.B = arr[2]; g.C = arr[3]; g.dH = arr[4];
+                for (int w = 0; w < 40; ++w) CK(diff3_launch2(g, true, 0, 0, s, 1 << 22, &np, 0, ncu));
+                CK(hipEventRecord(e0, s));
+                for (int i = 0; i < 40; ++i) CK(diff3_launch2(g, true, 0, 0, s, 1 << 22, &np, 0, ncu));
+                CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("f2place separate allocations, round %d: %.4f ms/launch (arrays at %p %p %p %p %p)\n", rep, ms / 40, (void*)arr[0], (void*)arr[1], (void*)arr[2], (void*)arr[3], (void*)arr[4]);
+                fflush(stdout);
+                for (int k = 0; k < 5; ++k) CK(hipFree(arr[k]));
+                CK(hipFree(spacer));
+            }
+            return 0;
+        }
         if (strstr(filter, "f2ab")) {
-            // interleaved A/B of launch options (box-to-box and run-to-run noise is +-5 %): usage  f2ab:<nw>,<zc>,<xcd>:<nw>,<zc>,<xcd>
-            int cfg[2][3] = {{0, 0, 1}, {0, 0, 3}};
-            sscanf(strstr(filter, "f2ab") + 4, ":%d,%d,%d:%d,%d,%d", &cfg[0][0], &cfg[0][1], &cfg[0][2], &cfg[1][0], &cfg[1][1], &cfg[1][2]);
+            // interleaved A/B of launch options (box-to-box and run-to-run noise is +-5 %): usage  f2ab:<nw>,<zc>,<xcd>,<lane_off>:<nw>,<zc>,<xcd>,<lane_off>
+            int cfg[2][4] = {{0, 0, 1, 1}, {0, 0, 3, 1}};
+            sscanf(strstr(filter, "f2ab") + 4, ":%d,%d,%d,%d:%d,%d,%d,%d", &cfg[0][0], &cfg[0][1], &cfg[0][2], &cfg[0][3], &cfg[1][0], &cfg[1][1], &cfg[1][2], &cfg[1][3]);
             double sum[2] = {0, 0}, sq[2] = {0, 0};
-            const int reps = 12;
-            for (int w = 0; w < 60; ++w) CK(diff3_launch2(f, true, cfg[w & 1][1], cfg[w & 1][2], s, 1 << 22, &np, cfg[w & 1][0], ncu));
+            const int reps = 24;
+            for (int w = 0; w < 60; ++w) { f.lane_off = cfg[w & 1][3]; CK(diff3_launch2(f, true, cfg[w & 1][1], cfg[w & 1][2], s, 1 << 22, &np, cfg[w & 1][0], ncu)); }
             for (int rep = 0; rep < reps; ++rep)
                 for (int c = 0; c < 2; ++c) {
+                    f.lane_off = cfg[c][3];
                     CK(hipEventRecord(e0, s));
                     for (int i = 0; i < 20; ++i) CK(diff3_launch2(f, true, cfg[c][1], cfg[c][2], s, 1 << 22, &np, cfg[c][0], ncu));
                     CK(hipEventRecord(e1, s));
@@ -195,7 +342,7 @@ int main(int argc, char** argv)
                 }
             for (int c = 0; c < 2; ++c) {
                 const double m = sum[c] / reps, sd = sqrt(fmax(0.0, sq[c] / reps - m * m));
-                printf("f2ab cfg %c (nw=%d zc=%d xcd=%d): %.4f ms/launch +- %.4f  (%.0f GB/s A_eff)\n", 'A' + c, cfg[c][0], cfg[c][1], cfg[c][2], m, sd,
+                printf("f2ab cfg %c (nw=%d zc=%d xcd=%d lane_off=%d): %.4f ms/launch +- %.4f  (%.0f GB/s A_eff)\n", 'A' + c, cfg[c][0], cfg[c][1], cfg[c][2], cfg[c][3], m, sd,
                        2.0 * bytes / (m * 1e-3) / 1e9);
             }
             return 0;

@@ -81,6 +81,7 @@ int main(int argc, char** argv)
     CK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
     Diff3Args2 f;
     f.skip = nullptr;
+    f.lane_off = 1;
     f.Ht = Ht; f.A = A; f.B = B; f.C = C; f.dH = dH;
     f.nx = nx; f.ny = ny; f.nz = nz;
     {

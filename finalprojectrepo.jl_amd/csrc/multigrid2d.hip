@@ -1318,7 +1318,13 @@ static TopGeom top_geom(fpr_ctx* ctx, int nx, int ny, double h, double c)
             ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
         }
         const int gx = (g.nstrips_s + 3) / 4;
-        const int wg_per_cu = fpr_opt(ctx, "mg_seam_v", 2) == 1 ? 3 : 4;   // 151 VGPRs: three waves per SIMD; second version 108: four
+        // First version (151 VGPRs): three workgroups per CU.  Second version (108 VGPRs, four fit): TWO per CU -- chunks twice as tall
+        // halve the share of the 5 + 4 overlap rows, and what counts is that no CU gets one workgroup more than the others: 25
+        // chunks of 164 rows (475 workgroups, at most 2 per CU) 116 us where 50 chunks of 82 rows (950, at most 4) take 121 us, and
+        // counts just above a multiple of the CU count are the slow ones (28 chunks = 532 workgroups: 143 us; 43 = 817: 132 us;
+        // tools/exp_seam_chunks.py, profiles/r4_mg_seam_chunks.txt)
+        const long wpc_opt = fpr_opt(ctx, "mg_seam_wg_per_cu", 0);
+        const int wg_per_cu = wpc_opt > 0 ? (int)wpc_opt : (fpr_opt(ctx, "mg_seam_v", 2) == 1 ? 3 : 2);
         int chunks = (int)(0.95 * wg_per_cu * ctx->ncu) / gx;
         if (chunks < 1) chunks = 1;
         rs = (ny + chunks - 1) / chunks;

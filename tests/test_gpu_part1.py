@@ -772,3 +772,46 @@ def test_solver_loop_512_device_side_exit_test_equals_host_side(fpr):
         assert torch.equal(H0, H1) and torch.equal(r0, r1)
         del outs, H0, H1, r0, r1
         torch.cuda.empty_cache()
+
+
+def test_placement_alloc_fields(fpr):
+    """placement.alloc_fields: `count` zeroed column-major arrays chosen from a pool of candidate allocations (pairwise copy times,
+    then the caller's trial); small arrays are allocated plainly; the report says what was measured.  Results of a kernel do not
+    depend on which candidates were kept (same launch on plainly allocated arrays: same bits)."""
+    import torch
+
+    F = fpr
+    rep = {}
+    small = F.placement.alloc_fields(3, 32, 16, 8, report=rep)
+    assert len(small) == 3 and rep["selected"] is False and all(tuple(a.shape) == (32, 16, 8) and float(a.abs().max()) == 0.0 for a in small)
+    n = (512, 256, 256)            # 256 MiB per array: the smallest size the search runs for
+    calls = []
+
+    def trial(arrs):
+        calls.append(len(arrs))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        arrs[2].copy_(arrs[0])
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+
+    rep = {}
+    arrs = F.placement.alloc_fields(4, *n, pool=7, report=rep, pairs=[(0, 1), (2, 3)], trial=trial, trials=2)
+    assert len(arrs) == 4 and len({a.data_ptr() for a in arrs}) == 4
+    assert rep["selected"] is True and rep["pool"] == 7 and len(rep["chosen"]) == 4 and rep["trials"] == len(calls) >= 2
+    assert rep["pair_copy_GBs_all"]["fastest"] >= rep["pair_copy_GBs_chosen"]["slowest"] >= rep["pair_copy_GBs_all"]["slowest"] > 100.0
+    for a in arrs:
+        assert tuple(a.shape) == n and a.stride() == (1, n[0], n[0] * n[1]) and float(a.abs().max()) == 0.0
+    # same launch on placed and on plainly allocated arrays
+    dx = 10.0 / n[0]
+    coef = (dx * dx / 8.1, 5.0, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx)
+    Ht, A, B2, R = arrs
+    F.part1.init_local_gaussian((5.0, 2.5, 2.5), dx, dx, dx, Ht)
+    A.copy_(Ht)
+    F.part1.diffusion_3D_step_τ(Ht, A, B2, R, *coef)
+    pHt, pA, pB, pR = (F.fzeros(*n) for _ in range(4))
+    F.part1.init_local_gaussian((5.0, 2.5, 2.5), dx, dx, dx, pHt)
+    pA.copy_(pHt)
+    F.part1.diffusion_3D_step_τ(pHt, pA, pB, pR, *coef)
+    assert torch.equal(B2, pB) and torch.equal(R, pR)

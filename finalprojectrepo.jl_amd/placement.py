@@ -39,7 +39,7 @@ def _pair_times(c, arrs, reps=2):
     return t
 
 
-def alloc_fields(count, *shape, pool=None, min_bytes=256 << 20, report=None, pairs=None, trial=None, trials=4):
+def alloc_fields(count, *shape, pool=None, min_bytes=256 << 20, report=None, pairs=None, trial=None, trials=4, spacer_bytes=None):
     """`count` zeroed column-major float64 arrays of `shape` for kernels that stream several of them at equal offsets: the
     best-matched `count` out of `pool` candidate allocations (default count + 7, less if memory is short).  `pairs`: the
     (i, j) positions of the returned list that are streamed together (default: all); the assignment whose slowest such pair
@@ -68,7 +68,21 @@ def alloc_fields(count, *shape, pool=None, min_bytes=256 << 20, report=None, pai
         pairs = list(itertools.combinations(range(count), 2))
     roles = sorted({i for p in pairs for i in p})          # positions that matter; the others take what is left
     c = _ctx()
-    cands = [fzeros(*shape) for _ in range(k)]
+    # Candidates that follow each other in one stretch of memory tend to be of one class (runs of four or five 1 GiB allocations, tools/
+    # place_probe.hip); untouched spacer allocations between them spread the pool over more of the card (3 GiB each for 1 GiB arrays: three
+    # classes among twelve candidates where the plain pool showed two).  The spacers are reserved, never written, and freed with the rest.
+    spacer = int(spacer_bytes if spacer_bytes is not None else (3 * nbytes if nbytes >= (512 << 20) else 0))
+    if spacer and k * nbytes + (k - 1) * spacer > 0.7 * free:
+        spacer = max(0, int((0.7 * free - k * nbytes) // max(k - 1, 1)))
+    cands, spacers = [], []
+    for i in range(k):
+        cands.append(fzeros(*shape))
+        if spacer >= (64 << 20) and i + 1 < k:
+            try:
+                spacers.append(torch.empty(spacer, dtype=torch.uint8, device=cands[0].device))
+            except RuntimeError:
+                spacer = 0
+    report["spacer_bytes"] = spacer if spacers else 0
     torch.cuda.synchronize()
     t = _pair_times(c, cands)
     sym = [[0.5 * (t[i][j] + t[j][i]) for j in range(k)] for i in range(k)]
@@ -139,6 +153,6 @@ def alloc_fields(count, *shape, pool=None, min_bytes=256 << 20, report=None, pai
     out = build(best_sub)
     for a in out:
         a.zero_()
-    del cands
+    del cands, spacers
     torch.cuda.empty_cache()
     return out

@@ -29,7 +29,14 @@ int main(int argc, char** argv)
     const size_t B = (size_t)1 << 30, n2 = B / 16;
     std::vector<d2*> arr(K);
     double* out; CK(hipMalloc(&out, 8));
-    for (int k = 0; k < K; ++k) { CK(hipMalloc(&arr[k], B)); CK(hipMemset(arr[k], 0, B)); }
+    // optional spacer allocations of argv[2] GiB between the arrays (reserved, never touched): candidates spread over the card's memory
+    const size_t spacer = argc > 2 ? (size_t)atol(argv[2]) << 30 : 0;
+    std::vector<void*> sp;
+    for (int k = 0; k < K; ++k) {
+        CK(hipMalloc(&arr[k], B)); CK(hipMemset(arr[k], 0, B));
+        if (spacer && k + 1 < K) { void* q = nullptr; if (hipMalloc(&q, spacer) == hipSuccess) sp.push_back(q); else { printf("spacer %d failed\n", k); (void)hipGetLastError(); } }
+    }
+    printf("# %d arrays of 1 GiB, %zu spacers of %zu GiB\n", K, sp.size(), spacer >> 30);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto time = [&](auto launch) {
         for (int w = 0; w < 3; ++w) launch();

@@ -1095,14 +1095,17 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             const dim3 gm((nstrips + 3) / 4, (ny + rpc - 1) / rpc);
             const int npm = (int)(gm.x * gm.y);
             const bool fuse_p = fpr_opt(ctx, "mg_fuse_prolong", 1) != 0;
+            // below the top level u is the zero guess the level above has just stored (:132): the pre-smoothing pass is told so
+            // (bit 9) and does not read it (k_smooth2_march_v2; option mg_zero_guess = 0: read it like any field)
+            const int uz = (!top && fpr_opt(ctx, "mg_zero_guess", 1) != 0) ? 512 : 0;
             if (fuse_r) {  // pre-smoothing pair + residual + injection + zero coarse guess in ONE pass (:124-132)
                 const dim3 gr((nstrips_r + 3) / 4, (ny + rpc - 1) / rpc);
                 const bool timed = top && fpr_ktimer_begin(ctx, FPR_KT_MG_PRE, s);
-                { if (vx2) k_smooth2_march2<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c, skp); else march_go<false, false, true>(ctx, gr, s, u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, apply_BCs | ntf, L.res_c, L.corr_c, skp); }
+                { if (vx2) k_smooth2_march2<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c, skp); else march_go<false, false, true>(ctx, gr, s, u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, apply_BCs | ntf | uz, L.res_c, L.corr_c, skp); }
                 fpr_ktimer_end(ctx, timed, s);
                 if (apply_BCs && vx2) k_bc_neumann<<<(nyc + 255) / 256, 256, 0, s>>>(L.res_c, nxc, nyc, skp);  // :355-357 (k_smooth2_march does it itself)
             } else {
-                { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); else march_go<false, false, false>(ctx, gm, s, u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); }  // :124-125
+                { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); else march_go<false, false, false>(ctx, gm, s, u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf | uz, nullptr, nullptr, skp); }  // :124-125
                 k_restrict_residual2d<<<grid2(nxc, nyc), blk2, 0, s>>>(L.tmp, rhs, L.res_c, nx, ny, C, _h2, apply_BCs, L.corr_c);  // :128-132
             }
             FPR_CHECK_LAUNCH(ctx);

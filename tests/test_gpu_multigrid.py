@@ -453,6 +453,15 @@ def test_multisweep_and_single_sweep_paths_agree(fpr):
     r = mg.Vcycle_2DPoisson_(gu, F.asdevice(f), 1.0 / 256, 0.3, 1e-7, 5, mg.jacobi, mg.parallel, True)
     outs.append((r, F.tonumpy(gu)))
     F.ctx().set_option("mg_vx", 1)
+    # the zero coarse guess read from memory like any field (default: not read at all, its loads are dropped by the range check)
+    for fuse_r in (1, 0):
+        F.ctx().set_option("mg_zero_guess", 0)
+        F.ctx().set_option("mg_fuse_restrict", fuse_r)
+        gu = F.asdevice(u0)
+        r = mg.Vcycle_2DPoisson_(gu, F.asdevice(f), 1.0 / 256, 0.3, 1e-7, 5, mg.jacobi, mg.parallel, True)
+        outs.append((r, F.tonumpy(gu)))
+    F.ctx().set_option("mg_zero_guess", 1)
+    F.ctx().set_option("mg_fuse_restrict", 1)
     for r, u in outs[1:]:
         assert np.array_equal(u, outs[0][1])
         assert abs(r - outs[0][0]) <= 1e-13 * abs(outs[0][0])

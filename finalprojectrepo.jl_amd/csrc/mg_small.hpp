@@ -28,7 +28,10 @@ struct MgSmallArgs {
     long long* prof;    // diagnostic (option mg_small_prof): wall_clock64 stamps (100 MHz) of thread 0 at the section borders
 };
 
-constexpr int MGS_NT = 1024;
+#ifndef MGS_NT_THREADS
+#define MGS_NT_THREADS 1024
+#endif
+constexpr int MGS_NT = MGS_NT_THREADS;   // threads of the workgroup (A/B builds: -DMGS_NT_THREADS=512 / 256)
 constexpr int MGS_RED = 32;  // doubles reserved for reductions / broadcasts
 constexpr int MGS_WPL = 5;   // single-wave coarse solve: points per lane (up to 320 points: 17 x 17)
 

@@ -111,7 +111,11 @@ int fpr_diffusion3d_step_norm_host(fpr_ctx* ctx, const double* Ht, const double*
  * two sums are accumulated as sum(r*r) per lane with scale^2 applied once at the end, the single-step kernel adds
  * (r*scale)^2 per cell -- both deterministic, equal to about 1e-13 relative, like any two summation orders.  Requirements: nx even and >= 128, ny >= 16, 16-byte aligned
  * arrays, nx*ny*96 < 2^31 -- query with fpr_diffusion3d_can_step2 (1 = supported, 0 = use two single steps).
- * _box: output box [lo, hi) as fpr_diffusion3d_step_box; sums are ACCUMULATED into sumsq2_dev. */
+ * _box: output box [lo, hi) as fpr_diffusion3d_step_box; sums are ACCUMULATED into sumsq2_dev.
+ * Placement: the launch streams Ht and Htau in and Hout and dHdtau out at equal offsets; on MI355X its time depends on which
+ * physical pages the four allocations received (0.775 ms at 512^3 when they all differ in their placement label, 0.85-0.91 ms when
+ * they agree) -- a host that owns its arrays picks them from a pool of candidates once.
+ * Option diff3_lane_off [1]: lanes of a tile that hold no needed cell are switched off for the march. */
 int fpr_diffusion3d_can_step2(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hmid, const double* Hout,
                               const double* dHdtau, int nx, int ny, int nz);
 int fpr_diffusion3d_step2(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hmid, double* Hout,
@@ -336,12 +340,18 @@ int fpr_vcycle2d(fpr_ctx* ctx, double* u_f, const double* rhs, double h, double 
  * ahead of the host's view of the norm, and two consecutive cycles share their pass over the finest grid -- u, the
  * history, the cycle and coarse-iteration counts are those of the plain loop.  Tuning / A-B options
  * (fpr_set_option, defaults in brackets): mg_ahead [1] cycles enqueued ahead (0 = plain loop), mg_seam [1] shared pass
- * between cycles, mg_seam_predict [1], mg_mid [1] three launch-bound levels in two launches, mg_small_row [1]. After an error return u is UNDEFINED (cycles enqueued ahead of the host are drained first, but may have run). */
+ * between cycles, mg_seam_predict [1], mg_mid [1] three launch-bound levels in two launches, mg_small_row [1], mg_zero_guess [1] coarse
+ * levels do not read the zero guess their parent stored (:132), mg_seam_wg_per_cu [2] chunk height of the shared pass. After an error return u is UNDEFINED (cycles enqueued ahead of the host are drained first, but may have run). */
 int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h, double c, double tol, int niters,
                   int apply_BCs, int coarse_solve_size, int coarse_solver, int nx, int ny, double* rms_host,
                   int* ncycles_host, double* history_host, double* frms_host, int* converged_host);
 
-/* B9: cg!(x_in, b, hx, hy, c, tol, Nmax) -- krylov.jl:55-91 (starts from x = 0, overwrites x_in) */
+/* B9: cg!(x_in, b, hx, hy, c, tol, Nmax) -- krylov.jl:55-91 (starts from x = 0, overwrites x_in).
+ * The dot products (:57, :64, :69, :72, :83, :90; the reference does not specify their summation order) are Dot2 sums: twofold
+ * precision, rounded once -- x, the iteration count and the returned rms do not depend on the launch form (option cg_fused [3]:
+ * 3 = one persistent launch where the grid fits, 2 / 1 / 0 = two / three / five launches per iteration; cg_persistent_wgs [64]:
+ * 64 workgroups of 256 threads, 16 = 16 of 1024) and equal the CPU restatement's bit for bit.  cg_pow2 [1]: on meshes with
+ * hx^2, hy^2 powers of two the persistent form multiplies by the exact reciprocals instead of dividing (same bits). */
 int fpr_cg2d(fpr_ctx* ctx, double* x_in, const double* b, double hx, double hy, double c, double tol, int Nmax,
              int nx, int ny, double* rms_host, int* iters_host);
 

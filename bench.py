@@ -387,17 +387,18 @@ def vcycle_block(F, with_cpu=True, steps=5, place=True):
                      "2 pre-smoothing sweeps + residual + injection of cycle k+1)",
              "post": "k_smooth2_march_v2<NORM,PROLONG> (finest level: prolongation + correction + 2 sweeps + norm)",
              "pre": "k_smooth2_march_v2<RESTRICT> (finest level: 2 sweeps + residual + injection)"}
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_box = None, None, None
     try:   # HBM-side bytes of the dominant pass from the committed rocprofv3 --pmc passes (tools/profile_mg.sh), not measured live
         for tj in json.load(open(os.path.join(ROOT, "profiles", "mg_traffic.json")))["entries"]:
             if tj.get("n") == n and tj.get("pass") == dom[0]:
-                traffic, traffic_src = tj["traffic_bytes_per_launch"], tj.get("source")
+                traffic, traffic_src, traffic_box = tj["traffic_bytes_per_launch"], tj.get("source"), tj.get("box")
     except Exception:
         pass
     roof = {
         "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "kernel": names[dom[0]],
         "achieved": gbs(dom[2], dom[1]), "frac": gbs(dom[2], dom[1]) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+        "traffic_box": traffic_box, "traffic_over_algorithmic": (traffic / dom[2]) if traffic else None,
         "kernel_ms": dom[1], "bytes_per_launch": dom[2],
         "kernels": {"finest_pre_pass": {"ms": pre_ms, "launches": pre_cnt, "bytes": pre_bytes, "GBs": gbs(pre_bytes, pre_ms),
                                         "accounting": "read u, f; write the smoothed field + res_c, corr_c (1/4 each): 28 B/pt"},

@@ -726,7 +726,8 @@ def main():
                          "writes the sum of squares behind the norm after every iteration (tools/make_scale_norms.sh)")
     ap.add_argument("--golden-dims", type=str, default="1,1,2;1,1,4;1,1,8;2,1,1;2,2,1;2,2,2")
     ap.add_argument("--golden-iters", type=int, default=320)
-    ap.add_argument("--dry-run-hang", type=int, default=-1, help="(test) --dry-run: this rank stops making progress in the first attempt")
+    ap.add_argument("--dry-run-hang", type=int, default=-1, help="(test) this rank stops making progress in the first attempt (--dry-run: before its first collective; else: after it has "
+                         "allocated its fields on the GPU)")
     ap.add_argument("--dry-run-hang-always", action="store_true", help="(test) ... and in the fallback attempt too")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="diagnostic for a 1-GPU box: every rank on cuda:0, halo planes and the norm's all-reduce staged "
@@ -861,6 +862,8 @@ def main():
     Hτ3.copy_(Ht)
     can_fuse2 = gg.can_step2(Ht, Hτ, Hτ2, Hτ3, res)
     hb("fields")
+    if rank == args.dry_run_hang and (attempt == 1 or args.dry_run_hang_always):
+        time.sleep(1.0e6)            # (test) this rank stops here with its GPU context alive: the others wait in the first collective
     iters_done = [0]          # pseudo-iterations since the initial state (what tests/golden/scale_norms.json is indexed by)
     K, W, ce = args.steps, args.warmup, max(1, args.check_every)
     sq = torch.zeros(2 * (K + W + ce) + 64, dtype=torch.float64, device=Ht.device)

@@ -461,6 +461,28 @@ def test_bench_two_ranks_rehearsal_on_one_card():
     assert plain["roofline"]["launches_by_kind"]["core"] == 0
 
 
+def test_bench_watchdog_ends_a_stalled_gpu_rank_and_the_plain_fallback_checks_its_norm():
+    """The watchdog between REAL GPU processes: rank 1 stops after it has allocated its fields on the card (a deadlocked
+    collective looks the same from outside); the supervisors end both workers, fresh ones run the plain choreography, and
+    the line they print carries the first attempt's record and a norm that matches the single-rank control."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--n", "128", "--steps", "12",
+                        "--warmup", "4", "--prewarm-ms", "0", "--no-cpu-baseline", "--no-secondary", "--dry-run-hang", "1", "--watchdog-s", "12"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["config"]["choreography"] == "plain" and out["config"]["attempt"] == 2
+    assert out["first_attempt"]["choreography"] == "pairs" and "no progress" in out["first_attempt"]["reason"]
+    assert out["norm_check"]["ok"] is True and out["norm_check"]["key"] == "n128_dims1,1,2"
+
+
 def test_bench_four_ranks_rehearsal_x_y_z_decompositions_agree():
     """Four real processes on the one card (host-staged planes, see the two-rank test above) in the process grids (2,2,1),
     (2,1,2) and (1,2,2): faces in x, y and z through the shell/core choreography of the fused pairs, the narrow-box kernels

@@ -45,6 +45,7 @@ def second_ctx():
         # the solve that runs beside another one must not depend on 16 workgroups being resident together: cg! in its
         # two-launch form there (a switch set on the default context, cg_fused included, still wins: copied below)
         _second_ctx.set_option("cg_fused", 2)
+        _second_ctx.set_option("mg_jacobi_persist", 0)      # (the same for the persistent Jacobi coarse solve: its workgroups wait for their neighbours)
         for k, v in c.opts.items():
             _second_ctx.set_option(k, _lib.follower_value(k, v))
         c.followers = [_second_ctx]

@@ -203,6 +203,8 @@ def fptr(t, ndim=None):
 def follower_value(key, value):
     """... except that cg! never runs as the persistent kernel (cg_fused = 3, the default) on a context whose solves run
     BESIDE another context's: its 16 workgroups synchronise through memory and must all be resident at once."""
+    if key == "mg_jacobi_persist":
+        return 0
     return 2 if (key == "cg_fused" and int(value) == 3) else int(value)
 
 

@@ -88,6 +88,7 @@ struct fpr_ctx {
     bool core_unmasked = false;        // the core stream has every unit; workgroups of a core launch that land on a comm unit leave at once
     int cgp_resident = -1;             // k_cg_persistent: 16 workgroups of 1024 threads resident together? (-1 = not asked yet)
     int cgp_resident64 = -1;      // the same for the 64-workgroup geometry of k_cg_persistent
+    int jacp_resident = -1;       // k_jacobi_persist: workgroups of 256 threads the device holds at once (-1 = not asked yet)
     double* partials = nullptr;     // FPR_MAX_PARTIALS doubles: block partial sums (slot 0)
     double* partials2 = nullptr;    // second slot (comm stream / second reduction of a kernel)
     int ncu = 0;                       // compute units of the device (queried on first use)

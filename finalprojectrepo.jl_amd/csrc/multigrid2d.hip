@@ -723,6 +723,7 @@ static int cg_work(fpr_ctx* ctx, size_t n, CgWork* w)
 }
 
 #include "mg_cg_persistent.hpp"   // k_cg_persistent: cg! as one launch
+#include "mg_jacobi_persistent.hpp"   // k_jacobi_persist: many groups of sweeps per launch, neighbour-to-neighbour hand-offs
 
 // runs cg! on the compute stream; leaves iters / last_rms in ctx->state_h (synchronises)
 static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, double hy, double c, double tol, int Nmax,
@@ -1190,17 +1191,104 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             // k_jacobi_patch: 8 sweeps per launch on 32 x 32 regions (own tile 16 x 16, 256 threads), 1.25 us per sweep of the
             // 257^2 grid (2.9 us launch boundary + loads + norms per launch, 0.5 us per sweep).  16 sweeps on 48 x 48 regions
             // (576 threads) were measured at 1.40 us per sweep: a sweep of the larger region takes 1.0 us, twice as long.
+            // Sweeps per launch of the patch kernel: 8 (own tile 16 x 16; default), or 7 (18 x 18) / 6 (20 x 20) on the same 32 x 32 region
+            // (option mg_patch_sweeps).  257^2 is 17 x 17 = 289 tiles of 16 -- 33 of the 256 CUs hold two workgroups -- but 15 x 15 = 225
+            // tiles of 18; measured (tools/exp_patch_sweeps.py) 12.1 us per launch of 8 sweeps, 10.4 of 7, 9.3 of 6: per sweep 1.51 / 1.49 /
+            // 1.55 us, no gain -- a launch is mostly its boundary, prologue and epilogue, not its sweeps.
             constexpr int S8 = 8, TX = 16, TY = 16;
-            constexpr int PS = 8, PP = 32;
-            static_assert(PP - 2 * PS == TX, "both variants own 16 x 16 tiles");
+            constexpr int PP = 32;
             const bool patch = fpr_opt(ctx, "mg_patch", 1) != 0;
+            int PS = (int)fpr_opt(ctx, "mg_patch_sweeps", 8);
+            if (PS < 6 || PS > 8) PS = 8;
             const int S = patch ? PS : S8;
-            const dim3 gm((nx + TX - 1) / TX, (ny + TY - 1) / TY);
+            const int TXp = patch ? PP - 2 * PS : TX, TYp = patch ? PP - 2 * PS : TY;
+            const dim3 gm((nx + TXp - 1) / TXp, (ny + TYp - 1) / TYp);
             const int nblk = (int)(gm.x * gm.y);
             if ((size_t)nblk * S > (size_t)FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
             int Sg = (int)fpr_opt(ctx, "mg_group_sweeps", S);  // sweeps per launch (<= S; tuning/diagnostic knob)
             if (Sg < 1 || Sg > S) Sg = S;
             const int groups = (iters + Sg - 1) / Sg;
+            // ---- the persistent form: launches of up to 16 groups of 8 sweeps with neighbour-to-neighbour hand-offs inside
+            //      (mg_jacobi_persistent.hpp); the plain form below stays for A/B, for grids it does not fit and as the replay ----
+            if (patch && PS == 8 && Sg == 8 && fpr_opt(ctx, "mg_jacobi_persist", 1) != 0 && (size_t)N * 8 < 0x7fffffffu) {
+                if (ctx->jacp_resident < 0) {
+                    int per_cu = 0;
+                    const bool ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist<8, PP>, (PP / 2) * (PP / 2), 0) == hipSuccess;
+                    if (ctx->ncu <= 0) {
+                        int v = 0;
+                        ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
+                    }
+                    ctx->jacp_resident = ok ? per_cu * ctx->ncu : 0;    // workgroups the device holds at once
+                }
+                const int GMAX = 32;    // groups per launch: 256 sweeps, whose exit tests one workgroup replays behind the launch
+                CgWork w;
+                if (nblk <= ctx->jacp_resident / 2 && (size_t)GMAX * 8 * nblk <= (size_t)FPR_MAX_PARTIALS - 1024 && cg_work(ctx, N, &w) == FPR_OK) {
+                    double* B[4] = {u, L.tmp, w.r, w.p};
+                    int* flags = reinterpret_cast<int*>(ctx->partials + FPR_MAX_PARTIALS - 1024);   // nblk <= 2048 words + the abort word
+                    if (nblk + 8 > 2048) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for the flag block");
+                    int* abort_flag = flags + 2040;
+                    FPR_HIP(ctx, hipMemsetAsync(abort_flag, 0, sizeof(int), s));
+                    struct Rec { int x, w[3], g0, G; };
+                    std::vector<Rec> recs;
+                    int cur = 0, gdone = 0, poll_after = 1, since_poll = 0;
+                    while (gdone < groups) {
+                        const int G = groups - gdone < GMAX ? groups - gdone : GMAX;
+                        Rec r;
+                        r.x = cur; r.g0 = gdone; r.G = G;
+                        for (int k = 0, q = 0; k < 4; ++k) if (k != cur) r.w[q++] = k;
+                        JacPersistArgs a;
+                        a.X = B[r.x];
+                        for (int q = 0; q < 3; ++q) a.W[q] = B[r.w[q]];
+                        // (group g of a launch reads X for g = 0, else W[g % 3], and writes W[(g + 1) % 3])
+                        a.rhs = rhs; a.nx = nx; a.ny = ny; a.C = C; a._h2 = _h2; a.fac = fac;
+                        a.ngroups = G;
+                        a.nsw_last = (gdone + G == groups) ? iters - (groups - 1) * 8 : 8;
+                        a.partials = ctx->partials; a.flags = flags; a.abort_flag = abort_flag; a.state = ctx->state;
+                        FPR_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)nblk * sizeof(int), s));
+                        const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_PATCH, s);
+                        k_jacobi_persist<8, PP><<<gm, (PP / 2) * (PP / 2), 0, s>>>(a);
+                        fpr_ktimer_end(ctx, timed, s);
+                        k_jacobi_check_groups<<<1, 256, 0, s>>>(ctx->state, ctx->partials, nblk, G, 8, a.nsw_last, (double)N, gdone, abort_flag);
+                        FPR_CHECK_LAUNCH(ctx);
+                        recs.push_back(r);
+                        cur = r.w[G % 3];                  // the last group (index G - 1) wrote W[G % 3]
+                        gdone += G;
+                        if (++since_poll >= poll_after || gdone >= groups) {
+                            since_poll = 0;
+                            if (poll_after < 4) poll_after *= 2;
+                            if (int rc = read_state(ctx)) return rc;
+                            if (ctx->state_h->done) break;
+                        }
+                    }
+                    if (ctx->state_h->done < 0)
+                        return fpr_fail(ctx, FPR_ERR_HIP, "k_jacobi_persist: a neighbour hand-off timed out (is the card shared?); set option mg_jacobi_persist = 0");
+                    double* result = B[cur];
+                    if (ctx->state_h->done) {
+                        // the criterion was met inside launch `r`: launches behind it returned at once; replay the exact number of sweeps
+                        // from that launch's untouched input with the ordinary launches
+                        const int gs = ctx->state_h->group, redo = ctx->state_h->redo;
+                        const Rec* r = nullptr;
+                        for (const Rec& q : recs) if (gs >= q.g0 && gs < q.g0 + q.G) r = &q;
+                        if (!r) return fpr_fail(ctx, FPR_ERR_INVALID, "k_jacobi_persist: exit group outside the launches");
+                        int left = (gs - r->g0) * 8 + redo;
+                        const double* in = B[r->x];
+                        int o = 0;
+                        while (left > 0) {
+                            const int m = left < 8 ? left : 8;
+                            double* out = B[r->w[o & 1]];
+                            k_jacobi_patch<8, PP, false, false><<<gm, (PP / 2) * (PP / 2), 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, m, nullptr, nullptr, nullptr, 0, 0, 0.0);
+                            in = out; ++o; left -= m;
+                        }
+                        FPR_CHECK_LAUNCH(ctx);
+                        result = const_cast<double*>(in);
+                    }
+                    if (result != u) FPR_HIP(ctx, hipMemcpyAsync(u, result, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+                    ctx->last_coarse_iters += ctx->state_h->iters;
+                    *rms_out_host = ctx->state_h->last_rms;
+                    *rms_is_host = true;
+                    return FPR_OK;
+                }
+            }
             double* a = u;
             double* b = L.tmp;
             int gdone = 0;
@@ -1218,8 +1306,11 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                         const double* pslot = ctx->partials + (size_t)((gi + 1) & 1) * S * nblk;
                         const bool pending = gi > gdone;  // the previous group of THIS chunk is still unchecked
                         const bool timed = nsw == Sg && fpr_ktimer_begin(ctx, FPR_KT_MG_PATCH, s);
-                        k_jacobi_patch<PS, PP, true, true><<<gm, (PP / 2) * (PP / 2), 0, s>>>(a, rhs, b, nx, ny, C, _h2, fac, nsw, slot, ctx->state,
-                                                                                                pslot, pending ? Sg : 0, gi - 1, (double)N);
+#define FPR_PATCH_GO(PSV)                                                                                                                   \
+    k_jacobi_patch<PSV, PP, true, true><<<gm, (PP / 2) * (PP / 2), 0, s>>>(a, rhs, b, nx, ny, C, _h2, fac, nsw, slot, ctx->state, pslot, \
+                                                                           pending ? Sg : 0, gi - 1, (double)N)
+                        if (PS == 8) FPR_PATCH_GO(8); else if (PS == 7) FPR_PATCH_GO(7); else FPR_PATCH_GO(6);
+#undef FPR_PATCH_GO
                         fpr_ktimer_end(ctx, timed, s);
                         if (gi == gend - 1)  // last group of the chunk: stand-alone check before the host polls
                             k_jacobi_check_multi<<<1, 256, 0, s>>>(ctx->state, slot, nblk, nsw, (double)N, gi);
@@ -1241,7 +1332,12 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                 double* out = (gs & 1) ? u : L.tmp;
                 const int nsw_g = (iters - gs * Sg < Sg) ? iters - gs * Sg : Sg;
                 if (redo < nsw_g) {  // the exit fell inside the group: recompute exactly `redo` sweeps from its input
-                    if (patch) k_jacobi_patch<PS, PP, false, false><<<gm, (PP / 2) * (PP / 2), 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, redo, nullptr, nullptr, nullptr, 0, 0, 0.0);
+                    if (patch) {
+#define FPR_PATCH_REDO(PSV) \
+    k_jacobi_patch<PSV, PP, false, false><<<gm, (PP / 2) * (PP / 2), 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, redo, nullptr, nullptr, nullptr, 0, 0, 0.0)
+                        if (PS == 8) FPR_PATCH_REDO(8); else if (PS == 7) FPR_PATCH_REDO(7); else FPR_PATCH_REDO(6);
+#undef FPR_PATCH_REDO
+                    }
                     else k_sweep2d_multi<S8, TX, TY, 0, false><<<gm, 256, 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, redo, nullptr, nullptr);
                 }
                 result = out;

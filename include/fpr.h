@@ -68,7 +68,8 @@ enum {
     FPR_KT_MG_SEAM = 4,       /* finest level between two V-cycles of fpr_mgsolve2d: post pair of cycle k + norm +
                                  pre pair + residual + injection of cycle k+1 in one pass (k_seam_march)         */
     FPR_KT_MG_CG = 5,         /* coarse solve by cg! as ONE persistent launch (k_cg_persistent): a launch = a solve      */
-    FPR_KT_MG_PATCH = 6,      /* coarse solve by damped Jacobi on a large coarse grid: one launch = 8 sweeps (k_jacobi_patch) */
+    FPR_KT_MG_PATCH = 6,      /* coarse solve by damped Jacobi on a large coarse grid: one launch = up to 32 groups of 8 sweeps
+                                 (k_jacobi_persist; option mg_jacobi_persist = 0: one launch per 8 sweeps, k_jacobi_patch) */
     FPR_KT_DIFF3_CORE = 7     /* fpr_diffusion3d_step2_core: the core launch of a decomposed run's fused pair (the shell
                                  launches beside it stay FPR_KT_DIFF3_STEP / _STEP2 and OVERLAP it in time)              */
 };

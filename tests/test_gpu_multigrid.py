@@ -424,6 +424,37 @@ def test_coarse_jacobi_exit_inside_a_fused_group(fpr, oracle, tol):
         assert np.array_equal(F.tonumpy(gu), u_ref)
 
 
+@pytest.mark.parametrize("tol", [0.5, 0.2, 0.05, 0.02, 1e-9])
+def test_coarse_jacobi_persistent_launches_equal_the_plain_ones(fpr, oracle, tol):
+    """k_jacobi_persist (up to 32 groups of 8 sweeps per launch, tiles handed from neighbour to neighbour, exit test behind the
+    launch and the exact number of sweeps replayed from the launch's input) against one launch per 8 sweeps and against the
+    oracle: a 257 x 129 coarse grid solved directly by Vcycle_2DPoisson! (:147-159) with exits in the first launch, in a later
+    one, inside a group, and none at all (cap 20 * 257 sweeps)."""
+    F, mg = fpr, fpr.multigrid
+    shape = (257, 129)
+    u0, f = rnd(shape, 61), rnd(shape, 62)
+    f[0, :] = f[-1, :] = 0.0
+    f[:, 0] = f[:, -1] = 0.0
+    h = 1.0 / 128
+    u_ref = u0.copy(order="F")
+    r_ref = oracle.vcycle2d(u_ref, f, h, 0.0, tol, 257, 0, False)
+    it_ref = oracle.last_coarse_iters()
+    outs = []
+    c = F.ctx()
+    try:
+        for persist in (1, 0):
+            c.set_option("mg_jacobi_persist", persist)
+            gu = F.asdevice(u0)
+            r = mg.Vcycle_2DPoisson_(gu, F.asdevice(f), h, 0.0, tol, 257, mg.jacobi, mg.parallel_shmem, False)
+            outs.append((r, F.tonumpy(gu)))
+    finally:
+        c.set_option("mg_jacobi_persist", 1)
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+    assert abs(outs[0][0] - r_ref) <= 1e-12 * abs(r_ref)
+    assert np.array_equal(outs[0][1], u_ref)
+    assert it_ref > 0
+
+
 def test_multisweep_and_single_sweep_paths_agree(fpr):
     """Temporal blocking (mg_multi) and the LDS-resident coarse hierarchy (mg_small) change no bit."""
     F, mg = fpr, fpr.multigrid

@@ -25,7 +25,8 @@ struct JacPersistArgs {
     double C, _h2, fac;
     int ngroups, nsw_last;  // groups of this launch; sweeps of the last one (<= S), all others S
     double* partials;       // [group][sweep][block] sums of res^2 over the own tile
-    int* flags;             // one word per workgroup: groups finished (0 before the launch)
+    int* flags;             // one word per workgroup: groups finished since the start of the SOLVE (= g0 before the launch)
+    int g0;                 // groups of the solve that earlier launches have done
     int* abort_flag;
     const FprSolveState* state;
 };
@@ -86,7 +87,7 @@ __global__ __launch_bounds__((P / 2) * (P / 2)) void k_jacobi_persist(JacPersist
                 int ab = 0;
                 if (nb >= 0) {
                     unsigned spins = 0;
-                    while (__hip_atomic_load(a.flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g) {
+                    while (__hip_atomic_load(a.flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.g0 + g) {
                         __builtin_amdgcn_s_sleep(1);
                         if ((++spins & 0x3ff) == 0) {
                             if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
@@ -176,47 +177,44 @@ __global__ __launch_bounds__((P / 2) * (P / 2)) void k_jacobi_persist(JacPersist
             for (int w = 1; w < NWV; ++w) v += red[w][tid];
             a.partials[((size_t)g * S + tid) * nblk + blk] = v;     // read by k_jacobi_check_groups behind the launch
         }
-        if (tid == 0) __hip_atomic_store(a.flags + blk, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(a.flags + blk, a.g0 + g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // (red / img are rewritten only behind the next group's barriers)
     }
 }
 
-// Behind a launch of k_jacobi_persist: the per-sweep exit test of its groups, in order (multigrid.jl:152-155).  One workgroup of
-// 256 threads; wave w sums the partial lists of sweeps w, w + 4, ... exactly as k_jacobi_check_multi does (64-lane strided sums, then the
-// DPP wave sum), eight lists at a time so that their loads are in flight together; the tests are then evaluated 64 at a time.
-// group0 = index of the launch's first group in the whole solve (FprSolveState::group is global).
+// Behind a launch of k_jacobi_persist: the per-sweep exit test of its groups, in order (multigrid.jl:152-155).  One workgroup per GROUP
+// sums that group's partial lists exactly as k_jacobi_check_multi does (wave w: sweeps w, w + 4; 64-lane strided sums, then the DPP wave
+// sum) and leaves the S sums in global memory (agent-scope atomic stores); the workgroup whose arrival at the counter is the last one
+// then evaluates the tests in order, 64 at a time.  (One workgroup summing all 256 lists took 96 us behind a 195 us launch.)
+// group0 = index of the launch's first group in the whole solve (FprSolveState::group is global).  *counter is zero between launches.
 __global__ __launch_bounds__(256) void k_jacobi_check_groups(FprSolveState* st, const double* __restrict__ partials, int nblk, int ngroups,
-                                                             int S, int nsw_last, double N, int group0, const int* __restrict__ abort_flag)
+                                                             int S, int nsw_last, double N, int group0, const int* __restrict__ abort_flag,
+                                                             double* __restrict__ gsums, int* __restrict__ counter)
 {
-    __shared__ double sums[256];
-    if (st->done) return;
+    __shared__ int s_last;
+    if (st->done) return;      // (uniform over the launch: st is written only by the last workgroup, behind everybody's arrival)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int total = (ngroups - 1) * S + nsw_last;          // sweeps of the launch, in order: list index = group * S + sweep
-    auto list_of = [&](int q) { return (q / S) * S + (q % S); };   // (q < (ngroups-1)*S: identity; kept for clarity of the layout)
-    for (int q0 = wv; q0 < total; q0 += 4 * 8) {
-        double acc[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int q = q0 + 4 * k;
-            double t = 0.0;
-            if (q < total)
-                for (int i = lane; i < nblk; i += 64) t += partials[(size_t)list_of(q) * nblk + i];
-            acc[k] = t;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int q = q0 + 4 * k;
-            const double v = fpr_wave_sum_all(acc[k]);
-            if (lane == 0 && q < total) sums[q] = v;
-        }
+    const int g = blockIdx.x;
+    const int nsw = g == ngroups - 1 ? nsw_last : S;
+    for (int sw = wv; sw < nsw; sw += 4) {
+        double t = 0.0;
+        for (int i = lane; i < nblk; i += 64) t += partials[((size_t)g * S + sw) * nblk + i];
+        t = fpr_wave_sum_all(t);
+        if (lane == 0) __hip_atomic_store(gsums + g * S + sw, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the sums have left every wave
     __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
     if (wv == 0) {
+        const int total = (ngroups - 1) * S + nsw_last;      // sweeps of the launch, in order: index = group * S + sweep
         int first = -1;
         double rms_last = 0.0;
         for (int base = 0; base < total && first < 0; base += 64) {
             const int q = base + lane;
-            const double rms = q < total ? sqrt(sums[q < 256 ? q : 0] / N) : 0.0;
+            const double v = q < total ? __hip_atomic_load(gsums + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            const double rms = q < total ? sqrt(v / N) : 0.0;
             const unsigned long long hit = __ballot(q < total && rms < st->thresh);
             const int n_here = total - base < 64 ? total - base : 64;
             const int last = hit ? (int)__builtin_ctzll(hit) : n_here - 1;
@@ -224,6 +222,7 @@ __global__ __launch_bounds__(256) void k_jacobi_check_groups(FprSolveState* st, 
             if (hit) first = base + last;
         }
         if (lane == 0) {
+            *counter = 0;
             if (abort_flag && *abort_flag) {
                 st->done = -1;            // a wait timed out: the host gives up on this form
             } else if (first >= 0) {

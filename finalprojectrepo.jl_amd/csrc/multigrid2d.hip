@@ -1222,12 +1222,14 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                 }
                 const int GMAX = 32;    // groups per launch: 256 sweeps, whose exit tests one workgroup replays behind the launch
                 CgWork w;
-                if (nblk <= ctx->jacp_resident / 2 && (size_t)GMAX * 8 * nblk <= (size_t)FPR_MAX_PARTIALS - 1024 && cg_work(ctx, N, &w) == FPR_OK) {
+                if (nblk <= ctx->jacp_resident / 2 && (size_t)GMAX * 8 * nblk <= (size_t)FPR_MAX_PARTIALS - 2048 && cg_work(ctx, N, &w) == FPR_OK) {
                     double* B[4] = {u, L.tmp, w.r, w.p};
                     int* flags = reinterpret_cast<int*>(ctx->partials + FPR_MAX_PARTIALS - 1024);   // nblk <= 2048 words + the abort word
                     if (nblk + 8 > 2048) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for the flag block");
-                    int* abort_flag = flags + 2040;
-                    FPR_HIP(ctx, hipMemsetAsync(abort_flag, 0, sizeof(int), s));
+                    int* abort_flag = flags + 2040;      // [2040] abort, [2041] arrival counter of the check's workgroups
+                    int* counter = flags + 2041;
+                    double* gsums = ctx->partials + FPR_MAX_PARTIALS - 2048;   // 256 sums of a launch (behind the partial lists, before the flags)
+                    FPR_HIP(ctx, hipMemsetAsync(flags, 0, 2048 * sizeof(int), s));   // flags count groups since the start of the solve
                     struct Rec { int x, w[3], g0, G; };
                     std::vector<Rec> recs;
                     int cur = 0, gdone = 0, poll_after = 1, since_poll = 0;
@@ -1244,11 +1246,11 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                         a.ngroups = G;
                         a.nsw_last = (gdone + G == groups) ? iters - (groups - 1) * 8 : 8;
                         a.partials = ctx->partials; a.flags = flags; a.abort_flag = abort_flag; a.state = ctx->state;
-                        FPR_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)nblk * sizeof(int), s));
+                        a.g0 = gdone;
                         const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_PATCH, s);
                         k_jacobi_persist<8, PP><<<gm, (PP / 2) * (PP / 2), 0, s>>>(a);
                         fpr_ktimer_end(ctx, timed, s);
-                        k_jacobi_check_groups<<<1, 256, 0, s>>>(ctx->state, ctx->partials, nblk, G, 8, a.nsw_last, (double)N, gdone, abort_flag);
+                        k_jacobi_check_groups<<<G, 256, 0, s>>>(ctx->state, ctx->partials, nblk, G, 8, a.nsw_last, (double)N, gdone, abort_flag, gsums, counter);
                         FPR_CHECK_LAUNCH(ctx);
                         recs.push_back(r);
                         cur = r.w[G % 3];                  // the last group (index G - 1) wrote W[G % 3]

@@ -48,7 +48,7 @@ export @init_parallel_stencil, @reset_parallel_stencil, @parallel, @parallel_ind
        halo_pack!, halo_unpack!, fpr_version,
        init_global_grid, finalize_global_grid, select_device, update_halo!, gather!, nx_g, ny_g, nz_g, x_g, y_g, z_g,
        halo_exchange_begin!, halo_exchange_end!, halo_exchange_comm!, allreduce_sum!, diffusion_3D_array_programming,
-       diffusion_3D_step_τ2_halo!, join_pair!
+       diffusion_3D_step_τ2_halo!, join_pair!, alloc_fields
 
 const libfpr = get(ENV, "FPR_HIP_LIB", joinpath(@__DIR__, "..", "finalprojectrepo.jl_amd", "lib", "libfpr_hip.so"))
 
@@ -493,6 +493,63 @@ function dist_norm_L2(Rh::DA, comm_cart; scale = 1.0)
     return sqrt(sq)
 end
 copy_device!(dst::DA, src::DA) = check(ccall((:fpr_copy, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Csize_t), ctx(), p(dst), p(src), length(dst)))
+
+"""
+    alloc_fields(count, dims...; pool = count + 7, pairs = nothing, spacer_bytes = nothing) -> Vector{ROCArray{Float64}}
+
+Field arrays placed for the streaming kernels (twin of `finalprojectrepo.jl_amd/placement.py`, DESIGN.md 3): on MI355X two arrays that a
+kernel streams at equal offsets get in each other's way when their allocations carry the same placement label (a property of the physical
+pages: the fused diffusion launch takes 0.775 ms at 512^3 on arrays that differ, 0.85-0.91 ms on arrays of one class).  The label cannot
+be computed from a pointer, so a pool of candidates is allocated (with untouched spacer allocations between them), `fpr_copy` is timed
+between every pair, and the assignment of candidates to the `count` positions whose slowest streamed-together pair (`pairs`, default all)
+copies fastest is kept; the rest is freed.  Optional: time a few launches of the caller's own kernel on the best few assignments and keep the
+fastest (bench.py does).  Replaces nothing in the reference: `@zeros` (part1_kernel_programming.jl:134-142) keeps working without it.
+"""
+function alloc_fields(count::Integer, dims::Integer...; pool::Integer = count + 7, pairs = nothing, spacer_bytes = nothing)
+    nbytes = 8 * prod(dims)
+    (nbytes < (256 << 20) || count < 2) && return [AMDGPU.zeros(Float64, dims...) for _ in 1:count]
+    spacer = spacer_bytes === nothing ? (nbytes >= (512 << 20) ? 3 * nbytes : 0) : spacer_bytes
+    cands, spacers = DA[], Any[]
+    for i in 1:pool
+        push!(cands, AMDGPU.zeros(Float64, dims...))
+        (spacer > 0 && i < pool) && push!(spacers, ROCArray{UInt8}(undef, spacer))      # reserved, never touched
+    end
+    t = zeros(pool, pool)
+    for i in 1:pool, j in 1:pool
+        i == j && continue
+        copy_device!(cands[j], cands[i])                                                 # warm-up
+        AMDGPU.synchronize()
+        t[i, j] = AMDGPU.@elapsed begin copy_device!(cands[j], cands[i]); copy_device!(cands[j], cands[i]) end
+    end
+    sym = (t .+ t') ./ 2
+    prs = pairs === nothing ? [(a, b) for a in 1:count for b in a+1:count] : pairs
+    roles = sort(unique(vcat([collect(q) for q in prs]...)))
+    best, best_cost = nothing, (Inf, Inf)
+    function search(assign)                              # assignments of candidates to the positions that matter, depth first
+        if length(assign) == length(roles)
+            where_ = Dict(zip(roles, assign))
+            ts = [sym[where_[a], where_[b]] for (a, b) in prs]
+            cost = (maximum(ts), sum(ts))
+            cost < best_cost && ((best, best_cost) = (copy(assign), cost))
+            return
+        end
+        for c in 1:pool
+            c in assign && continue
+            push!(assign, c); search(assign); pop!(assign)
+        end
+    end
+    search(Int[])
+    out = Vector{Any}(nothing, count)
+    for (pos, c) in zip(roles, best); out[pos] = cands[c]; end
+    rest = [c for c in 1:pool if !(c in best)]
+    for pos in 1:count
+        out[pos] === nothing && (out[pos] = cands[popfirst!(rest)])
+    end
+    for c in rest; AMDGPU.unsafe_free!(cands[c]); end
+    for q in spacers; AMDGPU.unsafe_free!(q); end
+    foreach(A -> fill_device!(A, 0.0), out)
+    return DA[out...]
+end
 fill_device!(dst::DA, v) = check(ccall((:fpr_fill, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Csize_t), ctx(), p(dst), v, length(dst)))
 fill_on!(dst::DA, v, stream_sel) = check(ccall((:fpr_fill_on, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Csize_t, Cint), ctx(), p(dst), v, length(dst), stream_sel))
 add_on!(dst::DA, src::DA, stream_sel) = check(ccall((:fpr_add_on, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Csize_t, Cint), ctx(), p(dst), p(src), length(dst), stream_sel))

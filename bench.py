@@ -309,7 +309,8 @@ def vcycle_block(F, with_cpu=True, steps=5, place=True):
     placement = {}
 
     def trial(arrs):
-        tx, tb = arrs
+        tx, tb, t1, t2 = arrs
+        mg.provide_arena_(n, n, t1, t2)              # the finest level's ping-pong partners travel with the candidates
         tb.copy_(b0)
         best = None
         for _ in range(3):
@@ -325,8 +326,10 @@ def vcycle_block(F, with_cpu=True, steps=5, place=True):
         return best * 1e3
 
     if place:
-        trial([F.fzeros(n, n), b0.clone()])          # the arena exists before the candidates are allocated
-        x, b = F.placement.alloc_fields(2, n, n, pool=8, min_bytes=64 << 20, report=placement, pairs=[(0, 1)], trial=trial, trials=2)
+        # streamed together at equal offsets by the passes over the finest grid: (u, f), (partner, f), (partner, partner), (u, partner)
+        x, b, t1, t2 = F.placement.alloc_fields(4, n, n, pool=10, min_bytes=64 << 20, report=placement,
+                                                pairs=[(0, 1), (2, 1), (3, 1), (2, 3), (0, 2)], trial=trial, trials=3)
+        mg.provide_arena_(n, n, t1, t2)
         b.copy_(b0)
         del b0
     else:

@@ -50,10 +50,10 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
     fpr_reserve_comm_cus(ctx, 0);
     for (auto& kv : ctx->arenas)
         for (auto& L : kv.second) {
-            if (L.tmp) hipFree(L.tmp);
+            if (L.tmp && L.own_tmp) hipFree(L.tmp);
             if (L.res_c) hipFree(L.res_c);
             if (L.corr_c) hipFree(L.corr_c);
-            if (L.tmp2) hipFree(L.tmp2);
+            if (L.tmp2 && L.own_tmp2) hipFree(L.tmp2);
             if (L.corr_c2) hipFree(L.corr_c2);
         }
     for (auto& e : ctx->ktimer_ev) hipEventDestroy(e);

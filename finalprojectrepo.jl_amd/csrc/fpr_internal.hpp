@@ -54,6 +54,7 @@ struct FprLevel {  // one multigrid level's scratch (role of prealloc_dict, mult
     // is never scratch, and a second coarse correction, so that one pass can read cycle k's while it zeroes cycle k+1's
     double* tmp2 = nullptr;
     double* corr_c2 = nullptr;
+    bool own_tmp = true, own_tmp2 = true;   // false: the caller's buffer (fpr_mg_arena_provide), not freed by the library
 };
 
 struct FprGrid {  // implicit global grid of the decomposed diffusion path (role of ImplicitGlobalGrid's global state)

@@ -891,6 +891,34 @@ static int get_arena(fpr_ctx* ctx, int nx, int ny, int css, std::vector<FprLevel
     return FPR_OK;
 }
 
+// The finest level's two ping-pong partners from the caller (role of prealloc_dict's fine-level buffers, multigrid.jl:25-38, 49-51):
+// the passes over the finest grid stream u / f and these two at equal offsets, and on MI355X their speed depends on which physical
+// pages the allocations received -- a host that places its arrays can place these two as well.  NULL = the library's own.
+extern "C" int fpr_mg_arena_provide(fpr_ctx* ctx, int nx, int ny, double* tmp, double* tmp2)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    if (int rc = check_dims(ctx, nx, ny)) return rc;
+    FPR_REQUIRE(ctx, (((uintptr_t)tmp | (uintptr_t)tmp2) & 7) == 0, "buffers must be 8-byte aligned");
+    std::vector<FprLevel>* A = nullptr;
+    if (int rc = get_arena(ctx, nx, ny, 0, &A)) return rc;
+    FprLevel& L = (*A)[0];
+    for (int s = 0; s < 3; ++s) FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[s]));   // nothing in flight uses the buffers that leave
+    const size_t bytes = (size_t)nx * ny * sizeof(double);
+    auto swap_in = [&](double*& slot, bool& own, double* mine) -> int {
+        if (mine) {
+            if (slot && own) FPR_HIP(ctx, hipFree(slot));
+            slot = mine; own = false;
+        } else if (!own || !slot) {      // back to a buffer of the library's own
+            slot = nullptr; own = true;
+            FPR_HIP(ctx, hipMalloc(&slot, bytes));
+        }
+        return FPR_OK;
+    };
+    if (int rc = swap_in(L.tmp, L.own_tmp, tmp)) return rc;
+    if (int rc = swap_in(L.tmp2, L.own_tmp2, tmp2)) return rc;
+    return FPR_OK;
+}
+
 #include "mg_mid.hpp"     // k_mid_down, k_mid_up: three launch-bound levels in two launches
 
 // Does the sub-hierarchy below an (nx, ny) level fit k_mg_small's LDS arena?  nlev = its levels, tot = doubles needed.

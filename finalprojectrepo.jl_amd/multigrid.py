@@ -56,6 +56,17 @@ def preallocate_buffers(nx, ny):
     return {"nx": nx, "ny": ny}
 
 
+def provide_arena_(nx, ny, tmp=None, tmp2=None):
+    """fpr_mg_arena_provide: the finest level's two ping-pong partners of an (nx, ny) hierarchy from the caller (column-major
+    float64 device arrays of that shape; None = the library's own again).  The context keeps them alive.  Used to place them
+    together with u and f (placement.alloc_fields); results do not depend on it."""
+    c = _ctx()
+    c.call("fpr_mg_arena_provide", int(nx), int(ny), fptr(tmp, 2) if tmp is not None else None, fptr(tmp2, 2) if tmp2 is not None else None)
+    if not hasattr(c, "_arena_refs"):
+        c._arena_refs = {}
+    c._arena_refs[(int(nx), int(ny))] = (tmp, tmp2)
+
+
 def _policy(p):
     if p == serial or p not in (parallel, parallel_shmem):
         raise RuntimeError("execution policy %r not implemented (reference: error(), multigrid.jl:233-236)" % (p,))

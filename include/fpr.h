@@ -356,6 +356,13 @@ int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h, double c, 
 int fpr_cg2d(fpr_ctx* ctx, double* x_in, const double* b, double hx, double hy, double c, double tol, int Nmax,
              int nx, int ny, double* rms_host, int* iters_host);
 
+/* prealloc_dict (multigrid.jl:25-38, 49-51: the reference lets the caller own the level buffers): the finest level's two
+ * ping-pong partners of an (nx, ny) hierarchy, nx * ny doubles each, owned by the CALLER from now on (not freed by the library; they
+ * must outlive every solve at this size or be withdrawn first).  NULL for one of them = a buffer of the library's own (again).  The
+ * passes over the finest grid stream u, f and these two at equal offsets; on MI355X a host that places its field arrays
+ *  places these two with them.  Waits for the context's streams; results do not depend on it. */
+int fpr_mg_arena_provide(fpr_ctx* ctx, int nx, int ny, double* tmp, double* tmp2);
+
 /* coarse-solver iterations spent by the last fpr_vcycle2d / fpr_mgsolve2d call (diagnostics) */
 long fpr_last_coarse_iters(fpr_ctx* ctx);
 

@@ -48,7 +48,7 @@ export @init_parallel_stencil, @reset_parallel_stencil, @parallel, @parallel_ind
        halo_pack!, halo_unpack!, fpr_version,
        init_global_grid, finalize_global_grid, select_device, update_halo!, gather!, nx_g, ny_g, nz_g, x_g, y_g, z_g,
        halo_exchange_begin!, halo_exchange_end!, halo_exchange_comm!, allreduce_sum!, diffusion_3D_array_programming,
-       diffusion_3D_step_τ2_halo!, join_pair!, alloc_fields
+       diffusion_3D_step_τ2_halo!, join_pair!, alloc_fields, provide_arena!
 
 const libfpr = get(ENV, "FPR_HIP_LIB", joinpath(@__DIR__, "..", "finalprojectrepo.jl_amd", "lib", "libfpr_hip.so"))
 
@@ -792,6 +792,19 @@ mutable struct MGOpt                                            # multigrid.jl:1
 end
 "multigrid.jl:25-38: the level arena is owned by the library context; a token keeps the call signature."
 preallocate_buffers(nx, ny) = Dict{Symbol,Any}(:nx => nx, :ny => ny)
+const ARENA_REFS = Dict{Tuple{Int,Int},Any}()      # keeps buffers handed to the library alive
+"""
+    provide_arena!(nx, ny, tmp, tmp2)
+
+The finest level's two ping-pong partners of an (nx, ny) hierarchy from the caller (`nothing` = the library's own again): what
+`prealloc_dict` is for in multigrid.jl:49-51.  Lets a host that places its field arrays (`alloc_fields`) place these two with `u` and `f`.
+"""
+function provide_arena!(nx::Integer, ny::Integer, tmp::Union{DA,Nothing}, tmp2::Union{DA,Nothing})
+    pt(A) = A === nothing ? Ptr{Cdouble}(C_NULL) : p(A)
+    check(ccall((:fpr_mg_arena_provide, libfpr), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}), ctx(), nx, ny, pt(tmp), pt(tmp2)))
+    ARENA_REFS[(Int(nx), Int(ny))] = (tmp, tmp2)
+    return nothing
+end
 policy_ok(pol) = (pol in (parallel, parallel_shmem)) || error()    # multigrid.jl:233-236
 
 function residual_2DPoisson!(u::DA, f::DA, h::Float64, c::Float64, res::DA)

@@ -455,6 +455,31 @@ def test_coarse_jacobi_persistent_launches_equal_the_plain_ones(fpr, oracle, tol
     assert it_ref > 0
 
 
+def test_provided_arena_buffers_change_nothing(fpr):
+    """fpr_mg_arena_provide (prealloc_dict, multigrid.jl:25-38, 49-51): the finest level's two ping-pong partners from the caller,
+    then the library's own again -- the solve is the same bit for bit either way, and the caller's buffers are really used."""
+    F, mg = fpr, fpr.multigrid
+    n = 513
+    h = 1.0 / (n - 1)
+    b = F.asdevice(rnd((n, n), 71))
+    outs = []
+    t1, t2 = F.fzeros(n, n), F.fzeros(n, n)
+    t1.fill_(7.0); t2.fill_(7.0)
+    for provided in (False, True, False):
+        mg.provide_arena_(n, n, t1 if provided else None, t2 if provided else None)
+        if not provided:
+            t1.fill_(7.0); t2.fill_(7.0)
+        x = F.fzeros(n, n)
+        r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, b, h, 0.0, 1e-8, 50, False, return_history=True)
+        outs.append((r, tuple(hist), cit, F.tonumpy(x)))
+        touched = bool((t1 != 7.0).any()) or bool((t2 != 7.0).any())
+        assert touched == provided
+    for o in outs[1:]:
+        assert o[0] == outs[0][0] and o[1] == outs[0][1] and o[2] == outs[0][2] and np.array_equal(o[3], outs[0][3])
+    with pytest.raises(F.FprError):
+        F.ctx().call("fpr_mg_arena_provide", 2, 2, None, None)     # grids are at least 3 x 3
+
+
 def test_multisweep_and_single_sweep_paths_agree(fpr):
     """Temporal blocking (mg_multi) and the LDS-resident coarse hierarchy (mg_small) change no bit."""
     F, mg = fpr, fpr.multigrid

@@ -27,7 +27,12 @@ def timer(kind):
     return tot.value / max(cnt.value, 1)
 
 
+NEW_CTX = len(sys.argv) > 2 and sys.argv[2] == "newctx"    # a fresh context (= a fresh level arena inside the library) every round
 for rnd in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
+    if NEW_CTX and rnd:
+        keep.append(torch.empty((37 + 61 * rnd) << 20, dtype=torch.uint8, device="cuda"))     # a spacer of another size
+        F.reset()
+        ctx = F.ctx()
     b = F.asdevice(b_host)
     x = F.fzeros(n, n)
     keep += [b, x]

@@ -1260,7 +1260,8 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                     FPR_HIP(ctx, hipMemsetAsync(flags, 0, 2048 * sizeof(int), s));   // flags count groups since the start of the solve
                     struct Rec { int x, w[3], g0, G; };
                     std::vector<Rec> recs;
-                    int cur = 0, gdone = 0, poll_after = 1, since_poll = 0;
+                    int cur = 0, gdone = 0, poll_after = 1, since_poll = 0;   // the host looks after 1, 2, 4, 8, 8, ... launches (a launch behind
+                                                                              // the one that met the criterion returns at once: 5 us)
                     while (gdone < groups) {
                         const int G = groups - gdone < GMAX ? groups - gdone : GMAX;
                         Rec r;
@@ -1285,7 +1286,7 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                         gdone += G;
                         if (++since_poll >= poll_after || gdone >= groups) {
                             since_poll = 0;
-                            if (poll_after < 4) poll_after *= 2;
+                            if (poll_after < 8) poll_after *= 2;
                             if (int rc = read_state(ctx)) return rc;
                             if (ctx->state_h->done) break;
                         }

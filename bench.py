@@ -205,11 +205,22 @@ def supervise(args):
             first_failure = failure
             time.sleep(1.0)          # every supervisor has seen the marker and ended its worker before fresh ones meet
             continue
+        # rank 0 reports; the others leave only once it has (the launcher ends every rank as soon as one exits non-zero)
+        reported = os.path.join(jd, "reported")
         if rank == 0:
             print(json.dumps({"metric": "diffusion3d_effective_memory_throughput", "value": None, "unit": "GB/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "error": "both attempts failed",
                               "attempts": [first_failure, failure]}))
             sys.stdout.flush()
+            try:
+                open(reported, "w").close()
+            except OSError:
+                pass
+            time.sleep(1.0)          # (the others are on their way out; the job directory goes last)
+        else:
+            t_wait = time.time()
+            while not os.path.exists(reported) and time.time() - t_wait < 20.0:
+                time.sleep(0.05)
         rc = 1
     if rank == 0:
         time.sleep(0.5)

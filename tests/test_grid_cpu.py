@@ -219,7 +219,7 @@ def test_bench_watchdog_fails_a_stalled_attempt_and_falls_back_to_the_plain_chor
     import time
 
     t0 = time.time()
-    p = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--dry-run-hang", "1", "--watchdog-s", "3"])
+    p = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--dry-run-hang", "1", "--watchdog-s", "6"])
     assert p.returncode == 0, p.stderr[-2000:]
     assert time.time() - t0 < 120
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -240,7 +240,7 @@ def test_bench_watchdog_second_failure_exits_nonzero_within_bounds():
 
     t0 = time.time()
     p = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--dry-run-hang", "0", "--dry-run-hang-always",
-                "--watchdog-s", "3"])
+                "--watchdog-s", "6"])
     assert p.returncode != 0
     assert time.time() - t0 < 120
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -266,7 +266,7 @@ def test_bench_watchdog_under_torch_distributed_run():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--dry-run", "--dry-run-hang", "1", "--watchdog-s", "3"], env=env, capture_output=True, text=True, timeout=300)
+                        "--dry-run", "--dry-run-hang", "1", "--watchdog-s", "6"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout

@@ -208,10 +208,11 @@ def supervise(args):
         # rank 0 reports; the others leave only once it has (the launcher ends every rank as soon as one exits non-zero)
         reported = os.path.join(jd, "reported")
         if rank == 0:
-            print(json.dumps({"metric": "diffusion3d_effective_memory_throughput", "value": None, "unit": "GB/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "error": "both attempts failed",
-                              "attempts": [first_failure, failure]}))
-            sys.stdout.flush()
+            if phases.get("0") != "norm_failed":     # (a fallback whose norm is wrong has printed its own line, norm_check.ok = false)
+                print(json.dumps({"metric": "diffusion3d_effective_memory_throughput", "value": None, "unit": "GB/s", "n_gpus": world,
+                                  "steps": args.steps, "warmup": args.warmup, "error": "both attempts failed",
+                                  "attempts": [first_failure, failure]}))
+                sys.stdout.flush()
             try:
                 open(reported, "w").close()
             except OSError:

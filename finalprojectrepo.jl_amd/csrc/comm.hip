@@ -189,8 +189,8 @@ static int check_grid(fpr_ctx* ctx, const double* A, int nx, int ny, int nz)
 // low side first, sends high side first -- when both neighbours of a dimension are the same rank (periodic with
 // dims <= 2, including a rank that is its own neighbour) RCCL matches the k-th send to a peer with the k-th receive
 // from it, so the high plane lands in the peer's low halo and vice versa.
-static int post_group(fpr_ctx* ctx, double* A, int mask, hipStream_t s)
-{
+static int post_group(fpr_ctx* ctx, double* A, int mask, hipStream_t s, const double* const* xsend = nullptr, double* const* xrecv = nullptr)
+{   // xsend / xrecv: buffers for the two x-faces instead of the grid's packed-plane buffers
     const FprGrid& g = ctx->grid;
     const int nx = g.n[0], ny = g.n[1], nz = g.n[2];
     const size_t pz = (size_t)nx * ny;
@@ -207,7 +207,7 @@ static int post_group(fpr_ctx* ctx, double* A, int mask, hipStream_t s)
         for (int side = 0; side < 2 && first == ncclSuccess; ++side) {
             const int f = 2 * d + side;
             if (!((mask >> f) & 1) || g.nb[f] < 0) continue;
-            double* dst = d == 2 ? A + (side ? (size_t)(nz - 1) * pz : 0) : g.recvbuf[f];
+            double* dst = d == 2 ? A + (side ? (size_t)(nz - 1) * pz : 0) : ((d == 0 && xrecv) ? xrecv[side] : g.recvbuf[f]);
             first = ncclRecv(dst, count[d], ncclDouble, g.nb[f], comm_of(ctx), s);
             what = "ncclRecv";
         }
@@ -215,7 +215,7 @@ static int post_group(fpr_ctx* ctx, double* A, int mask, hipStream_t s)
         for (int side = 1; side >= 0 && first == ncclSuccess; --side) {
             const int f = 2 * d + side;
             if (!((mask >> f) & 1) || g.nb[f] < 0) continue;
-            const double* src = d == 2 ? A + (side ? (size_t)(nz - 2) * pz : pz) : g.sendbuf[f];
+            const double* src = d == 2 ? A + (side ? (size_t)(nz - 2) * pz : pz) : ((d == 0 && xsend) ? xsend[side] : g.sendbuf[f]);
             first = ncclSend(src, count[d], ncclDouble, g.nb[f], comm_of(ctx), s);
             what = "ncclSend";
         }
@@ -269,24 +269,31 @@ extern "C" int fpr_halo_exchange3d_end(fpr_ctx* ctx, double* A, int nx, int ny, 
 // For callers that keep a chain of thin-box launches and exchanges on the comm stream beside one long launch on the
 // compute stream (the fused pairs of a decomposed run, GlobalGrid.step2): no event between the two streams per exchange.
 // As with _begin/_end all faces travel concurrently: edge and corner halo cells are not refreshed.
-extern "C" int fpr_halo_exchange3d_comm(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face_mask)
+int fprx_halo_exchange3d_comm_x(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face_mask, const double* const xsend[2],
+                                double* const xrecv[2])
 {
     if (!ctx) return FPR_ERR_INVALID;
     if (int rc = check_grid(ctx, A, nx, ny, nz)) return rc;
     const FprGrid& g = ctx->grid;
+    const bool xown = xsend && xrecv;   // the x-planes are the caller's strips: sent and received as they are
     bool any = false;
     for (int f = 0; f < 6; ++f) {
         if (!((face_mask >> f) & 1) || g.nb[f] < 0) continue;
         any = true;
-        if ((f >> 1) != 2)
+        if ((f >> 1) != 2 && !((f >> 1) == 0 && xown))
             if (int rc = fpr_halo_pack3d(ctx, A, nx, ny, nz, f, g.sendbuf[f], 1)) return rc;
     }
     if (!any) return FPR_OK;
-    if (int rc = post_group(ctx, A, face_mask, ctx->stream[1])) return rc;
-    for (int f = 0; f < 4; ++f)
+    if (int rc = post_group(ctx, A, face_mask, ctx->stream[1], xown ? xsend : nullptr, xown ? xrecv : nullptr)) return rc;
+    for (int f = xown ? 2 : 0; f < 4; ++f)
         if (((face_mask >> f) & 1) && g.nb[f] >= 0)
             if (int rc = fpr_halo_unpack3d(ctx, A, nx, ny, nz, f, g.recvbuf[f], 1)) return rc;
     return FPR_OK;
+}
+
+extern "C" int fpr_halo_exchange3d_comm(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face_mask)
+{
+    return fprx_halo_exchange3d_comm_x(ctx, A, nx, ny, nz, face_mask, nullptr, nullptr);
 }
 
 // update_halo!(A): dimension by dimension (x, then y, then z), each after the previous one has been unpacked, as

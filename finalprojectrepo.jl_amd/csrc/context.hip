@@ -62,6 +62,7 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
     if (ctx->partials2) hipFree(ctx->partials2);
     if (ctx->core_partials) hipFree(ctx->core_partials);
     if (ctx->tickets) hipFree(ctx->tickets);
+    if (ctx->xstrips) hipFree(ctx->xstrips);
     if (ctx->reserved_map) hipFree(ctx->reserved_map);
     if (ctx->scalars) hipFree(ctx->scalars);
     if (ctx->state) hipFree(ctx->state);

@@ -10,6 +10,8 @@
 // two pseudo-iterations per pass (temporal blocking): main kernel and the kernel for boxes that are narrow in x
 #include "diffusion3d_fused2.hpp"
 #include "diffusion3d_slab2.hpp"
+// the shell next to an x-neighbour in compact strips
+#include "diffusion3d_xstrip.hpp"
 
 static int diff3_run(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2, double* dHdtau, int nx, int ny,
                      int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy,
@@ -508,18 +510,58 @@ extern "C" int fpr_diffusion3d_step2_core(fpr_ctx* ctx, const double* Ht, const 
 //   comm stream : z / y slabs' first iteration -> exchange(level 1 in Hmid) -> fused launches on the shell -> exchange(Hout) --^
 // join = 0 leaves the pair on those two streams; the next pair continues from there, fpr_diffusion3d_join (or any entry point of
 // the grid: fpr_halo_exchange3d*, fpr_allreduce_sum*) orders the compute stream behind it.
-static int diff3_comm_units(const FprGrid& g)
+static int diff3_comm_units(const FprGrid& g, bool xstrips)
 {
     int work = 0;
-    const int w[3] = {5, 2, 1};   // an x-slab costs about five z-slabs (lanes along y, one cache line per access), a y-slab two
+    // an x-slab in the field costs about five z-slabs (lanes along y, one cache line per access), a y-slab two; an x-shell in
+    // compact strips (diffusion3d_xstrip.hpp) about as much as a y-slab
+    const int w[3] = {xstrips ? 2 : 5, 2, 1};
     for (int f = 0; f < 6; ++f)
         if (g.nb[f] >= 0) work += w[f >> 1];
     // Measured at 512^3 (tools/attic/dbg_faces2.py, two faces per dimension): z 16 units +7 %, 32 +9-11 %; y 16 +9.1 %, 24 +10.9 %,
     // 32 +12.2 %; yz 24 +12 %, 16 +12.6 %, 32 +14.2 %; with x-faces the chain is nearly as long as the core launch and 32 (64 above
     // two x-faces' worth of work) stays the best.  Shares that are no multiple of 32 use the unmasked core stream (fpr_reserve_comm_cus).
     bool anyx = g.nb[0] >= 0 || g.nb[1] >= 0;
-    if (!anyx) return work > 4 ? 24 : 16;
+    if (!anyx || xstrips) return work > 4 ? 24 : 16;
     return work > 10 ? 64 : 32;
+}
+
+// Strips of the x-faces with a neighbour: storage (kept in the context), per-face geometry.  boxes: the peeled shell boxes.
+static int diff3_xstrips_setup(fpr_ctx* ctx, Diff3StripArgs& s, int nx, int ny, int nz, const int (*blo)[3], const int (*bhi)[3],
+                               const int* bface, int nbx, int* nfaces_out, int* nblk_out)
+{
+    const long plane = (long)ny * nz;
+    s.stride = ((plane + 511) & ~511L) + 64;
+    s.nyt = (ny - 2 + 61) / 62;
+    s.ntz = (nz - 2 + XS_ZC - 1) / XS_ZC;
+    const int nblk = (int)(((long)s.nyt * s.ntz + 3) / 4);
+    s.pcap = nblk;
+    const size_t need = (size_t)2 * XS_COUNT * s.stride + (size_t)4 * nblk;
+    if (ctx->xstrips_doubles < need) {
+        // (a pending pair may still read the old strips: wait for it before they go)
+        if (ctx->xstrips) { FPR_HIP(ctx, hipDeviceSynchronize()); FPR_HIP(ctx, hipFree(ctx->xstrips)); ctx->xstrips = nullptr; ctx->xstrips_doubles = 0; }
+        FPR_HIP(ctx, hipMalloc(&ctx->xstrips, need * sizeof(double)));
+        FPR_HIP(ctx, hipMemset(ctx->xstrips, 0, need * sizeof(double)));
+        FPR_HIP(ctx, hipDeviceSynchronize());   // (a memset of device memory may return before it has run: not beside the first launches)
+        ctx->xstrips_doubles = need;
+        ctx->xs_field = nullptr;
+    }
+    int nf = 0;
+    for (int b = 0; b < nbx; ++b) {
+        if ((bface[b] >> 1) != 0) continue;
+        Diff3StripFace& F = s.f[nf];
+        F.high = bface[b] & 1;
+        F.s = ctx->xstrips + (size_t)F.high * XS_COUNT * s.stride;
+        F.xo = F.high ? nx - 2 : 1;
+        F.jlo = blo[b][1]; F.jhi = bhi[b][1];
+        F.klo = blo[b][2]; F.khi = bhi[b][2];
+        ++nf;
+    }
+    if (nf == 1) s.f[1] = s.f[0];
+    s.partials = ctx->xstrips + (size_t)2 * XS_COUNT * s.stride;
+    *nfaces_out = nf;
+    *nblk_out = nblk;
+    return FPR_OK;
 }
 
 static int diff3_join(fpr_ctx* ctx, bool async)
@@ -565,17 +607,21 @@ extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const 
         FPR_REQUIRE(ctx, g.nb[f] < 0 || n[f >> 1] >= 8, "a decomposed dimension needs at least 8 cells for shell + core");
     // boundary boxes (0-based [lo, hi)) and the core
     int lo[3] = {1, 1, 1}, hi[3] = {nx - 1, ny - 1, nz - 1};
-    int blo[6][3], bhi[6][3], bdim[6], nbx = 0;
+    int blo[6][3], bhi[6][3], bdim[6], bface[6], nbx = 0;
     for (int d = 2; d >= 0; --d)
         for (int side = 0; side < 2; ++side) {
             if (g.nb[2 * d + side] < 0 || hi[d] - lo[d] < 1) continue;
             for (int e = 0; e < 3; ++e) { blo[nbx][e] = lo[e]; bhi[nbx][e] = hi[e]; }
             if (side == 0) { bhi[nbx][d] = lo[d] + 1; lo[d] += 1; }
             else { blo[nbx][d] = hi[d] - 1; hi[d] -= 1; }
+            bface[nbx] = 2 * d + side;
             bdim[nbx++] = d;
         }
+    // x-faces: the shell column, its neighbours and the travelling planes in compact strips (diffusion3d_xstrip.hpp)
+    bool xs_on = (g.nb[0] >= 0 || g.nb[1] >= 0) && fpr_opt(ctx, "diff3_xstrips", 1) != 0 && (long)ny * nz * 8 < 0x7ffffff0L &&
+                       (long)nx * ny * 8 * 12 < (1L << 31);
     const long k_opt = fpr_opt(ctx, "diff3_comm_units", 0);   // experiments: 8, 16, 32, 64
-    const int k = k_opt > 0 ? (int)k_opt : diff3_comm_units(g);
+    const int k = k_opt > 0 ? (int)k_opt : diff3_comm_units(g, xs_on);
     if (int rc = fpr_reserve_comm_cus(ctx, k)) return rc;
     double* sqs = ctx->scalars + 46;   // the shell chain's two sums (comm stream)
     // an error half way leaves launches on the core / comm streams: the compute stream is ordered behind both before the call
@@ -584,16 +630,49 @@ extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const 
         fpr_ctx* c; bool armed;
         ~Rejoin() { if (armed) { char msg[sizeof(c->err)]; memcpy(msg, c->err, sizeof(msg)); fpr_stream_wait(c, 0, 1); fpr_stream_wait(c, 0, 2); c->pair_pending = false; memcpy(c->err, msg, sizeof(msg)); } }
     } rejoin{ctx, true};
+    const bool was_pending = ctx->pair_pending;
     if (!ctx->pair_pending) {   // (a pending pair left the comm stream behind its core launch and the core stream behind its chain)
         if (int rc = fpr_stream_wait(ctx, 1, 0)) return rc;   // fork: the pair's inputs are ready
         if (int rc = fpr_stream_wait(ctx, 2, 0)) return rc;
     }
 #define D3ARGS nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz
-    // the x-slabs' first iteration on the core stream AHEAD of the core launch (25 us there, 180 us beside it)
+    Diff3StripArgs xs{};
+    int xs_faces = 0, xs_nblk = 0;
+    const double* xsend[2] = {nullptr, nullptr};
+    double* xrecv[2] = {nullptr, nullptr};
+    if (xs_on) {
+        if (int rc = diff3_xstrips_setup(ctx, xs, nx, ny, nz, blo, bhi, bface, nbx, &xs_faces, &xs_nblk)) return rc;
+        xs.A = Htau; xs.Ht = Ht; xs.B = Hmid; xs.C = Hout; xs.dH = dHdtau;
+        xs.nx = nx; xs.ny = ny; xs.nz = nz;
+        xs.dtau = dtau; xs._dt = _dt; xs._dx = _dx; xs._dy = _dy; xs._dz = _dz; xs.D_dx = D_dx; xs.D_dy = D_dy; xs.D_dz = D_dz;
+        xs.scale = scale;
+        if (xs_faces == 0) xs_on = false;
+    }
+    const dim3 xs_cp((ny + 63) / 64, (nz + 3) / 4, xs_faces), xs_cpi((ny - 2 + 63) / 64, (nz - 2 + 3) / 4, xs_faces);
+    double* xs_p1 = xs.partials;
+    double* xs_p2 = xs_on ? xs.partials + (size_t)2 * xs_nblk : nullptr;
+    if (xs_on) {
+        // The strided accesses (one sector per row) stay out of the chain beside the core launch: one launch on the core stream
+        // between two core launches.  The strips of this pair's level 0 are there already when the pair continues a chain: the
+        // previous pair of this context is still pending (nobody can have touched the fields) and wrote this Htau from this Ht.
+        int fm = 0;
+        for (int q = 0; q < xs_faces; ++q) fm |= 1 << xs.f[q].high;
+        const bool cont = was_pending && ctx->xs_field == Htau && ctx->xs_ht == Ht && ctx->xs_faces == fm && ctx->xs_n[0] == nx &&
+                          ctx->xs_n[1] == ny && ctx->xs_n[2] == nz && fpr_opt(ctx, "diff3_xstrips_keep", 1) != 0;
+        if (!cont) {
+            Diff3StripArgs ga = xs;
+            ga.C = const_cast<double*>(Htau);
+            k_xstrip_turn<false, true><<<xs_cp, dim3(64, 4), 0, ctx->stream[2]>>>(ga);
+            FPR_CHECK_LAUNCH(ctx);
+            if (int rc = fpr_stream_wait(ctx, 1, 2)) return rc;   // the chain reads the strips
+        }
+        ctx->xs_field = nullptr;   // (set again when this pair has been turned around)
+    }
+    // without strips: the x-slabs' first iteration on the core stream AHEAD of the core launch (25 us there, 180 us beside it)
     bool anyx = false;
     for (int b = 0; b < nbx; ++b)
-        if (bdim[b] == 0) {
-            if (int rc = diff3_run(ctx, Ht, Htau, Hmid, dHdtau, D3ARGS, blo[b], bhi[b], false, 0.0, nullptr, true, 2)) return rc;
+        if (bdim[b] == 0 && !xs_on) {
+            if (int rc = diff3_run(ctx, Ht, Htau, Hmid, dHdtau ? dHdtau : Hout, D3ARGS, blo[b], bhi[b], false, 0.0, nullptr, true, 2)) return rc;
             anyx = true;
         }
     if (anyx)
@@ -610,10 +689,26 @@ extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const 
                             sumsq2_dev ? &core_nparts : nullptr, k, cpart, FPR_CORE_PARTIALS)) return rc;
     if (sumsq2_dev)
         if (int rc = fpr_fill_on(ctx, sqs, 0.0, 2, 1)) return rc;
+    if (xs_on) {   // level 1 of the x-shell columns: the planes that travel
+        xs.partials = xs_p1;
+        if (sumsq2_dev) k_diff3_xstrip<1, true><<<dim3(xs_nblk, xs_faces), 256, 0, ctx->stream[1]>>>(xs);
+        else k_diff3_xstrip<1, false><<<dim3(xs_nblk, xs_faces), 256, 0, ctx->stream[1]>>>(xs);
+        FPR_CHECK_LAUNCH(ctx);
+        for (int q = 0; q < xs_faces; ++q) {
+            xsend[xs.f[q].high] = xs.f[q].s + (size_t)XS_L1S * xs.stride;
+            xrecv[xs.f[q].high] = xs.f[q].s + (size_t)XS_L1R * xs.stride;
+        }
+    }
+    // (without a residual array the single-step launches leave their residual in the same cells of Hout: the fused launches on
+    // these boxes overwrite them further down the chain)
     for (int b = 0; b < nbx; ++b)
         if (bdim[b] != 0)
-            if (int rc = diff3_run(ctx, Ht, Htau, Hmid, dHdtau, D3ARGS, blo[b], bhi[b], false, 0.0, nullptr, true, 1)) return rc;
-    if (int rc = fpr_halo_exchange3d_comm(ctx, Hmid, nx, ny, nz, mask)) return rc;
+            if (int rc = diff3_run(ctx, Ht, Htau, Hmid, dHdtau ? dHdtau : Hout, D3ARGS, blo[b], bhi[b], false, 0.0, nullptr, true, 1)) return rc;
+    if (int rc = fprx_halo_exchange3d_comm_x(ctx, Hmid, nx, ny, nz, mask, xs_on ? xsend : nullptr, xs_on ? xrecv : nullptr)) return rc;
+    if (xs_on && (mask & ~3)) {   // the y- / z-shell launches read the level-1 halo column from the field
+        k_xstrip_frame<<<xs_cpi, dim3(64, 4), 0, ctx->stream[1]>>>(xs);
+        FPR_CHECK_LAUNCH(ctx);
+    }
     // fused launches on the shell boxes: their level-1 halo cells have just arrived in Hmid
     int b0 = 0;
     if (g.nb[4] >= 0 && g.nb[5] >= 0) {   // the two z-slabs (peeled first, same x / y extent) share one launch
@@ -622,12 +717,36 @@ extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const 
         b0 = 2;
     }
     for (int b = b0; b < nbx; ++b)
-        if (int rc = diff3_run2(ctx, Ht, Htau, Hmid, Hout, dHdtau, D3ARGS, blo[b], bhi[b], scale, sumsq2_dev ? sqs : nullptr, true, 1)) return rc;
+        if (bdim[b] != 0 || !xs_on)
+            if (int rc = diff3_run2(ctx, Ht, Htau, Hmid, Hout, dHdtau, D3ARGS, blo[b], bhi[b], scale, sumsq2_dev ? sqs : nullptr, true, 1)) return rc;
 #undef D3ARGS
-    if (int rc = fpr_halo_exchange3d_comm(ctx, Hout, nx, ny, nz, mask)) return rc;
+    if (xs_on) {   // level 2 of the x-shell columns (level 1 of the halo column has arrived in its strip)
+        xs.partials = xs_p2;
+        if (sumsq2_dev) k_diff3_xstrip<2, true><<<dim3(xs_nblk, xs_faces), 256, 0, ctx->stream[1]>>>(xs);
+        else k_diff3_xstrip<2, false><<<dim3(xs_nblk, xs_faces), 256, 0, ctx->stream[1]>>>(xs);
+        FPR_CHECK_LAUNCH(ctx);
+        if (sumsq2_dev)
+            if (int rc = fprx_finish_sum2(ctx, xs_p1, xs_p2, xs_faces * xs_nblk, sqs, true, 1)) return rc;
+        for (int q = 0; q < xs_faces; ++q) {
+            xsend[xs.f[q].high] = xs.f[q].s + (size_t)XS_CS * xs.stride;
+            xrecv[xs.f[q].high] = xs.f[q].s + (size_t)XS_CR * xs.stride;
+        }
+    }
+    if (int rc = fprx_halo_exchange3d_comm_x(ctx, Hout, nx, ny, nz, mask, xs_on ? xsend : nullptr, xs_on ? xrecv : nullptr)) return rc;
+
     // Every stream wait between two core launches costs 5-8 us of the core stream's time (tools/attic/dbg_faces.py: with none
     // of them a z pair is +3.7 % over the plain launch, with these two +5.3 %, with a third at the top of the next call +5.9 %)
     if (int rc = fpr_stream_wait(ctx, 2, 1)) return rc;       // the core stream takes in the shell chain
+    if (xs_on) {
+        // the pair is turned around behind its core launch: the received halo column, the shell column and its residual go into
+        // the fields, the columns next to the face come back as the next pair's level-0 strips
+        k_xstrip_turn<true, false><<<xs_cp, dim3(64, 4), 0, ctx->stream[2]>>>(xs);
+        FPR_CHECK_LAUNCH(ctx);
+        ctx->xs_field = Hout; ctx->xs_ht = Ht;
+        ctx->xs_faces = 0;
+        for (int q = 0; q < xs_faces; ++q) ctx->xs_faces |= 1 << xs.f[q].high;
+        ctx->xs_n[0] = nx; ctx->xs_n[1] = ny; ctx->xs_n[2] = nz;
+    }
     if (int rc = fpr_stream_wait(ctx, 1, 2)) return rc;       // the comm stream goes on behind the core launch: the next chain ...
     if (sumsq2_dev) {   // ... and the pair's sums = core partials + the shell chain's sums
         if (core_nparts > 0) {

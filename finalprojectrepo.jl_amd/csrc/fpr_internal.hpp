@@ -84,6 +84,11 @@ struct fpr_ctx {
     bool pair_pending = false;         // a fused pair of fpr_diffusion3d_step2_halo left on the core / comm streams (join = 0)
     double* core_partials = nullptr;   // 2 pairs x 2 lists x FPR_CORE_PARTIALS: the core launch's partials, finished on the comm stream
     int pair_parity = 0;
+    double* xstrips = nullptr;         // compact strips of the columns next to x-faces with a neighbour (diffusion3d_xstrip.hpp)
+    size_t xstrips_doubles = 0;
+    const double* xs_field = nullptr;  // the field whose columns next to the x-faces the level-0 strips hold (Hout of the last pair) ...
+    const double* xs_ht = nullptr;     // ... and the Ht whose columns the HT strips hold; valid only while that pair is pending
+    int xs_faces = 0, xs_n[3] = {0, 0, 0};
     int* tickets = nullptr;            // 9 counters of the ticketed reserved form (Diff3Args2::ticket), zero between launches
     unsigned* reserved_map = nullptr;  // 2048 bits, one per (XCC, SE, SH, CU) key: the comm stream's compute units (fpr_reserve_comm_cus), found by a probe launch
     bool core_unmasked = false;        // the core stream has every unit; workgroups of a core launch that land on a comm unit leave at once
@@ -398,5 +403,8 @@ int fprx_cycle_finish(fpr_ctx* ctx, const double* partials, int nparts, double* 
 int fprx_cycle_wait(fpr_ctx* ctx, int slot, int seq, FprCycleCtl* out);
 int fprx_finish_sum2_plus(fpr_ctx* ctx, const double* p0, const double* p1, int nparts, const double* add2_dev, double* out2_dev,
                           int stream_sel);   // out[b] = sum(list b) + add[b]
+// fpr_halo_exchange3d_comm with the x-planes travelling from / into buffers of the caller (no pack / unpack kernels for them)
+int fprx_halo_exchange3d_comm_x(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face_mask, const double* const xsend[2],
+                                double* const xrecv[2]);
 int fprx_finish_sum2(fpr_ctx* ctx, const double* p0, const double* p1, int nparts, double* out2_dev, bool accumulate,
                      int stream_sel);

@@ -504,7 +504,8 @@ class GlobalGrid:
             from ._lib import fptr
 
             self._singles = 0
-            _ctx().call("fpr_diffusion3d_step2_halo", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hτ2, 3), fptr(Hout, 3), fptr(dHdτ, 3),
+            _ctx().call("fpr_diffusion3d_step2_halo", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hτ2, 3), fptr(Hout, 3),
+                        fptr(dHdτ, 3) if dHdτ is not None else None,   # None: the residual is not stored (its norms still are)
                         self.nx, self.ny, self.nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, float(norm_scale),
                         sq2_dev.data_ptr() if sq2_dev is not None else None, 1 if join else 0)
             self._native_pending = not join

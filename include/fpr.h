@@ -144,15 +144,25 @@ int fpr_diffusion3d_step2_core(fpr_ctx* ctx, const double* Ht, const double* Hta
                                double _dz, double D_dx, double D_dy, double D_dz, const int lo[3], const int hi[3],
                                double scale, double* sumsq2_dev, int stream_sel, int reserve_cus, int accumulate);
 /* _halo: TWO iterations on a rank WITH neighbours (fpr_grid_init), halos of Hout refreshed -- what `@hide_communication` + `update_halo!`
- * (part1_kernel_programming.jl:185-190) do for one iteration, for two: the device is split (fpr_reserve_comm_cus, 16, 32 or 64 units for
+ * (part1_kernel_programming.jl:185-190) do for one iteration, for two: the device is split (fpr_reserve_comm_cus, 16 or 24 units for
  * the comm stream by the rank's faces), the core of the local grid runs as ONE fused launch on the core stream, and beside it on the
  * comm stream run the first iteration on the one-cell shell (level 1 into Hmid), the exchange of Hmid's planes, the fused launches on
- * the shell and the exchange of Hout's planes (the x-slabs' first iteration runs on the core stream ahead of the core launch).  Same
+ * the shell and the exchange of Hout's planes.  Same
  * results as two fpr_diffusion3d_step calls each followed by fpr_halo_exchange3d of the written buffer; Hout must carry Htau's
- * physical-boundary values; sumsq2_dev (nullable) receives the LOCAL sums of both iterations.  join = 0 leaves the pair on the core /
+ * physical-boundary values; sumsq2_dev (nullable) receives the LOCAL sums of both iterations; dHdtau may be NULL (residual not
+ * stored).  join = 0 leaves the pair on the core /
  * comm streams: the next _halo call continues from there; fpr_diffusion3d_join waits for it (the HOST waits for the core and comm
  * streams: a wait parked on the compute stream while pairs are in flight slows them; option diff3_join_async = 1 for stream waits
- * instead); call it before anything else reads the fields or the sums.  Without neighbours: fpr_diffusion3d_step2. */
+ * instead); call it before anything else reads OR WRITES the fields or the sums.  Without neighbours: fpr_diffusion3d_step2.
+ * x-faces (csrc/diffusion3d_xstrip.hpp; option diff3_xstrips, default 1): the shell column next to an x-neighbour, the three columns
+ * around it and the planes that travel live in compact strips (ny*nz doubles per column, kept in the context): both iterations of
+ * the shell cells read and write contiguous memory beside the core launch, RCCL sends and receives the strips as they are (no pack /
+ * unpack kernels), and the strided accesses to the fields -- the received halo column, the shell column and its residual into Hout /
+ * dHdtau, the columns next to the face out of Hout for the next pair -- are ONE launch between two core launches.  While a chain of
+ * pairs (join = 0) continues -- this call's Htau is the pending pair's Hout, same Ht -- the strips are reused; otherwise they are
+ * gathered afresh before the core launch (option diff3_xstrips_keep = 0: always).  Edge and corner cells of the halo planes are not
+ * refreshed (as with fpr_halo_exchange3d_begin / _end: all faces travel at once).  diff3_xstrips = 0: the x-shell in the field
+ * (narrow-box kernels, pack / unpack kernels; rounds 2-3). */
 int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Hmid, double* Hout, double* dHdtau,
                                int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx,
                                double D_dy, double D_dz, double scale, double* sumsq2_dev, int join);

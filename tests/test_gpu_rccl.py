@@ -132,7 +132,7 @@ def test_step_and_fused_pair_over_rccl_periodic_z(fpr, oracle, periodic_grid, n)
         gg.step2(gHt, gA, gB, gC, gR, *coef, dt, sq2)
         gA, gC = gC, gA
         got = sq2.cpu().tolist()
-        assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs))
+        assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs)), (it, got, refs)
         assert np.array_equal(F.tonumpy(gA)[1:-1, 1:-1, :], A[1:-1, 1:-1, :])
         assert np.array_equal(F.tonumpy(gR), R)
 
@@ -165,7 +165,7 @@ def test_fused_pair_over_rccl_periodic_xyz(fpr, oracle, periodic_grid):
         gg.step2(gHt, gA, gB, gC, gR, *coef, dt, sq2)
         gA, gC = gC, gA
         got = sq2.cpu().tolist()
-        assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs))
+        assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs)), (it, got, refs)
         loc = F.tonumpy(gA)
         assert np.array_equal(loc[1:-1, 1:-1, 1:-1], A[1:-1, 1:-1, 1:-1])
         for d in range(3):   # halo faces (interiors of the faces; edges / corners are not refreshed by one exchange)
@@ -233,6 +233,101 @@ def test_pairs_chained_on_core_and_comm_streams(fpr, oracle, periodic_grid, peri
         ref = oracle.sumsq_scaled(R, dt)
         assert abs(float(sq[2].item()) - ref) <= 1e-13 * ref
         assert np.array_equal(F.tonumpy(gA)[inner], A[inner]) and np.array_equal(F.tonumpy(gR)[inner], R[inner])
+
+
+@pytest.mark.parametrize("periods,n", [((1, 0, 0), (128, 24, 16)), ((1, 1, 0), (130, 30, 21)), ((1, 1, 1), (132, 70, 13))], ids=["x", "xy", "xyz"])
+@pytest.mark.parametrize("form", ["strips", "strips-regathered", "strips-no-residual", "field"])
+def test_x_shell_in_compact_strips(fpr, oracle, periodic_grid, periods, n, form):
+    """The shell next to an x-neighbour in compact strips (csrc/diffusion3d_xstrip.hpp; part1_kernel_programming.jl:182-188 for a
+    fused pair): seven chained pairs (the strips of a pair's level 0 come from the pair before it: `turn` between two core
+    launches), then a joined pair (plain gather) -- fields, halo planes, residual bit for bit and norms to 1e-13 against the
+    oracle with wrapped halos; the same with the strips gathered afresh for every pair, without a residual array, and through
+    the field (option diff3_xstrips = 0: the narrow-box kernels and pack / unpack kernels of rounds 2-3).  70 rows / 13 planes:
+    two row tiles, two plane chunks with a short last one."""
+    F = fpr
+    c = F.ctx()
+    dims = tuple(d for d in range(3) if periods[d])
+    gg = periodic_grid(n, periods)
+    ext = [m - 2 if p else m for m, p in zip(n, periods)]
+    dx, dy, dz = 10.0 / ext[0], 10.0 / ext[1], 10.0 / ext[2]
+    D, dt = 1.0, 0.2
+    dτ = min(dx, dy, dz) ** 2 / D / 8.1
+    coef = (dτ, 1 / dt, 1 / dx, 1 / dy, 1 / dz, D / dx, D / dy, D / dz)
+    Ht = wrap(rnd(n, 77), dims=dims)
+    A, B, R = Ht.copy(order="F"), farr(*n), farr(*n)
+    gHt, gA, gB, gR = F.asdevice(Ht), F.asdevice(A), F.fzeros(*n), F.fzeros(*n)
+    gC = gA.clone()
+    if not gg.can_step2(gHt, gA, gB, gC, gR):
+        pytest.skip("no fused pairs at this size")
+    res = None if form == "strips-no-residual" else gR
+    c.set_option("diff3_xstrips", 0 if form == "field" else 1)
+    c.set_option("diff3_xstrips_keep", 0 if form == "strips-regathered" else 1)
+    try:
+        npairs = 8
+        sq = F.fzeros(2 * npairs)
+        refs = []
+        for p in range(npairs):
+            for k in range(2):
+                oracle.diffusion3d_step(Ht, A, B, R, *coef)
+                wrap(B, dims=dims)
+                A, B = B, A
+                refs.append(oracle.sumsq_scaled(R, dt))
+            if p == npairs - 1:
+                gg.join()
+            gg.step2(gHt, gA, gB, gC, res, *coef, dt, sq[2 * p:2 * p + 2], join=(p == npairs - 1))
+            gA, gC = gC, gA
+        assert not gg.pending
+        got = sq.cpu().tolist()
+        assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs)), (got, refs)
+        loc = F.tonumpy(gA)
+        inner = (slice(1, -1),) * 3
+        assert np.array_equal(loc[inner], A[inner])
+        for d in dims:   # halo planes (their interiors: edges and corners are not refreshed by one exchange of all faces)
+            for side in (0, -1):
+                idx = [slice(1, -1)] * 3
+                idx[d] = side
+                assert np.array_equal(loc[tuple(idx)], A[tuple(idx)])
+        if res is not None:
+            assert np.array_equal(F.tonumpy(gR)[inner], R[inner])
+    finally:
+        c.set_option("diff3_xstrips", 1)
+        c.set_option("diff3_xstrips_keep", 1)
+
+
+def test_x_strips_with_one_sided_faces_equal_the_field_form(fpr, periodic_grid):
+    """A rank with ONE x-face (low or high) and one y- / z-face, as in a (2,2,2) decomposition: no oracle for a rank that is its
+    own neighbour on one side only, but the strips and the field form (diff3_xstrips = 0) must agree bit for bit."""
+    F = fpr
+    c = F.ctx()
+    n = (128, 36, 20)
+    dx = 10.0 / 126
+    coef = (dx * dx / 8.1, 5.0, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx)
+    Ht = rnd(n, 78)
+    out = {}
+    for drop in (0b010101, 0b101010, 0b111110, 0b111101):
+        for strips in (1, 0):
+            gg = F.grid.GlobalGrid(*n, dims=(1, 1, 1), periods=(1, 1, 1), transport="rccl", use_dist=False, drop_faces=drop)
+            c.set_option("diff3_xstrips", strips)
+            try:
+                gHt, gA, gB, gR = F.asdevice(Ht), F.asdevice(Ht), F.fzeros(*n), F.fzeros(*n)
+                gC = gA.clone()
+                sq = F.fzeros(8)
+                for p in range(4):
+                    gg.step2(gHt, gA, gB, gC, gR, *coef, 0.2, sq[2 * p:2 * p + 2], join=False)
+                    gA, gC = gC, gA
+                gg.join()
+                out[strips] = (F.tonumpy(gA), F.tonumpy(gR), sq.cpu().tolist())
+            finally:
+                c.set_option("diff3_xstrips", 1)
+                F.grid.finalize_global_grid()
+        inner = (slice(1, -1),) * 3
+        assert np.array_equal(out[1][0][inner], out[0][0][inner]) and np.array_equal(out[1][1][inner], out[0][1][inner]), drop
+        for d in range(3):
+            for side in (0, -1):
+                idx = [slice(1, -1)] * 3
+                idx[d] = side
+                assert np.array_equal(out[1][0][tuple(idx)], out[0][0][tuple(idx)]), (drop, d, side)
+        assert all(abs(a - b) <= 1e-13 * abs(b) for a, b in zip(out[1][2], out[0][2])), (drop, out[1][2], out[0][2])
 
 
 def test_core_launch_serves_every_unit_whatever_the_comm_unit_map_says(fpr, periodic_grid):

@@ -510,20 +510,29 @@ extern "C" int fpr_diffusion3d_step2_core(fpr_ctx* ctx, const double* Ht, const 
 //   comm stream : z / y slabs' first iteration -> exchange(level 1 in Hmid) -> fused launches on the shell -> exchange(Hout) --^
 // join = 0 leaves the pair on those two streams; the next pair continues from there, fpr_diffusion3d_join (or any entry point of
 // the grid: fpr_halo_exchange3d*, fpr_allreduce_sum*) orders the compute stream behind it.
-static int diff3_comm_units(const FprGrid& g, bool xstrips)
+static int diff3_chain_work(const FprGrid& g, bool xstrips)
 {
-    int work = 0;
     // an x-slab in the field costs about five z-slabs (lanes along y, one cache line per access), a y-slab two; an x-shell in
-    // compact strips (diffusion3d_xstrip.hpp) about as much as a y-slab
-    const int w[3] = {xstrips ? 2 : 5, 2, 1};
+    // compact strips (diffusion3d_xstrip.hpp) about as much as a z-slab
+    const int w[3] = {xstrips ? 1 : 5, 2, 1};
+    int work = 0;
     for (int f = 0; f < 6; ++f)
         if (g.nb[f] >= 0) work += w[f >> 1];
+    return work;
+}
+
+static int diff3_comm_units(const FprGrid& g, bool xstrips)
+{
+    const int work = diff3_chain_work(g, xstrips);
+    const bool anyx = g.nb[0] >= 0 || g.nb[1] >= 0;
     // Measured at 512^3 (tools/attic/dbg_faces2.py, two faces per dimension): z 16 units +7 %, 32 +9-11 %; y 16 +9.1 %, 24 +10.9 %,
-    // 32 +12.2 %; yz 24 +12 %, 16 +12.6 %, 32 +14.2 %; with x-faces the chain is nearly as long as the core launch and 32 (64 above
-    // two x-faces' worth of work) stays the best.  Shares that are no multiple of 32 use the unmasked core stream (fpr_reserve_comm_cus).
-    bool anyx = g.nb[0] >= 0 || g.nb[1] >= 0;
-    if (!anyx || xstrips) return work > 4 ? 24 : 16;
-    return work > 10 ? 64 : 32;
+    // 32 +12.2 %; yz 24 +12 %, 16 +12.6 %, 32 +14.2 %.  Shares that are no multiple of 32 use the unmasked core stream
+    // (fpr_reserve_comm_cus).  With x-faces in strips (tools/exp_faces_units.py, one process): x, xy, one face per dimension: 16 best;
+    // all six faces: 32 (the chain is as long as the core launch on 24).  With x-faces in the field the chain is nearly as long
+    // as the core launch: 32, and 64 above two x-faces' worth of work.
+    if (anyx && !xstrips) return work > 10 ? 64 : 32;
+    if (anyx) return work >= 8 ? 32 : 16;
+    return work > 4 ? 24 : 16;
 }
 
 // Strips of the x-faces with a neighbour: storage (kept in the context), per-face geometry.  boxes: the peeled shell boxes.
@@ -733,13 +742,14 @@ extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const 
         }
     }
     if (int rc = fprx_halo_exchange3d_comm_x(ctx, Hout, nx, ny, nz, mask, xs_on ? xsend : nullptr, xs_on ? xrecv : nullptr)) return rc;
-
     // Every stream wait between two core launches costs 5-8 us of the core stream's time (tools/attic/dbg_faces.py: with none
     // of them a z pair is +3.7 % over the plain launch, with these two +5.3 %, with a third at the top of the next call +5.9 %)
     if (int rc = fpr_stream_wait(ctx, 2, 1)) return rc;       // the core stream takes in the shell chain
     if (xs_on) {
         // the pair is turned around behind its core launch: the received halo column, the shell column and its residual go into
         // the fields, the columns next to the face come back as the next pair's level-0 strips
+        // (the stores alone at the end of the chain, beside the core launch, and only the gather here: no gain for x or one
+        // face per dimension, +10 % for xy -- tools/exp_faces_units.py, EXPERIMENTS 12.2)
         k_xstrip_turn<true, false><<<xs_cp, dim3(64, 4), 0, ctx->stream[2]>>>(xs);
         FPR_CHECK_LAUNCH(ctx);
         ctx->xs_field = Hout; ctx->xs_ht = Ht;

@@ -1,7 +1,9 @@
 """Soak of the fused-pair choreography between ranks (one rank, periodic = its own neighbour over the library's RCCL transport):
 P pairs chained on the core / comm streams of the split device (step2(join=False), what bench.py runs) against the same P pairs
-with a device-wide synchronisation after every phase of every pair (nothing overlaps anything).  Fields, residuals and all 2P
-norms must agree bit for bit; repeated R times.  usage: soak_step2.py <n> <periods e.g. 001> <pairs> <repeats> [drop_faces]"""
+with a device-wide synchronisation after every phase of every pair (nothing overlaps anything; the phased form keeps the x-shell
+in the field, the chained one-call form in compact strips).  Interior cells, the interiors of the halo planes and the residuals must
+agree bit for bit (edge and corner halo cells are refreshed by neither form's contract), all 2P norms to 1e-13 (the strips sum
+their cells in another order); repeated R times.  usage: soak_step2.py <n> <periods e.g. 001> <pairs> <repeats> [drop_faces]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -32,12 +34,22 @@ def run(serial):
     gg.join(); torch.cuda.synchronize()
     return A, Rr, sq
 
+def same(a, b):
+    inner = (slice(1, -1),) * 3
+    ok = torch.equal(a[inner], b[inner])
+    for d in range(3):
+        for side in (0, -1):
+            idx = [slice(1, -1)] * 3
+            idx[d] = side
+            ok = ok and torch.equal(a[tuple(idx)], b[tuple(idx)])
+    return ok
+
 ref = run(True)
 bad = 0
 t0 = time.time()
 for r in range(R):
     got = run(False)
-    ok = torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+    ok = same(got[0], ref[0]) and same(got[1], ref[1]) and bool(((got[2] - ref[2]).abs() <= 1e-13 * ref[2].abs()).all())
     bad += not ok
 print("n=%d periods=%s drop=%d: %d pairs chained x %d repeats against the fully serialised run: %d mismatching repeats (%.1f s); last norm %.6e"
       % (n, sys.argv[2], drop, P, R, bad, time.time() - t0, float(ref[2][-1])))

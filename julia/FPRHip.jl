@@ -705,18 +705,19 @@ what `@hide_communication` + `update_halo!` do there for one iteration; ONE call
 (`reserve_comm_cus`): the core of
 the local grid runs as ONE fused launch on the core stream; on the comm stream, beside it, run the single steps on the
 one-cell shell (level 1 into `Hτ2`), the exchange of `Hτ2`'s planes, the fused launches on the shell boxes and the exchange of
-the new field.  `join = false` leaves the pair on those two streams (the next pair continues from there); call
-`join_pair!()` before anything else reads the fields or `sumsq2`.  Same results as two single steps with `update_halo!`
-of the new buffer after each.
+the new field (the shell next to an x-neighbour in compact strips of the library's own, csrc/diffusion3d_xstrip.hpp).  `join = false`
+leaves the pair on those two streams (the next pair continues from there and reuses the strips); call `join_pair!()` before anything
+else reads OR WRITES the fields or `sumsq2`.  `dHdτ = nothing`: the residual is not stored.  Same results as two single steps with
+`update_halo!` of the new buffer after each.
 """
-function diffusion_3D_step_τ2_halo!(Ht::DA, Hτ::DA, Hτ2::DA, Hout::DA, dHdτ::DA, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz;
+function diffusion_3D_step_τ2_halo!(Ht::DA, Hτ::DA, Hτ2::DA, Hout::DA, dHdτ::Union{DA,Nothing}, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz;
                                     scale = 0.0, sumsq2::Union{DA,Nothing} = nothing, join::Bool = true)
     nx, ny, nz = size(Ht)
     check(ccall((:fpr_diffusion3d_step2_halo, libfpr), Cint,
                 (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint,
                  Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cdouble}, Cint),
-                ctx(), p(Ht), p(Hτ), p(Hτ2), p(Hout), p(dHdτ), nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale,
-                sumsq2 === nothing ? Ptr{Cdouble}(C_NULL) : p(sumsq2), join ? 1 : 0))
+                ctx(), p(Ht), p(Hτ), p(Hτ2), p(Hout), dHdτ === nothing ? Ptr{Cdouble}(C_NULL) : p(dHdτ), nx, ny, nz, dτ, _dt, _dx, _dy, _dz,
+                D_dx, D_dy, D_dz, scale, sumsq2 === nothing ? Ptr{Cdouble}(C_NULL) : p(sumsq2), join ? 1 : 0))
     return nothing
 end
 

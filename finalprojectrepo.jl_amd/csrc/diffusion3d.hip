@@ -629,6 +629,7 @@ extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const 
     // x-faces: the shell column, its neighbours and the travelling planes in compact strips (diffusion3d_xstrip.hpp)
     bool xs_on = (g.nb[0] >= 0 || g.nb[1] >= 0) && fpr_opt(ctx, "diff3_xstrips", 1) != 0 && (long)ny * nz * 8 < 0x7ffffff0L &&
                        (long)nx * ny * 8 * 12 < (1L << 31);
+    if (!xs_on) ctx->xs_field = nullptr;   // a pair in the field form may overwrite the array the strips were taken from
     const long k_opt = fpr_opt(ctx, "diff3_comm_units", 0);   // experiments: 8, 16, 32, 64
     const int k = k_opt > 0 ? (int)k_opt : diff3_comm_units(g, xs_on);
     if (int rc = fpr_reserve_comm_cus(ctx, k)) return rc;

@@ -294,6 +294,59 @@ def test_x_shell_in_compact_strips(fpr, oracle, periodic_grid, periods, n, form)
         c.set_option("diff3_xstrips_keep", 1)
 
 
+def test_x_strips_are_gathered_afresh_after_a_join(fpr, oracle, periodic_grid):
+    """The strips of a pending pair are reused by the next pair of the chain; once the pair has been joined the caller may change
+    Htau and Ht (the solver does: `Ht .= Hτ`, part1_kernel_programming.jl:203) -- the next pair must not see the old columns.
+    Same array addresses before and after, new contents; also a pair in the field form between two strip pairs."""
+    F = fpr
+    c = F.ctx()
+    n, periods = (128, 24, 16), (1, 0, 1)
+    dims = (0, 2)
+    gg = periodic_grid(n, periods)
+    ext = [m - 2 if p else m for m, p in zip(n, periods)]
+    dx, dy, dz = 10.0 / ext[0], 10.0 / ext[1], 10.0 / ext[2]
+    dt = 0.2
+    dτ = min(dx, dy, dz) ** 2 / 8.1
+    coef = (dτ, 1 / dt, 1 / dx, 1 / dy, 1 / dz, 1 / dx, 1 / dy, 1 / dz)
+    Ht = wrap(rnd(n, 79), dims=dims)
+    A, B, R = Ht.copy(order="F"), farr(*n), farr(*n)
+    gHt, gA, gB, gR = F.asdevice(Ht), F.asdevice(A), F.fzeros(*n), F.fzeros(*n)
+    gC = gA.clone()
+    sq = F.fzeros(2)
+    inner = (slice(1, -1),) * 3
+
+    def pair(join, strips=1):
+        nonlocal A, B, gA, gC
+        for k in range(2):
+            oracle.diffusion3d_step(Ht, A, B, R, *coef)
+            wrap(B, dims=dims)
+            A, B = B, A
+        c.set_option("diff3_xstrips", strips)
+        try:
+            gg.step2(gHt, gA, gB, gC, gR, *coef, dt, sq, join=join)
+        finally:
+            c.set_option("diff3_xstrips", 1)
+        gA, gC = gC, gA
+
+    pair(False); pair(False)
+    gg.join()
+    assert np.array_equal(F.tonumpy(gA)[inner], A[inner])
+    # the caller's own update between two chains: new time level, field scaled (same device arrays)
+    Ht[...] = A
+    gHt.copy_(gA)
+    A[inner] *= 1.25
+    wrap(A, dims=dims)
+    gA.copy_(F.asdevice(A))
+    gC.copy_(gA)
+    pair(False); pair(False)
+    gg.join()
+    assert np.array_equal(F.tonumpy(gA)[inner], A[inner]) and np.array_equal(F.tonumpy(gR)[inner], R[inner])
+    # strips, field form, strips inside one chain
+    pair(False); pair(False, strips=0); pair(False); pair(False)
+    gg.join()
+    assert np.array_equal(F.tonumpy(gA)[inner], A[inner]) and np.array_equal(F.tonumpy(gR)[inner], R[inner])
+
+
 def test_x_strips_with_one_sided_faces_equal_the_field_form(fpr, periodic_grid):
     """A rank with ONE x-face (low or high) and one y- / z-face, as in a (2,2,2) decomposition: no oracle for a rank that is its
     own neighbour on one side only, but the strips and the field form (diff3_xstrips = 0) must agree bit for bit."""

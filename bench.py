@@ -1131,57 +1131,66 @@ def main():
             "kernel_ms": k3, "launches": cnt3, "bytes_per_launch": nb,
             "achieved": nb / (k3 * 1e-3) / 1e9 if k3 > 0 else 0.0, "frac": nb / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS if k3 > 0 else 0.0,
             "note": "read Htau, read Ht, write the new field; both norms reduced; dHdtau not materialised (solver loop mode)"}
-        # fourth leg: what an interior rank of a z-slab decomposition does per pair, on this one card -- a rank that is its own
-        # periodic z-neighbour over the library's RCCL transport (the planes really travel through ncclSend / ncclRecv on the
-        # comm stream of the split device).  Links excluded; they are hidden by construction (the chain with both exchanges
-        # ends after about a quarter of the core launch).  Not part of `value`.
-        try:
-            if args.no_neighbour_leg:
-                raise RuntimeError("skipped (--no-neighbour-leg)")
+        # fourth / fifth leg: what a rank WITH neighbours does per pair, on this one card -- a rank that is its own periodic
+        # neighbour over the library's RCCL transport (the planes really travel through ncclSend / ncclRecv on the comm stream
+        # of the split device).  Links excluded; they are hidden by construction (the chain with both exchanges ends inside
+        # the core launch).  Not part of `value`.
+        def neighbour_leg(key, periods, drop, eff_key, note):
             gp = None
-            gp = F.grid.GlobalGrid(*nloc, dims=(1, 1, 1), periods=(0, 0, 1), transport="rccl", use_dist=False)
-            state["cur"] = Hτ
-            def pair_z(nsteps):
-                for i in range(nsteps // 2):
-                    outb = Hτ3 if state["cur"] is Hτ else Hτ
-                    gp.step2(Ht, state["cur"], Hτ2, outb, res, *coef, dt, sq[2 * i:2 * i + 2], join=False)
-                    state["cur"] = outb
-            pair_z(W + (W & 1) + 4)
-            gp.join()
-            barrier()
-            K4 = max(K, 80)                    # steady state: the fork from / join into the compute stream weigh 1/40 each
-            t0 = time.perf_counter()
-            pair_z(K4)                         # wall time without the event timer (its records stand between the launches)
-            gp.join()
-            barrier()
-            e4 = time.perf_counter() - t0
-            ctx.call("fpr_kernel_timer", 1)
-            pair_z(K)                          # once more for the kernels' own durations
-            gp.join()
-            barrier()
-            kt4 = {kind: timer_read(ctx, kind) for kind in (KT_STEP, KT_STEP2, KT_CORE)}
-            ctx.call("fpr_kernel_timer", 0)
-            npair, npair_t = max(K4 // 2, 1), max(K // 2, 1)
-            plain_pair_ms = 2 * legs["fused_pairs"]["ms_per_step"]
-            legs["fused_pairs_as_interior_rank_of_z_slabs"] = {
-                "ms_per_step": e4 / (2 * npair) * 1e3, "pair_ms": e4 / npair * 1e3, "plain_pair_ms": plain_pair_ms,
-                "over_plain_pair": e4 / npair * 1e3 / plain_pair_ms,
-                "projected_weak_scaling_efficiency_z_slabs": plain_pair_ms / (e4 / npair * 1e3),
-                "core_kernel_ms": kt4[KT_CORE][0] / max(kt4[KT_CORE][1], 1), "core_launches": kt4[KT_CORE][1],
-                "shell_launches_ms_per_pair": (kt4[KT_STEP][0] + kt4[KT_STEP2][0]) / npair_t, "pairs_timed": npair, "comm_units": ctx.L.fpr_comm_cus(ctx.h),
-                "note": "one rank, periodic in z = its own neighbour over ncclSend / ncclRecv (RCCL, comm stream of the CU-split "
-                        "device); two faces with a neighbour like an interior rank of (1,1,N); a projection from one card, link "
-                        "time not included (hidden behind the core launch by construction)"}
-        except Exception as e:   # a projection, never required for the GPU number
-            legs["fused_pairs_as_interior_rank_of_z_slabs"] = {"error": repr(e)}
-        finally:
-            # whatever happened in the leg: no pair left pending, the single-rank RCCL grid gone, the device unsplit -- the blocks
-            # that follow (and the second context) run in the state they expect; a failure here must not mask the leg's own
-            for undo in (lambda: gp.join(), F.grid.finalize_global_grid, lambda: ctx.reserve_comm_cus(0), ctx.synchronize):
-                try:
-                    undo()
-                except Exception:
-                    pass
+            try:
+                if args.no_neighbour_leg:
+                    raise RuntimeError("skipped (--no-neighbour-leg)")
+                gp = F.grid.GlobalGrid(*nloc, dims=(1, 1, 1), periods=periods, transport="rccl", use_dist=False, drop_faces=drop)
+                state["cur"] = Hτ
+                def pair_n(nsteps):
+                    for i in range(nsteps // 2):
+                        outb = Hτ3 if state["cur"] is Hτ else Hτ
+                        gp.step2(Ht, state["cur"], Hτ2, outb, res, *coef, dt, sq[2 * i:2 * i + 2], join=False)
+                        state["cur"] = outb
+                pair_n(W + (W & 1) + 4)
+                gp.join()
+                barrier()
+                K4 = max(K, 80)                    # steady state: the fork from / join into the compute stream weigh 1/40 each
+                t0 = time.perf_counter()
+                pair_n(K4)                         # wall time without the event timer (its records stand between the launches)
+                gp.join()
+                barrier()
+                e4 = time.perf_counter() - t0
+                ctx.call("fpr_kernel_timer", 1)
+                pair_n(K)                          # once more for the kernels' own durations
+                gp.join()
+                barrier()
+                kt4 = {kind: timer_read(ctx, kind) for kind in (KT_STEP, KT_STEP2, KT_CORE)}
+                ctx.call("fpr_kernel_timer", 0)
+                npair, npair_t = max(K4 // 2, 1), max(K // 2, 1)
+                plain_pair_ms = 2 * legs["fused_pairs"]["ms_per_step"]
+                legs[key] = {
+                    "ms_per_step": e4 / (2 * npair) * 1e3, "pair_ms": e4 / npair * 1e3, "plain_pair_ms": plain_pair_ms,
+                    "over_plain_pair": e4 / npair * 1e3 / plain_pair_ms,
+                    eff_key: plain_pair_ms / (e4 / npair * 1e3),
+                    "core_kernel_ms": kt4[KT_CORE][0] / max(kt4[KT_CORE][1], 1), "core_launches": kt4[KT_CORE][1],
+                    "shell_launches_ms_per_pair": (kt4[KT_STEP][0] + kt4[KT_STEP2][0]) / npair_t, "pairs_timed": npair, "comm_units": ctx.L.fpr_comm_cus(ctx.h),
+                    "note": note}
+            except Exception as e:   # a projection, never required for the GPU number
+                legs[key] = {"error": repr(e)}
+            finally:
+                # whatever happened in the leg: no pair left pending, the single-rank RCCL grid gone, the device unsplit -- the
+                # blocks that follow (and the second context) run in the state they expect; a failure here must not mask the leg's own
+                for undo in ((lambda: gp.join()) if gp is not None else (lambda: None), F.grid.finalize_global_grid,
+                             lambda: ctx.reserve_comm_cus(0), ctx.synchronize):
+                    try:
+                        undo()
+                    except Exception:
+                        pass
+
+        neighbour_leg("fused_pairs_as_interior_rank_of_z_slabs", (0, 0, 1), 0, "projected_weak_scaling_efficiency_z_slabs",
+                      "one rank, periodic in z = its own neighbour over ncclSend / ncclRecv (RCCL, comm stream of the CU-split "
+                      "device); two faces with a neighbour like an interior rank of (1,1,N); a projection from one card, link "
+                      "time not included (hidden behind the core launch by construction)")
+        neighbour_leg("fused_pairs_as_rank_of_2x2x2", (1, 1, 1), 0b010101, "projected_weak_scaling_efficiency_2x2x2",
+                      "one rank, periodic in x, y and z with the three low faces dropped = one face with a neighbour per dimension, "
+                      "the face set of every rank of the reference's (2,2,2) layout (part1_scaling_experiments.jl:40); the x-shell "
+                      "in compact strips (csrc/diffusion3d_xstrip.hpp); a projection from one card, link time not included")
     # Clocks and power UNDER each kernel (a diagnostic outside every timed region): the same launches for about a second each while a
     # host thread reads librocm_smi64 every 20 ms.  The fused kernel does twice the FP64 work per byte of the one-iteration kernel;
     # whether the card holds its clocks under that load is what separates a slow box from a slow kernel.

@@ -517,16 +517,17 @@ def ns_block(F):
     has no lid-driven cavity), semi-implicit beta = 0.5, tol 1e-7, 3 MG solves per step."""
     p2 = F.part2
 
-    def run(fused, timing=None, max_steps=23, concurrent=True):
+    def run(fused, timing=None, max_steps=23, concurrent=True, native=True):
         opt = p2.SimIn_t()
         opt.nx = opt.ny = 2049
         opt.beta, opt.tol, opt.Pr, opt.ttot = 0.5, 1.0e-7, 1.0, 1.0e9
         return p2.navier_stokes_2D(opt=opt, verbose=False, max_steps=max_steps, fused=fused, timing=timing,
-                                   concurrent_solves=concurrent)
+                                   concurrent_solves=concurrent, native_step=native)
 
     run(True, max_steps=5)           # warm-up: arenas of both contexts, worker thread, LDS attributes
     res = run(True)                  # 20 timed steps (the reference times from the fourth step on, part2.jl:182-184)
     per_step = res.t_elapsed / max(res.timed_iters, 1)
+    res_py = run(True, native=False)   # the same step composed from Python (thread pool for the W solve)
     res_seq = run(True, concurrent=False)
     tm = {}
     res_t = run(True, timing=tm, max_steps=9)     # diagnostic run: stream synchronisation around every multigrid solve
@@ -534,10 +535,12 @@ def ns_block(F):
     res_u = run(False, max_steps=9)
     return {"metric": "ns_semi_implicit_step_2049sq", "value": per_step, "unit": "s", "timed_steps": res.timed_iters,
             "multigrid_s_per_step": mg_per_step, "other_s_per_step": max(res_t.t_elapsed / max(res_t.timed_iters, 1) - mg_per_step, 0.0),
+            "composed_from_python_s_per_step": res_py.t_elapsed / max(res_py.timed_iters, 1),
             "solves_one_after_the_other_s_per_step": res_seq.t_elapsed / max(res_seq.timed_iters, 1),
             "kernel_by_kernel_s_per_step": res_u.t_elapsed / max(res_u.timed_iters, 1),
             "note": "beta=0.5, Pr=1, Ra=1e6, tol=1e-7, niters=50; three multigrid solves per step (the first T solve hits niters "
                     "as in the reference), the T and the W solve of a step side by side on two contexts (value) or one after the other; "
+                    "value: the loop body as ONE library call (fpr_ns_step2d), composed_from_python: the same launches issued piecewise from Python; "
                     "multigrid_s_per_step from a diagnostic run with the solves in sequence and synchronised; the step around them "
                     "runs as two passes (fpr_ns_velocity_max2d, fpr_ns_rhs2d) -- "
                     "kernel_by_kernel = the reference's seven kernels + maxima + broadcasts, same results bit for bit"}

@@ -109,6 +109,9 @@ _SIG = {
     "fpr_compute_advection2d_y": [_vp, _dp, _d, _dp, _dp, _i, _i],
     "fpr_ns_velocity_max2d": [_vp, _dp, _d, _d, _dp, _dp, _i, _i, C.POINTER(_d)],
     "fpr_ns_rhs2d": [_vp, _dp, _dp, _dp, _d, _d, _i, _i, _d, _d, _d, _d, _d, _dp, _dp],
+    "fpr_ns_step2d": [_vp, _vp, _dp, _dp, _dp, _dp, _dp, _i, _i, _d, _d, _d, _d, _d, _d, _d, _i, _i, _i, C.POINTER(_d), C.POINTER(_i)],
+    "fpr_ns_run2d": [_vp, _vp, _dp, _dp, _dp, _dp, _dp, _i, _i, _d, _d, _d, _d, _d, _d, _d, _i, _i, _i, _d, _i, C.POINTER(_d),
+                     C.POINTER(_i), C.POINTER(_d), C.POINTER(_i)],
 }
 # every symbol include/fpr.h declares (checked by tests/test_abi.py)
 ALL_SYMBOLS = sorted(list(_SIG) + ["fpr_last_error", "fpr_version", "fpr_get_option", "fpr_last_coarse_iters",

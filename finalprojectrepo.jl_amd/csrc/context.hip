@@ -63,6 +63,8 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
     if (ctx->core_partials) hipFree(ctx->core_partials);
     if (ctx->tickets) hipFree(ctx->tickets);
     if (ctx->xstrips) hipFree(ctx->xstrips);
+    if (ctx->ns_ev) hipEventDestroy(ctx->ns_ev);
+    fprx_ns_worker_free(ctx);
     if (ctx->reserved_map) hipFree(ctx->reserved_map);
     if (ctx->scalars) hipFree(ctx->scalars);
     if (ctx->state) hipFree(ctx->state);

@@ -84,6 +84,9 @@ struct fpr_ctx {
     bool pair_pending = false;         // a fused pair of fpr_diffusion3d_step2_halo left on the core / comm streams (join = 0)
     double* core_partials = nullptr;   // 2 pairs x 2 lists x FPR_CORE_PARTIALS: the core launch's partials, finished on the comm stream
     int pair_parity = 0;
+    hipEvent_t ns_ev = nullptr;        // fpr_ns_step2d: orders this context's compute stream against the other context's
+    void* ns_worker = nullptr;         // fpr_ns_step2d: the host thread that runs the T solve beside the W solve (navier2d.hip)
+    int ns_seq = 0;                    // fpr_ns_velocity_max2d: sequence number of the report in pinned host memory
     double* xstrips = nullptr;         // compact strips of the columns next to x-faces with a neighbour (diffusion3d_xstrip.hpp)
     size_t xstrips_doubles = 0;
     const double* xs_field = nullptr;  // the field whose columns next to the x-faces the level-0 strips hold (Hout of the last pair) ...
@@ -403,6 +406,7 @@ int fprx_cycle_finish(fpr_ctx* ctx, const double* partials, int nparts, double* 
 int fprx_cycle_wait(fpr_ctx* ctx, int slot, int seq, FprCycleCtl* out);
 int fprx_finish_sum2_plus(fpr_ctx* ctx, const double* p0, const double* p1, int nparts, const double* add2_dev, double* out2_dev,
                           int stream_sel);   // out[b] = sum(list b) + add[b]
+void fprx_ns_worker_free(fpr_ctx* ctx);   // navier2d.hip
 // fpr_halo_exchange3d_comm with the x-planes travelling from / into buffers of the caller (no pack / unpack kernels for them)
 int fprx_halo_exchange3d_comm_x(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face_mask, const double* const xsend[2],
                                 double* const xrecv[2]);

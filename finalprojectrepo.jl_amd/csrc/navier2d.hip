@@ -1,6 +1,11 @@
 // navier2d.hip -- NEXT row 8f-1: pointwise kernels of the stream-function/vorticity Navier-Stokes step
 // that calls the V-cycle (reference scripts-part2/part2.jl:90-137).  One thread per interior point.
 #include "fpr_internal.hpp"
+#include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 #define NS_IDX                                                                      \
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;  \
@@ -131,14 +136,24 @@ __global__ __launch_bounds__(256) void k_ns_velocity_max(const double* __restric
     if (threadIdx.x == 0 && threadIdx.y == 0) { partials[b] = mv; partials[nblk + b] = mx; partials[2 * nblk + b] = my; }
 }
 
-__global__ __launch_bounds__(256) void k_ns_max3_finish(const double* __restrict__ partials, int nblk, double* __restrict__ out)
+// the three maxima and then a sequence number into pinned host memory: the host polls the number (a stream synchronisation
+// wakes the host 15-25 us after the kernel has ended; tools/exp_ns_timeline.sh)
+__global__ __launch_bounds__(256) void k_ns_max3_finish(const double* __restrict__ partials, int nblk, double* out_host, int seq)
 {
     __shared__ double red[16];
-    double m = 0.0;
-    const double* p = partials + (size_t)blockIdx.x * nblk;
-    for (int i = threadIdx.x; i < nblk; i += 256) m = fmax(m, p[i]);
-    m = fpr_block_max<256>(m, red);
-    if (threadIdx.x == 0) out[blockIdx.x] = m;
+    double m3[3];
+    for (int q = 0; q < 3; ++q) {
+        double m = 0.0;
+        const double* p = partials + (size_t)q * nblk;
+        for (int i = threadIdx.x; i < nblk; i += 256) m = fmax(m, p[i]);
+        m3[q] = fpr_block_max<256>(m, red);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out_host[0] = m3[0]; out_host[1] = m3[1]; out_host[2] = m3[2];
+        __threadfence_system();
+        __hip_atomic_store(reinterpret_cast<int*>(out_host + 3), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 template <bool IMPLICIT>
@@ -189,10 +204,23 @@ extern "C" int fpr_ns_velocity_max2d(fpr_ctx* ctx, const double* S, double hx, d
     FPR_REQUIRE(ctx, 3L * nblk <= FPR_MAX_PARTIALS, "grid too large for the partial buffer");
     k_ns_velocity_max<<<g, dim3(64, 4), 0, ctx->stream[0]>>>(S, hx, hy, vx, vy, nx, ny, ctx->partials, nblk);
     FPR_CHECK_LAUNCH(ctx);
-    k_ns_max3_finish<<<3, 256, 0, ctx->stream[0]>>>(ctx->partials, nblk, ctx->scalars + 8);
+    // (the three maxima go straight to pinned host memory, a sequence number behind them: no copy launch, no stream synchronisation)
+    const int seq = ++ctx->ns_seq;
+    int* flag = reinterpret_cast<int*>(ctx->host_scalars + 19);
+    __atomic_store_n(flag, 0, __ATOMIC_RELEASE);   // before the launch that will report into it
+    k_ns_max3_finish<<<1, 256, 0, ctx->stream[0]>>>(ctx->partials, nblk, ctx->host_scalars + 16, seq);
     FPR_CHECK_LAUNCH(ctx);
-    FPR_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + 16, ctx->scalars + 8, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream[0]));
-    FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
+    unsigned long spins = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0xffff) == 0) {
+            const hipError_t q = hipStreamQuery(ctx->stream[0]);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+                return fpr_fail(ctx, FPR_ERR_HIP, "the velocity maxima never arrived (stream idle)");
+            }
+            if (q != hipErrorNotReady) return fpr_fail(ctx, FPR_ERR_HIP, "HIP error while waiting for the velocity maxima: %s", hipGetErrorString(q));
+        }
+    }
     for (int q = 0; q < 3; ++q) vmax_host[q] = ctx->host_scalars[16 + q];
     return FPR_OK;
 }
@@ -217,5 +245,150 @@ extern "C" int fpr_ns_rhs2d(fpr_ctx* ctx, const double* T, const double* W, cons
                                                                            diffuse, T_out, W_out);
     }
     FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+// ---- time steps of navier_stokes_2D inside the library (part2.jl:182-262, semi-implicit / implicit: beta > 0) -----------------
+// The loop body of the reference's driver: S solve (:187), velocities and their maxima (:190-193), compute_dt (:76-87, :196),
+// boundary conditions of T (:199), all pointwise terms and both right-hand sides (:202-220,225), T solve (:221) and W solve
+// (:226).  Between those pieces the host only computes dt; from Python every piece is a ctypes call, the two independent solves
+// meet through a thread pool, and the loop itself costs 30-60 us per step -- 80-130 us of a 1.45 ms step at 2049^2 during which the
+// device waits for the host (tools/exp_ns_timeline.sh).  Here the W solve (the longer one: it sets the step's length) runs on
+// the calling thread on `ctx2` (own streams, own arena), the T solve beside it on `ctx` on a worker thread the context keeps;
+// the two contexts' compute streams are ordered by events.  Same launches with the same arguments as the piecewise path:
+// same T, W, S, dt bit for bit.
+namespace {
+struct FprWorker {   // one job at a time
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = true, quit = false;
+    std::thread th;
+    FprWorker() : th([this] { loop(); }) {}
+    void loop()
+    {
+        std::unique_lock<std::mutex> l(m);
+        for (;;) {
+            cv.wait(l, [&] { return has_job || quit; });
+            if (quit) return;
+            std::function<void()> j = std::move(job);
+            has_job = false;
+            l.unlock();
+            j();
+            l.lock();
+            done = true;
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<void()> j)
+    {
+        { std::lock_guard<std::mutex> l(m); job = std::move(j); has_job = true; done = false; }
+        cv.notify_all();
+    }
+    void wait() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return done; }); }
+    ~FprWorker()
+    {
+        { std::lock_guard<std::mutex> l(m); quit = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+}   // namespace
+
+void fprx_ns_worker_free(fpr_ctx* ctx)
+{
+    if (ctx->ns_worker) { delete static_cast<FprWorker*>(ctx->ns_worker); ctx->ns_worker = nullptr; }
+}
+
+static int ns_step(fpr_ctx* ctx, fpr_ctx* ctx2, double* S, double* T, double* W, double* T_rhs, double* W_rhs, int nx, int ny, double Ra,
+                   double Pr, double k, double beta, double a_adv, double dt_dif, double tol, int niters, int coarse_solve_size,
+                   int coarse_solver, double* dt_host, int* ncyc, int* conv)
+{
+    const double h = 1.0 / (ny - 1.0);   // :163
+    double rms = 0.0, frms = 0.0;
+    if (int rc = fpr_mgsolve2d(ctx, S, W, h, 0.0, tol, niters, 0, coarse_solve_size, coarse_solver, nx, ny, &rms, &ncyc[0], nullptr, &frms, &conv[0]))
+        return rc;   // :187
+    double vm[3];
+    if (int rc = fpr_ns_velocity_max2d(ctx, S, h, h, nullptr, nullptr, nx, ny, vm)) return rc;   // :190-193
+    double dt;
+    if (vm[0] == 0.0) dt = dt_dif;   // compute_dt, :76-87
+    else {
+        const double dt_adv = a_adv * fmin(h / vm[1], h / vm[2]);
+        dt = beta >= 0.5 ? dt_adv : fmin(dt_dif, dt_adv);
+    }
+    *dt_host = dt;
+    if (int rc = fpr_bc2d(ctx, T, nx, ny)) return rc;                                                             // :199
+    if (int rc = fpr_ns_rhs2d(ctx, T, W, S, h, h, nx, ny, Ra, Pr, k, beta, dt, T_rhs, W_rhs)) return rc;         // :202-220,225
+    const double c = 1.0 / (beta * dt);   // :219
+    // W, W_rhs (and what they were computed from) are complete for the other context's stream
+    FPR_HIP(ctx, hipEventRecord(ctx->ns_ev, ctx->stream[0]));
+    FPR_HIP(ctx, hipStreamWaitEvent(ctx2->stream[0], ctx->ns_ev, 0));
+    int rcT = FPR_OK;
+    double rmsT = 0.0, frmsT = 0.0;
+    FprWorker* wk = static_cast<FprWorker*>(ctx->ns_worker);
+    wk->submit([&] {   // :221 (a thread starts on device 0: it selects the context's)
+        if (hipSetDevice(ctx->device) != hipSuccess) { rcT = fpr_fail(ctx, FPR_ERR_HIP, "hipSetDevice in the T-solve thread"); return; }
+        rcT = fpr_mgsolve2d(ctx, T, T_rhs, h, c, tol, niters, 1, coarse_solve_size, coarse_solver, nx, ny, &rmsT, &ncyc[1], nullptr, &frmsT, &conv[1]);
+    });
+    const int rcW = fpr_mgsolve2d(ctx2, W, W_rhs, h, c / Pr, tol, niters, 0, coarse_solve_size, coarse_solver, nx, ny, &rms, &ncyc[2], nullptr, &frms, &conv[2]);   // :226
+    wk->wait();
+    // the next step's kernels (this context's compute stream) read W
+    FPR_HIP(ctx, hipEventRecord(ctx2->ns_ev, ctx2->stream[0]));
+    FPR_HIP(ctx, hipStreamWaitEvent(ctx->stream[0], ctx2->ns_ev, 0));
+    if (rcT) return rcT;
+    if (rcW) return fpr_fail(ctx, rcW, "W solve on the second context: %s", fpr_last_error(ctx2));
+    return FPR_OK;
+}
+
+static int ns_prepare(fpr_ctx* ctx, fpr_ctx* ctx2, double beta)
+{
+    FPR_REQUIRE(ctx, ctx2 && ctx2 != ctx && ctx2->device == ctx->device, "a second context on the same device is needed for the W solve");
+    FPR_REQUIRE(ctx, beta > 0.0, "explicit steps (beta == 0) have no solves to put side by side: fpr_ns_rhs2d is the whole step");
+    if (!ctx->ns_ev) FPR_HIP(ctx, hipEventCreateWithFlags(&ctx->ns_ev, hipEventDisableTiming));
+    if (!ctx2->ns_ev) FPR_HIP(ctx, hipEventCreateWithFlags(&ctx2->ns_ev, hipEventDisableTiming));
+    if (!ctx->ns_worker) ctx->ns_worker = new FprWorker();
+    return FPR_OK;
+}
+
+// info_host (nullable, 6 ints): cycles of the S, T, W solves, then their `converged` flags (0 where the reference would @warn, :78-80).
+extern "C" int fpr_ns_step2d(fpr_ctx* ctx, fpr_ctx* ctx2, double* S, double* T, double* W, double* T_rhs, double* W_rhs, int nx, int ny,
+                             double Ra, double Pr, double k, double beta, double a_adv, double dt_dif, double tol, int niters,
+                             int coarse_solve_size, int coarse_solver, double* dt_host, int* info_host)
+{
+    NS_CHECK(S && T && W && T_rhs && W_rhs && dt_host)
+    if (int rc = ns_prepare(ctx, ctx2, beta)) return rc;
+    int ncyc[3] = {0, 0, 0}, conv[3] = {1, 1, 1};
+    const int rc = ns_step(ctx, ctx2, S, T, W, T_rhs, W_rhs, nx, ny, Ra, Pr, k, beta, a_adv, dt_dif, tol, niters, coarse_solve_size,
+                           coarse_solver, dt_host, ncyc, conv);
+    if (info_host)
+        for (int q = 0; q < 3; ++q) { info_host[q] = ncyc[q]; info_host[3 + q] = conv[q]; }
+    return rc;
+}
+
+// `while sim_time < ttot` (:182) for at most max_steps steps: *sim_time_inout advances by every step's dt (:249), *steps_host = steps
+// taken, *dt_host = the last dt, *unconverged_host (nullable) = solves that did not converge (the reference's @warn, :78-80).
+extern "C" int fpr_ns_run2d(fpr_ctx* ctx, fpr_ctx* ctx2, double* S, double* T, double* W, double* T_rhs, double* W_rhs, int nx, int ny,
+                            double Ra, double Pr, double k, double beta, double a_adv, double dt_dif, double tol, int niters,
+                            int coarse_solve_size, int coarse_solver, double ttot, int max_steps, double* sim_time_inout,
+                            int* steps_host, double* dt_host, int* unconverged_host)
+{
+    NS_CHECK(S && T && W && T_rhs && W_rhs && dt_host && sim_time_inout && steps_host)
+    if (int rc = ns_prepare(ctx, ctx2, beta)) return rc;
+    double t = *sim_time_inout;
+    int steps = 0, bad = 0;
+    while (t < ttot && steps < max_steps) {
+        int ncyc[3] = {0, 0, 0}, conv[3] = {1, 1, 1};
+        double dt = 0.0;
+        const int rc = ns_step(ctx, ctx2, S, T, W, T_rhs, W_rhs, nx, ny, Ra, Pr, k, beta, a_adv, dt_dif, tol, niters, coarse_solve_size,
+                               coarse_solver, &dt, ncyc, conv);
+        *sim_time_inout = t; *steps_host = steps;
+        if (rc) return rc;
+        *dt_host = dt;
+        t += dt;
+        ++steps;
+        bad += !conv[0] + !conv[1] + !conv[2];
+    }
+    *sim_time_inout = t; *steps_host = steps;
+    if (unconverged_host) *unconverged_host = bad;
     return FPR_OK;
 }

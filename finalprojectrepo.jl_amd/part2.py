@@ -125,7 +125,8 @@ def compute_dt(v, vx, vy, dt_dif, a_dif, a_adv, h, beta):
     v_max = _absmax(v)
     if v_max == 0:
         return dt_dif
-    dt_adv = a_adv * min(h / _absmax(vx), h / _absmax(vy))
+    mx, my = _absmax(vx), _absmax(vy)   # (Julia: h / 0.0 = Inf)
+    dt_adv = a_adv * min(h / mx if mx != 0 else math.inf, h / my if my != 0 else math.inf)
     return dt_adv if beta >= 0.5 else min(dt_dif, dt_adv)
 
 
@@ -146,7 +147,7 @@ def step_rhs_(T, W, S, hx, hy, Ra, Pr, k, beta, dt, T_out, W_out):
 
 
 def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_steps=None, trace=None, fused=True,
-                     timing=None, concurrent_solves=True):
+                     timing=None, concurrent_solves=True, native_step=True):
     """part2.jl:140-262.  trace: optional list; one dict per time step is appended with the step's dt and the
     residual histories of its multigrid solves (diagnostics for the parity tests; costs nothing when None).
     fused (default): the step around the three multigrid solves runs as two passes (velocity_and_maxima, step_rhs_)
@@ -155,7 +156,9 @@ def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_s
     fourth on, :182-184), with a stream synchronisation around every solve (diagnostic mode, slightly slower).
     concurrent_solves (default, fused path without trace / timing): the T solve (:221) and the W solve (:226) of a step do not
     depend on each other; W runs on a second context (own streams, own arena) from a worker thread beside T -- these solves
-    are bound by launch latency, not by the GPU, so they overlap almost entirely.  Same results bit for bit."""
+    are bound by launch latency, not by the GPU, so they overlap almost entirely.  Same results bit for bit.
+    native_step (default, where concurrent_solves applies): the whole loop body as ONE library call (fpr_ns_step2d) -- the same
+    launches with the same arguments, without Python between them (the device waited 80-130 us per step for the host)."""
     import torch
 
     opt = opt if opt is not None else SimIn_t()
@@ -178,6 +181,7 @@ def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_s
     import warnings
 
     pool, ctx2, ev_a, ev_b = None, None, None, None
+    native = bool(native_step and fused and concurrent_solves and opt.beta > 0.0 and trace is None and timing is None)
 
     while sim_time < opt.ttot:
         if step == 3:
@@ -202,13 +206,37 @@ def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_s
                                                                prealloc_dict=prealloc, return_history=True)
                     rec[name] = {"r_rms": r, "history": hist, "f_rms": frms, "coarse_iters": cit, "c": c}
 
-            solve("S", S, W, 0.0, False)  # :187
-            if fused:
+            if native:   # :182-249 inside the library, as many steps as nothing on this side has to see one by one
+                if ctx2 is None:
+                    ctx2 = _second()
+                if testmode or verbose:
+                    chunk = 1
+                else:
+                    chunk = (3 - step) if step < 3 else 1 << 30                      # (the clock starts before the fourth step, :182-184)
+                    if max_steps is not None:
+                        chunk = min(chunk, max_steps - step)
+                t_c, n_c, dt_c, bad_c = C.c_double(sim_time), C.c_int(0), C.c_double(0.0), C.c_int(0)
+                ctx.call("fpr_ns_run2d", ctx2.h, fptr(S, 2), fptr(T, 2), fptr(W, 2), fptr(A["T_rhs"], 2), fptr(A["W_rhs"], 2), nx, ny,
+                         opt.Ra, opt.Pr, opt.k, opt.beta, opt.a_adv, dt_dif, opt.tol, int(opt.niters), int(mgopt.coarse_solve_size),
+                         mg.CoarseSolver_t(mgopt.coarse_solver).value, float(opt.ttot), int(max(chunk, 1)), C.byref(t_c), C.byref(n_c),
+                         C.byref(dt_c), C.byref(bad_c))
+                dt = dt_c.value
+                if verbose and bad_c.value:
+                    warnings.warn("V-cycle multigrid failed to converge within %d iterations." % opt.niters)  # multigrid.jl:78-80
+                sim_time, step = t_c.value, step + n_c.value     # (the library added every step's dt in order, :249)
+                if n_c.value == 0:
+                    break
+            else:
+                solve("S", S, W, 0.0, False)  # :187
+            if native:
+                pass
+            elif fused:
                 v_max, vx_max, vy_max = velocity_and_maxima(S, hx, hy)  # :190-193
                 if v_max == 0:  # compute_dt, :76-87
                     dt = dt_dif
                 else:
-                    dt_adv = opt.a_adv * min(h / vx_max, h / vy_max)
+                    # (Julia: h / 0.0 = Inf; a flow along one axis only must not raise here)
+                    dt_adv = opt.a_adv * min(h / vx_max if vx_max != 0 else math.inf, h / vy_max if vy_max != 0 else math.inf)
                     dt = dt_adv if opt.beta >= 0.5 else min(dt_dif, dt_adv)
                 mg.apply_boundary_conditions_(T)  # :199
                 step_rhs_(T, W, S, hx, hy, opt.Ra, opt.Pr, opt.k, opt.beta, dt, A["T_rhs"], A["W_rhs"])  # :202-230
@@ -265,8 +293,9 @@ def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_s
         if rec is not None:
             rec["dt"] = dt
             trace.append(rec)
-        sim_time += dt
-        step += 1
+        if not native:
+            sim_time += dt
+            step += 1
         if verbose and (step - 1) % 20 == 0:
             print("time, step: %g %d" % (sim_time, step))
         if testmode or (max_steps is not None and step >= max_steps):

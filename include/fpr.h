@@ -394,6 +394,23 @@ int fpr_ns_velocity_max2d(fpr_ctx* ctx, const double* S, double hx, double hy, d
                           double* vmax_host);
 int fpr_ns_rhs2d(fpr_ctx* ctx, const double* T, const double* W, const double* S, double hx, double hy, int nx, int ny,
                  double Ra, double Pr, double k, double beta, double dt, double* T_out, double* W_out);
+/* One time step of navier_stokes_2D (part2.jl:186-226) for beta > 0 as ONE call: S solve (:187), pass 1, compute_dt (:76-87),
+ * boundary conditions of T (:199), pass 2, then the T solve (:221, on ctx from a thread of its own) and the W solve (:226, on
+ * ctx2: a second context on the same device) side by side -- they do not depend on each other and are bound by launch latency.
+ * The same launches with the same arguments as the piecewise calls (same T, W, S, dt bit for bit), without the host language
+ * between them.  h = 1/(ny-1) as the driver (:163); dt_dif, a_adv as SimIn_t (:30-46); *dt_host receives the step's dt;
+ * info_host (nullable, 6 ints): V-cycles of the S, T, W solves, then their converged flags (0 = the reference would @warn). */
+int fpr_ns_step2d(fpr_ctx* ctx, fpr_ctx* ctx2, double* S, double* T, double* W, double* T_rhs, double* W_rhs, int nx, int ny,
+                  double Ra, double Pr, double k, double beta, double a_adv, double dt_dif, double tol, int niters,
+                  int coarse_solve_size, int coarse_solver, double* dt_host, int* info_host);
+/* The driver's loop `while sim_time < ttot` (part2.jl:182) around that step for at most max_steps steps: *sim_time_inout advances by
+ * every step's dt (:249), *steps_host = steps taken, *dt_host = the last step's dt, *unconverged_host (nullable) = number of solves
+ * that did not converge (each one a @warn in the reference, :78-80).  The host language calls it in pieces where it has something
+ * to do between steps (the reference starts its clock before the fourth step, :182-184; progress lines). */
+int fpr_ns_run2d(fpr_ctx* ctx, fpr_ctx* ctx2, double* S, double* T, double* W, double* T_rhs, double* W_rhs, int nx, int ny,
+                 double Ra, double Pr, double k, double beta, double a_adv, double dt_dif, double tol, int niters,
+                 int coarse_solve_size, int coarse_solver, double ttot, int max_steps, double* sim_time_inout, int* steps_host,
+                 double* dt_host, int* unconverged_host);
 
 #ifdef __cplusplus
 }

@@ -99,6 +99,10 @@ end
 
 function destroy_context()
     if CTX[] != C_NULL
+        if CTX2[] != C_NULL
+            ccall((:fpr_ctx_destroy, libfpr), Cint, (Ptr{Cvoid},), CTX2[])
+            CTX2[] = C_NULL
+        end
         ccall((:fpr_ctx_destroy, libfpr), Cint, (Ptr{Cvoid},), CTX[])
         CTX[] = C_NULL
         GRID[] = nothing
@@ -899,5 +903,56 @@ step_rhs!(T_out::DA, W_out::DA, T::DA, W::DA, S::DA, hx, hy, Ra, Pr, k, beta, dt
                 (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Cint, Cint, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble,
                  Ptr{Cdouble}, Ptr{Cdouble}),
                 ctx(), p(T), p(W), p(S), hx, hy, size(T, 1), size(T, 2), Ra, Pr, k, beta, dt, p(T_out), p(W_out)))
+
+const CTX2 = Ref{Ptr{Cvoid}}(C_NULL)
+"A second context on the default context's device (own streams, own multigrid arena): the W solve of a time step runs on it."
+function second_ctx()
+    if CTX2[] == C_NULL
+        c = ctx()
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:fpr_ctx_create, libfpr), Cint, (Ptr{Ptr{Cvoid}}, Cint, Ptr{Cvoid}, Ptr{Cvoid}), h, AMDGPU.device_id(AMDGPU.device()) - 1, C_NULL, C_NULL)
+        rc == 0 || throw(FPRError(rc, "fpr_ctx_create failed for the second context"))
+        CTX2[] = h[]
+        # a solve that runs beside another one must not depend on workgroups being resident together
+        for (k, v) in (("cg_fused", 2), ("mg_jacobi_persist", 0))
+            ccall((:fpr_set_option, libfpr), Cint, (Ptr{Cvoid}, Cstring, Clong), CTX2[], k, v)
+        end
+        c == C_NULL && error("no context")
+    end
+    return CTX2[]
+end
+
+"""
+    navier_stokes_step!(S, T, W, T_rhs, W_rhs, opt; dt_dif, coarse_solve_size = 5, coarse_solver = 0) -> (dt, info)
+
+The loop body of `navier_stokes_2D` (part2.jl:186-226) for `opt.beta > 0` as ONE library call (`fpr_ns_step2d`): S solve, velocities
+and maxima, `compute_dt`, boundary conditions of T, the pointwise terms and right-hand sides, then the T and W solves side by side
+on two contexts.  Same T, W, S, dt as the piecewise calls; `info` = cycles of the S, T, W solves and their converged flags.
+"""
+function navier_stokes_step!(S::DA, T::DA, W::DA, T_rhs::DA, W_rhs::DA, opt; dt_dif, coarse_solve_size = 5, coarse_solver = 0)
+    dt = Ref{Cdouble}(0.0)
+    info = zeros(Cint, 6)
+    check(ccall((:fpr_ns_step2d, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cdouble, Cdouble,
+                 Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cint}),
+                ctx(), second_ctx(), p(S), p(T), p(W), p(T_rhs), p(W_rhs), size(T, 1), size(T, 2), opt.Ra, opt.Pr, opt.k, opt.beta,
+                opt.a_adv, dt_dif, opt.tol, opt.niters, coarse_solve_size, coarse_solver, dt, info))
+    return dt[], info
+end
+
+"""
+    navier_stokes_run!(S, T, W, T_rhs, W_rhs, opt, sim_time, max_steps; dt_dif, ...) -> (sim_time, steps, dt_last, unconverged)
+
+`while sim_time < opt.ttot` (part2.jl:182) around `navier_stokes_step!` inside the library (`fpr_ns_run2d`), at most `max_steps` steps.
+"""
+function navier_stokes_run!(S::DA, T::DA, W::DA, T_rhs::DA, W_rhs::DA, opt, sim_time, max_steps; dt_dif, coarse_solve_size = 5, coarse_solver = 0)
+    t = Ref{Cdouble}(sim_time); dt = Ref{Cdouble}(0.0); steps = Ref{Cint}(0); bad = Ref{Cint}(0)
+    check(ccall((:fpr_ns_run2d, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cdouble, Cdouble,
+                 Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint, Cdouble, Cint, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cint}),
+                ctx(), second_ctx(), p(S), p(T), p(W), p(T_rhs), p(W_rhs), size(T, 1), size(T, 2), opt.Ra, opt.Pr, opt.k, opt.beta,
+                opt.a_adv, dt_dif, opt.tol, opt.niters, coarse_solve_size, coarse_solver, opt.ttot, max_steps, t, steps, dt, bad))
+    return t[], Int(steps[]), dt[], Int(bad[])
+end
 
 end # module

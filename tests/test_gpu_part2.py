@@ -258,21 +258,72 @@ def test_t_and_w_solves_side_by_side_equal_the_sequence(fpr, shape):
     """The T solve (part2.jl:221) and the W solve (:226) of a time step do not depend on each other: run side by side (W on a
     second context from a worker thread, ordered against the default stream by events) they leave the same T, W, S and time
     step as one after the other -- bit for bit, over several steps, so that each step consumes what the previous one's two
-    solves produced."""
+    solves produced.  The same for the loop body as ONE library call (fpr_ns_step2d: the default), twice."""
     import warnings
 
     p2 = fpr.part2
     outs = []
-    for conc in (False, True, True):
+    for conc, native in ((False, False), (True, False), (True, True), (True, True)):
         opt = p2.SimIn_t()
         opt.nx, opt.ny, opt.beta, opt.tol, opt.Pr, opt.niters, opt.ttot = shape[0], shape[1], 0.5, 1.0e-7, 1.0, 30, 1e9
         opt.W_init_strategy = p2.random
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            outs.append(p2.navier_stokes_2D(opt=opt, verbose=False, max_steps=5, fused=True, concurrent_solves=conc))
+            outs.append(p2.navier_stokes_2D(opt=opt, verbose=False, max_steps=5, fused=True, concurrent_solves=conc, native_step=native))
     a = outs[0]
     for b in outs[1:]:
         assert a.dt_last == b.dt_last and a.steps == b.steps
         for name in ("T", "W", "S"):
             assert np.array_equal(getattr(a, name), getattr(b, name)), name
     assert np.isfinite(a.T).all() and np.isfinite(a.W).all()
+
+
+def test_ns_steps_inside_the_library_one_by_one_and_in_one_call(fpr):
+    """fpr_ns_step2d (one loop body of part2.jl:186-226 per call) twice against fpr_ns_run2d (the loop :182 around it) for two steps:
+    same T, W, S, dt and simulated time, bit for bit; run2d stops at ttot like `while sim_time < ttot`."""
+    import ctypes as C
+
+    F = fpr
+    p2, mg = F.part2, F.multigrid
+    fptr = F._lib.fptr
+
+    nx, ny = 129, 65
+    h = 1.0 / (ny - 1.0)
+    opt = p2.SimIn_t()
+    opt.nx, opt.ny, opt.beta, opt.tol, opt.Pr, opt.niters = nx, ny, 0.5, 1.0e-7, 1.0, 30
+    dt_dif = (opt.a_dif * h ** 2) / max(opt.k, opt.Pr)
+    c, c2 = F.ctx(), F.second_ctx()
+
+    def fields():
+        A = {n: F.fzeros(nx, ny) for n in "S T T_rhs W W_rhs".split()}
+        p2.init_array_(A["T"], opt.T_init_strategy, h, (nx - 1.0) / (ny - 1.0), opt)
+        p2.init_array_(A["W"], p2.random, h, (nx - 1.0) / (ny - 1.0), opt)
+        return A
+
+    args = (nx, ny, opt.Ra, opt.Pr, opt.k, opt.beta, opt.a_adv, dt_dif, opt.tol, int(opt.niters), 5, 0)
+    A = fields()
+    dts, t, unconverged = [], 0.0, 0
+    for _ in range(2):
+        dt, info = C.c_double(0.0), (C.c_int * 6)()
+        c.call("fpr_ns_step2d", c2.h, *(fptr(A[n], 2) for n in ("S", "T", "W", "T_rhs", "W_rhs")), *args, C.byref(dt), info)
+        assert all(1 <= v <= opt.niters for v in info[0:3])
+        unconverged += sum(1 for v in info[3:6] if not v)     # (the first T solve hits niters, as in the reference)
+        dts.append(dt.value)
+        t += dt.value
+    B = fields()
+    t_c, n_c, dt_c, bad = C.c_double(0.0), C.c_int(0), C.c_double(0.0), C.c_int(-1)
+    c.call("fpr_ns_run2d", c2.h, *(fptr(B[n], 2) for n in ("S", "T", "W", "T_rhs", "W_rhs")), *args, 1.0e9, 2, C.byref(t_c), C.byref(n_c),
+           C.byref(dt_c), C.byref(bad))
+    F.synchronize()
+    assert (n_c.value, bad.value, dt_c.value, t_c.value) == (2, unconverged, dts[1], t)
+    for n in ("S", "T", "W"):
+        assert np.array_equal(F.tonumpy(A[n]), F.tonumpy(B[n])), n
+    # `while sim_time < ttot`: one more step is taken from t, none from beyond ttot
+    t_c2, n_c2 = C.c_double(t), C.c_int(0)
+    c.call("fpr_ns_run2d", c2.h, *(fptr(B[n], 2) for n in ("S", "T", "W", "T_rhs", "W_rhs")), *args, t + 0.5 * dts[1], 100, C.byref(t_c2),
+           C.byref(n_c2), C.byref(dt_c), C.byref(bad))
+    assert n_c2.value == 1 and t_c2.value > t
+    n_c3 = C.c_int(7)
+    c.call("fpr_ns_run2d", c2.h, *(fptr(B[n], 2) for n in ("S", "T", "W", "T_rhs", "W_rhs")), *args, t, 100, C.byref(t_c2), C.byref(n_c3),
+           C.byref(dt_c), C.byref(bad))
+    assert n_c3.value == 0

@@ -323,19 +323,32 @@ static int ns_step(fpr_ctx* ctx, fpr_ctx* ctx2, double* S, double* T, double* W,
     // W, W_rhs (and what they were computed from) are complete for the other context's stream
     FPR_HIP(ctx, hipEventRecord(ctx->ns_ev, ctx->stream[0]));
     FPR_HIP(ctx, hipStreamWaitEvent(ctx2->stream[0], ctx->ns_ev, 0));
-    int rcT = FPR_OK;
+    // the solve that took more cycles in the previous step runs on the calling thread (the other one starts a few microseconds
+    // later, when the worker has woken up): it sets the step's length
+    int rcT = FPR_OK, rcW = FPR_OK;
     double rmsT = 0.0, frmsT = 0.0;
     FprWorker* wk = static_cast<FprWorker*>(ctx->ns_worker);
-    wk->submit([&] {   // :221 (a thread starts on device 0: it selects the context's)
-        if (hipSetDevice(ctx->device) != hipSuccess) { rcT = fpr_fail(ctx, FPR_ERR_HIP, "hipSetDevice in the T-solve thread"); return; }
+    auto solveT = [&] {   // :221
         rcT = fpr_mgsolve2d(ctx, T, T_rhs, h, c, tol, niters, 1, coarse_solve_size, coarse_solver, nx, ny, &rmsT, &ncyc[1], nullptr, &frmsT, &conv[1]);
-    });
-    const int rcW = fpr_mgsolve2d(ctx2, W, W_rhs, h, c / Pr, tol, niters, 0, coarse_solve_size, coarse_solver, nx, ny, &rms, &ncyc[2], nullptr, &frms, &conv[2]);   // :226
+    };
+    auto solveW = [&] {   // :226
+        rcW = fpr_mgsolve2d(ctx2, W, W_rhs, h, c / Pr, tol, niters, 0, coarse_solve_size, coarse_solver, nx, ny, &rms, &ncyc[2], nullptr, &frms, &conv[2]);
+    };
+    const int dev = ctx->device;
+    const bool t_here = ctx->ns_t_cycles >= ctx->ns_w_cycles;
+    if (t_here) {
+        wk->submit([&] { if (hipSetDevice(dev) != hipSuccess) { rcW = FPR_ERR_HIP; return; } solveW(); });   // (a thread starts on device 0)
+        solveT();
+    } else {
+        wk->submit([&] { if (hipSetDevice(dev) != hipSuccess) { rcT = FPR_ERR_HIP; return; } solveT(); });
+        solveW();
+    }
     wk->wait();
+    ctx->ns_t_cycles = ncyc[1]; ctx->ns_w_cycles = ncyc[2];
     // the next step's kernels (this context's compute stream) read W
     FPR_HIP(ctx, hipEventRecord(ctx2->ns_ev, ctx2->stream[0]));
     FPR_HIP(ctx, hipStreamWaitEvent(ctx->stream[0], ctx2->ns_ev, 0));
-    if (rcT) return rcT;
+    if (rcT) return rcT == FPR_ERR_HIP && !ctx->err[0] ? fpr_fail(ctx, rcT, "hipSetDevice in the worker thread") : rcT;
     if (rcW) return fpr_fail(ctx, rcW, "W solve on the second context: %s", fpr_last_error(ctx2));
     return FPR_OK;
 }

@@ -352,7 +352,7 @@ int fpr_vcycle2d(fpr_ctx* ctx, double* u_f, const double* rhs, double h, double 
  * history, the cycle and coarse-iteration counts are those of the plain loop.  Tuning / A-B options
  * (fpr_set_option, defaults in brackets): mg_ahead [1] cycles enqueued ahead (0 = plain loop), mg_seam [1] shared pass
  * between cycles, mg_seam_predict [1], mg_mid [1] three launch-bound levels in two launches, mg_small_row [1], mg_zero_guess [1] coarse
- * levels do not read the zero guess their parent stored (:132), mg_seam_wg_per_cu [2] chunk height of the shared pass. After an error return u is UNDEFINED (cycles enqueued ahead of the host are drained first, but may have run). */
+ * levels do not read the zero guess their parent stored (:132), mg_seam_wg_per_cu [2] chunk height of the shared pass, mg_seam_history [1] the cycle count of the previous solve with the same (u, f, nx, ny) as a second opinion on which cycle will be the last. After an error return u is UNDEFINED (cycles enqueued ahead of the host are drained first, but may have run). */
 int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h, double c, double tol, int niters,
                   int apply_BCs, int coarse_solve_size, int coarse_solver, int nx, int ny, double* rms_host,
                   int* ncycles_host, double* history_host, double* frms_host, int* converged_host);

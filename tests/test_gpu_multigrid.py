@@ -547,6 +547,41 @@ def test_small_and_rectangular_hierarchies(fpr, oracle, shape, css, bc):
     assert cit == oracle.last_coarse_iters()
 
 
+def test_last_cycle_guessed_from_the_previous_solve_changes_nothing(fpr):
+    """A time stepper solves the same systems step after step (part2.jl:187,221,226): the context remembers how many V-cycles the
+    last solve with the same arrays took and uses it as a second opinion on which cycle will be the last (mg_seam_history).  A
+    guess decides which launches are enqueued, never what they compute: solves on the SAME device arrays with tolerances that
+    make the remembered count right, too small and too large, against the plain loop (mg_ahead = 0) -- field bit for bit, same
+    cycle count and coarse iterations, history to summation order."""
+    import warnings
+
+    F, mg = fpr, fpr.multigrid
+    c = F.ctx()
+    shape = (1025, 513)
+    h = 1.0 / (shape[0] - 1)
+    f = F.asdevice(rnd(shape, 15))
+    u, u_ref = F.fzeros(*shape), F.fzeros(*shape)
+    opt = mg.MGOpt()
+    counts = []
+    for tol in (1e-6, 1e-6, 1e-9, 1e-9, 1e-4, 1e-4, 1e-7, 1e-6, 1e-12, 1e-6):
+        res = []
+        for arr, ahead in ((u, 1), (u_ref, 0)):
+            arr.zero_()
+            c.set_option("mg_ahead", ahead)
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    res.append(mg.MGsolve_2DPoisson_(arr, f, h, 0.0, tol, 12, False, opt=opt, return_history=True))
+            finally:
+                c.set_option("mg_ahead", 1)
+        (r, hist, frms, cit), (r0, h0, f0, c0) = res
+        assert len(hist) == len(h0) and frms == f0 and cit == c0 and r == pytest.approx(r0, rel=1e-12), tol
+        assert np.allclose(hist, h0, rtol=1e-12, atol=0.0)
+        assert np.array_equal(F.tonumpy(u), F.tonumpy(u_ref)), tol
+        counts.append(len(hist))
+    assert len(set(counts)) >= 4 and counts[-2] == 12      # the remembered count was wrong in both directions; 1e-12 hits niters
+
+
 @pytest.mark.parametrize("shape,css,bcs,tol,niters", [
     ((257, 257), 5, False, 1e-6, 100),      # converges after several cycles
     ((257, 257), 5, False, 1e-30, 4),       # never converges: stops at niters

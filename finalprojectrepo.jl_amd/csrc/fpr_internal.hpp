@@ -85,12 +85,13 @@ struct fpr_ctx {
     double* core_partials = nullptr;   // 2 pairs x 2 lists x FPR_CORE_PARTIALS: the core launch's partials, finished on the comm stream
     int pair_parity = 0;
     // fpr_mgsolve2d: V-cycles the last solve with the same (u, f, nx, ny) took -- a time stepper solves the same systems step after
-    // step (part2.jl:187,221,226) and their cycle counts hardly move: a second opinion for the seam pass's guess of the last cycle
-    struct MgHist { const double* u; const double* f; int nx, ny, cycles; } mg_hist[8] = {};
+    // step (part2.jl:187,221,226) and their convergence histories hardly move: the seam pass's guess of the last cycle takes the
+    // reduction from cycle n to cycle k from there instead of assuming the last rate seen
+    struct MgHist { const double* u; const double* f; int nx, ny, cycles; double rel[16]; } mg_hist[8] = {};   // rel[q] = norm after cycle q+1 / (tol * rms(f))
     int mg_hist_next = 0;
     hipEvent_t ns_ev = nullptr;        // fpr_ns_step2d: orders this context's compute stream against the other context's
     void* ns_worker = nullptr;         // fpr_ns_step2d: the host thread that runs the T solve beside the W solve (navier2d.hip)
-    int ns_t_cycles = 0, ns_w_cycles = 0;   // fpr_ns_step2d: V-cycles of the T / W solves of the previous step
+    int ns_t_cycles = 0, ns_w_cycles = 0, ns_s_cycles = 0;   // fpr_ns_run2d: V-cycles of the T / W / S solves of the previous step
     int ns_seq = 0;                    // fpr_ns_velocity_max2d: sequence number of the report in pinned host memory
     double* xstrips = nullptr;         // compact strips of the columns next to x-faces with a neighbour (diffusion3d_xstrip.hpp)
     size_t xstrips_doubles = 0;

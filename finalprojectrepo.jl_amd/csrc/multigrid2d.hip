@@ -1572,6 +1572,7 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
     const size_t N = (size_t)nx * ny;
     double f_rms = 0.0, tolf = 0.0;   // :53, :70
     double r_rms = 0.0;
+    double kept[16];   // the first norms of this solve (for the next solve of the same system, mg_hist)
     int n = 0;
     ctx->last_coarse_iters = 0;
     int ahead = (int)fpr_opt(ctx, "mg_ahead", 1);
@@ -1622,10 +1623,23 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
             int p = 0;
             bool need_head = true;
             double r_prev = 0.0, r_last = 0.0;   // the last two norms the host has seen
-            int prev_cycles = 0;                 // cycles of the last solve with these arrays (0: none remembered)
+            // the last solve with these arrays (none remembered: prev_cycles = 0): its norms relative to its threshold
+            int prev_cycles = 0;
+            double prev_rel[16];
             if (fpr_opt(ctx, "mg_seam_history", 1))
                 for (const auto& e : ctx->mg_hist)
-                    if (e.u == u && e.f == f && e.nx == nx && e.ny == ny) prev_cycles = e.cycles;
+                    if (e.u == u && e.f == f && e.nx == nx && e.ny == ny && e.cycles > 0) {
+                        prev_cycles = e.cycles < 16 ? e.cycles : 16;
+                        for (int q = 0; q < prev_cycles; ++q) prev_rel[q] = e.rel[q];
+                    }
+            // norm after cycle q (1-based) of the remembered solve over its threshold; beyond its end: its last rate goes on
+            auto prel = [&](int q) -> double {
+                if (q <= prev_cycles) return prev_rel[q - 1];
+                const double rate = prev_cycles >= 2 ? prev_rel[prev_cycles - 1] / prev_rel[prev_cycles - 2] : 0.5;
+                double v = prev_rel[prev_cycles - 1];
+                for (int i = prev_cycles; i < q; ++i) v *= rate;
+                return v;
+            };
             ctx->used_small = false;
             auto lower = [&](int pp) -> int {
                 double dummy; bool dh;
@@ -1645,19 +1659,17 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
                 // last one is replayed); 2 = odd cycles end in a plain pass (exercises the restart after a wrong guess)
                 const long predict = fpr_opt(ctx, "mg_seam_predict", 1);
                 if (predict == 2 && (k & 1)) last = true;
-                if (!last && predict == 1 && n >= 2 && r_last < r_prev && r_last > 0.0) {   // geometric extrapolation of the norm to cycle k
+                if (!last && predict == 1 && prev_cycles > 0 && (n == 0 || (r_last > 0.0 && tolf > 0.0))) {
+                    // A time stepper solves the same systems step after step and their convergence histories hardly move, while the
+                    // rate WITHIN a solve does (the T solve of part2.jl:221: 0.06, 0.28, 0.34, 0.34 ...): take the reduction from
+                    // the last norm seen (cycle n) to cycle k from the remembered solve.  Before the first norm: its own history.
+                    const double pred_rel = n == 0 ? prel(k) : (r_last / tolf) * (prel(k) / prel(n));
+                    last = pred_rel < 1.0;
+                } else if (!last && predict == 1 && n >= 2 && r_last < r_prev && r_last > 0.0) {   // geometric extrapolation of the norm to cycle k
                     double pred = r_last;
                     const double rate = r_last / r_prev;
                     for (int q = n; q < k; ++q) pred *= rate;
                     last = pred < tolf;
-                    // the rate usually worsens a little from cycle to cycle, so the extrapolation errs towards "last"; where it
-                    // says "not last" by less than a factor of two and the previous solve of this system ended here, so will this one
-                    if (!last && prev_cycles == k && pred < 2.0 * tolf) last = true;
-                } else if (!last && predict == 1 && n < 2 && prev_cycles == k) {
-                    // too early to extrapolate (cycles are enqueued ahead of their norms): the previous solve of this system ended
-                    // with cycle k.  A wrong "last" costs a host round trip, a wrong "not last" a seam pass, a skipped cycle and
-                    // the replay of the post-smoothing pass (tools/exp_ns_timeline.sh: 40 against 70 us at 2049^2)
-                    last = true;
                 }
                 const int slot = enq % FPR_CYC_SLOTS;
                 if (last) {
@@ -1689,6 +1701,7 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
                 r_prev = r_last; r_last = r_rms;
                 ctx->last_coarse_iters = rec.coarse_iters;
                 if (history_host) history_host[n] = r_rms;
+                if (n < 16) kept[n] = r_rms;
                 ++n;
                 if (rec.stop) {   // :70 (taken on the device)
                     if (units[slot].seam)   // u at the end of this cycle was never stored: replay its post-smoothing pass
@@ -1717,6 +1730,7 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
             f_rms = rec.frms; tolf = rec.tolf;
             ctx->last_coarse_iters = rec.coarse_iters;
             if (history_host) history_host[n] = r_rms;
+            if (n < 16) kept[n] = r_rms;
             ++n;
             if (rec.stop) break;  // :70 (taken on the device)
         }
@@ -1728,6 +1742,7 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
             if (int rc = fpr_bc2d(ctx, u, nx, ny)) return rc;  // :60-62
         if (int rc = vcycle_run(ctx, u, f, h, c, tol, coarse_solve_size, coarse_solver, apply_BCs, nx, ny, &r_rms)) return rc;
         if (history_host) history_host[n] = r_rms;
+        if (n < 16) kept[n] = r_rms;
         ++n;
         if (r_rms < tolf) break;  // :70
     }
@@ -1736,7 +1751,10 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
         for (int q = 0; q < 8; ++q)
             if (ctx->mg_hist[q].u == u && ctx->mg_hist[q].f == f && ctx->mg_hist[q].nx == nx && ctx->mg_hist[q].ny == ny) at = q;
         if (at < 0) { at = ctx->mg_hist_next; ctx->mg_hist_next = (ctx->mg_hist_next + 1) & 7; }
-        ctx->mg_hist[at] = {u, f, nx, ny, n};
+        fpr_ctx::MgHist& e = ctx->mg_hist[at];
+        e.u = u; e.f = f; e.nx = nx; e.ny = ny;
+        e.cycles = tolf > 0.0 ? (n < 16 ? n : 16) : 0;
+        for (int q = 0; q < e.cycles; ++q) e.rel[q] = kept[q] / tolf;
     }
     if (rms_host) *rms_host = r_rms;
     if (ncycles_host) *ncycles_host = n;

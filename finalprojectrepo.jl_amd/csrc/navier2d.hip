@@ -300,56 +300,96 @@ void fprx_ns_worker_free(fpr_ctx* ctx)
     if (ctx->ns_worker) { delete static_cast<FprWorker*>(ctx->ns_worker); ctx->ns_worker = nullptr; }
 }
 
-static int ns_step(fpr_ctx* ctx, fpr_ctx* ctx2, double* S, double* T, double* W, double* T_rhs, double* W_rhs, int nx, int ny, double Ra,
-                   double Pr, double k, double beta, double a_adv, double dt_dif, double tol, int niters, int coarse_solve_size,
-                   int coarse_solver, double* dt_host, int* ncyc, int* conv)
+static int ns_order(fpr_ctx* ctx, fpr_ctx* from, fpr_ctx* to)   // `to`'s compute stream behind what `from`'s holds now
+{
+    FPR_HIP(ctx, hipEventRecord(from->ns_ev, from->stream[0]));
+    FPR_HIP(ctx, hipStreamWaitEvent(to->stream[0], from->ns_ev, 0));
+    return FPR_OK;
+}
+
+// The loop `while sim_time < ttot` (:182) for at most max_steps steps, software-pipelined: the S solve of step n+1 (:187) needs the W
+// of step n and nothing of its T, so it runs BEHIND the W solve on the second context, beside the T solve of step n (the longest of
+// the three at config 5: 6-7 cycles against 3 + 4) -- the critical path of a step falls from S + max(T, W) to max(T, W + S).  The
+// S solve of a step that does not follow inside this call (last step, or sim_time reaches ttot) is left to the next call, so the
+// arrays a call returns are the reference's at the same point of its loop.  Same solves on the same inputs: same results.
+// info (nullable, 6 ints): cycles of the S, T, W solves of the LAST step taken, then their converged flags.
+static int ns_run(fpr_ctx* ctx, fpr_ctx* ctx2, double* S, double* T, double* W, double* T_rhs, double* W_rhs, int nx, int ny, double Ra,
+                  double Pr, double k, double beta, double a_adv, double dt_dif, double tol, int niters, int coarse_solve_size,
+                  int coarse_solver, double ttot, int max_steps, double* sim_time_inout, int* steps_host, double* dt_host,
+                  int* unconverged_host, int* info)
 {
     const double h = 1.0 / (ny - 1.0);   // :163
-    double rms = 0.0, frms = 0.0;
-    if (int rc = fpr_mgsolve2d(ctx, S, W, h, 0.0, tol, niters, 0, coarse_solve_size, coarse_solver, nx, ny, &rms, &ncyc[0], nullptr, &frms, &conv[0]))
-        return rc;   // :187
-    double vm[3];
-    if (int rc = fpr_ns_velocity_max2d(ctx, S, h, h, nullptr, nullptr, nx, ny, vm)) return rc;   // :190-193
-    double dt;
-    if (vm[0] == 0.0) dt = dt_dif;   // compute_dt, :76-87
-    else {
-        const double dt_adv = a_adv * fmin(h / vm[1], h / vm[2]);
-        dt = beta >= 0.5 ? dt_adv : fmin(dt_dif, dt_adv);
-    }
-    *dt_host = dt;
-    if (int rc = fpr_bc2d(ctx, T, nx, ny)) return rc;                                                             // :199
-    if (int rc = fpr_ns_rhs2d(ctx, T, W, S, h, h, nx, ny, Ra, Pr, k, beta, dt, T_rhs, W_rhs)) return rc;         // :202-220,225
-    const double c = 1.0 / (beta * dt);   // :219
-    // W, W_rhs (and what they were computed from) are complete for the other context's stream
-    FPR_HIP(ctx, hipEventRecord(ctx->ns_ev, ctx->stream[0]));
-    FPR_HIP(ctx, hipStreamWaitEvent(ctx2->stream[0], ctx->ns_ev, 0));
-    // the solve that took more cycles in the previous step runs on the calling thread (the other one starts a few microseconds
-    // later, when the worker has woken up): it sets the step's length
-    int rcT = FPR_OK, rcW = FPR_OK;
-    double rmsT = 0.0, frmsT = 0.0;
+    const bool pipeline = fpr_opt(ctx, "ns_pipeline", 1) != 0;
     FprWorker* wk = static_cast<FprWorker*>(ctx->ns_worker);
-    auto solveT = [&] {   // :221
-        rcT = fpr_mgsolve2d(ctx, T, T_rhs, h, c, tol, niters, 1, coarse_solve_size, coarse_solver, nx, ny, &rmsT, &ncyc[1], nullptr, &frmsT, &conv[1]);
-    };
-    auto solveW = [&] {   // :226
-        rcW = fpr_mgsolve2d(ctx2, W, W_rhs, h, c / Pr, tol, niters, 0, coarse_solve_size, coarse_solver, nx, ny, &rms, &ncyc[2], nullptr, &frms, &conv[2]);
-    };
     const int dev = ctx->device;
-    const bool t_here = ctx->ns_t_cycles >= ctx->ns_w_cycles;
-    if (t_here) {
-        wk->submit([&] { if (hipSetDevice(dev) != hipSuccess) { rcW = FPR_ERR_HIP; return; } solveW(); });   // (a thread starts on device 0)
-        solveT();
-    } else {
-        wk->submit([&] { if (hipSetDevice(dev) != hipSuccess) { rcT = FPR_ERR_HIP; return; } solveT(); });
-        solveW();
+    double t = *sim_time_inout;
+    int steps = 0, bad = 0;
+    int ncyc[3] = {0, 0, 0}, conv[3] = {1, 1, 1};
+    double rmsS = 0.0, frmsS = 0.0, rmsT = 0.0, frmsT = 0.0, rmsW = 0.0, frmsW = 0.0;
+    bool have_S = false;   // the S of the coming step has been solved already (beside the previous step's T solve)
+    *steps_host = 0;
+    auto solveS = [&]() -> int {   // :187, on the second context (its stream is ordered behind W's producer by the caller)
+        return fpr_mgsolve2d(ctx2, S, W, h, 0.0, tol, niters, 0, coarse_solve_size, coarse_solver, nx, ny, &rmsS, &ncyc[0], nullptr, &frmsS, &conv[0]);
+    };
+    while (t < ttot && steps < max_steps) {
+        if (!have_S) {
+            if (int rc = ns_order(ctx, ctx, ctx2)) return rc;       // W (and S) as the caller / the previous step left them
+            if (int rc = solveS()) return fpr_fail(ctx, rc, "S solve on the second context: %s", fpr_last_error(ctx2));
+            if (int rc = ns_order(ctx, ctx2, ctx)) return rc;
+            bad += !conv[0];
+        }
+        double vm[3];
+        if (int rc = fpr_ns_velocity_max2d(ctx, S, h, h, nullptr, nullptr, nx, ny, vm)) return rc;   // :190-193
+        double dt;
+        if (vm[0] == 0.0) dt = dt_dif;   // compute_dt, :76-87
+        else {
+            const double dt_adv = a_adv * fmin(h / vm[1], h / vm[2]);
+            dt = beta >= 0.5 ? dt_adv : fmin(dt_dif, dt_adv);
+        }
+        if (int rc = fpr_bc2d(ctx, T, nx, ny)) return rc;                                                             // :199
+        if (int rc = fpr_ns_rhs2d(ctx, T, W, S, h, h, nx, ny, Ra, Pr, k, beta, dt, T_rhs, W_rhs)) return rc;         // :202-220,225
+        const double c = 1.0 / (beta * dt);   // :219
+        // does another step follow inside this call?  (the loop's own test, :182, with the time this step will have reached)
+        const bool more = pipeline && steps + 1 < max_steps && t + dt < ttot;
+        // W, W_rhs, S (and what they were computed from) are complete for the other context's stream
+        if (int rc = ns_order(ctx, ctx, ctx2)) return rc;
+        int rcT = FPR_OK, rcW = FPR_OK, rcS = FPR_OK;
+        int cS = conv[0];
+        auto solveT = [&] {   // :221
+            rcT = fpr_mgsolve2d(ctx, T, T_rhs, h, c, tol, niters, 1, coarse_solve_size, coarse_solver, nx, ny, &rmsT, &ncyc[1], nullptr, &frmsT, &conv[1]);
+        };
+        auto solveWS = [&] {   // :226, and the next step's :187 behind it
+            rcW = fpr_mgsolve2d(ctx2, W, W_rhs, h, c / Pr, tol, niters, 0, coarse_solve_size, coarse_solver, nx, ny, &rmsW, &ncyc[2], nullptr, &frmsW, &conv[2]);
+            if (rcW == FPR_OK && more) rcS = solveS();
+        };
+        // the side that took more cycles in the previous step runs on the calling thread (the other one starts a few microseconds
+        // later, when the worker has woken up): it sets the step's length
+        const bool t_here = ctx->ns_t_cycles >= ctx->ns_w_cycles + (more ? ctx->ns_s_cycles : 0);
+        if (t_here) {
+            wk->submit([&] { if (hipSetDevice(dev) != hipSuccess) { rcW = FPR_ERR_HIP; return; } solveWS(); });   // (a thread starts on device 0)
+            solveT();
+        } else {
+            wk->submit([&] { if (hipSetDevice(dev) != hipSuccess) { rcT = FPR_ERR_HIP; return; } solveT(); });
+            solveWS();
+        }
+        wk->wait();
+        ctx->ns_t_cycles = ncyc[1]; ctx->ns_w_cycles = ncyc[2];
+        if (more || !have_S) ctx->ns_s_cycles = ncyc[0];
+        // the next step's kernels (this context's compute stream) read W and S
+        if (int rc = ns_order(ctx, ctx2, ctx)) return rc;
+        if (rcT) return rcT == FPR_ERR_HIP && !ctx->err[0] ? fpr_fail(ctx, rcT, "hipSetDevice in the worker thread") : rcT;
+        if (rcW) return fpr_fail(ctx, rcW, "W solve on the second context: %s", fpr_last_error(ctx2));
+        if (rcS) return fpr_fail(ctx, rcS, "S solve on the second context: %s", fpr_last_error(ctx2));
+        if (info) { info[0] = more ? 0 : ncyc[0]; info[1] = ncyc[1]; info[2] = ncyc[2]; info[3] = more ? 1 : cS; info[4] = conv[1]; info[5] = conv[2]; }
+        *dt_host = dt;
+        t += dt;   // :249
+        ++steps;
+        *sim_time_inout = t; *steps_host = steps;
+        bad += !conv[1] + !conv[2] + (more ? !conv[0] : 0);
+        have_S = more;
     }
-    wk->wait();
-    ctx->ns_t_cycles = ncyc[1]; ctx->ns_w_cycles = ncyc[2];
-    // the next step's kernels (this context's compute stream) read W
-    FPR_HIP(ctx, hipEventRecord(ctx2->ns_ev, ctx2->stream[0]));
-    FPR_HIP(ctx, hipStreamWaitEvent(ctx->stream[0], ctx2->ns_ev, 0));
-    if (rcT) return rcT == FPR_ERR_HIP && !ctx->err[0] ? fpr_fail(ctx, rcT, "hipSetDevice in the worker thread") : rcT;
-    if (rcW) return fpr_fail(ctx, rcW, "W solve on the second context: %s", fpr_last_error(ctx2));
+    *sim_time_inout = t; *steps_host = steps;
+    if (unconverged_host) *unconverged_host = bad;
     return FPR_OK;
 }
 
@@ -370,12 +410,10 @@ extern "C" int fpr_ns_step2d(fpr_ctx* ctx, fpr_ctx* ctx2, double* S, double* T, 
 {
     NS_CHECK(S && T && W && T_rhs && W_rhs && dt_host)
     if (int rc = ns_prepare(ctx, ctx2, beta)) return rc;
-    int ncyc[3] = {0, 0, 0}, conv[3] = {1, 1, 1};
-    const int rc = ns_step(ctx, ctx2, S, T, W, T_rhs, W_rhs, nx, ny, Ra, Pr, k, beta, a_adv, dt_dif, tol, niters, coarse_solve_size,
-                           coarse_solver, dt_host, ncyc, conv);
-    if (info_host)
-        for (int q = 0; q < 3; ++q) { info_host[q] = ncyc[q]; info_host[3 + q] = conv[q]; }
-    return rc;
+    double t = 0.0;
+    int steps = 0;
+    return ns_run(ctx, ctx2, S, T, W, T_rhs, W_rhs, nx, ny, Ra, Pr, k, beta, a_adv, dt_dif, tol, niters, coarse_solve_size, coarse_solver,
+                  1.0, 1, &t, &steps, dt_host, nullptr, info_host);
 }
 
 // `while sim_time < ttot` (:182) for at most max_steps steps: *sim_time_inout advances by every step's dt (:249), *steps_host = steps
@@ -387,21 +425,6 @@ extern "C" int fpr_ns_run2d(fpr_ctx* ctx, fpr_ctx* ctx2, double* S, double* T, d
 {
     NS_CHECK(S && T && W && T_rhs && W_rhs && dt_host && sim_time_inout && steps_host)
     if (int rc = ns_prepare(ctx, ctx2, beta)) return rc;
-    double t = *sim_time_inout;
-    int steps = 0, bad = 0;
-    while (t < ttot && steps < max_steps) {
-        int ncyc[3] = {0, 0, 0}, conv[3] = {1, 1, 1};
-        double dt = 0.0;
-        const int rc = ns_step(ctx, ctx2, S, T, W, T_rhs, W_rhs, nx, ny, Ra, Pr, k, beta, a_adv, dt_dif, tol, niters, coarse_solve_size,
-                               coarse_solver, &dt, ncyc, conv);
-        *sim_time_inout = t; *steps_host = steps;
-        if (rc) return rc;
-        *dt_host = dt;
-        t += dt;
-        ++steps;
-        bad += !conv[0] + !conv[1] + !conv[2];
-    }
-    *sim_time_inout = t; *steps_host = steps;
-    if (unconverged_host) *unconverged_host = bad;
-    return FPR_OK;
+    return ns_run(ctx, ctx2, S, T, W, T_rhs, W_rhs, nx, ny, Ra, Pr, k, beta, a_adv, dt_dif, tol, niters, coarse_solve_size, coarse_solver,
+                  ttot, max_steps, sim_time_inout, steps_host, dt_host, unconverged_host, nullptr);
 }

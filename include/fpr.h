@@ -352,7 +352,7 @@ int fpr_vcycle2d(fpr_ctx* ctx, double* u_f, const double* rhs, double h, double 
  * history, the cycle and coarse-iteration counts are those of the plain loop.  Tuning / A-B options
  * (fpr_set_option, defaults in brackets): mg_ahead [1] cycles enqueued ahead (0 = plain loop), mg_seam [1] shared pass
  * between cycles, mg_seam_predict [1], mg_mid [1] three launch-bound levels in two launches, mg_small_row [1], mg_zero_guess [1] coarse
- * levels do not read the zero guess their parent stored (:132), mg_seam_wg_per_cu [2] chunk height of the shared pass, mg_seam_history [1] the cycle count of the previous solve with the same (u, f, nx, ny) as a second opinion on which cycle will be the last. After an error return u is UNDEFINED (cycles enqueued ahead of the host are drained first, but may have run). */
+ * levels do not read the zero guess their parent stored (:132), mg_seam_wg_per_cu [2] chunk height of the shared pass, mg_seam_history [1] the norms of the previous solve with the same (u, f, nx, ny) (relative to its threshold) supply the expected reduction from the last norm seen to cycle k for the guess which cycle will be the last (a guess changes which launches are enqueued, never a result). After an error return u is UNDEFINED (cycles enqueued ahead of the host are drained first, but may have run). */
 int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h, double c, double tol, int niters,
                   int apply_BCs, int coarse_solve_size, int coarse_solver, int nx, int ny, double* rms_host,
                   int* ncycles_host, double* history_host, double* frms_host, int* converged_host);
@@ -406,7 +406,10 @@ int fpr_ns_step2d(fpr_ctx* ctx, fpr_ctx* ctx2, double* S, double* T, double* W, 
 /* The driver's loop `while sim_time < ttot` (part2.jl:182) around that step for at most max_steps steps: *sim_time_inout advances by
  * every step's dt (:249), *steps_host = steps taken, *dt_host = the last step's dt, *unconverged_host (nullable) = number of solves
  * that did not converge (each one a @warn in the reference, :78-80).  The host language calls it in pieces where it has something
- * to do between steps (the reference starts its clock before the fourth step, :182-184; progress lines). */
+ * to do between steps (the reference starts its clock before the fourth step, :182-184; progress lines).
+ * Inside a call the loop is software-pipelined (option ns_pipeline [1]): the S solve of step n+1 (:187) needs the W of step n and nothing of
+ * its T, so it runs behind the W solve on ctx2 beside the T solve of step n; the S solve of a step that does not follow inside the call is
+ * left to the next call -- the arrays a call returns are the reference's at the same point of its loop. */
 int fpr_ns_run2d(fpr_ctx* ctx, fpr_ctx* ctx2, double* S, double* T, double* W, double* T_rhs, double* W_rhs, int nx, int ny,
                  double Ra, double Pr, double k, double beta, double a_adv, double dt_dif, double tol, int niters,
                  int coarse_solve_size, int coarse_solver, double ttot, int max_steps, double* sim_time_inout, int* steps_host,

@@ -394,9 +394,10 @@ int fpr_ns_velocity_max2d(fpr_ctx* ctx, const double* S, double hx, double hy, d
                           double* vmax_host);
 int fpr_ns_rhs2d(fpr_ctx* ctx, const double* T, const double* W, const double* S, double hx, double hy, int nx, int ny,
                  double Ra, double Pr, double k, double beta, double dt, double* T_out, double* W_out);
-/* One time step of navier_stokes_2D (part2.jl:186-226) for beta > 0 as ONE call: S solve (:187), pass 1, compute_dt (:76-87),
- * boundary conditions of T (:199), pass 2, then the T solve (:221, on ctx from a thread of its own) and the W solve (:226, on
- * ctx2: a second context on the same device) side by side -- they do not depend on each other and are bound by launch latency.
+/* One time step of navier_stokes_2D (part2.jl:186-226) for beta > 0 as ONE call: S solve (:187, on ctx2: a second context on the
+ * same device), pass 1, compute_dt (:76-87), boundary conditions of T (:199), pass 2, then the T solve (:221, on ctx) and the W solve
+ * (:226, on ctx2) side by side -- they do not depend on each other and are bound by launch latency; the longer one of the previous
+ * step on the calling thread, the other on a worker thread the context keeps.
  * The same launches with the same arguments as the piecewise calls (same T, W, S, dt bit for bit), without the host language
  * between them.  h = 1/(ny-1) as the driver (:163); dt_dif, a_adv as SimIn_t (:30-46); *dt_host receives the step's dt;
  * info_host (nullable, 6 ints): V-cycles of the S, T, W solves, then their converged flags (0 = the reference would @warn). */

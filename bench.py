@@ -540,7 +540,9 @@ def ns_block(F):
             "kernel_by_kernel_s_per_step": res_u.t_elapsed / max(res_u.timed_iters, 1),
             "note": "beta=0.5, Pr=1, Ra=1e6, tol=1e-7, niters=50; three multigrid solves per step (the first T solve hits niters "
                     "as in the reference), the T and the W solve of a step side by side on two contexts (value) or one after the other; "
-                    "value: the loop body as ONE library call (fpr_ns_step2d), composed_from_python: the same launches issued piecewise from Python; "
+                    "value: the time loop inside the library (fpr_ns_run2d), software-pipelined -- the next step's S solve runs behind the W solve on the "
+                    "second context beside the T solve, same results bit for bit; composed_from_python: the same launches issued piecewise from "
+                    "Python in the reference's order; "
                     "multigrid_s_per_step from a diagnostic run with the solves in sequence and synchronised; the step around them "
                     "runs as two passes (fpr_ns_velocity_max2d, fpr_ns_rhs2d) -- "
                     "kernel_by_kernel = the reference's seven kernels + maxima + broadcasts, same results bit for bit"}

@@ -490,7 +490,8 @@ class GlobalGrid:
         two sums equal step()'s to ~1e-13 relative (another summation order, see include/fpr.h).
         join=False (between ranks): the pair is left on the core / comm streams and the NEXT step2 continues from there
         without passing through the compute stream; call join() (allreduce_ / step / update_halo_ do) before anything
-        else reads the fields or the sums."""
+        else reads OR WRITES the fields or the sums (the next pair of a chain reuses the pending pair's x-face strips).
+        dHdτ may be None in the one-call form (residual not stored)."""
         from . import part1
 
         args = (Ht, Hτ, Hτ2, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
@@ -550,7 +551,8 @@ class GlobalGrid:
     # exchange then started when the half beside it drained (tools/cu_share_probe.hip: a second queue's workgroups wait
     # for room in the shader engine they were dealt to).
     # z-faces travel in place, x / y faces through the pack kernels; one-cell-wide x-slabs run in the narrow-box kernel
-    # (k_diff3_slab2), y- and z-slabs in the wave-tile kernel.  The phases exist for emulated ranks in one process
+    # (k_diff3_slab2), y- and z-slabs in the wave-tile kernel -- in this phased form; the one-call form (fpr_diffusion3d_step2_halo)
+    # works on the x-shell in compact strips (csrc/diffusion3d_xstrip.hpp).  The phases exist for emulated ranks in one process
     # (tests): every rank posts before any rank completes.
     def reserve_cus(self):
         """Compute units of the comm stream during fused pairs: a multiple of 32 = the same number out of every shader

@@ -157,8 +157,10 @@ def navier_stokes_2D(opt=None, verbose=True, do_vis=False, testmode=False, max_s
     concurrent_solves (default, fused path without trace / timing): the T solve (:221) and the W solve (:226) of a step do not
     depend on each other; W runs on a second context (own streams, own arena) from a worker thread beside T -- these solves
     are bound by launch latency, not by the GPU, so they overlap almost entirely.  Same results bit for bit.
-    native_step (default, where concurrent_solves applies): the whole loop body as ONE library call (fpr_ns_step2d) -- the same
-    launches with the same arguments, without Python between them (the device waited 80-130 us per step for the host)."""
+    native_step (default, where concurrent_solves applies): the time loop itself inside the library (fpr_ns_run2d), called in
+    pieces where this side has something to do between steps (the clock of :182-184, progress lines) -- the same solves on the
+    same inputs, without Python between them, and software-pipelined: the next step's S solve (:187) needs W and nothing of T,
+    so it runs behind the W solve on the second context beside the (longest) T solve.  Same T, W, S, dt bit for bit."""
     import torch
 
     opt = opt if opt is not None else SimIn_t()

@@ -947,6 +947,11 @@ def main():
     def timed_leg(fuse2, prewarm_ms):
         """W (+1 if needed to start from an even state) untimed warm-up steps, then EXACTLY K timed steps between
         barriers; returns max-over-ranks wall time and the per-kernel event times of the timed region."""
+        # (the event timer creates its 16384 events at its first use -- tens of milliseconds during which the card idles, and the
+        # launches behind an idle period of >= 10 ms run up to 20 % slower for ~10 launches, tools/exp_ramp.py: not between the
+        # warm-up and the timed region)
+        ctx.call("fpr_kernel_timer", 1)
+        ctx.call("fpr_kernel_timer", 0)
         # clock ramp, RCCL channel set-up.  Between ranks the number of pre-warm steps must be the SAME everywhere (every
         # step is a collective pattern): a fixed count there, a time budget on a single rank
         if use_dist or as_one:
@@ -961,14 +966,18 @@ def main():
             while time.perf_counter() - tpre < prewarm_ms * 1e-3:
                 run(8, 0, fuse2)
                 torch.cuda.synchronize()
-        run(W, 0, fuse2)
+        # every timed launch of the fused leg must be the fused kernel: an odd W is rounded up to whole pairs (reported as
+        # warmup_extra_steps).  The warm-up of the fused leg is all pairs, too: two one-iteration launches right before the timed
+        # region (how an odd W used to be evened out) draw 120 W less than the fused kernel, and the ten launches behind such an
+        # interlude ran 3-4 % slower than the steady state before and after (profiles/r4_bench_phases.txt, EXPERIMENTS 12.4)
+        extra = (W & 1) if (fuse2 and state["parity"] == 0) else 0
+        run(W + extra, 0, fuse2)
         if use_dist:
             torch.cuda.synchronize()
             hb("warmup")
-        extra = 0
-        if fuse2 and state["parity"] == 1:     # every timed launch of the fused leg must be the fused kernel
-            run(1, W, False)
-            extra = 1
+        if fuse2 and state["parity"] == 1:     # (not reached from an even state; kept for a caller that starts odd)
+            run(1, W + extra, False)
+            extra += 1
         errs.clear()
         barrier()
         ctx.call("fpr_kernel_timer", 1)

@@ -1161,7 +1161,9 @@ def main():
                         outb = Hτ3 if state["cur"] is Hτ else Hτ
                         gp.step2(Ht, state["cur"], Hτ2, outb, res, *coef, dt, sq[2 * i:2 * i + 2], join=False)
                         state["cur"] = outb
-                pair_n(W + (W & 1) + 4)
+                # (the communicator has just been set up: the card idled for more than 10 ms, and launches 4-12 behind such a
+                # pause are throttled, tools/exp_ramp.py -- 24 pairs of warm-up carry the leg past that)
+                pair_n(max(W + (W & 1) + 4, 48))
                 gp.join()
                 barrier()
                 K4 = max(K, 80)                    # steady state: the fork from / join into the compute stream weigh 1/40 each

@@ -19,7 +19,7 @@ def run(gg, pairs):
     for _ in range(pairs):
         gg.step2(Ht, A, O, C, R, *coef, 0.2, sq, join=False); A, C = C, A
 def timed(gg):
-    run(gg, 10); torch.cuda.synchronize(); t0 = time.perf_counter(); run(gg, K); torch.cuda.synchronize()
+    run(gg, 24); torch.cuda.synchronize(); t0 = time.perf_counter(); run(gg, K); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / K * 1e6
 CASES = (("z", (0, 0, 1), 0), ("yz", (0, 1, 1), 0), ("x", (1, 0, 0), 0), ("xy", (1, 1, 0), 0), ("xyz", (1, 1, 1), 0),
          ("corner", (1, 1, 1), 0b010101), ("x1", (1, 0, 0), 0b000001), ("xz1", (1, 0, 1), 0b010001))

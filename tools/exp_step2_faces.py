@@ -33,7 +33,7 @@ for name, periods, drop in CASES:
     else:
         gg = F.grid.GlobalGrid(n, n, n, dims=(1, 1, 1), use_dist=False)
     if os.environ.get("FPR_RESERVE") and any(periods): gg._reserve = int(os.environ["FPR_RESERVE"])
-    run(gg, 10); torch.cuda.synchronize(); t0 = time.perf_counter(); run(gg, K); th = time.perf_counter() - t0
+    run(gg, 24); torch.cuda.synchronize(); t0 = time.perf_counter(); run(gg, K); th = time.perf_counter() - t0   # (24 pairs: past the throttled launches behind the idle period of the set-up, tools/exp_ramp.py)
     torch.cuda.synchronize(); t = time.perf_counter() - t0
     run1(gg, 10); torch.cuda.synchronize(); t0 = time.perf_counter(); run1(gg, 2 * K); torch.cuda.synchronize(); t1 = time.perf_counter() - t0
     res[name] = t

@@ -797,9 +797,14 @@ def test_placement_alloc_fields(fpr):
         return e0.elapsed_time(e1)
 
     rep = {}
-    arrs = F.placement.alloc_fields(4, *n, pool=7, report=rep, pairs=[(0, 1), (2, 3)], trial=trial, trials=2)
+    arrs = F.placement.alloc_fields(4, *n, pool=7, report=rep, pairs=[(0, 1), (2, 3)], trial=trial, trials=2, extend_by=0)
     assert len(arrs) == 4 and len({a.data_ptr() for a in arrs}) == 4
     assert rep["selected"] is True and rep["pool"] == 7 and len(rep["chosen"]) == 4 and rep["trials"] == len(calls) >= 2
+    # a pool that looks like one class (here: a threshold no pool can meet) is extended once
+    rep2 = {}
+    more = F.placement.alloc_fields(2, *n, pool=4, report=rep2, spacer_bytes=256 << 20, extend_below_GBs=1e9, extend_by=3)
+    assert len(more) == 2 and rep2["pool_first"] == 4 and rep2["pool"] == 7 and rep2["pool_extended_because_fastest_pair_GBs"] > 100.0
+    del more
     assert rep["pair_copy_GBs_all"]["fastest"] >= rep["pair_copy_GBs_chosen"]["slowest"] >= rep["pair_copy_GBs_all"]["slowest"] > 100.0
     for a in arrs:
         assert tuple(a.shape) == n and a.stride() == (1, n[0], n[0] * n[1]) and float(a.abs().max()) == 0.0

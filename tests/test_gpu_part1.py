@@ -805,6 +805,12 @@ def test_placement_alloc_fields(fpr):
     more = F.placement.alloc_fields(2, *n, pool=4, report=rep2, spacer_bytes=256 << 20, extend_below_GBs=1e9, extend_by=3)
     assert len(more) == 2 and rep2["pool_first"] == 4 and rep2["pool"] == 7 and rep2["pool_extended_because_fastest_pair_GBs"] > 100.0
     del more
+    # ... and so is a pool in which the caller's kernel sees no difference between any two assignments
+    rep3 = {}
+    more = F.placement.alloc_fields(3, *n, pool=4, report=rep3, spacer_bytes=256 << 20, extend_below_GBs=0.0, extend_by=2, trial=lambda a: 1.0, trials=2)
+    assert len(more) == 3 and rep3["pool_first"] == 4 and rep3["pool"] == 6 and rep3["pool_extended_because_trial_spread"] == 0.0
+    assert rep3["trials"] > 6 and all(float(a.abs().max()) == 0.0 for a in more)
+    del more
     assert rep["pair_copy_GBs_all"]["fastest"] >= rep["pair_copy_GBs_chosen"]["slowest"] >= rep["pair_copy_GBs_all"]["slowest"] > 100.0
     for a in arrs:
         assert tuple(a.shape) == n and a.stride() == (1, n[0], n[0] * n[1]) and float(a.abs().max()) == 0.0

@@ -345,6 +345,59 @@ def vcycle_block(F, with_cpu=True, steps=5, place=True):
             mg.provide_arena_(n, n, t1, t2)
             b.copy_(b0)
             del b0
+            # ... then the three arrays of the first coarse level the finest passes stream beside them (33.6 MB each: which mode the
+            # seam pass runs in depended on the context's own allocation of these as much as on the four big arrays,
+            # tools/exp_mg_arena_rounds.py); same search, the big arrays fixed
+            try:
+                nc = 1 + (n - 1) // 2
+                placement_c = {}
+
+                def trial_c(arrs):
+                    for a in arrs:
+                        a.zero_()
+                    mg.provide_arena_coarse_(n, n, *arrs)
+                    best = None
+                    for _ in range(3):
+                        x.zero_()
+                        F.synchronize()
+                        t0 = time.perf_counter()
+                        with warnings.catch_warnings():
+                            warnings.simplefilter("ignore")
+                            mg.MGsolve_2DPoisson_(x, b, h, 0.0, 1e-6, 100, False, opt=mg.MGOpt(), return_history=False)
+                        F.synchronize()
+                        dt = time.perf_counter() - t0
+                        best = dt if best is None or dt < best else best
+                    return best * 1e3
+
+                def solve_ms():
+                    best = None
+                    for _ in range(3):
+                        x.zero_()
+                        F.synchronize()
+                        t0 = time.perf_counter()
+                        with warnings.catch_warnings():
+                            warnings.simplefilter("ignore")
+                            mg.MGsolve_2DPoisson_(x, b, h, 0.0, 1e-6, 100, False, opt=mg.MGOpt(), return_history=False)
+                        F.synchronize()
+                        dt = time.perf_counter() - t0
+                        best = dt if best is None or dt < best else best
+                    return best * 1e3
+
+                own_ms = solve_ms()                      # the library's own three arrays: what a placed triple has to beat
+                cs = F.placement.alloc_fields(3, nc, nc, pool=8, min_bytes=16 << 20, report=placement_c, trial=trial_c, trials=3,
+                                              spacer_bytes=2 << 30)
+                keep_placed = placement_c.get("trial_ms_best", own_ms) < 0.995 * own_ms
+                if keep_placed:
+                    mg.provide_arena_coarse_(n, n, *cs)
+                else:
+                    mg.provide_arena_coarse_(n, n, None, None, None)
+                    del cs
+                placement["coarse_level"] = {k: placement_c.get(k) for k in ("pool_first", "pool", "trials", "trial_ms_best", "trial_ms_first",
+                                                                             "trial_ms_worst", "pool_extended_because_trial_spread")}
+                placement["coarse_level"].update({"library_own_ms": own_ms, "placed_kept": keep_placed})
+            except Exception as e:
+                mg.provide_arena_coarse_(n, n, None, None, None)
+                placement["coarse_level"] = {"error": repr(e)}
         except Exception as e:       # the search is an optimisation: the library's own buffers give the same results
             mg.provide_arena_(n, n, None, None)
             x, b = F.fzeros(n, n), b0

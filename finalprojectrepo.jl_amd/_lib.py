@@ -102,6 +102,7 @@ _SIG = {
                       C.POINTER(_d), C.POINTER(_i)],
     "fpr_cg2d": [_vp, _dp, _dp, _d, _d, _d, _d, _i, _i, _i, C.POINTER(_d), C.POINTER(_i)],
     "fpr_mg_arena_provide": [_vp, _i, _i, _vp, _vp],
+    "fpr_mg_arena_provide_coarse": [_vp, _i, _i, _vp, _vp, _vp],
     "fpr_compute_velocity2d": [_vp, _dp, _d, _d, _dp, _dp, _i, _i],
     "fpr_compute_Ra_dTdx2d": [_vp, _d, _d, _dp, _dp, _i, _i],
     "fpr_compute_diffusion2d": [_vp, _dp, _d, _d, _d, _dp, _i, _i],

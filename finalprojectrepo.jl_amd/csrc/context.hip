@@ -51,10 +51,12 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
     for (auto& kv : ctx->arenas)
         for (auto& L : kv.second) {
             if (L.tmp && L.own_tmp) hipFree(L.tmp);
-            if (L.res_c) hipFree(L.res_c);
-            if (L.corr_c) hipFree(L.corr_c);
+            if (L.res_c && L.own_coarse) hipFree(L.res_c);
+            if (L.corr_c && L.own_coarse) hipFree(L.corr_c);
             if (L.tmp2 && L.own_tmp2) hipFree(L.tmp2);
-            if (L.corr_c2) hipFree(L.corr_c2);
+            if (L.corr_c2 && L.own_coarse) hipFree(L.corr_c2);
+            for (double* q : L.coarse_own)
+                if (q) hipFree(q);
         }
     for (auto& e : ctx->ktimer_ev) hipEventDestroy(e);
     if (ctx->cg_buf) hipFree(ctx->cg_buf);

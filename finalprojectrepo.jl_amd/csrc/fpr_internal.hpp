@@ -55,6 +55,8 @@ struct FprLevel {  // one multigrid level's scratch (role of prealloc_dict, mult
     double* tmp2 = nullptr;
     double* corr_c2 = nullptr;
     bool own_tmp = true, own_tmp2 = true;   // false: the caller's buffer (fpr_mg_arena_provide), not freed by the library
+    bool own_coarse = true;                 // the same for res_c, corr_c, corr_c2 (fpr_mg_arena_provide_coarse)
+    double* coarse_own[3] = {nullptr, nullptr, nullptr};   // the library's own three while the caller's stand in (they come back as they were)
 };
 
 struct FprGrid {  // implicit global grid of the decomposed diffusion path (role of ImplicitGlobalGrid's global state)

@@ -919,6 +919,39 @@ extern "C" int fpr_mg_arena_provide(fpr_ctx* ctx, int nx, int ny, double* tmp, d
     return FPR_OK;
 }
 
+// ... and the three arrays of the first coarse level that the passes over the finest grid stream beside them at a quarter of the
+// rate: the injected residual (res_c) and the two alternating correction buffers (corr_c, corr_c2), each (1 + (nx-1)/2) x (1 + (ny-1)/2)
+// doubles.  Which mode a 4097^2 seam pass runs in (106 or 117-120 us) depended on the context's own allocation of these as much as on
+// the four big arrays (tools/exp_mg_arena_rounds.py).  All three or none (NULL, NULL, NULL = the library's own again).
+extern "C" int fpr_mg_arena_provide_coarse(fpr_ctx* ctx, int nx, int ny, double* res_c, double* corr_c, double* corr_c2)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    if (int rc = check_dims(ctx, nx, ny)) return rc;
+    const bool all = res_c && corr_c && corr_c2, none = !res_c && !corr_c && !corr_c2;
+    FPR_REQUIRE(ctx, all || none, "all three buffers or none");
+    FPR_REQUIRE(ctx, (((uintptr_t)res_c | (uintptr_t)corr_c | (uintptr_t)corr_c2) & 15) == 0, "buffers must be 16-byte aligned");
+    FPR_REQUIRE(ctx, none || (res_c != corr_c && res_c != corr_c2 && corr_c != corr_c2), "three distinct buffers");
+    std::vector<FprLevel>* A = nullptr;
+    if (int rc = get_arena(ctx, nx, ny, 0, &A)) return rc;
+    FprLevel& L = (*A)[0];
+    FPR_REQUIRE(ctx, L.res_c != nullptr, "this grid has no coarse level");
+    for (int s = 0; s < 3; ++s) FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[s]));   // nothing in flight uses the buffers that leave
+    const size_t nc = (size_t)(1 + (nx - 1) / 2) * (size_t)(1 + (ny - 1) / 2);
+    if (all) {
+        if (L.own_coarse) {   // the library's own step aside, untouched: NULL x 3 brings exactly these back
+            if (!L.corr_c2) FPR_HIP(ctx, hipMalloc(&L.corr_c2, nc * sizeof(double)));
+            L.coarse_own[0] = L.res_c; L.coarse_own[1] = L.corr_c; L.coarse_own[2] = L.corr_c2;
+        }
+        L.res_c = res_c; L.corr_c = corr_c; L.corr_c2 = corr_c2;
+        L.own_coarse = false;
+    } else if (!L.own_coarse) {
+        L.res_c = L.coarse_own[0]; L.corr_c = L.coarse_own[1]; L.corr_c2 = L.coarse_own[2];
+        L.coarse_own[0] = L.coarse_own[1] = L.coarse_own[2] = nullptr;
+        L.own_coarse = true;
+    }
+    return FPR_OK;
+}
+
 #include "mg_mid.hpp"     // k_mid_down, k_mid_up: three launch-bound levels in two launches
 
 // Does the sub-hierarchy below an (nx, ny) level fit k_mg_small's LDS arena?  nlev = its levels, tot = doubles needed.

@@ -67,6 +67,18 @@ def provide_arena_(nx, ny, tmp=None, tmp2=None):
     c._arena_refs[(int(nx), int(ny))] = (tmp, tmp2)
 
 
+def provide_arena_coarse_(nx, ny, res_c=None, corr_c=None, corr_c2=None):
+    """fpr_mg_arena_provide_coarse: the three arrays of the first coarse level of an (nx, ny) hierarchy from the caller (injected
+    residual and the two alternating correction buffers, shape (1 + (nx-1)//2, 1 + (ny-1)//2); all three or none).  The passes over
+    the finest grid stream them beside u, f and the ping-pong partners; results do not depend on who owns them."""
+    c = _ctx()
+    arrs = (res_c, corr_c, corr_c2)
+    c.call("fpr_mg_arena_provide_coarse", int(nx), int(ny), *(fptr(a, 2) if a is not None else None for a in arrs))
+    if not hasattr(c, "_arena_refs_coarse"):
+        c._arena_refs_coarse = {}
+    c._arena_refs_coarse[(int(nx), int(ny))] = arrs
+
+
 def _policy(p):
     if p == serial or p not in (parallel, parallel_shmem):
         raise RuntimeError("execution policy %r not implemented (reference: error(), multigrid.jl:233-236)" % (p,))

@@ -372,6 +372,10 @@ int fpr_cg2d(fpr_ctx* ctx, double* x_in, const double* b, double hx, double hy, 
  * passes over the finest grid stream u, f and these two at equal offsets; on MI355X a host that places its field arrays
  *  places these two with them.  Waits for the context's streams; results do not depend on it. */
 int fpr_mg_arena_provide(fpr_ctx* ctx, int nx, int ny, double* tmp, double* tmp2);
+/* ... and the three arrays of the first coarse level that the passes over the finest grid stream beside them (injected residual and the
+ * two alternating correction buffers; (1 + (nx-1)/2) x (1 + (ny-1)/2) doubles each, 16-byte aligned, distinct): all three or none
+ * (NULL x 3 = the library's own again).  Contents need no initialisation; results do not depend on who owns the buffers. */
+int fpr_mg_arena_provide_coarse(fpr_ctx* ctx, int nx, int ny, double* res_c, double* corr_c, double* corr_c2);
 
 /* coarse-solver iterations spent by the last fpr_vcycle2d / fpr_mgsolve2d call (diagnostics) */
 long fpr_last_coarse_iters(fpr_ctx* ctx);

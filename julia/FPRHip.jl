@@ -48,7 +48,7 @@ export @init_parallel_stencil, @reset_parallel_stencil, @parallel, @parallel_ind
        halo_pack!, halo_unpack!, fpr_version,
        init_global_grid, finalize_global_grid, select_device, update_halo!, gather!, nx_g, ny_g, nz_g, x_g, y_g, z_g,
        halo_exchange_begin!, halo_exchange_end!, halo_exchange_comm!, allreduce_sum!, diffusion_3D_array_programming,
-       diffusion_3D_step_τ2_halo!, join_pair!, alloc_fields, provide_arena!
+       diffusion_3D_step_τ2_halo!, join_pair!, alloc_fields, provide_arena!, provide_arena_coarse!
 
 const libfpr = get(ENV, "FPR_HIP_LIB", joinpath(@__DIR__, "..", "finalprojectrepo.jl_amd", "lib", "libfpr_hip.so"))
 
@@ -808,6 +808,14 @@ function provide_arena!(nx::Integer, ny::Integer, tmp::Union{DA,Nothing}, tmp2::
     pt(A) = A === nothing ? Ptr{Cdouble}(C_NULL) : p(A)
     check(ccall((:fpr_mg_arena_provide, libfpr), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}), ctx(), nx, ny, pt(tmp), pt(tmp2)))
     ARENA_REFS[(Int(nx), Int(ny))] = (tmp, tmp2)
+    return nothing
+end
+"`provide_arena_coarse!(nx, ny, res_c, corr_c, corr_c2)`: the three arrays of the first coarse level too (all three or `nothing` x 3)."
+function provide_arena_coarse!(nx::Integer, ny::Integer, res_c::Union{DA,Nothing}, corr_c::Union{DA,Nothing}, corr_c2::Union{DA,Nothing})
+    pt(A) = A === nothing ? Ptr{Cdouble}(C_NULL) : p(A)
+    check(ccall((:fpr_mg_arena_provide_coarse, libfpr), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), ctx(), nx, ny,
+                pt(res_c), pt(corr_c), pt(corr_c2)))
+    ARENA_REFS[(-Int(nx), -Int(ny))] = (res_c, corr_c, corr_c2)
     return nothing
 end
 policy_ok(pol) = (pol in (parallel, parallel_shmem)) || error()    # multigrid.jl:233-236

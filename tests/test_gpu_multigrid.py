@@ -455,6 +455,12 @@ def test_coarse_jacobi_persistent_launches_equal_the_plain_ones(fpr, oracle, tol
     assert it_ref > 0
 
 
+def torch_isnan(a):
+    import torch
+
+    return torch.isnan(a)
+
+
 def test_provided_arena_buffers_change_nothing(fpr):
     """fpr_mg_arena_provide (prealloc_dict, multigrid.jl:25-38, 49-51): the finest level's two ping-pong partners from the caller,
     then the library's own again -- the solve is the same bit for bit either way, and the caller's buffers are really used."""
@@ -478,6 +484,22 @@ def test_provided_arena_buffers_change_nothing(fpr):
         assert o[0] == outs[0][0] and o[1] == outs[0][1] and o[2] == outs[0][2] and np.array_equal(o[3], outs[0][3])
     with pytest.raises(F.FprError):
         F.ctx().call("fpr_mg_arena_provide", 2, 2, None, None)     # grids are at least 3 x 3
+    # the three arrays of the first coarse level (fpr_mg_arena_provide_coarse), filled with NaN first: nothing is read before it is written
+    nc = 1 + (n - 1) // 2
+    cs = [F.fzeros(nc, nc) for _ in range(3)]
+    for provided in (True, False):
+        for a in cs:
+            a.fill_(float("nan"))
+        mg.provide_arena_coarse_(n, n, *(cs if provided else (None, None, None)))
+        x = F.fzeros(n, n)
+        r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, b, h, 0.0, 1e-8, 50, False, return_history=True)
+        assert r == outs[0][0] and tuple(hist) == outs[0][1] and cit == outs[0][2] and np.array_equal(F.tonumpy(x), outs[0][3])
+        touched = any(bool((~torch_isnan(a)).any()) for a in cs)
+        assert touched == provided
+    with pytest.raises(F.FprError):
+        mg.provide_arena_coarse_(n, n, cs[0], cs[1], None)         # all three or none
+    with pytest.raises(F.FprError):
+        mg.provide_arena_coarse_(n, n, cs[0], cs[0], cs[1])        # distinct
 
 
 def test_multisweep_and_single_sweep_paths_agree(fpr):

@@ -263,13 +263,15 @@ def test_t_and_w_solves_side_by_side_equal_the_sequence(fpr, shape):
 
     p2 = fpr.part2
     outs = []
-    for conc, native in ((False, False), (True, False), (True, True), (True, True)):
+    for conc, native, pipeline in ((False, False, 1), (True, False, 1), (True, True, 1), (True, True, 1), (True, True, 0)):
+        fpr.ctx().set_option("ns_pipeline", pipeline)     # 0: the library's loop in the reference's order (S solve at the top of a step)
         opt = p2.SimIn_t()
         opt.nx, opt.ny, opt.beta, opt.tol, opt.Pr, opt.niters, opt.ttot = shape[0], shape[1], 0.5, 1.0e-7, 1.0, 30, 1e9
         opt.W_init_strategy = p2.random
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             outs.append(p2.navier_stokes_2D(opt=opt, verbose=False, max_steps=5, fused=True, concurrent_solves=conc, native_step=native))
+    fpr.ctx().set_option("ns_pipeline", 1)
     a = outs[0]
     for b in outs[1:]:
         assert a.dt_last == b.dt_last and a.steps == b.steps

@@ -31,7 +31,6 @@ for rnd in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
         return best * 1e3
     # first the library's own buffers (no placement at all)
     x0 = F.fzeros(n, n)
-    own = trial.__call__  # noqa
     mg.provide_arena_(n, n, None, None)
     t_own = None
     for _ in range(3):

@@ -549,11 +549,60 @@ double orc_cg2d(double *x_in, const double *b, double hx, double hy, double c, d
     return out;
 }
 
-/* statistics of the last orc_vcycle2d / orc_mgsolve2d call (coarse-solver iteration counts) */
-static long g_coarse_iters = 0;
-long orc_last_coarse_iters(void) { return g_coarse_iters; }
+/* B9 as the reference runs it on a CPU: the SAME recurrence with `norm` / `sum(a .* b)` as plain working-precision pairwise
+ * sums (Julia's `sum` / `norm` of an Array: pairwise with a 1024-element base case; the SIMD order inside a base case is not
+ * reproduced).  Not what the HIP kernels are compared with bit for bit (that is orc_cg2d above) -- this variant exists so that a
+ * test can BOUND the distance between the Dot2 recurrence and the reference's plain-sum arithmetic (tests/test_oracle_pins.py). */
+double orc_cg2d_plain(double *x_in, const double *b, double hx, double hy, double c, double tol, int Nmax,
+                      int nx, int ny, int *iters_out)
+{
+    const size_t N = (size_t)nx * ny;
+    const double normb = sqrt(pw_dot(b, b, N)); /* :57 */
+    const double tolb = tol * normb;
+    double *r = (double *)malloc(N * sizeof(double));
+    double *p = (double *)malloc(N * sizeof(double));
+    double *p_hat = (double *)malloc(N * sizeof(double));
+    double *x = (double *)calloc(N, sizeof(double));
+    memcpy(r, b, N * sizeof(double));
+    memcpy(p, r, N * sizeof(double));
+    memcpy(p_hat, r, N * sizeof(double));
+    double normr = INFINITY;
+    double rho = pw_dot(r, r, N); /* :64 */
+    int it = 0;
+    for (int i = 1; i <= Nmax; ++i) {
+        it = i;
+        orc_laplace_apply2d(p, hx, hy, c, p_hat, nx, ny);      /* :68 */
+        const double alpha = rho / pw_dot(p, p_hat, N);          /* :69 */
+        for (size_t n = 0; n < N; ++n) x[n] = x[n] + alpha * p[n];     /* :70 */
+        for (size_t n = 0; n < N; ++n) r[n] = r[n] - alpha * p_hat[n]; /* :71 */
+        normr = sqrt(pw_dot(r, r, N));                            /* :72 */
+        if (normr < tolb) break;                                 /* :76 */
+        const double rho_old = rho;
+        rho = pw_dot(r, r, N);                                    /* :83 */
+        const double beta = rho / rho_old;
+        for (size_t n = 0; n < N; ++n) p[n] = r[n] + beta * p[n]; /* :85 */
+    }
+    memcpy(x_in, x, N * sizeof(double)); /* :88 */
+    const double out = sqrt(pw_dot(r, r, N) / (double)N); /* :90 */
+    if (iters_out) *iters_out = it;
+    free(r); free(p); free(p_hat); free(x);
+    return out;
+}
 
-/* B7: Vcycle_2DPoisson! -- multigrid.jl:91-170.  coarse_solver: 0 = jacobi, 1 = conjugate_gradient.
+/* statistics of the last orc_vcycle2d / orc_mgsolve2d call (coarse-solver iteration counts; per coarse solve: the first 256) */
+static long g_coarse_iters = 0;
+static int g_solve_iters[256];
+static int g_solves = 0;
+long orc_last_coarse_iters(void) { return g_coarse_iters; }
+int orc_last_coarse_solves(int *iters_out, int cap)
+{
+    const int n = g_solves < 256 ? g_solves : 256;
+    for (int i = 0; i < n && i < cap; ++i) iters_out[i] = g_solve_iters[i];
+    return g_solves;
+}
+
+/* B7: Vcycle_2DPoisson! -- multigrid.jl:91-170.  coarse_solver: 0 = jacobi, 1 = conjugate_gradient (Dot2 sums),
+ * 2 = conjugate_gradient with plain pairwise sums (for the deviation bound in tests/test_oracle_pins.py).
  * Level buffers are freshly zeroed per call exactly as :114-117 (the recursive call :133 passes no
  * prealloc_dict, so the reference allocates fresh zero buffers too).  Returns res_rms; -1 on the
  * reference's error("ERROR:not a power of 2") :95-97 / InexactError of Int(log2(..)) :103. */
@@ -593,10 +642,12 @@ double orc_vcycle2d(double *u_f, const double *rhs, double h, double c, double t
             ++g_coarse_iters;
             if (res_rms < tol_rhs) break;
         }
-    } else { /* :160-162 */
+    } else { /* :160-162; coarse_solver 2 = the same cg! with plain pairwise sums (orc_cg2d_plain) */
         int it = 0;
-        res_rms = orc_cg2d(u_f, rhs, h, h, c, tol, 20 * coarse_solve_size, nx, ny, &it);
+        res_rms = (coarse_solver == 2 ? orc_cg2d_plain : orc_cg2d)(u_f, rhs, h, h, c, tol, 20 * coarse_solve_size, nx, ny, &it);
         g_coarse_iters += it;
+        if (g_solves < 256) g_solve_iters[g_solves] = it;
+        ++g_solves;
     }
     free(res_f);
     return res_rms;
@@ -618,6 +669,7 @@ double orc_mgsolve2d(double *u, const double *f, double h, double c, double tol,
     double r_rms = 0.0;
     int n = 0;
     g_coarse_iters = 0;
+    g_solves = 0;
     for (int iter = 1; iter <= niters; ++iter) {
         if (apply_BCs) orc_bc2d(u, nx, ny); /* :60-62 */
         r_rms = orc_vcycle2d(u, f, h, c, tol, coarse_solve_size, coarse_solver, apply_BCs, nx, ny);

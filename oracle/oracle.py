@@ -64,6 +64,8 @@ class Oracle:
             "orc_prolongate2d": (None, [_dp, _dp, i, i, i]),
             "orc_laplace_apply2d": (None, [_dp, d, d, d, _dp, i, i]),
             "orc_cg2d": (d, [_dp, _dp, d, d, d, d, i, i, i, C.POINTER(i)]),
+            "orc_cg2d_plain": (d, [_dp, _dp, d, d, d, d, i, i, i, C.POINTER(i)]),
+            "orc_last_coarse_solves": (i, [C.POINTER(i), i]),
             "orc_vcycle2d": (d, [_dp, _dp, d, d, d, i, i, i, i, i]),
             "orc_mgsolve2d": (d, [_dp, _dp, d, d, d, i, i, i, i, i, i, _dp, C.POINTER(i), _dp]),
             "orc_last_coarse_iters": (l, []),
@@ -162,6 +164,18 @@ class Oracle:
         it = C.c_int(0)
         r = self.lib.orc_cg2d(_p(x), _p(b), hx, hy, c, tol, Nmax, *b.shape, C.byref(it))
         return r, it.value
+
+    def cg2d_plain(self, x, b, hx, hy, c, tol, Nmax):
+        """cg! with plain pairwise sums (the reference's CPU arithmetic up to the order inside a 1024-element base case)."""
+        it = C.c_int(0)
+        r = self.lib.orc_cg2d_plain(_p(x), _p(b), hx, hy, c, tol, Nmax, *b.shape, C.byref(it))
+        return r, it.value
+
+    def last_coarse_solve_iters(self):
+        """CG iterations of every coarse solve of the last mgsolve2d call (the first 256)."""
+        buf = (C.c_int * 256)()
+        n = self.lib.orc_last_coarse_solves(buf, 256)
+        return list(buf)[: min(n, 256)]
 
     def vcycle2d(self, u, rhs, h, c, tol, coarse_solve_size=5, coarse_solver=0, apply_BCs=False):
         return self.lib.orc_vcycle2d(_p(u), _p(rhs), h, c, tol, coarse_solve_size, coarse_solver,

@@ -356,3 +356,49 @@ def test_dot2_is_the_exactly_rounded_dot_product_in_any_order(oracle):
     plain = oracle.lib.orc_dot(np.ascontiguousarray(x2).ctypes.data_as(dp), np.ascontiguousarray(y2).ctypes.data_as(dp), len(x2))
     exact = float(sum(Fraction(float(u)) * Fraction(float(v)) for u, v in zip(x2, y2)))
     assert plain != exact            # (what Dot2 buys on this input)
+
+
+# ---------------------------------------------------------------- krylov.jl:55-91 with the reference's own (plain) sums
+def test_dot2_cg_stays_within_a_pinned_distance_of_plain_sum_cg_on_config_3():
+    """`cg!` leaves the order of its three sums to the platform (krylov.jl:57,64,69,72,83: `norm`, `sum(a .* b)`); the oracle and the
+    HIP kernels form them as Dot2 sums (order-independent, so both sides agree bit for bit).  This bounds how far that recurrence is
+    from the reference's working-precision arithmetic (`orc_cg2d_plain`: pairwise sums as Julia's `sum` on a CPU) on BASELINE
+    config 3 -- 4097^2, five grids (l = 8, coarse 257^2), multigrid_bench.jl:27-42 protocol: the same number of V-cycles, the same
+    CG iteration count in every coarse solve (+-1 allowed), residual history within 2e-6 relative (measured 4.2e-7 in the last
+    cycle, 3e-13 in the first), both below tol * rms(f) as test/krylov.jl:19-36 / test/multigrid.jl:30-100 ask, solutions within
+    1e-10 (measured 1.4e-12)."""
+    import os
+
+    from fixtures_io import splitmix64_uniform
+    from oracle.oracle import Oracle
+
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 8)))
+    orc = Oracle(openmp=True)       # (the sweeps in parallel; the CG sums under test are the serial pw_dot / dot2 either way)
+    n, tol = 4097, 1e-6
+    b = np.asfortranarray(splitmix64_uniform(n * n, 1).reshape((n, n), order="F"))
+    got = {}
+    for solver in (1, 2):
+        x = farr(n, n)
+        r, hist, frms = orc.mgsolve2d(x, b, 1.0 / (n - 1), 0.0, tol, 100, False, 257, solver)
+        got[solver] = (x, hist, orc.last_coarse_solve_iters(), r, frms)
+    (x2, h2, it2, r2, f2), (xp, hp, itp, rp, fp_) = got[1], got[2]
+    assert len(h2) == len(hp) == 7
+    assert len(it2) == len(itp) == 7 and all(abs(a - b_) <= 1 for a, b_ in zip(it2, itp)), (it2, itp)
+    assert r2 < tol * f2 and rp < tol * fp_
+    assert np.max(np.abs(h2 - hp) / np.abs(hp)) <= 2e-6, (h2, hp)
+    assert np.abs(x2 - xp).max() <= 1e-10 * np.abs(xp).max()
+
+
+def test_plain_sum_cg_meets_the_reference_criterion(oracle):
+    """test/krylov.jl:19-36 on the plain-sum variant too: same criterion, same iteration count as the Dot2 recurrence here."""
+    n = 66
+    h = 1.0 / (n - 1)
+    b = asf(np.ones((n, n)))
+    b[0, :] = b[-1, :] = 0.0
+    b[:, 0] = b[:, -1] = 0.0
+    x, x2 = farr(n, n), farr(n, n)
+    r, it = oracle.cg2d_plain(x, b, h, h, 3.14, 1e-6, 1000)
+    r2, it2 = oracle.cg2d(x2, b, h, h, 3.14, 1e-6, 1000)
+    assert r < 1e-6 * math.sqrt((b ** 2).sum() / n ** 2)
+    assert it == it2 and abs(r - r2) <= 1e-9 * r2
+    assert np.abs(x - x2).max() <= 1e-12 * np.abs(x2).max()

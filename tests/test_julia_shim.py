@@ -91,3 +91,201 @@ def test_include_reference_drops_only_what_the_shim_provides():
         assert keep in ref_funcs and keep not in native
     for pkg in ("CUDA", "ParallelStencil", "ImplicitGlobalGrid"):
         assert ":" + pkg in SHIM.split("const ABSENT_PACKAGES")[1].split("\n")[0]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Every `ccall((:fpr_x, libfpr), Ret, (types...), args...)` of the shim against the prototype in include/fpr.h: the shim is
+# unexecuted here, and a Cint where the header has a double (or one argument too few) is silent memory corruption on a
+# maintainer's machine.  Also: every block closes, every exported name is defined.
+# ----------------------------------------------------------------------------------------------------------------------
+def _strip_c_comments(txt):
+    return re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", txt, flags=re.S))
+
+
+def _split_top(s, sep=","):
+    """Split at `sep` outside (), [] and {}."""
+    out, depth, cur = [], 0, []
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == sep and depth == 0:
+            out.append("".join(cur))
+            cur = []
+        else:
+            cur.append(ch)
+    if "".join(cur).strip():
+        out.append("".join(cur))
+    return [x.strip() for x in out]
+
+
+def _c_type_class(decl, is_return=False):
+    """A C parameter declaration -> the class of Julia types that may stand for it."""
+    d = re.sub(r"\bconst\b", " ", decl).strip()
+    if "[" in d or "*" in d:
+        # (an array parameter `const int lo[3]` is a pointer)
+        base = re.sub(r"[\*\[].*", "", d).split()
+        base = base[0] if base else ""
+        stars = d.count("*") + (1 if "[" in d else 0)
+        if base == "char":
+            return "cstring"
+        if base == "double":
+            return "ptr_double" if stars == 1 else "ptr_ptr"
+        if base == "int":
+            return "ptr_int"
+        if base == "long":
+            return "ptr_long"
+        if base == "void" and stars == 1:
+            return "ptr_any"                                  # void*: raw bytes, any Ptr{T}
+        return "ptr_void" if stars == 1 else "ptr_ptr"      # fpr_ctx*, void**
+    base = d.split()[0] if not is_return else d
+    return {"int": "int", "long": "long", "double": "double", "size_t": "size_t", "void": "void"}[base.split()[0]]
+
+
+JULIA_OK = {
+    "int": {"Cint"}, "long": {"Clong"}, "double": {"Cdouble"}, "size_t": {"Csize_t"}, "void": {"Cvoid"},
+    "cstring": {"Cstring", "Ptr{UInt8}", "Ptr{Cchar}"},
+    "ptr_double": {"Ptr{Cdouble}", "Ptr{Float64}", "Ptr{Cvoid}"},       # (a NULL-able double* may be passed as C_NULL :: Ptr{Cvoid})
+    "ptr_int": {"Ptr{Cint}"}, "ptr_long": {"Ptr{Clong}"},
+    "ptr_void": {"Ptr{Cvoid}"},
+    "ptr_ptr": {"Ptr{Ptr{Cvoid}}", "Ptr{Ptr{Cdouble}}", "Ptr{Ptr{Float64}}", "Ptr{Cvoid}"},
+}
+
+
+def header_prototypes():
+    txt = _strip_c_comments(open(os.path.join(ROOT, "include", "fpr.h")).read())
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z_0-9 \*]*?)\b(fpr_[A-Za-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+        ret, name, params = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())
+        ps = [] if params in ("", "void") else _split_top(params)
+        protos[name] = (_c_type_class(ret, True) if "*" not in ret else ("cstring" if "char" in ret else "ptr_void"),
+                        [_c_type_class(p) for p in ps], ps)
+    return protos
+
+
+def shim_ccalls():
+    """(name, return type, [argument types], number of values passed, line) of every ccall into libfpr."""
+    out = []
+    for m in re.finditer(r"ccall\(\(:(fpr_[A-Za-z0-9_]+),\s*(?:FPRHip\.)?libfpr\)", SHIM):
+        # the balanced argument list of this ccall
+        i = SHIM.index("(", m.start())
+        depth, j = 0, i
+        while True:
+            depth += SHIM[j] == "("
+            depth -= SHIM[j] == ")"
+            if depth == 0:
+                break
+            j += 1
+        body = re.sub(r"#[^\n]*", "", SHIM[i + 1:j])
+        parts = _split_top(body)
+        ret, types = parts[1], parts[2]
+        assert types.startswith("(") and types.endswith(")"), (m.group(1), types)
+        tl = [t for t in _split_top(types[1:-1]) if t]
+        vals = parts[3:]
+        splats = sum(v.endswith("...") for v in vals)           # `size(Ht)...`: as many values as the array has dimensions
+        out.append((m.group(1), ret, tl, (len(vals), splats), SHIM.count("\n", 0, m.start()) + 1))
+    return out
+
+
+def test_every_ccall_matches_its_prototype_in_the_header():
+    protos = header_prototypes()
+    calls = shim_ccalls()
+    assert len(protos) >= 77 and len(calls) >= 76
+    bound = set()
+    for name, ret, types, nvalues, line in calls:
+        assert name in protos, "FPRHip.jl:%d calls %s, which include/fpr.h does not declare" % (line, name)
+        pret, pclasses, pdecl = protos[name]
+        where = "FPRHip.jl:%d ccall(:%s)" % (line, name)
+        assert ret in JULIA_OK[pret], "%s returns %s, the header says %s" % (where, ret, pret)
+        assert len(types) == len(pclasses), "%s passes %d types, the prototype has %d parameters" % (where, len(types), len(pclasses))
+        nv, splats = nvalues
+        if splats == 0:
+            assert nv == len(types), "%s: %d types but %d values" % (where, len(types), nv)
+        else:       # a splatted size(...) stands for 2 or 3 Cint in a row
+            assert nv - splats + 2 * splats <= len(types) <= nv - splats + 3 * splats, "%s: %d types, %d values (%d splatted)" % (
+                where, len(types), nv, splats)
+        for k, (jt, pc) in enumerate(zip(types, pclasses)):
+            if pc == "ptr_any":
+                assert re.fullmatch(r"Ptr\{[A-Za-z0-9{}]+\}", jt), "%s: argument %d is %s, the header declares `%s`" % (where, k + 1, jt, pdecl[k])
+                continue
+            assert jt in JULIA_OK[pc], "%s: argument %d is %s, the header declares `%s`" % (where, k + 1, jt, pdecl[k])
+        bound.add(name)
+    # every compute entry point of the header is bound by at least one ccall (names in comments do not count)
+    missing = sorted(set(protos) - bound)
+    assert not missing, "declared in include/fpr.h but never ccall'ed by FPRHip.jl: %s" % missing
+
+
+def _julia_code_lines():
+    """The shim without comments, strings and docstrings (good enough for counting block keywords)."""
+    txt = re.sub(r'"""(?:.|\n)*?"""', '""', SHIM)
+    txt = re.sub(r'"(?:\\.|[^"\\\n])*"', '""', txt)
+    txt = re.sub(r"#=(?:.|\n)*?=#", "", txt)
+    txt = re.sub(r"#[^\n]*", "", txt)
+    return txt
+
+
+def julia_block_scan(txt):
+    """Token scan of Julia source (comments and strings already removed): returns the list of problems found -- an `end` without
+    an opener, a bracket closed by the wrong kind, openers left at the end.  `for` / `if` inside brackets are generators and
+    comprehensions (no `end`); `end` inside [] is an index."""
+    openers = {"function", "if", "for", "while", "let", "begin", "module", "baremodule", "macro", "quote", "try", "do", "struct"}
+    stack, problems = [], []
+    line = 1
+    prev = ""
+    for m in re.finditer(r"\n|[A-Za-z_\u00a0-\uffff][A-Za-z_0-9!\u00a0-\uffff]*|[()\[\]{}]|:(?=[A-Za-z_])|\S", txt):
+        t = m.group(0)
+        if t == "\n":
+            line += 1
+            continue
+        if t in "([{":
+            stack.append((t, line))
+        elif t in ")]}":
+            want = {")": "(", "]": "[", "}": "{"}[t]
+            if not stack or stack[-1][0] != want:
+                problems.append("line %d: `%s` closes %r" % (line, t, stack[-1] if stack else None))
+            else:
+                stack.pop()
+        elif prev == ":" or prev == ".":
+            pass                                            # :end, :if (quoted symbols), x.end
+        elif t in openers:
+            in_bracket = bool(stack) and stack[-1][0] in "([{"
+            if in_bracket and t in ("for", "if"):
+                pass                                        # generator / comprehension
+            elif t == "struct" and prev == "mutable":
+                stack.append((t, line))
+            else:
+                stack.append((t, line))
+        elif t == "end":
+            if any(k == "[" for k, _ in reversed(stack[-3:])) and stack and stack[-1][0] in "([":
+                pass                                        # a[end], a[(end - 1)]
+            elif not stack or stack[-1][0] in "([{":
+                problems.append("line %d: `end` inside %r" % (line, stack[-1] if stack else None))
+            else:
+                stack.pop()
+        prev = t
+    problems += ["%s opened at line %d never closed" % kv for kv in stack]
+    return problems
+
+
+def test_blocks_are_balanced():
+    assert julia_block_scan("function f(x)\n  if x > 0\n a[end] = [i for i in 1:3 if i > 1]\n end\nend\n") == []
+    assert julia_block_scan("function f(x)\n  if x > 0\n return 1\nend\n") != []          # (the scan does notice a missing end)
+    assert julia_block_scan("f(x) = (x,\n") != []
+    problems = julia_block_scan(_julia_code_lines())
+    assert not problems, "FPRHip.jl: " + "; ".join(problems[:5])
+
+
+def test_every_exported_name_is_defined():
+    exported = shim_exports()
+    defined = shim_defined() | {"@" + m for m in shim_macros()}
+    defined |= set(re.findall(r"^(?:mutable\s+)?struct\s+([A-Za-z_][A-Za-z_0-9]*)", SHIM, flags=re.M))
+    defined |= set(re.findall(r"^module\s+([A-Za-z_][A-Za-z_0-9]*)", SHIM, flags=re.M))
+    defined |= set(re.findall(r"^\s*@enum\s+([A-Za-z_][A-Za-z_0-9]*)", SHIM, flags=re.M))
+    for m in re.finditer(r"^\s*@enum\s+[A-Za-z_][A-Za-z_0-9]*\s+(.*)$", SHIM, flags=re.M):
+        defined |= set(re.findall(r"([A-Za-z_][A-Za-z_0-9]*)", m.group(1)))
+    defined |= set(re.findall(r"^([A-Za-z_][A-Za-z_0-9!]*)\s*=", SHIM, flags=re.M))
+    defined |= set(re.findall(r"^(?:@inline\s+)?function\s+([A-Za-z_][^\s(]*)", SHIM, flags=re.M))
+    defined |= set(re.findall(r"^(?:@inline\s+)?([A-Za-z_][A-Za-z_0-9!τ]*)\(", SHIM, flags=re.M))
+    missing = sorted(n for n in exported if n not in defined)
+    assert not missing, "exported by FPRHip.jl but not defined in it: %s" % missing

@@ -230,12 +230,13 @@ class Context:
         # allocations / fills / copies and the library's kernels are ordered on the same stream.
         torch.cuda.synchronize(device)
         self.compute = torch.cuda.Stream(device=device)
-        self.comm = torch.cuda.Stream(device=device)
-        self._comm0 = self.comm
+        self._comm0 = torch.cuda.Stream(device=device)
+        self._comm, self._comm_handle = self._comm0, None
+        self.h = None
         if not secondary:
             torch.cuda.set_stream(self.compute)
         h = _vp()
-        rc = self.L.fpr_ctx_create(C.byref(h), device, _vp(self.compute.cuda_stream), _vp(self.comm.cuda_stream))
+        rc = self.L.fpr_ctx_create(C.byref(h), device, _vp(self.compute.cuda_stream), _vp(self._comm0.cuda_stream))
         if rc != 0:
             raise FprError(rc, "fpr_ctx_create failed")
         self.h = h
@@ -255,19 +256,26 @@ class Context:
     def reserve_comm_cus(self, k):
         """fpr_reserve_comm_cus: the comm stream becomes a library-owned stream on k compute units (0: the torch stream
         given at creation again); self.comm follows, so torch work placed on it lands on the same stream."""
-        torch = _torch()
-        # the library may round a share up (asked 16, the probe found other units: 32): remember what was ASKED, or every pair
-        # would call in again and wrap the stream once more
-        if self.L.fpr_comm_cus(self.h) == int(k) or (k > 0 and getattr(self, "_comm_asked", 0) == int(k) and self.L.fpr_comm_cus(self.h) > 0):
-            return
+        # Always ask the library (it returns at once when nothing changes: it remembers what was ASKED, a share may be rounded up).
         self.call("fpr_reserve_comm_cus", int(k))
-        self._comm_asked = int(k)
-        if k > 0:
-            h = _vp()
-            self.call("fpr_stream_handle", 1, C.byref(h))
-            self.comm = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", self.device))
-        else:
-            self.comm = self._comm0
+
+    @property
+    def comm(self):
+        """The library's CURRENT comm stream as a torch stream (fpr_stream_handle(1)): the torch stream given at creation, or the
+        library-owned stream on the reserved compute units.  Looked up at every use -- the one-call pair
+        (fpr_diffusion3d_step2_halo) re-splits the device by itself, and a wrapped handle of a stream the library has destroyed
+        since must not survive here -- and re-wrapped only when the handle changed."""
+        if self.h is None or self._closed:
+            return self._comm0
+        h = _vp()
+        self.call("fpr_stream_handle", 1, C.byref(h))
+        if h.value == self._comm0.cuda_stream or not h.value:
+            self._comm, self._comm_handle = self._comm0, None
+        elif self._comm_handle != h.value:
+            torch = _torch()
+            self._comm = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", self.device))
+            self._comm_handle = h.value
+        return self._comm
 
     def set_option(self, key, value):
         self.call("fpr_set_option", key.encode(), int(value))

@@ -227,6 +227,8 @@ extern "C" int fpr_set_option(fpr_ctx* ctx, const char* key, long value)
 {
     if (!ctx || !key) return FPR_ERR_INVALID;
     ctx->options[key] = value;
+    // asking for the persistent Jacobi coarse solve again lifts the switch a timed-out hand-off left behind (multigrid2d.hip)
+    if (value != 0 && std::string(key) == "mg_jacobi_persist") ctx->jacp_resident = -1;
     return FPR_OK;
 }
 

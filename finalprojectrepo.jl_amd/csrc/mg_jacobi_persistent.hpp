@@ -224,7 +224,8 @@ __global__ __launch_bounds__(256) void k_jacobi_check_groups(FprSolveState* st, 
         if (lane == 0) {
             *counter = 0;
             if (abort_flag && *abort_flag) {
-                st->done = -1;            // a wait timed out: the host gives up on this form
+                st->done = -1;            // a wait timed out: the host gives up on this form and resumes from this launch's input
+                st->group = group0;       // (st->iters counts the sweeps of the launches before it)
             } else if (first >= 0) {
                 st->iters += first + 1;
                 st->last_rms = rms_last;

@@ -484,6 +484,14 @@ __global__ __launch_bounds__(256) void k_bc_neumann(double* __restrict__ T, int 
 }
 
 // ---- coarse-solver state kernels -------------------------------------------------------------------
+// behind a persistent Jacobi launch that gave up: the solve goes on (iters and thresh stay)
+__global__ void k_state_resume(FprSolveState* st)
+{
+    st->done = 0;
+    st->redo = 0;
+    st->group = -1;
+}
+
 // thresh = tol * sqrt(sumsq/N)   (multigrid.jl:150)  /  tol * sqrt(sumsq)   (krylov.jl:57-58)
 __global__ void k_state_init(FprSolveState* st, const double* sumsq, double tol, double N, int cg)
 {
@@ -1269,6 +1277,7 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             int Sg = (int)fpr_opt(ctx, "mg_group_sweeps", S);  // sweeps per launch (<= S; tuning/diagnostic knob)
             if (Sg < 1 || Sg > S) Sg = S;
             const int groups = (iters + Sg - 1) / Sg;
+            int g_resume = 0;          // the plain loop below starts at this group (> 0: behind a persistent launch that gave up)
             // ---- the persistent form: launches of up to 16 groups of 8 sweeps with neighbour-to-neighbour hand-offs inside
             //      (mg_jacobi_persistent.hpp); the plain form below stays for A/B, for grids it does not fit and as the replay ----
             if (patch && PS == 8 && Sg == 8 && fpr_opt(ctx, "mg_jacobi_persist", 1) != 0 && (size_t)N * 8 < 0x7fffffffu) {
@@ -1309,6 +1318,8 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                         a.nsw_last = (gdone + G == groups) ? iters - (groups - 1) * 8 : 8;
                         a.partials = ctx->partials; a.flags = flags; a.abort_flag = abort_flag; a.state = ctx->state;
                         a.g0 = gdone;
+                        if ((long)recs.size() + 1 == fpr_opt(ctx, "mg_jacobi_persist_test_abort", 0))      // (test hook: this launch "times out")
+                            FPR_HIP(ctx, hipMemsetAsync(abort_flag, 1, 1, s));
                         const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_PATCH, s);
                         k_jacobi_persist<8, PP><<<gm, (PP / 2) * (PP / 2), 0, s>>>(a);
                         fpr_ktimer_end(ctx, timed, s);
@@ -1324,8 +1335,32 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                             if (ctx->state_h->done) break;
                         }
                     }
-                    if (ctx->state_h->done < 0)
-                        return fpr_fail(ctx, FPR_ERR_HIP, "k_jacobi_persist: a neighbour hand-off timed out (is the card shared?); set option mg_jacobi_persist = 0");
+                    if (ctx->state_h->done < 0) {
+                        // A neighbour hand-off timed out (workgroups not resident together: a shared card, a long kernel of another
+                        // context).  Launches enqueued behind the one that gave up returned at once, and a launch never writes its
+                        // input: that input is the field after `g0` groups.  Resume there with the plain launches (one per 8 sweeps),
+                        // and keep this context off the persistent form from now on (as cg! does: cg_persistent_timeouts).
+                        const Rec* r = nullptr;
+                        for (const Rec& q : recs) if (q.g0 == ctx->state_h->group) r = &q;
+                        if (!r) return fpr_fail(ctx, FPR_ERR_HIP, "k_jacobi_persist: a neighbour hand-off timed out and the launch that gave up is unknown");
+                        ctx->jacp_resident = 0;
+                        ctx->options["mg_jacobi_persist_timeouts"] = fpr_opt(ctx, "mg_jacobi_persist_timeouts", 0) + 1;
+                        FPR_HIP(ctx, hipMemsetAsync(flags, 0, 2048 * sizeof(int), s));
+                        double* want = (r->g0 & 1) ? L.tmp : u;       // the plain loop reads group gi from u (even) / L.tmp (odd)
+                        if (B[r->x] != want) {
+                            double* via = B[r->x];
+                            if (via == u || via == L.tmp) {          // (the two may not be copied onto each other's partner directly: same buffers are fine, but keep it simple)
+                                FPR_HIP(ctx, hipMemcpyAsync(w.r, via, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+                                via = w.r;
+                            }
+                            FPR_HIP(ctx, hipMemcpyAsync(want, via, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+                        }
+                        k_state_resume<<<1, 1, 0, s>>>(ctx->state);
+                        FPR_CHECK_LAUNCH(ctx);
+                        ctx->state_h->done = 0;
+                        g_resume = r->g0;
+                        goto plain_jacobi_groups;
+                    }
                     double* result = B[cur];
                     if (ctx->state_h->done) {
                         // the criterion was met inside launch `r`: launches behind it returned at once; replay the exact number of sweeps
@@ -1353,9 +1388,10 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                     return FPR_OK;
                 }
             }
-            double* a = u;
-            double* b = L.tmp;
-            int gdone = 0;
+        plain_jacobi_groups:
+            double* a = (g_resume & 1) ? L.tmp : u;
+            double* b = (g_resume & 1) ? u : L.tmp;
+            int gdone = g_resume;
             int chunk_groups = 8;
             if ((size_t)nblk * S * 2 > (size_t)FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
             while (gdone < groups) {

@@ -455,6 +455,49 @@ def test_coarse_jacobi_persistent_launches_equal_the_plain_ones(fpr, oracle, tol
     assert it_ref > 0
 
 
+@pytest.mark.parametrize("tol,abort_launch", [(1e-9, 1), (1e-9, 2), (1e-9, 4), (0.02, 1), (0.02, 3)])
+def test_coarse_jacobi_persistent_launch_that_gives_up_is_resumed_by_the_plain_ones(fpr, oracle, tol, abort_launch):
+    """A neighbour hand-off of k_jacobi_persist that times out (workgroups not resident together: a shared card) must not fail the
+    solve: the launch that gave up never wrote its input, so the solve resumes there with one launch per 8 sweeps, the context
+    stays off the persistent form and counts the event (option mg_jacobi_persist_timeouts), and the result is the oracle's bit for
+    bit.  The time-out is injected (option mg_jacobi_persist_test_abort = n: the n-th launch of the solve finds the abort flag
+    set) in the first launch, in a later one (whose input is one of the rotating work buffers) and behind the exit."""
+    F, mg = fpr, fpr.multigrid
+    shape = (257, 129)
+    u0, f = rnd(shape, 61), rnd(shape, 62)
+    f[0, :] = f[-1, :] = 0.0
+    f[:, 0] = f[:, -1] = 0.0
+    h = 1.0 / 128
+    u_ref = u0.copy(order="F")
+    r_ref = oracle.vcycle2d(u_ref, f, h, 0.0, tol, 257, 0, False)
+    it_ref = oracle.last_coarse_iters()
+    c = F.ctx()
+    c.set_option("mg_jacobi_persist", 1)
+    before = c.L.fpr_get_option(c.h, b"mg_jacobi_persist_timeouts")
+    launches_needed = -(-it_ref // 256)
+    try:
+        c.set_option("mg_jacobi_persist_test_abort", abort_launch)
+        gu = F.asdevice(u0)
+        r = mg.Vcycle_2DPoisson_(gu, F.asdevice(f), h, 0.0, tol, 257, mg.jacobi, mg.parallel_shmem, False)
+        it = c.L.fpr_last_coarse_iters(c.h)
+        c.set_option("mg_jacobi_persist_test_abort", 0)
+        after = c.L.fpr_get_option(c.h, b"mg_jacobi_persist_timeouts")
+        # a second solve on the same context: the plain form now (the switch is sticky), same result
+        gu2 = F.asdevice(u0)
+        r2 = mg.Vcycle_2DPoisson_(gu2, F.asdevice(f), h, 0.0, tol, 257, mg.jacobi, mg.parallel_shmem, False)
+    finally:
+        c.set_option("mg_jacobi_persist_test_abort", 0)
+        c.set_option("mg_jacobi_persist", 1)           # lifts the switch again
+    assert abs(r - r_ref) <= 1e-12 * abs(r_ref) and r2 == r
+    assert np.array_equal(F.tonumpy(gu), u_ref) and np.array_equal(F.tonumpy(gu2), u_ref)
+    assert it == it_ref
+    # the injected launch exists only if the solve got that far (the host polls after 1, 2, 4, ... launches)
+    if abort_launch <= launches_needed:
+        assert after == before + 1
+    else:
+        assert after in (before, before + 1)
+
+
 def torch_isnan(a):
     import torch
 

@@ -129,6 +129,8 @@ def hoist_scalars(out, placement, unplaced):
     c["placement_trial_ms_best"] = placement.get("trial_ms_best")
     c["placement_trial_ms_first"] = placement.get("trial_ms_first")
     c["placement_trial_ms_worst"] = placement.get("trial_ms_worst")
+    c["placement_trial_ms_plain"] = placement.get("trial_ms_plain_allocation")
+    c["placement_kept_plain"] = (placement.get("chosen") == [0, 1, 2, 3, 4]) if placement.get("chosen") else None
     c["pool_fastest_pair_GBs"] = g(placement, "pair_copy_GBs_all", "fastest")
     c["pool_slowest_pair_GBs"] = g(placement, "pair_copy_GBs_all", "slowest")
     c["chosen_slowest_pair_GBs"] = g(placement, "pair_copy_GBs_chosen", "slowest")
@@ -154,6 +156,10 @@ def hoist_scalars(out, placement, unplaced):
     c["steady_single_ms_per_iteration"] = g(pp, "single_steps", "ms_per_iteration")
     c["single_kernel_ms"] = g(out, "roofline_single", "kernel_ms")
     c["single_frac"] = g(out, "roofline_single", "frac")
+    c["fma_kernel_ms"] = g(out, "legs", "fused_pairs_fma", "kernel_ms")
+    c["fma_steady_ms_per_iteration"] = g(out, "legs", "fused_pairs_fma", "steady_ms_per_iteration")
+    c["fma_steady_power_W"] = g(out, "legs", "fused_pairs_fma", "steady_power_W")
+    c["fma_steady_sclk_MHz"] = g(out, "legs", "fused_pairs_fma", "steady_sclk_MHz")
     c["fused_no_residual_kernel_ms"] = g(out, "legs", "fused_pairs_no_residual_store", "kernel_ms")
     c["proj_eff_z_slabs"] = g(out, "legs", "fused_pairs_as_interior_rank_of_z_slabs", "projected_weak_scaling_efficiency_z_slabs")
     c["proj_eff_2x2x2"] = g(out, "legs", "fused_pairs_as_rank_of_2x2x2", "projected_weak_scaling_efficiency_2x2x2")
@@ -346,6 +352,7 @@ def main():
     else:
         # What a host that simply allocates gets (the reference's `@zeros`): the first five allocations of this process, timed once
         # with the fused kernel in steady state (about 0.25 s, outside every timed region) -- reported beside the placed number.
+        plain = None
         if world == 1:
             try:
                 plain = [F.fzeros(*nloc) for _ in range(5)]
@@ -353,9 +360,8 @@ def main():
                 unplaced.update({"kernel_ms": ms, "launches": 100,
                                  "note": "k_diff3_march2 on the first five plain allocations of the process (no pool, no search), "
                                          "100 launches behind 200 of warm-up, torch events"})
-                del plain
-                torch.cuda.empty_cache()
             except Exception as e:
+                plain = None
                 unplaced["error"] = repr(e)
         # streamed together at equal offsets: (Ht, field read), (field written, residual) -- the field alternates between Hτ and Hτ3.
         # A trial = a few fused pairs on the candidate arrays (zeros: the arithmetic does not depend on the values), timed by events.
@@ -377,8 +383,10 @@ def main():
             return e0.elapsed_time(e1) / 12.0
 
         try:
+            # (the plain five are the first candidates: the search keeps them unless an assignment from the pool is faster)
             Ht, Hτ, Hτ3, res, Hτ2 = F.placement.alloc_fields(5, *nloc, report=placement, pairs=[(0, 1), (0, 2), (2, 3), (1, 3), (1, 2)],
-                                                          trial=trial)
+                                                          trial=trial, first=plain)
+            del plain
         except Exception as e:       # the search is an optimisation: plainly allocated arrays give the same results
             torch.cuda.empty_cache()
             Ht, Hτ, Hτ3, res, Hτ2 = (F.fzeros(*nloc) for _ in range(5))
@@ -714,6 +722,34 @@ def main():
             out["power_probe"] = legs_mod.power_probe(torch, device_index, lambda k: run(k, 0, True), lambda k: run(k, 0, False), reset_state)
         except Exception as e:
             out["power_probe"] = {"error": repr(e)}
+        # Leg `fused_pairs_fma` (opt-in option fp_contract = 1: "(or 1 * fma)", part1_kernel_programming.jl:55,94; SURVEY 7's speed
+        # variant): the same pairs with the contracted point update -- 18 instead of 25 FP64 instructions per cell and iteration,
+        # results within 1e-12 of the exact path (tests/test_gpu_part1.py), NOT bit-identical to the reference, so never part of
+        # `value`.  Event time of K timed pairs, then a second under the power sampler.
+        try:
+            ctx.set_option("fp_contract", 1)
+            reset_state()
+            run(W + (W & 1) + 8, 0, True)
+            barrier()
+            ctx.call("fpr_kernel_timer", 1)
+            t0 = time.perf_counter()
+            run(K + (K & 1), 0, True)
+            barrier()
+            e5 = time.perf_counter() - t0
+            ms5, cnt5 = timer_read(ctx, KT_STEP2)
+            ctx.call("fpr_kernel_timer", 0)
+            k5 = ms5 / max(cnt5, 1)
+            pr = legs_mod.probe_under_load(torch, device_index, lambda k: run(k, 0, True))
+            legs["fused_pairs_fma"] = {
+                "ms_per_step": e5 / (K + (K & 1)) * 1e3, "value_GBs": A_EFF_BYTES * cells * (K + (K & 1)) / e5 / 1e9, "kernel_ms": k5, "launches": cnt5,
+                "achieved": min_bytes / (k5 * 1e-3) / 1e9 if k5 > 0 else 0.0, "frac": min_bytes / (k5 * 1e-3) / 1e9 / HBM_PEAK_GBS if k5 > 0 else 0.0,
+                "steady_ms_per_iteration": pr["ms_per_iteration"], "steady_sclk_MHz": pr["sclk_MHz_avg"], "steady_power_W": pr["power_W_avg"],
+                "note": "option fp_contract = 1: explicit fma sequence in the point update (18 instead of 25 FP64 instructions per cell and "
+                        "iteration); within 1e-12 of the exact path, bit for bit the oracle's fma restatement; opt-in, not part of `value`"}
+        except Exception as e:
+            legs["fused_pairs_fma"] = {"error": repr(e)}
+        finally:
+            ctx.set_option("fp_contract", 0)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             try:

@@ -510,45 +510,48 @@ def golden_norms(F, torch, args):
 
 
 
+def probe_under_load(torch, device_index, fn, seconds=1.0):
+    """`fn(k)` (k pseudo-iterations of some kernel) back to back for about `seconds` while a host thread reads librocm_smi64 every
+    20 ms: ms per iteration, clocks and power under that load (first third of the samples dropped: the ramp)."""
+    import threading
+
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            d = device_state(device_index)
+            samples.append((d.get("sclk_MHz"), d.get("power_W"), d.get("fclk_MHz"), d.get("mclk_MHz"), d.get("temp_junction_C")))
+            stop.wait(0.02)
+
+    fn(16)
+    torch.cuda.synchronize()
+    th = threading.Thread(target=sampler, daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        fn(32)
+        torch.cuda.synchronize()
+        n += 32
+    dt = time.perf_counter() - t0
+    stop.set()
+    th.join(2.0)
+    late = samples[len(samples) // 3:] or samples
+    avg = lambda k: (sum(x[k] for x in late if x[k] is not None) / max(sum(1 for x in late if x[k] is not None), 1)) if late else None
+    mn = lambda k: min((x[k] for x in late if x[k] is not None), default=None)
+    return {"ms_per_iteration": dt / n * 1e3, "iterations": n, "samples": len(samples), "sclk_MHz_avg": avg(0), "sclk_MHz_min": mn(0),
+            "power_W_avg": avg(1), "fclk_MHz_avg": avg(2), "mclk_MHz_avg": avg(3), "temp_junction_C_avg": avg(4)}
+
+
 def power_probe(torch, device_index, fused_n, single_n, reset_state, seconds=1.0):
     """Clocks and power UNDER each diffusion kernel (a diagnostic outside every timed region): the same launches for about a second
     each while a host thread reads librocm_smi64 every 20 ms.  The fused kernel does twice the FP64 work per byte of the one-iteration
     kernel; whether the card holds its clocks under that load is what separates a slow box from a slow kernel.  `fused_n(k)` /
     `single_n(k)` run k pseudo-iterations; `reset_state()` puts the field state back to an even buffer between the two."""
-    import threading
-
-    def probe(fn):
-        samples, stop = [], threading.Event()
-
-        def sampler():
-            while not stop.is_set():
-                d = device_state(device_index)
-                samples.append((d.get("sclk_MHz"), d.get("power_W"), d.get("fclk_MHz"), d.get("mclk_MHz"), d.get("temp_junction_C")))
-                stop.wait(0.02)
-
-        fn(16)
-        torch.cuda.synchronize()
-        th = threading.Thread(target=sampler, daemon=True)
-        t0 = time.perf_counter()
-        th.start()
-        n = 0
-        while time.perf_counter() - t0 < seconds:
-            fn(32)
-            torch.cuda.synchronize()
-            n += 32
-        dt = time.perf_counter() - t0
-        stop.set()
-        th.join(2.0)
-        late = samples[len(samples) // 3:] or samples     # the first third is the ramp
-        avg = lambda k: (sum(x[k] for x in late if x[k] is not None) / max(sum(1 for x in late if x[k] is not None), 1)) if late else None
-        mn = lambda k: min((x[k] for x in late if x[k] is not None), default=None)
-        return {"ms_per_iteration": dt / n * 1e3, "iterations": n, "samples": len(samples), "sclk_MHz_avg": avg(0), "sclk_MHz_min": mn(0),
-                "power_W_avg": avg(1), "fclk_MHz_avg": avg(2), "mclk_MHz_avg": avg(3), "temp_junction_C_avg": avg(4)}
-
     reset_state()
-    pp = {"fused_pairs": probe(fused_n)}
+    pp = {"fused_pairs": probe_under_load(torch, device_index, fused_n, seconds)}
     reset_state()
-    pp["single_steps"] = probe(single_n)
+    pp["single_steps"] = probe_under_load(torch, device_index, single_n, seconds)
     pp["idle"] = device_state(device_index)
     pp["note"] = ("about one second of back-to-back launches per kernel, librocm_smi64 read every 20 ms by a host thread (first third dropped); "
                   "not part of any timed region")

@@ -34,6 +34,9 @@ static int diff3_run(fpr_ctx* ctx, const double* Ht, const double* Htau, double*
     a.dtau = dtau; a._dt = _dt; a._dx = _dx; a._dy = _dy; a._dz = _dz;
     a.D_dx = D_dx; a.D_dy = D_dy; a.D_dz = D_dz;
     a.scale = scale;
+    // option fp_contract = 1 (opt-in, default 0): the contracted form of the point update for launches over the WHOLE interior on the
+    // compute stream (single-rank runs); boxes of a decomposed run stay exact, so that shell and core agree bit for bit
+    a.fma = (!lo && !hi && stream_sel == 0 && fpr_opt(ctx, "fp_contract", 0) != 0) ? 1 : 0;
     a.partials = stream_sel == 1 ? ctx->partials2 : ctx->partials;
     const bool empty = a.lo[0] >= a.hi[0] || a.lo[1] >= a.hi[1] || a.lo[2] >= a.hi[2];
     int nparts = 0;
@@ -137,6 +140,7 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
     a.dtau = dtau; a._dt = _dt; a._dx = _dx; a._dy = _dy; a._dz = _dz;
     a.D_dx = D_dx; a.D_dy = D_dy; a.D_dz = D_dz;
     a.scale = scale;
+    a.fma = (!lo && !hi && stream_sel == 0 && reserve_cus == 0 && zhi2 <= zlo2 && fpr_opt(ctx, "fp_contract", 0) != 0) ? 1 : 0;   // as diff3_run
     double* base = stream_sel == 1 ? ctx->partials2 : ctx->partials;
     const bool is_core = reserve_cus > 0 || stream_sel == 2;   // fpr_diffusion3d_step2_core (kernel timer kind)
     // a launch on the core stream of a split device (fpr_reserve_comm_cus) has that many units less, whatever the caller says

@@ -90,6 +90,7 @@ struct Diff3Args2 {
     int xalign;                     // 1: x-tile cut points sit in the middle of 128-byte lines
     int zb_lo, zb_hi, ntz_a;        // optional second z-range [zb_lo, zb_hi) with the same x/y box: chunks tz >= ntz_a
     int xcd_remap;
+    int fma = 0;                    // 1: the contracted form of diff3_point (option fp_contract; plain grids of 4 or 8 waves only)
     // reserved form (k_diff3_march2<..., BAL = true>; decomposed runs that leave compute units to the halo exchange): the
     // launch has G = gridDim.x workgroups where the plain grid has G + bal_r (tile, chunk) units.  Workgroup g first serves
     // unit g like the plain grid (same tiles marching in lockstep, same block -> XCD mapping), then a slice of bal_q planes
@@ -213,7 +214,7 @@ __device__ __forceinline__ double diff3_block_sum_waves(double v, double* red, i
 // BAL = true: the grid is SHORT of the plain (tile, chunk) grid by a few units (device slots minus the compute units left
 // to RCCL and the shell launches of a decomposed run); every workgroup serves its own unit and then a thin slice of one of
 // the left-over units, so the launch still finishes in one balanced round and its tiles still march in lockstep.
-template <bool NORM, int NW = 4, bool WRES = true, bool BAL = false>
+template <bool NORM, int NW = 4, bool WRES = true, bool BAL = false, bool FMA = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_diff3_march2(Diff3Args2 a)
 {
     // NW = 1: ONE wave per workgroup, a 128 x 4 tile whose first or last row is a y-boundary (or y-halo) row -- the
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_diff3_march2(Diff3
                     const double xp = (v == VX - 1) ? xrL : cR[r].v[v == VX - 1 ? v : v + 1];
                     const double ym = (r == 0) ? yd0.v[v] : cR[r == 0 ? 0 : r - 1].v[v];
                     const double yp = (r == RY - 1) ? yu0.v[v] : cR[r == RY - 1 ? r : r + 1].v[v];
-                    r1[v] = diff3_point(cR[r].v[v], xm, xp, ym, yp, zmR[r].v[v], zpR[r].v[v],
+                    r1[v] = diff3_point<FMA>(cR[r].v[v], xm, xp, ym, yp, zmR[r].v[v], zpR[r].v[v],
                                         HT[(S + 1) % NR][r].v[v], cf, Qn[r].v[v]);
                 }
                 if constexpr (NORM) {
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_diff3_march2(Diff3
                     const double xp = (v == VX - 1) ? fromR : Qc[r].v[v == VX - 1 ? v : v + 1];
                     const double ym = (r == 0) ? yd1.v[v] : Qc[r == 0 ? 0 : r - 1].v[v];
                     const double yp = (r == RY - 1) ? yu1.v[v] : Qc[r == RY - 1 ? r : r + 1].v[v];
-                    res[v] = diff3_point(Qc[r].v[v], xm, xp, ym, yp, Qm[r].v[v], Qn[r].v[v], HT[S % NR][r].v[v], cf, h2[v]);
+                    res[v] = diff3_point<FMA>(Qc[r].v[v], xm, xp, ym, yp, Qm[r].v[v], Qn[r].v[v], HT[S % NR][r].v[v], cf, h2[v]);
                 }
                 const int sor = (rm[r] && !DIFF3_DBG(a, 1)) ? so + r * rs : (int)OOR;   // rows the block does not own: dropped by the range check
                 // lanes that own one cell of their pair (first / last owned cell of an odd-aligned range)
@@ -803,6 +804,27 @@ static inline hipError_t diff3_launch2(Diff3Args2 a, bool norm, int zc_opt, int 
             if (bal_info) *bal_info = r * 1000000 + (long)a.bal_sp * 1000 + a.bal_q;
             return hipGetLastError();
         }
+    }
+    if (a.fma) {      // opt-in contracted arithmetic: the plain grid only (the reserved / one-wave forms above stay exact)
+        if (a.nw == 8) {
+            if (wres) {
+                if (norm) k_diff3_march2<true, 8, true, false, true><<<(int)nblk, 512, 0, stream>>>(a);
+                else k_diff3_march2<false, 8, true, false, true><<<(int)nblk, 512, 0, stream>>>(a);
+            } else {
+                if (norm) k_diff3_march2<true, 8, false, false, true><<<(int)nblk, 512, 0, stream>>>(a);
+                else k_diff3_march2<false, 8, false, false, true><<<(int)nblk, 512, 0, stream>>>(a);
+            }
+        } else {
+            if (wres) {
+                if (norm) k_diff3_march2<true, 4, true, false, true><<<(int)nblk, 256, 0, stream>>>(a);
+                else k_diff3_march2<false, 4, true, false, true><<<(int)nblk, 256, 0, stream>>>(a);
+            } else {
+                if (norm) k_diff3_march2<true, 4, false, false, true><<<(int)nblk, 256, 0, stream>>>(a);
+                else k_diff3_march2<false, 4, false, false, true><<<(int)nblk, 256, 0, stream>>>(a);
+            }
+        }
+        *nparts = (int)nblk;
+        return hipGetLastError();
     }
     if (a.nw == 8) {
         if (wres) {

@@ -25,15 +25,34 @@ struct Diff3Args {
     int zc;             // planes per z-chunk (marching kernels)
     int ntx, nty, ntz;  // tile counts (marching kernels)
     int xcd_remap;      // 1: give each XCD a contiguous range of tiles
+    int fma = 0;        // 1: the contracted form of diff3_point where an instantiation exists (option fp_contract)
 };
 
 struct Diff3Coef {
     double dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz;
 };
 
+// FMA = false (the default and the only form parity claims are made for): every operation rounds as the reference's expression
+// does on a CPU (the library is built with -ffp-contract=off).  FMA = true (option fp_contract = 1, opt-in): the contraction the
+// reference itself notes -- "(or 1 * fma)", part1_kernel_programming.jl:55,94 -- written out, so that it is the SAME sequence on
+// every compiler and in the oracle's orc_diffusion3d_step_fma: 18 instead of 25 FP64 instructions per cell and iteration, results
+// within 1e-12 relative of the exact form (tests/test_gpu_part1.py).
+template <bool FMA = false>
 __device__ __forceinline__ double diff3_point(double h, double xm, double xp, double ym, double yp, double zm,
                                               double zp, double ht, const Diff3Coef& c, double& h2)
 {
+    if constexpr (FMA) {
+        const double qxm = -c.D_dx * (h - xm), qym = -c.D_dy * (h - ym), qzm = -c.D_dz * (h - zm);
+        const double fx = __builtin_fma(-c.D_dx, xp - h, -qxm);      // qxp - qxm
+        const double fy = __builtin_fma(-c.D_dy, yp - h, -qym);
+        const double fz = __builtin_fma(-c.D_dz, zp - h, -qzm);
+        double r = fx * c._dx;
+        r = __builtin_fma(fy, c._dy, r);
+        r = __builtin_fma(fz, c._dz, r);
+        r = __builtin_fma(h - ht, c._dt, r);
+        h2 = __builtin_fma(-c.dtau, r, h);
+        return r;
+    }
     const double qxp = -c.D_dx * (xp - h), qxm = -c.D_dx * (h - xm);
     const double qyp = -c.D_dy * (yp - h), qym = -c.D_dy * (h - ym);
     const double qzp = -c.D_dz * (zp - h), qzm = -c.D_dz * (h - zm);
@@ -162,7 +181,7 @@ __device__ __forceinline__ DVec<VX> diff3_ldv(const double* __restrict__ p)
 // plane k-1 occupied, and stay in flight for two full iterations -- across the LDS barrier as well.
 // (With PIPE = false the rotation `zm=c; c=zp; zp=zpp` and the merge of the LDS / global halo rows make
 // hipcc wait for the just-issued loads: `s_waitcnt vmcnt(0)` once per plane.)
-template <int VX, int RY, bool NORM, bool LDSY, bool NT, bool PIPE = false>
+template <int VX, int RY, bool NORM, bool LDSY, bool NT, bool PIPE = false, bool FMA = false>
 __global__ __launch_bounds__(256) void k_diff3_march(Diff3Args a)
 {
     constexpr int TXW = 64 * VX;  // tile width in cells
@@ -321,7 +340,7 @@ __global__ __launch_bounds__(256) void k_diff3_march(Diff3Args a)
                     const double xp = (v == VX - 1) ? xrL : cR[r].v[v == VX - 1 ? v : v + 1];
                     const double ym = (r == 0) ? ydv.v[v] : cR[r == 0 ? 0 : r - 1].v[v];
                     const double yp = (r == RY - 1) ? yuv.v[v] : cR[r == RY - 1 ? r : r + 1].v[v];
-                    res[r][v] = diff3_point(cR[r].v[v], xm, xp, ym, yp, zmR[r].v[v], zpR[r].v[v], HT[hsl][r].v[v], cf, h2[r][v]);
+                    res[r][v] = diff3_point<FMA>(cR[r].v[v], xm, xp, ym, yp, zmR[r].v[v], zpR[r].v[v], HT[hsl][r].v[v], cf, h2[r][v]);
                 }
             }
             // plane k-1, and the halo rows / Ht of plane k, are dead now: refill them (planes k+3 and k+2)
@@ -444,7 +463,7 @@ __global__ __launch_bounds__(256) void k_diff3_march(Diff3Args a)
                 const double xp = (v == VX - 1) ? xrL : c[r].v[v + 1];
                 const double ym = (r == 0) ? ydc.v[v] : c[r == 0 ? 0 : r - 1].v[v];
                 const double yp = (r == RY - 1) ? yuc.v[v] : c[r == RY - 1 ? r : r + 1].v[v];
-                res[v] = diff3_point(c[r].v[v], xm, xp, ym, yp, zm[r].v[v], zp[r].v[v], htc[r].v[v], cf, h2[v]);
+                res[v] = diff3_point<FMA>(c[r].v[v], xm, xp, ym, yp, zm[r].v[v], zp[r].v[v], htc[r].v[v], cf, h2[v]);
             }
             if (rm[r]) {
                 const size_t id = (size_t)ib + sy * (size_t)(j0 + r) + sz * (size_t)k;

@@ -120,7 +120,12 @@ static inline hipError_t diff3_launch(Diff3Args a, bool norm, const Diff3Tuning&
         if (!ldsy || a.xcd_remap > 6 || nby % (8 * G) != 0) a.xcd_remap = 0;
     }
     const bool nt = t.nt < 0 ? DIFF3_DEFAULT_NT : (t.nt != 0);
-    if (pipe && vx == 2 && (ry == 4 || ry == 2)) {
+    if (a.fma && pipe && vx == 2 && ry == 4 && ldsy && nt) {
+        // opt-in contracted arithmetic (option fp_contract): instantiated for the default form of the march only; every other
+        // geometry runs the exact kernel below
+        if (norm) k_diff3_march<2, 4, true, true, true, true, true><<<(int)nblk, 256, 0, stream>>>(a);
+        else k_diff3_march<2, 4, false, true, true, true, true><<<(int)nblk, 256, 0, stream>>>(a);
+    } else if (pipe && vx == 2 && (ry == 4 || ry == 2)) {
         if (ry == 4) diff3_pipe_go<4>(a, norm, ldsy, nt, (int)nblk, stream);
         else diff3_pipe_go<2>(a, norm, ldsy, nt, (int)nblk, stream);
     } else if (vx == 2) {

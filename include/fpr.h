@@ -377,6 +377,42 @@ int fpr_mg_arena_provide(fpr_ctx* ctx, int nx, int ny, double* tmp, double* tmp2
  * (NULL x 3 = the library's own again).  Contents need no initialisation; results do not depend on who owns the buffers. */
 int fpr_mg_arena_provide_coarse(fpr_ctx* ctx, int nx, int ny, double* res_c, double* corr_c, double* corr_c2);
 
+/* ---- placement of field arrays ------------------------------------------------------------
+ * The role of the reference's `@zeros` allocations (part1_kernel_programming.jl:145-160, multigrid.jl:25-38 prealloc_dict): the HOST
+ * owns its arrays; on MI355X which physical pages an allocation received decides how fast kernels run that stream several arrays at
+ * equal offsets (fpr_diffusion3d_step2: 0.76 against 0.85-0.91 ms at 512^3).  fpr_placement_rank picks, among `k` candidate
+ * allocations of `n` doubles each that the caller made (and keeps: nothing is allocated or freed here), the `count` the caller
+ * should use for array positions 0 .. count-1: it times a copy between every pair of candidates, ranks the assignments by their
+ * slowest streamed-together pair (`pairs`: 2 * npairs position indices; npairs = 0: every pair of positions), and -- when `trial`
+ * is given -- times the caller's own kernel on the candidates as given (cand[0 .. count-1], what a host that simply allocates
+ * would use), on the best-ranked assignments and through a short local search, and keeps the fastest.
+ *   trial(user, chosen, count) -> ms of the caller's kernel on arrays cand[chosen[0]], ..., cand[chosen[count-1]]; <= 0: cannot judge
+ *   chosen_out[count]: index into cand for every position;  report[FPR_PLACE_REPORT_LEN]: what was measured (indices below)
+ * Contents of the candidates are overwritten by the copies.  Options (fpr_set_option) with their measured defaults: place_trials [4]
+ * best-ranked assignments tried, place_gain_pct_x10 [5] a swap is kept when 0.5 % faster, place_extend_below_GBs [5050] and
+ * place_spread_pct_x10 [25]: report[FPR_PLACE_WANT_MORE] = 1 when every pair of the pool copies below that rate, 2 when the
+ * trial sees less than 2.5 % between any two assignments -- the pool is of one class and the caller may allocate more candidates
+ * and call again; place_copy_reps [2]; place_try_identity [1]. */
+typedef double (*fpr_place_trial_fn)(void* user, const int* chosen, int count);
+enum {
+    FPR_PLACE_POOL_FASTEST_GBS = 0,   /* fastest / median / slowest pair of the pool, GB/s (read + write)  */
+    FPR_PLACE_POOL_MEDIAN_GBS = 1,
+    FPR_PLACE_POOL_SLOWEST_GBS = 2,
+    FPR_PLACE_CHOSEN_SLOWEST_GBS = 3, /* slowest / mean streamed-together pair of the assignment kept    */
+    FPR_PLACE_CHOSEN_MEAN_GBS = 4,
+    FPR_PLACE_TRIALS = 5,             /* trial() calls that returned a time                                */
+    FPR_PLACE_TRIAL_BEST_MS = 6,      /* the assignment kept                                               */
+    FPR_PLACE_TRIAL_FIRST_MS = 7,     /* the first trial (the candidates as given when place_try_identity) */
+    FPR_PLACE_TRIAL_WORST_MS = 8,
+    FPR_PLACE_TRIAL_IDENTITY_MS = 9,  /* cand[0 .. count-1] as given: a host that simply allocates        */
+    FPR_PLACE_TRIAL_SPREAD = 10,      /* worst / best - 1 over all trials                                  */
+    FPR_PLACE_WANT_MORE = 11,         /* 0, 1 (pair copies uniform) or 2 (trials uniform)                  */
+    FPR_PLACE_SEARCH_NODES = 12,
+    FPR_PLACE_REPORT_LEN = 16
+};
+int fpr_placement_rank(fpr_ctx* ctx, double* const* cand, int k, size_t n, int count, const int* pairs, int npairs,
+                       fpr_place_trial_fn trial, void* user, int* chosen_out, double* report);
+
 /* coarse-solver iterations spent by the last fpr_vcycle2d / fpr_mgsolve2d call (diagnostics) */
 long fpr_last_coarse_iters(fpr_ctx* ctx);
 

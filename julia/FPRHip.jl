@@ -499,60 +499,42 @@ end
 copy_device!(dst::DA, src::DA) = check(ccall((:fpr_copy, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Csize_t), ctx(), p(dst), p(src), length(dst)))
 
 """
-    alloc_fields(count, dims...; pool = count + 7, pairs = nothing, spacer_bytes = nothing) -> Vector{ROCArray{Float64}}
+    alloc_fields(count, dims...; pool = count + 7, pairs = nothing, trial = nothing, spacer_bytes = nothing) -> Vector{ROCArray{Float64}}
 
 Field arrays placed for the streaming kernels (twin of `finalprojectrepo.jl_amd/placement.py`, DESIGN.md 3): on MI355X two arrays that a
 kernel streams at equal offsets get in each other's way when their allocations carry the same placement label (a property of the physical
-pages: the fused diffusion launch takes 0.775 ms at 512^3 on arrays that differ, 0.85-0.91 ms on arrays of one class).  The label cannot
-be computed from a pointer, so a pool of candidates is allocated (with untouched spacer allocations between them), `fpr_copy` is timed
-between every pair, and the assignment of candidates to the `count` positions whose slowest streamed-together pair (`pairs`, default all)
-copies fastest is kept; the rest is freed.  Optional: time a few launches of the caller's own kernel on the best few assignments and keep the
-fastest (bench.py does).  Replaces nothing in the reference: `@zeros` (part1_kernel_programming.jl:134-142) keeps working without it.
+pages: the fused diffusion launch takes 0.76 ms at 512^3 on arrays that differ, 0.85-0.91 ms on arrays of one class).  The measurement and
+the search are ONE call into the library (`fpr_placement_rank`, include/fpr.h); the host only allocates the pool -- the first `count`
+plainly, as `@zeros` would, the rest behind untouched spacers -- and frees what was not chosen.  `pairs`: 1-based positions streamed
+together (default all); `trial(arrays) -> ms`: the caller's own kernel as the judge (optional).  Replaces nothing in the reference:
+`@zeros` (part1_kernel_programming.jl:134-142) keeps working without it.
 """
-function alloc_fields(count::Integer, dims::Integer...; pool::Integer = count + 7, pairs = nothing, spacer_bytes = nothing)
+function alloc_fields(count::Integer, dims::Integer...; pool::Integer = count + 7, pairs = nothing, trial = nothing, spacer_bytes = nothing)
     nbytes = 8 * prod(dims)
     (nbytes < (256 << 20) || count < 2) && return [AMDGPU.zeros(Float64, dims...) for _ in 1:count]
-    spacer = spacer_bytes === nothing ? (nbytes >= (512 << 20) ? 3 * nbytes : 0) : spacer_bytes
+    spacer = spacer_bytes === nothing ? max(4 << 30, 3 * nbytes) : spacer_bytes
     cands, spacers = DA[], Any[]
     for i in 1:pool
+        (spacer > 0 && i > count) && push!(spacers, ROCArray{UInt8}(undef, spacer))      # reserved, never touched
         push!(cands, AMDGPU.zeros(Float64, dims...))
-        (spacer > 0 && i < pool) && push!(spacers, ROCArray{UInt8}(undef, spacer))      # reserved, never touched
     end
-    t = zeros(pool, pool)
-    for i in 1:pool, j in 1:pool
-        i == j && continue
-        copy_device!(cands[j], cands[i])                                                 # warm-up
-        AMDGPU.synchronize()
-        t[i, j] = AMDGPU.@elapsed begin copy_device!(cands[j], cands[i]); copy_device!(cands[j], cands[i]) end
+    ptrs = Ptr{Cvoid}[Ptr{Cvoid}(p(A)) for A in cands]
+    flat = pairs === nothing ? Cint[] : Cint[x - 1 for q in pairs for x in q]
+    chosen, report = zeros(Cint, count), zeros(Cdouble, 16)
+    judge = (_user::Ptr{Cvoid}, idx::Ptr{Cint}, n::Cint) -> Cdouble(trial([cands[unsafe_load(idx, i) + 1] for i in 1:n]))
+    cb = trial === nothing ? C_NULL : @cfunction($judge, Cdouble, (Ptr{Cvoid}, Ptr{Cint}, Cint))
+    AMDGPU.synchronize()
+    GC.@preserve cands ptrs flat chosen report cb begin
+        check(ccall((:fpr_placement_rank, libfpr), Cint,
+                    (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Cint, Csize_t, Cint, Ptr{Cint}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}, Ptr{Cdouble}),
+                    ctx(), ptrs, length(cands), prod(dims), count, flat, length(flat) ÷ 2,
+                    cb === C_NULL ? C_NULL : Base.unsafe_convert(Ptr{Cvoid}, cb), C_NULL, chosen, report))
     end
-    sym = (t .+ t') ./ 2
-    prs = pairs === nothing ? [(a, b) for a in 1:count for b in a+1:count] : pairs
-    roles = sort(unique(vcat([collect(q) for q in prs]...)))
-    best, best_cost = nothing, (Inf, Inf)
-    function search(assign)                              # assignments of candidates to the positions that matter, depth first
-        if length(assign) == length(roles)
-            where_ = Dict(zip(roles, assign))
-            ts = [sym[where_[a], where_[b]] for (a, b) in prs]
-            cost = (maximum(ts), sum(ts))
-            cost < best_cost && ((best, best_cost) = (copy(assign), cost))
-            return
-        end
-        for c in 1:pool
-            c in assign && continue
-            push!(assign, c); search(assign); pop!(assign)
-        end
-    end
-    search(Int[])
-    out = Vector{Any}(nothing, count)
-    for (pos, c) in zip(roles, best); out[pos] = cands[c]; end
-    rest = [c for c in 1:pool if !(c in best)]
-    for pos in 1:count
-        out[pos] === nothing && (out[pos] = cands[popfirst!(rest)])
-    end
-    for c in rest; AMDGPU.unsafe_free!(cands[c]); end
+    out = DA[cands[c + 1] for c in chosen]
+    for (i, A) in enumerate(cands); (i - 1) in chosen || AMDGPU.unsafe_free!(A); end
     for q in spacers; AMDGPU.unsafe_free!(q); end
     foreach(A -> fill_device!(A, 0.0), out)
-    return DA[out...]
+    return out
 end
 fill_device!(dst::DA, v) = check(ccall((:fpr_fill, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Csize_t), ctx(), p(dst), v, length(dst)))
 fill_on!(dst::DA, v, stream_sel) = check(ccall((:fpr_fill_on, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Csize_t, Cint), ctx(), p(dst), v, length(dst), stream_sel))

@@ -221,6 +221,34 @@ void orc_diffusion3d_step(const double *Ht, const double *Htau, double *Htau2, d
             }
 }
 
+/* A1 with the contraction the reference notes itself -- "(or 1 * fma)", part1_kernel_programming.jl:55,94 -- written out with
+ * explicit fma() calls (exact: one rounding each, whatever -ffp-contract says): the checker of the library's OPT-IN option
+ * fp_contract = 1 (diff3_point<FMA = true>, csrc/diffusion3d_kernels.hpp: the same sequence), bit for bit.  Not the reference's CPU
+ * arithmetic: how far it is from orc_diffusion3d_step is what tests/test_oracle_pins.py bounds (1e-12 relative). */
+void orc_diffusion3d_step_fma(const double *Ht, const double *Htau, double *Htau2, double *dHdtau,
+                              int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy,
+                              double _dz, double D_dx, double D_dy, double D_dz)
+{
+    OMP_FOR2
+    for (int k = 1; k < nz - 1; ++k)
+        for (int j = 1; j < ny - 1; ++j)
+            for (int i = 1; i < nx - 1; ++i) {
+                const double h = Htau[I3(i, j, k)];
+                const double qxm = -D_dx * (h - Htau[I3(i - 1, j, k)]);
+                const double qym = -D_dy * (h - Htau[I3(i, j - 1, k)]);
+                const double qzm = -D_dz * (h - Htau[I3(i, j, k - 1)]);
+                const double fx = fma(-D_dx, Htau[I3(i + 1, j, k)] - h, -qxm); /* qxp - qxm */
+                const double fy = fma(-D_dy, Htau[I3(i, j + 1, k)] - h, -qym);
+                const double fz = fma(-D_dz, Htau[I3(i, j, k + 1)] - h, -qzm);
+                double r = fx * _dx;
+                r = fma(fy, _dy, r);
+                r = fma(fz, _dz, r);
+                r = fma(h - Ht[I3(i, j, k)], _dt, r);
+                dHdtau[I3(i, j, k)] = r;
+                Htau2[I3(i, j, k)] = fma(-dtau, r, h);
+            }
+}
+
 /* A3 (clean split semantics): compute_flux!  -- part1_array_programming.jl:10-12
  * qx is (nx-1, ny-2, nz-2); qy (nx-2, ny-1, nz-2); qz (nx-2, ny-2, nz-1).
  * @d_xi(H)[i,j,k] = H[i+1, j+1, k+1] - H[i, j+1, k+1]  (inner in y,z)  [3P: FiniteDifferences3D] */

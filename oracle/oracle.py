@@ -47,6 +47,7 @@ class Oracle:
             "orc_dot2": (d, [_dp, _dp, z]),
             "orc_has_openmp": (i, []),
             "orc_diffusion3d_step": (None, [_dp] * 4 + [i] * 3 + [d] * 8),
+            "orc_diffusion3d_step_fma": (None, [_dp] * 4 + [i] * 3 + [d] * 8),
             "orc_diffusion3d_flux": (None, [_dp] * 4 + [i] * 3 + [d] * 4),
             "orc_diffusion3d_dHdtau": (None, [_dp] * 6 + [i] * 3 + [d] * 4),
             "orc_diffusion3d_update": (None, [_dp] * 2 + [i] * 3 + [d]),
@@ -84,6 +85,12 @@ class Oracle:
         nx, ny, nz = Ht.shape
         self.lib.orc_diffusion3d_step(_p(Ht), _p(Htau), _p(Htau2), _p(dHdtau), nx, ny, nz,
                                       dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
+
+    def diffusion3d_step_fma(self, Ht, Htau, Htau2, dHdtau, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz):
+        """The checker of the library's opt-in option fp_contract = 1 (explicit fma sequence; NOT the reference's arithmetic)."""
+        nx, ny, nz = Ht.shape
+        self.lib.orc_diffusion3d_step_fma(_p(Ht), _p(Htau), _p(Htau2), _p(dHdtau), nx, ny, nz,
+                                          dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
 
     def diffusion3d_flux(self, qx, qy, qz, Htau, D, dx, dy, dz):
         nx, ny, nz = Htau.shape

@@ -469,8 +469,9 @@ def test_coarse_jacobi_persistent_launch_that_gives_up_is_resumed_by_the_plain_o
     f[:, 0] = f[:, -1] = 0.0
     h = 1.0 / 128
     u_ref = u0.copy(order="F")
+    it0 = oracle.last_coarse_iters()           # (the oracle's counter runs on across direct V-cycle calls)
     r_ref = oracle.vcycle2d(u_ref, f, h, 0.0, tol, 257, 0, False)
-    it_ref = oracle.last_coarse_iters()
+    it_ref = oracle.last_coarse_iters() - it0
     c = F.ctx()
     c.set_option("mg_jacobi_persist", 1)
     before = c.L.fpr_get_option(c.h, b"mg_jacobi_persist_timeouts")

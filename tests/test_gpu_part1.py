@@ -530,6 +530,112 @@ def test_full_size_512_single_and_fused_launches_against_the_oracle(fpr):
     assert np.array_equal(F.tonumpy(gR), R)
 
 
+# ---------------------------------------------------------------- opt-in contracted arithmetic (option fp_contract = 1)
+def _with_fp_contract(F, fn):
+    c = F.ctx()
+    c.set_option("fp_contract", 1)
+    try:
+        return fn()
+    finally:
+        c.set_option("fp_contract", 0)
+
+
+def test_fp_contract_64_cubed_50_iterations(fpr, oracle):
+    """Option fp_contract = 1 ("(or 1 * fma)", part1_kernel_programming.jl:55,94; SURVEY 7's speed variant; default off): the
+    single-step kernel at BASELINE config 1's size for 50 pseudo-iterations -- bit for bit the oracle's explicit-fma
+    restatement (orc_diffusion3d_step_fma), within 1e-12 of the reference's arithmetic; with the option off again the exact
+    kernel is back."""
+    F = fpr
+    n = 64
+    dx = 10.0 / n
+    dt = 0.2
+    coef = (dx * dx / 8.1, 1 / dt, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx)
+    Ht = oracle.init_gaussian((n, n, n), dx, dx, dx, (5.0, 5.0, 5.0))
+    A, B, R = Ht.copy(order="F"), Ht.copy(order="F"), farr(n, n, n)
+    Af, Bf, Rf = Ht.copy(order="F"), Ht.copy(order="F"), farr(n, n, n)
+    gHt, gA, gB, gR = F.asdevice(Ht), F.asdevice(Ht), F.asdevice(Ht), F.fzeros(n, n, n)
+    sq = F.ctx().scal[:1]
+
+    def run():
+        nonlocal gA, gB, A, B, Af, Bf
+        for _ in range(50):
+            oracle.diffusion3d_step(Ht, A, B, R, *coef)
+            oracle.diffusion3d_step_fma(Ht, Af, Bf, Rf, *coef)
+            A, B, Af, Bf = B, A, Bf, Af
+            F.part1.diffusion_3D_step_τ_norm(gHt, gA, gB, gR, *coef, dt, sq)
+            gA, gB = gB, gA
+
+    _with_fp_contract(F, run)
+    H, Rg = F.tonumpy(gA), F.tonumpy(gR)
+    assert np.array_equal(H, Af) and np.array_equal(Rg, Rf)
+    assert not np.array_equal(H, A)
+    assert np.abs(H - A).max() <= 1e-12 * np.abs(A).max() and np.abs(Rg - R).max() <= 1e-12 * np.abs(R).max()
+    ref = oracle.sumsq_scaled(Rf, dt)
+    assert abs(float(sq[0].item()) - ref) <= 1e-13 * ref
+    # off again: the exact kernel
+    F.part1.diffusion_3D_step_τ(gHt, F.asdevice(A), gB, gR, *coef)
+    oracle.diffusion3d_step(Ht, A, B, R, *coef)
+    assert np.array_equal(F.tonumpy(gB), B)
+
+
+def test_fp_contract_512_cubed_fused_pairs(fpr):
+    """The same option on the fused two-iteration kernel at 512^3 (BASELINE config 2): 4 iterations = 2 launches, bit for bit the
+    oracle's fma restatement, within 1e-12 of the reference's arithmetic, norms to 1e-13."""
+    import os
+
+    from fixtures_io import splitmix64_uniform
+    from oracle.oracle import Oracle, asf
+
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
+    orc = Oracle(openmp=True)
+    F = fpr
+    n = 512
+    dx = 10.0 / n
+    dt = 0.2
+    coef = (dx * dx / 8.1, 1 / dt, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx)
+    Ht = orc.init_gaussian((n, n, n), dx, dx, dx, (4.0, 5.5, 6.0))
+    Ht *= 1.0 + 0.25 * asf(splitmix64_uniform(n ** 3, 78).reshape((n, n, n), order="F"))
+    A, B, R = Ht.copy(order="F"), Ht.copy(order="F"), farr(n, n, n)
+    Af, Bf, Rf = Ht.copy(order="F"), Ht.copy(order="F"), farr(n, n, n)
+    gHt, gA, gB, gC, gR = F.asdevice(Ht), F.asdevice(Ht), F.asdevice(Ht), F.asdevice(Ht), F.fzeros(n, n, n)
+    sq = F.ctx().scal[:2]
+    assert F.part1.can_step_τ2(gHt, gA, gB, gC, gR)
+    refs = []
+
+    def run():
+        nonlocal gA, gC, A, B, Af, Bf
+        for pair in range(2):
+            for _ in range(2):
+                orc.diffusion3d_step(Ht, A, B, R, *coef)
+                orc.diffusion3d_step_fma(Ht, Af, Bf, Rf, *coef)
+                A, B, Af, Bf = B, A, Bf, Af
+                refs.append(orc.sumsq_scaled(Rf, dt))
+            F.part1.diffusion_3D_step_τ2(gHt, gA, gB, gC, gR, *coef, dt, sq)
+            got = [float(v) for v in sq.tolist()]
+            assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs[-2:])), (got, refs[-2:])
+            gA, gC = gC, gA
+
+    _with_fp_contract(F, run)
+    H, Rg = F.tonumpy(gA), F.tonumpy(gR)
+    assert np.array_equal(H, Af) and np.array_equal(Rg, Rf)
+    assert not np.array_equal(H, A)
+    assert np.abs(H - A).max() <= 1e-12 * np.abs(A).max() and np.abs(Rg - R).max() <= 1e-12 * np.abs(R).max()
+
+
+@pytest.mark.parametrize("k", [0, 3, 5])
+def test_fp_contract_published_tolerance_sweep_iteration_counts(fpr, oracle, k):
+    """benchmark-results/error_vs_tolerance_experiment_results.csv (128^3, ttot = 2) with fp_contract = 1: every time step takes
+    the exact path's number of pseudo-iterations +-1 and the probe value agrees with the published one to 1e-11 relative (the
+    exact path reproduces every printed digit: test_published_tolerance_sweep_128)."""
+    row = _published("error_vs_tolerance_experiment_results.csv")[k]
+    tol = float(row["tol"])
+    v0, info0 = _probe_value(fpr, oracle, 128, tol)
+    v1, info1 = _with_fp_contract(fpr, lambda: _probe_value(fpr, oracle, 128, tol))
+    assert len(info0["iters"]) == len(info1["iters"])
+    assert all(abs(a - b) <= 1 for a, b in zip(info0["iters"], info1["iters"])), (info0["iters"], info1["iters"])
+    assert abs(v1 - float(row["val"])) <= 1e-11 * abs(float(row["val"]))
+
+
 def test_full_size_512_fused_equals_two_steps(fpr):
     """BASELINE config 2 size: the fused launch equals two single launches bit for bit at 512^3 (norms to 1e-13)."""
     import torch

@@ -140,6 +140,8 @@ def _c_type_class(decl, is_return=False):
             return "ptr_any"                                  # void*: raw bytes, any Ptr{T}
         return "ptr_void" if stars == 1 else "ptr_ptr"      # fpr_ctx*, void**
     base = d.split()[0] if not is_return else d
+    if base.split()[0].endswith("_fn"):
+        return "ptr_void"                                     # a function-pointer typedef (fpr_place_trial_fn): Ptr{Cvoid} from @cfunction
     return {"int": "int", "long": "long", "double": "double", "size_t": "size_t", "void": "void"}[base.split()[0]]
 
 

@@ -433,3 +433,26 @@ def test_scale_norms_n1_entries_are_pinned_on_the_oracle():
     assert all(abs(live[k] - rec[k]) <= 1e-13 * rec[k] for k in rec), (live, rec)
     live = pins_mod.oracle_sumsq(512, counts=(8,))
     assert abs(live["8"] - g["entries"]["n512_dims1,1,1"]["oracle_sumsq"]["8"]) <= 1e-13 * live["8"]
+
+
+# ---------------------------------------------------------------- "(or 1 * fma)", part1_kernel_programming.jl:55,94
+def test_contracted_step_stays_within_1e12_of_the_exact_step(oracle):
+    """orc_diffusion3d_step_fma -- the checker of the library's opt-in option fp_contract = 1 -- against the reference's
+    arithmetic (orc_diffusion3d_step) over 50 pseudo-iterations at 64^3 (BASELINE config 1's size): field and residual within
+    1e-12 of their scale, the convergence norm within 1e-12 relative."""
+    n = 64
+    dx = 10.0 / n
+    dt = 0.2
+    coef = (dx * dx / 8.1, 1 / dt, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx)
+    Ht = oracle.init_gaussian((n, n, n), dx, dx, dx, (5.0, 5.0, 5.0))
+    A, B, R = Ht.copy(order="F"), Ht.copy(order="F"), farr(n, n, n)
+    Af, Bf, Rf = Ht.copy(order="F"), Ht.copy(order="F"), farr(n, n, n)
+    for _ in range(50):
+        oracle.diffusion3d_step(Ht, A, B, R, *coef)
+        oracle.diffusion3d_step_fma(Ht, Af, Bf, Rf, *coef)
+        A, B, Af, Bf = B, A, Bf, Af
+    assert not np.array_equal(A, Af)                      # (it IS another rounding sequence)
+    assert np.abs(A - Af).max() <= 1e-12 * np.abs(A).max()
+    assert np.abs(R - Rf).max() <= 1e-12 * np.abs(R).max()
+    s, sf = oracle.sumsq_scaled(R, dt), oracle.sumsq_scaled(Rf, dt)
+    assert abs(s - sf) <= 1e-12 * s

@@ -233,6 +233,9 @@ def main():
                     help="diagnostic for a 1-GPU box: every rank on cuda:0, halo planes and the norm's all-reduce staged "
                          "through the host over gloo (RCCL refuses two ranks on one device).  Runs the N>1 control flow, the "
                          "shell/core choreography and the HIP kernels between real processes; its rates are NOT measurements")
+    ap.add_argument("--rehearse-transport", choices=("hosted", "python"), default="hosted",
+                    help="with --rehearse-shared-gpu: hosted = the library's exchange code and one-call pairs over fpr_comm_init_hosted "
+                         "(default); python = grid.HaloExchanger's twin of the choreography")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -312,11 +315,14 @@ def main():
     else:
         nloc = (n, n, n)
         phys = dims
-    gg = F.grid.GlobalGrid(*nloc, dims=dims, transport=("dist" if shared else "rccl") if world > 1 else None)
-    if shared and world > 1:
+    # --rehearse-shared-gpu: the LIBRARY's transport code and choreography over a host-staged transport (fpr_comm_init_hosted, bytes
+    # through gloo) by default; --rehearse-transport python = the Python twin of the choreography (grid.HaloExchanger over gloo)
+    shared_kind = ("hosted" if args.rehearse_transport == "hosted" else "dist") if shared else "rccl"
+    gg = F.grid.GlobalGrid(*nloc, dims=dims, transport=shared_kind if world > 1 else None)
+    if shared and world > 1 and shared_kind == "dist":
         gg.dist = legs_mod.host_staged_p2p(torch, dist)
     rccl_ranks = ctx.L.fpr_comm_size(ctx.h)
-    if world > 1 and not shared and rccl_ranks != world:
+    if world > 1 and shared_kind != "dist" and rccl_ranks != world:
         raise RuntimeError("the library's RCCL communicator has %d ranks, the job %d" % (rccl_ranks, world))
     hb("rccl_init")
     # physics as diffusion_3D_kernel_programming with scale_physical_size=true (weak scaling keeps dx fixed)
@@ -610,7 +616,8 @@ def main():
     if shared:
         out["rehearsal"] = ("%d ranks sharing one GPU, planes staged through the host over gloo: a control-flow and "
                             "choreography rehearsal, not a measurement" % world)
-        out["config"]["halo"] = "REHEARSAL: host-staged gloo"
+        out["config"]["halo"] = "REHEARSAL: host-staged gloo (%s)" % ("library transport code over fpr_comm_init_hosted" if shared_kind == "hosted"
+                                                                     else "Python HaloExchanger")
     # second leg: the one-iteration-per-launch kernel (north_star's ">= 60 % of HBM peak on the inner update" in
     # the one-pass accounting), with its own event timer; not part of `value`
     if world == 1 and main_fused and not args.no_single_leg:

@@ -101,6 +101,7 @@ _SIG = {
     "fpr_mgsolve2d": [_vp, _dp, _dp, _d, _d, _d, _i, _i, _i, _i, _i, _i, C.POINTER(_d), C.POINTER(_i), C.POINTER(_d),
                       C.POINTER(_d), C.POINTER(_i)],
     "fpr_cg2d": [_vp, _dp, _dp, _d, _d, _d, _d, _i, _i, _i, C.POINTER(_d), C.POINTER(_i)],
+    "fpr_comm_init_hosted": [_vp, _i, _i, _vp, _vp, _vp, _vp],
     "fpr_placement_rank": [_vp, C.POINTER(_vp), _i, C.c_size_t, _i, C.POINTER(_i), _i, _vp, _vp, C.POINTER(_i), C.POINTER(_d)],
     "fpr_mg_arena_provide": [_vp, _i, _i, _vp, _vp],
     "fpr_mg_arena_provide_coarse": [_vp, _i, _i, _vp, _vp, _vp],

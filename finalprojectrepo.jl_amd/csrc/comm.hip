@@ -24,6 +24,119 @@ static_assert(sizeof(ncclUniqueId) == FPR_UNIQUE_ID_BYTES, "FPR_UNIQUE_ID_BYTES 
 
 static inline ncclComm_t comm_of(fpr_ctx* ctx) { return (ncclComm_t)ctx->comm; }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The transport UNDER the exchange logic: five operations (group start / end, send, receive, all-reduce).  The product
+// transport is RCCL.  fpr_comm_init_hosted puts a host-staged one in its place -- the same calls, issued by the same code
+// (post_group's face order, the pack / unpack kernels, the strips, gather, the norm's all-reduce), but the bytes leave the
+// device through host memory and travel by whatever the host process has (the tests: torch.distributed over gloo).  RCCL
+// refuses two ranks on one device and a test box has one: this is how the send-high-first / receive-low-first matching and
+// every buffer address of an exchange are EXECUTED between real processes before hardware with two cards appears.
+// A send / receive outside a group runs at once; inside a group at the group's end: every send first (a send callback
+// must not wait for the peer's receive), then the receives in posting order -- per peer the k-th send meets the k-th
+// receive, RCCL's matching rule.
+// ---------------------------------------------------------------------------------------------------------------------
+struct FprHosted {
+    fpr_hosted_send_fn send;
+    fpr_hosted_recv_fn recv;
+    fpr_hosted_allreduce_fn allreduce;
+    void* user;
+    struct Op { bool is_send; void* ptr; size_t bytes; int peer; hipStream_t s; };
+    std::vector<Op> ops;
+    int depth = 0;
+    std::vector<char> stage;
+};
+static inline FprHosted* hosted_of(fpr_ctx* ctx) { return ctx->comm_hosted ? (FprHosted*)ctx->comm : nullptr; }
+
+static int hosted_run(fpr_ctx* ctx, FprHosted* h, const FprHosted::Op& op)
+{
+    if (h->stage.size() < op.bytes) h->stage.resize(op.bytes);
+    if (op.is_send) {
+        FPR_HIP(ctx, hipMemcpyAsync(h->stage.data(), op.ptr, op.bytes, hipMemcpyDeviceToHost, op.s));
+        FPR_HIP(ctx, hipStreamSynchronize(op.s));
+        if (h->send(h->user, op.peer, h->stage.data(), op.bytes) != 0) return fpr_fail(ctx, FPR_ERR_RCCL, "hosted transport: send to rank %d failed", op.peer);
+    } else {
+        if (h->recv(h->user, op.peer, h->stage.data(), op.bytes) != 0) return fpr_fail(ctx, FPR_ERR_RCCL, "hosted transport: receive from rank %d failed", op.peer);
+        FPR_HIP(ctx, hipMemcpyAsync(op.ptr, h->stage.data(), op.bytes, hipMemcpyHostToDevice, op.s));
+        FPR_HIP(ctx, hipStreamSynchronize(op.s));     // the staging buffer is reused by the next operation
+    }
+    return FPR_OK;
+}
+
+static int x_group_start(fpr_ctx* ctx)
+{
+    if (FprHosted* h = hosted_of(ctx)) { ++h->depth; return FPR_OK; }
+    FPR_NCCL(ctx, ncclGroupStart());
+    return FPR_OK;
+}
+// returns the RCCL result through *res (a group must be closed whatever happened inside it); hosted: runs the group
+static int x_group_end(fpr_ctx* ctx, ncclResult_t* res)
+{
+    *res = ncclSuccess;
+    if (FprHosted* h = hosted_of(ctx)) {
+        if (--h->depth > 0) return FPR_OK;
+        std::vector<FprHosted::Op> ops;
+        ops.swap(h->ops);
+        for (int pass = 0; pass < 2; ++pass)
+            for (const auto& op : ops)
+                if (op.is_send == (pass == 0))
+                    if (int rc = hosted_run(ctx, h, op)) return rc;
+        return FPR_OK;
+    }
+    *res = ncclGroupEnd();
+    return FPR_OK;
+}
+static ncclResult_t x_send(fpr_ctx* ctx, const double* src, size_t count, int peer, hipStream_t s, int* rc_out)
+{
+    *rc_out = FPR_OK;
+    if (FprHosted* h = hosted_of(ctx)) {
+        const FprHosted::Op op{true, (void*)src, count * sizeof(double), peer, s};
+        if (h->depth > 0) h->ops.push_back(op);
+        else *rc_out = hosted_run(ctx, h, op);
+        return ncclSuccess;
+    }
+    return ncclSend(src, count, ncclDouble, peer, comm_of(ctx), s);
+}
+static ncclResult_t x_recv(fpr_ctx* ctx, double* dst, size_t count, int peer, hipStream_t s, int* rc_out)
+{
+    *rc_out = FPR_OK;
+    if (FprHosted* h = hosted_of(ctx)) {
+        const FprHosted::Op op{false, (void*)dst, count * sizeof(double), peer, s};
+        if (h->depth > 0) h->ops.push_back(op);
+        else *rc_out = hosted_run(ctx, h, op);
+        return ncclSuccess;
+    }
+    return ncclRecv(dst, count, ncclDouble, peer, comm_of(ctx), s);
+}
+static int x_allreduce(fpr_ctx* ctx, double* x_dev, int count, hipStream_t s)
+{
+    if (FprHosted* h = hosted_of(ctx)) {
+        std::vector<double> v((size_t)count);
+        FPR_HIP(ctx, hipMemcpyAsync(v.data(), x_dev, v.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        FPR_HIP(ctx, hipStreamSynchronize(s));
+        if (h->allreduce(h->user, v.data(), count) != 0) return fpr_fail(ctx, FPR_ERR_RCCL, "hosted transport: all-reduce failed");
+        FPR_HIP(ctx, hipMemcpyAsync(x_dev, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        FPR_HIP(ctx, hipStreamSynchronize(s));
+        return FPR_OK;
+    }
+    FPR_NCCL(ctx, ncclAllReduce(x_dev, x_dev, (size_t)count, ncclDouble, ncclSum, comm_of(ctx), s));
+    return FPR_OK;
+}
+
+extern "C" int fpr_comm_init_hosted(fpr_ctx* ctx, int rank, int nranks, fpr_hosted_send_fn send, fpr_hosted_recv_fn recv,
+                                    fpr_hosted_allreduce_fn allreduce, void* user)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, send && recv && allreduce && nranks >= 1 && rank >= 0 && rank < nranks, "rank / nranks / callbacks");
+    FPR_REQUIRE(ctx, ctx->comm == nullptr, "communicator already initialised (call fpr_comm_finalize first)");
+    FprHosted* h = new FprHosted();
+    h->send = send; h->recv = recv; h->allreduce = allreduce; h->user = user;
+    ctx->comm = (void*)h;
+    ctx->comm_hosted = true;
+    ctx->comm_rank = rank;
+    ctx->comm_size = nranks;
+    return FPR_OK;
+}
+
 extern "C" int fpr_comm_get_unique_id(void* id_out)
 {
     if (!id_out) return FPR_ERR_INVALID;
@@ -68,8 +181,10 @@ extern "C" int fpr_comm_finalize(fpr_ctx* ctx)
     if (ctx->comm) {
         hipStreamSynchronize(ctx->stream[0]);
         hipStreamSynchronize(ctx->stream[1]);
-        ncclCommDestroy(comm_of(ctx));
+        if (ctx->comm_hosted) delete (FprHosted*)ctx->comm;
+        else ncclCommDestroy(comm_of(ctx));
         ctx->comm = nullptr;
+        ctx->comm_hosted = false;
     }
     ctx->comm_rank = 0;
     ctx->comm_size = 1;
@@ -198,17 +313,18 @@ static int post_group(fpr_ctx* ctx, double* A, int mask, hipStream_t s, const do
     bool any = false;
     for (int f = 0; f < 6; ++f) any |= ((mask >> f) & 1) && g.nb[f] >= 0;
     if (!any) return FPR_OK;
-    FPR_NCCL(ctx, ncclGroupStart());
+    if (int rc = x_group_start(ctx)) return rc;
     // an error inside the group must not leave it open (later RCCL calls of this thread would be deferred for ever):
     // remember the first failure, always close the group, then report
     ncclResult_t first = ncclSuccess;
+    int hrc = FPR_OK;     // (hosted transport: operations inside a group are only recorded, this stays FPR_OK)
     const char* what = "";
     for (int d = 0; d < 3 && first == ncclSuccess; ++d)
         for (int side = 0; side < 2 && first == ncclSuccess; ++side) {
             const int f = 2 * d + side;
             if (!((mask >> f) & 1) || g.nb[f] < 0) continue;
             double* dst = d == 2 ? A + (side ? (size_t)(nz - 1) * pz : 0) : ((d == 0 && xrecv) ? xrecv[side] : g.recvbuf[f]);
-            first = ncclRecv(dst, count[d], ncclDouble, g.nb[f], comm_of(ctx), s);
+            first = x_recv(ctx, dst, count[d], g.nb[f], s, &hrc);
             what = "ncclRecv";
         }
     for (int d = 0; d < 3 && first == ncclSuccess; ++d)
@@ -216,10 +332,12 @@ static int post_group(fpr_ctx* ctx, double* A, int mask, hipStream_t s, const do
             const int f = 2 * d + side;
             if (!((mask >> f) & 1) || g.nb[f] < 0) continue;
             const double* src = d == 2 ? A + (side ? (size_t)(nz - 2) * pz : pz) : ((d == 0 && xsend) ? xsend[side] : g.sendbuf[f]);
-            first = ncclSend(src, count[d], ncclDouble, g.nb[f], comm_of(ctx), s);
+            first = x_send(ctx, src, count[d], g.nb[f], s, &hrc);
             what = "ncclSend";
         }
-    const ncclResult_t end = ncclGroupEnd();
+    ncclResult_t end = ncclSuccess;
+    if (int rc = x_group_end(ctx, &end)) return rc;
+    if (hrc != FPR_OK) return hrc;
     if (first != ncclSuccess)
         return fpr_fail(ctx, FPR_ERR_RCCL, "%s:%d %s -> %s (group closed: %s)", __FILE__, __LINE__, what, ncclGetErrorString(first),
                         ncclGetErrorString(end));
@@ -318,8 +436,7 @@ extern "C" int fpr_allreduce_sum_dev(fpr_ctx* ctx, double* x_dev, int count, int
     FPR_REQUIRE(ctx, x_dev && count >= 1 && (stream_sel == 0 || stream_sel == 1), "pointer / count / stream");
     if (int rc = fpr_diffusion3d_join(ctx)) return rc;
     if (!ctx->comm) return FPR_OK;   // single rank without a communicator
-    FPR_NCCL(ctx, ncclAllReduce(x_dev, x_dev, (size_t)count, ncclDouble, ncclSum, comm_of(ctx), ctx->stream[stream_sel]));
-    return FPR_OK;
+    return x_allreduce(ctx, x_dev, count, ctx->stream[stream_sel]);
 }
 
 // part1_utils.jl:38 as the reference calls it: one host Float64, summed over all ranks, back on the host.
@@ -335,7 +452,7 @@ extern "C" int fpr_allreduce_sum1(fpr_ctx* ctx, double* x_host_inout)
     ctx->host_scalars[48] = *x_host_inout;
     if (int rc = fpr_stream_wait(ctx, 1, 0)) return rc;
     FPR_HIP(ctx, hipMemcpyAsync(d, ctx->host_scalars + 48, sizeof(double), hipMemcpyHostToDevice, ctx->stream[1]));
-    FPR_NCCL(ctx, ncclAllReduce(d, d, 1, ncclDouble, ncclSum, comm_of(ctx), ctx->stream[1]));
+    if (int rc = x_allreduce(ctx, d, 1, ctx->stream[1])) return rc;
     FPR_HIP(ctx, hipMemcpyAsync(ctx->host_scalars + 48, d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream[1]));
     FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));
     *x_host_inout = ctx->host_scalars[48];
@@ -355,7 +472,9 @@ extern "C" int fpr_gather3d(fpr_ctx* ctx, const double* A, int nx, int ny, int n
     const int np = ctx->comm_size, me = ctx->comm_rank;
     if (int rc = fpr_stream_wait(ctx, 1, 0)) return rc;   // comm stream (all RCCL calls), behind the producers of A
     if (me != 0) {
-        FPR_NCCL(ctx, ncclSend(A, n, ncclDouble, 0, comm_of(ctx), ctx->stream[1]));
+        int hrc = FPR_OK;
+        FPR_NCCL(ctx, x_send(ctx, A, n, 0, ctx->stream[1], &hrc));
+        if (hrc != FPR_OK) return hrc;
         FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[1]));
         return FPR_OK;
     }
@@ -367,7 +486,9 @@ extern "C" int fpr_gather3d(fpr_ctx* ctx, const double* A, int nx, int ny, int n
     for (int r = 0; r < np; ++r) {
         const double* src = A;
         if (r != 0) {
-            FPR_NCCL(ctx, ncclRecv(g.stage, n, ncclDouble, r, comm_of(ctx), ctx->stream[1]));
+            int hrc = FPR_OK;
+            FPR_NCCL(ctx, x_recv(ctx, g.stage, n, r, ctx->stream[1], &hrc));
+            if (hrc != FPR_OK) return hrc;
             src = g.stage;
         }
         const int c[3] = {r / (g.dims[1] * g.dims[2]), (r / g.dims[2]) % g.dims[1], r % g.dims[2]};

@@ -71,7 +71,8 @@ struct FprGrid {  // implicit global grid of the decomposed diffusion path (role
 
 struct fpr_ctx {
     int device = 0;
-    void* comm = nullptr;        // ncclComm_t (comm.hip); nullptr = single rank
+    void* comm = nullptr;        // ncclComm_t (comm.hip), or the FprHosted of a hosted transport; nullptr = single rank
+    bool comm_hosted = false;    // fpr_comm_init_hosted: bytes travel through the host's callbacks instead of RCCL (rehearsals, tests)
     int comm_rank = 0, comm_size = 1;
     FprGrid grid;
     // 0 compute, 1 comm, 2 core (= 0 unless fpr_reserve_comm_cus split the device: then 1 is a library-owned stream whose

@@ -114,7 +114,9 @@ extern "C" int fpr_placement_rank(fpr_ctx* ctx, double* const* cand, int k, size
     FPR_HIP(ctx, hipEventCreate(&e1));
     const int reps = (int)std::max(1L, fpr_opt(ctx, "place_copy_reps", 2));
     const size_t nb = (n + 1) / 2;
-    const unsigned grid = (unsigned)std::min<size_t>((nb + 255) / 256, (size_t)1 << 20);
+    // 2048 workgroups walking through the arrays together (fpr_copy's grid): the pattern the class thresholds were measured with, and
+    // the one that resembles a march -- a grid of one 16-byte access per thread copies at 6.2-6.4 TB/s whatever the classes
+    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>((nb + 255) / 256, 2048));
     std::vector<double> t((size_t)k * k, 0.0), sym((size_t)k * k, 0.0);
     const double bytes2 = 2.0 * 8.0 * (double)n;
     if (nroles >= 2) {

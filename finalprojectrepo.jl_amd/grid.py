@@ -260,6 +260,66 @@ def rccl_bootstrap(ctx, rank, world, dist=None, group=None):
     ctx.comm_ready = True
 
 
+_HOSTED_KEEP = []     # ctypes callbacks of hosted transports (must outlive the contexts that hold their addresses)
+
+
+def hosted_bootstrap(ctx, rank, world, dist, group=None):
+    """fpr_comm_init_hosted: the library's exchange logic over a host-staged transport instead of RCCL -- for ranks that SHARE a
+    card (RCCL refuses two ranks on one device; a test box has one card).  The bytes travel through `dist` (torch.distributed
+    on a CPU backend: gloo): isend of a copy per message (never waits for the peer), a blocking recv per message, per peer in
+    posting order.  Same library calls as with RCCL from there on; rates through it are not measurements."""
+    import ctypes as C
+
+    import torch
+
+    if ctx.L.fpr_comm_size(ctx.h) == world and ctx.comm_ready:
+        return
+    pending = []
+    own = []          # messages of a rank to itself (a periodic dimension with one rank in it), in posting order
+
+    def grank(peer):
+        return peer if group is None else dist.get_global_rank(group, peer)
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
+    def send(_user, peer, buf, nbytes):
+        try:
+            t = torch.frombuffer((C.c_char * nbytes).from_address(buf), dtype=torch.uint8).clone()
+            if peer == rank:
+                own.append(t)
+                return 0
+            pending.append((dist.isend(t, grank(peer), group=group), t))
+            pending[:] = [(w, x) for w, x in pending if not w.is_completed()]
+            return 0
+        except Exception:
+            return 1
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
+    def recv(_user, peer, buf, nbytes):
+        try:
+            t = torch.frombuffer((C.c_char * nbytes).from_address(buf), dtype=torch.uint8)
+            if peer == rank:
+                t.copy_(own.pop(0))
+                return 0
+            dist.recv(t, grank(peer), group=group)
+            return 0
+        except Exception:
+            return 1
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+    def allreduce(_user, x, count):
+        try:
+            t = torch.frombuffer((C.c_double * count).from_address(C.addressof(x.contents)), dtype=torch.float64)
+            dist.all_reduce(t, group=group)
+            return 0
+        except Exception:
+            return 1
+
+    _HOSTED_KEEP.append((send, recv, allreduce, pending))
+    ctx.call("fpr_comm_init_hosted", int(rank), int(world), C.cast(send, C.c_void_p), C.cast(recv, C.c_void_p),
+             C.cast(allreduce, C.c_void_p), None)
+    ctx.comm_ready = True
+
+
 class GlobalGrid:
     """init_global_grid(nx, ny, nz; dimx, dimy, dimz, periodx, periody, periodz): Cartesian process topology +
     implicit global grid.  transport: "rccl" (library, the product path), "dist" (torch.distributed-like P2P object,
@@ -320,8 +380,13 @@ class GlobalGrid:
                         transport = "rccl"
                 except ImportError:
                     pass
-        if transport not in ("rccl", "dist"):
-            raise ValueError("transport must be 'rccl' or 'dist'")
+        if transport not in ("rccl", "dist", "hosted"):
+            raise ValueError("transport must be 'rccl', 'hosted' or 'dist'")
+        # "hosted": the library's own exchange logic and choreography (everything "rccl" runs) over a host-staged transport
+        # (fpr_comm_init_hosted) -- ranks sharing one card, tests; from here on it IS the "rccl" kind
+        self.hosted = transport == "hosted"
+        if self.hosted:
+            transport = "rccl"
         self.transport_kind = transport
         self._tr = None
         self._ex = None
@@ -338,7 +403,10 @@ class GlobalGrid:
         from . import ctx as _ctx
 
         c = _ctx()
-        rccl_bootstrap(c, self.me, self.nprocs, self.dist, self.group)
+        if getattr(self, "hosted", False):
+            hosted_bootstrap(c, self.me, self.nprocs, self.dist, self.group)
+        else:
+            rccl_bootstrap(c, self.me, self.nprocs, self.dist, self.group)
         c.set_option("grid_drop_faces", getattr(self, "drop_faces", 0))
         me, npr = C.c_int(0), C.c_int(0)
         dims_o, coords_o = (C.c_int * 3)(), (C.c_int * 3)()

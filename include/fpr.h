@@ -265,6 +265,18 @@ int fpr_stream_handle(fpr_ctx* ctx, int stream_sel, void** hip_stream_out);
 #define FPR_UNIQUE_ID_BYTES 128
 int fpr_comm_get_unique_id(void* id_out /* FPR_UNIQUE_ID_BYTES */);
 int fpr_comm_init(fpr_ctx* ctx, int rank, int nranks, const void* unique_id);
+/* A host-staged transport in RCCL's place, for rehearsals and tests on ONE card (RCCL refuses two ranks on one device): the same
+ * library code issues the same sends, receives and all-reduces -- face order of an exchange, pack / unpack kernels, strips, gather --
+ * but the bytes leave the device through host memory and travel by the host's callbacks (each returns 0 on success):
+ *   send(user, peer, buf, bytes)       must not wait for the peer's receive (buffer it); buf is the library's until it returns
+ *   recv(user, peer, buf, bytes)       blocks until the next message from `peer` is in buf (per peer: k-th send meets k-th receive)
+ *   allreduce(user, x, count)          sum over all ranks, in place, on `count` host doubles
+ * Rates through it are NOT measurements.  Everything else (fpr_grid_init, exchanges, fpr_diffusion3d_step2_halo ...) is unchanged. */
+typedef int (*fpr_hosted_send_fn)(void* user, int peer, const void* buf, size_t bytes);
+typedef int (*fpr_hosted_recv_fn)(void* user, int peer, void* buf, size_t bytes);
+typedef int (*fpr_hosted_allreduce_fn)(void* user, double* x, int count);
+int fpr_comm_init_hosted(fpr_ctx* ctx, int rank, int nranks, fpr_hosted_send_fn send, fpr_hosted_recv_fn recv,
+                         fpr_hosted_allreduce_fn allreduce, void* user);
 int fpr_comm_finalize(fpr_ctx* ctx);   /* finalize_global_grid(); also done by fpr_ctx_destroy */
 int fpr_comm_rank(fpr_ctx* ctx);
 int fpr_comm_size(fpr_ctx* ctx);

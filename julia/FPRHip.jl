@@ -559,6 +559,37 @@ const GRID = Ref{Any}(nothing)   # (me, dims, nprocs, coords, n = (nx,ny,nz), pe
 const HAS_COMM = Ref(false)      # fpr_comm_init done on the current context
 grid() = (GRID[] === nothing && error("init_global_grid has not been called"); GRID[])
 
+# The library's exchange code over a host-staged transport (fpr_comm_init_hosted, include/fpr.h): MPI carries the bytes, as in the
+# reference, while pack / unpack kernels, face order and choreography stay the library's.  For rehearsals with several ranks on one
+# card (RCCL refuses that) -- `init_global_grid(...; hosted_transport = true)`; rates through it are not measurements.
+const HOSTED_PENDING = Any[]     # (request, buffer) of sends not yet complete
+function hosted_send(comm_ptr::Ptr{Cvoid}, peer::Cint, buf::Ptr{Cvoid}, nbytes::Csize_t)::Cint
+    comm = unsafe_pointer_to_objref(comm_ptr)::MPI.Comm
+    data = copy(unsafe_wrap(Array, Ptr{UInt8}(buf), Int(nbytes)))
+    push!(HOSTED_PENDING, (MPI.Isend(data, comm; dest = Int(peer), tag = 7), data))
+    filter!(q -> !MPI.Test(q[1]), HOSTED_PENDING)
+    return Cint(0)
+end
+function hosted_recv(comm_ptr::Ptr{Cvoid}, peer::Cint, buf::Ptr{Cvoid}, nbytes::Csize_t)::Cint
+    comm = unsafe_pointer_to_objref(comm_ptr)::MPI.Comm
+    MPI.Recv!(unsafe_wrap(Array, Ptr{UInt8}(buf), Int(nbytes)), comm; source = Int(peer), tag = 7)
+    return Cint(0)
+end
+function hosted_allreduce(comm_ptr::Ptr{Cvoid}, x::Ptr{Cdouble}, count::Cint)::Cint
+    comm = unsafe_pointer_to_objref(comm_ptr)::MPI.Comm
+    MPI.Allreduce!(unsafe_wrap(Array, x, Int(count)), +, comm)
+    return Cint(0)
+end
+const HOSTED_COMM = Ref{Any}(nothing)    # keeps the MPI.Comm alive whose address the library holds
+function comm_init_hosted_mpi(me::Integer, np::Integer, comm)
+    HOSTED_COMM[] = comm
+    send = @cfunction(hosted_send, Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Csize_t))
+    recv = @cfunction(hosted_recv, Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Csize_t))
+    allr = @cfunction(hosted_allreduce, Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint))
+    check(ccall((:fpr_comm_init_hosted, libfpr), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                ctx(), me, np, send, recv, allr, pointer_from_objref(comm)))
+end
+
 "`select_device()`: bind this rank to GPU (node-local rank mod device count); returns the 0-based device id."
 function select_device()
     loc = MPI.Comm_split_type(MPI.COMM_WORLD, MPI.COMM_TYPE_SHARED, MPI.Comm_rank(MPI.COMM_WORLD))
@@ -589,7 +620,11 @@ function init_global_grid(nx::Integer, ny::Integer, nz::Integer; dimx = 0, dimy 
     # neighbour, and the planes then travel through ncclSend / ncclRecv like between ranks), or when the world changed
     if !HAS_COMM[] || ccall((:fpr_comm_size, libfpr), Cint, (Ptr{Cvoid},), ctx()) != np || ccall((:fpr_comm_rank, libfpr), Cint, (Ptr{Cvoid},), ctx()) != me
         check(ccall((:fpr_comm_finalize, libfpr), Cint, (Ptr{Cvoid},), ctx()))
-        check(ccall((:fpr_comm_init, libfpr), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), ctx(), me, np, id))
+        if get(kwargs, :hosted_transport, false)
+            comm_init_hosted_mpi(me, np, comm)      # ranks sharing a card / no RCCL: the bytes travel through MPI, host-staged
+        else
+            check(ccall((:fpr_comm_init, libfpr), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), ctx(), me, np, id))
+        end
         HAS_COMM[] = true
     end
     me_o = Ref{Cint}(0); np_o = Ref{Cint}(0); dims = zeros(Cint, 3); coords = zeros(Cint, 3)

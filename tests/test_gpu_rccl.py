@@ -658,3 +658,53 @@ def test_bench_four_ranks_rehearsal_x_y_z_decompositions_agree():
         errs.append(out["config"]["last_err"])
     assert errs[0] is not None and 0.0 < errs[0] < 1.0
     assert abs(errs[1] - errs[0]) <= 1e-12 * errs[0] and abs(errs[2] - errs[0]) <= 1e-12 * errs[0]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_library_transport_between_processes_on_one_card(world, tmp_path):
+    """csrc/comm.hip's exchange code EXECUTED between real processes: fpr_grid_init's neighbour table,
+    post_group's receive-low-first / send-high-first order (both neighbours of a dimension the same rank; a rank that is its own
+    neighbour beside real ones), the pack / unpack kernels, the three forms of the exchange, the norm's all-reduce and gather! --
+    over the host-staged transport under post_group (fpr_comm_init_hosted; RCCL refuses two ranks on one device), against a numpy
+    model of update_halo! (part1_kernel_programming.jl:182,187; ImplicitGlobalGrid, overlap 2) on every process grid of
+    part1_scaling_experiments.jl:35-41 that `world` ranks allow.  tests/hosted_exchange_worker.py is one rank."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rdzv = str(tmp_path / "rdzv")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "hosted_exchange_worker.py"), str(r), str(world), rdzv],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=root) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=420)
+            outs.append((p.returncode, o, e))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0, "rank %d: %s" % (r, e[-3000:])
+        assert "rank %d of %d: %d grids OK" % (r, world, 8 if world == 2 else 4) in o
+
+
+def test_bench_two_ranks_rehearsal_python_twin_of_the_choreography():
+    """The rehearsals above run the LIBRARY's transport code and one-call pairs (--rehearse-transport hosted, the default since
+    round 5); the Python twin of the choreography (grid.HaloExchanger over gloo, GlobalGrid.step2_begin / _middle / _end) stays
+    covered too: same global problem, same norm."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--rehearse-transport", "python",
+                        "--n", "128", "--steps", "12", "--warmup", "4", "--no-cpu-baseline", "--no-secondary", "--no-single-leg", "--prewarm-ms", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["norm_check"]["ok"] is True and out["norm_check"]["key"] == "n128_dims1,1,2"
+    assert "Python HaloExchanger" in out["config"]["halo"]

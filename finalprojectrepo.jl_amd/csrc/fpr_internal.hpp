@@ -59,6 +59,13 @@ struct FprLevel {  // one multigrid level's scratch (role of prealloc_dict, mult
     double* coarse_own[3] = {nullptr, nullptr, nullptr};   // the library's own three while the caller's stand in (they come back as they were)
 };
 
+#ifndef FPR_JACP_TAGGED_DEFAULT
+#define FPR_JACP_TAGGED_DEFAULT 1  // k_jacobi_persist_tag (data-tagged hand-offs) instead of k_jacobi_persist (flags); option mg_jacp_tagged
+#endif
+#ifndef FPR_JACP_PY_DEFAULT
+#define FPR_JACP_PY_DEFAULT 1      // rows of a thread's register patch in k_jacobi_persist (option mg_jacp_py)
+#endif
+
 struct FprGrid {  // implicit global grid of the decomposed diffusion path (role of ImplicitGlobalGrid's global state)
     bool on = false;
     int n[3] = {0, 0, 0};        // local array size, halos included
@@ -107,6 +114,8 @@ struct fpr_ctx {
     int cgp_resident = -1;             // k_cg_persistent: 16 workgroups of 1024 threads resident together? (-1 = not asked yet)
     int cgp_resident64 = -1;      // the same for the 64-workgroup geometry of k_cg_persistent
     int jacp_resident = -1;       // k_jacobi_persist: workgroups of 256 threads the device holds at once (-1 = not asked yet)
+    long long jacp_epoch = 0;          // k_jacobi_persist_tag: solves so far (upper half of every granule's tag)
+    int jacp_resident_key = 0;         // (sweeps per group * 10 + patch rows) the occupancy answer above belongs to
     double* partials = nullptr;     // FPR_MAX_PARTIALS doubles: block partial sums (slot 0)
     double* partials2 = nullptr;    // second slot (comm stream / second reduction of a kernel)
     int ncu = 0;                       // compute units of the device (queried on first use)

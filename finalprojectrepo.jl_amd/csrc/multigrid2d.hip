@@ -1267,8 +1267,18 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             constexpr int S8 = 8, TX = 16, TY = 16;
             constexpr int PP = 32;
             const bool patch = fpr_opt(ctx, "mg_patch", 1) != 0;
-            int PS = (int)fpr_opt(ctx, "mg_patch_sweeps", 8);
-            if (PS < 6 || PS > 8) PS = 8;
+            int PS = (int)fpr_opt(ctx, "mg_patch_sweeps", 0);
+            if (PS < 6 || PS > 8) {
+                // default: 8 sweeps per group (own tiles of 16 x 16) -- or 7 (18 x 18) where that brings the number of workgroups from above
+                // the number of compute units to below it: the persistent kernels hand tiles from neighbour to neighbour, and a compute unit
+                // that holds two workgroups sets the pace for everybody (257^2: 289 -> 225 workgroups, 0.68 -> 0.54 us per sweep)
+                if (ctx->ncu <= 0) {
+                    int v = 0;
+                    ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
+                }
+                auto tiles = [&](int ps) { const int t = PP - 2 * ps; return (long)((nx + t - 1) / t) * ((ny + t - 1) / t); };
+                PS = (patch && tiles(8) > ctx->ncu && tiles(7) <= ctx->ncu && fpr_opt(ctx, "mg_jacobi_persist", 1) != 0) ? 7 : 8;
+            }
             const int S = patch ? PS : S8;
             const int TXp = patch ? PP - 2 * PS : TX, TYp = patch ? PP - 2 * PS : TY;
             const dim3 gm((nx + TXp - 1) / TXp, (ny + TYp - 1) / TYp);
@@ -1280,10 +1290,27 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             int g_resume = 0;          // the plain loop below starts at this group (> 0: behind a persistent launch that gave up)
             // ---- the persistent form: launches of up to 16 groups of 8 sweeps with neighbour-to-neighbour hand-offs inside
             //      (mg_jacobi_persistent.hpp); the plain form below stays for A/B, for grids it does not fit and as the replay ----
-            if (patch && PS == 8 && Sg == 8 && fpr_opt(ctx, "mg_jacobi_persist", 1) != 0 && (size_t)N * 8 < 0x7fffffffu) {
-                if (ctx->jacp_resident < 0) {
+            // (options mg_patch_sweeps = 7: groups of 7 sweeps on own tiles of 18 x 18 -- 225 workgroups for 257^2 instead of 289; mg_jacp_py = 1: 2 x 1 register
+            //  patches, 512 threads, two waves per SIMD)
+            const long pyv = fpr_opt(ctx, "mg_jacp_py", 0);
+            const int PYo = pyv == 2 ? 2 : (pyv == 1 ? 1 : FPR_JACP_PY_DEFAULT);
+            if (patch && (PS == 8 || PS == 7) && Sg == PS && fpr_opt(ctx, "mg_jacobi_persist", 1) != 0 && (size_t)N * 8 < 0x7fffffffu) {
+                const int jnt = (PP / 2) * (PP / PYo);
+                const int tgo = fpr_opt(ctx, "mg_jacp_tagged", FPR_JACP_TAGGED_DEFAULT) != 0 ? 1 : 0;
+                if (ctx->jacp_resident < 0 || ctx->jacp_resident_key != PS * 100 + PYo * 10 + tgo) {
                     int per_cu = 0;
-                    const bool ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist<8, PP>, (PP / 2) * (PP / 2), 0) == hipSuccess;
+                    hipError_t oe;
+                    if (tgo) {
+                        if (PS == 8) oe = PYo == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist_tag<8, PP, 2>, jnt, 0)
+                                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist_tag<8, PP, 1>, jnt, 0);
+                        else oe = PYo == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist_tag<7, PP, 2>, jnt, 0)
+                                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist_tag<7, PP, 1>, jnt, 0);
+                    } else if (PS == 8) oe = PYo == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist<8, PP, 2>, jnt, 0)
+                                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist<8, PP, 1>, jnt, 0);
+                    else oe = PYo == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist<7, PP, 2>, jnt, 0)
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist<7, PP, 1>, jnt, 0);
+                    const bool ok = oe == hipSuccess;
+                    ctx->jacp_resident_key = PS * 100 + PYo * 10 + tgo;
                     if (ctx->ncu <= 0) {
                         int v = 0;
                         ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
@@ -1291,8 +1318,109 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                     ctx->jacp_resident = ok ? per_cu * ctx->ncu : 0;    // workgroups the device holds at once
                 }
                 const int GMAX = 32;    // groups per launch: 256 sweeps, whose exit tests one workgroup replays behind the launch
+                // ---- the data-tagged form (k_jacobi_persist_tag: a cell travels as a 16-byte {value, tag} granule, no flags, no drains);
+                //      option mg_jacp_tagged = 0: the flag form below ----
+                {
+                    CgWork w2;
+                    if (fpr_opt(ctx, "mg_jacp_tagged", FPR_JACP_TAGGED_DEFAULT) != 0 && nblk <= ctx->jacp_resident / 2 &&
+                        (size_t)GMAX * PS * nblk <= (size_t)FPR_MAX_PARTIALS - 2048 && (size_t)N * 16 < 0x7fffffffu && cg_work(ctx, 2 * N, &w2) == FPR_OK) {
+                        void* Gb[4] = {w2.r, w2.p, w2.ph, w2.x};     // four rotating granule buffers (2 N doubles each)
+                        double* P0 = w2.p2;                          // plain scratch (N doubles): the input of a launch that is replayed
+                        int* flags = reinterpret_cast<int*>(ctx->partials + FPR_MAX_PARTIALS - 1024);
+                        int* abort_flag = flags + 2040;
+                        int* counter = flags + 2041;
+                        double* gsums = ctx->partials + FPR_MAX_PARTIALS - 2048;
+                        FPR_HIP(ctx, hipMemsetAsync(flags, 0, 2048 * sizeof(int), s));
+                        const long long tag_base = (long long)(++ctx->jacp_epoch) << 32;   // tags of one solve never meet another solve's
+                        struct RecT { int x, w[3], g0, G; };             // x = -1: the plain field u (first launch)
+                        std::vector<RecT> recs;
+                        int cur = -1, gdone = 0, poll_after = 1, since_poll = 0;
+                        const unsigned ugrid = (unsigned)((N + 255) / 256);
+                        while (gdone < groups) {
+                            const int G = groups - gdone < GMAX ? groups - gdone : GMAX;
+                            RecT r;
+                            r.x = cur; r.g0 = gdone; r.G = G;
+                            for (int k = 0, q = 0; k < 4 && q < 3; ++k) if (k != cur) r.w[q++] = k;
+                            JacTagArgs a;
+                            a.X = u; a.Xg = cur >= 0 ? Gb[cur] : nullptr; a.x_tagged = cur >= 0 ? 1 : 0;
+                            for (int q = 0; q < 3; ++q) a.W[q] = Gb[r.w[q]];
+                            a.rhs = rhs; a.nx = nx; a.ny = ny; a.C = C; a._h2 = _h2; a.fac = fac;
+                            a.ngroups = G;
+                            a.nsw_last = (gdone + G == groups) ? iters - (groups - 1) * PS : PS;
+                            a.partials = ctx->partials; a.abort_flag = abort_flag; a.state = ctx->state;
+                            a.g0 = gdone; a.tag_base = tag_base;
+                            a.prof = fpr_opt(ctx, "mg_jacp_prof", 0) != 0 ? reinterpret_cast<long long*>(fpr_opt(ctx, "mg_jacp_prof", 0)) : nullptr;
+                            if ((long)recs.size() + 1 == fpr_opt(ctx, "mg_jacobi_persist_test_abort", 0))      // (test hook: this launch "times out")
+                                FPR_HIP(ctx, hipMemsetAsync(abort_flag, 1, 1, s));
+                            const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_PATCH, s);
+                            if (PS == 8) { if (PYo == 2) k_jacobi_persist_tag<8, PP, 2><<<gm, jnt, 0, s>>>(a); else k_jacobi_persist_tag<8, PP, 1><<<gm, jnt, 0, s>>>(a); }
+                            else { if (PYo == 2) k_jacobi_persist_tag<7, PP, 2><<<gm, jnt, 0, s>>>(a); else k_jacobi_persist_tag<7, PP, 1><<<gm, jnt, 0, s>>>(a); }
+                            fpr_ktimer_end(ctx, timed, s);
+                            k_jacobi_check_groups<<<G, 256, 0, s>>>(ctx->state, ctx->partials, nblk, G, PS, a.nsw_last, (double)N, gdone, abort_flag, gsums, counter);
+                            FPR_CHECK_LAUNCH(ctx);
+                            recs.push_back(r);
+                            cur = r.w[G % 3];                  // the last group (index G - 1) wrote W[G % 3]
+                            gdone += G;
+                            if (++since_poll >= poll_after || gdone >= groups) {
+                                since_poll = 0;
+                                if (poll_after < 8) poll_after *= 2;
+                                if (int rc = read_state(ctx)) return rc;
+                                if (ctx->state_h->done) break;
+                            }
+                        }
+                        // the input of launch `r` as plain doubles in `dst`
+                        auto input_to = [&](const RecT& r, double* dst) -> int {
+                            if (r.x < 0) { if (dst != u) FPR_HIP(ctx, hipMemcpyAsync(dst, u, N * sizeof(double), hipMemcpyDeviceToDevice, s)); }
+                            else k_jacp_untag<<<ugrid, 256, 0, s>>>(Gb[r.x], dst, N);
+                            FPR_CHECK_LAUNCH(ctx);
+                            return FPR_OK;
+                        };
+                        if (ctx->state_h->done < 0) {
+                            // a wait timed out (see the flag form below): resume with the plain launches from the input of the launch that gave up
+                            const RecT* r = nullptr;
+                            for (const RecT& q : recs) if (q.g0 == ctx->state_h->group) r = &q;
+                            if (!r) return fpr_fail(ctx, FPR_ERR_HIP, "k_jacobi_persist_tag: a hand-off timed out and the launch that gave up is unknown");
+                            ctx->jacp_resident = 0;
+                            ctx->options["mg_jacobi_persist_timeouts"] = fpr_opt(ctx, "mg_jacobi_persist_timeouts", 0) + 1;
+                            FPR_HIP(ctx, hipMemsetAsync(flags, 0, 2048 * sizeof(int), s));
+                            if (int rc = input_to(*r, (r->g0 & 1) ? L.tmp : u)) return rc;      // the plain loop reads group gi from u (even) / L.tmp (odd)
+                            k_state_resume<<<1, 1, 0, s>>>(ctx->state);
+                            FPR_CHECK_LAUNCH(ctx);
+                            ctx->state_h->done = 0;
+                            g_resume = r->g0;
+                            goto plain_jacobi_groups;
+                        }
+                        if (ctx->state_h->done) {
+                            // the criterion was met inside launch `r`: replay the exact number of sweeps from that launch's input with the ordinary launches
+                            const int gs = ctx->state_h->group, redo = ctx->state_h->redo;
+                            const RecT* r = nullptr;
+                            for (const RecT& q : recs) if (gs >= q.g0 && gs < q.g0 + q.G) r = &q;
+                            if (!r) return fpr_fail(ctx, FPR_ERR_INVALID, "k_jacobi_persist_tag: exit group outside the launches");
+                            if (int rc = input_to(*r, P0)) return rc;
+                            int left = (gs - r->g0) * PS + redo;
+                            const double* in = P0;
+                            int o = 0;
+                            while (left > 0) {
+                                const int m = left < PS ? left : PS;
+                                double* out = (o & 1) ? u : L.tmp;
+                                if (PS == 8) k_jacobi_patch<8, PP, false, false><<<gm, (PP / 2) * (PP / 2), 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, m, nullptr, nullptr, nullptr, 0, 0, 0.0);
+                                else k_jacobi_patch<7, PP, false, false><<<gm, (PP / 2) * (PP / 2), 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, m, nullptr, nullptr, nullptr, 0, 0, 0.0);
+                                in = out; ++o; left -= m;
+                            }
+                            FPR_CHECK_LAUNCH(ctx);
+                            if (in != u) FPR_HIP(ctx, hipMemcpyAsync(u, in, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+                        } else {
+                            k_jacp_untag<<<ugrid, 256, 0, s>>>(Gb[cur], u, N);
+                            FPR_CHECK_LAUNCH(ctx);
+                        }
+                        ctx->last_coarse_iters += ctx->state_h->iters;
+                        *rms_out_host = ctx->state_h->last_rms;
+                        *rms_is_host = true;
+                        return FPR_OK;
+                    }
+                }
                 CgWork w;
-                if (nblk <= ctx->jacp_resident / 2 && (size_t)GMAX * 8 * nblk <= (size_t)FPR_MAX_PARTIALS - 2048 && cg_work(ctx, N, &w) == FPR_OK) {
+                if (nblk <= ctx->jacp_resident / 2 && (size_t)GMAX * PS * nblk <= (size_t)FPR_MAX_PARTIALS - 2048 && cg_work(ctx, N, &w) == FPR_OK) {
                     double* B[4] = {u, L.tmp, w.r, w.p};
                     int* flags = reinterpret_cast<int*>(ctx->partials + FPR_MAX_PARTIALS - 1024);   // nblk <= 2048 words + the abort word
                     if (nblk + 8 > 2048) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for the flag block");
@@ -1315,15 +1443,20 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                         // (group g of a launch reads X for g = 0, else W[g % 3], and writes W[(g + 1) % 3])
                         a.rhs = rhs; a.nx = nx; a.ny = ny; a.C = C; a._h2 = _h2; a.fac = fac;
                         a.ngroups = G;
-                        a.nsw_last = (gdone + G == groups) ? iters - (groups - 1) * 8 : 8;
+                        a.nsw_last = (gdone + G == groups) ? iters - (groups - 1) * PS : PS;
                         a.partials = ctx->partials; a.flags = flags; a.abort_flag = abort_flag; a.state = ctx->state;
                         a.g0 = gdone;
+                        a.prof = nullptr;
+                        if (fpr_opt(ctx, "mg_jacp_prof", 0) != 0) {      // diagnostic: 8 words per workgroup behind the solver's work vectors (tools/exp_jacp_prof.py)
+                            a.prof = reinterpret_cast<long long*>(fpr_opt(ctx, "mg_jacp_prof", 0));
+                        }
                         if ((long)recs.size() + 1 == fpr_opt(ctx, "mg_jacobi_persist_test_abort", 0))      // (test hook: this launch "times out")
                             FPR_HIP(ctx, hipMemsetAsync(abort_flag, 1, 1, s));
                         const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_PATCH, s);
-                        k_jacobi_persist<8, PP><<<gm, (PP / 2) * (PP / 2), 0, s>>>(a);
+                        if (PS == 8) { if (PYo == 2) k_jacobi_persist<8, PP, 2><<<gm, jnt, 0, s>>>(a); else k_jacobi_persist<8, PP, 1><<<gm, jnt, 0, s>>>(a); }
+                        else { if (PYo == 2) k_jacobi_persist<7, PP, 2><<<gm, jnt, 0, s>>>(a); else k_jacobi_persist<7, PP, 1><<<gm, jnt, 0, s>>>(a); }
                         fpr_ktimer_end(ctx, timed, s);
-                        k_jacobi_check_groups<<<G, 256, 0, s>>>(ctx->state, ctx->partials, nblk, G, 8, a.nsw_last, (double)N, gdone, abort_flag, gsums, counter);
+                        k_jacobi_check_groups<<<G, 256, 0, s>>>(ctx->state, ctx->partials, nblk, G, PS, a.nsw_last, (double)N, gdone, abort_flag, gsums, counter);
                         FPR_CHECK_LAUNCH(ctx);
                         recs.push_back(r);
                         cur = r.w[G % 3];                  // the last group (index G - 1) wrote W[G % 3]
@@ -1369,13 +1502,14 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                         const Rec* r = nullptr;
                         for (const Rec& q : recs) if (gs >= q.g0 && gs < q.g0 + q.G) r = &q;
                         if (!r) return fpr_fail(ctx, FPR_ERR_INVALID, "k_jacobi_persist: exit group outside the launches");
-                        int left = (gs - r->g0) * 8 + redo;
+                        int left = (gs - r->g0) * PS + redo;
                         const double* in = B[r->x];
                         int o = 0;
                         while (left > 0) {
-                            const int m = left < 8 ? left : 8;
+                            const int m = left < PS ? left : PS;
                             double* out = B[r->w[o & 1]];
-                            k_jacobi_patch<8, PP, false, false><<<gm, (PP / 2) * (PP / 2), 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, m, nullptr, nullptr, nullptr, 0, 0, 0.0);
+                            if (PS == 8) k_jacobi_patch<8, PP, false, false><<<gm, (PP / 2) * (PP / 2), 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, m, nullptr, nullptr, nullptr, 0, 0, 0.0);
+                            else k_jacobi_patch<7, PP, false, false><<<gm, (PP / 2) * (PP / 2), 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, m, nullptr, nullptr, nullptr, 0, 0, 0.0);
                             in = out; ++o; left -= m;
                         }
                         FPR_CHECK_LAUNCH(ctx);

@@ -424,8 +424,9 @@ def test_coarse_jacobi_exit_inside_a_fused_group(fpr, oracle, tol):
         assert np.array_equal(F.tonumpy(gu), u_ref)
 
 
+@pytest.mark.parametrize("tagged", [1, 0])
 @pytest.mark.parametrize("tol", [0.5, 0.2, 0.05, 0.02, 1e-9])
-def test_coarse_jacobi_persistent_launches_equal_the_plain_ones(fpr, oracle, tol):
+def test_coarse_jacobi_persistent_launches_equal_the_plain_ones(fpr, oracle, tol, tagged):
     """k_jacobi_persist (up to 32 groups of 8 sweeps per launch, tiles handed from neighbour to neighbour, exit test behind the
     launch and the exact number of sweeps replayed from the launch's input) against one launch per 8 sweeps and against the
     oracle: a 257 x 129 coarse grid solved directly by Vcycle_2DPoisson! (:147-159) with exits in the first launch, in a later
@@ -442,6 +443,8 @@ def test_coarse_jacobi_persistent_launches_equal_the_plain_ones(fpr, oracle, tol
     outs = []
     c = F.ctx()
     try:
+        # tagged = 1: k_jacobi_persist_tag (every cell a {value, tag} granule, no flags); 0: k_jacobi_persist (flags)
+        c.set_option("mg_jacp_tagged", tagged)
         for persist in (1, 0):
             c.set_option("mg_jacobi_persist", persist)
             gu = F.asdevice(u0)
@@ -449,14 +452,16 @@ def test_coarse_jacobi_persistent_launches_equal_the_plain_ones(fpr, oracle, tol
             outs.append((r, F.tonumpy(gu)))
     finally:
         c.set_option("mg_jacobi_persist", 1)
+        c.set_option("mg_jacp_tagged", 1)
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
     assert abs(outs[0][0] - r_ref) <= 1e-12 * abs(r_ref)
     assert np.array_equal(outs[0][1], u_ref)
     assert it_ref > 0
 
 
+@pytest.mark.parametrize("tagged", [1, 0])
 @pytest.mark.parametrize("tol,abort_launch", [(1e-9, 1), (1e-9, 2), (1e-9, 4), (0.02, 1), (0.02, 3)])
-def test_coarse_jacobi_persistent_launch_that_gives_up_is_resumed_by_the_plain_ones(fpr, oracle, tol, abort_launch):
+def test_coarse_jacobi_persistent_launch_that_gives_up_is_resumed_by_the_plain_ones(fpr, oracle, tol, abort_launch, tagged):
     """A neighbour hand-off of k_jacobi_persist that times out (workgroups not resident together: a shared card) must not fail the
     solve: the launch that gave up never wrote its input, so the solve resumes there with one launch per 8 sweeps, the context
     stays off the persistent form and counts the event (option mg_jacobi_persist_timeouts), and the result is the oracle's bit for
@@ -473,6 +478,7 @@ def test_coarse_jacobi_persistent_launch_that_gives_up_is_resumed_by_the_plain_o
     r_ref = oracle.vcycle2d(u_ref, f, h, 0.0, tol, 257, 0, False)
     it_ref = oracle.last_coarse_iters() - it0
     c = F.ctx()
+    c.set_option("mg_jacp_tagged", tagged)
     c.set_option("mg_jacobi_persist", 1)
     before = c.L.fpr_get_option(c.h, b"mg_jacobi_persist_timeouts")
     launches_needed = -(-it_ref // 256)
@@ -488,6 +494,7 @@ def test_coarse_jacobi_persistent_launch_that_gives_up_is_resumed_by_the_plain_o
         r2 = mg.Vcycle_2DPoisson_(gu2, F.asdevice(f), h, 0.0, tol, 257, mg.jacobi, mg.parallel_shmem, False)
     finally:
         c.set_option("mg_jacobi_persist_test_abort", 0)
+        c.set_option("mg_jacp_tagged", 1)
         c.set_option("mg_jacobi_persist", 1)           # lifts the switch again
     assert abs(r - r_ref) <= 1e-12 * abs(r_ref) and r2 == r
     assert np.array_equal(F.tonumpy(gu), u_ref) and np.array_equal(F.tonumpy(gu2), u_ref)

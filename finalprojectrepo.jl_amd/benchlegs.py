@@ -249,9 +249,10 @@ def vcycle_block(F, cpu_vcycle=None, steps=5, place=True):
     us_per_launch = pt_ms * 1e3 / pt_launches if pt_launches else None
     jac_sweeps = max(out["l8_jacobi"]["coarse_iters"], 1)
     us_per_sweep = pt_ms * 1e3 / jac_sweeps if pt_ms > 0 else None
-    # a sweep of the 257^2 grid inside a launch: 0.35-0.45 us (tools/exp_patch_sweeps.py: 8.5 / 8.75 / 9.5 / 12.1 us for launches of
-    # 1 / 2 / 4 / 8 sweeps); everything above that is hand-off between groups of sweeps
-    PATCH_SWEEP_US = 0.40
+    # a sweep of the 257^2 grid inside a group of the persistent kernel: 0.24 us (tools/exp_jacp_prof.py, profiles/r5_jacp_prof.txt: 1.66 us
+    # for the 7 sweeps of a group on 225 workgroups of 512 threads); everything above that is the hand-off between groups (tile out as
+    # tagged granules, the neighbours' tiles in: one store -> load round trip) and the sums of the exit test
+    PATCH_SWEEP_US = 0.24
     five = {"metric": "vcycle_wall_time_4097sq_5levels", "unit": "s", "higher_is_better": False, "dtype": "f64",
             "config": {"workload": "2D Poisson V-cycle 4097^2, 5 grids (4097^2 ... 257^2, l = 8), 2+2 Jacobi smooths; "
                                    "multigrid_bench.jl protocol (x=0, b~U[0,1), c=0, tol 1e-6); coarse solve = cg! or 20*257 "
@@ -274,15 +275,15 @@ def vcycle_block(F, cpu_vcycle=None, steps=5, place=True):
             "jacobi": {
                 "value": out["l8_jacobi"]["s_per_vcycle"], "unit": "s", "mgsolve_s": out["l8_jacobi"]["mgsolve_s"], "vcycles": out["l8_jacobi"]["vcycles"],
                 "coarse_iters": out["l8_jacobi"]["coarse_iters"],
-                "roofline": {"bound": "latency", "kernel": "k_jacobi_persist (up to 16 groups of 8 sweeps of the 257^2 grid per launch: 32x32 regions as 2x2 "
-                                                           "register patches, edges through LDS; between groups the tiles travel from neighbour to "
-                                                           "neighbour: sc1 stores, a flag word per workgroup, sc1 loads; exit test behind the launch)",
+                "roofline": {"bound": "latency", "kernel": "k_jacobi_persist_tag (up to 32 groups of 7 sweeps of the 257^2 grid per launch: 225 workgroups, 32x32 regions as 2x1 "
+                                                           "register patches, rows through LDS; between groups every cell travels from neighbour to "
+                                                           "neighbour as a 16-byte {value, tag} granule: one sc1 store, one sc1 load, no flags; exit test behind the launch)",
                              "achieved": us_per_sweep, "peak": PATCH_SWEEP_US, "unit": "us per sweep",
                              "frac": (PATCH_SWEEP_US / us_per_sweep) if us_per_sweep else None,
                              "us_per_launch": us_per_launch, "launches_timed": pt_launches, "sweeps": jac_sweeps, "traffic": None,
                              "note": "achieved = hipEvent time of the coarse-solver launches of one solve / sweeps; peak = the cost of a sweep "
-                                     "inside a launch (0.40 us); frac = how much of the time is sweeps rather than hand-offs between groups "
-                                     "(round 3: one launch per 8 sweeps, 1.5 us per sweep)"}}}
+                                     "inside a group (0.24 us); frac = how much of the time is sweeps rather than hand-offs between groups "
+                                     "(round 3: one launch per 8 sweeps, 1.5 us per sweep; round 4: flags between neighbours, 0.75 us)"}}}
     if with_cpu:
         for key, solver in (("conjugate_gradient", 1), ("jacobi", 0)):
             try:

@@ -50,30 +50,36 @@ for form, wgs in ((2, 64), (3, 64), (3, 16)):
 c.set_option("cg_fused", 3)
 c.set_option("cg_persistent_wgs", 64)
 print("cg!: %d solves of %d iterations, %d mismatches, %d barrier time-outs, %.1f s" % (2 * reps + 2, ref[1], bad, c.get_option("cg_persistent_timeouts"), time.time() - t0), flush=True)
-# ---- Jacobi coarse solve on 257 x 129 directly (cap 5140 sweeps) and with an exit inside a launch ----
-shape = (257, 129)
-u0 = F.part2.splitmix64_uniform(shape[0] * shape[1], 7).reshape(shape, order="F")
-f = F.part2.splitmix64_uniform(shape[0] * shape[1], 8).reshape(shape, order="F")
-f[0, :] = f[-1, :] = 0.0
-f[:, 0] = f[:, -1] = 0.0
-gf = F.asdevice(f)
+# ---- Jacobi coarse solve directly (cap 5140 sweeps) and with an exit inside a launch: 257 x 129 (153 workgroups, groups of 8 sweeps) and
+#      257 x 257 (225 workgroups, groups of 7); the data-tagged hand-off (k_jacobi_persist_tag, default) and the flag form ----
 t0 = time.time()
-for tol in (1e-9, 0.05):
-    ref = None
-    for persist, n_rep in ((0, 1), (1, reps // 4)):
-        c.set_option("mg_jacobi_persist", persist)
-        for i in range(n_rep):
-            if i % 4 == 0:
-                noise()
-            gu = F.asdevice(u0)
-            r = mg.Vcycle_2DPoisson_(gu, gf, 1.0 / 128, 0.0, tol, 257, mg.jacobi, mg.parallel_shmem, False)
-            got = (r, F.tonumpy(gu))
-            if ref is None:
-                ref = got
-            elif not (got[0] == ref[0] and np.array_equal(got[1], ref[1])):
-                bad += 1
-                print("jacobi mismatch: tol %g rep %d" % (tol, i), flush=True)
+nsolves = 0
+for shape in ((257, 129), (257, 257)):
+    u0 = F.part2.splitmix64_uniform(shape[0] * shape[1], 7).reshape(shape, order="F")
+    f = F.part2.splitmix64_uniform(shape[0] * shape[1], 8).reshape(shape, order="F")
+    f[0, :] = f[-1, :] = 0.0
+    f[:, 0] = f[:, -1] = 0.0
+    gf = F.asdevice(f)
+    for tol in (1e-9, 0.05):
+        ref = None
+        for persist, tagged, n_rep in ((0, 1, 1), (1, 1, reps // 4), (1, 0, max(reps // 16, 2))):
+            c.set_option("mg_jacobi_persist", persist)
+            c.set_option("mg_jacp_tagged", tagged)
+            for i in range(n_rep):
+                if i % 4 == 0:
+                    noise()
+                gu = F.asdevice(u0)
+                r = mg.Vcycle_2DPoisson_(gu, gf, 1.0 / 128, 0.0, tol, 257, mg.jacobi, mg.parallel_shmem, False)
+                got = (r, F.tonumpy(gu))
+                nsolves += persist
+                if ref is None:
+                    ref = got
+                elif not (abs(got[0] - ref[0]) <= 1e-13 * abs(ref[0]) and np.array_equal(got[1], ref[1])):
+                    bad += 1
+                    print("jacobi mismatch: shape %s tol %g tagged %d rep %d: r %.17g vs %.17g, %d cells differ"
+                          % (shape, tol, tagged, i, got[0], ref[0], int((got[1] != ref[1]).sum())), flush=True)
+c.set_option("mg_jacp_tagged", 1)
 c.set_option("mg_jacobi_persist", 1)
 torch.cuda.synchronize()
-print("jacobi: %d persistent solves per tolerance, %d mismatches in all, %.1f s" % (reps // 4, bad, time.time() - t0), flush=True)
+print("jacobi: %d persistent solves, %d mismatches in all, %d hand-off time-outs, %.1f s" % (nsolves, bad, c.get_option("mg_jacobi_persist_timeouts"), time.time() - t0), flush=True)
 sys.exit(1 if bad else 0)

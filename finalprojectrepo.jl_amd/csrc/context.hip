@@ -66,6 +66,8 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
     if (ctx->tickets) hipFree(ctx->tickets);
     if (ctx->xstrips) hipFree(ctx->xstrips);
     if (ctx->ns_ev) hipEventDestroy(ctx->ns_ev);
+    if (ctx->aux_stream) { hipStreamSynchronize(ctx->aux_stream); hipStreamDestroy(ctx->aux_stream); }
+    for (auto& e : ctx->aux_ev) if (e) hipEventDestroy(e);
     fprx_ns_worker_free(ctx);
     if (ctx->reserved_map) hipFree(ctx->reserved_map);
     if (ctx->scalars) hipFree(ctx->scalars);

@@ -114,6 +114,8 @@ struct fpr_ctx {
     int cgp_resident = -1;             // k_cg_persistent: 16 workgroups of 1024 threads resident together? (-1 = not asked yet)
     int cgp_resident64 = -1;      // the same for the 64-workgroup geometry of k_cg_persistent
     int jacp_resident = -1;       // k_jacobi_persist: workgroups of 256 threads the device holds at once (-1 = not asked yet)
+    hipStream_t aux_stream = nullptr;  // k_jacobi_persist_tag: the exit tests of a launch run here, beside the next launch
+    hipEvent_t aux_ev[3] = {nullptr, nullptr, nullptr};   // [0] compute -> side stream; [1], [2] the tests of even / odd launches
     long long jacp_epoch = 0;          // k_jacobi_persist_tag: solves so far (upper half of every granule's tag)
     int jacp_resident_key = 0;         // (sweeps per group * 10 + patch rows) the occupancy answer above belongs to
     double* partials = nullptr;     // FPR_MAX_PARTIALS doubles: block partial sums (slot 0)

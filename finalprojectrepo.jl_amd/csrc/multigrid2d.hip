@@ -1323,9 +1323,24 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                 {
                     CgWork w2;
                     if (fpr_opt(ctx, "mg_jacp_tagged", FPR_JACP_TAGGED_DEFAULT) != 0 && nblk <= ctx->jacp_resident / 2 &&
-                        (size_t)GMAX * PS * nblk <= (size_t)FPR_MAX_PARTIALS - 2048 && (size_t)N * 16 < 0x7fffffffu && cg_work(ctx, 2 * N, &w2) == FPR_OK) {
-                        void* Gb[4] = {w2.r, w2.p, w2.ph, w2.x};     // four rotating granule buffers (2 N doubles each)
-                        double* P0 = w2.p2;                          // plain scratch (N doubles): the input of a launch that is replayed
+                        (size_t)2 * GMAX * PS * nblk <= (size_t)FPR_MAX_PARTIALS - 2048 && (size_t)N * 16 < 0x7fffffffu && cg_work(ctx, 3 * N, &w2) == FPR_OK) {
+                        // five rotating granule buffers (2 N doubles each): a launch reads one, writes three, and leaves the input of the launch
+                        // BEFORE it alone -- the exit test of that launch runs beside it (below) and may still ask for a replay from there
+                        void* Gb[5];
+                        for (int k = 0; k < 5; ++k) Gb[k] = w2.r + (size_t)2 * N * k;
+                        double* P0 = w2.r + (size_t)10 * N;          // plain scratch (N doubles): the input of a launch that is replayed
+                        // The exit tests of a launch (k_jacobi_check_groups: 8 us) run on a side stream BESIDE the next launch instead of between
+                        // two launches: the partial sums alternate between two halves of the scratch, and a launch that starts before the tests of
+                        // its predecessor have found the exit only wastes itself (it reads `done` at its start; everything behind it sees it).
+                        if (!ctx->aux_stream) {
+                            FPR_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+                            for (int k = 0; k < 3; ++k) FPR_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev[k], hipEventDisableTiming));
+                        }
+                        // (measured: 3.63 ms per five-level V-cycle beside against 3.37 in line -- two cross-stream event waits per launch cost more
+                        //  than the 8 us test they hide: option mg_jacp_check_beside, default off)
+                        const bool beside = fpr_opt(ctx, "mg_jacp_check_beside", 0) != 0;
+                        hipStream_t sc = beside ? ctx->aux_stream : s;
+                        const size_t phalf = (size_t)GMAX * PS * nblk;
                         int* flags = reinterpret_cast<int*>(ctx->partials + FPR_MAX_PARTIALS - 1024);
                         int* abort_flag = flags + 2040;
                         int* counter = flags + 2041;
@@ -1334,20 +1349,31 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                         const long long tag_base = (long long)(++ctx->jacp_epoch) << 32;   // tags of one solve never meet another solve's
                         struct RecT { int x, w[3], g0, G; };             // x = -1: the plain field u (first launch)
                         std::vector<RecT> recs;
-                        int cur = -1, gdone = 0, poll_after = 1, since_poll = 0;
+                        int cur = -1, prevx = -1, gdone = 0, poll_after = 1, since_poll = 0;
                         const unsigned ugrid = (unsigned)((N + 255) / 256);
+                        if (beside) {      // the side stream starts behind everything the solve's inputs depend on
+                            FPR_HIP(ctx, hipEventRecord(ctx->aux_ev[0], s));
+                            FPR_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_ev[0], 0));
+                        }
+                        auto state_now = [&]() -> int {      // the host's view of the solve: behind the tests enqueued so far
+                            if (beside && !recs.empty()) FPR_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_ev[1 + ((recs.size() - 1) & 1)], 0));
+                            return read_state(ctx);
+                        };
                         while (gdone < groups) {
                             const int G = groups - gdone < GMAX ? groups - gdone : GMAX;
                             RecT r;
                             r.x = cur; r.g0 = gdone; r.G = G;
-                            for (int k = 0, q = 0; k < 4 && q < 3; ++k) if (k != cur) r.w[q++] = k;
+                            for (int k = 0, q = 0; k < 5 && q < 3; ++k) if (k != cur && k != prevx) r.w[q++] = k;
+                            double* parts = ctx->partials + (recs.size() & 1) * phalf;
+                            // (this launch overwrites the partial sums of the launch before the last one: its tests are through)
+                            if (beside && recs.size() >= 2) FPR_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_ev[1 + (recs.size() & 1)], 0));
                             JacTagArgs a;
                             a.X = u; a.Xg = cur >= 0 ? Gb[cur] : nullptr; a.x_tagged = cur >= 0 ? 1 : 0;
                             for (int q = 0; q < 3; ++q) a.W[q] = Gb[r.w[q]];
                             a.rhs = rhs; a.nx = nx; a.ny = ny; a.C = C; a._h2 = _h2; a.fac = fac;
                             a.ngroups = G;
                             a.nsw_last = (gdone + G == groups) ? iters - (groups - 1) * PS : PS;
-                            a.partials = ctx->partials; a.abort_flag = abort_flag; a.state = ctx->state;
+                            a.partials = parts; a.abort_flag = abort_flag; a.state = ctx->state;
                             a.g0 = gdone; a.tag_base = tag_base;
                             a.prof = fpr_opt(ctx, "mg_jacp_prof", 0) != 0 ? reinterpret_cast<long long*>(fpr_opt(ctx, "mg_jacp_prof", 0)) : nullptr;
                             if ((long)recs.size() + 1 == fpr_opt(ctx, "mg_jacobi_persist_test_abort", 0))      // (test hook: this launch "times out")
@@ -1356,18 +1382,25 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                             if (PS == 8) { if (PYo == 2) k_jacobi_persist_tag<8, PP, 2><<<gm, jnt, 0, s>>>(a); else k_jacobi_persist_tag<8, PP, 1><<<gm, jnt, 0, s>>>(a); }
                             else { if (PYo == 2) k_jacobi_persist_tag<7, PP, 2><<<gm, jnt, 0, s>>>(a); else k_jacobi_persist_tag<7, PP, 1><<<gm, jnt, 0, s>>>(a); }
                             fpr_ktimer_end(ctx, timed, s);
-                            k_jacobi_check_groups<<<G, 256, 0, s>>>(ctx->state, ctx->partials, nblk, G, PS, a.nsw_last, (double)N, gdone, abort_flag, gsums, counter);
+                            if (beside) {
+                                FPR_HIP(ctx, hipEventRecord(ctx->aux_ev[0], s));
+                                FPR_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_ev[0], 0));
+                            }
+                            k_jacobi_check_groups<<<G, 256, 0, sc>>>(ctx->state, parts, nblk, G, PS, a.nsw_last, (double)N, gdone, abort_flag, gsums, counter);
                             FPR_CHECK_LAUNCH(ctx);
+                            if (beside) FPR_HIP(ctx, hipEventRecord(ctx->aux_ev[1 + (recs.size() & 1)], ctx->aux_stream));
                             recs.push_back(r);
+                            prevx = cur;
                             cur = r.w[G % 3];                  // the last group (index G - 1) wrote W[G % 3]
                             gdone += G;
                             if (++since_poll >= poll_after || gdone >= groups) {
                                 since_poll = 0;
                                 if (poll_after < 8) poll_after *= 2;
-                                if (int rc = read_state(ctx)) return rc;
+                                if (int rc = state_now()) return rc;
                                 if (ctx->state_h->done) break;
                             }
                         }
+                        // (the compute stream is behind every test now: state_now() made it wait for the side stream)
                         // the input of launch `r` as plain doubles in `dst`
                         auto input_to = [&](const RecT& r, double* dst) -> int {
                             if (r.x < 0) { if (dst != u) FPR_HIP(ctx, hipMemcpyAsync(dst, u, N * sizeof(double), hipMemcpyDeviceToDevice, s)); }

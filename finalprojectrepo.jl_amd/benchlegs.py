@@ -257,7 +257,9 @@ def vcycle_block(F, cpu_vcycle=None, steps=5, place=True):
             "config": {"workload": "2D Poisson V-cycle 4097^2, 5 grids (4097^2 ... 257^2, l = 8), 2+2 Jacobi smooths; "
                                    "multigrid_bench.jl protocol (x=0, b~U[0,1), c=0, tol 1e-6); coarse solve = cg! or 20*257 "
                                    "damped-Jacobi sweeps (the reference's default coarse solver)"},
-            "value": out["l8_cg"]["s_per_vcycle"], "value_is": "conjugate_gradient (the faster coarse solver, as in the reference's table)",
+            "value": min(out["l8_cg"]["s_per_vcycle"], out["l8_jacobi"]["s_per_vcycle"]),
+            "value_is": ("conjugate_gradient" if out["l8_cg"]["s_per_vcycle"] <= out["l8_jacobi"]["s_per_vcycle"] else
+                         "jacobi (the reference's default coarse solver)") + ": the faster of the two coarse solvers on this run; both are reported below",
             "conjugate_gradient": {
                 "value": out["l8_cg"]["s_per_vcycle"], "unit": "s", "mgsolve_s": out["l8_cg"]["mgsolve_s"], "vcycles": out["l8_cg"]["vcycles"],
                 "coarse_iters": out["l8_cg"]["coarse_iters"],
@@ -290,8 +292,8 @@ def vcycle_block(F, cpu_vcycle=None, steps=5, place=True):
                 five[key]["cpu_baseline"] = cpu_vcycle(n, b_host, 257, solver)
             except Exception as e:
                 five[key]["cpu_baseline"] = {"value": None, "unit": "s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-        five["cpu_baseline"] = five["conjugate_gradient"]["cpu_baseline"]
-    five["roofline"] = five["conjugate_gradient"]["roofline"]
+        five["cpu_baseline"] = five["conjugate_gradient" if five["value_is"].startswith("conjugate") else "jacobi"]["cpu_baseline"]
+    five["roofline"] = five["conjugate_gradient" if five["value_is"].startswith("conjugate") else "jacobi"]["roofline"]
     block["vcycle_5levels"] = five
     return block
 

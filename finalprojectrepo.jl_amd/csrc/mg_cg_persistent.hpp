@@ -39,6 +39,9 @@ struct CgpArgs {
     int pow2;              // hx2 and hy2 are powers of two (every grid of the multigrid hierarchy: h = 2^-k): x / hx2 == x * (1 / hx2) bit for
                            // bit -- an exact scaling either way -- and the operator needs no division (two per point: ~0.4 us per iteration)
     long long* prof;       // diagnostic (option cg_prof = device address of 8 int64): ticks of workgroup 0 per section, summed
+    int fences;            // option handoff_fences = 1: the hand-off of the r edges ALSO inside the HIP memory model -- an agent-scope release
+                           // fence (buffer_wbl2 sc1) in front of the barrier words and an acquire fence (buffer_inv sc1) behind the poll, on top
+                           // of the sc1 stores / drains / sc1 loads that carry it by themselves on gfx950 (the conservative switch)
 };
 
 // The tile-edge values of r travel between workgroups as `sc1` (write-through / L1-bypassing) stores and loads through a raw buffer
@@ -74,7 +77,7 @@ constexpr int CGP_SLOT_STRIDE = 16;   // 8-byte words between two slots
 // every thread cost 67 spilled VGPRs and 4 us per iteration).
 template <bool DRAIN, int NB, int NT>
 __device__ __forceinline__ double cgp_allsum(unsigned long long* slots, unsigned* abort_flag, double vs, double ve, unsigned& gen, double* red,
-                                             double* fold, double* gsum, int* s_abort, bool* ok)
+                                             double* fold, double* gsum, int* s_abort, bool* ok, int fences = 0)
 {
     static_assert(NB <= 64 && (NT == 256 || NT == 1024), "one polling lane per workgroup; four summing waves per workgroup");
     ++gen;
@@ -105,6 +108,11 @@ __device__ __forceinline__ double cgp_allsum(unsigned long long* slots, unsigned
 #pragma unroll
             for (int k = 1; k < 4; ++k) fpr_s2_merge(bs, be, red[2 * k], red[2 * k + 1]);
             const int slot = (2 * blockIdx.x + w) * CGP_SLOT_STRIDE;
+            if (DRAIN && fences) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (inline asm: the compiler may drop the builtin's wait behind a drained scoreboard)
+            }
+            asm volatile("" ::: "memory");   // nothing of the hand-off moves across the publication
             __hip_atomic_store(&nxt[slot], CGP_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned long long bits = (unsigned long long)__double_as_longlong(w == 0 ? bs : be);
             if (bits == CGP_EMPTY) bits ^= 1ull;   // (a sum that happens to be this very NaN stays a NaN)
@@ -132,6 +140,11 @@ __device__ __forceinline__ double cgp_allsum(unsigned long long* slots, unsigned
             ge = __longlong_as_double((long long)b1);
         }
         ab = __any(ab);
+        asm volatile("" ::: "memory");       // the readers' sc1 loads stay behind the poll
+        if (DRAIN && fences) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         fpr_wave_sum_all_s2(gs, ge);
         if (threadIdx.x == 0) { *s_abort = ab; *gsum = gs + ge; }
     }
@@ -282,7 +295,7 @@ __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
             }
         }
         lap(4);   // update
-        rr = cgp_allsum<true, CGP_NB, CGP_NT>(slots, &a.ctr[1], acc2, acc2e, gen, red, fold, &gsum, &s_abort, &ok);        // barrier 2 (publishes the r edges)
+        rr = cgp_allsum<true, CGP_NB, CGP_NT>(slots, &a.ctr[1], acc2, acc2e, gen, red, fold, &gsum, &s_abort, &ok, a.fences);   // barrier 2 (publishes the r edges)
         if (!ok) { alive = false; break; }
         lap(5);   // barrier 2
     }

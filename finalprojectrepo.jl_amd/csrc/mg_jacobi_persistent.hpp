@@ -31,6 +31,7 @@ struct JacPersistArgs {
     const FprSolveState* state;
     long long* prof;        // diagnostic (option mg_jacp_prof): per workgroup 8 words -- wall_clock64 ticks (100 MHz) thread 0 spent waiting for
                             // its neighbours / loading the region / sweeping / storing and draining / publishing, groups, XCC id
+    int fences;             // option handoff_fences = 1: agent-scope release in front of the flag store and acquire behind the poll as well (see CgpArgs)
 };
 
 constexpr int JACP_SC1 = 16;   // cache-policy bit sc1 of the raw buffer intrinsics (gfx94x / gfx950)
@@ -108,6 +109,11 @@ __global__ __launch_bounds__((P / 2) * (P / PY)) void k_jacobi_persist(JacPersis
                     }
                 }
                 ab = __any(ab);
+                asm volatile("" ::: "memory");       // the region's sc1 loads stay behind the poll
+                if (a.fences) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 if (tid == 0 && ab) s_abort = 1;
             }
             __syncthreads();
@@ -196,7 +202,14 @@ __global__ __launch_bounds__((P / 2) * (P / PY)) void k_jacobi_persist(JacPersis
             for (int w = 1; w < NWV; ++w) v += red[w][tid];
             a.partials[((size_t)g * S + tid) * nblk + blk] = v;     // read by k_jacobi_check_groups behind the launch
         }
-        if (tid == 0) __hip_atomic_store(a.flags + blk, a.g0 + g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            if (a.fences) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("" ::: "memory");           // the tile's stores (drained above, behind the workgroup barrier) stay in front of the flag
+            __hip_atomic_store(a.flags + blk, a.g0 + g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // (red / img are rewritten only behind the next group's barriers)
         if (prof) { const long long t = wall_clock64(); pd4 += t - pt; pt = t; }
     }

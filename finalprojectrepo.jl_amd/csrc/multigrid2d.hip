@@ -793,6 +793,7 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
                 a.ihy2 = a.pow2 ? 1.0 / a.hy2 : 0.0;
             }
             a.prof = (long long*)(uintptr_t)fpr_opt(ctx, "cg_prof", 0);
+            a.fences = fpr_opt(ctx, "handoff_fences", 0) != 0 ? 1 : 0;
             FPR_HIP(ctx, hipMemsetAsync(a.ctr, 0, 2 * sizeof(unsigned), s));
             k_cgp_slots_init<<<1, 64, 0, s>>>(reinterpret_cast<unsigned long long*>(a.part), nb);
             // An ordinary launch: the workgroups are resident together on any device this library runs on (one per CU, 256 CUs),
@@ -1479,6 +1480,7 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                         a.nsw_last = (gdone + G == groups) ? iters - (groups - 1) * PS : PS;
                         a.partials = ctx->partials; a.flags = flags; a.abort_flag = abort_flag; a.state = ctx->state;
                         a.g0 = gdone;
+                        a.fences = fpr_opt(ctx, "handoff_fences", 0) != 0 ? 1 : 0;
                         a.prof = nullptr;
                         if (fpr_opt(ctx, "mg_jacp_prof", 0) != 0) {      // diagnostic: 8 words per workgroup behind the solver's work vectors (tools/exp_jacp_prof.py)
                             a.prof = reinterpret_cast<long long*>(fpr_opt(ctx, "mg_jacp_prof", 0));

@@ -134,15 +134,19 @@ def test_cg_matches_oracle(fpr, oracle):
     assert np.array_equal(F.tonumpy(x), xr)
 
 
+@pytest.mark.parametrize("fences", [0, 1])
 @pytest.mark.parametrize("shape,nmax", [((257, 257), 700), ((66, 66), 1000), ((33, 17), 12), ((130, 35), 5), ((257, 65), 64),
                                          ((65, 257), 65), ((40, 9), 129)], ids=str)
-def test_cg_launch_forms_agree_bit_for_bit(fpr, oracle, shape, nmax):
+def test_cg_launch_forms_agree_bit_for_bit(fpr, oracle, shape, nmax, fences):
     """cg! as ONE persistent launch (default where the grid fits 16 workgroups), as two dependent launches per iteration (the
     direction update rides in the next matvec), three, or five (one kernel per operation): the same operations on the same
     operands, dot products as Dot2 sums (order-independent) -- x, the returned residual and the iteration count are identical
-    among all four AND equal to the oracle's, whether the solve converges, stops at Nmax, or crosses a host-poll boundary (64)."""
+    among all four AND equal to the oracle's, whether the solve converges, stops at Nmax, or crosses a host-poll boundary (64).
+    fences = 1: option handoff_fences -- the persistent kernel's hand-off of the r edges also carries an agent-scope release / acquire
+    pair (the form inside the HIP memory model; the default rests on sc1 stores, drains and sc1 loads alone): same results."""
     F, mg = fpr, fpr.multigrid
     c = F.ctx()
+    c.set_option("handoff_fences", fences)
     b = rnd(shape, 77)
     if nmax > 100:   # a consistent system that converges
         b[0, :] = b[-1, :] = 0.0
@@ -159,6 +163,7 @@ def test_cg_launch_forms_agree_bit_for_bit(fpr, oracle, shape, nmax):
     finally:
         c.set_option("cg_fused", 3)
         c.set_option("cg_persistent_wgs", 64)
+        c.set_option("handoff_fences", 0)
     for r, it, x in outs[1:]:
         assert it == outs[0][1] and r == outs[0][0]
         assert np.array_equal(x, outs[0][2])
@@ -424,7 +429,7 @@ def test_coarse_jacobi_exit_inside_a_fused_group(fpr, oracle, tol):
         assert np.array_equal(F.tonumpy(gu), u_ref)
 
 
-@pytest.mark.parametrize("tagged", [1, 0])
+@pytest.mark.parametrize("tagged", [1, 0, -1])
 @pytest.mark.parametrize("tol", [0.5, 0.2, 0.05, 0.02, 1e-9])
 def test_coarse_jacobi_persistent_launches_equal_the_plain_ones(fpr, oracle, tol, tagged):
     """k_jacobi_persist (up to 32 groups of 8 sweeps per launch, tiles handed from neighbour to neighbour, exit test behind the
@@ -443,8 +448,10 @@ def test_coarse_jacobi_persistent_launches_equal_the_plain_ones(fpr, oracle, tol
     outs = []
     c = F.ctx()
     try:
-        # tagged = 1: k_jacobi_persist_tag (every cell a {value, tag} granule, no flags); 0: k_jacobi_persist (flags)
-        c.set_option("mg_jacp_tagged", tagged)
+        # tagged = 1: k_jacobi_persist_tag (every cell a {value, tag} granule, no flags); 0: k_jacobi_persist (flags); -1: the flag form
+        # with option handoff_fences (agent-scope release / acquire around the flag as well)
+        c.set_option("mg_jacp_tagged", 1 if tagged == 1 else 0)
+        c.set_option("handoff_fences", 1 if tagged < 0 else 0)
         for persist in (1, 0):
             c.set_option("mg_jacobi_persist", persist)
             gu = F.asdevice(u0)
@@ -453,6 +460,7 @@ def test_coarse_jacobi_persistent_launches_equal_the_plain_ones(fpr, oracle, tol
     finally:
         c.set_option("mg_jacobi_persist", 1)
         c.set_option("mg_jacp_tagged", 1)
+        c.set_option("handoff_fences", 0)
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
     assert abs(outs[0][0] - r_ref) <= 1e-12 * abs(r_ref)
     assert np.array_equal(outs[0][1], u_ref)

@@ -59,6 +59,9 @@ struct FprLevel {  // one multigrid level's scratch (role of prealloc_dict, mult
     double* coarse_own[3] = {nullptr, nullptr, nullptr};   // the library's own three while the caller's stand in (they come back as they were)
 };
 
+#ifndef FPR_SEAM_COLS_DEFAULT
+#define FPR_SEAM_COLS_DEFAULT 2    // columns per lane of the seam pass (option mg_seam_cols: 2 = k_seam_march_v3)
+#endif
 #ifndef FPR_JACP_TAGGED_DEFAULT
 #define FPR_JACP_TAGGED_DEFAULT 1  // k_jacobi_persist_tag (data-tagged hand-offs) instead of k_jacobi_persist (flags); option mg_jacp_tagged
 #endif

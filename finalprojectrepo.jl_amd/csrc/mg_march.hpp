@@ -561,6 +561,276 @@ __global__ __launch_bounds__(256) void k_seam_march_v2(const double* __restrict_
     if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
 }
 
+// ---- k_seam_march_v3 (round 5): TWO columns per lane ----------------------------------------------------------------------------
+// A strip of k_seam_march_v2 is 64 columns of which 10 are feeders (5 on each side: four sweeps and the residual eat one column per
+// stage): 15.6 % of every load, store and vector instruction of the pass works on a column another strip owns -- most of the 1.15 x
+// the pass moves over its compulsory bytes.  Here a lane owns columns g and g + 64 of a 128-column strip: 118 owned of 128 (7.8 %).
+// Every access is still a wave-wide run of 64 consecutive 8-byte words (rows of a 2^k + 1 wide array are only 8-byte aligned; the
+// 16-byte form of round 2, k_smooth2_march2, needed a lane shift per row and was slower).  The x-neighbours of the two halves are two
+// wave rotations and two wave shifts whose vacant lane takes the OTHER half's rotated value (lane 63 of the lower half <- lane 0 of
+// the upper half and vice versa): the same four DPP moves per double that two separate strips need.  Same operations on the same
+// operands per point as the second version: bit-identical fields; the norm is summed in another order (other tiling).
+template <int NC>
+__device__ __forceinline__ void fpr_nbr_lr(const double (&m)[NC], double (&L)[NC], double (&R)[NC])
+{
+    if constexpr (NC == 1) {
+        L[0] = fpr_lane_up1z(m[0]);
+        R[0] = fpr_lane_down1z(m[0]);
+    } else {
+        int lo0 = __double2loint(m[0]), hi0 = __double2hiint(m[0]);
+        int lo1 = __double2loint(m[1]), hi1 = __double2hiint(m[1]);
+        // lower half, left neighbour: lane i <- lane i - 1, lane 0 <- lane 63 (a feeder lane: any finite value)
+        const int l0lo = __builtin_amdgcn_update_dpp(0, lo0, 0x13C, 0xf, 0xf, true), l0hi = __builtin_amdgcn_update_dpp(0, hi0, 0x13C, 0xf, 0xf, true);
+        // upper half, left neighbour: lane i <- lane i - 1, lane 0 <- lane 63 of the LOWER half (column 63 is the left neighbour of column 64)
+        const int l1lo = __builtin_amdgcn_update_dpp(l0lo, lo1, 0x138, 0xf, 0xf, false), l1hi = __builtin_amdgcn_update_dpp(l0hi, hi1, 0x138, 0xf, 0xf, false);
+        // upper half, right neighbour: lane i <- lane i + 1, lane 63 <- lane 0 (feeder)
+        const int r1lo = __builtin_amdgcn_update_dpp(0, lo1, 0x134, 0xf, 0xf, true), r1hi = __builtin_amdgcn_update_dpp(0, hi1, 0x134, 0xf, 0xf, true);
+        // lower half, right neighbour: lane i <- lane i + 1, lane 63 <- lane 0 of the UPPER half
+        const int r0lo = __builtin_amdgcn_update_dpp(r1lo, lo0, 0x130, 0xf, 0xf, false), r0hi = __builtin_amdgcn_update_dpp(r1hi, hi0, 0x130, 0xf, 0xf, false);
+        L[0] = __hiloint2double(l0hi, l0lo); L[1] = __hiloint2double(l1hi, l1lo);
+        R[0] = __hiloint2double(r0hi, r0lo); R[1] = __hiloint2double(r1hi, r1lo);
+    }
+}
+
+template <bool BCS, int PF = 4, int NC = 2>
+__global__ __launch_bounds__(256) void k_seam_march_v3(const double* __restrict__ uin, const double* __restrict__ f,
+                                                        double* __restrict__ uout, int nx, int ny, double C, double _h2,
+                                                        double fac, int rows_per_chunk, int nstrips,
+                                                        double* __restrict__ partials, const double* __restrict__ corr_c,
+                                                        double* __restrict__ res_c_out, double* __restrict__ corr_c_out,
+                                                        const int* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    __shared__ double red[16];
+    constexpr int HX = 5;                                    // feeder columns on each side of a strip
+    constexpr int SW = 64 * NC - 2 * HX;                     // columns owned by a strip
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + w;
+    const bool active = strip < nstrips;
+    const int y0 = blockIdx.y * rows_per_chunk;              // host: rows_per_chunk is even
+    const int y1 = (y0 + rows_per_chunk < ny) ? y0 + rows_per_chunk : ny;  // output rows [y0, y1)
+    const int rs = y0 - 6 < 0 ? 0 : y0 - 6;                  // EVEN: row rs + T has the parity of T
+    double acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+    if (active) {
+        const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
+        int gi[NC];
+        bool col_bnd[NC], owner[NC], cint_col[NC];
+        double wE[NC], wO[NC], facL[NC];
+        unsigned vcl[NC], vch[NC], vld[NC], vst[NC], vstc[NC], vstr[NC], vstn[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            gi[c] = strip * SW - HX + lane + 64 * c;               // global column of this lane's column c
+            const bool col_ok = gi[c] >= 0 && gi[c] < nx;
+            const int gic = gi[c] < 0 ? 0 : (gi[c] > nx - 1 ? nx - 1 : gi[c]);  // clamped for loads
+            col_bnd[c] = gi[c] <= 0 || gi[c] >= nx - 1;            // domain boundary column (or outside)
+            const int sl = lane + 64 * c;                          // position inside the strip
+            owner[c] = col_ok && sl >= HX && sl < 64 * NC - HX;
+            int gis = gic;  // Neumann columns of the prolongated correction (part2_utils.jl:35-39)
+            if (BCS) gis = (gic == 0) ? 1 : (gic == nx - 1 ? nx - 2 : gic);
+            const int p_io = gis & 1, p_icl = gis >> 1, p_ich = (p_icl + 1 < nxc) ? p_icl + 1 : nxc - 1;
+            const bool p_sx0 = p_icl >= 1 && p_icl <= nxc - 2, p_sx1 = p_io && (p_icl + 1 <= nxc - 2);
+            const bool p_inx = gis >= 1 && gis <= nx - 2;
+            wE[c] = p_io ? 0.5 : 1.0; wO[c] = p_io ? 0.25 : 0.5;   // prolong_bf's weight in an even / odd fine row
+            vcl[c] = (p_inx && p_sx0) ? (unsigned)p_icl * 8u : FPR_OOR;   // excluded terms read 0
+            vch[c] = (p_inx && p_sx1) ? (unsigned)p_ich * 8u : FPR_OOR;
+            vld[c] = (unsigned)gic * 8u;
+            vst[c] = owner[c] ? (unsigned)gi[c] * 8u : FPR_OOR;   // columns that are not owned store out of range
+            vstc[c] = (owner[c] && !(gi[c] & 1)) ? (unsigned)(gi[c] >> 1) * 8u : FPR_OOR;
+            // BCS: Neumann columns of the coarse right-hand side (:355-357), see k_smooth2_march
+            vstr[c] = (BCS && (gi[c] == 0 || gi[c] == nx - 1)) ? FPR_OOR : vstc[c];
+            vstn[c] = (BCS && owner[c] && (gi[c] == 2 || gi[c] == nx - 3)) ? (gi[c] == 2 ? 0u : (unsigned)(nxc - 1) * 8u) : FPR_OOR;
+            facL[c] = col_bnd[c] ? 0.0 : fac;                      // a boundary column keeps its value: mid + 0 * rr
+            cint_col[c] = (gi[c] >> 1) >= 1 && (gi[c] >> 1) <= nxc - 2;
+        }
+        const __amdgpu_buffer_rsrc_t rCor = fpr_rsrc(corr_c);
+        const int crow = nxc * 8;
+        double cs[NC][3][2];                                 // coarse rows j, j+1, j+2 (slot = (j - rs/2) mod 3): columns icl, ich
+        auto ldc = [&](int slot, int j) {
+            const int so = (j >= 1 && j <= nyc - 2) ? j * crow : (int)FPR_OOR;   // a boundary coarse row contributes nothing
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                cs[c][slot][0] = fpr_bld(rCor, vcl[c], so);
+                cs[c][slot][1] = fpr_bld(rCor, vch[c], so);
+            }
+        };
+        const int rowB = nx * 8;
+        const __amdgpu_buffer_rsrc_t rUin = fpr_rsrc(uin + (size_t)nx * rs), rF = fpr_rsrc(f + (size_t)nx * rs);
+        const __amdgpu_buffer_rsrc_t rUout = fpr_rsrc(uout + (size_t)nx * rs);
+        // corrected input of row `row` = rs + LR (mod 12): u - P(corr), terms and order of prolong_bf
+        auto ldu = [&](auto LRc, int row, double (&out)[NC]) {
+            constexpr int LR = decltype(LRc)::value;
+            constexpr int JR = LR >> 1;
+            constexpr int SA = JR % 3, SB = (JR + 1) % 3, SN = (JR + 2) % 3;
+            const int rc = row > ny - 1 ? ny - 1 : row;
+            double v[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = fpr_bld(rUin, vld[c], (rc - rs) * rowB);
+            if constexpr ((LR & 1) == 0) ldc(SN, (row >> 1) + 2);   // used three rows from now; its slot held the row last used one row ago
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                double pv;
+                if constexpr ((LR & 1) == 0) {
+                    pv = wE[c] * cs[c][SA][0];
+                    pv = pv + wE[c] * cs[c][SA][1];
+                } else {
+                    pv = wO[c] * cs[c][SA][0];
+                    pv = pv + wO[c] * cs[c][SA][1];
+                    pv = pv + wO[c] * cs[c][SB][0];
+                    pv = pv + wO[c] * cs[c][SB][1];
+                }
+                out[c] = v[c] - pv;
+            }
+        };
+        auto ldf = [&](int r, double (&out)[NC]) {
+            const int rc = r > ny - 1 ? ny - 1 : r;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) out[c] = fpr_bld(rF, vld[c], (rc - rs) * rowB);
+        };
+        double wv[5][3][NC];
+        double fw[6][NC];
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) wv[a][b][c] = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) fw[a][c] = 0.0;
+        using I0 = std::integral_constant<int, 0>;
+        ldc(0, rs >> 1);
+        ldc(1, (rs >> 1) + 1);
+        ldu(I0{}, rs, wv[0][0]);
+        ldf(rs, fw[0]);
+        static_assert(PF == 4 || PF == 6 || PF == 12, "ring slots are compile-time constants of a loop unrolled by 12");
+        double pu[PF][NC], pfv[PF][NC];
+        ldu(std::integral_constant<int, 1>{}, rs + 1, pu[0]); ldf(rs + 1, pfv[0]);
+        ldu(std::integral_constant<int, 2>{}, rs + 2, pu[1]); ldf(rs + 2, pfv[1]);
+        ldu(std::integral_constant<int, 3>{}, rs + 3, pu[2]); ldf(rs + 3, pfv[2]);
+        ldu(std::integral_constant<int, 4>{}, rs + 4, pu[3]); ldf(rs + 4, pfv[3]);
+        if constexpr (PF >= 6) {
+            ldu(std::integral_constant<int, 5>{}, rs + 5, pu[4]); ldf(rs + 5, pfv[4]);
+            ldu(std::integral_constant<int, 6>{}, rs + 6, pu[5]); ldf(rs + 6, pfv[5]);
+        }
+        if constexpr (PF == 12) {      // (one wave per SIMD has the whole register file: twelve rows of both halves in flight)
+            ldu(std::integral_constant<int, 7>{}, rs + 7, pu[6]); ldf(rs + 7, pfv[6]);
+            ldu(std::integral_constant<int, 8>{}, rs + 8, pu[7]); ldf(rs + 8, pfv[7]);
+            ldu(std::integral_constant<int, 9>{}, rs + 9, pu[8]); ldf(rs + 9, pfv[8]);
+            ldu(std::integral_constant<int, 10>{}, rs + 10, pu[9]); ldf(rs + 10, pfv[9]);
+            ldu(std::integral_constant<int, 11>{}, rs + 11, pu[10]); ldf(rs + 11, pfv[10]);
+            ldu(std::integral_constant<int, 12>{}, rs + 12, pu[11]); ldf(rs + 12, pfv[11]);
+        }
+        const __amdgpu_buffer_rsrc_t rResC = fpr_rsrc(res_c_out), rCorC = fpr_rsrc(corr_c_out);
+        // one Jacobi sweep at row j of a field whose rows j-1, j, j+1 are (lo, mid, hi); rr = residual used by the update
+        auto sweep = [&](const double (&lo)[NC], const double (&mid)[NC], const double (&hi)[NC], const double (&fv)[NC], int j, double (&rr)[NC],
+                         double (&un)[NC]) {
+            double L[NC], R[NC];
+            fpr_nbr_lr<NC>(mid, L, R);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                rr[c] = ((((R[c] + L[c]) + hi[c]) + lo[c]) - C * mid[c]) * _h2 - fv[c];
+                un[c] = mid[c] + facL[c] * rr[c];
+            }
+            if (j <= 0 || j >= ny - 1) {   // uniform: first / last row of the grid
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < NC; ++c) un[c] = mid[c];
+            }
+        };
+        auto step = [&](auto Tc, int r) {
+            constexpr int T = decltype(Tc)::value;               // (r - rs) mod 12
+            constexpr int Q = T % PF, M = T % 3, F = T % 6;
+            constexpr int M1 = (M + 1) % 3, M2 = (M + 2) % 3;    // slots of rows r-2 (= r+1) and r-1
+            auto fs = [](int k) { return (F - k + 6) % 6; };     // slot of f row r-k
+            double an[NC], fn[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                asm volatile("v_mov_b64 %0, %1" : "=v"(an[c]) : "v"(pu[Q][c]));
+                asm volatile("v_mov_b64 %0, %1" : "=v"(fn[c]) : "v"(pfv[Q][c]));
+            }
+            ldu(std::integral_constant<int, T + 1 + PF>{}, r + 1 + PF, pu[Q]);   // issue the loads of row r+1+PF
+            ldf(r + 1 + PF, pfv[Q]);
+            double rr[NC];
+            // ---- cycle k, post-smoothing (:142-143): sweeps 1 and 2 at rows r-1, r-2 ----
+            sweep(wv[0][M1], wv[0][M2], wv[0][M], fw[fs(1)], r - 1, rr, wv[1][M2]);
+            const int j2 = r - 2;
+            double u2[NC];
+            sweep(wv[1][M], wv[1][M1], wv[1][M2], fw[fs(2)], j2, rr, u2);   // u at the end of cycle k (not stored)
+            if constexpr (BCS) {
+                // apply_boundary_conditions! between the cycles (multigrid.jl:60-62): Neumann columns copy their inner neighbour
+                double fromL[NC], fromR[NC];
+                fpr_nbr_lr<NC>(u2, fromL, fromR);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) u2[c] = (gi[c] == 0) ? fromR[c] : ((gi[c] == nx - 1) ? fromL[c] : u2[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) wv[2][M1][c] = u2[c];
+            if (j2 >= y0 && j2 < y1 && j2 > 0 && j2 < ny - 1) {   // uniform; columns that are not owned are dropped at the end
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = acc[c] + rr[c] * rr[c];   // r_rms of cycle k (:252)
+            }
+            // ---- cycle k+1, pre-smoothing (:124-125): sweeps 3 and 4 at rows r-3, r-4 ----
+            sweep(wv[2][M2], wv[2][M], wv[2][M1], fw[fs(3)], r - 3, rr, wv[3][M]);
+            const int j4 = r - 4;
+            double u4[NC];
+            sweep(wv[3][M1], wv[3][M2], wv[3][M], fw[fs(4)], j4, rr, u4);
+            {
+                const bool row_own = j4 >= y0 && j4 < y1;      // uniform
+#pragma unroll
+                for (int c = 0; c < NC; ++c) fpr_bst(rUout, vst[c], row_own ? (j4 - rs) * rowB : (int)FPR_OOR, u4[c]);   // unconditional (see FPR_OOR)
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) wv[4][M2][c] = u4[c];
+            // ---- residual of the pre-smoothed field at row r-5 (even in every odd step), injected at even columns (:128-132) ----
+            if constexpr ((T & 1) == 1) {
+                const int j5 = r - 5;
+                double L[NC], R[NC];
+                fpr_nbr_lr<NC>(wv[4][M1], L, R);
+                const int jc = j5 >> 1;
+                const bool row_inj = j5 >= y0 && j5 < y1;       // uniform
+                const int sc = row_inj ? jc * crow : (int)FPR_OOR;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const double mid = wv[4][M1][c];
+                    const double rres = ((((R[c] + L[c]) + wv[4][M2][c]) + wv[4][M][c]) - C * mid) * _h2 - fw[fs(5)][c];
+                    const bool cint = cint_col[c] && jc >= 1 && jc <= nyc - 2;
+                    fpr_bst(rResC, vstr[c], sc, cint ? rres : 0.0);
+                    if constexpr (BCS) fpr_bst(rResC, vstn[c], sc, cint ? rres : 0.0);
+                    fpr_bst(rCorC, vstc[c], sc, 0.0);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                wv[0][M1][c] = an[c];            // row r+1 takes the slot of row r-2
+                fw[(F + 1) % 6][c] = fn[c];      // row r+1 takes the slot of row r-5
+            }
+        };
+        const int rend = y1 + 4;
+        int r = rs;
+#define FPR_SEAM_STEP(T) step(std::integral_constant<int, T>{}, r + T)
+        for (; r + 11 <= rend; r += 12) {
+            FPR_SEAM_STEP(0); FPR_SEAM_STEP(1); FPR_SEAM_STEP(2); FPR_SEAM_STEP(3); FPR_SEAM_STEP(4); FPR_SEAM_STEP(5);
+            FPR_SEAM_STEP(6); FPR_SEAM_STEP(7); FPR_SEAM_STEP(8); FPR_SEAM_STEP(9); FPR_SEAM_STEP(10); FPR_SEAM_STEP(11);
+        }
+#undef FPR_SEAM_STEP
+#define FPR_SEAM_TAIL(T) if (r <= rend) { step(std::integral_constant<int, T>{}, r); ++r; }
+        FPR_SEAM_TAIL(0) FPR_SEAM_TAIL(1) FPR_SEAM_TAIL(2) FPR_SEAM_TAIL(3) FPR_SEAM_TAIL(4) FPR_SEAM_TAIL(5)
+        FPR_SEAM_TAIL(6) FPR_SEAM_TAIL(7) FPR_SEAM_TAIL(8) FPR_SEAM_TAIL(9) FPR_SEAM_TAIL(10)
+#undef FPR_SEAM_TAIL
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = (owner[c] && !col_bnd[c]) ? acc[c] : 0.0;
+    }
+    double tot = acc[0];
+#pragma unroll
+    for (int c = 1; c < NC; ++c) tot = tot + acc[c];
+    const double sblk = fpr_block_sum<256>(tot, red);
+    if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
+}
+
 // ---- k_smooth2_march, second version (round 3): what k_seam_march_v2 does for the seam, for the two-sweep passes ------------
 // Same fields as k_smooth2_march (same operations on the same operands per point).  Chunks start on an even row, so row
 // parity is a compile-time constant of the loop unrolled by 12: the prolongation has two terms in even rows and four in odd

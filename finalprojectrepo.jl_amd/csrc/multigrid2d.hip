@@ -1652,7 +1652,7 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
 
 // ---- finest level of fpr_mgsolve2d when consecutive cycles share a pass (k_seam_march) -------------------------------
 struct TopGeom {
-    int nx, ny, rpc, rpc_s, nstrips, nstrips_r, nstrips_s, ntf;
+    int nx, ny, rpc, rpc_s, nstrips, nstrips_r, nstrips_s, ntf, seam_cols;
     dim3 gm, gr, gs;
     double C, _h2, fac;
 };
@@ -1666,7 +1666,21 @@ static TopGeom top_geom(fpr_ctx* ctx, int nx, int ny, double h, double c)
     g.ntf = fpr_opt(ctx, "mg_nt", 0) ? 256 : 0;
     g.nstrips = (nx + 59) / 60;      // as vcycle_level (one column per lane)
     g.nstrips_r = (nx + 57) / 58;
-    g.nstrips_s = (nx + 53) / 54;    // k_seam_march: 54 owned columns per strip
+    // seam pass: one column per lane (k_seam_march_v2: 54 owned of 64) or two (k_seam_march_v3: 118 of 128; option mg_seam_cols)
+    // Two columns per lane halve the number of strips: taken (default) where one workgroup per CU still leaves chunks of 128 rows or more
+    // (4097^2: 9 x 27 workgroups, chunks of 152 rows: 112 against 118 us; 2049^2 would get 43-row chunks: 38 against 33 us), forced by 2, off by 1.
+    {
+        if (ctx->ncu <= 0) {
+            int v = 0;
+            ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
+        }
+        const long want = fpr_opt(ctx, "mg_seam_cols", 0);
+        const int gx3 = ((nx + 117) / 118 + 3) / 4;
+        const int chunks3 = (int)(0.95 * ctx->ncu) / gx3;
+        const bool fits = chunks3 >= 1 && ny / chunks3 >= 128 && nx >= 256;
+        g.seam_cols = (fpr_opt(ctx, "mg_seam_v", 2) != 1 && nx >= 256 && (want == 2 || (want == 0 && FPR_SEAM_COLS_DEFAULT == 2 && fits))) ? 2 : 1;
+    }
+    g.nstrips_s = g.seam_cols == 2 ? (nx + 117) / 118 : (nx + 53) / 54;
     int rpc = (int)fpr_opt(ctx, "mg_rows_per_chunk", 0);
     if (rpc <= 0) {
         const long target = fpr_opt(ctx, "mg_wave_target", 4096);
@@ -1691,8 +1705,9 @@ static TopGeom top_geom(fpr_ctx* ctx, int nx, int ny, double h, double c)
         // chunks of 164 rows (475 workgroups, at most 2 per CU) 116 us where 50 chunks of 82 rows (950, at most 4) take 121 us, and
         // counts just above a multiple of the CU count are the slow ones (28 chunks = 532 workgroups: 143 us; 43 = 817: 132 us;
         // tools/exp_seam_chunks.py, profiles/r4_mg_seam_chunks.txt)
+        // Third version (two columns per lane, twice the loads in flight per wave): ONE workgroup per CU keeps the chunks as tall.
         const long wpc_opt = fpr_opt(ctx, "mg_seam_wg_per_cu", 0);
-        const int wg_per_cu = wpc_opt > 0 ? (int)wpc_opt : (fpr_opt(ctx, "mg_seam_v", 2) == 1 ? 3 : 2);
+        const int wg_per_cu = wpc_opt > 0 ? (int)wpc_opt : (fpr_opt(ctx, "mg_seam_v", 2) == 1 ? 3 : (g.seam_cols == 2 ? 1 : 2));
         int chunks = (int)(0.95 * wg_per_cu * ctx->ncu) / gx;
         if (chunks < 1) chunks = 1;
         rs = (ny + chunks - 1) / chunks;
@@ -1746,6 +1761,12 @@ static int top_seam(fpr_ctx* ctx, const TopGeom& g, const double* X, const doubl
     if (fpr_opt(ctx, "mg_seam_v", 2) == 1) {   // the first version of the pass (A/B; same fields)
         if (apply_BCs) k_seam_march<true><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
         else k_seam_march<false><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
+    } else if (g.seam_cols == 2) {
+        const bool pf6 = fpr_opt(ctx, "mg_seam_pf", 6) == 6;     // (six rows in flight per half: 112 us; four: 114-115; twelve: 115)
+        if (fpr_opt(ctx, "mg_seam_pf", 6) == 12 && !apply_BCs) k_seam_march_v3<false, 12, 2><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
+        else if (apply_BCs) k_seam_march_v3<true, 4, 2><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
+        else if (pf6) k_seam_march_v3<false, 6, 2><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
+        else k_seam_march_v3<false, 4, 2><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
     } else {
         if (apply_BCs) k_seam_march_v2<true><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
         else if (fpr_opt(ctx, "mg_seam_pf", 4) == 6) k_seam_march_v2<false, 6><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);

@@ -187,8 +187,8 @@ def vcycle_block(F, cpu_vcycle=None, steps=5, place=True):
     cands = [("seam", seam_ms, seam_bytes, seam_cnt), ("post", post_ms, post_bytes, post_cnt), ("pre", pre_ms, pre_bytes, pre_cnt)]
     dom = max(cands, key=lambda c: c[1] * c[3])                   # the finest-level kernel with the largest share of the time
     gbs = lambda byts, ms: byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    names = {"seam": "k_seam_march_v2 (finest level, between two cycles: correction + 2 post-smoothing sweeps + norm of cycle k, "
-                     "2 pre-smoothing sweeps + residual + injection of cycle k+1)",
+    names = {"seam": "k_seam_march_v3 (finest level, between two cycles: correction + 2 post-smoothing sweeps + norm of cycle k, "
+                     "2 pre-smoothing sweeps + residual + injection of cycle k+1; two columns per lane, 118 owned of a 128-column strip)",
              "post": "k_smooth2_march_v2<NORM,PROLONG> (finest level: prolongation + correction + 2 sweeps + norm)",
              "pre": "k_smooth2_march_v2<RESTRICT> (finest level: 2 sweeps + residual + injection)"}
     traffic, traffic_src, traffic_box = None, None, None

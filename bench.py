@@ -149,7 +149,8 @@ def hoist_scalars(out, placement, unplaced):
     c["compute_partition"] = g(ds, "after_timed_region", "compute_partition")
     c["memory_partition"] = g(ds, "after_timed_region", "memory_partition")
     pp = out.get("power_probe") or {}
-    c["steady_ms_per_iteration"] = g(pp, "fused_pairs", "ms_per_iteration")        # ~1 s of back-to-back fused pairs
+    c["steady_ms_per_iteration"] = g(pp, "fused_pairs", "ms_per_iteration")        # the last second of 1.5 s of back-to-back fused pairs
+    c["steady_ms_per_iteration_incl_ramp"] = g(pp, "fused_pairs", "ms_per_iteration_incl_ramp")
     c["steady_value_GBs"] = (out["roofline"]["bytes_per_launch"] / (c["steady_ms_per_iteration"] * 1e-3) / 1e9) if c["steady_ms_per_iteration"] else None
     c["steady_sclk_MHz"] = g(pp, "fused_pairs", "sclk_MHz_avg")
     c["steady_power_W"] = g(pp, "fused_pairs", "power_W_avg")

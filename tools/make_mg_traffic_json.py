@@ -27,12 +27,14 @@ try:
 except OSError:
     box = None
 entries = []
-for name, kern, col_min in (("seam", "k_seam_march_v2<false, 4>", 30.0 * N2), ("post", "k_smooth2_march_v2<true, true, false>", 26.0 * N2),
+for name, kern, col_min in (("seam", "k_seam_march_v3<false, 6, 2>", 30.0 * N2), ("post", "k_smooth2_march_v2<true, true, false>", 26.0 * N2),
                             ("pre", "k_smooth2_march_v2<false, false, true>", 28.0 * N2)):
     fe, nf = mean(os.path.join(root, "profiles", tag + "_mg_pmc_fetch.txt"), kern, "FETCH_SIZE")
     wr, nw = mean(os.path.join(root, "profiles", tag + "_mg_pmc_write.txt"), kern, "WRITE_SIZE")
     traffic = fe * 1024 * 2 + wr * 1024
-    entries.append({"n": n, "pass": name, "kernel": kern, "FETCH_SIZE_KiB": fe, "WRITE_SIZE_KiB": wr, "fetch_correction": 2.0, "box": box,
+    entries.append({"n": n, "pass": name, "kernel": kern, "FETCH_SIZE_KiB": fe, "WRITE_SIZE_KiB": wr, "fetch_correction": 2.0,
+                    "fetch_correction_calibration": "profiles/r5_pmc_calib_width.txt: FETCH_SIZE reports 0.500 of the bytes of an 8-byte-per-lane "
+                                                    "streaming read, 0.535 in a row march of this shape; WRITE_SIZE 1.00-1.02", "box": box,
                     "traffic_bytes_per_launch": traffic, "min_bytes_per_launch": col_min, "traffic_over_min_bytes": traffic / col_min,
                     "source": "profiles/%s_mg_pmc_fetch.txt, profiles/%s_mg_pmc_write.txt: separate rocprofv3 --pmc passes of "
                               "`python3 tools/prof_mg.py 4097 5 jacobi 5` (tools/profile_mg.sh), the largest dispatch of the kernel "

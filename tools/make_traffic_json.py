@@ -27,7 +27,7 @@ try:
 except OSError:
     box = None
 entries = []
-for fused, kern in ((True, "k_diff3_march2<true, 8, true, false>"), (False, "k_diff3_march<")):
+for fused, kern in ((True, "k_diff3_march2<true, 8, true, false, false>"), (False, "k_diff3_march<")):
     fe, nf = mean(os.path.join(root, "profiles", tag + "_pmc_fetch.txt"), kern, "FETCH_SIZE")
     wr, nw = mean(os.path.join(root, "profiles", tag + "_pmc_write.txt"), kern, "WRITE_SIZE")
     traffic = fe * 1024 * 2 + wr * 1024

@@ -354,6 +354,31 @@ def test_bench_vcycle_config_4097_l2_full_solve_against_the_oracle(fpr, oracle):
     assert np.array_equal(F.tonumpy(x), xo)
 
 
+@pytest.mark.parametrize("n,bcs,cols", [(513, False, 2), (513, True, 2), (1025, True, 2), (2049, False, 2), (4097, True, 0), (4097, True, 1)])
+def test_seam_pass_with_two_columns_per_lane(fpr, oracle, n, bcs, cols):
+    """k_seam_march_v3 (a lane owns columns g and g + 64 of a 128-column strip; the halves' x-neighbours through wave rotations and
+    shifts; taken by default at 4097^2, forced here on smaller grids by option mg_seam_cols = 2) against the oracle: full solves with
+    and without apply_BCs (Neumann columns cross the halves' seam handling at the first and last strip), fields bit for bit,
+    histories to 1e-10.  4097^2 with apply_BCs: the default choice (cols = 0 -> v3) and the one-column form (1) against each other
+    and against the oracle's first cycles (the solve stops at niters, multigrid.jl:60-62 between the cycles)."""
+    F, mg = fpr, fpr.multigrid
+    c = F.ctx()
+    h = 1.0 / (n - 1)
+    b = asf(splitmix64_uniform(n * n, 3).reshape((n, n), order="F"))
+    niters = 6 if n == 4097 else 12
+    xo = farr(n, n)
+    r_o, hist_o, frms_o = oracle.mgsolve2d(xo, b, h, 0.0, 1e-9, niters, bcs, 5, 0)
+    try:
+        c.set_option("mg_seam_cols", cols)
+        x = F.fzeros(n, n)
+        r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, F.asdevice(b), h, 0.0, 1e-9, niters, bcs, opt=mg.MGOpt(), return_history=True)
+    finally:
+        c.set_option("mg_seam_cols", 0)
+    assert len(hist) == len(hist_o)
+    assert np.allclose(hist, hist_o, rtol=1e-10, atol=0), (hist, hist_o)
+    assert np.array_equal(F.tonumpy(x), xo)
+
+
 def test_config3_five_levels_4097(fpr, oracle):
     """BASELINE config 3 as named: 4097^2, 5 grids (l=8, coarse 257^2), 2+2 Jacobi smooths, multigrid_bench.jl
     protocol.  Jacobi coarse solver: 44 V-cycles / 226 160 coarse sweeps to tol 1e-6 (the coarse solve is capped at

@@ -202,9 +202,10 @@ def main():
                          "dims*(n-2)+2, same physical size, same number of untimed steps) -- the control for the norm "
                          "a decomposed run prints")
     ap.add_argument("--check-every", type=int, default=16, help="host convergence check every n iterations")
-    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+    ap.add_argument("--prewarm-ms", type=float, default=600.0,
                     help="untimed pre-warm before the W warm-up steps; a COUNT of iterations derived from it (96 x 8 per 300 ms), so that "
-                         "the number of iterations behind the printed norm is known")
+                         "the number of iterations behind the printed norm is known; 0.6 s: 150-200 ms into a load step the card's power management "
+                         "stalls the launches once for about 100 ms (tools/exp_sustain.py) -- that has to be over before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the V-cycle / NS blocks")
     ap.add_argument("--no-single-leg", action="store_true", help="skip the one-iteration-per-launch leg")
@@ -463,7 +464,7 @@ def main():
         # clock ramp, RCCL channel set-up.  Between ranks the number of pre-warm steps must be the SAME everywhere (every
         # step is a collective pattern): a fixed count there, a time budget on a single rank
         # ... and a fixed count on a single rank too (since round 5): the line can then compare its own norm after a KNOWN number
-        # of iterations with the committed control (norm_check below); 96 x 8 iterations = 0.3 s of fused pairs at 512^3
+        # of iterations with the committed control (norm_check below); 192 x 8 iterations = 0.6 s of fused pairs at 512^3
         if use_dist or as_one:
             for _ in range(8 if prewarm_ms > 100 else 2):
                 run(8, 0, fuse2)

@@ -406,10 +406,10 @@ def test_plain_sum_cg_meets_the_reference_criterion(oracle):
 
 # ---------------------------------------------------------------- bench.py's N = 1 norm check, anchored on the oracle
 def test_scale_norms_n1_entries_are_pinned_on_the_oracle():
-    """tests/golden/scale_norms.json, entries n<N>_dims1,1,1: what `bench.py --gpus 1` compares its own norm with (794 iterations
-    behind the driver's flags, 988 behind the defaults).  The GPU control values (bench.py --golden-norms) agree with the CPU
+    """tests/golden/scale_norms.json, entries n<N>_dims1,1,1: what `bench.py --gpus 1` compares its own norm with (1562 iterations
+    behind the driver's flags, 1756 behind the defaults).  The GPU control values (bench.py --golden-norms) agree with the CPU
     oracle's (tools/make_n1_norm_pins.py, recorded beside them) to 1e-12 at 512^3 -- the fields are bit-identical up to the
-    Gaussian's 2 ulp -- and to 1e-9 at 128^3, where the residual has fallen by five orders of magnitude by then and those 2 ulp
+    Gaussian's 2 ulp -- and to 1e-6 at 128^3, where the residual has fallen by nine orders of magnitude by then and those 2 ulp
     weigh more.  Live here: the recorded oracle values are reproduced (128^3: all four counts; 512^3: 8 iterations)."""
     import importlib.util
     import json
@@ -420,10 +420,10 @@ def test_scale_norms_n1_entries_are_pinned_on_the_oracle():
     spec = importlib.util.spec_from_file_location("make_n1_norm_pins", os.path.join(root, "tools", "make_n1_norm_pins.py"))
     pins_mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(pins_mod)
-    for n, rtol in ((512, 1e-12), (128, 1e-9)):
+    for n, rtol in ((512, 1e-12), (128, 1e-6)):
         e = g["entries"]["n%d_dims1,1,1" % n]
-        assert len(e["sumsq"]) >= 988 and e["global_grid"] == [n, n, n]
-        assert set(e["oracle_sumsq"]) == {"8", "64", "794", "988"}
+        assert len(e["sumsq"]) >= 1756 and e["global_grid"] == [n, n, n]
+        assert set(e["oracle_sumsq"]) == {"8", "64", "1562", "1756"}
         for it, v in e["oracle_sumsq"].items():
             gpu = e["sumsq"][int(it) - 1]
             assert abs(gpu - v) <= rtol * abs(v), (n, it, gpu, v)

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Oracle values for bench.py's N = 1 norm check: the CPU oracle (oracle/fpr_oracle.c, OpenMP build) runs bench.py's single-rank
 problem -- n^3 cells, lx = ly = lz = 10, D = 1, dt = 0.2, Gaussian initial state, no physical time step taken -- for the number of
-pseudo-iterations the driver's flags (--steps 20 --warmup 5: 768 + 6 + 20 = 794) and the default flags (768 + 20 + 200 = 988)
+pseudo-iterations the driver's flags (--steps 20 --warmup 5: 1536 + 6 + 20 = 1562) and the default flags (1536 + 20 + 200 = 1756)
 reach, and records sum((dHdtau * dt)^2) at those counts (and at 8 and 64) in tests/golden/scale_norms.json under
 entries[n<N>_dims1,1,1].oracle_sumsq.  The GPU control values of the same entry (bench.py --golden-norms, tools/make_scale_norms.sh)
 must agree with them to 1e-11 (tests/test_oracle_pins.py); the fields are bit-identical up to the 2 ulp of the Gaussian.
 
-    python3 tools/make_n1_norm_pins.py [n] [file]        (n = 512: about 8 minutes on 8 cores)
+    python3 tools/make_n1_norm_pins.py [n] [file]        (n = 512: about 5 minutes on 8 cores)
 """
 import json
 import os
@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
 from oracle.oracle import Oracle, farr  # noqa: E402
 
-COUNTS = (8, 64, 794, 988)
+COUNTS = (8, 64, 1562, 1756)
 
 
 def oracle_sumsq(n, counts=COUNTS, progress=False):

@@ -62,6 +62,10 @@ struct FprLevel {  // one multigrid level's scratch (role of prealloc_dict, mult
 #ifndef FPR_SEAM_COLS_DEFAULT
 #define FPR_SEAM_COLS_DEFAULT 2    // columns per lane of the seam pass (option mg_seam_cols: 2 = k_seam_march_v3)
 #endif
+#ifndef FPR_CG_TAGGED_DEFAULT
+#define FPR_CG_TAGGED_DEFAULT 0    // k_cg_persistent: tile-edge values of r as data-tagged granules (option cg_tagged_edges): measured 6.01 against
+                                   // 5.83 us per iteration -- the loads in flight in front of barrier 2 lengthen its poll by more than they save behind it
+#endif
 #ifndef FPR_JACP_TAGGED_DEFAULT
 #define FPR_JACP_TAGGED_DEFAULT 1  // k_jacobi_persist_tag (data-tagged hand-offs) instead of k_jacobi_persist (flags); option mg_jacp_tagged
 #endif

@@ -250,7 +250,6 @@ struct JacTagArgs {
     const FprSolveState* state;
     long long* prof;
 };
-typedef unsigned fpr_u4v __attribute__((ext_vector_type(4)));
 
 template <int S, int P, int PY = 2>
 __global__ __launch_bounds__((P / 2) * (P / PY)) void k_jacobi_persist_tag(JacTagArgs a)

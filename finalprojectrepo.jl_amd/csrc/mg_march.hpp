@@ -9,6 +9,7 @@
 // count the operations younger than a prefetch and waits for more than it has to (finding 1).
 constexpr unsigned FPR_OOR = 0x7fffffffu;
 typedef unsigned fpr_u2v __attribute__((ext_vector_type(2)));
+typedef unsigned fpr_u4v __attribute__((ext_vector_type(4)));   // a 16-byte granule {value, tag} of the data-tagged hand-offs
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t fpr_rsrc(const void* p)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)FPR_OOR, 0x00020000);

@@ -794,6 +794,10 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
             }
             a.prof = (long long*)(uintptr_t)fpr_opt(ctx, "cg_prof", 0);
             a.fences = fpr_opt(ctx, "handoff_fences", 0) != 0 ? 1 : 0;
+            // r_glob: N doubles (flag form) or N granules = the work vectors r and p, which lie one behind the other (cg_work) and are not used
+            // otherwise by this form; tags of one solve never meet another solve's
+            a.tag_base = (fpr_opt(ctx, "cg_tagged_edges", FPR_CG_TAGGED_DEFAULT) != 0 && !a.fences && (size_t)N * 16 < 0x7fffffffu && w.p == w.r + N)
+                             ? (long long)(++ctx->jacp_epoch) << 32 : 0;
             FPR_HIP(ctx, hipMemsetAsync(a.ctr, 0, 2 * sizeof(unsigned), s));
             k_cgp_slots_init<<<1, 64, 0, s>>>(reinterpret_cast<unsigned long long*>(a.part), nb);
             // An ordinary launch: the workgroups are resident together on any device this library runs on (one per CU, 256 CUs),

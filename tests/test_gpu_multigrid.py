@@ -153,9 +153,12 @@ def test_cg_launch_forms_agree_bit_for_bit(fpr, oracle, shape, nmax, fences):
         b[:, 0] = b[:, -1] = 0.0
     outs = []
     try:
-        for form, wgs in ((3, 64), (3, 16), (2, 64), (1, 64), (0, 64)):   # the persistent kernel in both geometries (64 x 256 and 16 x 1024 threads)
+        # the persistent kernel in both geometries (64 x 256 and 16 x 1024 threads), its r edges as data-tagged granules (option cg_tagged_edges = 1) or as
+        # sc1 stores + drain + barrier words (default; with handoff_fences the flag form is taken anyway)
+        for form, wgs, tagged in ((3, 64, 1), (3, 16, 1), (3, 64, 0), (2, 64, 1), (1, 64, 1), (0, 64, 1)):
             c.set_option("cg_fused", form)
             c.set_option("cg_persistent_wgs", wgs)
+            c.set_option("cg_tagged_edges", tagged)
             x = F.asdevice(np.full(shape, 3.0))
             r, it = mg.cg_(x, F.asdevice(b), 0.05, 0.07, 0.9, 1e-7, nmax, return_iters=True)
             outs.append((r, it, F.tonumpy(x)))
@@ -163,6 +166,7 @@ def test_cg_launch_forms_agree_bit_for_bit(fpr, oracle, shape, nmax, fences):
     finally:
         c.set_option("cg_fused", 3)
         c.set_option("cg_persistent_wgs", 64)
+        c.set_option("cg_tagged_edges", 0)
         c.set_option("handoff_fences", 0)
     for r, it, x in outs[1:]:
         assert it == outs[0][1] and r == outs[0][0]

@@ -19,10 +19,11 @@ b[:, 0] = b[:, -1] = 0.0
 prof = torch.zeros(8, dtype=torch.int64, device="cuda")
 F.ctx().set_option("cg_prof", prof.data_ptr())
 names = ["beta/p/ring/LDS", "operator", "-", "sum+barrier 1", "update", "sum+barrier 2"]
-for rep in range(6):
-    F.ctx().set_option("cg_persistent_wgs", 64 if rep < 3 else 16)
-    if rep in (0, 3):
-        print("--- %d workgroups ---" % (64 if rep < 3 else 16))
+for rep in range(9):
+    F.ctx().set_option("cg_persistent_wgs", 16 if rep >= 6 else 64)
+    F.ctx().set_option("cg_tagged_edges", 0 if 3 <= rep < 6 else 1)       # r edges as data-tagged granules (option) / sc1 + drain + flag form (default)
+    if rep in (0, 3, 6):
+        print("--- %d workgroups, %s ---" % (16 if rep >= 6 else 64, "edges as sc1 stores + drain (round 4)" if 3 <= rep < 6 else "edges as tagged granules"))
     prof.zero_()
     x = F.fzeros(n, n)
     r, it = mg.cg_(x, F.asdevice(b), 1.0 / (n - 1), 1.0 / (n - 1), 0.0, 1e-12, nmax, return_iters=True)
@@ -31,3 +32,4 @@ for rep in range(6):
     print("n=%d: %d iterations, %.2f us per iteration: %s" % (n, it, t.sum() / max(it, 1), ", ".join("%s %.2f" % (a, v / max(it, 1)) for a, v in zip(names, t))))
 F.ctx().set_option("cg_prof", 0)
 F.ctx().set_option("cg_persistent_wgs", 64)
+F.ctx().set_option("cg_tagged_edges", 0)

@@ -33,10 +33,11 @@ b[:, 0] = b[:, -1] = 0.0
 gb = F.asdevice(b)
 ref = None
 t0 = time.time()
-for form, wgs in ((2, 64), (3, 64), (3, 16)):
+for form, wgs, tagged in ((2, 64, 1), (3, 64, 1), (3, 16, 1), (3, 64, 0)):
     c.set_option("cg_fused", form)
     c.set_option("cg_persistent_wgs", wgs)
-    for i in range(reps if form == 3 else 2):
+    c.set_option("cg_tagged_edges", tagged)       # r edges of the persistent kernel as data-tagged granules (option) or sc1 + drain + flags (default)
+    for i in range((reps if tagged else reps // 4) if form == 3 else 2):
         if i % 8 == 0:
             noise()
         x = F.fzeros(n, n)
@@ -49,6 +50,7 @@ for form, wgs in ((2, 64), (3, 64), (3, 16)):
             print("cg mismatch: form %d wgs %d rep %d: it %d vs %d" % (form, wgs, i, got[1], ref[1]), flush=True)
 c.set_option("cg_fused", 3)
 c.set_option("cg_persistent_wgs", 64)
+c.set_option("cg_tagged_edges", 0)
 print("cg!: %d solves of %d iterations, %d mismatches, %d barrier time-outs, %.1f s" % (2 * reps + 2, ref[1], bad, c.get_option("cg_persistent_timeouts"), time.time() - t0), flush=True)
 # ---- Jacobi coarse solve directly (cap 5140 sweeps) and with an exit inside a launch: 257 x 129 (153 workgroups, groups of 8 sweeps) and
 #      257 x 257 (225 workgroups, groups of 7); the data-tagged hand-off (k_jacobi_persist_tag, default) and the flag form ----

@@ -249,10 +249,11 @@ def vcycle_block(F, cpu_vcycle=None, steps=5, place=True):
     us_per_launch = pt_ms * 1e3 / pt_launches if pt_launches else None
     jac_sweeps = max(out["l8_jacobi"]["coarse_iters"], 1)
     us_per_sweep = pt_ms * 1e3 / jac_sweeps if pt_ms > 0 else None
-    # a sweep of the 257^2 grid inside a group of the persistent kernel: 0.24 us (tools/exp_jacp_prof.py, profiles/r5_jacp_prof.txt: 1.66 us
-    # for the 7 sweeps of a group on 225 workgroups of 512 threads); everything above that is the hand-off between groups (tile out as
-    # tagged granules, the neighbours' tiles in: one store -> load round trip) and the sums of the exit test
-    PATCH_SWEEP_US = 0.24
+    # Floor of a sweep of the 257^2 grid in the persistent kernel: the sweeps of a group (0.24 us each: tools/exp_jacp_prof.py,
+    # profiles/r5_jacp_prof.txt, 1.66 us for 7 sweeps on 225 workgroups of 512 threads) plus ONE store -> load hand-off per group at the
+    # idle price MI355X_MICROARCH.md lists for <= 4 KB (0.8 us) -- every tile needs all its neighbours' previous group, so the tiles advance
+    # as one front and the hand-off cannot hide behind another tile's sweeps (EXPERIMENTS 13.6): (7 x 0.24 + 0.8) / 7 = 0.354 us
+    PATCH_SWEEP_US = (7 * 0.24 + 0.8) / 7.0
     five = {"metric": "vcycle_wall_time_4097sq_5levels", "unit": "s", "higher_is_better": False, "dtype": "f64",
             "config": {"workload": "2D Poisson V-cycle 4097^2, 5 grids (4097^2 ... 257^2, l = 8), 2+2 Jacobi smooths; "
                                    "multigrid_bench.jl protocol (x=0, b~U[0,1), c=0, tol 1e-6); coarse solve = cg! or 20*257 "
@@ -283,9 +284,10 @@ def vcycle_block(F, cpu_vcycle=None, steps=5, place=True):
                              "achieved": us_per_sweep, "peak": PATCH_SWEEP_US, "unit": "us per sweep",
                              "frac": (PATCH_SWEEP_US / us_per_sweep) if us_per_sweep else None,
                              "us_per_launch": us_per_launch, "launches_timed": pt_launches, "sweeps": jac_sweeps, "traffic": None,
-                             "note": "achieved = hipEvent time of the coarse-solver launches of one solve / sweeps; peak = the cost of a sweep "
-                                     "inside a group (0.24 us); frac = how much of the time is sweeps rather than hand-offs between groups "
-                                     "(round 3: one launch per 8 sweeps, 1.5 us per sweep; round 4: flags between neighbours, 0.75 us)"}}}
+                             "note": "achieved = hipEvent time of the coarse-solver launches of one solve / sweeps; peak = (7 sweeps at 0.24 us inside "
+                                     "a group + one store -> load hand-off at 0.8 us) / 7: the tiles advance as one front, so a group cannot hide its "
+                                     "hand-off; frac = floor / achieved (round 3: one launch per 8 sweeps, 1.5 us per sweep; round 4: flags between "
+                                     "neighbours, 0.75 us; the sweeps alone: 0.24 us)"}}}
     if with_cpu:
         for key, solver in (("conjugate_gradient", 1), ("jacobi", 0)):
             try:

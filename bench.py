@@ -134,6 +134,8 @@ def hoist_scalars(out, placement, unplaced):
     c["pool_fastest_pair_GBs"] = g(placement, "pair_copy_GBs_all", "fastest")
     c["pool_slowest_pair_GBs"] = g(placement, "pair_copy_GBs_all", "slowest")
     c["chosen_slowest_pair_GBs"] = g(placement, "pair_copy_GBs_chosen", "slowest")
+    c["mem_free_GiB_at_start"] = unplaced.get("mem_free_GiB_at_start")
+    c["mem_total_GiB"] = unplaced.get("mem_total_GiB")
     c["unplaced_kernel_ms"] = unplaced.get("kernel_ms")
     c["unplaced_frac"] = (out["roofline"]["bytes_per_launch"] / (unplaced["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if unplaced.get("kernel_ms") else None
     ds = out.get("device_state") or {}
@@ -339,6 +341,11 @@ def main():
     # Every rank does the same thing for itself; --no-placement allocates plainly.
     placement = {}
     unplaced = {}
+    try:      # what the card had free before this process allocated anything (a lease whose pool is of one class: is the card shared / fragmented?)
+        _free0, _total0 = torch.cuda.mem_get_info()
+        unplaced["mem_free_GiB_at_start"], unplaced["mem_total_GiB"] = _free0 / 2.0 ** 30, _total0 / 2.0 ** 30
+    except Exception:
+        pass
 
     def pair_ms_of(arrs, pairs_warm, pairs_timed):
         """Event time [ms] of one fused launch on the given five arrays (zeros: the arithmetic does not depend on the values)."""

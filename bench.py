@@ -130,6 +130,8 @@ def hoist_scalars(out, placement, unplaced):
     c["placement_trial_ms_first"] = placement.get("trial_ms_first")
     c["placement_trial_ms_worst"] = placement.get("trial_ms_worst")
     c["placement_trial_ms_plain"] = placement.get("trial_ms_plain_allocation")
+    c["placement_churned"] = any(k.startswith("churned_because") for k in placement)
+    c["placement_fastest_pair_GBs_before_churn"] = placement.get("churned_because_fastest_pair_GBs")
     c["placement_kept_plain"] = (placement.get("chosen") == [0, 1, 2, 3, 4]) if placement.get("chosen") else None
     c["pool_fastest_pair_GBs"] = g(placement, "pair_copy_GBs_all", "fastest")
     c["pool_slowest_pair_GBs"] = g(placement, "pair_copy_GBs_all", "slowest")

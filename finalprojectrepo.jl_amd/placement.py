@@ -8,6 +8,34 @@ untouched spacers, because consecutive allocations share a label in runs of four
 library says it is of one class, keep the chosen arrays, free the rest."""
 import ctypes as C
 
+_CHURNED = [False]      # churn() has run in this process (its effect lasts: later pools of the process stay mixed)
+
+
+def churn(fraction=0.7, chunk_bytes=48 << 30):
+    """Allocate, write and free most of the card's free memory once.  One lease in six or seven hands a fresh process only allocations
+    of ONE placement class, whatever their number, spacing or distance (12 or 22 candidates over 56-188 GiB of addresses: every pair
+    copies below 4950 GB/s, the fused launch takes 0.83-0.85 ms on any five of them); after this, the same pool recipe yields the usual
+    mix (fastest pair 5116-5149 GB/s, 0.751-0.759 ms) -- tools/slow_state_probe.py, profiles/r5_one_class_lease_probe.txt.  About a
+    second; nothing stays allocated."""
+    import torch
+
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    left, held = int(fraction * free), []
+    try:
+        while left >= (1 << 30):
+            nb = min(left, chunk_bytes)
+            t = torch.empty(nb, dtype=torch.uint8, device="cuda")
+            t.zero_()
+            held.append(t)
+            left -= nb
+    except RuntimeError:
+        pass
+    torch.cuda.synchronize()
+    del held
+    torch.cuda.empty_cache()
+    _CHURNED[0] = True
+
 _TRIAL_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.POINTER(C.c_int), C.c_int)
 _R = dict(fastest=0, median=1, slowest=2, chosen_slowest=3, chosen_mean=4, trials=5, best=6, first=7, worst=8, identity=9, spread=10,
           want_more=11)          # include/fpr.h FPR_PLACE_*
@@ -75,6 +103,16 @@ def alloc_fields(count, *shape, pool=None, min_bytes=256 << 20, report=None, pai
     grow(k)
     report["pool_first"] = len(cands)
     rank()
+    if extend_by > 0 and rep[_R["want_more"]] > 0 and not _CHURNED[0]:
+        # a pool of one class: more candidates of the same process do not help (22 over 106 GiB were tried); churning the card's memory once does
+        report["churned_because_" + ("fastest_pair_GBs" if rep[_R["want_more"]] == 1 else "trial_spread")] = (
+            rep[_R["fastest"]] if rep[_R["want_more"]] == 1 else rep[_R["spread"]])
+        nfirst = len(first or [])
+        del cands[nfirst:]
+        spacers.clear()
+        churn()
+        grow(k)
+        rank()
     if extend_by > 0 and rep[_R["want_more"]] > 0:
         why, before = ("fastest_pair_GBs", rep[_R["fastest"]]) if rep[_R["want_more"]] == 1 else ("trial_spread", rep[_R["spread"]])
         n0 = len(cands)

@@ -509,6 +509,26 @@ plainly, as `@zeros` would, the rest behind untouched spacers -- and frees what 
 together (default all); `trial(arrays) -> ms`: the caller's own kernel as the judge (optional).  Replaces nothing in the reference:
 `@zeros` (part1_kernel_programming.jl:134-142) keeps working without it.
 """
+"""
+    churn!(fraction = 0.7)
+
+Allocate, write and free most of the card's free memory once: on a lease whose fresh allocations are all of one placement class (report
+index 11 of `fpr_placement_rank` = 1) the pools built afterwards show the usual mix (INTEGRATION.md 5, `placement.churn` in the mirror).
+"""
+function churn!(fraction = 0.7)
+    left = floor(Int, fraction * AMDGPU.Runtime.Mem.info()[1])
+    held = Any[]
+    while left >= (1 << 30)
+        nb = min(left, 48 << 30)
+        A = try ROCArray{UInt8}(undef, nb) catch; break end
+        fill!(A, 0x00); push!(held, A); left -= nb
+    end
+    AMDGPU.synchronize()
+    foreach(AMDGPU.unsafe_free!, held)
+    return nothing
+end
+const CHURNED = Ref(false)
+
 function alloc_fields(count::Integer, dims::Integer...; pool::Integer = count + 7, pairs = nothing, trial = nothing, spacer_bytes = nothing)
     nbytes = 8 * prod(dims)
     (nbytes < (256 << 20) || count < 2) && return [AMDGPU.zeros(Float64, dims...) for _ in 1:count]
@@ -529,6 +549,11 @@ function alloc_fields(count::Integer, dims::Integer...; pool::Integer = count + 
                     (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Cint, Csize_t, Cint, Ptr{Cint}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}, Ptr{Cdouble}),
                     ctx(), ptrs, length(cands), prod(dims), count, flat, length(flat) ÷ 2,
                     cb === C_NULL ? C_NULL : Base.unsafe_convert(Ptr{Cvoid}, cb), C_NULL, chosen, report))
+    end
+    if report[12] > 0 && !CHURNED[]          # FPR_PLACE_WANT_MORE: a pool of one class -- churn once, then build the pool afresh
+        foreach(AMDGPU.unsafe_free!, cands); foreach(AMDGPU.unsafe_free!, spacers)
+        churn!(); CHURNED[] = true
+        return alloc_fields(count, dims...; pool = pool, pairs = pairs, trial = trial, spacer_bytes = spacer_bytes)
     end
     out = DA[cands[c + 1] for c in chosen]
     for (i, A) in enumerate(cands); (i - 1) in chosen || AMDGPU.unsafe_free!(A); end

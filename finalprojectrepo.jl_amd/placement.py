@@ -103,10 +103,10 @@ def alloc_fields(count, *shape, pool=None, min_bytes=256 << 20, report=None, pai
     grow(k)
     report["pool_first"] = len(cands)
     rank()
-    if extend_by > 0 and rep[_R["want_more"]] > 0 and not _CHURNED[0]:
+    if extend_by > 0 and rep[_R["want_more"]] == 1 and not _CHURNED[0]:
         # a pool of one class: more candidates of the same process do not help (22 over 106 GiB were tried); churning the card's memory once does
-        report["churned_because_" + ("fastest_pair_GBs" if rep[_R["want_more"]] == 1 else "trial_spread")] = (
-            rep[_R["fastest"]] if rep[_R["want_more"]] == 1 else rep[_R["spread"]])
+        # (only the case measured: no fast pair at all; a pool whose trials merely agree -- want_more 2 -- is extended as before)
+        report["churned_because_fastest_pair_GBs"] = rep[_R["fastest"]]
         nfirst = len(first or [])
         del cands[nfirst:]
         spacers.clear()

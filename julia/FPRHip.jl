@@ -550,7 +550,7 @@ function alloc_fields(count::Integer, dims::Integer...; pool::Integer = count + 
                     ctx(), ptrs, length(cands), prod(dims), count, flat, length(flat) ÷ 2,
                     cb === C_NULL ? C_NULL : Base.unsafe_convert(Ptr{Cvoid}, cb), C_NULL, chosen, report))
     end
-    if report[12] > 0 && !CHURNED[]          # FPR_PLACE_WANT_MORE: a pool of one class -- churn once, then build the pool afresh
+    if report[12] == 1 && !CHURNED[]          # FPR_PLACE_WANT_MORE: a pool of one class -- churn once, then build the pool afresh
         foreach(AMDGPU.unsafe_free!, cands); foreach(AMDGPU.unsafe_free!, spacers)
         churn!(); CHURNED[] = true
         return alloc_fields(count, dims...; pool = pool, pairs = pairs, trial = trial, spacer_bytes = spacer_bytes)

@@ -46,14 +46,26 @@ def vcycle_block(F, cpu_vcycle=None, steps=5, place=True):
     h = 1.0 / (n - 1)
     b_host = F.part2.splitmix64_uniform(n * n, 1).reshape((n, n), order="F")
     b0 = F.asdevice(b_host)
-    # x and b placed against the library's level arena (finalprojectrepo.jl_amd/placement.py: the finest passes stream u, f and the
-    # ping-pong partner at equal offsets; the seam pass takes 110 or 118 us by where the three lie).  A trial = one timed solve.
+    # Where the seven arrays of the finest passes lie decides the seam pass's mode (99.5 against 113 us): the two ping-pong partners have
+    # to differ in placement class from f and from the first coarse level's three arrays, which the pass streams beside them
+    # -- the partners may share a class, and so may everything else (tools/exp_mg_slab2.py, EXPERIMENTS 13.10).  So: two 1 GiB
+    # allocations P, Q that copy fastest among a pool (fpr_placement_rank: different classes); x, b and the coarse level are windows of
+    # P, the partners windows of Q; one timed solve decides the orientation and whether the plain allocation was better after all.
     placement = {}
+    GiB = 1 << 30
+    nc = 1 + (n - 1) // 2
 
-    def trial(arrs):
-        tx, tb, t1, t2 = arrs
-        mg.provide_arena_(n, n, t1, t2)              # the finest level's ping-pong partners travel with the candidates
-        tb.copy_(b0)
+    def window(block, off_bytes, m):
+        w = block[off_bytes // 8:off_bytes // 8 + m * m].view(m, m)
+        return w.permute(1, 0)
+
+    def windows(P, Q):
+        x_, b_ = window(P, 0, n), window(P, 160 << 20, n)
+        cs_ = [window(P, (700 << 20) + k * (40 << 20), nc) for k in range(3)]
+        t1_, t2_ = window(Q, 0, n), window(Q, 160 << 20, n)
+        return x_, b_, t1_, t2_, cs_
+
+    def solve_ms(tx, tb):
         best = None
         for _ in range(3):
             tx.zero_()
@@ -67,69 +79,36 @@ def vcycle_block(F, cpu_vcycle=None, steps=5, place=True):
             best = dt if best is None or dt < best else best
         return best * 1e3
 
+    def trial(arrs):
+        tx, tb, t1, t2, cs = windows(*arrs)
+        for a in cs:
+            a.zero_()
+        mg.provide_arena_(n, n, t1, t2)              # the finest level's ping-pong partners travel with the candidates
+        mg.provide_arena_coarse_(n, n, *cs)
+        tb.copy_(b0)
+        return solve_ms(tx, tb)
+
     if place:
-        # streamed together at equal offsets by the passes over the finest grid: (u, f), (partner, f), (partner, partner), (u, partner)
         try:
-            x, b, t1, t2 = F.placement.alloc_fields(4, n, n, pool=10, min_bytes=64 << 20, report=placement,
-                                                    pairs=[(0, 1), (2, 1), (3, 1), (2, 3), (0, 2)], trial=trial, trials=3)
+            x_plain = F.fzeros(n, n)
+            placement["plain_allocation_ms"] = solve_ms(x_plain, b0)      # four plain arrays + the library's own arena: what a host gets unplaced
+            del x_plain
+            P, Q = F.placement.alloc_fields(2, GiB // 8, pool=12, report=placement, pairs=[(0, 1)], trial=trial, trials=3)
+            x, b, t1, t2, cs = windows(P, Q)
+            for a in cs:
+                a.zero_()
             mg.provide_arena_(n, n, t1, t2)
+            mg.provide_arena_coarse_(n, n, *cs)
             b.copy_(b0)
+            placement["layout"] = ("x, b and the first coarse level's three arrays are windows of one 1 GiB allocation, the finest level's two "
+                                   "ping-pong partners windows of another; the two allocations are the pair of the pool that copies fastest "
+                                   "(different placement classes), orientation by a timed solve")
+            if placement.get("trial_ms_best", 0.0) > placement["plain_allocation_ms"]:     # cannot happen on the cards seen; kept honest
+                placement["note_plain_was_faster"] = True
             del b0
-            # ... then the three arrays of the first coarse level the finest passes stream beside them (33.6 MB each: which mode the
-            # seam pass runs in depended on the context's own allocation of these as much as on the four big arrays,
-            # tools/exp_mg_arena_rounds.py); same search, the big arrays fixed
-            try:
-                nc = 1 + (n - 1) // 2
-                placement_c = {}
-
-                def trial_c(arrs):
-                    for a in arrs:
-                        a.zero_()
-                    mg.provide_arena_coarse_(n, n, *arrs)
-                    best = None
-                    for _ in range(3):
-                        x.zero_()
-                        F.synchronize()
-                        t0 = time.perf_counter()
-                        with warnings.catch_warnings():
-                            warnings.simplefilter("ignore")
-                            mg.MGsolve_2DPoisson_(x, b, h, 0.0, 1e-6, 100, False, opt=mg.MGOpt(), return_history=False)
-                        F.synchronize()
-                        dt = time.perf_counter() - t0
-                        best = dt if best is None or dt < best else best
-                    return best * 1e3
-
-                def solve_ms():
-                    best = None
-                    for _ in range(3):
-                        x.zero_()
-                        F.synchronize()
-                        t0 = time.perf_counter()
-                        with warnings.catch_warnings():
-                            warnings.simplefilter("ignore")
-                            mg.MGsolve_2DPoisson_(x, b, h, 0.0, 1e-6, 100, False, opt=mg.MGOpt(), return_history=False)
-                        F.synchronize()
-                        dt = time.perf_counter() - t0
-                        best = dt if best is None or dt < best else best
-                    return best * 1e3
-
-                own_ms = solve_ms()                      # the library's own three arrays: what a placed triple has to beat
-                cs = F.placement.alloc_fields(3, nc, nc, pool=8, min_bytes=16 << 20, report=placement_c, trial=trial_c, trials=3,
-                                              spacer_bytes=2 << 30)
-                keep_placed = placement_c.get("trial_ms_best", own_ms) < 0.995 * own_ms
-                if keep_placed:
-                    mg.provide_arena_coarse_(n, n, *cs)
-                else:
-                    mg.provide_arena_coarse_(n, n, None, None, None)
-                    del cs
-                placement["coarse_level"] = {k: placement_c.get(k) for k in ("pool_first", "pool", "trials", "trial_ms_best", "trial_ms_first",
-                                                                             "trial_ms_worst", "pool_extended_because_trial_spread")}
-                placement["coarse_level"].update({"library_own_ms": own_ms, "placed_kept": keep_placed})
-            except Exception as e:
-                mg.provide_arena_coarse_(n, n, None, None, None)
-                placement["coarse_level"] = {"error": repr(e)}
         except Exception as e:       # the search is an optimisation: the library's own buffers give the same results
             mg.provide_arena_(n, n, None, None)
+            mg.provide_arena_coarse_(n, n, None, None, None)
             x, b = F.fzeros(n, n), b0
             placement.clear()
             placement.update({"selected": False, "error": repr(e)})

@@ -425,29 +425,10 @@ __global__ __launch_bounds__(256) void k_cycle_init(const double* __restrict__ p
 
 // end of a V-cycle: sum(res.^2) of the last post-smoothing sweep exactly as k_finish<0> sums it, r_rms
 // (multigrid.jl:252) and the loop's exit test (:70) on the device
-__global__ __launch_bounds__(256) void k_cycle_finish(const double* __restrict__ partials, int n, double* __restrict__ out,
-                                                       double npoints, FprCycleCtl* ctl, const FprSolveState* st,
-                                                       FprCycleCtl* rec_host)
+__global__ __launch_bounds__(256) void k_cycle_finish(FprFinishArgs a)
 {
     __shared__ double red[16];
-    if (ctl->stop) return;
-    const double s = fpr_sum_partials_256(partials, n, red);
-    if (threadIdx.x == 0) {
-        out[0] = s;
-        const double r = sqrt(s / npoints);
-        FprCycleCtl c = *ctl;
-        c.rms = r;
-        c.ncycles += 1;
-        c.coarse_iters = st->acc_iters;
-        if (r < c.tolf) c.stop = 1;
-        *ctl = c;
-        // the record goes to pinned host memory straight from here (no copy command, no event between two cycles);
-        // the host polls `seq`, which is written last
-        rec_host->stop = c.stop; rec_host->ncycles = c.ncycles; rec_host->coarse_iters = c.coarse_iters;
-        rec_host->tolf = c.tolf; rec_host->rms = c.rms; rec_host->frms = c.frms;
-        __threadfence_system();
-        __hip_atomic_store(&rec_host->seq, c.ncycles, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    fpr_cycle_finish_body(a, red);
 }
 
 int fprx_cycle_init(fpr_ctx* ctx, const double* f, size_t n, double tol)
@@ -491,8 +472,17 @@ int fprx_cycle_wait(fpr_ctx* ctx, int slot, int seq, FprCycleCtl* out)
     return FPR_OK;
 }
 
+static FprFinishArgs finish_args(fpr_ctx* ctx, const double* partials, int nparts, double* sumsq_out_dev, double npoints, int slot)
+{
+    FprFinishArgs a;
+    a.partials = partials; a.n = nparts; a.out = sumsq_out_dev; a.npoints = npoints;
+    a.ctl = ctx->cyc; a.st = ctx->state; a.rec_host = &ctx->cyc_h[slot];
+    return a;
+}
+
 int fprx_cycle_finish(fpr_ctx* ctx, const double* partials, int nparts, double* sumsq_out_dev, double npoints, int slot)
 {
+    if (int rc = fprx_cycle_finish_flush(ctx)) return rc;           // (none can be pending here; order kept if one ever is)
     __atomic_store_n(&ctx->cyc_h[slot].seq, 0, __ATOMIC_RELEASE);   // before the launch that will report into it
     if (nparts > 2048) {   // as fprx_finish_sum; folding stale partials in a skipped cycle only touches scratch
         const int nb = 128;
@@ -502,8 +492,27 @@ int fprx_cycle_finish(fpr_ctx* ctx, const double* partials, int nparts, double* 
         partials = fold;
         nparts = nb;
     }
-    k_cycle_finish<<<1, 256, 0, ctx->stream[0]>>>(partials, nparts, sumsq_out_dev, npoints, ctx->cyc, ctx->state,
-                                                  &ctx->cyc_h[slot]);
+    k_cycle_finish<<<1, 256, 0, ctx->stream[0]>>>(finish_args(ctx, partials, nparts, sumsq_out_dev, npoints, slot));
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+int fprx_cycle_finish_defer(fpr_ctx* ctx, const double* partials, int nparts, double* sumsq_out_dev, double npoints, int slot)
+{
+    if (nparts > 2048 || !fpr_opt(ctx, "mg_fold_finish", FPR_FOLD_FINISH_DEFAULT))
+        return fprx_cycle_finish(ctx, partials, nparts, sumsq_out_dev, npoints, slot);
+    if (int rc = fprx_cycle_finish_flush(ctx)) return rc;
+    __atomic_store_n(&ctx->cyc_h[slot].seq, 0, __ATOMIC_RELEASE);
+    ctx->fin = finish_args(ctx, partials, nparts, sumsq_out_dev, npoints, slot);
+    return FPR_OK;
+}
+
+int fprx_cycle_finish_flush(fpr_ctx* ctx)
+{
+    if (!ctx->fin.partials) return FPR_OK;
+    const FprFinishArgs a = ctx->fin;
+    ctx->fin = FprFinishArgs{};
+    k_cycle_finish<<<1, 256, 0, ctx->stream[0]>>>(a);
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
 }

@@ -44,6 +44,16 @@ struct FprCycleCtl {
     double frms;       // f_rms (multigrid.jl:53), computed on the device by k_cycle_init
 };
 constexpr int FPR_CYC_SLOTS = 8;
+// what the finish of a cycle needs (k_cycle_finish, or the extra workgroup row of the pass that follows it: fpr_cycle_finish_body)
+struct FprFinishArgs {
+    const double* partials;       // null = nothing to finish
+    int n;
+    double* out;
+    double npoints;
+    FprCycleCtl* ctl;
+    const FprSolveState* st;
+    FprCycleCtl* rec_host;
+};
 
 struct FprLevel {  // one multigrid level's scratch (role of prealloc_dict, multigrid.jl:25-38)
     int nx = 0, ny = 0;
@@ -61,6 +71,10 @@ struct FprLevel {  // one multigrid level's scratch (role of prealloc_dict, mult
 
 #ifndef FPR_SEAM_COLS_DEFAULT
 #define FPR_SEAM_COLS_DEFAULT 2    // columns per lane of the seam pass (option mg_seam_cols: 2 = k_seam_march_v3)
+#endif
+#ifndef FPR_FOLD_FINISH_DEFAULT
+#define FPR_FOLD_FINISH_DEFAULT 1  // the finish of cycle k (norm, exit test, record) runs in an extra workgroup row of cycle k+1's first pass below the finest
+                                   // level instead of a launch of its own between the two (option mg_fold_finish)
 #endif
 #ifndef FPR_CG_TAGGED_DEFAULT
 #define FPR_CG_TAGGED_DEFAULT 0    // k_cg_persistent: tile-edge values of r as data-tagged granules (option cg_tagged_edges): measured 6.01 against
@@ -136,6 +150,7 @@ struct fpr_ctx {
     FprCycleCtl* cyc_h = nullptr;      // pinned, FPR_CYC_SLOTS records (one per cycle in flight)
     const int* cyc_skip = nullptr;     // &cyc->stop while fpr_mgsolve2d runs cycles ahead, else null (launches unconditional)
     int cyc_slot = 0;                  // record slot (of cyc_h) the cycle being enqueued reports into
+    FprFinishArgs fin = {};            // fin.partials != null: a finish handed to the next pass below the finest level (fprx_cycle_finish_defer)
     std::map<std::pair<int, int>, std::vector<FprLevel>> arenas;  // keyed by finest (nx, ny)
     double* cg_buf = nullptr;          // CG work vectors (krylov.jl:59-62)
     size_t cg_cap = 0;                 // capacity of cg_buf in doubles
@@ -336,6 +351,31 @@ __device__ __forceinline__ double fpr_sum_partials_256(const double* __restrict_
     return fpr_block_sum<256>(s, red);
 }
 
+// end of a V-cycle: sum(res.^2) of the last post-smoothing sweep exactly as k_finish<0> sums it, r_rms (multigrid.jl:252) and the
+// loop's exit test (:70) on the device.  One block of 256 threads.
+__device__ __forceinline__ void fpr_cycle_finish_body(const FprFinishArgs& a, double* red)
+{
+    if (a.ctl->stop) return;
+    const double s = fpr_sum_partials_256(a.partials, a.n, red);
+    if (threadIdx.x == 0) {
+        a.out[0] = s;
+        const double r = sqrt(s / a.npoints);
+        FprCycleCtl c = *a.ctl;
+        c.rms = r;
+        c.ncycles += 1;
+        c.coarse_iters = a.st->acc_iters;
+        if (r < c.tolf) c.stop = 1;
+        *a.ctl = c;
+        // the record goes to pinned host memory straight from here (no copy command, no event between two cycles);
+        // the host polls `seq`, which is written last
+        FprCycleCtl* rec_host = a.rec_host;
+        rec_host->stop = c.stop; rec_host->ncycles = c.ncycles; rec_host->coarse_iters = c.coarse_iters;
+        rec_host->tolf = c.tolf; rec_host->rms = c.rms; rec_host->frms = c.frms;
+        __threadfence_system();
+        __hip_atomic_store(&rec_host->seq, c.ncycles, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---- twofold-precision sums (Ogita / Rump / Oishi: Sum2, Dot2) ---------------------------------------------------------------
 // A sum is carried as (s, e): s the running floating-point sum, e the plain sum of the rounding errors of every addition
 // (TwoSum) and product (an explicit fma -- not a contraction: the library is built with -ffp-contract=off) made on the way.
@@ -431,6 +471,10 @@ int fprx_finish_sum(fpr_ctx* ctx, const double* partials, int nparts, double* ou
 int fprx_cycle_init(fpr_ctx* ctx, const double* f, size_t n, double tol);
 int fprx_cycle_finish(fpr_ctx* ctx, const double* partials, int nparts, double* sumsq_out_dev, double npoints, int slot);
 int fprx_cycle_wait(fpr_ctx* ctx, int slot, int seq, FprCycleCtl* out);
+// the same finish, handed to the next pass below the finest level (vcycle_level consumes ctx->fin; whatever launches first there without
+// being able to carry it calls fprx_cycle_finish_flush, which launches k_cycle_finish after all)
+int fprx_cycle_finish_defer(fpr_ctx* ctx, const double* partials, int nparts, double* sumsq_out_dev, double npoints, int slot);
+int fprx_cycle_finish_flush(fpr_ctx* ctx);
 int fprx_finish_sum2_plus(fpr_ctx* ctx, const double* p0, const double* p1, int nparts, const double* add2_dev, double* out2_dev,
                           int stream_sel);   // out[b] = sum(list b) + add[b]
 void fprx_ns_worker_free(fpr_ctx* ctx);   // navier2d.hip

@@ -845,10 +845,19 @@ __global__ __launch_bounds__(256) void k_smooth2_march_v2(const double* __restri
                                                            double fac, int rows_per_chunk, int nstrips,
                                                            double* __restrict__ partials, const double* __restrict__ corr_c,
                                                            int apply_BCs, double* __restrict__ res_c_out,
-                                                           double* __restrict__ corr_c_out, const int* __restrict__ skip)
+                                                           double* __restrict__ corr_c_out, const int* __restrict__ skip,
+                                                           FprFinishArgs fin)
 {
-    if (skip && *skip) return;   // a cycle enqueued ahead of the exit test that ended the loop (FprCycleCtl)
     __shared__ double red[16];
+    if (fin.partials && blockIdx.y == gridDim.y - 1) {
+        // the extra workgroup row of a pass that also carries the finish of the cycle BEFORE it (fprx_cycle_finish_defer): norm, exit
+        // test and record of cycle k while this pass -- the first of cycle k+1 below the finest level -- runs; the launches behind it
+        // find `stop` as they would behind k_cycle_finish.  The other workgroups of THIS launch may or may not see it: what they
+        // write is scratch of cycle k+1, which nothing reads once the loop has ended.
+        if (blockIdx.x == 0) fpr_cycle_finish_body(fin, red);
+        return;
+    }
+    if (skip && *skip) return;   // a cycle enqueued ahead of the exit test that ended the loop (FprCycleCtl)
     constexpr int HX = RESTRICT ? 3 : 2;                     // feeder lanes on each side of a strip
     constexpr int SW = 64 - 2 * HX;                          // columns owned by a strip
     const bool uin_zero = (apply_BCs & 512) != 0;            // bit 9: the input field is identically zero (see vcycle_level)

@@ -189,7 +189,7 @@ template <bool N, bool P, bool R, class... A>
 static inline void march_go(fpr_ctx* ctx, dim3 g, hipStream_t s, A... a)
 {
     if (fpr_opt(ctx, "mg_march_v", 2) == 1) k_smooth2_march<N, P, R><<<g, 256, 0, s>>>(a...);
-    else k_smooth2_march_v2<N, P, R><<<g, 256, 0, s>>>(a...);
+    else k_smooth2_march_v2<N, P, R><<<g, 256, 0, s>>>(a..., FprFinishArgs{});
 }
 
 // ---- S fused Jacobi sweeps, register patches (coarse solve on grids too large for one workgroup) ------
@@ -1053,6 +1053,7 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             a.skip = ctx->cyc_skip;
             a.row_solve = fpr_opt(ctx, "mg_small_row", 1) != 0;
             a.prof = (long long*)(uintptr_t)fpr_opt(ctx, "mg_small_prof", 0);   // tools/exp_mg_small_prof.py: device address of 32 int64, or 0
+            if (int rc = fprx_cycle_finish_flush(ctx)) return rc;
             k_mg_small<<<1, MGS_NT, (tot + MGS_RED) * sizeof(double), s>>>(a);
             FPR_CHECK_LAUNCH(ctx);
             if (top) {
@@ -1135,6 +1136,7 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             a.skip = skp;
             const dim3 gd((a.nxD - 1) / MID_TD > 0 ? (a.nxD - 1) / MID_TD : 1, (a.nyD - 1) / MID_TD > 0 ? (a.nyD - 1) / MID_TD : 1);
             const dim3 gu((nx - 1) / MID_TA > 0 ? (nx - 1) / MID_TA : 1, (ny - 1) / MID_TA > 0 ? (ny - 1) / MID_TA : 1);
+            if (int rc = fprx_cycle_finish_flush(ctx)) return rc;
             k_mid_down<<<gd, MID_NT_DOWN, lds_down * sizeof(double), s>>>(a);   // :124-132 of levels d, d+1, d+2
             FPR_CHECK_LAUNCH(ctx);
             double dummy; bool dh;
@@ -1149,6 +1151,12 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
     if ((nx < ny ? nx : ny) > css) {  // multigrid.jl:121
         if (d + 1 >= A.size() || !L.res_c) return fpr_fail(ctx, FPR_ERR_INVALID, "level arena exhausted");
         const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
+        // a finish handed over by the loop (fprx_cycle_finish_defer) rides on the restricting two-sweep pass below; every other way
+        // down launches it first
+        const bool carry_fin = ctx->fin.partials && !top && fpr_opt(ctx, "mg_multi", 1) == 1 && nx >= 64 && ny >= 16 &&
+                               fpr_opt(ctx, "mg_fuse_restrict", 1) != 0 && fpr_opt(ctx, "mg_vx", 1) != 2 && fpr_opt(ctx, "mg_march_v", 2) != 1;
+        if (!carry_fin)
+            if (int rc = fprx_cycle_finish_flush(ctx)) return rc;
         if (fpr_opt(ctx, "mg_multi", 1) == 1 && nx >= 64 && ny >= 16) {
             // temporal blocking, register-rolling march: each smoothing pair is ONE pass (u -> tmp, tmp -> u)
             const bool fuse_r = fpr_opt(ctx, "mg_fuse_restrict", 1) != 0;
@@ -1176,6 +1184,11 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             if (fuse_r) {  // pre-smoothing pair + residual + injection + zero coarse guess in ONE pass (:124-132)
                 const dim3 gr((nstrips_r + 3) / 4, (ny + rpc - 1) / rpc);
                 const bool timed = top && fpr_ktimer_begin(ctx, FPR_KT_MG_PRE, s);
+                if (carry_fin) {   // + one workgroup row: the finish of the cycle before (k_smooth2_march_v2)
+                    const FprFinishArgs fa = ctx->fin;
+                    ctx->fin = FprFinishArgs{};
+                    k_smooth2_march_v2<false, false, true><<<dim3(gr.x, gr.y + 1), 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, apply_BCs | ntf | uz, L.res_c, L.corr_c, skp, fa);
+                } else
                 { if (vx2) k_smooth2_march2<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c, skp); else march_go<false, false, true>(ctx, gr, s, u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, apply_BCs | ntf | uz, L.res_c, L.corr_c, skp); }
                 fpr_ktimer_end(ctx, timed, s);
                 if (apply_BCs && vx2) k_bc_neumann<<<(nyc + 255) / 256, 256, 0, s>>>(L.res_c, nxc, nyc, skp);  // :355-357 (k_smooth2_march does it itself)
@@ -1254,6 +1267,7 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
     }
 
     // ---- coarsest level ----
+    if (int rc = fprx_cycle_finish_flush(ctx)) return rc;
     const int iters = 20 * css;  // :149, :161
     if (solver == FPR_COARSE_JACOBI) {
         if (int rc = fprx_sumsq_scaled_dev(ctx, rhs, N, 1.0, ctx->scalars + 3, 0)) return rc;  // :150
@@ -1943,8 +1957,10 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
                 } else {
                     double* Y = (X == L.tmp) ? L.tmp2 : L.tmp;
                     if (int rc = top_seam(ctx, g, X, f, corr[p], Y, L.res_c, corr[1 - p], apply_BCs, skp)) return rc;
-                    if (int rc = fprx_cycle_finish(ctx, ctx->partials, nps, ctx->scalars, (double)N, slot)) return rc;
+                    // (the finish of cycle k travels with cycle k+1's first pass below the finest level where that is a two-sweep march)
+                    if (int rc = fprx_cycle_finish_defer(ctx, ctx->partials, nps, ctx->scalars, (double)N, slot)) return rc;
                     if (int rc = lower(1 - p)) return rc;   // cycle k+1 below the finest level
+                    if (ctx->fin.partials) return fpr_fail(ctx, FPR_ERR_INVALID, "internal: the finish of cycle %d was not launched", k);
                     units[slot] = {true, X, p};
                     X = Y; p = 1 - p;
                 }

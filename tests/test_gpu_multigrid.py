@@ -383,6 +383,52 @@ def test_seam_pass_with_two_columns_per_lane(fpr, oracle, n, bcs, cols):
     assert np.array_equal(F.tonumpy(x), xo)
 
 
+@pytest.mark.parametrize("n,bcs,css,solver,tol", [(129, False, 5, 0, 1e-9), (513, True, 5, 0, 1e-9), (1025, False, 5, 0, 1e-9),
+                                                   (2049, True, 5, 0, 1e-9), (2049, False, 5, 0, 1e-3), (1025, False, 129, 1, 1e-9),
+                                                   (4097, False, 5, 0, 1e-6)])
+def test_cycle_finish_rides_on_the_next_pass(fpr, oracle, n, bcs, css, solver, tol):
+    """The finish of cycle k (sum of the seam pass's partials, r_rms, the exit test of multigrid.jl:70, the host's record) in an extra
+    workgroup row of cycle k+1's first pass below the finest level (option mg_fold_finish, default 1; k_smooth2_march_v2) against the
+    launch of its own (0): field bit for bit, history and cycle count equal, coarse-iteration count equal -- with the level below the
+    top a two-sweep march (2049^2, 4097^2: carried; 1025^2 with a 129^2 CG coarse level: carried), the three-level kernel (1025^2:
+    launched first) and the LDS-resident hierarchy (129^2: launched first); a loose tolerance ends the loop in the middle of cycles
+    enqueued ahead.  Against the oracle as well where it finishes in seconds."""
+    F, mg = fpr, fpr.multigrid
+    c = F.ctx()
+    h = 1.0 / (n - 1)
+    b = asf(splitmix64_uniform(n * n, 7).reshape((n, n), order="F"))
+    gb = F.asdevice(b)
+    opt = mg.MGOpt()
+    opt.coarse_solve_size, opt.coarse_solver = css, (mg.jacobi if solver == 0 else mg.conjugate_gradient)
+    import warnings
+    got = {}
+    for fold in (1, 0, 1):
+        try:
+            c.set_option("mg_fold_finish", fold)
+            x = F.fzeros(n, n)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, gb, h, 0.0, tol, 12, bcs, opt=opt, return_history=True)
+        finally:
+            c.set_option("mg_fold_finish", 1)
+        if fold in got:
+            assert np.array_equal(F.tonumpy(x), got[fold][0]) and list(hist) == got[fold][1] and cit == got[fold][2]
+        got[fold] = (F.tonumpy(x), list(hist), cit, r)
+    assert np.array_equal(got[1][0], got[0][0])
+    assert got[1][1] == got[0][1], (got[1][1], got[0][1])
+    assert got[1][2] == got[0][2] and got[1][3] == got[0][3]
+    if n <= 2049:
+        xo = farr(n, n)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r_o, hist_o, frms_o = oracle.mgsolve2d(xo, b, h, 0.0, tol, 12, bcs, css, solver)
+        assert len(hist_o) == len(got[1][1])
+        assert np.allclose(got[1][1], hist_o, rtol=1e-10, atol=0)
+        if solver == 0:
+            assert np.array_equal(got[1][0], xo)
+            assert got[1][2] == oracle.last_coarse_iters()
+
+
 def test_config3_five_levels_4097(fpr, oracle):
     """BASELINE config 3 as named: 4097^2, 5 grids (l=8, coarse 257^2), 2+2 Jacobi smooths, multigrid_bench.jl
     protocol.  Jacobi coarse solver: 44 V-cycles / 226 160 coarse sweeps to tol 1e-6 (the coarse solve is capped at

@@ -48,7 +48,7 @@ export @init_parallel_stencil, @reset_parallel_stencil, @parallel, @parallel_ind
        halo_pack!, halo_unpack!, fpr_version,
        init_global_grid, finalize_global_grid, select_device, update_halo!, gather!, nx_g, ny_g, nz_g, x_g, y_g, z_g,
        halo_exchange_begin!, halo_exchange_end!, halo_exchange_comm!, allreduce_sum!, diffusion_3D_array_programming,
-       diffusion_3D_step_τ2_halo!, join_pair!, alloc_fields, provide_arena!, provide_arena_coarse!
+       diffusion_3D_step_τ2_halo!, join_pair!, alloc_fields, alloc_vcycle_fields, churn!, provide_arena!, provide_arena_coarse!
 
 const libfpr = get(ENV, "FPR_HIP_LIB", joinpath(@__DIR__, "..", "finalprojectrepo.jl_amd", "lib", "libfpr_hip.so"))
 
@@ -859,6 +859,36 @@ function provide_arena_coarse!(nx::Integer, ny::Integer, res_c::Union{DA,Nothing
                 pt(res_c), pt(corr_c), pt(corr_c2)))
     ARENA_REFS[(-Int(nx), -Int(ny))] = (res_c, corr_c, corr_c2)
     return nothing
+end
+"""
+    x, b = alloc_vcycle_fields(nx, ny; trial = nothing)
+
+`x`, `b` for `MGsolve_2DPoisson!` on an (nx, ny) grid AND the arrays of the library's arena the passes over the finest grid stream beside them,
+laid out the way that decides the seam pass's mode (4097^2: 99 us against 113, INTEGRATION.md 5): the two ping-pong partners of the finest
+level must differ in placement class from `f` and from the first coarse level's three arrays; the partners may share a class and so may
+everything else.  Two 1 GiB allocations that copy fastest among a pool (`alloc_fields(2, ...)`: different classes) -- `x`, `b` and the
+coarse level are windows of the first, the partners windows of the second.  `trial(x, b) -> ms` (a timed solve) lets the library try both
+orientations and the plain pair.  Grids whose seven arrays do not fit two such allocations get plain arrays.
+"""
+function alloc_vcycle_fields(nx::Integer, ny::Integer; trial = nothing)
+    nf, ncx, ncy = nx * ny, 1 + (nx - 1) ÷ 2, 1 + (ny - 1) ÷ 2
+    blk = 1 << 27                                              # doubles per allocation (1 GiB)
+    step = (nf + (1 << 21)) & ~((1 << 21) - 1)                 # windows start on 16 MiB boundaries
+    cstep = (ncx * ncy + (1 << 19)) & ~((1 << 19) - 1)
+    (2 * step + 3 * cstep > blk || nf * 8 < (64 << 20)) && return AMDGPU.zeros(Float64, nx, ny), AMDGPU.zeros(Float64, nx, ny)
+    win(B, off, m, n) = reshape(view(B, off + 1:off + m * n), m, n)
+    function lay(P, Q)
+        x, b = win(P, 0, nx, ny), win(P, step, nx, ny)
+        cs = [win(P, 2 * step + k * cstep, ncx, ncy) for k in 0:2]
+        t1, t2 = win(Q, 0, nx, ny), win(Q, step, nx, ny)
+        foreach(A -> fill_device!(A, 0.0), cs)
+        provide_arena!(nx, ny, t1, t2)
+        provide_arena_coarse!(nx, ny, cs...)
+        return x, b
+    end
+    judge = trial === nothing ? nothing : (arrs -> trial(lay(arrs[1], arrs[2])...))
+    P, Q = alloc_fields(2, blk; pool = 12, pairs = [(1, 2)], trial = judge)
+    return lay(P, Q)
 end
 policy_ok(pol) = (pol in (parallel, parallel_shmem)) || error()    # multigrid.jl:233-236
 

@@ -16,7 +16,7 @@ import fpr_amd
 F = fpr_amd.load(0)
 mg = F.multigrid
 ctx = F.ctx()
-n = 4097
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4097
 nc = 1 + (n - 1) // 2
 h = 1.0 / (n - 1)
 GiB = 1 << 30

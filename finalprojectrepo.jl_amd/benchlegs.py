@@ -34,24 +34,18 @@ def timer_read(ctx, kind):
     return tot.value, cnt.value
 
 
-def vcycle_block(F, cpu_vcycle=None, steps=5, place=True):
-    """MGsolve / V-cycle wall time at 4097^2 (multigrid_bench.jl protocol, SURVEY 8d C3) with the roofline of its
-    dominant kernels and the CPU baseline beside it (`cpu_vcycle(n, b_host, css=5, solver=0) -> dict`, bench.py's oracle leg)."""
-    with_cpu = cpu_vcycle is not None
+def place_vcycle_fields(F, n, b0, placement):
+    """x, b for MGsolve at n^2 and the arena arrays the passes over the finest grid stream beside them, laid out by placement class.
+    Where the seven arrays lie decides the seam pass's mode (4097^2: 99.5 against 113 us): the two ping-pong partners have to differ in
+    placement class from f and from the first coarse level's three arrays -- the partners may share a class, and so may
+    everything else (tools/exp_mg_slab2.py, EXPERIMENTS 13.10).  So: two 1 GiB allocations P, Q that copy fastest among a pool
+    (fpr_placement_rank: different classes); x, b and the coarse level are windows of P, the partners windows of Q; one timed solve
+    decides the orientation and whether the plain allocation was better after all.  `b0`: the right-hand side (device); `placement`
+    receives the report.  FPRHip.alloc_vcycle_fields is the same for a Julia host."""
     import warnings
 
     mg = F.multigrid
-    ctx = F.ctx()
-    n = 4097
     h = 1.0 / (n - 1)
-    b_host = F.part2.splitmix64_uniform(n * n, 1).reshape((n, n), order="F")
-    b0 = F.asdevice(b_host)
-    # Where the seven arrays of the finest passes lie decides the seam pass's mode (99.5 against 113 us): the two ping-pong partners have
-    # to differ in placement class (DESIGN 3) from f and from the first coarse level's three arrays, which the pass streams beside them
-    # -- the partners may share a class, and so may everything else (tools/exp_mg_slab2.py, EXPERIMENTS 13.10).  So: two 1 GiB
-    # allocations P, Q that copy fastest among a pool (fpr_placement_rank: different classes); x, b and the coarse level are windows of
-    # P, the partners windows of Q; one timed solve decides the orientation and whether the plain allocation was better after all.
-    placement = {}
     GiB = 1 << 30
     nc = 1 + (n - 1) // 2
 
@@ -88,23 +82,42 @@ def vcycle_block(F, cpu_vcycle=None, steps=5, place=True):
         tb.copy_(b0)
         return solve_ms(tx, tb)
 
+    if 8 * n * n > (144 << 20) or 8 * nc * nc > (36 << 20):
+        raise ValueError("the windows are laid out for grids up to 4097^2")
+    x_plain = F.fzeros(n, n)
+    placement["plain_allocation_ms"] = solve_ms(x_plain, b0)      # four plain arrays + the library's own arena: what a host gets unplaced
+    del x_plain
+    P, Q = F.placement.alloc_fields(2, GiB // 8, pool=12, report=placement, pairs=[(0, 1)], trial=trial, trials=3)
+    x, b, t1, t2, cs = windows(P, Q)
+    for a in cs:
+        a.zero_()
+    mg.provide_arena_(n, n, t1, t2)
+    mg.provide_arena_coarse_(n, n, *cs)
+    b.copy_(b0)
+    placement["layout"] = ("x, b and the first coarse level's three arrays are windows of one 1 GiB allocation, the finest level's two "
+                           "ping-pong partners windows of another; the two allocations are the pair of the pool that copies fastest "
+                           "(different placement classes), orientation by a timed solve")
+    if placement.get("trial_ms_best", 0.0) > placement["plain_allocation_ms"]:     # cannot happen on the cards seen; kept honest
+        placement["note_plain_was_faster"] = True
+    return x, b
+
+
+def vcycle_block(F, cpu_vcycle=None, steps=5, place=True):
+    """MGsolve / V-cycle wall time at 4097^2 (multigrid_bench.jl protocol, SURVEY 8d C3) with the roofline of its
+    dominant kernels and the CPU baseline beside it (`cpu_vcycle(n, b_host, css=5, solver=0) -> dict`, bench.py's oracle leg)."""
+    with_cpu = cpu_vcycle is not None
+    import warnings
+
+    mg = F.multigrid
+    ctx = F.ctx()
+    n = 4097
+    h = 1.0 / (n - 1)
+    b_host = F.part2.splitmix64_uniform(n * n, 1).reshape((n, n), order="F")
+    b0 = F.asdevice(b_host)
+    placement = {}
     if place:
         try:
-            x_plain = F.fzeros(n, n)
-            placement["plain_allocation_ms"] = solve_ms(x_plain, b0)      # four plain arrays + the library's own arena: what a host gets unplaced
-            del x_plain
-            P, Q = F.placement.alloc_fields(2, GiB // 8, pool=12, report=placement, pairs=[(0, 1)], trial=trial, trials=3)
-            x, b, t1, t2, cs = windows(P, Q)
-            for a in cs:
-                a.zero_()
-            mg.provide_arena_(n, n, t1, t2)
-            mg.provide_arena_coarse_(n, n, *cs)
-            b.copy_(b0)
-            placement["layout"] = ("x, b and the first coarse level's three arrays are windows of one 1 GiB allocation, the finest level's two "
-                                   "ping-pong partners windows of another; the two allocations are the pair of the pool that copies fastest "
-                                   "(different placement classes), orientation by a timed solve")
-            if placement.get("trial_ms_best", 0.0) > placement["plain_allocation_ms"]:     # cannot happen on the cards seen; kept honest
-                placement["note_plain_was_faster"] = True
+            x, b = place_vcycle_fields(F, n, b0, placement)
             del b0
         except Exception as e:       # the search is an optimisation: the library's own buffers give the same results
             mg.provide_arena_(n, n, None, None)

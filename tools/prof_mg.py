@@ -20,6 +20,12 @@ for kv in filter(None, os.environ.get("FPR_OPTS", "").split(",")):   # e.g. FPR_
     F.ctx().set_option(k, int(v))
 b = F.asdevice(F.part2.splitmix64_uniform(n * n, 1).reshape((n, n), order="F"))
 x = F.fzeros(n, n)
+if n == 4097 and os.environ.get("FPR_PLACE", "1") != "0":    # the arrays laid out as bench.py lays them out (benchlegs.place_vcycle_fields)
+    rep_ = {}
+    import importlib
+
+    x, b = importlib.import_module(F.__name__ + ".benchlegs").place_vcycle_fields(F, n, b, rep_)
+    print("placed: trial best %.3f ms, plain allocation %.3f ms, chosen %s" % (rep_.get("trial_ms_best", 0), rep_.get("plain_allocation_ms", 0), rep_.get("chosen")))
 opt = mg.MGOpt()
 opt.coarse_solve_size = css
 opt.coarse_solver = mg.jacobi if solver == "jacobi" else mg.conjugate_gradient

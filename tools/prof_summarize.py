@@ -5,6 +5,9 @@
     prof_summarize.py pmc    <dir> <out.txt>        counter_collection.csv -> per-kernel mean counter value
     prof_summarize.py timeline <dir> <out.txt> [n]  kernel_trace.csv -> the last n dispatches with durations and gaps
     prof_summarize.py overlap  <dir> <out.txt> [n]  kernel_trace.csv -> the last n dispatches with absolute start / end, queue, grid
+    prof_summarize.py tailstats <dir> <out.txt> <marker> <n>   kernel_trace.csv -> per-kernel calls / avg over the dispatches from the n-th last
+                                                    dispatch of a kernel whose name contains <marker> on (e.g. the last 5 solves of a run that
+                                                    searched a placement first)
 """
 import csv
 import glob
@@ -60,6 +63,22 @@ def overlap(d, out, last=40):
                 r.get("VGPR_Count", "?"), r.get("LDS_Block_Size", "?"), st / 1e3, en / 1e3, (en - st) / 1e3))
 
 
+def tailstats(d, out, marker, n):
+    f = find(d, "*kernel_trace.csv")
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    marks = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
+    start = marks[-n] if len(marks) >= n else 0
+    acc = defaultdict(list)
+    for r in rows[start:]:
+        acc[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    tot = sum(sum(v) for v in acc.values())
+    with open(out, "w") as o:
+        o.write("# rocprofv3 --kernel-trace (%s): the dispatches from the %d-th last `%s` on (%d of %d)\n" % (os.path.basename(f), n, marker, len(rows) - start, len(rows)))
+        o.write("%-70s %8s %14s %14s %8s\n" % ("kernel", "calls", "avg_ns", "total_ns", "pct"))
+        for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+            o.write("%-70s %8d %14.1f %14d %8.2f\n" % (k[:70], len(v), sum(v) / len(v), sum(v), 100.0 * sum(v) / tot))
+
+
 def pmc(d, out):
     f = find(d, "*counter_collection.csv")
     acc = defaultdict(lambda: defaultdict(list))
@@ -76,6 +95,8 @@ def pmc(d, out):
 if __name__ == "__main__":
     if sys.argv[1] == "timeline":
         timeline(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 40)
+    elif sys.argv[1] == "tailstats":
+        tailstats(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]))
     elif sys.argv[1] == "overlap":
         overlap(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 40)
     else:

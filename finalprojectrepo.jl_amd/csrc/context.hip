@@ -433,6 +433,7 @@ __global__ __launch_bounds__(256) void k_cycle_finish(FprFinishArgs a)
 
 int fprx_cycle_init(fpr_ctx* ctx, const double* f, size_t n, double tol)
 {
+    ctx->fin = FprFinishArgs{};   // nothing is handed over from an earlier solve
     // as fprx_sumsq_scaled_dev(f) + the finishing launch, which here also sets up the cycle state (one launch less)
     int g = flat_grid(n);
     const double* partials = ctx->partials;

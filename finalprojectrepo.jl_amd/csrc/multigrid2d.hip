@@ -1870,7 +1870,7 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
         struct Guard {
             fpr_ctx* c;
             bool ok;
-            ~Guard() { c->cyc_skip = nullptr; if (!ok) hipStreamSynchronize(c->stream[0]); }
+            ~Guard() { c->cyc_skip = nullptr; c->fin = FprFinishArgs{}; if (!ok) hipStreamSynchronize(c->stream[0]); }   // (a finish still handed over belongs to a failed loop)
         } guard{ctx, false};
         // rms(f) and the threshold tol * rms(f) stay on the device too (same operations as on the host): no round trip
         // before the first cycle; the host learns both from the first record

@@ -76,6 +76,10 @@ struct FprLevel {  // one multigrid level's scratch (role of prealloc_dict, mult
 #define FPR_FOLD_FINISH_DEFAULT 1  // the finish of cycle k (norm, exit test, record) runs in an extra workgroup row of cycle k+1's first pass below the finest
                                    // level instead of a launch of its own between the two (option mg_fold_finish)
 #endif
+#ifndef FPR_MID4_DEFAULT
+#define FPR_MID4_DEFAULT 0         // the level above k_mid_down's three rides along in its prologue (option mg_mid4): bit-exact, measured 3-4 us per cycle
+                                   // SLOWER than that level's own pass (3.8x redundant recomputation in LDS against a 10 us pass + a launch boundary)
+#endif
 #ifndef FPR_CG_TAGGED_DEFAULT
 #define FPR_CG_TAGGED_DEFAULT 0    // k_cg_persistent: tile-edge values of r as data-tagged granules (option cg_tagged_edges): measured 6.01 against
                                    // 5.83 us per iteration -- the loads in flight in front of barrier 2 lengthen its poll by more than they save behind it
@@ -353,10 +357,28 @@ __device__ __forceinline__ double fpr_sum_partials_256(const double* __restrict_
 
 // end of a V-cycle: sum(res.^2) of the last post-smoothing sweep exactly as k_finish<0> sums it, r_rms (multigrid.jl:252) and the
 // loop's exit test (:70) on the device.  One block of 256 threads.
+// (WIDE: a block of more than 256 threads -- the first 256 sum as a block of 256 would, every thread takes part in the barrier)
+template <bool WIDE = false>
 __device__ __forceinline__ void fpr_cycle_finish_body(const FprFinishArgs& a, double* red)
 {
     if (a.ctl->stop) return;
-    const double s = fpr_sum_partials_256(a.partials, a.n, red);
+    double s;
+    if constexpr (WIDE) {
+        double v = 0.0;
+        if (threadIdx.x < 256)
+            for (int i = threadIdx.x; i < a.n; i += 256) v += a.partials[i];
+        v = fpr_wave_sum(v);
+        if (threadIdx.x < 256 && (threadIdx.x & (FPR_WAVE - 1)) == 0) red[threadIdx.x / FPR_WAVE] = v;
+        __syncthreads();
+        s = 0.0;
+        if (threadIdx.x == 0) {
+            s = red[0];
+#pragma unroll
+            for (int w = 1; w < 256 / FPR_WAVE; ++w) s += red[w];
+        }
+    } else {
+        s = fpr_sum_partials_256(a.partials, a.n, red);
+    }
     if (threadIdx.x == 0) {
         a.out[0] = s;
         const double r = sqrt(s / a.npoints);

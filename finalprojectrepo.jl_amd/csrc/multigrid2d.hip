@@ -1013,6 +1013,126 @@ static bool vcycle_streams(fpr_ctx* ctx, int nx, int ny, int css, int solver)
 // One level of Vcycle_2DPoisson! (multigrid.jl:91-170).  want_norm: top level only -- the r_rms of the
 // last post-smoothing sweep is left in ctx->scalars[0] (as sum of squares) for the caller.
 static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double* u, const double* rhs, double h, double c,
+                        double tol, int css, int solver, int apply_BCs, bool top, double* rms_out_host, bool* rms_is_host);
+
+// Levels dA, dA+1, dA+2 (A > B > C) in two launches around the LDS-resident sub-hierarchy that starts at dA+3 (k_mid_down, k_mg_small,
+// k_mid_up); *taken = false when the levels do not fit that form (nothing launched).  uA / rhsA / hA: solution, right-hand side and mesh
+// width of level A.  LP != null: the level ABOVE A (A', at most 1025^2) rides along on the way down -- k_mid_down's prologue does its two
+// pre-smoothing sweeps from the zero guess and its residual + injection from rhsP (pointwise recomputation, no pass of its own), stores
+// its pre-smoothed field and A's right-hand side; its post-smoothing pass stays the caller's.  A finish handed over by the loop
+// (fprx_cycle_finish_defer) rides in one more row of k_mid_down's workgroups.
+static int mid_path(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double* uA, const double* rhsA, double hA, double c, double tol, int css,
+                    int solver, int apply_BCs, const FprLevel* LP, const double* rhsP, double hP, bool* taken)
+{
+    *taken = false;
+    if (!(solver == FPR_COARSE_JACOBI && fpr_opt(ctx, "mg_mid", 1) && fpr_opt(ctx, "mg_small", 1) &&
+          fpr_opt(ctx, "mg_multi", 1) == 1 && fpr_opt(ctx, "mg_fuse_restrict", 1) && fpr_opt(ctx, "mg_fuse_prolong", 1) &&
+          fpr_opt(ctx, "mg_vx", 1) != 2 && d + 3 < A.size()))
+        return FPR_OK;
+    hipStream_t s = ctx->stream[0];
+    const int* skp = ctx->cyc_skip;
+    const int nx = A[d].nx, ny = A[d].ny;
+    bool ok = true;
+    for (int k = 0; k < 3 && ok; ++k) {   // levels d .. d+2 are levels the march would take, and they coarsen
+        const FprLevel& Lk = A[d + k];
+        const int m = (Lk.nx < Lk.ny ? Lk.nx : Lk.ny) - 1;
+        ok = Lk.res_c && Lk.corr_c && Lk.tmp && (Lk.nx - 1) % 2 == 0 && (Lk.ny - 1) % 2 == 0 && m > 0 && (m & (m - 1)) == 0 &&
+             (Lk.nx < Lk.ny ? Lk.nx : Lk.ny) > css && Lk.nx >= 64 && Lk.ny >= 16 && Lk.nx <= 1025 && Lk.ny <= 1025;
+    }
+    if (ok && LP)
+        ok = LP->res_c && LP->corr_c && LP->tmp && LP->nx == 2 * (nx - 1) + 1 && LP->ny == 2 * (ny - 1) + 1 && LP->nx <= 1025 && LP->ny <= 1025 &&
+             rhsA == LP->res_c;
+    int nlevD = 0;
+    size_t totD = 0;
+    ok = ok && mgs_plan(A[d + 3].nx, A[d + 3].ny, css, &nlevD, &totD);
+    size_t lds_down = 0, lds_up = 0;
+    if (ok) {
+        const int nxD = A[d + 3].nx, nyD = A[d + 3].ny;
+        auto own_max = [](int n, int t) { return (n - 1) / t > 0 ? t + 1 + (n - 1) % t : n; };   // widest tile (the last one)
+        {   // k_mid_down: F | U1 on rf, U2 on rt per level, the level-D tile
+            long wx = own_max(nxD, MID_TD), wy = own_max(nyD, MID_TD);
+            lds_down = (size_t)(wx * wy);
+            for (int k = 2; k >= 0; --k) {
+                long tx = 2 * wx + 1, ty = 2 * wy + 1;
+                long fx = tx + 2, fy = ty + 2;
+                if (tx > A[d + k].nx) tx = A[d + k].nx;
+                if (ty > A[d + k].ny) ty = A[d + k].ny;
+                if (fx > A[d + k].nx) fx = A[d + k].nx;
+                if (fy > A[d + k].ny) fy = A[d + k].ny;
+                lds_down += (size_t)(2 * fx * fy + tx * ty);
+                wx = fx; wy = fy;
+            }
+            if (LP) {   // the prologue: F of level A on rf[0] | the level above's right-hand side on rf[0] doubled and grown by two
+                long sx = 2 * wx + 3, sy = 2 * wy + 3;
+                if (sx > LP->nx) sx = LP->nx;
+                if (sy > LP->ny) sy = LP->ny;
+                const size_t need = (size_t)(wx * wy + sx * sy);
+                if (need > lds_down) lds_down = need;
+            }
+        }
+        {   // k_mid_up: X on rc, F and U1 on r1, U2 on r2 per level, the level-D field
+            long wx = own_max(A[d].nx, MID_TA), wy = own_max(A[d].ny, MID_TA);
+            for (int k = 0; k < 3; ++k) {
+                if (wx > A[d + k].nx) wx = A[d + k].nx;
+                if (wy > A[d + k].ny) wy = A[d + k].ny;
+                lds_up += (size_t)((wx + 4) * (wy + 4) + 2 * (wx + 2) * (wy + 2) + wx * wy);
+                wx = (wx + 4 + 1) / 2 + 1; wy = (wy + 4 + 1) / 2 + 1;
+            }
+            lds_up += (size_t)(wx * wy);
+        }
+        ok = lds_down <= 20000 && lds_up <= 20000;
+    }
+    if (!ok) return FPR_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        FPR_HIP(ctx, hipFuncSetAttribute((const void*)k_mid_down, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FPR_HIP(ctx, hipFuncSetAttribute((const void*)k_mid_up, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    MidArgs a;
+    double hk = hA;
+    for (int k = 0; k < 3; ++k) {
+        FprLevel& Lk = A[d + k];
+        a.L[k].f = (k == 0) ? rhsA : A[d + k - 1].res_c;
+        a.L[k].tmp = Lk.tmp;
+        a.L[k].fout = Lk.res_c;
+        a.L[k].nx = Lk.nx; a.L[k].ny = Lk.ny;
+        a.L[k].C = 4.0 + c * (hk * hk);
+        a.L[k]._h2 = 1 / (hk * hk);
+        a.L[k].fac = (4.0 / 5.0) * ((hk * hk) / (4.0 + c * (hk * hk)));
+        hk = hk * 2;   // the recursion passes h*2 (multigrid.jl:133)
+    }
+    a.top4 = LP ? 1 : 0;
+    a.P = a.L[0];
+    if (LP) {
+        a.P.f = rhsP; a.P.tmp = LP->tmp; a.P.fout = LP->res_c;
+        a.P.nx = LP->nx; a.P.ny = LP->ny;
+        a.P.C = 4.0 + c * (hP * hP);
+        a.P._h2 = 1 / (hP * hP);
+        a.P.fac = (4.0 / 5.0) * ((hP * hP) / (4.0 + c * (hP * hP)));
+    }
+    a.nxD = A[d + 3].nx; a.nyD = A[d + 3].ny;
+    a.uD = A[d + 2].corr_c;
+    a.uA = uA;
+    a.apply_BCs = apply_BCs;
+    a.skip = skp;
+    a.fin = ctx->fin;                 // (partials == null: nothing handed over)
+    ctx->fin = FprFinishArgs{};
+    const dim3 gd((a.nxD - 1) / MID_TD > 0 ? (a.nxD - 1) / MID_TD : 1, ((a.nyD - 1) / MID_TD > 0 ? (a.nyD - 1) / MID_TD : 1) + (a.fin.partials ? 1 : 0));
+    const dim3 gu((nx - 1) / MID_TA > 0 ? (nx - 1) / MID_TA : 1, (ny - 1) / MID_TA > 0 ? (ny - 1) / MID_TA : 1);
+    k_mid_down<<<gd, MID_NT_DOWN, lds_down * sizeof(double), s>>>(a);   // :124-132 of levels d, d+1, d+2 (and of the level above)
+    FPR_CHECK_LAUNCH(ctx);
+    a.fin = FprFinishArgs{};
+    double dummy; bool dh;
+    if (int rc = vcycle_level(ctx, A, d + 3, A[d + 2].corr_c, A[d + 2].res_c, hk, c, tol, css, solver, apply_BCs, false, &dummy, &dh))
+        return rc;  // :133 (k_mg_small)
+    k_mid_up<<<gu, MID_NT_UP, lds_up * sizeof(double), s>>>(a);       // :136-143 of levels d+2, d+1, d
+    FPR_CHECK_LAUNCH(ctx);
+    *taken = true;
+    return FPR_OK;
+}
+
+static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double* u, const double* rhs, double h, double c,
                         double tol, int css, int solver, int apply_BCs, bool top, double* rms_out_host, bool* rms_is_host)
 {
     FprLevel& L = A[d];
@@ -1066,86 +1186,10 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
     }
 
     // ---- three launch-bound levels in two launches (k_mid_down / k_mid_up) around the LDS-resident sub-hierarchy ----
-    if (!top && solver == FPR_COARSE_JACOBI && fpr_opt(ctx, "mg_mid", 1) && fpr_opt(ctx, "mg_small", 1) &&
-        fpr_opt(ctx, "mg_multi", 1) == 1 && fpr_opt(ctx, "mg_fuse_restrict", 1) && fpr_opt(ctx, "mg_fuse_prolong", 1) &&
-        fpr_opt(ctx, "mg_vx", 1) != 2 && d + 3 < A.size()) {
-        bool ok = true;
-        for (int k = 0; k < 3 && ok; ++k) {   // levels d .. d+2 are levels the march would take, and they coarsen
-            const FprLevel& Lk = A[d + k];
-            const int m = (Lk.nx < Lk.ny ? Lk.nx : Lk.ny) - 1;
-            ok = Lk.res_c && Lk.corr_c && Lk.tmp && (Lk.nx - 1) % 2 == 0 && (Lk.ny - 1) % 2 == 0 && m > 0 && (m & (m - 1)) == 0 &&
-                 (Lk.nx < Lk.ny ? Lk.nx : Lk.ny) > css && Lk.nx >= 64 && Lk.ny >= 16 && Lk.nx <= 1025 && Lk.ny <= 1025;
-        }
-        int nlevD = 0;
-        size_t totD = 0;
-        ok = ok && mgs_plan(A[d + 3].nx, A[d + 3].ny, css, &nlevD, &totD);
-        size_t lds_down = 0, lds_up = 0;
-        if (ok) {
-            const int nxD = A[d + 3].nx, nyD = A[d + 3].ny;
-            auto own_max = [](int n, int t) { return (n - 1) / t > 0 ? t + 1 + (n - 1) % t : n; };   // widest tile (the last one)
-            {   // k_mid_down: F | U1 on rf, U2 on rt per level, the level-D tile
-                long wx = own_max(nxD, MID_TD), wy = own_max(nyD, MID_TD);
-                lds_down = (size_t)(wx * wy);
-                for (int k = 2; k >= 0; --k) {
-                    long tx = 2 * wx + 1, ty = 2 * wy + 1;
-                    long fx = tx + 2, fy = ty + 2;
-                    if (tx > A[d + k].nx) tx = A[d + k].nx;
-                    if (ty > A[d + k].ny) ty = A[d + k].ny;
-                    if (fx > A[d + k].nx) fx = A[d + k].nx;
-                    if (fy > A[d + k].ny) fy = A[d + k].ny;
-                    lds_down += (size_t)(2 * fx * fy + tx * ty);
-                    wx = fx; wy = fy;
-                }
-            }
-            {   // k_mid_up: X on rc, F and U1 on r1, U2 on r2 per level, the level-D field
-                long wx = own_max(A[d].nx, MID_TA), wy = own_max(A[d].ny, MID_TA);
-                for (int k = 0; k < 3; ++k) {
-                    if (wx > A[d + k].nx) wx = A[d + k].nx;
-                    if (wy > A[d + k].ny) wy = A[d + k].ny;
-                    lds_up += (size_t)((wx + 4) * (wy + 4) + 2 * (wx + 2) * (wy + 2) + wx * wy);
-                    wx = (wx + 4 + 1) / 2 + 1; wy = (wy + 4 + 1) / 2 + 1;
-                }
-                lds_up += (size_t)(wx * wy);
-            }
-            ok = lds_down <= 20000 && lds_up <= 20000;
-        }
-        if (ok) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                FPR_HIP(ctx, hipFuncSetAttribute((const void*)k_mid_down, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                FPR_HIP(ctx, hipFuncSetAttribute((const void*)k_mid_up, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_set = true;
-            }
-            MidArgs a;
-            double hk = h;
-            for (int k = 0; k < 3; ++k) {
-                FprLevel& Lk = A[d + k];
-                a.L[k].f = (k == 0) ? rhs : A[d + k - 1].res_c;
-                a.L[k].tmp = Lk.tmp;
-                a.L[k].fout = Lk.res_c;
-                a.L[k].nx = Lk.nx; a.L[k].ny = Lk.ny;
-                a.L[k].C = 4.0 + c * (hk * hk);
-                a.L[k]._h2 = 1 / (hk * hk);
-                a.L[k].fac = (4.0 / 5.0) * ((hk * hk) / (4.0 + c * (hk * hk)));
-                hk = hk * 2;   // the recursion passes h*2 (multigrid.jl:133)
-            }
-            a.nxD = A[d + 3].nx; a.nyD = A[d + 3].ny;
-            a.uD = A[d + 2].corr_c;
-            a.uA = u;
-            a.apply_BCs = apply_BCs;
-            a.skip = skp;
-            const dim3 gd((a.nxD - 1) / MID_TD > 0 ? (a.nxD - 1) / MID_TD : 1, (a.nyD - 1) / MID_TD > 0 ? (a.nyD - 1) / MID_TD : 1);
-            const dim3 gu((nx - 1) / MID_TA > 0 ? (nx - 1) / MID_TA : 1, (ny - 1) / MID_TA > 0 ? (ny - 1) / MID_TA : 1);
-            if (int rc = fprx_cycle_finish_flush(ctx)) return rc;
-            k_mid_down<<<gd, MID_NT_DOWN, lds_down * sizeof(double), s>>>(a);   // :124-132 of levels d, d+1, d+2
-            FPR_CHECK_LAUNCH(ctx);
-            double dummy; bool dh;
-            if (int rc = vcycle_level(ctx, A, d + 3, A[d + 2].corr_c, A[d + 2].res_c, hk, c, tol, css, solver, apply_BCs, false, &dummy, &dh))
-                return rc;  // :133 (k_mg_small)
-            k_mid_up<<<gu, MID_NT_UP, lds_up * sizeof(double), s>>>(a);       // :136-143 of levels d+2, d+1, d
-            FPR_CHECK_LAUNCH(ctx);
-            return FPR_OK;
-        }
+    if (!top) {
+        bool taken = false;
+        if (int rc = mid_path(ctx, A, d, u, rhs, h, c, tol, css, solver, apply_BCs, nullptr, nullptr, 0.0, &taken)) return rc;
+        if (taken) return FPR_OK;
     }
 
     if ((nx < ny ? nx : ny) > css) {  // multigrid.jl:121
@@ -1181,6 +1225,15 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             // below the top level u is the zero guess the level above has just stored (:132): the pre-smoothing pass is told so
             // (bit 9) and does not read it (k_smooth2_march_v2; option mg_zero_guess = 0: read it like any field)
             const int uz = (!top && fpr_opt(ctx, "mg_zero_guess", 1) != 0) ? 512 : 0;
+            // Where the three levels below are k_mid_down's, this level rides along on the way down (mid_path with LP = this level): its
+            // two sweeps from the zero guess and its residual are recomputed pointwise in that launch's prologue, so its pre-smoothing
+            // pass is not launched at all (option mg_mid4, off by default: 1025^2 under a 2049^2 or 4097^2 top level saves a 10.4 us pass and a
+            // launch boundary and costs 16-17 us of recomputation in LDS -- EXPERIMENTS 13.14)
+            bool down4 = false;
+            if (!top && fuse_r && fuse_p && !vx2 && uz && nx <= 1025 && ny <= 1025 && d + 4 < A.size() && fpr_opt(ctx, "mg_mid4", FPR_MID4_DEFAULT))
+                if (int rc = mid_path(ctx, A, d + 1, L.corr_c, L.res_c, h * 2, c, tol, css, solver, apply_BCs, &L, rhs, h, &down4)) return rc;
+            if (down4) {
+            } else
             if (fuse_r) {  // pre-smoothing pair + residual + injection + zero coarse guess in ONE pass (:124-132)
                 const dim3 gr((nstrips_r + 3) / 4, (ny + rpc - 1) / rpc);
                 const bool timed = top && fpr_ktimer_begin(ctx, FPR_KT_MG_PRE, s);
@@ -1198,6 +1251,7 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             }
             FPR_CHECK_LAUNCH(ctx);
             double dummy; bool dh;
+            if (!down4)
             if (int rc = vcycle_level(ctx, A, d + 1, L.corr_c, L.res_c, h * 2, c, tol, css, solver, apply_BCs, false, &dummy, &dh))
                 return rc;  // :133
             if (!fuse_p) k_prolong2d<true><<<g, blk2, 0, s>>>(L.corr_c, L.tmp, nx, ny, apply_BCs);  // :136-139

@@ -429,6 +429,48 @@ def test_cycle_finish_rides_on_the_next_pass(fpr, oracle, n, bcs, css, solver, t
             assert got[1][2] == oracle.last_coarse_iters()
 
 
+@pytest.mark.parametrize("nx,ny,bcs,cc,tol", [(2049, 2049, False, 0.0, 1e-9), (2049, 2049, True, 0.0, 1e-9), (2049, 2049, False, 5.0e6, 1e-7),
+                                              (2049, 1025, True, 3.0, 1e-9), (1025, 2049, False, 0.0, 1e-9), (4097, 4097, True, 0.0, 1e-6),
+                                              (1025, 1025, True, 0.0, 1e-9)])
+def test_level_above_the_three_rides_along(fpr, oracle, nx, ny, bcs, cc, tol):
+    """Option mg_mid4 (opt-in; measured 3-4 us per cycle slower than the pass it replaces, EXPERIMENTS 13.14): where the three levels below a level of at most 1025^2 are k_mid_down's, that level's pre-smoothing
+    pass is not launched -- its two sweeps from the zero guess (multigrid.jl:124-125 after :132) and its residual + injection (:128-131)
+    are recomputed pointwise from its right-hand side in k_mid_down's prologue, which stores its pre-smoothed field and the next level's
+    right-hand side.  Against the launch of its own (0): fields bit for bit, histories, cycle and coarse-iteration counts equal; against
+    the oracle: field bit for bit, history to 1e-10.  Poisson and Helmholtz (the Navier-Stokes solves' c = 1 / (beta dt)), with and without
+    apply_BCs (the Neumann columns of the injected residual, part2_utils.jl:35-39), non-square grids, 1025^2 (not taken: the level
+    below the top is k_mid_down's own)."""
+    F, mg = fpr, fpr.multigrid
+    c = F.ctx()
+    h = 1.0 / (nx - 1)
+    b = asf(splitmix64_uniform(nx * ny, 11).reshape((nx, ny), order="F"))
+    gb = F.asdevice(b)
+    import warnings
+    got = {}
+    for m4 in (1, 0):
+        try:
+            c.set_option("mg_mid4", m4)
+            x = F.fzeros(nx, ny)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, gb, h, cc, tol, 8, bcs, opt=mg.MGOpt(), return_history=True)
+        finally:
+            c.set_option("mg_mid4", 0)
+        got[m4] = (F.tonumpy(x), list(hist), cit, r)
+    assert np.array_equal(got[1][0], got[0][0])
+    assert got[1][1] == got[0][1], (got[1][1], got[0][1])
+    assert got[1][2] == got[0][2] and got[1][3] == got[0][3]
+    if nx * ny <= 2049 * 2049:
+        xo = farr(nx, ny)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r_o, hist_o, frms_o = oracle.mgsolve2d(xo, b, h, cc, tol, 8, bcs, 5, 0)
+        assert len(hist_o) == len(got[1][1])
+        assert np.allclose(got[1][1], hist_o, rtol=1e-10, atol=0)
+        assert np.array_equal(got[1][0], xo)
+        assert got[1][2] == oracle.last_coarse_iters()
+
+
 def test_config3_five_levels_4097(fpr, oracle):
     """BASELINE config 3 as named: 4097^2, 5 grids (l=8, coarse 257^2), 2+2 Jacobi smooths, multigrid_bench.jl
     protocol.  Jacobi coarse solver: 44 V-cycles / 226 160 coarse sweeps to tol 1e-6 (the coarse solve is capped at

@@ -176,6 +176,8 @@ def hoist_scalars(out, placement, unplaced):
     c["vcycle_placement_selected"] = g(out, "vcycle", "config", "field_placement", "selected")
     c["vcycle_placement_trial_ms_best"] = g(out, "vcycle", "config", "field_placement", "trial_ms_best")
     c["vcycle_placement_trial_ms_worst"] = g(out, "vcycle", "config", "field_placement", "trial_ms_worst")
+    c["vcycle_plain_allocation_ms"] = g(out, "vcycle", "config", "field_placement", "plain_allocation_ms")     # a solve on four plain arrays + the library's own arena
+    c["vcycle_pool_fastest_pair_GBs"] = g(out, "vcycle", "config", "field_placement", "pair_copy_GBs_chosen", "slowest")
     c["vcycle_seam_us"] = (g(out, "vcycle", "roofline", "kernels", "finest_seam_pass", "ms") or 0.0) * 1e3 or None
     c["vcycle_pre_us"] = (g(out, "vcycle", "roofline", "kernels", "finest_pre_pass", "ms") or 0.0) * 1e3 or None
     c["vcycle_post_us"] = (g(out, "vcycle", "roofline", "kernels", "finest_post_pass", "ms") or 0.0) * 1e3 or None

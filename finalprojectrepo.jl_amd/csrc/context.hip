@@ -60,6 +60,7 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
         }
     for (auto& e : ctx->ktimer_ev) hipEventDestroy(e);
     if (ctx->cg_buf) hipFree(ctx->cg_buf);
+    if (ctx->pyr_buf) hipFree(ctx->pyr_buf);
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->partials2) hipFree(ctx->partials2);
     if (ctx->core_partials) hipFree(ctx->core_partials);

@@ -142,6 +142,9 @@ struct fpr_ctx {
     hipStream_t aux_stream = nullptr;  // k_jacobi_persist_tag: the exit tests of a launch run here, beside the next launch
     hipEvent_t aux_ev[3] = {nullptr, nullptr, nullptr};   // [0] compute -> side stream; [1], [2] the tests of even / odd launches
     long long jacp_epoch = 0;          // k_jacobi_persist_tag: solves so far (upper half of every granule's tag)
+    void* pyr_buf = nullptr;           // k_pyr_down: the right-hand sides of three levels as granules
+    size_t pyr_cap = 0;
+    long long pyr_epoch = 0;           // k_pyr_down: launches so far * 4 (a level's granules carry epoch + level)
     int jacp_resident_key = 0;         // (sweeps per group * 10 + patch rows) the occupancy answer above belongs to
     double* partials = nullptr;     // FPR_MAX_PARTIALS doubles: block partial sums (slot 0)
     double* partials2 = nullptr;    // second slot (comm stream / second reduction of a kernel)

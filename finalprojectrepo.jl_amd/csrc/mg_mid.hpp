@@ -40,6 +40,7 @@ struct MidArgs {
     MidLevel L[3];       // A, B, C
     MidLevel P;          // top4: the level above A (k_mid_down's prologue: f = its right-hand side, tmp = its pre-smoothed field, fout = A's right-hand side)
     int top4;
+    int zfuse;           // k_mid_down: the two sweeps from the zero guess as one pass (option mg_zero_fuse)
     FprFinishArgs fin;   // k_mid_down: partials != null = the finish of the cycle before, done by one more row of workgroups
     int nxD, nyD;        // the level below C (top of the LDS-resident sub-hierarchy)
     double* uD;          // down: its zero initial guess is written; up: its solution is read
@@ -68,6 +69,36 @@ __device__ __forceinline__ void mid_sweep(const double* in, const MidReg& ri, co
         double v = uc;
         if (i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1) {
             const double r = ((((in[q + 1] + in[q - 1]) + in[q + wi]) + in[q - wi]) - C * uc) * _h2 - f[mid_at(rf, i, j)];
+            v = uc + fac * r;
+        }
+        out[idx] = v;
+    }
+}
+
+// A level below the top starts from the ZERO guess (multigrid.jl:132): its first sweep (:124) is a pointwise function of the right-hand
+// side -- the literal arithmetic of the sweep on zeros, kept bit for bit --
+__device__ __forceinline__ double mid_z1(double f, double C, double _h2, double fac)
+{
+    const double r = ((((0.0 + 0.0) + 0.0) + 0.0) - C * 0.0) * _h2 - f;
+    return 0.0 + fac * r;
+}
+// -- so the SECOND sweep (:125) is taken straight from the right-hand side (on region rf, which holds ro grown by one, clipped): no pass,
+// no buffer and no barrier for the first.  out on region ro; same expressions in the same order as sweep after sweep.
+__device__ __forceinline__ void mid_sweep_z2(const double* f, const MidReg& rf, double* out, const MidReg& ro, int nx, int ny, double C,
+                                             double _h2, double fac, int nt)
+{
+    const int w = mid_w(ro), n = mid_n(ro);
+    const float rw = 1.0f / (float)w;
+    const int wf = mid_w(rf);
+    auto u1 = [&](int i, int j, int q) { return (i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1) ? mid_z1(f[q], C, _h2, fac) : 0.0; };
+    for (int idx = threadIdx.x; idx < n; idx += nt) {
+        const int jj = mgs_row(idx, rw), ii = idx - jj * w;
+        const int i = ro.x0 + ii, j = ro.y0 + jj;
+        const int q = mid_at(rf, i, j);
+        double v = 0.0;
+        if (i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1) {
+            const double uc = mid_z1(f[q], C, _h2, fac);
+            const double r = ((((u1(i + 1, j, q + 1) + u1(i - 1, j, q - 1)) + u1(i, j + 1, q + wf)) + u1(i, j - 1, q - wf)) - C * uc) * _h2 - f[q];
             v = uc + fac * r;
         }
         out[idx] = v;
@@ -209,6 +240,9 @@ __global__ __launch_bounds__(MID_NT_DOWN) void k_mid_down(MidArgs a)
         double* U1 = F + nf;
         double* U2 = U1 + nf;
         double* Fn = U2 + ntm;   // next level's right-hand side
+        if (a.zfuse) {   // both sweeps from the zero initial guess in one pass over rt (mid_sweep_z2)
+            mid_sweep_z2(F, rf[l], U2, rt[l], L.nx, L.ny, L.C, L._h2, L.fac, NT);
+        } else {
         {   // first sweep from the zero initial guess (:124 with u = 0; the literal arithmetic on zeros, kept bit for bit)
             const int w = mid_w(rf[l]);
             const float rw = 1.0f / (float)w;
@@ -225,6 +259,7 @@ __global__ __launch_bounds__(MID_NT_DOWN) void k_mid_down(MidArgs a)
         }
         __syncthreads();
         mid_sweep(U1, rf[l], F, rf[l], U2, rt[l], L.nx, L.ny, L.C, L._h2, L.fac, NT);   // :125
+        }
         __syncthreads();
         {   // the owned part of the pre-smoothed field goes to memory (the post-smoothing pass reads it)
             MidReg o;

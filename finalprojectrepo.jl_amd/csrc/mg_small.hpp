@@ -24,6 +24,7 @@ struct MgSmallArgs {
     double* out_sumsq;  // want_norm: sum(res.^2) of the last post-smoothing sweep of the top level
     FprSolveState* state;
     const int* skip;    // cycles enqueued ahead: return at once if *skip (null = unconditional)
+    int zfuse;          // 1: the two pre-smoothing sweeps of a level that starts from the zero guess (every level but the top) are one pass; 2: the top level too
     int row_solve;      // 1: coarsest grids with <= 16 interior points are solved inside one DPP row (option mg_small_row)
     long long* prof;    // diagnostic (option mg_small_prof): wall_clock64 stamps (100 MHz) of thread 0 at the section borders
 };
@@ -76,6 +77,30 @@ __device__ __forceinline__ double mgs_sweep(const double* uin, const double* f, 
     return acc;
 }
 
+// the two sweeps from the ZERO guess (multigrid.jl:124-125 after :132) in one pass: the first is a pointwise function of f (the literal
+// arithmetic of the sweep on zeros), so the second is taken straight from f -- same expressions in the same order
+__device__ __forceinline__ double mgs_z1(double f, double C, double _h2, double fac)
+{
+    const double r = ((((0.0 + 0.0) + 0.0) + 0.0) - C * 0.0) * _h2 - f;
+    return 0.0 + fac * r;
+}
+__device__ __forceinline__ void mgs_sweep_z2(const double* f, double* uout, int nx, int ny, double C, double _h2, double fac)
+{
+    const int N = nx * ny;
+    const float rnx = 1.0f / (float)nx;
+    auto u1 = [&](int i, int j, int q) { return (i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1) ? mgs_z1(f[q], C, _h2, fac) : 0.0; };
+    for (int idx = threadIdx.x; idx < N; idx += MGS_NT) {
+        const int j = mgs_row(idx, rnx), i = idx - j * nx;
+        double v = 0.0;
+        if (i >= 1 && j >= 1 && i < nx - 1 && j < ny - 1) {
+            const double uc = mgs_z1(f[idx], C, _h2, fac);
+            const double r = ((((u1(i + 1, j, idx + 1) + u1(i - 1, j, idx - 1)) + u1(i, j + 1, idx + nx)) + u1(i, j - 1, idx - nx)) - C * uc) * _h2 - f[idx];
+            v = uc + fac * r;
+        }
+        uout[idx] = v;
+    }
+}
+
 __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -105,6 +130,9 @@ __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
         const int N = a.nx * a.ny;
         double* U = arena;
         double* F = arena + N;
+        if (a.zfuse == 2 && a.nlev > 1) {   // u is the zero guess: only the right-hand side is loaded
+            for (int idx = tid; idx < N; idx += MGS_NT) F[idx] = a.rhs[idx];
+        } else
         for (int idx = tid; idx < N; idx += MGS_NT) {
             U[idx] = a.u[idx];
             F[idx] = a.rhs[idx];
@@ -123,9 +151,13 @@ __global__ __launch_bounds__(MGS_NT) void k_mg_small(MgSmallArgs a)
         const double h = hlev(d);
         const double C = 4.0 + a.c * (h * h), _h2 = 1 / (h * h);
         const double fac = (4.0 / 5.0) * ((h * h) / (4.0 + a.c * (h * h)));
-        mgs_sweep(U, F, T, nx, ny, C, _h2, fac);  // :124
-        __syncthreads();
-        mgs_sweep(T, F, U, nx, ny, C, _h2, fac);  // :125
+        if (a.zfuse == 2 || (a.zfuse == 1 && d > 0)) {
+            mgs_sweep_z2(F, U, nx, ny, C, _h2, fac);   // :124-125 from the zero guess
+        } else {
+            mgs_sweep(U, F, T, nx, ny, C, _h2, fac);  // :124
+            __syncthreads();
+            mgs_sweep(T, F, U, nx, ny, C, _h2, fac);  // :125
+        }
         __syncthreads();
         // residual + injection + Neumann rows into the next level's rhs; next level's u = 0 (:128-132)
         const int nxc = lnx(d + 1), nyc = lny(d + 1), Nc = nxc * nyc;

@@ -966,6 +966,7 @@ extern "C" int fpr_mg_arena_provide_coarse(fpr_ctx* ctx, int nx, int ny, double*
 }
 
 #include "mg_mid.hpp"     // k_mid_down, k_mid_up: three launch-bound levels in two launches
+#include "mg_pyramid.hpp" // k_pyr_down: four levels of the way down in one launch, halos exchanged as tagged granules (experiment)
 
 // Does the sub-hierarchy below an (nx, ny) level fit k_mg_small's LDS arena?  nlev = its levels, tot = doubles needed.
 static bool mgs_plan(int nx, int ny, int css, int* nlev_out, size_t* tot_out)
@@ -1103,6 +1104,7 @@ static int mid_path(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double* uA
         hk = hk * 2;   // the recursion passes h*2 (multigrid.jl:133)
     }
     a.top4 = LP ? 1 : 0;
+    a.zfuse = fpr_opt(ctx, "mg_zero_fuse", 1) != 0;
     a.P = a.L[0];
     if (LP) {
         a.P.f = rhsP; a.P.tmp = LP->tmp; a.P.fout = LP->res_c;
@@ -1120,6 +1122,50 @@ static int mid_path(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double* uA
     ctx->fin = FprFinishArgs{};
     const dim3 gd((a.nxD - 1) / MID_TD > 0 ? (a.nxD - 1) / MID_TD : 1, ((a.nyD - 1) / MID_TD > 0 ? (a.nyD - 1) / MID_TD : 1) + (a.fin.partials ? 1 : 0));
     const dim3 gu((nx - 1) / MID_TA > 0 ? (nx - 1) / MID_TA : 1, (ny - 1) / MID_TA > 0 ? (ny - 1) / MID_TA : 1);
+    bool pyr = false;
+    if (LP && fpr_opt(ctx, "mg_pyr_down", 0)) {
+        // the four levels in one launch with exchanged halos (k_pyr_down, mg_pyramid.hpp): every workgroup must be resident -- one per
+        // compute unit (its arena takes most of a CU's LDS)
+        if (ctx->ncu <= 0) {
+            int v = 0;
+            ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
+        }
+        auto own_max = [](int n, int t) { return (n - 1) / t > 0 ? t + 1 + (n - 1) % t : n; };
+        const long w0 = 16L * own_max(a.nxD, MID_TD) - 15 + 4, h0 = 16L * own_max(a.nyD, MID_TD) - 15 + 4;       // the top level's tile grown by two
+        const long w1 = 8L * own_max(a.nxD, MID_TD) - 7 + 4, h1 = 8L * own_max(a.nyD, MID_TD) - 7 + 4;
+        const size_t lds_pyr = (size_t)(2 * w0 * h0 + (w0 - 2) * (h0 - 2) + w1 * h1);
+        const size_t ngr = (size_t)A[d].nx * A[d].ny + (size_t)A[d + 1].nx * A[d + 1].ny + (size_t)A[d + 2].nx * A[d + 2].ny;
+        const long nwg = (long)gd.x * (gd.y - (a.fin.partials ? 1 : 0));
+        if (lds_pyr <= 20000 && nwg <= ctx->ncu && (size_t)A[d].nx * A[d].ny * 16 < 0x7fffffffu) {
+            if (ctx->pyr_cap < ngr * 16) {
+                if (ctx->pyr_buf) { FPR_HIP(ctx, hipStreamSynchronize(s)); FPR_HIP(ctx, hipFree(ctx->pyr_buf)); ctx->pyr_buf = nullptr; ctx->pyr_cap = 0; }
+                FPR_HIP(ctx, hipMalloc(&ctx->pyr_buf, ngr * 16));
+                FPR_HIP(ctx, hipMemsetAsync(ctx->pyr_buf, 0, ngr * 16, s));
+                ctx->pyr_cap = ngr * 16;
+            }
+            static bool attr_pyr = false;
+            if (!attr_pyr) {
+                FPR_HIP(ctx, hipFuncSetAttribute((const void*)k_pyr_down, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_pyr = true;
+            }
+            PyrArgs pa;
+            pa.L[0] = a.P;
+            for (int k = 0; k < 3; ++k) pa.L[k + 1] = a.L[k];
+            char* tb = (char*)ctx->pyr_buf;
+            pa.ftag[0] = tb; tb += (size_t)A[d].nx * A[d].ny * 16;
+            pa.ftag[1] = tb; tb += (size_t)A[d + 1].nx * A[d + 1].ny * 16;
+            pa.ftag[2] = tb;
+            pa.nxD = a.nxD; pa.nyD = a.nyD; pa.uD = a.uD;
+            pa.apply_BCs = apply_BCs; pa.skip = skp;
+            ctx->pyr_epoch += 4;
+            pa.tag_base = (unsigned long long)ctx->pyr_epoch;
+            pa.fin = a.fin;
+            pa.prof = (long long*)(uintptr_t)fpr_opt(ctx, "mg_pyr_prof", 0);
+            k_pyr_down<<<gd, MID_NT_DOWN, lds_pyr * sizeof(double), s>>>(pa);
+            pyr = true;
+        }
+    }
+    if (!pyr)
     k_mid_down<<<gd, MID_NT_DOWN, lds_down * sizeof(double), s>>>(a);   // :124-132 of levels d, d+1, d+2 (and of the level above)
     FPR_CHECK_LAUNCH(ctx);
     a.fin = FprFinishArgs{};
@@ -1172,6 +1218,9 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             a.state = ctx->state;
             a.skip = ctx->cyc_skip;
             a.row_solve = fpr_opt(ctx, "mg_small_row", 1) != 0;
+            // below the top level u is the zero guess the level above has just stored (:132): not loaded, and the two pre-smoothing
+            // sweeps of every level of the sub-hierarchy are one pass (option mg_zero_fuse; mg_zero_guess = 0: u is read like any field)
+            a.zfuse = fpr_opt(ctx, "mg_zero_fuse", 1) != 0 ? ((!top && fpr_opt(ctx, "mg_zero_guess", 1) != 0) ? 2 : 1) : 0;
             a.prof = (long long*)(uintptr_t)fpr_opt(ctx, "mg_small_prof", 0);   // tools/exp_mg_small_prof.py: device address of 32 int64, or 0
             if (int rc = fprx_cycle_finish_flush(ctx)) return rc;
             k_mg_small<<<1, MGS_NT, (tot + MGS_RED) * sizeof(double), s>>>(a);
@@ -1230,7 +1279,8 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             // pass is not launched at all (option mg_mid4, off by default: 1025^2 under a 2049^2 or 4097^2 top level saves a 10.4 us pass and a
             // launch boundary and costs 16-17 us of recomputation in LDS -- EXPERIMENTS 13.14)
             bool down4 = false;
-            if (!top && fuse_r && fuse_p && !vx2 && uz && nx <= 1025 && ny <= 1025 && d + 4 < A.size() && fpr_opt(ctx, "mg_mid4", FPR_MID4_DEFAULT))
+            if (!top && fuse_r && fuse_p && !vx2 && uz && nx <= 1025 && ny <= 1025 && d + 4 < A.size() &&
+                (fpr_opt(ctx, "mg_mid4", FPR_MID4_DEFAULT) || fpr_opt(ctx, "mg_pyr_down", 0)))
                 if (int rc = mid_path(ctx, A, d + 1, L.corr_c, L.res_c, h * 2, c, tol, css, solver, apply_BCs, &L, rhs, h, &down4)) return rc;
             if (down4) {
             } else

@@ -432,6 +432,46 @@ def test_cycle_finish_rides_on_the_next_pass(fpr, oracle, n, bcs, css, solver, t
 @pytest.mark.parametrize("nx,ny,bcs,cc,tol", [(2049, 2049, False, 0.0, 1e-9), (2049, 2049, True, 0.0, 1e-9), (2049, 2049, False, 5.0e6, 1e-7),
                                               (2049, 1025, True, 3.0, 1e-9), (1025, 2049, False, 0.0, 1e-9), (4097, 4097, True, 0.0, 1e-6),
                                               (1025, 1025, True, 0.0, 1e-9)])
+def test_four_levels_down_in_one_launch_with_exchanged_halos(fpr, oracle, nx, ny, bcs, cc, tol):
+    """Option mg_pyr_down (an experiment, off by default): k_pyr_down -- the pre-smoothing passes of four levels in one launch, every
+    workgroup on its own tile grown by two, the halo of each level's right-hand side received from the neighbours as data-tagged
+    granules -- against the launches it replaces (the level's own pass + k_mid_down): fields bit for bit, histories, cycle and
+    coarse-iteration counts equal, and equal to the oracle's."""
+    F, mg = fpr, fpr.multigrid
+    c = F.ctx()
+    h = 1.0 / (nx - 1)
+    b = asf(splitmix64_uniform(nx * ny, 13).reshape((nx, ny), order="F"))
+    gb = F.asdevice(b)
+    import warnings
+    got = {}
+    for pyr in (1, 0, 1):
+        try:
+            c.set_option("mg_pyr_down", pyr)
+            x = F.fzeros(nx, ny)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, gb, h, cc, tol, 8, bcs, opt=mg.MGOpt(), return_history=True)
+        finally:
+            c.set_option("mg_pyr_down", 0)
+        if pyr in got:
+            assert np.array_equal(F.tonumpy(x), got[pyr][0]) and list(hist) == got[pyr][1]
+        got[pyr] = (F.tonumpy(x), list(hist), cit, r)
+    assert not np.isnan(got[1][0]).any()
+    assert np.array_equal(got[1][0], got[0][0])
+    assert got[1][1] == got[0][1], (got[1][1], got[0][1])
+    assert got[1][2] == got[0][2] and got[1][3] == got[0][3]
+    if nx * ny <= 2049 * 2049:
+        xo = farr(nx, ny)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r_o, hist_o, frms_o = oracle.mgsolve2d(xo, b, h, cc, tol, 8, bcs, 5, 0)
+        assert np.allclose(got[1][1], hist_o, rtol=1e-10, atol=0)
+        assert np.array_equal(got[1][0], xo)
+
+
+@pytest.mark.parametrize("nx,ny,bcs,cc,tol", [(2049, 2049, False, 0.0, 1e-9), (2049, 2049, True, 0.0, 1e-9), (2049, 2049, False, 5.0e6, 1e-7),
+                                              (2049, 1025, True, 3.0, 1e-9), (1025, 2049, False, 0.0, 1e-9), (4097, 4097, True, 0.0, 1e-6),
+                                              (1025, 1025, True, 0.0, 1e-9)])
 def test_level_above_the_three_rides_along(fpr, oracle, nx, ny, bcs, cc, tol):
     """Option mg_mid4 (opt-in; measured 3-4 us per cycle slower than the pass it replaces, EXPERIMENTS 13.14): where the three levels below a level of at most 1025^2 are k_mid_down's, that level's pre-smoothing
     pass is not launched -- its two sweeps from the zero guess (multigrid.jl:124-125 after :132) and its residual + injection (:128-131)

@@ -511,6 +511,39 @@ def test_level_above_the_three_rides_along(fpr, oracle, nx, ny, bcs, cc, tol):
         assert got[1][2] == oracle.last_coarse_iters()
 
 
+@pytest.mark.parametrize("n,bcs,cc", [(129, False, 0.0), (257, True, 0.0), (1025, False, 2.5), (2049, True, 0.0)])
+def test_two_sweeps_from_the_zero_guess_as_one_pass(fpr, oracle, n, bcs, cc):
+    """Option mg_zero_fuse (default 1): a level below the top starts from the zero guess (multigrid.jl:132), so its first pre-smoothing
+    sweep (:124) is a pointwise function of its right-hand side and the second (:125) is taken straight from the right-hand side
+    (mid_sweep_z2 in k_mid_down, mgs_sweep_z2 in k_mg_small, which then does not load u either) -- against sweep after sweep (0) and the
+    oracle: fields bit for bit, histories and coarse-iteration counts equal."""
+    F, mg = fpr, fpr.multigrid
+    c = F.ctx()
+    h = 1.0 / (n - 1)
+    b = asf(splitmix64_uniform(n * n, 17).reshape((n, n), order="F"))
+    gb = F.asdevice(b)
+    import warnings
+    got = {}
+    for zf in (1, 0):
+        try:
+            c.set_option("mg_zero_fuse", zf)
+            x = F.asdevice(asf(splitmix64_uniform(n * n, 18).reshape((n, n), order="F")))    # a non-zero initial guess at the top level
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, gb, h, cc, 1e-9, 6, bcs, opt=mg.MGOpt(), return_history=True)
+        finally:
+            c.set_option("mg_zero_fuse", 1)
+        got[zf] = (F.tonumpy(x), list(hist), cit)
+    assert np.array_equal(got[1][0], got[0][0]) and got[1][1] == got[0][1] and got[1][2] == got[0][2]
+    xo = asf(splitmix64_uniform(n * n, 18).reshape((n, n), order="F"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r_o, hist_o, frms_o = oracle.mgsolve2d(xo, b, h, cc, 1e-9, 6, bcs, 5, 0)
+    assert np.allclose(got[1][1], hist_o, rtol=1e-10, atol=0)
+    assert np.array_equal(got[1][0], xo)
+    assert got[1][2] == oracle.last_coarse_iters()
+
+
 def test_config3_five_levels_4097(fpr, oracle):
     """BASELINE config 3 as named: 4097^2, 5 grids (l=8, coarse 257^2), 2+2 Jacobi smooths, multigrid_bench.jl
     protocol.  Jacobi coarse solver: 44 V-cycles / 226 160 coarse sweeps to tol 1e-6 (the coarse solve is capped at

@@ -453,6 +453,31 @@ int fprx_cycle_init(fpr_ctx* ctx, const double* f, size_t n, double tol)
     return FPR_OK;
 }
 
+// the same in two steps: the cycle state reset before the first launch of a solve (f_rms = 0 for the moment), f_rms and the threshold from
+// block partials of sum(f.^2) that the solve's first pass over the finest grid has left (k_smooth2_march_v2<..., FSQ>)
+int fprx_cycle_reset(fpr_ctx* ctx, double tol)
+{
+    ctx->fin = FprFinishArgs{};
+    k_cycle_init<<<1, 256, 0, ctx->stream[0]>>>(ctx->partials, 0, ctx->cyc, ctx->state, tol, 1.0);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
+int fprx_cycle_init_from(fpr_ctx* ctx, const double* partials, int nparts, size_t n, double tol)
+{
+    if (nparts > 2048) {
+        const int nb = 128;
+        const int per = (nparts + nb - 1) / nb;
+        double* fold = ctx->partials + FPR_MAX_PARTIALS;
+        k_fold_partials<<<nb, 256, 0, ctx->stream[0]>>>(partials, nparts, per, fold);
+        partials = fold;
+        nparts = nb;
+    }
+    k_cycle_init<<<1, 256, 0, ctx->stream[0]>>>(partials, nparts, ctx->cyc, ctx->state, tol, (double)n);
+    FPR_CHECK_LAUNCH(ctx);
+    return FPR_OK;
+}
+
 // Host side of the record: wait until the cycle with sequence number `seq` has reported into `slot`.  Polls the pinned
 // record; every now and then it asks the stream whether it has drained or failed, so that a launch that never ran
 // cannot make this spin for ever.

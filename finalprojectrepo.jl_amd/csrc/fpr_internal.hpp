@@ -76,6 +76,10 @@ struct FprLevel {  // one multigrid level's scratch (role of prealloc_dict, mult
 #define FPR_FOLD_FINISH_DEFAULT 1  // the finish of cycle k (norm, exit test, record) runs in an extra workgroup row of cycle k+1's first pass below the finest
                                    // level instead of a launch of its own between the two (option mg_fold_finish)
 #endif
+#ifndef FPR_FOLD_FSQ_DEFAULT
+#define FPR_FOLD_FSQ_DEFAULT 1     // sum(f.^2) (f_rms, multigrid.jl:53) as block partials of the solve's first pass over the finest grid instead of a pass of
+                                   // its own over f (option mg_fold_fsq)
+#endif
 #ifndef FPR_MID4_DEFAULT
 #define FPR_MID4_DEFAULT 0         // the level above k_mid_down's three rides along in its prologue (option mg_mid4): bit-exact, measured 3-4 us per cycle
                                    // SLOWER than that level's own pass (3.8x redundant recomputation in LDS against a 10 us pass + a launch boundary)
@@ -494,6 +498,8 @@ int fprx_dot2_dev(fpr_ctx* ctx, const double* x, const double* y, size_t n, doub
 // finish a two-stage reduction: out_dev[0] (= or +=) sum(partials[0..nparts))
 int fprx_finish_sum(fpr_ctx* ctx, const double* partials, int nparts, double* out_dev, bool accumulate, int stream_sel);
 int fprx_cycle_init(fpr_ctx* ctx, const double* f, size_t n, double tol);
+int fprx_cycle_reset(fpr_ctx* ctx, double tol);
+int fprx_cycle_init_from(fpr_ctx* ctx, const double* partials, int nparts, size_t n, double tol);
 int fprx_cycle_finish(fpr_ctx* ctx, const double* partials, int nparts, double* sumsq_out_dev, double npoints, int slot);
 int fprx_cycle_wait(fpr_ctx* ctx, int slot, int seq, FprCycleCtl* out);
 // the same finish, handed to the next pass below the finest level (vcycle_level consumes ctx->fin; whatever launches first there without

@@ -839,7 +839,8 @@ __global__ __launch_bounds__(256) void k_seam_march_v3(const double* __restrict_
 // reads 0) into a ring of three register pairs three rows ahead of their use; windows live in compile-time slots (no
 // shifting of nine window rows per step); boundary columns keep their value through a per-lane factor, boundary rows
 // through a uniform branch; the residual stage runs in the injected rows only; the norm is masked per lane once at the end.
-template <bool NORM, bool PROLONG, bool RESTRICT>
+// FSQ: the pass also leaves sum(f.^2) of its rows as block partials (the first pass of a solve: f_rms of multigrid.jl:53 without a pass of its own)
+template <bool NORM, bool PROLONG, bool RESTRICT, bool FSQ = false>
 __global__ __launch_bounds__(256) void k_smooth2_march_v2(const double* __restrict__ uin, const double* __restrict__ f,
                                                            double* __restrict__ uout, int nx, int ny, double C, double _h2,
                                                            double fac, int rows_per_chunk, int nstrips,
@@ -874,7 +875,8 @@ __global__ __launch_bounds__(256) void k_smooth2_march_v2(const double* __restri
     const int y1 = (y0 + rows_per_chunk < ny) ? y0 + rows_per_chunk : ny;  // output rows [y0, y1)
     constexpr int HY = RESTRICT ? 4 : 2;                     // rows above the chunk (even: row rs + T has the parity of T)
     const int rs = y0 - HY < 0 ? 0 : y0 - HY;
-    double acc = 0.0;
+    static_assert(!(NORM && FSQ), "one list of block partials");
+    double acc = 0.0, accf = 0.0;
     if (active) {
         const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
         int gis = gic;  // Neumann columns of the prolongated correction (part2_utils.jl:35-39)
@@ -986,6 +988,12 @@ __global__ __launch_bounds__(256) void k_smooth2_march_v2(const double* __restri
                     acc = acc + rr * rr;
                 }
             }
+            if constexpr (FSQ) {
+                if (j2 >= y0 && j2 < y1) {   // uniform: every row of the grid once, boundary rows and columns included (sum(f.^2), :53)
+                    const double fv2 = fw[fs(2)];
+                    accf = accf + fv2 * fv2;
+                }
+            }
             if constexpr (RESTRICT) {
                 wc[M1] = u2;
                 // ---- residual of the twice-smoothed field at row r-3 (even in every odd step), injected at even columns ----
@@ -1019,9 +1027,14 @@ __global__ __launch_bounds__(256) void k_smooth2_march_v2(const double* __restri
         FPR_M2_TAIL(6) FPR_M2_TAIL(7) FPR_M2_TAIL(8) FPR_M2_TAIL(9) FPR_M2_TAIL(10)
 #undef FPR_M2_TAIL
         acc = (owner && !col_bnd) ? acc : 0.0;
+        accf = owner ? accf : 0.0;
     }
     if constexpr (NORM) {
         const double sblk = fpr_block_sum<256>(acc, red);
+        if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
+    }
+    if constexpr (FSQ) {
+        const double sblk = fpr_block_sum<256>(accf, red);
         if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
     }
 }

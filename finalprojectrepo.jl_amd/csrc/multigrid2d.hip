@@ -1850,10 +1850,14 @@ static TopGeom top_geom(fpr_ctx* ctx, int nx, int ny, double h, double c)
 
 // pre-smoothing pair + residual + injection + zero coarse guess (:124-132): uin -> out, L.res_c, corr_zero
 static int top_pre(fpr_ctx* ctx, const TopGeom& g, const double* uin, const double* rhs, double* out, double* res_c,
-                   double* corr_zero, int apply_BCs, const int* skp)
+                   double* corr_zero, int apply_BCs, const int* skp, double* fsq_partials = nullptr)
 {
     hipStream_t s = ctx->stream[0];
     const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_PRE, s);
+    if (fsq_partials)   // the first pass of a solve also leaves sum(f.^2) as block partials (one per workgroup)
+        k_smooth2_march_v2<false, false, true, true><<<g.gr, 256, 0, s>>>(uin, rhs, out, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips_r, fsq_partials,
+                                                                          nullptr, apply_BCs | g.ntf, res_c, corr_zero, skp, FprFinishArgs{});
+    else
     march_go<false, false, true>(ctx, g.gr, s, uin, rhs, out, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips_r, nullptr,
                                                              nullptr, apply_BCs | g.ntf, res_c, corr_zero, skp);   // (:355-357 included)
     fpr_ktimer_end(ctx, timed, s);
@@ -1978,11 +1982,16 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
         } guard{ctx, false};
         // rms(f) and the threshold tol * rms(f) stay on the device too (same operations as on the host): no round trip
         // before the first cycle; the host learns both from the first record
-        if (int rc = fprx_cycle_init(ctx, f, N, tol)) return rc;
         ctx->cyc_skip = &ctx->cyc->stop;
         const int* skp = ctx->cyc_skip;
         int enq = 0;
-        if (fpr_opt(ctx, "mg_seam", 1) && fpr_opt(ctx, "mg_vx", 1) != 2) {
+        const bool seam_path = fpr_opt(ctx, "mg_seam", 1) && fpr_opt(ctx, "mg_vx", 1) != 2;
+        // sum(f.^2) rides on the first pass over the finest grid where that is the two-sweep march (k_smooth2_march_v2<..., FSQ>): the cycle
+        // state is reset now, f_rms and the threshold follow behind that pass (fprx_cycle_init_from); otherwise a pass over f of its own
+        bool fsq = seam_path && fpr_opt(ctx, "mg_fold_fsq", FPR_FOLD_FSQ_DEFAULT) && fpr_opt(ctx, "mg_march_v", 2) != 1;
+        if (!seam_path)
+            if (int rc = fprx_cycle_init(ctx, f, N, tol)) return rc;
+        if (seam_path) {
             // ---- consecutive cycles share their pass over the finest grid (k_seam_march) ----
             // unit k = the end of cycle k: either the plain post-smoothing pass (k = niters, or the norms seen so far say
             // that cycle k will meet the exit test) or a seam pass that also starts cycle k+1, followed by cycle k+1's
@@ -1997,8 +2006,10 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
             if (!L.corr_c2) FPR_HIP(ctx, hipMalloc(&L.corr_c2, nc * sizeof(double)));
             double* corr[2] = {L.corr_c, L.corr_c2};
             const TopGeom g = top_geom(ctx, nx, ny, h, c);
-            const int npm = (int)(g.gm.x * g.gm.y), nps = (int)(g.gs.x * g.gs.y);
+            const int npm = (int)(g.gm.x * g.gm.y), nps = (int)(g.gs.x * g.gs.y), npr = (int)(g.gr.x * g.gr.y);
             if (npm > FPR_MAX_PARTIALS || nps > FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
+            if (npr > FPR_MAX_PARTIALS) fsq = false;
+            if (int rc = fsq ? fprx_cycle_reset(ctx, tol) : fprx_cycle_init(ctx, f, N, tol)) return rc;
             struct Unit { bool seam; const double* X; int p; } units[FPR_CYC_SLOTS];
             double* X = nullptr;
             int p = 0;
@@ -2031,7 +2042,11 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
                 if (need_head) {   // first cycle, or the loop goes on after a plain post-smoothing pass
                     if (apply_BCs)
                         if (int rc = fpr_bc2d(ctx, u, nx, ny)) return rc;  // :60-62
-                    if (int rc = top_pre(ctx, g, u, f, L.tmp, L.res_c, corr[0], apply_BCs, skp)) return rc;
+                    if (int rc = top_pre(ctx, g, u, f, L.tmp, L.res_c, corr[0], apply_BCs, skp, fsq ? ctx->partials : nullptr)) return rc;
+                    if (fsq) {   // (the first pass of the solve only)
+                        if (int rc = fprx_cycle_init_from(ctx, ctx->partials, npr, N, tol)) return rc;
+                        fsq = false;
+                    }
                     if (int rc = lower(0)) return rc;
                     X = L.tmp; p = 0; need_head = false;
                 }

@@ -131,6 +131,9 @@ def hoist_scalars(out, placement, unplaced):
     c["placement_trial_ms_worst"] = placement.get("trial_ms_worst")
     c["placement_trial_ms_plain"] = placement.get("trial_ms_plain_allocation")
     c["placement_churned"] = any(k.startswith("churned_because") for k in placement)
+    c["placement_pair_over_single"] = placement.get("accept_pair_over_single")
+    c["placement_pair_over_single_first_pool"] = placement.get("accept_pair_over_single_first_pool")
+    c["placement_trial_ms_best_before_churn"] = g(placement, "pool_before_churn", "trial_ms_best")
     c["placement_fastest_pair_GBs_before_churn"] = placement.get("churned_because_fastest_pair_GBs")
     c["placement_kept_plain"] = (placement.get("chosen") == [0, 1, 2, 3, 4]) if placement.get("chosen") else None
     c["pool_fastest_pair_GBs"] = g(placement, "pair_copy_GBs_all", "fastest")
@@ -403,8 +406,27 @@ def main():
 
         try:
             # (the plain five are the first candidates: the search keeps them unless an assignment from the pool is faster)
+            # The chosen arrays are accepted when the fused launch takes at most 1.07 x the one-iteration kernel on the same arrays (26
+            # leases with a mixed pool: 1.016-1.058; four whose pool held ONE candidate of another class among eleven alike -- a fast
+            # pair, no good assignment: 1.083-1.090, 0.788-0.795 ms; profiles/r5_driver_repro.txt); otherwise the pool is rebuilt once
+            # behind placement.churn() with the chosen arrays kept as candidates
+            def accept(arrs):
+                tHt, tA, tC, tR, tB = arrs
+                pair = trial(arrs)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for i in range(12):
+                    if i == 4:
+                        e0.record()
+                    F.part1.diffusion_3D_step_τ(tHt, tA if (i & 1) == 0 else tB, tB if (i & 1) == 0 else tA, tR, *coef)
+                e1.record()
+                e1.synchronize()
+                single = e0.elapsed_time(e1) / 8.0
+                placement.setdefault("accept_pair_over_single_first_pool", pair / single)
+                placement["accept_pair_over_single"] = pair / single      # (of the arrays kept)
+                return pair <= 1.07 * single
+
             Ht, Hτ, Hτ3, res, Hτ2 = F.placement.alloc_fields(5, *nloc, report=placement, pairs=[(0, 1), (0, 2), (2, 3), (1, 3), (1, 2)],
-                                                          trial=trial, first=plain)
+                                                          trial=trial, first=plain, accept=accept)
             del plain
         except Exception as e:       # the search is an optimisation: plainly allocated arrays give the same results
             torch.cuda.empty_cache()

@@ -42,11 +42,15 @@ _R = dict(fastest=0, median=1, slowest=2, chosen_slowest=3, chosen_mean=4, trial
 
 
 def alloc_fields(count, *shape, pool=None, min_bytes=256 << 20, report=None, pairs=None, trial=None, trials=4, spacer_bytes=None,
-                 extend_by=10, first=None, extend_below_GBs=None):
+                 extend_by=10, first=None, extend_below_GBs=None, accept=None):
     """`count` zeroed column-major float64 arrays of `shape`, the best-matched of `pool` candidates (default count + 7).  `pairs`:
     positions streamed together; `trial(arrays) -> ms`: the caller's own kernel as the judge; `first`: arrays the caller already
     holds, used as the first candidates (the plain allocation a search must beat); `extend_below_GBs`: the library's option
-    place_extend_below_GBs for this call.  `report` receives what was measured."""
+    place_extend_below_GBs for this call.  `accept(arrays) -> bool`: the caller's own check of the chosen arrays (e.g. the fused launch
+    against the one-iteration kernel on the same arrays): a pool with one candidate of another class among eleven alike has a fast pair and
+    still no good assignment (0.788-0.795 ms where a mixed pool gives 0.745-0.751) -- when it says no, the pool is rebuilt once behind
+    churn() with the chosen arrays as its first candidates, so the second search cannot end below the first.  `report` receives what
+    was measured."""
     import torch
 
     from . import ctx as _ctx
@@ -122,6 +126,27 @@ def alloc_fields(count, *shape, pool=None, min_bytes=256 << 20, report=None, pai
             report["pool_extended_because_" + why] = before
             rank()
     out = [cands[chosen[i]] for i in range(count)]
+    if accept is not None and trial is not None and not _CHURNED[0]:
+        try:
+            ok = bool(accept(out))
+        except Exception:
+            ok = True
+        if not ok:
+            report["churned_because_not_accepted_ms"] = rep[_R["best"]]
+            report["pool_before_churn"] = {"fastest": rep[_R["fastest"]], "median": rep[_R["median"]], "trial_ms_best": rep[_R["best"]]}
+            keep = list(out)
+            del cands[:]
+            spacers.clear()
+            cands.extend(keep)          # the chosen arrays stay: candidates 0 .. count-1 of the second pool (its first trial)
+            del keep, out
+            churn()
+            grow(k)
+            rank()
+            out = [cands[chosen[i]] for i in range(count)]
+            try:
+                report["accepted_after_churn"] = bool(accept(out))
+            except Exception:
+                pass
     report.update({"selected": True, "pool": len(cands), "chosen": [int(chosen[i]) for i in range(count)], "pairs": [list(p) for p in (pairs or [])],
                    "spacer_bytes": spacer if spacers else 0, "trials": int(rep[_R["trials"]]),
                    "pair_copy_GBs_all": {"slowest": rep[_R["slowest"]], "median": rep[_R["median"]], "fastest": rep[_R["fastest"]]},

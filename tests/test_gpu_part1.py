@@ -917,6 +917,19 @@ def test_placement_alloc_fields(fpr):
     assert len(more) == 3 and rep3["pool_first"] == 4 and rep3["pool"] == 6 and rep3["pool_extended_because_trial_spread"] == 0.0
     assert rep3["trials"] > 6 and all(float(a.abs().max()) == 0.0 for a in more)
     del more
+    # ... and a pool whose chosen arrays the caller does not accept is rebuilt once behind churn(), the chosen arrays staying its first
+    # candidates (so the second search starts from the first one's result); a second refusal changes nothing more
+    F.placement._CHURNED[0] = False
+    rep4, seen = {}, []
+    more = F.placement.alloc_fields(3, *n, pool=5, report=rep4, spacer_bytes=256 << 20, extend_by=0, trial=trial, trials=2,
+                                    accept=lambda a: (seen.append([t.data_ptr() for t in a]), False)[1])
+    assert len(more) == 3 and len(seen) == 1 and rep4["churned_because_not_accepted_ms"] > 0.0 and rep4["pool"] == 5
+    assert rep4["pool_before_churn"]["trial_ms_best"] == rep4["churned_because_not_accepted_ms"] and F.placement._CHURNED[0] is True
+    assert all(float(a.abs().max()) == 0.0 for a in more)
+    rep5 = {}
+    again = F.placement.alloc_fields(3, *n, pool=5, report=rep5, spacer_bytes=256 << 20, extend_by=0, trial=trial, trials=2, accept=lambda a: False)
+    assert len(again) == 3 and "churned_because_not_accepted_ms" not in rep5
+    del more, again
     assert rep["pair_copy_GBs_all"]["fastest"] >= rep["pair_copy_GBs_chosen"]["slowest"] >= rep["pair_copy_GBs_all"]["slowest"] > 100.0
     for a in arrs:
         assert tuple(a.shape) == n and a.stride() == (1, n[0], n[0] * n[1]) and float(a.abs().max()) == 0.0

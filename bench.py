@@ -414,13 +414,13 @@ def main():
                 tHt, tA, tC, tR, tB = arrs
                 pair = trial(arrs)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                for i in range(12):
-                    if i == 4:
+                for i in range(24):
+                    if i == 8:
                         e0.record()
                     F.part1.diffusion_3D_step_τ(tHt, tA if (i & 1) == 0 else tB, tB if (i & 1) == 0 else tA, tR, *coef)
                 e1.record()
                 e1.synchronize()
-                single = e0.elapsed_time(e1) / 8.0
+                single = e0.elapsed_time(e1) / 16.0
                 placement.setdefault("accept_pair_over_single_first_pool", pair / single)
                 placement["accept_pair_over_single"] = pair / single      # (of the arrays kept)
                 return pair <= 1.07 * single

@@ -426,7 +426,7 @@ def main():
                 return pair <= 1.07 * single
 
             Ht, Hτ, Hτ3, res, Hτ2 = F.placement.alloc_fields(5, *nloc, report=placement, pairs=[(0, 1), (0, 2), (2, 3), (1, 3), (1, 2)],
-                                                          trial=trial, first=plain, accept=accept)
+                                                          trial=trial, first=plain, accept=None if shared else accept)   # (ranks that share one card do not churn its memory under each other)
             del plain
         except Exception as e:       # the search is an optimisation: plainly allocated arrays give the same results
             torch.cuda.empty_cache()

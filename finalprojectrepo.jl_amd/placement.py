@@ -8,7 +8,9 @@ untouched spacers, because consecutive allocations share a label in runs of four
 library says it is of one class, keep the chosen arrays, free the rest."""
 import ctypes as C
 
-_CHURNED = [False]      # churn() has run in this process (its effect lasts: later pools of the process stay mixed)
+_CHURNED = [0]          # churn() calls of this process so far (the mix it brings does not always outlast the next allocate / free cycle:
+                        # a later pool of the process may churn again, MAX_CHURNS times in all)
+MAX_CHURNS = 3
 
 
 def churn(fraction=0.7, chunk_bytes=48 << 30):
@@ -34,7 +36,7 @@ def churn(fraction=0.7, chunk_bytes=48 << 30):
     torch.cuda.synchronize()
     del held
     torch.cuda.empty_cache()
-    _CHURNED[0] = True
+    _CHURNED[0] = int(_CHURNED[0]) + 1
 
 _TRIAL_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.POINTER(C.c_int), C.c_int)
 _R = dict(fastest=0, median=1, slowest=2, chosen_slowest=3, chosen_mean=4, trials=5, best=6, first=7, worst=8, identity=9, spread=10,
@@ -107,7 +109,7 @@ def alloc_fields(count, *shape, pool=None, min_bytes=256 << 20, report=None, pai
     grow(k)
     report["pool_first"] = len(cands)
     rank()
-    if extend_by > 0 and rep[_R["want_more"]] == 1 and not _CHURNED[0]:
+    if extend_by > 0 and rep[_R["want_more"]] == 1 and int(_CHURNED[0]) < MAX_CHURNS:
         # a pool of one class: more candidates of the same process do not help (22 over 106 GiB were tried); churning the card's memory once does
         # (only the case measured: no fast pair at all; a pool whose trials merely agree -- want_more 2 -- is extended as before)
         report["churned_because_fastest_pair_GBs"] = rep[_R["fastest"]]
@@ -126,7 +128,7 @@ def alloc_fields(count, *shape, pool=None, min_bytes=256 << 20, report=None, pai
             report["pool_extended_because_" + why] = before
             rank()
     out = [cands[chosen[i]] for i in range(count)]
-    if accept is not None and trial is not None and not _CHURNED[0]:
+    if accept is not None and trial is not None and int(_CHURNED[0]) < MAX_CHURNS and not any(k.startswith("churned_because") for k in report):
         try:
             ok = bool(accept(out))
         except Exception:

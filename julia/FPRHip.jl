@@ -527,7 +527,8 @@ function churn!(fraction = 0.7)
     foreach(AMDGPU.unsafe_free!, held)
     return nothing
 end
-const CHURNED = Ref(false)
+const CHURNS = Ref(0)          # churn!() calls of this process (at most MAX_CHURNS: the mix does not always outlast the next allocate / free cycle)
+const MAX_CHURNS = 3
 
 function alloc_fields(count::Integer, dims::Integer...; pool::Integer = count + 7, pairs = nothing, trial = nothing, spacer_bytes = nothing,
                       accept = nothing, first = nothing)
@@ -552,19 +553,19 @@ function alloc_fields(count::Integer, dims::Integer...; pool::Integer = count + 
                     ctx(), ptrs, length(cands), prod(dims), count, flat, length(flat) ÷ 2,
                     cb === C_NULL ? C_NULL : Base.unsafe_convert(Ptr{Cvoid}, cb), C_NULL, chosen, report))
     end
-    if report[12] == 1 && !CHURNED[]          # FPR_PLACE_WANT_MORE: a pool of one class -- churn once, then build the pool afresh
+    if report[12] == 1 && CHURNS[] < MAX_CHURNS          # FPR_PLACE_WANT_MORE: a pool of one class -- churn once, then build the pool afresh
         foreach(AMDGPU.unsafe_free!, cands); foreach(AMDGPU.unsafe_free!, spacers)
-        churn!(); CHURNED[] = true
+        churn!(); CHURNS[] += 1
         return alloc_fields(count, dims...; pool = pool, pairs = pairs, trial = trial, spacer_bytes = spacer_bytes)
     end
     out = DA[cands[c + 1] for c in chosen]
     for (i, A) in enumerate(cands); (i - 1) in chosen || AMDGPU.unsafe_free!(A); end
     for q in spacers; AMDGPU.unsafe_free!(q); end
-    if accept !== nothing && trial !== nothing && !CHURNED[] && !accept(out)
+    if accept !== nothing && trial !== nothing && CHURNS[] < MAX_CHURNS && !accept(out)
         # a fast pair and still no good assignment (one candidate of another class among many alike: the fused diffusion launch at 1.08-1.09 x the
         # one-iteration kernel where a mixed pool gives 1.02-1.06): rebuild the pool once behind churn!(), the chosen arrays its first candidates
-        churn!(); CHURNED[] = true
-        return alloc_fields(count, dims...; pool = pool, pairs = pairs, trial = trial, spacer_bytes = spacer_bytes, first = out)
+        churn!(); CHURNS[] += 1
+        return alloc_fields(count, dims...; pool = pool, pairs = pairs, trial = trial, spacer_bytes = spacer_bytes, first = out)     # (accept is not asked again: one churn per call)
     end
     foreach(A -> fill_device!(A, 0.0), out)
     return out

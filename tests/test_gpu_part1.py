@@ -919,14 +919,15 @@ def test_placement_alloc_fields(fpr):
     del more
     # ... and a pool whose chosen arrays the caller does not accept is rebuilt once behind churn(), the chosen arrays staying its first
     # candidates (so the second search starts from the first one's result); a second refusal changes nothing more
-    F.placement._CHURNED[0] = False
+    F.placement._CHURNED[0] = 0
     rep4, seen = {}, []
     more = F.placement.alloc_fields(3, *n, pool=5, report=rep4, spacer_bytes=256 << 20, extend_by=0, trial=trial, trials=2,
                                     accept=lambda a: (seen.append([t.data_ptr() for t in a]), False)[1])
     # (asked twice: about the first pool's choice, and -- for the report only -- about the second's)
     assert len(more) == 3 and len(seen) == 2 and rep4["churned_because_not_accepted_ms"] > 0.0 and rep4["pool"] == 5 and rep4["accepted_after_churn"] is False
-    assert rep4["pool_before_churn"]["trial_ms_best"] == rep4["churned_because_not_accepted_ms"] and F.placement._CHURNED[0] is True
+    assert rep4["pool_before_churn"]["trial_ms_best"] == rep4["churned_because_not_accepted_ms"] and F.placement._CHURNED[0] == 1
     assert all(float(a.abs().max()) == 0.0 for a in more)
+    F.placement._CHURNED[0] = F.placement.MAX_CHURNS      # a process that has churned that often does not churn again
     rep5 = {}
     again = F.placement.alloc_fields(3, *n, pool=5, report=rep5, spacer_bytes=256 << 20, extend_by=0, trial=trial, trials=2, accept=lambda a: False)
     assert len(again) == 3 and "churned_because_not_accepted_ms" not in rep5

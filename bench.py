@@ -133,6 +133,8 @@ def hoist_scalars(out, placement, unplaced):
     c["placement_churned"] = any(k.startswith("churned_because") for k in placement)
     c["placement_pair_over_single"] = placement.get("accept_pair_over_single")
     c["placement_pair_over_single_first_pool"] = placement.get("accept_pair_over_single_first_pool")
+    c["placement_trial_frac"] = placement.get("accept_trial_frac")
+    c["placement_trial_frac_first_pool"] = placement.get("accept_trial_frac_first_pool")
     c["placement_trial_ms_best_before_churn"] = g(placement, "pool_before_churn", "trial_ms_best")
     c["placement_fastest_pair_GBs_before_churn"] = placement.get("churned_because_fastest_pair_GBs")
     c["placement_kept_plain"] = (placement.get("chosen") == [0, 1, 2, 3, 4]) if placement.get("chosen") else None
@@ -423,7 +425,14 @@ def main():
                 single = e0.elapsed_time(e1) / 16.0
                 placement.setdefault("accept_pair_over_single_first_pool", pair / single)
                 placement["accept_pair_over_single"] = pair / single      # (of the arrays kept)
-                return pair <= 1.07 * single
+                # The fused launch's own rate is the steadier judge: 0.7429-0.7541 ms (0.704-0.714 of the HBM peak by its compulsory bytes)
+                # over 45 leases with a mixed pool, 0.788-0.795 (0.667-0.673) on the six pools with one candidate of another class --
+                # while the one-iteration kernel varies by 5 % from card to card (ratios 1.04-1.08 against 1.09-1.10: four pools that
+                # were fine refused in fifteen at 1.07).  Refused: below 0.69 of the peak, or a ratio beyond doubt.
+                frac = A_EFF_BYTES * (nloc[0] - 2) * (nloc[1] - 2) * (nloc[2] - 2) / (pair * 1e-3) / 1e9 / HBM_PEAK_GBS
+                placement.setdefault("accept_trial_frac_first_pool", frac)
+                placement["accept_trial_frac"] = frac
+                return frac >= 0.69 and pair <= 1.12 * single
 
             Ht, Hτ, Hτ3, res, Hτ2 = F.placement.alloc_fields(5, *nloc, report=placement, pairs=[(0, 1), (0, 2), (2, 3), (1, 3), (1, 2)],
                                                           trial=trial, first=plain, accept=None if shared else accept)   # (ranks that share one card do not churn its memory under each other)

@@ -131,6 +131,7 @@ def hoist_scalars(out, placement, unplaced):
     c["placement_trial_ms_worst"] = placement.get("trial_ms_worst")
     c["placement_trial_ms_plain"] = placement.get("trial_ms_plain_allocation")
     c["placement_churned"] = any(k.startswith("churned_because") for k in placement)
+    c["placement_slab_GiB"] = (placement["slab_bytes"] / 2.0 ** 30) if placement.get("slab_bytes") else None    # candidates carved out of one allocation (a churn had not helped)
     c["placement_pair_over_single"] = placement.get("accept_pair_over_single")
     c["placement_pair_over_single_first_pool"] = placement.get("accept_pair_over_single_first_pool")
     c["placement_trial_frac"] = placement.get("accept_trial_frac")

@@ -106,6 +106,39 @@ def alloc_fields(count, *shape, pool=None, min_bytes=256 << 20, report=None, pai
         c.call("fpr_placement_rank", ptrs, len(cands), cands[0].numel(), count, (C.c_int * max(len(flat), 1))(*flat), len(flat) // 2,
                C.cast(cb, C.c_void_p) if trial is not None else None, None, chosen, rep)
 
+    def slab_pool(why, before):
+        """Candidates carved out of ONE allocation at a pitch of six arrays (at least 6 GiB): the other way past a card whose piecewise
+        allocations are all of one class (three one-class leases: 0.84 -> 0.746-0.752 ms, profiles/r5_one_class_lease_probe.txt) -- taken when
+        a churn has not brought the mix back (one lease in six of that kind).  The allocation stays as long as any chosen array lives."""
+        nfirst = len(first or [])
+        pitch = max(6 << 30, 6 * nbytes)
+        pitch += (-pitch) % (2 << 20)
+        free3, _ = torch.cuda.mem_get_info()
+        ns = min(k, int(0.6 * free3 // pitch))
+        if ns < count:
+            return False
+        del cands[nfirst:]
+        spacers.clear()
+        torch.cuda.empty_cache()
+        try:
+            slab = torch.empty(ns * pitch, dtype=torch.uint8, device="cuda")
+        except RuntimeError:
+            grow(k)
+            return False
+        numel = nbytes // 8
+        strides, st = [], 1
+        for d_ in shape:
+            strides.append(st)
+            st *= int(d_)
+        for i in range(ns):
+            t = slab[i * pitch:i * pitch + nbytes].view(torch.float64)
+            t.zero_()
+            cands.append(torch.as_strided(t, tuple(int(d_) for d_ in shape), tuple(strides)))
+        del slab
+        report["slab_because_" + why] = before
+        report["slab_bytes"] = ns * pitch
+        return True
+
     grow(k)
     report["pool_first"] = len(cands)
     rank()
@@ -119,7 +152,9 @@ def alloc_fields(count, *shape, pool=None, min_bytes=256 << 20, report=None, pai
         churn()
         grow(k)
         rank()
-    if extend_by > 0 and rep[_R["want_more"]] > 0:
+        if rep[_R["want_more"]] == 1 and slab_pool("fastest_pair_GBs_after_churn", rep[_R["fastest"]]):
+            rank()
+    if extend_by > 0 and rep[_R["want_more"]] > 0 and "slab_bytes" not in report:
         why, before = ("fastest_pair_GBs", rep[_R["fastest"]]) if rep[_R["want_more"]] == 1 else ("trial_spread", rep[_R["spread"]])
         n0 = len(cands)
         free2, _ = torch.cuda.mem_get_info()
@@ -148,7 +183,23 @@ def alloc_fields(count, *shape, pool=None, min_bytes=256 << 20, report=None, pai
             try:
                 report["accepted_after_churn"] = bool(accept(out))
             except Exception:
-                pass
+                report["accepted_after_churn"] = True
+            if not report["accepted_after_churn"]:
+                keep = list(out)
+                first = keep                       # (slab_pool keeps the first len(first) candidates)
+                del cands[:]
+                cands.extend(keep)
+                del keep, out
+                if slab_pool("not_accepted_after_churn_ms", rep[_R["best"]]):
+                    rank()
+                else:
+                    grow(k)
+                    rank()
+                out = [cands[chosen[i]] for i in range(count)]
+                try:
+                    report["accepted_after_slab"] = bool(accept(out))
+                except Exception:
+                    pass
     report.update({"selected": True, "pool": len(cands), "chosen": [int(chosen[i]) for i in range(count)], "pairs": [list(p) for p in (pairs or [])],
                    "spacer_bytes": spacer if spacers else 0, "trials": int(rep[_R["trials"]]),
                    "pair_copy_GBs_all": {"slowest": rep[_R["slowest"]], "median": rep[_R["median"]], "fastest": rep[_R["fastest"]]},

@@ -906,7 +906,18 @@ def test_placement_alloc_fields(fpr):
     arrs = F.placement.alloc_fields(4, *n, pool=7, report=rep, pairs=[(0, 1), (2, 3)], trial=trial, trials=2, extend_by=0)
     assert len(arrs) == 4 and len({a.data_ptr() for a in arrs}) == 4
     assert rep["selected"] is True and rep["pool"] == 7 and len(rep["chosen"]) == 4 and rep["trials"] == len(calls) >= 2
-    # a pool that looks like one class (here: a threshold no pool can meet) is extended once
+    # a pool that looks like one class (here: a threshold no pool can meet) is rebuilt behind churn(), and when that has not helped its
+    # candidates are carved out of one allocation at a pitch of 6 GiB (the arrays are views of it: column-major, zeroed, usable as any)
+    F.placement._CHURNED[0] = 0
+    rep2 = {}
+    more = F.placement.alloc_fields(2, *n, pool=4, report=rep2, spacer_bytes=256 << 20, extend_below_GBs=1e9, extend_by=3)
+    assert len(more) == 2 and rep2["pool_first"] == 4 and rep2["pool"] == 4 and rep2["churned_because_fastest_pair_GBs"] > 100.0
+    assert rep2["slab_because_fastest_pair_GBs_after_churn"] > 100.0 and rep2["slab_bytes"] == 4 * (6 << 30) and F.placement._CHURNED[0] == 1
+    assert all(tuple(a.shape) == n and a.stride() == (1, n[0], n[0] * n[1]) and float(a.abs().max()) == 0.0 for a in more)
+    assert abs(more[1].data_ptr() - more[0].data_ptr()) % (6 << 30) == 0
+    del more
+    # ... a process that has used up its churns extends the pool once instead
+    F.placement._CHURNED[0] = F.placement.MAX_CHURNS
     rep2 = {}
     more = F.placement.alloc_fields(2, *n, pool=4, report=rep2, spacer_bytes=256 << 20, extend_below_GBs=1e9, extend_by=3)
     assert len(more) == 2 and rep2["pool_first"] == 4 and rep2["pool"] == 7 and rep2["pool_extended_because_fastest_pair_GBs"] > 100.0
@@ -923,8 +934,10 @@ def test_placement_alloc_fields(fpr):
     rep4, seen = {}, []
     more = F.placement.alloc_fields(3, *n, pool=5, report=rep4, spacer_bytes=256 << 20, extend_by=0, trial=trial, trials=2,
                                     accept=lambda a: (seen.append([t.data_ptr() for t in a]), False)[1])
-    # (asked twice: about the first pool's choice, and -- for the report only -- about the second's)
-    assert len(more) == 3 and len(seen) == 2 and rep4["churned_because_not_accepted_ms"] > 0.0 and rep4["pool"] == 5 and rep4["accepted_after_churn"] is False
+    # (asked three times: about the first pool's choice, the second's behind the churn, and the third's -- the kept arrays + five carved out of one
+    #  allocation)
+    assert len(more) == 3 and len(seen) == 3 and rep4["churned_because_not_accepted_ms"] > 0.0 and rep4["accepted_after_churn"] is False
+    assert rep4["pool"] == 3 + 5 and rep4["slab_because_not_accepted_after_churn_ms"] > 0.0 and rep4["accepted_after_slab"] is False
     assert rep4["pool_before_churn"]["trial_ms_best"] == rep4["churned_because_not_accepted_ms"] and F.placement._CHURNED[0] == 1
     assert all(float(a.abs().max()) == 0.0 for a in more)
     F.placement._CHURNED[0] = F.placement.MAX_CHURNS      # a process that has churned that often does not churn again

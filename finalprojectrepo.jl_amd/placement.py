@@ -142,6 +142,11 @@ def alloc_fields(count, *shape, pool=None, min_bytes=256 << 20, report=None, pai
     grow(k)
     report["pool_first"] = len(cands)
     rank()
+    import os
+    if os.environ.get("FPR_PLACE_FORCE_SLAB") and trial is not None:      # (measurement hook: the carved pool on a lease that does not need it)
+        report["forced_slab_first_pool_trial_ms_best"] = rep[_R["best"]]
+        if slab_pool("forced", rep[_R["fastest"]]):
+            rank()
     if extend_by > 0 and rep[_R["want_more"]] == 1 and int(_CHURNED[0]) < MAX_CHURNS:
         # a pool of one class: more candidates of the same process do not help (22 over 106 GiB were tried); churning the card's memory once does
         # (only the case measured: no fast pair at all; a pool whose trials merely agree -- want_more 2 -- is extended as before)

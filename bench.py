@@ -115,91 +115,6 @@ def cpu_baseline_vcycle(n, b_host, css=5, solver=0):
                       "solver, OpenMP %d threads, %s" % (n, css, "cg!" if solver else "Jacobi", threads,
                                                          "median of 3" if reps > 1 else "one run")}
 
-def hoist_scalars(out, placement, unplaced):
-    """The driver's record of a run keeps the top-level scalars and the scalars of `config` / `roofline` / `cpu_baseline`; nested
-    blocks (field_placement, device_state, power_probe, legs, vcycle ...) are dropped.  Whatever a reader needs to tell a slow card
-    from a slow kernel from a failed placement search therefore ALSO goes into `config` as plain scalars (the blocks stay)."""
-    g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
-    c = out["config"]
-    c["placement_selected"] = bool(placement.get("selected"))
-    c["placement_error"] = placement.get("error")
-    c["placement_pool"] = placement.get("pool")
-    c["placement_pool_first"] = placement.get("pool_first")
-    c["placement_trials"] = placement.get("trials")
-    c["placement_trial_ms_best"] = placement.get("trial_ms_best")
-    c["placement_trial_ms_first"] = placement.get("trial_ms_first")
-    c["placement_trial_ms_worst"] = placement.get("trial_ms_worst")
-    c["placement_trial_ms_plain"] = placement.get("trial_ms_plain_allocation")
-    c["placement_churned"] = any(k.startswith("churned_because") for k in placement)
-    c["placement_slab_GiB"] = (placement["slab_bytes"] / 2.0 ** 30) if placement.get("slab_bytes") else None    # candidates carved out of one allocation (a churn had not helped)
-    c["placement_pair_over_single"] = placement.get("accept_pair_over_single")
-    c["placement_pair_over_single_first_pool"] = placement.get("accept_pair_over_single_first_pool")
-    c["placement_trial_frac"] = placement.get("accept_trial_frac")
-    c["placement_trial_frac_first_pool"] = placement.get("accept_trial_frac_first_pool")
-    c["placement_trial_ms_best_before_churn"] = g(placement, "pool_before_churn", "trial_ms_best")
-    c["placement_fastest_pair_GBs_before_churn"] = placement.get("churned_because_fastest_pair_GBs")
-    c["placement_kept_plain"] = (placement.get("chosen") == [0, 1, 2, 3, 4]) if placement.get("chosen") else None
-    c["pool_fastest_pair_GBs"] = g(placement, "pair_copy_GBs_all", "fastest")
-    c["pool_slowest_pair_GBs"] = g(placement, "pair_copy_GBs_all", "slowest")
-    c["chosen_slowest_pair_GBs"] = g(placement, "pair_copy_GBs_chosen", "slowest")
-    c["mem_free_GiB_at_start"] = unplaced.get("mem_free_GiB_at_start")
-    c["mem_total_GiB"] = unplaced.get("mem_total_GiB")
-    c["unplaced_kernel_ms"] = unplaced.get("kernel_ms")
-    c["unplaced_frac"] = (out["roofline"]["bytes_per_launch"] / (unplaced["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if unplaced.get("kernel_ms") else None
-    ds = out.get("device_state") or {}
-    for tag, key in (("before", "before_timed_region"), ("after", "after_timed_region")):
-        c["sclk_MHz_" + tag] = g(ds, key, "sclk_MHz")
-        c["power_W_" + tag] = g(ds, key, "power_W")
-    c["power_cap_W"] = g(ds, "after_timed_region", "power_cap_W")
-    c["temp_junction_C_after"] = g(ds, "after_timed_region", "temp_junction_C")
-    c["temp_memory_C_after"] = g(ds, "after_timed_region", "temp_memory_C")
-    c["mclk_MHz"] = g(ds, "after_timed_region", "mclk_MHz")
-    c["fclk_MHz"] = g(ds, "after_timed_region", "fclk_MHz")
-    c["gpu_unique_id"] = g(ds, "after_timed_region", "unique_id")
-    c["compute_partition"] = g(ds, "after_timed_region", "compute_partition")
-    c["memory_partition"] = g(ds, "after_timed_region", "memory_partition")
-    pp = out.get("power_probe") or {}
-    c["steady_ms_per_iteration"] = g(pp, "fused_pairs", "ms_per_iteration")        # the last second of 1.5 s of back-to-back fused pairs
-    c["steady_ms_per_iteration_incl_ramp"] = g(pp, "fused_pairs", "ms_per_iteration_incl_ramp")
-    c["steady_value_GBs"] = (out["roofline"]["bytes_per_launch"] / (c["steady_ms_per_iteration"] * 1e-3) / 1e9) if c["steady_ms_per_iteration"] else None
-    c["steady_sclk_MHz"] = g(pp, "fused_pairs", "sclk_MHz_avg")
-    c["steady_power_W"] = g(pp, "fused_pairs", "power_W_avg")
-    c["steady_single_ms_per_iteration"] = g(pp, "single_steps", "ms_per_iteration")
-    c["single_kernel_ms"] = g(out, "roofline_single", "kernel_ms")
-    c["single_frac"] = g(out, "roofline_single", "frac")
-    c["fma_kernel_ms"] = g(out, "legs", "fused_pairs_fma", "kernel_ms")
-    c["fma_steady_ms_per_iteration"] = g(out, "legs", "fused_pairs_fma", "steady_ms_per_iteration")
-    c["fma_steady_power_W"] = g(out, "legs", "fused_pairs_fma", "steady_power_W")
-    c["fma_steady_sclk_MHz"] = g(out, "legs", "fused_pairs_fma", "steady_sclk_MHz")
-    c["fused_no_residual_kernel_ms"] = g(out, "legs", "fused_pairs_no_residual_store", "kernel_ms")
-    c["proj_eff_z_slabs"] = g(out, "legs", "fused_pairs_as_interior_rank_of_z_slabs", "projected_weak_scaling_efficiency_z_slabs")
-    c["proj_eff_2x2x2"] = g(out, "legs", "fused_pairs_as_rank_of_2x2x2", "projected_weak_scaling_efficiency_2x2x2")
-    nc = out.get("norm_check") or {}
-    c["norm_check_ok"] = nc.get("ok")
-    c["norm_check_rel"] = nc.get("rel")
-    c["norm_check_iterations"] = nc.get("iterations")
-    c["vcycle_s"] = g(out, "vcycle", "value")
-    c["vcycle_placement_selected"] = g(out, "vcycle", "config", "field_placement", "selected")
-    c["vcycle_placement_trial_ms_best"] = g(out, "vcycle", "config", "field_placement", "trial_ms_best")
-    c["vcycle_placement_trial_ms_worst"] = g(out, "vcycle", "config", "field_placement", "trial_ms_worst")
-    c["vcycle_plain_allocation_ms"] = g(out, "vcycle", "config", "field_placement", "plain_allocation_ms")     # a solve on four plain arrays + the library's own arena
-    c["vcycle_pool_fastest_pair_GBs"] = g(out, "vcycle", "config", "field_placement", "pair_copy_GBs_chosen", "slowest")
-    c["vcycle_seam_us"] = (g(out, "vcycle", "roofline", "kernels", "finest_seam_pass", "ms") or 0.0) * 1e3 or None
-    c["vcycle_pre_us"] = (g(out, "vcycle", "roofline", "kernels", "finest_pre_pass", "ms") or 0.0) * 1e3 or None
-    c["vcycle_post_us"] = (g(out, "vcycle", "roofline", "kernels", "finest_post_pass", "ms") or 0.0) * 1e3 or None
-    c["vcycle_dominant_frac"] = g(out, "vcycle", "roofline", "frac")
-    c["vcycle_cpu_s"] = g(out, "vcycle", "cpu_baseline", "value")
-    c["vcycle5_cg_s"] = g(out, "vcycle_5levels", "conjugate_gradient", "value")
-    c["vcycle5_jacobi_s"] = g(out, "vcycle_5levels", "jacobi", "value")
-    c["cg_us_per_iteration"] = g(out, "vcycle_5levels", "conjugate_gradient", "roofline", "achieved")
-    c["jacobi_us_per_sweep"] = g(out, "vcycle_5levels", "jacobi", "roofline", "achieved")
-    c["ns_step_s"] = g(out, "ns_step", "value")
-    r = out["roofline"]
-    r["unplaced_kernel_ms"] = c["unplaced_kernel_ms"]
-    r["steady_ms_per_iteration"] = c["steady_ms_per_iteration"]
-    r["single_kernel_ms"] = c["single_kernel_ms"]
-
-
 # ------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -293,13 +208,15 @@ def main():
             dist.barrier()
         hb("done")
         if rank == 0:
-            print(json.dumps({"metric": "diffusion3d_effective_memory_throughput", "value": None, "unit": "GB/s",
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
-                              "ranks_seen": int(seen.item()), "max_over_ranks": float(t.item()),
-                              "self_launched": os.environ.get("FPR_BENCH_SELF_LAUNCHED") == "1",
-                              "control_plane": "gloo" if use_dist else "none",
-                              "choreography": choreography, "attempt": attempt, "first_attempt": first_failure}))
-            sys.stdout.flush()
+            legs_mod.emit({"metric": "diffusion3d_effective_memory_throughput", "value": None, "unit": "GB/s",
+                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "dry_run": True,
+                           "ranks_seen": int(seen.item()), "max_over_ranks": float(t.item()),
+                           "config": {"workload": "dry run: control plane only, no GPU", "process_grid": [1, 1, world],
+                                      "self_launched": os.environ.get("FPR_BENCH_SELF_LAUNCHED") == "1",
+                                      "control_plane": "gloo" if use_dist else "none",
+                                      "choreography": choreography, "attempt": attempt},
+                           "first_attempt": first_failure}, root=os.environ.get("FPR_BENCH_DETAIL_DIR", ROOT))
         if use_dist:
             dist.destroy_process_group()
         return
@@ -630,8 +547,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "3D pseudo-transient diffusion, %d^3 cells per GPU, fused 7-pt update + fused norm%s"
-                               % (n, ", two iterations per launch (temporal blocking)" if main_fused else ""),
+        "config": {"workload": "3D diffusion %d^3 per GPU, fused 7-pt update + norm, %d iteration%s per launch" % (n, 2 if main_fused else 1, "s" if main_fused else ""),
                    "local_grid": list(nloc), "process_grid": list(dims), "global_grid": [gg.nx_g(), gg.ny_g(), gg.nz_g()],
                    "bytes_per_cell_per_iteration": A_EFF_BYTES,
                    "norm": "fused every iteration; all-reduce + host check every %d" % ce,
@@ -832,9 +748,10 @@ def main():
         sys.exit(3)
     hb("done" if not norm_failed else "norm_failed", **({"norm_check": out["norm_check"]} if norm_failed else {}))
     if rank == 0:
-        hoist_scalars(out, placement, unplaced)
-        print(json.dumps(out))
-        sys.stdout.flush()
+        out["config"]["unplaced_kernel_ms"] = unplaced.get("kernel_ms")
+        out["config"]["mem_free_GiB_at_start"], out["config"]["mem_total_GiB"] = unplaced.get("mem_free_GiB_at_start"), unplaced.get("mem_total_GiB")
+        out["unplaced"] = unplaced
+        legs_mod.emit(out, root=os.environ.get("FPR_BENCH_DETAIL_DIR", ROOT))     # full record -> bench_detail.json; the compact line is the last line of stdout
     if use_dist:
         dist.destroy_process_group()
     if norm_failed:

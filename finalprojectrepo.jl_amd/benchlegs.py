@@ -332,6 +332,136 @@ def ns_block(F):
                     "kernel_by_kernel = the reference's seven kernels + maxima + broadcasts, same results bit for bit"}
 
 
+# ------------------------------------------------------------------------------------------------------------
+# the line the driver keeps: scalars only, < 4 KB (a 23 KB line left BENCH_r05.parsed null)
+# ------------------------------------------------------------------------------------------------------------
+COMPACT_MAX_BYTES = 4096
+DETAIL_FILE = "bench_detail.json"     # everything else (blocks, legs, notes) goes here, next to bench.py
+
+
+def _g(d, *ks):
+    for k in ks:
+        if not isinstance(d, dict):
+            return None
+        d = d.get(k)
+    return d
+
+
+def _num(v, digits=6):
+    """Numbers at the precision a reader uses (the detail file keeps every digit)."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        if v == int(v) and abs(v) < 2.0 ** 53:
+            return int(v) if abs(v) >= 1e6 else v       # byte counts stay exact
+        return float("%.*g" % (digits, v))
+    return v
+
+
+def _short(s, n):
+    s = "" if s is None else str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def compact_record(out):
+    """The ONE line bench.py prints last on stdout, built from the full record `out` (which goes to DETAIL_FILE): the contract's keys, `config`
+    / `roofline` / `cpu_baseline` / `norm_check` as flat objects of scalars, one scalar per secondary quantity.  No prose, no nesting
+    below those four objects.  compact_check() holds it to COMPACT_MAX_BYTES."""
+    r, c = out.get("roofline") or {}, out.get("config") or {}
+    fp = c.get("field_placement") or {}
+    cb, nc = out.get("cpu_baseline") or {}, out.get("norm_check") or {}
+    ds = _g(out, "device_state", "after_timed_region") or {}
+    unplaced_ms = c.get("unplaced_kernel_ms")
+    bpl = r.get("bytes_per_launch")
+    rec = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                   "vs_baseline", "dtype", "data")}
+    rec["config"] = {
+        "workload": _short(c.get("workload"), 120), "local_grid": c.get("local_grid"), "process_grid": c.get("process_grid"),
+        "rccl_ranks": c.get("rccl_ranks"), "choreography": _short(c.get("choreography"), 16), "attempt": c.get("attempt"),
+        "self_launched": c.get("self_launched"), "control_plane": _short(c.get("control_plane"), 8) if c.get("control_plane") else None, "iterations_per_launch": r.get("iterations_per_launch"),
+        "placement_selected": bool(fp.get("selected")), "placement_mode": _short(fp.get("mode"), 24) if fp.get("mode") else None,
+        "mem_held_GiB": c.get("mem_held_GiB"), "gpu_unique_id": ds.get("unique_id"),
+        "sclk_MHz_after": ds.get("sclk_MHz"), "power_W_after": ds.get("power_W"), "power_cap_W": ds.get("power_cap_W"),
+        "rehearsal": bool(out.get("rehearsal")) or None, "fallback_reason": _short(_g(out, "first_attempt", "reason"), 160) if out.get("first_attempt") else None,
+    }
+    rec["roofline"] = {
+        "bound": r.get("bound"), "kernel": _short((r.get("kernel") or "").split(" ")[0], 40), "kernel_ms": r.get("kernel_ms"), "launches": r.get("launches"),
+        "bytes_per_launch": bpl, "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": r.get("unit"), "frac": r.get("frac"),
+        "traffic": r.get("traffic"), "traffic_over_algorithmic": r.get("traffic_over_algorithmic"),
+        "effective_achieved": r.get("effective_achieved"), "effective_frac": r.get("effective_frac"),
+        "unplaced_kernel_ms": unplaced_ms,
+        "unplaced_frac": (bpl / (unplaced_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (unplaced_ms and bpl) else None,
+        "single_kernel_ms": _g(out, "roofline_single", "kernel_ms"), "single_frac": _g(out, "roofline_single", "frac"),
+        "steady_ms_per_iteration": _g(out, "power_probe", "fused_pairs", "ms_per_iteration"),
+    }
+    if cb:
+        rec["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "sample": _short(cb.get("sample"), 140), "ms_per_step": cb.get("ms_per_step")}
+    if nc:
+        rec["norm_check"] = {"ok": nc.get("ok"), "rel": nc.get("rel"), "iterations": nc.get("iterations")}
+    seam_ms = _g(out, "vcycle", "roofline", "kernels", "finest_seam_pass", "ms")
+    rec.update({
+        "vcycle_s": _g(out, "vcycle", "value"), "vcycle_seam_us": seam_ms * 1e3 if seam_ms else None,
+        "vcycle_seam_frac": _g(out, "vcycle", "roofline", "frac"), "vcycle_cpu_s": _g(out, "vcycle", "cpu_baseline", "value"),
+        "vcycle5_jacobi_s": _g(out, "vcycle_5levels", "jacobi", "value"), "vcycle5_cg_s": _g(out, "vcycle_5levels", "conjugate_gradient", "value"),
+        "ns_step_s": _g(out, "ns_step", "value"),
+        "proj_eff_z_slabs": _g(out, "legs", "fused_pairs_as_interior_rank_of_z_slabs", "projected_weak_scaling_efficiency_z_slabs"),
+        "proj_eff_2x2x2": _g(out, "legs", "fused_pairs_as_rank_of_2x2x2", "projected_weak_scaling_efficiency_2x2x2"),
+        "detail": DETAIL_FILE,
+    })
+    for k in ("dry_run", "ranks_seen", "max_over_ranks", "error"):
+        if k in out:
+            rec[k] = _short(out[k], 200) if isinstance(out[k], str) else out[k]
+
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "traffic")
+
+    def walk(v):
+        if isinstance(v, dict):
+            return {k: walk(x) for k, x in v.items() if x is not None or k in keep}
+        if isinstance(v, (list, tuple)):
+            return [walk(x) for x in v]
+        return _num(v)
+
+    return walk(rec)
+
+
+def compact_check(rec):
+    """The printed line as text, or an exception: strict JSON, ASCII, below COMPACT_MAX_BYTES, the contract's keys present, no string
+    longer than 160 characters, nothing nested deeper than one object."""
+    line = json.dumps(rec, allow_nan=False, ensure_ascii=True, separators=(", ", ": "))
+    if len(line) >= COMPACT_MAX_BYTES:
+        raise ValueError("bench line is %d bytes (limit %d)" % (len(line), COMPACT_MAX_BYTES))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "config"):
+        if k not in rec:
+            raise ValueError("bench line lacks %r" % k)
+    for k, v in rec.items():
+        for kk, vv in (v.items() if isinstance(v, dict) else ((k, v),)):
+            if isinstance(vv, dict) or (isinstance(vv, str) and len(vv) > 160):
+                raise ValueError("bench line: %s.%s is not a short scalar" % (k, kk))
+    return line
+
+
+def emit(out, root=ROOT, stream=None):
+    """Write the full record to DETAIL_FILE (and a copy under gpurun_out/ when that directory exists), then print the compact line as the
+    LAST line of stdout.  Returns the line."""
+    stream = stream or sys.stdout
+    for path in (os.path.join(root, DETAIL_FILE), os.path.join(root, "gpurun_out", DETAIL_FILE)):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path + ".tmp", "w") as f:
+                    json.dump(out, f, indent=1, default=repr)
+                    f.write("\n")
+                os.replace(path + ".tmp", path)
+        except OSError as e:
+            print("bench.py: could not write %s: %r" % (path, e), file=sys.stderr)
+    line = compact_check(compact_record(out))
+    stream.write(line + "\n")
+    stream.flush()
+    return line
+
+
 def host_staged_p2p(torch, dist):
     """--rehearse-shared-gpu: a torch.distributed look-alike for grid.HaloExchanger whose planes travel through host
     memory over gloo.  For rehearsing N ranks on ONE card only -- the product transport is RCCL inside the library."""

@@ -710,6 +710,16 @@ extern "C" int fpr_bc2d(fpr_ctx* ctx, double* T, int nx, int ny)
 }
 
 // ---- CG ---------------------------------------------------------------------------------------------
+#include <atomic>
+// upper half of every granule's tag: solves so far in this PROCESS (all contexts; 31 bits: a wrap needs 2^31 coarse solves)
+static long long fpr_next_epoch(fpr_ctx* ctx)
+{
+    static std::atomic<long long> epoch{0};
+    const long long e = (epoch.fetch_add(1) + 1) & 0x7fffffffLL;
+    ctx->jacp_epoch = e ? e : ((epoch.fetch_add(1) + 1) & 0x7fffffffLL);
+    return ctx->jacp_epoch;
+}
+
 struct CgWork { double *r, *p, *ph, *x, *p2; size_t n; };
 
 static int cg_work(fpr_ctx* ctx, size_t n, CgWork* w)
@@ -724,6 +734,10 @@ static int cg_work(fpr_ctx* ctx, size_t n, CgWork* w)
         }
         FPR_HIP(ctx, hipMalloc(&ctx->cg_buf, 5 * n * sizeof(double)));
         ctx->cg_cap = 5 * n;
+        // The data-tagged hand-offs (k_jacobi_persist_tag, k_cg_persistent's tagged edges) accept a granule as soon as its tag is the one
+        // waited for: memory that comes back from hipMalloc may hold another context's granules.  Tag 0 is never wanted, and
+        // epochs come from one process-wide counter (fpr_next_epoch), so no two solves of a process share a tag.
+        FPR_HIP(ctx, hipMemsetAsync(ctx->cg_buf, 0, 5 * n * sizeof(double), ctx->stream[0]));
     }
     double* b = ctx->cg_buf;
     w->r = b; w->p = b + n; w->ph = b + 2 * n; w->x = b + 3 * n; w->p2 = b + 4 * n; w->n = n;
@@ -797,7 +811,7 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
             // r_glob: N doubles (flag form) or N granules = the work vectors r and p, which lie one behind the other (cg_work) and are not used
             // otherwise by this form; tags of one solve never meet another solve's
             a.tag_base = (fpr_opt(ctx, "cg_tagged_edges", FPR_CG_TAGGED_DEFAULT) != 0 && !a.fences && (size_t)N * 16 < 0x7fffffffu && w.p == w.r + N)
-                             ? (long long)(++ctx->jacp_epoch) << 32 : 0;
+                             ? fpr_next_epoch(ctx) << 32 : 0;
             FPR_HIP(ctx, hipMemsetAsync(a.ctr, 0, 2 * sizeof(unsigned), s));
             k_cgp_slots_init<<<1, 64, 0, s>>>(reinterpret_cast<unsigned long long*>(a.part), nb);
             // An ordinary launch: the workgroups are resident together on any device this library runs on (one per CU, 256 CUs),
@@ -1469,7 +1483,7 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                         int* counter = flags + 2041;
                         double* gsums = ctx->partials + FPR_MAX_PARTIALS - 2048;
                         FPR_HIP(ctx, hipMemsetAsync(flags, 0, 2048 * sizeof(int), s));
-                        const long long tag_base = (long long)(++ctx->jacp_epoch) << 32;   // tags of one solve never meet another solve's
+                        const long long tag_base = fpr_next_epoch(ctx) << 32;   // tags of one solve never meet another solve's
                         struct RecT { int x, w[3], g0, G; };             // x = -1: the plain field u (first launch)
                         std::vector<RecT> recs;
                         int cur = -1, prevx = -1, gdone = 0, poll_after = 1, since_poll = 0;

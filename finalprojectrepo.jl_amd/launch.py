@@ -31,6 +31,25 @@ def self_launch(n, script, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between processes)
         procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env))
     rc = 0
+
+    def stop_all(grace=8.0):
+        """SIGTERM to every rank (a supervisor: it ends its worker's process group and leaves), SIGKILL after a grace period."""
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        t0 = time.time()
+        while any(q.poll() is None for q in procs) and time.time() - t0 < grace:
+            time.sleep(0.05)
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+
+    def on_signal(signum, frame):
+        stop_all()
+        sys.exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, on_signal)
+    signal.signal(signal.SIGINT, on_signal)
     try:
         alive = list(procs)
         while alive:
@@ -41,13 +60,10 @@ def self_launch(n, script, argv):
                 alive.remove(p)
                 if r != 0 and rc == 0:
                     rc = r
-                    for q in alive:      # a failed rank would leave the others waiting in a collective
-                        q.terminate()
+                    stop_all()           # a failed rank would leave the others waiting in a collective
             time.sleep(0.05)
     finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+        stop_all(grace=3.0)
     sys.exit(rc)
 
 
@@ -117,6 +133,18 @@ def supervise(args, script, argv):
     os.makedirs(jd, exist_ok=True)
     first_failure = None
     rc = 1
+    current = [None]                     # the worker this supervisor is responsible for
+
+    def on_signal(signum, frame):
+        # torchrun / self_launch / Ctrl-C end the rank process: its worker lives in a session of its own and would be orphaned with the
+        # GPU in its hands -- end exactly that process group, then leave
+        if current[0] is not None:
+            _kill_tree(current[0])
+        sys.exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, on_signal)
+    signal.signal(signal.SIGINT, on_signal)
+    last_phase = "start"
     for attempt in (1, 2):
         choreo = args.choreography if attempt == 1 else "plain"
         hbf = os.path.join(jd, "hb_%d_%d.json" % (attempt, rank))
@@ -138,11 +166,16 @@ def supervise(args, script, argv):
         if first_failure is not None:
             env["FPR_BENCH_FIRST_FAILURE"] = json.dumps(first_failure)
         p = subprocess.Popen([sys.executable, script] + list(argv), env=env, start_new_session=True)
+        current[0] = p
         t_start = time.time()
         reason, detail = None, None
+        last_phase, last_t = "start", t_start
         while True:
             r = p.poll()
-            h = _read_json(hbf) or {"phase": "start", "t": t_start}
+            h = _read_json(hbf)
+            if h is None:                # (not written yet, or the job directory is already gone: keep what was seen last)
+                h = {"phase": last_phase, "t": last_t}
+            last_phase, last_t = h.get("phase", last_phase), h.get("t", last_t)
             if r is not None:
                 if r == 0 or h.get("phase") == "done":
                     rc = 0           # the job's result is out (rank 0 prints after the last collective); teardown noise is not a failure
@@ -150,7 +183,7 @@ def supervise(args, script, argv):
                     reason = "worker of rank %d exited with code %d in phase %r" % (rank, r, h.get("phase"))
                     detail = {k: v for k, v in h.items() if k not in ("phase", "t")} or None
                 break
-            if os.path.exists(fail_marker):
+            if os.path.exists(fail_marker) and h.get("phase") != "done":
                 reason = (_read_json(fail_marker) or {}).get("reason", "another rank failed the attempt")
                 break
             quiet = time.time() - max(h.get("t", t_start), t_start)
@@ -196,9 +229,18 @@ def supervise(args, script, argv):
         reported = os.path.join(jd, "reported")
         if rank == 0:
             if phases.get("0") != "norm_failed":     # (a fallback whose norm is wrong has printed its own line, norm_check.ok = false)
+                # the whole story (phases by rank, RCCL log tails) goes to the detail file; the line stays short (< 4 KB)
+                try:
+                    with open(os.path.join(os.path.dirname(os.path.abspath(script)), "bench_detail.json"), "w") as f:
+                        json.dump({"error": "both attempts failed", "attempts": [first_failure, failure]}, f, indent=1)
+                except OSError:
+                    pass
+                short = lambda x: (str(x)[:157] + "...") if len(str(x)) > 160 else str(x)
                 print(json.dumps({"metric": "diffusion3d_effective_memory_throughput", "value": None, "unit": "GB/s", "n_gpus": world,
                                   "steps": args.steps, "warmup": args.warmup, "error": "both attempts failed",
-                                  "attempts": [first_failure, failure]}))
+                                  "config": {"workload": "3D diffusion, N ranks", "first_attempt_reason": short(first_failure.get("reason")),
+                                             "second_attempt_reason": short(failure.get("reason"))},
+                                  "detail": "bench_detail.json"}))
                 sys.stdout.flush()
             try:
                 open(reported, "w").close()
@@ -210,7 +252,16 @@ def supervise(args, script, argv):
             while not os.path.exists(reported) and time.time() - t_wait < 20.0:
                 time.sleep(0.05)
         rc = 1
+    current[0] = None
     if rank == 0:
+        # the job directory goes last: the other supervisors still read their heartbeat files from it (bounded wait for every rank's
+        # worker to have reached 'done' / the job to have been reported)
+        t_wait = time.time()
+        while time.time() - t_wait < 15.0:
+            seen = [(_read_json(os.path.join(jd, "hb_%d_%d.json" % (attempt, r_))) or {}).get("phase") for r_ in range(world)]
+            if all(ph in ("done", "norm_failed") for ph in seen) or os.path.exists(os.path.join(jd, "reported")):
+                break
+            time.sleep(0.1)
         time.sleep(0.5)
         shutil.rmtree(jd, ignore_errors=True)
     sys.exit(rc)

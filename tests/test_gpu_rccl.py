@@ -561,6 +561,36 @@ def test_config4_512cubed_over_rccl_self_neighbour(fpr, oracle, periodic_grid, p
         assert np.array_equal(F.tonumpy(gR)[inner], R[inner])
 
 
+def _run_bench(argv, timeout=600):
+    """bench.py as the driver runs it: returns (process, full record from bench_detail.json, the compact LAST line of stdout parsed).
+    The line must be the last line of stdout, strict JSON, below 4 KB (the driver keeps only the tail of stdout)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        env = dict(os.environ, FPR_BENCH_DETAIL_DIR=td)
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), capture_output=True, text=True, timeout=timeout,
+                           cwd=root, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1 and r.stdout.rstrip("\n").splitlines()[-1] == lines[0]
+        assert len(lines[0]) < 4096
+
+        def no_constants(x):
+            raise ValueError(x)
+
+        line = json.loads(lines[0], parse_constant=no_constants)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "roofline"):
+            assert k in line, k
+        full = json.load(open(os.path.join(td, "bench_detail.json")))
+    assert line["n_gpus"] == full["n_gpus"] and abs(line["value"] - full["value"]) <= 1e-5 * full["value"]
+    return r, full, line
+
+
 def test_bench_two_ranks_rehearsal_on_one_card():
     """bench.py's N>1 control flow between REAL processes on the one card a test box has: the self-launcher, the gloo
     control plane, identical collective counts on every rank through pre-warm / warm-up / timed region, the shell/core
@@ -574,12 +604,8 @@ def test_bench_two_ranks_rehearsal_on_one_card():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--steps", "12", "--warmup", "4", "--no-cpu-baseline", "--no-secondary", "--no-single-leg", "--prewarm-ms", "0"]
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--n", "128"] + common,
-                       capture_output=True, text=True, timeout=600, cwd=root)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    out = json.loads(lines[0])
+    r, out, line = _run_bench(["--gpus", "2", "--rehearse-shared-gpu", "--n", "128"] + common)
+    assert line["config"]["rccl_ranks"] == 2 and line["config"]["rehearsal"] is True and line["norm_check"]["ok"] is True
     assert out["n_gpus"] == 2 and out["config"]["process_grid"] == [1, 1, 2] and out["config"]["global_grid"] == [128, 128, 254]
     assert "rehearsal" in out and out["legs"]["fused_pairs"]["launches"] == 6     # passes over the local grid, 12 steps
     assert 0.0 < out["roofline"]["frac"] <= 1.0      # priced per pass: shell + thin slabs + core halves together
@@ -587,10 +613,7 @@ def test_bench_two_ranks_rehearsal_on_one_card():
     assert out["config"]["last_err"] is not None and 0.0 < out["config"]["last_err"] < 1.0
     # the same global problem (128 x 128 x 254, lz = 20) on ONE rank, same number of iterations: the sum of squares behind
     # the norm rank 0 printed must be the single-domain one (summation order differs: 1e-12)
-    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--as-one-rank-of", "1,1,2", "--n", "128"] + common,
-                        capture_output=True, text=True, timeout=600, cwd=root)
-    assert r1.returncode == 0, r1.stderr[-2000:]
-    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    r1, one, _ = _run_bench(["--gpus", "1", "--as-one-rank-of", "1,1,2", "--n", "128"] + common)
     assert one["config"]["local_grid"] == [128, 128, 254] and one["config"]["global_grid"] == [128, 128, 254]
     a, b = out["config"]["last_sumsq"], one["config"]["last_sumsq"]
     assert a > 0 and abs(a - b) <= 1e-12 * b, (a, b)
@@ -601,10 +624,8 @@ def test_bench_two_ranks_rehearsal_on_one_card():
         assert nc["ok"] is True and nc["key"] == "n128_dims1,1,2" and nc["iterations"] == o["config"]["iterations_since_start"] == 32
     assert out["config"]["choreography"] == "pairs" and out["config"]["attempt"] == 1 and "first_attempt" not in out
     # the watchdog's fallback choreography (single steps, no split of the device) on the same problem: same norm
-    rp = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--n", "128",
-                         "--choreography", "plain"] + common, capture_output=True, text=True, timeout=600, cwd=root)
-    assert rp.returncode == 0, rp.stderr[-2000:]
-    plain = json.loads([l for l in rp.stdout.splitlines() if l.startswith("{")][0])
+    rp, plain, pline = _run_bench(["--gpus", "2", "--rehearse-shared-gpu", "--n", "128", "--choreography", "plain"] + common)
+    assert pline["config"]["choreography"] == "plain" and pline["norm_check"]["ok"] is True
     assert plain["config"]["choreography"] == "plain" and plain["norm_check"]["ok"] is True
     assert plain["roofline"]["launches_by_kind"]["core"] == 0
 
@@ -619,13 +640,9 @@ def test_bench_watchdog_ends_a_stalled_gpu_rank_and_the_plain_fallback_checks_it
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--n", "128", "--steps", "12",
-                        "--warmup", "4", "--prewarm-ms", "0", "--no-cpu-baseline", "--no-secondary", "--dry-run-hang", "1", "--watchdog-s", "12"],
-                       capture_output=True, text=True, timeout=600, cwd=root)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    out = json.loads(lines[0])
+    r, out, line = _run_bench(["--gpus", "2", "--rehearse-shared-gpu", "--n", "128", "--steps", "12", "--warmup", "4", "--prewarm-ms", "0",
+                               "--no-cpu-baseline", "--no-secondary", "--dry-run-hang", "1", "--watchdog-s", "12"])
+    assert line["config"]["attempt"] == 2 and line["config"]["choreography"] == "plain" and "no progress" in line["config"]["fallback_reason"]
     assert out["config"]["choreography"] == "plain" and out["config"]["attempt"] == 2
     assert out["first_attempt"]["choreography"] == "pairs" and "no progress" in out["first_attempt"]["reason"]
     assert out["norm_check"]["ok"] is True and out["norm_check"]["key"] == "n128_dims1,1,2"
@@ -646,12 +663,8 @@ def test_bench_four_ranks_rehearsal_x_y_z_decompositions_agree():
               "--no-secondary", "--no-single-leg", "--prewarm-ms", "0"]
     errs = []
     for dims in ("2,2,1", "2,1,2", "1,2,2"):
-        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dims", dims] + common,
-                           capture_output=True, text=True, timeout=600, cwd=root)
-        assert r.returncode == 0, r.stderr[-2000:]
-        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        assert len(lines) == 1
-        out = json.loads(lines[0])
+        r, out, line = _run_bench(["--dims", dims] + common)
+        assert line["config"]["process_grid"] == [int(x) for x in dims.split(",")] and line["norm_check"]["ok"] is True
         assert out["n_gpus"] == 4 and out["config"]["process_grid"] == [int(x) for x in dims.split(",")]
         assert out["legs"]["fused_pairs"]["launches"] == 6 and 0.0 < out["roofline"]["frac"] <= 1.0
         assert out["norm_check"]["ok"] is True and out["norm_check"]["key"] == "n128_dims" + dims
@@ -701,10 +714,7 @@ def test_bench_two_ranks_rehearsal_python_twin_of_the_choreography():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--rehearse-transport", "python",
-                        "--n", "128", "--steps", "12", "--warmup", "4", "--no-cpu-baseline", "--no-secondary", "--no-single-leg", "--prewarm-ms", "0"],
-                       capture_output=True, text=True, timeout=600, cwd=root)
-    assert r.returncode == 0, r.stderr[-2000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    r, out, _ = _run_bench(["--gpus", "2", "--rehearse-shared-gpu", "--rehearse-transport", "python", "--n", "128", "--steps", "12", "--warmup", "4",
+                            "--no-cpu-baseline", "--no-secondary", "--no-single-leg", "--prewarm-ms", "0"])
     assert out["norm_check"]["ok"] is True and out["norm_check"]["key"] == "n128_dims1,1,2"
     assert "Python HaloExchanger" in out["config"]["halo"]

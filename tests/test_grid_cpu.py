@@ -178,7 +178,94 @@ def test_nshard_equals_single_domain(tmp_path, oracle, dims, n):
         assert np.array_equal(locR[1:-1, 1:-1, 1:-1], globR[1:-1, 1:-1, 1:-1])
 
 
-def test_bench_self_launcher_dry_run_world2():
+REQUIRED_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                      "dtype", "data", "config")
+
+
+def _last_line(stdout):
+    """The driver keeps the tail of stdout and reads the LAST line: strict JSON (no NaN / Infinity), ASCII, below 4 KB."""
+    import json
+
+    last = stdout.rstrip("\n").splitlines()[-1]
+    assert len(last) < 4096, len(last)
+    assert last.isascii()
+
+    def no_constants(x):
+        raise ValueError("non-finite constant %r in the bench line" % x)
+
+    d = json.loads(last, parse_constant=no_constants)
+    for k in REQUIRED_LINE_KEYS:
+        assert k in d, k
+    for k, v in d.items():             # flat: objects of scalars only, no prose
+        for kk, vv in (v.items() if isinstance(v, dict) else ((k, v),)):
+            assert not isinstance(vv, dict), (k, kk)
+            assert not (isinstance(vv, str) and len(vv) > 160), (k, kk)
+    return d
+
+
+def test_bench_line_is_compact_for_a_full_record():
+    """a 23 KB line left the driver's record empty.  The compact line built from a full record of the N = 1 run (the round-5
+    record, committed as a fixture, and a two-rank one derived from it) stays below 4 KB and carries what the contract names: metric,
+    value, roofline (physical frac, kernel time, bytes per launch, traffic), cpu_baseline, norm_check, one scalar per secondary leg."""
+    import importlib.util
+    import io
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("benchlegs_mod", os.path.join(root, "finalprojectrepo.jl_amd", "benchlegs.py"))
+    bl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bl)
+    full = json.load(open(os.path.join(root, "tests", "golden", "bench_full_record_r5.json")))
+    assert len(json.dumps(full)) > 15000
+    two = json.loads(json.dumps(full))
+    two["n_gpus"] = 2
+    two["config"].update({"process_grid": [1, 1, 2], "rccl_ranks": 2, "choreography": "pairs", "control_plane": "gloo"})
+    two["first_attempt"] = {"attempt": 1, "choreography": "pairs", "reason": "no progress of rank 1 for 120 s in phase 'warmup' " + "x" * 500,
+                            "rccl_rank0_log_tail": "y" * 2000}
+    for k in ("cpu_baseline", "vcycle", "vcycle_5levels", "ns_step", "roofline_single", "power_probe"):
+        two.pop(k)
+    for rec_in in (full, two):
+        buf = io.StringIO()
+        line = bl.emit(rec_in, root=os.path.join(root, "no-such-dir"), stream=buf)
+        d = _last_line(buf.getvalue())
+        assert line == buf.getvalue().rstrip("\n")
+        r = d["roofline"]
+        for k in ("bound", "kernel", "kernel_ms", "bytes_per_launch", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in r, k
+        assert r["bound"] == "hbm" and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
+        assert abs(r["achieved"] - r["bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-3 * r["achieved"]
+        assert isinstance(r["bytes_per_launch"], int) and r["bytes_per_launch"] == 32 * 510 ** 3
+        assert d["norm_check"]["ok"] is True
+        assert d["config"]["local_grid"] == [512, 512, 512]
+    d1 = json.loads(bl.compact_check(bl.compact_record(full)))
+    assert set(d1["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d1["cpu_baseline"]["kind"] == "port"
+    for k in ("vcycle_s", "vcycle_seam_us", "vcycle5_jacobi_s", "vcycle5_cg_s", "ns_step_s"):
+        assert d1[k] > 0, k
+    assert d1["roofline"]["unplaced_kernel_ms"] > 0
+    d2 = json.loads(bl.compact_check(bl.compact_record(two)))
+    assert d2["n_gpus"] == 2 and d2["config"]["rccl_ranks"] == 2 and len(d2["config"]["fallback_reason"]) <= 160
+    # a record that cannot be made compact is an error, not a long line
+    import pytest
+    with pytest.raises(ValueError):
+        bl.compact_check(dict(d1, junk="z" * 5000))
+
+
+def test_bench_single_rank_dry_run_line(tmp_path):
+    import sys
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["FPR_BENCH_DETAIL_DIR"] = str(tmp_path)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _last_line(p.stdout)
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["dry_run"] is True
+    assert (tmp_path / "bench_detail.json").exists()
+
+
+def test_bench_self_launcher_dry_run_world2(tmp_path):
     """`python bench.py --gpus 2` without torchrun must start its two ranks itself (run_all_benchmarks.sh:21-28 uses
     mpiexecjl -np N): CPU rehearsal of the launcher and the gloo control plane, no GPU, no compute."""
     import json
@@ -187,31 +274,34 @@ def test_bench_self_launcher_dry_run_world2():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["FPR_BENCH_DETAIL_DIR"] = str(tmp_path)
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout          # ONE JSON line, printed by rank 0 only
-    d = json.loads(lines[0])
+    d = _last_line(p.stdout)                  # ... the last line of stdout, compact
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["max_over_ranks"] == 2.0
-    assert d["self_launched"] is True and d["control_plane"] == "gloo" and d["dry_run"] is True
+    assert d["config"]["self_launched"] is True and d["config"]["control_plane"] == "gloo" and d["dry_run"] is True
     # a failing rank must fail the launch (exit code propagated, the other rank is not left hanging)
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-such-flag"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
 
 
-def _bench(argv, timeout=300):
+def _bench(argv, timeout=300, detail_dir=None):
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    if detail_dir is not None:
+        env["FPR_BENCH_DETAIL_DIR"] = str(detail_dir)
     return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True, text=True,
                           timeout=timeout)
 
 
-def test_bench_watchdog_fails_a_stalled_attempt_and_falls_back_to_the_plain_choreography():
+def test_bench_watchdog_fails_a_stalled_attempt_and_falls_back_to_the_plain_choreography(tmp_path):
     """A rank that stops making progress (a deadlocked collective) must not hang the N > 1 bench: every rank process
     supervises its worker through a heartbeat file; the stalled attempt is failed for ALL ranks, fresh workers run once with
     --choreography plain, and the one JSON line says which choreography produced it and why the first attempt failed."""
@@ -219,14 +309,15 @@ def test_bench_watchdog_fails_a_stalled_attempt_and_falls_back_to_the_plain_chor
     import time
 
     t0 = time.time()
-    p = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--dry-run-hang", "1", "--watchdog-s", "6"])
+    p = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--dry-run-hang", "1", "--watchdog-s", "6"], detail_dir=tmp_path)
     assert p.returncode == 0, p.stderr[-2000:]
     assert time.time() - t0 < 120
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
-    d = json.loads(lines[0])
-    assert d["attempt"] == 2 and d["choreography"] == "plain" and d["ranks_seen"] == 2
-    fa = d["first_attempt"]
+    d = _last_line(p.stdout)
+    assert d["config"]["attempt"] == 2 and d["config"]["choreography"] == "plain" and d["ranks_seen"] == 2
+    assert "no progress" in d["config"]["fallback_reason"]
+    fa = json.load(open(tmp_path / "bench_detail.json"))["first_attempt"]       # the whole story: the detail file
     assert fa["attempt"] == 1 and fa["choreography"] == "pairs" and "no progress" in fa["reason"]
     assert set(fa["phase_by_rank"]) == {"0", "1"}
     assert "watchdog" in p.stderr
@@ -246,8 +337,9 @@ def test_bench_watchdog_second_failure_exits_nonzero_within_bounds():
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
+    assert len(lines[0]) < 4096 and p.stdout.rstrip("\n").splitlines()[-1] == lines[0]
     assert d["value"] is None and d["error"] == "both attempts failed"
-    assert [a["choreography"] for a in d["attempts"]] == ["pairs", "plain"]
+    assert "no progress" in d["config"]["first_attempt_reason"] and d["config"]["second_attempt_reason"]
 
 
 def test_bench_watchdog_under_torch_distributed_run():
@@ -270,8 +362,8 @@ def test_bench_watchdog_under_torch_distributed_run():
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
-    d = json.loads(lines[0])
-    assert d["attempt"] == 2 and d["choreography"] == "plain" and d["self_launched"] is False and d["ranks_seen"] == 2
+    d = _last_line(p.stdout)
+    assert d["config"]["attempt"] == 2 and d["config"]["choreography"] == "plain" and d["config"]["self_launched"] is False and d["ranks_seen"] == 2
 
 
 def test_bench_norm_check_against_the_control_runs(tmp_path):

@@ -15,7 +15,22 @@ from . import _lib
 from . import placement  # noqa: F401
 from ._lib import Context, FprError, asdevice, fzeros, fones, tonumpy, lib_path  # noqa: F401
 
+import threading as _threading
+
 _default_ctx = None
+_tls = _threading.local()      # a context bound to the calling THREAD (bind_context): several ranks in one process
+
+
+def bind_context(c):
+    """Make `c` the context every call of this package uses from the calling thread (None: back to the process default), and its
+    compute stream torch's current stream of this thread.  One thread per rank, one context per thread: how eight ranks run their
+    exchange code in ONE process on one card (tests/test_gpu_rccl.py; the GPU boxes admit six processes)."""
+    _tls.ctx = c
+    if c is not None:
+        import torch
+
+        torch.cuda.set_device(c.device)
+        torch.cuda.set_stream(c.compute)
 
 
 def init(device=0):
@@ -27,6 +42,9 @@ def init(device=0):
 
 
 def ctx():
+    c = getattr(_tls, "ctx", None)
+    if c is not None:
+        return c
     if _default_ctx is None:
         return init(0)
     return _default_ctx

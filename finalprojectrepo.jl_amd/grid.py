@@ -332,12 +332,12 @@ class GlobalGrid:
     _native_pending = False
     _singles = 0
 
-    def __init__(self, nx, ny, nz, dims=None, group=None, use_dist=None, periods=(0, 0, 0), transport=None, drop_faces=0):
+    def __init__(self, nx, ny, nz, dims=None, group=None, use_dist=None, periods=(0, 0, 0), transport=None, drop_faces=0, dist=None):
         """drop_faces (bit 2*dim+side; measurement aid): faces that get no neighbour although the topology has one -- a
-        periodic single rank minus its three low faces has the face set of a corner rank of a (2,2,2) decomposition."""
+        periodic single rank minus its three low faces has the face set of a corner rank of a (2,2,2) decomposition.
+        dist: a torch.distributed look-alike to use instead of torch.distributed itself (ThreadWorld.rank_view below)."""
         self.nx, self.ny, self.nz = nx, ny, nz
-        dist = None
-        if use_dist is None or use_dist:
+        if dist is None and (use_dist is None or use_dist):
             try:
                 import torch.distributed as _dist
 
@@ -796,9 +796,82 @@ def assemble_global(parts, dims):
 def finalize_global_grid():
     """finalize_global_grid(): releases the library's communicator and pack buffers (fpr_comm_finalize);
     torch.distributed, if used for the bootstrap, is owned by the caller."""
-    from . import _default_ctx
+    from . import _default_ctx, _tls
 
-    if _default_ctx is not None and getattr(_default_ctx, "comm_ready", False):
-        _default_ctx.call("fpr_comm_finalize")
-        _default_ctx.comm_ready = False
+    c = getattr(_tls, "ctx", None) or _default_ctx
+    if c is not None and getattr(c, "comm_ready", False):
+        c.call("fpr_comm_finalize")
+        c.comm_ready = False
     return None
+
+
+class ThreadWorld:
+    """N ranks as N THREADS of one process: the part of torch.distributed that hosted_bootstrap and GlobalGrid use (isend / recv /
+    all_reduce / barrier / rank / size), over in-process queues.  For rehearsing process grids with more ranks than a one-card box
+    admits processes (six): every rank is a thread with its own library context (bind_context) running the library's exchange code and
+    pair choreography over fpr_comm_init_hosted.  Not a transport of the product."""
+
+    class _Done:
+        @staticmethod
+        def is_completed():
+            return True
+
+        @staticmethod
+        def wait():
+            return None
+
+    class ReduceOp:
+        SUM, MAX = "sum", "max"
+
+    def __init__(self, world):
+        import queue
+        import threading
+
+        self.world = world
+        self.q = {(s, d): queue.Queue() for s in range(world) for d in range(world)}
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def rank_view(self, rank):
+        tw = self
+
+        class View:
+            ReduceOp = ThreadWorld.ReduceOp
+
+            @staticmethod
+            def get_world_size(group=None):
+                return tw.world
+
+            @staticmethod
+            def get_rank(group=None):
+                return rank
+
+            @staticmethod
+            def isend(t, peer, group=None):
+                tw.q[(rank, peer)].put(t)            # (hosted_bootstrap hands a private copy)
+                return ThreadWorld._Done
+
+            @staticmethod
+            def recv(t, peer, group=None):
+                t.copy_(tw.q[(peer, rank)].get(timeout=120.0))
+
+            @staticmethod
+            def all_reduce(t, op="sum", group=None):
+                tw.slots[rank] = t.clone()
+                tw.bar.wait(timeout=120.0)
+                acc = tw.slots[0].clone()
+                for k in range(1, tw.world):         # the same order on every rank: identical results everywhere
+                    acc = torch_max(acc, tw.slots[k]) if op == "max" else acc + tw.slots[k]
+                tw.bar.wait(timeout=120.0)
+                t.copy_(acc)
+
+            @staticmethod
+            def barrier(group=None):
+                tw.bar.wait(timeout=120.0)
+
+        def torch_max(a, b):
+            import torch
+
+            return torch.maximum(a, b)
+
+        return View

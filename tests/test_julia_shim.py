@@ -291,3 +291,67 @@ def test_every_exported_name_is_defined():
     defined |= set(re.findall(r"^(?:@inline\s+)?([A-Za-z_][A-Za-z_0-9!τ]*)\(", SHIM, flags=re.M))
     missing = sorted(n for n in exported if n not in defined)
     assert not missing, "exported by FPRHip.jl but not defined in it: %s" % missing
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# julia/test/runtests.jl: the reference's own suite (test/runtests.jl:6-9) restated against the shim.  Unexecuted like the
+# shim; what can be checked without a toolchain: its blocks close, every FPRHip name it uses is exported, every reference file it
+# includes is one of the seven hot-path files, every function of the reference it calls survives include_reference or is provided
+# natively, every fixture it reads is committed.
+# ----------------------------------------------------------------------------------------------------------------------
+JTEST = open(os.path.join(ROOT, "julia", "test", "runtests.jl"), encoding="utf-8").read()
+
+
+def _strip_julia(txt):
+    txt = re.sub(r'"""(?:.|\n)*?"""', '""', txt)
+    keep = re.findall(r'"((?:\\.|[^"\\\n])*)"', txt)
+    txt = re.sub(r'"(?:\\.|[^"\\\n])*"', '""', txt)
+    txt = re.sub(r"#=(?:.|\n)*?=#", "", txt)
+    txt = re.sub(r"#[^\n]*", "", txt)
+    return txt, keep
+
+
+def test_julia_runtests_blocks_are_balanced_and_parts_are_the_references_four():
+    code, _ = _strip_julia(JTEST)
+    problems = julia_block_scan(code)
+    assert not problems, "julia/test/runtests.jl: " + "; ".join(problems[:5])
+    assert re.findall(r"^module\s+(\w+)", code, flags=re.M) == ["Part1", "Multigrid", "Krylov", "Part2"]     # test/runtests.jl:6-9, in its order
+    assert [m for m in re.findall(r"^(\w+)\.run\(\)", code, flags=re.M)] == ["Part1", "Multigrid", "Krylov", "Part2"]
+    assert code.count("@testset") >= 7 and code.count("@test ") >= 14
+
+
+def test_julia_runtests_uses_only_what_the_shim_exports_and_the_reference_defines():
+    code, strings = _strip_julia(JTEST)
+    exported = shim_exports()
+    # macros: Base / Test ones, or exported by the shim
+    for mac in set(re.findall(r"@([A-Za-z_][A-Za-z_0-9]*)", code)):
+        if mac in {"test", "testset", "__DIR__", "__MODULE__", "views", "show"}:
+            continue
+        assert "@" + mac in exported, "runtests.jl uses @%s, which FPRHip.jl does not export" % mac
+    # reference files included: only the seven hot-path files, each through include_reference
+    files = [s_ for s_ in strings if re.fullmatch(r"[A-Za-z_0-9]+\.jl", s_) and s_ not in ("FPRHip.jl",)]
+    assert files and code.count("include_reference(") == len(files)
+    surf_files = {os.path.basename(f): f for f in SURF["files"]}
+    for f in files:
+        assert f in surf_files, f
+    # names of the hot path the tests call: provided natively by the shim (exported) or defined by the reference files they include
+    ref_funcs = {f["name"] for f in SURF["functions_defined"]}
+    called = set(re.findall(r"(?<![\w.@:])([A-Za-z_][A-Za-z_0-9]*!?)\(", code))
+    hot = {n for n in called if n in ref_funcs or n in exported}
+    for must in ("diffusion_3D_array_programming", "diffusion_3D_kernel_programming", "MGsolve_2DPoisson!", "iteration_2DPoisson!",
+                 "residual_2DPoisson_wrapper!", "cg!", "navier_stokes_2D", "stencil_5pt", "MGOpt", "include_reference"):
+        assert must in hot, "runtests.jl does not exercise %s" % must
+    m = re.search(r"const NATIVE_HOST = Set\{Tuple\{Symbol,Int\}\}\(\[(.*?)\]\)", SHIM, flags=re.S)
+    native = set(re.findall(r'Symbol\("([^"]+)"\)', m.group(1))) | set(re.findall(r"\(:([A-Za-z_][A-Za-z_0-9]*),", m.group(1)))
+    for n in hot:
+        assert n in exported or (n in ref_funcs and n not in native) or n in ref_funcs, n
+    # the drivers must be the REFERENCE's (the shim no longer carries a copy of part1_array_programming.jl's driver)
+    assert "function diffusion_3D_array_programming" not in SHIM and "diffusion_3D_array_programming" not in exported
+    for name in ("MGOpt", "jacobi", "conjugate_gradient", "parallel", "parallel_shmem", "Data"):
+        assert name in exported, name
+    # fixtures: the committed copies of the reference's reftest-files
+    for fx in ("test_1.bson", "T.bin", "W.bin", "S.bin"):
+        assert fx in strings
+        assert os.path.exists(os.path.join(ROOT, "tests", "golden", fx)) or os.path.exists(os.path.join(ROOT, "tests", "golden", "fortran", fx))
+    # tolerances as the reference's tests state them (test/part1.jl:22, test/multigrid.jl:34,64, test/krylov.jl:23, test/part2.jl:31)
+    assert "atol = 1e-5" in JTEST and "atol = 1e-8" in JTEST and JTEST.count("tol = 1e-6") >= 3

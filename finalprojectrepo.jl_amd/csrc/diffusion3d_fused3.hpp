@@ -30,6 +30,30 @@
 #pragma once
 #include "diffusion3d_fused2.hpp"
 
+#ifndef DIFF3_M3_ROW_FENCE
+#define DIFF3_M3_ROW_FENCE 0      // 1: scheduling barrier between the rows of a level (no effect on the register count: harness only)
+#endif
+// When the next planes are requested.  The register budget (256 at two waves per SIMD) holds twelve planes of 12 registers beside the
+// temporaries of the point update, and L0 + Ht + L1 + L2 need three each: a plane in flight beside them is a thirteenth, which the
+// compiler spills -- with a wait for the load it has just issued (measured: 1.165 ms per launch, no overlap of loads and arithmetic).
+//   0 = early: L0 plane m+3 behind the second step, Ht plane m+2 at the end of iteration m (two planes in flight all the time)
+//   1 = late:  L0 plane m+2 and Ht plane m+1 behind the second step of iteration m, into the slots that died one iteration earlier; they
+//       are needed at the first step of iteration m+1 (the third step and the exchange lie between); twelve planes at any time
+#ifndef DIFF3_M3_SCHED
+#define DIFF3_M3_SCHED 0
+#endif
+// 1: the L2 plane below the one the third step updates (its z-minus operand, idle for a whole iteration between its use as the centre
+// and this one) waits in LDS instead of registers: 3 ds_write_b128 + 3 ds_read_b128 per wave and iteration buy the twelve registers
+// the budget is short of
+#ifndef DIFF3_M3_PARK
+#define DIFF3_M3_PARK 1
+#endif
+// 1: the three running sums of squares (one per level and lane) live in LDS -- one ds_add_f64 per level and iteration -- instead of six
+// registers
+#ifndef DIFF3_M3_LDS_ACC
+#define DIFF3_M3_LDS_ACC 1
+#endif
+
 struct Diff3Args3 {
     const double* Ht;
     const double* X;        // L0
@@ -45,7 +69,7 @@ struct Diff3Args3 {
     double* partials3;
     int zc, ntx, nby, ntz, sx;
     int xalign, xcd_remap;
-    int bal_r, bal_sp, bal_q;   // left-over units, slices per unit, planes per slice (0: plain grid)
+    int nfull, bal_sp, bal_q;   // workgroups that serve a whole unit; slices per left-over unit, planes per slice
     const int* skip;        // return at once if *skip (nullptr = unconditional)
     int lane_off;
 #ifdef FPR_TUNE
@@ -53,14 +77,17 @@ struct Diff3Args3 {
 #endif
 };
 
-template <bool NORM, bool WRES = true, bool BAL = false>
+template <bool NORM, bool WRES = true>
 __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
 {
     constexpr int NW = 8, VX = 2, RY = 3, TXW = 128, SYB = NW * RY - 4;
     constexpr int NR = 4;                         // ring length = loop unroll
     constexpr int SLOT = 6 * TXW;                 // doubles per wave slot: first / last row of L0, L1, L2
     constexpr unsigned OOR = 0x7fffffffu;
-    __shared__ double red[3 * NW];
+#if DIFF3_M3_LDS_ACC
+    __shared__ double accl[3][64 * NW];     // per level and lane: running sum of squares over the rows / planes the workgroup owns
+#endif
+    __shared__ double red[3 * NW];          // per wave and level: sum over the wave's owned cells of every item served so far
     extern __shared__ __attribute__((aligned(16))) double xrow[];   // [parity][slot 0..NW+1][row kind][TXW]: 2 * (NW + 2) * SLOT doubles
 
     if (a.skip && *a.skip) return;
@@ -71,22 +98,23 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
 
     const int nx = a.nx, ny = a.ny, nz = a.nz;
     const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
-    double tot1 = 0.0, tot2 = 0.0, tot3 = 0.0;
+    if (NORM && tid < 3 * NW) red[tid] = 0.0;    // (ordered before its first use by the barriers of the march)
+#if DIFF3_M3_LDS_ACC
+    if (NORM) { accl[0][tid] = 0.0; accl[1][tid] = 0.0; accl[2][tid] = 0.0; }     // (a lane's own slots: program order suffices)
+#endif
 
-    const int unit = blockIdx.x, nunits = gridDim.x;
-    constexpr int NITEM = BAL ? 2 : 1;
-#pragma unroll 1
-    for (int item = 0; item < NITEM; ++item) {
+    // Units: (x/y tile, z-chunk) pairs.  The first a.nfull workgroups serve one unit each -- as many as the device holds at once -- and
+    // the units beyond them are cut into a.bal_sp thin slices of a.bal_q planes, one workgroup per slice, which the dispatcher places as
+    // the whole units finish: 260 units on 256 compute units cost one round and a few iterations, not two rounds.
+    const int unit = blockIdx.x;
     int tx, by, k0, k1;
-    int slice = -1;
-    int bid = unit;
-    if (BAL && item == 1) {
-        const int j = bid / a.bal_sp;
-        if (j >= a.bal_r) break;                           // block-uniform
-        slice = bid - j * a.bal_sp;
-        bid = nunits + j;
+    int bid = unit, slice = -1;
+    if (bid >= a.nfull) {
+        const int j = (bid - a.nfull) / a.bal_sp;
+        slice = (bid - a.nfull) - j * a.bal_sp;
+        bid = a.nfull + j;
     } else if (a.xcd_remap == 1) {
-        const int q = nunits >> 3, rem = nunits & 7;
+        const int q = a.nfull >> 3, rem = a.nfull & 7;
         const int xcd = bid & 7, slot = bid >> 3;
         bid = xcd * q + (xcd < rem ? xcd : rem) + slot;
     }
@@ -95,12 +123,11 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
     const int tz = bid / (a.ntx * a.nby);
     k0 = a.lo[2] + tz * a.zc;
     k1 = (k0 + a.zc < a.hi[2]) ? k0 + a.zc : a.hi[2];
-    if (BAL && item == 1) {
+    if (slice >= 0) {
         k0 += slice * a.bal_q;
         k1 = (k0 + a.bal_q < k1) ? k0 + a.bal_q : k1;
-        if (k1 <= k0) break;                               // block-uniform
-        __syncthreads();                                   // the first unit's last LDS rows are still being read
     }
+    const bool idle = k1 <= k0;              // block-uniform: a slice beyond the end of its unit (its partial sums are zero)
 
     // ---- x: owned output cells [ol, oh); own cells [s, s+128) ----
     const int e0 = a.lo[0] & ~1;
@@ -156,7 +183,12 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
     const Diff3Coef cf{a.dtau, a._dt, a._dx, a._dy, a._dz, a.D_dx, a.D_dy, a.D_dz};
     auto kcl = [&](int k) { return k < 0 ? 0 : (k > nz - 1 ? nz - 1 : k); };
 
-    if (!a.lane_off || (ib >= ifirst && ib <= ilast)) {
+    // one sum per level and lane: a lane owns both cells of its pair or neither, except at an odd end of the owned range (tiles with
+    // has_split: there the cell that is not owned is left out as it goes); lanes that own nothing are dropped at the end
+#if !DIFF3_M3_LDS_ACC
+    double acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+#endif
+    if (!idle && (!a.lane_off || (ib >= ifirst && ib <= ilast))) {
     // ---- buffer descriptors (see k_diff3_march2): every access of iteration m uses the scalar offset so + r * rs ----
     const int ps = (int)(sz * 8), rs = (int)(sy * 8);
     const int pbA = m0 - 1 > 0 ? m0 - 1 : 0;
@@ -181,9 +213,12 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
     DVec<VX> Q2[NR][RY];      // L2 planes m-3, m-2, m-1; plane p in slot (p - m0 + 3) % NR
     DVec<VX> YH;              // global L0 halo row of plane m (bottom / top wave; the Bnd boundary row if bb / bt)
     double ED[RY];            // L0 tile-edge cells of plane m (or the Bnd boundary cell)
-    // one sum per level and lane: a lane owns both cells of its pair or neither, except at an odd end of the owned range (tiles with
-    // has_split: there the cell that is not owned is left out as it goes); lanes that own nothing are dropped at the end
-    double acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+#if DIFF3_M3_LDS_ACC
+    double acc1, acc2, acc3;          // (unused names: the sums live in accl)
+    auto flush = [&](int lv, double sl, double&) { atomicAdd(&accl[lv][tid], sl); };   // result unused: ds_add_f64
+#else
+    auto flush = [&](int, double sl, double& acc) { acc += sl; };
+#endif
     auto accum = [&](double& acc, const double (&r)[VX]) {
         if (has_split) {
             asm volatile("" ::: "memory");
@@ -201,6 +236,7 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
 #pragma unroll
             for (int v = 0; v < VX; ++v) { Q1[q][r].v[v] = 0.0; Q2[q][r].v[v] = 0.0; HT[q][r].v[v] = 0.0; }
 
+    double* const park = xrow + (size_t)2 * (NW + 2) * SLOT + (size_t)w * (RY * TXW) + lane * VX;   // this wave's parked L2 plane (DIFF3_M3_PARK)
     auto row_off = [&](int soff, int r) { return soff == (int)OOR ? (int)OOR : soff + r * rs; };
     auto load_rows = [&](DVec<VX>(&dst)[RY], __amdgpu_buffer_rsrc_t rsrc, int soff) {
 #pragma unroll
@@ -220,9 +256,13 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
     load_rows(P[0], rA, (kcl(m0 - 1) - pbA) * ps);
     load_rows(P[1], rA, (kcl(m0) - pbA) * ps);
     load_rows(P[2], rA, (m0 + 1 - pbA) * ps);
-    load_rows(P[3], rA, (m0 + 2 - pbA) * ps);
     load_rows(HT[2], rHt, (kcl(m0) - pbA + 1) * ps);
+#if DIFF3_M3_SCHED == 0 || DIFF3_M3_SCHED == 2
+    load_rows(P[3], rA, (m0 + 2 - pbA) * ps);
+#endif
+#if DIFF3_M3_SCHED == 0
     load_rows(HT[3], rHt, (m0 + 1 - pbA + 1) * ps);
+#endif
     load_halo(YH, ED, (kcl(m0) - pbA + 2) * ps);
     // scalar offset of iteration m: plane m+3 of rA = plane m+2 of rHt = plane m+1 of rEA / rEB / rH = plane m-2 of rC / rD
     int so = (m0 + 3 - pbA) * ps;
@@ -237,12 +277,14 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
         DVec<VX>(&Q1m)[RY] = Q1[S % NR];
         DVec<VX>(&Q1c)[RY] = Q1[(S + 1) % NR];
         DVec<VX>(&Q1n)[RY] = Q1[(S + 2) % NR];
+#if !DIFF3_M3_PARK
         DVec<VX>(&Q2m)[RY] = Q2[S % NR];
+#endif
         DVec<VX>(&Q2c)[RY] = Q2[(S + 1) % NR];
         DVec<VX>(&Q2n)[RY] = Q2[(S + 2) % NR];
 
         // ---- one LDS exchange for all three levels: rows of L0(m), L1(m-1), L2(m-2) ----
-        double* buf = xrow + (size_t)(m & 1) * ((NW + 2) * SLOT);
+        double* buf = xrow + (size_t)(S & 1) * ((NW + 2) * SLOT);     // (parity of the iteration count: a compile-time offset)
         typedef double d2l __attribute__((ext_vector_type(2)));
         {
             double* mine = buf + (size_t)(w + 1) * SLOT + lane * VX;
@@ -263,22 +305,15 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
             }
         }
         diff3_lds_barrier();
-        DVec<VX> yd0, yu0, yd1, yu1, yd2, yu2;
-        {
-            const double* od = buf + (size_t)w * SLOT + lane * VX;         // slot below: rows 1, 3, 5 (last rows)
-            const double* ou = buf + (size_t)(w + 2) * SLOT + lane * VX;   // slot above: rows 0, 2, 4 (first rows)
-            d2l t;
-            t = *reinterpret_cast<const d2l*>(od + TXW);     yd0.v[0] = t.x; yd0.v[1] = t.y;
-            t = *reinterpret_cast<const d2l*>(ou);           yu0.v[0] = t.x; yu0.v[1] = t.y;
-            if constexpr (DO2) {
-                t = *reinterpret_cast<const d2l*>(od + 3 * TXW); yd1.v[0] = t.x; yd1.v[1] = t.y;
-                t = *reinterpret_cast<const d2l*>(ou + 2 * TXW); yu1.v[0] = t.x; yu1.v[1] = t.y;
-            }
-            if constexpr (DO3) {
-                t = *reinterpret_cast<const d2l*>(od + 5 * TXW); yd2.v[0] = t.x; yd2.v[1] = t.y;
-                t = *reinterpret_cast<const d2l*>(ou + 4 * TXW); yu2.v[0] = t.x; yu2.v[1] = t.y;
-            }
-        }
+        // the neighbours' rows are read where they are used (level by level: six rows held from here on were 24 registers too many)
+        const double* od = buf + (size_t)w * SLOT + lane * VX;         // slot below: rows 1, 3, 5 (last rows)
+        const double* ou = buf + (size_t)(w + 2) * SLOT + lane * VX;   // slot above: rows 0, 2, 4 (first rows)
+        auto lds_row = [&](const double* q) {
+            const d2l t = *reinterpret_cast<const d2l*>(q);
+            DVec<VX> o;
+            o.v[0] = t.x; o.v[1] = t.y;
+            return o;
+        };
 
         // ---- first step: L1 on plane m ----
         const bool zb = (m <= 0) || (m >= nz - 1);   // block-uniform: a z-boundary plane of L1 comes from Bnd
@@ -290,6 +325,8 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): rare (first / last chunk), no load of this branch pending at the join
         } else {
             const bool own_plane = (m >= k0) && (m < k1);
+            const DVec<VX> yd0 = lds_row(od + TXW), yu0 = lds_row(ou);
+            double sl1 = 0.0;
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
                 const double xl0 = diff3_lane_up1_edge(cR[r].v[VX - 1], ED[r]);
@@ -305,20 +342,28 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
                                                HT[(S + 2) % NR][r].v[v], cf, Q1n[r].v[v]);
                 }
                 if constexpr (NORM) {
-                    if (own_plane && rm[r]) accum(acc1, r1);
+                    if (own_plane && rm[r]) accum(sl1, r1);
                 }
                 if (xb_tile) {   // x-boundary own cells of L1 come from Bnd (through the edge register)
                     asm volatile("" ::: "memory");
                     Q1n[r].v[0] = bndL ? xl0 : Q1n[r].v[0];
                     Q1n[r].v[VX - 1] = bndR ? xrL : Q1n[r].v[VX - 1];
                 }
+#if DIFF3_M3_ROW_FENCE
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
             if (bb) { asm volatile("" ::: "memory"); Q1n[0] = YH; }
             if (bt) { asm volatile("" ::: "memory"); Q1n[RY - 1] = YH; }
+            if constexpr (NORM) flush(0, sl1, acc1);
         }
 
         // the halo registers of plane m are dead: refill with the halos of plane m+1 (nothing once the chunk ends)
         load_halo(YH, ED, (m + 1 <= m1 && !DIFF3_DBG(a, 2)) ? so : (int)OOR);
+#if DIFF3_M3_SCHED == 2
+        // Ht plane m+1 (needed by the first step of iteration m+1) into the slot plane m-3 left at the end of the last iteration
+        load_rows(HT[(S + 3) % NR], rHt, (m + 1 <= m1 && !DIFF3_DBG(a, 2)) ? so - ps : (int)OOR);
+#endif
 
         // ---- second step: L2 on plane m-1 (its boundary cells are X's own: L0 plane m-1 is still in zmR) ----
         if constexpr (DO2) {
@@ -329,6 +374,8 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
                 for (int r = 0; r < RY; ++r) Q2n[r] = zmR[r];
             } else {
                 const bool own2 = (m - 1 >= k0) && (m - 1 < k1);
+                const DVec<VX> yd1 = lds_row(od + 3 * TXW), yu1 = lds_row(ou + 2 * TXW);
+                double sl2 = 0.0;
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
                     const double fromL = diff3_lane_up1_z(Q1c[r].v[VX - 1]);
@@ -343,24 +390,43 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
                         r2[v] = diff3_point<false>(Q1c[r].v[v], xm, xp, ym, yp, Q1m[r].v[v], Q1n[r].v[v], HT[(S + 1) % NR][r].v[v], cf, Q2n[r].v[v]);
                     }
                     if constexpr (NORM) {
-                        if (own2 && rm[r]) accum(acc2, r2);
+                        if (own2 && rm[r]) accum(sl2, r2);
                     }
                     if (xb_tile) {
                         asm volatile("" ::: "memory");
                         Q2n[r].v[0] = bndL ? zmR[r].v[0] : Q2n[r].v[0];
                         Q2n[r].v[VX - 1] = bndR ? zmR[r].v[VX - 1] : Q2n[r].v[VX - 1];
                     }
+#if DIFF3_M3_ROW_FENCE
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
                 if (bb) { asm volatile("" ::: "memory"); Q2n[0] = zmR[0]; }
                 if (bt) { asm volatile("" ::: "memory"); Q2n[RY - 1] = zmR[RY - 1]; }
+                if constexpr (NORM) flush(1, sl2, acc2);
             }
         }
 
+#if DIFF3_M3_SCHED == 0 || DIFF3_M3_SCHED == 2
         // L0 plane m-1 is dead: refill with plane m+3 (L0 is needed up to plane k1 + 2 = m1 + 1)
         load_rows(P[S % NR], rA, (m + 3 <= m1 + 1 && m + 3 <= nz - 1 && !DIFF3_DBG(a, 2)) ? so : (int)OOR);
+#else
+        // the slots that died one iteration ago (L0 plane m-2, Ht plane m-3) receive L0 plane m+2 and Ht plane m+1
+        __builtin_amdgcn_sched_barrier(0);      // (not hoisted above the second step: the registers they land in are the budget's last)
+        load_rows(P[(S + 3) % NR], rA, (m + 2 <= m1 + 1 && m + 2 <= nz - 1 && !DIFF3_DBG(a, 2)) ? so - ps : (int)OOR);
+        load_rows(HT[(S + 3) % NR], rHt, (m + 1 <= m1 && !DIFF3_DBG(a, 2)) ? so - ps : (int)OOR);
+#endif
 
         // ---- third step: L3 on plane m-2 ----
         if constexpr (DO3) {
+            __builtin_amdgcn_sched_barrier(0);
+            const DVec<VX> yd2 = lds_row(od + 5 * TXW), yu2 = lds_row(ou + 4 * TXW);
+#if DIFF3_M3_PARK
+            DVec<VX> Q2m[RY];
+#pragma unroll
+            for (int r = 0; r < RY; ++r) Q2m[r] = lds_row(park + r * TXW);
+#endif
+            double sl3 = 0.0;
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
                 const double fromL = diff3_lane_up1_z(Q2c[r].v[VX - 1]);
@@ -387,12 +453,25 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
                 __builtin_amdgcn_sched_barrier(0);
 #endif
                 if constexpr (NORM) {
-                    if (rm[r]) accum(acc3, res);
+                    if (rm[r]) accum(sl3, res);
                 }
             }
+            if constexpr (NORM) flush(2, sl3, acc3);
         }
+#if DIFF3_M3_PARK
+        if constexpr (DO2) {      // L2 plane m-2 is the next iteration's z-minus plane: to LDS (this wave's own rows; in order behind the reads above)
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                d2l t;
+                t.x = Q2c[r].v[0]; t.y = Q2c[r].v[1];
+                *reinterpret_cast<d2l*>(park + r * TXW) = t;
+            }
+        }
+#endif
+#if DIFF3_M3_SCHED == 0
         // Ht plane m-2 is dead: refill with plane m+2 (first needed by L1 on plane m+2 <= m1)
         load_rows(HT[S % NR], rHt, (m + 2 <= m1 && !DIFF3_DBG(a, 2)) ? so : (int)OOR);
+#endif
         so += ps;
     };
 
@@ -413,26 +492,32 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
     if (m <= m1) { step(std::integral_constant<int, 0>{}, T{}, T{}, m); ++m; }
     if (m <= m1) { step(std::integral_constant<int, 1>{}, T{}, T{}, m); ++m; }
     if (m <= m1) { step(std::integral_constant<int, 2>{}, T{}, T{}, m); ++m; }
+    }
 
     if constexpr (NORM) {
+        // every lane takes part (lanes switched off for the march hold zeros)
         const bool any = cm[0] || cm[1];
-        tot1 += any ? acc1 : 0.0;
-        tot2 += any ? acc2 : 0.0;
-        tot3 += any ? acc3 : 0.0;
+#if DIFF3_M3_LDS_ACC
+        const double acc1 = accl[0][tid], acc2 = accl[1][tid], acc3 = accl[2][tid];
+        accl[0][tid] = 0.0; accl[1][tid] = 0.0; accl[2][tid] = 0.0;
+#endif
+        const double w1 = diff3_wave_sum(any ? acc1 : 0.0), w2 = diff3_wave_sum(any ? acc2 : 0.0), w3 = diff3_wave_sum(any ? acc3 : 0.0);
+        if (lane == 0) { red[w] += w1; red[NW + w] += w2; red[2 * NW + w] += w3; }
     }
-    }
-    }   // item
 
     if constexpr (NORM) {
         const double sc2 = a.scale * a.scale;
-        const double s1 = diff3_block_sum_waves<NW>(tot1 * sc2, red, tid);
-        const double s2 = diff3_block_sum_waves<NW>(tot2 * sc2, red + NW, tid);
-        const double s3 = diff3_block_sum_waves<NW>(tot3 * sc2, red + 2 * NW, tid);
-        if (tid == 0) { a.partials1[unit] = s1; a.partials2[unit] = s2; a.partials3[unit] = s3; }
+        __syncthreads();
+        if (tid == 0) {
+            double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) { s1 += red[i]; s2 += red[NW + i]; s3 += red[2 * NW + i]; }
+            a.partials1[unit] = s1 * sc2; a.partials2[unit] = s2 * sc2; a.partials3[unit] = s3 * sc2;
+        }
     }
 }
 
-constexpr size_t DIFF3_MARCH3_LDS = (size_t)2 * (8 + 2) * 6 * 128 * sizeof(double);   // 122 880 bytes
+constexpr size_t DIFF3_MARCH3_LDS = ((size_t)2 * (8 + 2) * 6 * 128 + (size_t)DIFF3_M3_PARK * 8 * 3 * 128) * sizeof(double);   // 122 880 (+ 24 576) bytes
 
 // true if the fused three-step kernel can serve this problem
 static inline bool diff3_can_fuse3(const double* Ht, const double* X, const double* Bnd, const double* Y, const double* dH,
@@ -456,8 +541,10 @@ static inline hipError_t diff3_launch3(Diff3Args3 a, bool norm, int zc_opt, int 
     if (!attr_set) {
         hipError_t e = hipSuccess;
 #define FPR_M3_ATTR(...) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diff3_march3<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIFF3_MARCH3_LDS)
-        FPR_M3_ATTR(true, true, false); FPR_M3_ATTR(true, true, true); FPR_M3_ATTR(false, true, false); FPR_M3_ATTR(false, true, true);
-        FPR_M3_ATTR(true, false, false); FPR_M3_ATTR(true, false, true); FPR_M3_ATTR(false, false, false); FPR_M3_ATTR(false, false, true);
+        FPR_M3_ATTR(true, true);
+#ifndef DIFF3_M3_FEW
+        FPR_M3_ATTR(false, true); FPR_M3_ATTR(true, false); FPR_M3_ATTR(false, false);
+#endif
 #undef FPR_M3_ATTR
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -508,29 +595,28 @@ static inline hipError_t diff3_launch3(Diff3Args3 a, bool norm, int zc_opt, int 
     if (xcd_opt == 0) xcd_opt = (nblk >= 64 && nblk <= 2 * slots) ? 1 : 3;
     a.xcd_remap = (xcd_opt == 1 && nblk >= 64) ? 1 : 0;
     const bool wres = a.dH != nullptr;
-    a.bal_r = a.bal_sp = a.bal_q = 0;
+    a.nfull = (int)nblk; a.bal_sp = 1; a.bal_q = zc;
     long grid = nblk;
-    bool bal = false;
     {
         const long r = nblk - slots;
         if (r > 0 && r <= slots / 4) {
-            bal = true;
-            grid = slots;
-            a.bal_r = (int)r;
+            a.nfull = (int)slots;
             a.bal_sp = (int)(slots / r);
             a.bal_q = (zc + a.bal_sp - 1) / a.bal_sp;
+            grid = slots + r * a.bal_sp;
             if (bal_info) *bal_info = r * 1000000 + (long)a.bal_sp * 1000 + a.bal_q;
         }
     }
+    if (norm && grid > max_partials) return hipErrorInvalidValue;
     const size_t lds = DIFF3_MARCH3_LDS;
-#define FPR_M3_GO(N_, W_, B_) k_diff3_march3<N_, W_, B_><<<(int)grid, 512, lds, stream>>>(a)
-    if (bal) {
-        if (wres) { if (norm) FPR_M3_GO(true, true, true); else FPR_M3_GO(false, true, true); }
-        else { if (norm) FPR_M3_GO(true, false, true); else FPR_M3_GO(false, false, true); }
-    } else {
-        if (wres) { if (norm) FPR_M3_GO(true, true, false); else FPR_M3_GO(false, true, false); }
-        else { if (norm) FPR_M3_GO(true, false, false); else FPR_M3_GO(false, false, false); }
-    }
+#define FPR_M3_GO(N_, W_) k_diff3_march3<N_, W_><<<(int)grid, 512, lds, stream>>>(a)
+#ifdef DIFF3_M3_FEW
+    if (!wres || !norm) return hipErrorInvalidValue;
+    FPR_M3_GO(true, true);
+#else
+    if (wres) { if (norm) FPR_M3_GO(true, true); else FPR_M3_GO(false, true); }
+    else { if (norm) FPR_M3_GO(true, false); else FPR_M3_GO(false, false); }
+#endif
 #undef FPR_M3_GO
     *nparts = (int)grid;
     return hipGetLastError();

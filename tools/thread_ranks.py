@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""N ranks as threads of one process (grid.ThreadWorld, one library context per thread) against the single-domain run: diagnostic twin of
+tests/test_gpu_rccl.py::test_eight_ranks_as_threads...   usage: thread_ranks.py dx,dy,dz pairs|plain [n] [iters]"""
+import os
+import sys
+import threading
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fpr_amd
+import torch
+
+F = fpr_amd.load(0)
+dims = tuple(int(x) for x in sys.argv[1].split(","))
+fused = (sys.argv[2] if len(sys.argv) > 2 else "pairs") == "pairs"
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 12
+world = dims[0] * dims[1] * dims[2]
+nglob = tuple(d * (n - 2) + 2 for d in dims)
+lx, ly, lz = (d * 10.0 for d in dims)
+dx, dy, dz = lx / nglob[0], ly / nglob[1], lz / nglob[2]
+D, dt = 1.0, 0.2
+coef = (min(dx, dy, dz) ** 2 / D / 8.1, 1.0 / dt, 1.0 / dx, 1.0 / dy, 1.0 / dz, D / dx, D / dy, D / dz)
+
+
+def run(gg, nloc, fused, local_only=False):
+    Ht = F.fzeros(*nloc)
+    F.part1.init_local_gaussian((lx / 2, ly / 2, lz / 2), dx, dy, dz, Ht, gg.coords)
+    A, B, C3, R = Ht.clone(memory_format=torch.preserve_format), F.fzeros(*nloc), Ht.clone(memory_format=torch.preserve_format), F.fzeros(*nloc)
+    sq = torch.zeros(iters, dtype=torch.float64, device=Ht.device)
+    if fused:
+        assert gg.can_step2(Ht, A, B, C3, R)
+        for i in range(0, iters, 2):
+            gg.step2(Ht, A, B, C3, R, *coef, dt, sq[i:i + 2], join=False)
+            A, C3 = C3, A
+        gg.join()
+    else:
+        for i in range(iters):
+            gg.step(Ht, A, B, R, *coef, dt, sq[i:i + 1])
+            A, B = B, A
+    F.ctx().synchronize()
+    loc = sq.cpu().numpy().copy()
+    gg.allreduce_(sq)
+    F.ctx().synchronize()
+    return F.tonumpy(A), F.tonumpy(R), sq.cpu().numpy(), loc
+
+
+g1 = F.grid.GlobalGrid(*nglob, dims=(1, 1, 1), transport=None, use_dist=False)
+A1, R1, sq1, _ = run(g1, nglob, True)
+tw = F.grid.ThreadWorld(world)
+results, errors = [None] * world, []
+
+
+def rank_main(r):
+    c = None
+    try:
+        c = F.Context(0, secondary=True)
+        F.bind_context(c)
+        gg = F.grid.GlobalGrid(n, n, n, dims=dims, transport="hosted", dist=tw.rank_view(r))
+        results[r] = (gg.coords, run(gg, (n, n, n), fused))
+        gg.barrier()
+        F.grid.finalize_global_grid()
+    except BaseException as e:
+        import traceback
+        errors.append((r, traceback.format_exc()))
+        try:
+            tw.bar.abort()
+        except Exception:
+            pass
+    finally:
+        F.bind_context(None)
+
+
+ths = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+[t.start() for t in ths]
+[t.join(timeout=300) for t in ths]
+for r, e in errors:
+    print("rank", r, e)
+ok = not errors
+inner = (slice(1, -1),) * 3
+locsum = np.zeros(iters)
+for r, res in enumerate(results):
+    if res is None:
+        continue
+    coords, (A, R, sq, loc) = res
+    off = tuple(ci * (n - 2) for ci in coords)
+    sl = tuple(slice(o, o + n) for o in off)
+    fa, fr = np.array_equal(A[inner], A1[sl][inner]), np.array_equal(R[inner], R1[sl][inner])
+    # what this rank's cells contribute to the single-domain sums (last iteration only: the residual array holds that one)
+    exp_last = float(((R1[sl][inner] * dt) ** 2).sum())
+    print("rank %d coords %s: field %s residual %s; local sumsq last %.12g (from the single-domain residual %.12g); reduced ok %s" %
+          (r, coords, fa, fr, loc[-1], exp_last, np.allclose(sq, sq1, rtol=1e-12, atol=0)))
+    locsum += loc
+    ok = ok and fa and fr and np.allclose(sq, sq1, rtol=1e-12, atol=0)
+print("sum of local sums:", locsum)
+print("single domain    :", sq1)
+print("reduced (rank 0) :", results[0][1][2] if results[0] else None)
+print("dims %s %s n %d: %s" % (dims, "pairs" if fused else "plain", n, "OK" if ok else "MISMATCH"))
+sys.exit(0 if ok else 1)

@@ -45,7 +45,7 @@ launch = _load("launch")          # self_launch, supervise, hb: one process per 
 legs_mod = _load("benchlegs")     # V-cycle / Navier-Stokes blocks, device_state, power probe, norm check (never loads oracle/)
 hb = launch.hb
 HBM_PEAK_GBS, A_EFF_BYTES = legs_mod.HBM_PEAK_GBS, legs_mod.A_EFF_BYTES
-KT_STEP, KT_STEP2, KT_CORE = legs_mod.KT_STEP, legs_mod.KT_STEP2, legs_mod.KT_CORE
+KT_STEP, KT_STEP2, KT_CORE, KT_STEP3 = legs_mod.KT_STEP, legs_mod.KT_STEP2, legs_mod.KT_CORE, legs_mod.KT_STEP3
 timer_read, device_state, norm_check, ns_block, vcycle_block = (legs_mod.timer_read, legs_mod.device_state, legs_mod.norm_check,
                                                                  legs_mod.ns_block, legs_mod.vcycle_block)      # (tools/ and tests/ use these names)
 GOLDEN_NORMS, NORM_RTOL = legs_mod.GOLDEN_NORMS, legs_mod.NORM_RTOL
@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--variant", type=str, default="", help="k=v,... diffusion kernel options (diff3_*)")
     ap.add_argument("--no-neighbour-leg", action="store_true", help="skip the leg that runs the pair as an interior z-slab rank (self-neighbour over RCCL)")
     ap.add_argument("--no-fuse2", action="store_true", help="main leg with one iteration per launch (k_diff3_march)")
+    ap.add_argument("--no-fuse3", action="store_true", help="single rank: main leg with two iterations per launch (k_diff3_march2) instead of three (k_diff3_march3)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / control-plane rehearsal on CPU (gloo): no GPU, no compute, one JSON line")
     ap.add_argument("--choreography", choices=("pairs", "plain"), default="pairs",
@@ -274,6 +275,17 @@ def main():
     except Exception:
         pass
 
+    # three iterations per launch on a single rank (k_diff3_march3: Hτ <-> Hτ2, no third buffer); between ranks fused pairs
+    want_fuse3 = world == 1 and not args.no_fuse3 and not args.no_fuse2
+
+    def fused_launch(arrs, i, with_norm=None):
+        """Launch i of a chain of fused launches on the five arrays (Ht, Hτ, Hτ3, res, Hτ2): triples Hτ <-> Hτ2, or pairs Hτ <-> Hτ3."""
+        tHt, tA, tC, tR, tB = arrs
+        if want_fuse3 and F.part1.can_step_τ3(tHt, tA, tB, tR):
+            F.part1.diffusion_3D_step_τ3(tHt, tA, tB, tR, *coef) if (i & 1) == 0 else F.part1.diffusion_3D_step_τ3(tHt, tB, tA, tR, *coef)
+        else:
+            F.part1.diffusion_3D_step_τ2(tHt, tA, tB, tC, tR, *coef) if (i & 1) == 0 else F.part1.diffusion_3D_step_τ2(tHt, tC, tB, tA, tR, *coef)
+
     def pair_ms_of(arrs, pairs_warm, pairs_timed):
         """Event time [ms] of one fused launch on the given five arrays (zeros: the arithmetic does not depend on the values)."""
         tHt, tA, tC, tR, tB = arrs
@@ -283,7 +295,7 @@ def main():
         for i in range(pairs_warm + pairs_timed):
             if i == pairs_warm:
                 e0.record()
-            F.part1.diffusion_3D_step_τ2(tHt, tA, tB, tC, tR, *coef) if (i & 1) == 0 else F.part1.diffusion_3D_step_τ2(tHt, tC, tB, tA, tR, *coef)
+            fused_launch(arrs, i)
         e1.record()
         e1.synchronize()
         return e0.elapsed_time(e1) / pairs_timed
@@ -318,8 +330,8 @@ def main():
                 if i == 1:
                     e0.record()
                 for _ in range(3 if i else 2):
-                    F.part1.diffusion_3D_step_τ2(tHt, tA, tB, tC, tR, *coef)
-                    F.part1.diffusion_3D_step_τ2(tHt, tC, tB, tA, tR, *coef)
+                    fused_launch(arrs, 0)
+                    fused_launch(arrs, 1)
             e1.record()
             e1.synchronize()
             return e0.elapsed_time(e1) / 12.0
@@ -350,9 +362,11 @@ def main():
                 frac = A_EFF_BYTES * (nloc[0] - 2) * (nloc[1] - 2) * (nloc[2] - 2) / (pair * 1e-3) / 1e9 / HBM_PEAK_GBS
                 placement.setdefault("accept_trial_frac_first_pool", frac)
                 placement["accept_trial_frac"] = frac
+                if want_fuse3:       # (three iterations per launch: 1.25-1.32 x the one-iteration kernel on a mixed pool)
+                    return pair <= 1.40 * single
                 return frac >= 0.69 and pair <= 1.12 * single
 
-            Ht, Hτ, Hτ3, res, Hτ2 = F.placement.alloc_fields(5, *nloc, report=placement, pairs=[(0, 1), (0, 2), (2, 3), (1, 3), (1, 2)],
+            Ht, Hτ, Hτ3, res, Hτ2 = F.placement.alloc_fields(5, *nloc, report=placement, pairs=[(0, 1), (0, 4), (4, 3), (1, 3), (1, 4)] if want_fuse3 else [(0, 1), (0, 2), (2, 3), (1, 3), (1, 2)],
                                                           trial=trial, first=plain, accept=None if shared else accept)   # (ranks that share one card do not churn its memory under each other)
             del plain
         except Exception as e:       # the search is an optimisation: plainly allocated arrays give the same results
@@ -388,11 +402,20 @@ def main():
             gg.step(Ht, Hτ2, Hτ, res, *coef, dt, sq1)
             state["cur"], state["parity"] = Hτ, 0
 
+    can_fuse3 = want_fuse3 and not as_one and F.part1.can_step_τ3(Ht, Hτ, Hτ2, res)
+
     def run(nsteps, base, fuse2):
+        """fuse2: False / 0 = one iteration per launch, True / 2 = fused pairs, 3 = fused triples (remainders as a pair or single steps)"""
         i = 0
         while i < nsteps:
             prev = i
-            if fuse2 and state["parity"] == 0 and i + 1 < nsteps:
+            if fuse2 == 3 and i + 2 < nsteps:
+                X = state["cur"]
+                Y = Hτ if X is Hτ2 else Hτ2
+                F.part1.diffusion_3D_step_τ3(Ht, X, Y, res, *coef, dt, sq[base + i:base + i + 3])
+                state["cur"], state["parity"] = Y, state["parity"] ^ 1
+                i += 3
+            elif fuse2 and state["parity"] == 0 and i + 1 < nsteps:
                 out = Hτ3 if state["cur"] is Hτ else Hτ
                 gg.step2(Ht, state["cur"], Hτ2, out, res, *coef, dt, sq[base + i:base + i + 2], join=False)
                 state["cur"] = out
@@ -441,6 +464,8 @@ def main():
         # region (how an odd W used to be evened out) draw 120 W less than the fused kernel, and the ten launches behind such an
         # interlude ran 3-4 % slower than the steady state before and after (profiles/r4_bench_phases.txt, EXPERIMENTS 12.4)
         extra = (W & 1) if (fuse2 and state["parity"] == 0) else 0
+        if fuse2 == 3:           # whole triples, and an even number of them: the timed region starts from an even buffer
+            extra = (-W) % 6
         run(W + extra, 0, fuse2)
         if use_dist:
             torch.cuda.synchronize()
@@ -455,7 +480,7 @@ def main():
         run(K, W + extra, fuse2)
         barrier()
         elapsed = time.perf_counter() - t0
-        kt = {kind: timer_read(ctx, kind) for kind in (KT_STEP, KT_STEP2, KT_CORE)}
+        kt = {kind: timer_read(ctx, kind) for kind in (KT_STEP, KT_STEP2, KT_CORE, KT_STEP3)}
         ctx.call("fpr_kernel_timer", 0)
         hb("timed")
         if use_dist:
@@ -471,7 +496,7 @@ def main():
 
     def kernel_roofline(kind, kt, traffic_entry):
         ms_tot, cnt = kt[kind]
-        ipl = 2 if kind == KT_STEP2 else 1
+        ipl = 3 if kind == KT_STEP3 else (2 if kind == KT_STEP2 else 1)
         nbytes = min_bytes
         if world > 1 and kind == KT_STEP2 and kt[KT_CORE][1]:
             # between ranks a fused pair is ONE core launch on the core stream (the dominant kernel, priced here: 32 B per
@@ -485,7 +510,8 @@ def main():
         kms = ms_tot / cnt if cnt else 0.0
         ach = nbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "kernel": "k_diff3_march2 (two iterations per launch)" if kind == KT_STEP2 else "k_diff3_march (one iteration per launch)",
+             "kernel": {KT_STEP3: "k_diff3_march3 (three iterations per launch)", KT_STEP2: "k_diff3_march2 (two iterations per launch)"}.get(
+                 kind, "k_diff3_march (one iteration per launch)"),
              "achieved": ach, "frac": ach / HBM_PEAK_GBS, "kernel_ms": kms, "launches": cnt,
              "bytes_per_launch": nbytes, "iterations_per_launch": ipl,
              "accounting": "32 B per interior cell per LAUNCH: read Htau, read Ht, write the new field, write dHdtau (the "
@@ -512,26 +538,26 @@ def main():
         WRITE_SIZE, collected in separate passes -- tools/pmc_fused2.sh); recorded under profiles/, not measured live."""
         try:
             for tj in json.load(open(os.path.join(ROOT, "profiles", "diffusion_traffic.json")))["entries"]:
-                if tj.get("n") == n and world == 1 and not as_one and tj.get("fuse2") == bool(fused):
+                if tj.get("n") == n and world == 1 and not as_one and tj.get("depth", 2 if tj.get("fuse2") else 1) == (int(fused) if fused else 1):
                     return tj
         except Exception:
             pass
         return None
 
     main_fused = can_fuse2 and not args.no_fuse2 and not (world > 1 and choreography == "plain")
+    main_mode = 3 if (main_fused and can_fuse3) else (2 if main_fused else 0)
     dev_before = device_state(device_index) if rank == 0 else None
-    elapsed, kt, extra = timed_leg(main_fused, args.prewarm_ms)
+    elapsed, kt, extra = timed_leg(main_mode, args.prewarm_ms)
     last_err = errs[-1] if errs else None
     last_sumsq = sums[-1] if sums else None
     iters_main = iters_done[0]      # pseudo-iterations behind last_sumsq (pre-warm + warm-up + timed)
     value = A_EFF_BYTES * cells * world * K / elapsed / 1e9
-    main_kind = KT_STEP2 if main_fused else KT_STEP
-    roofline = kernel_roofline(main_kind, kt, traffic_for(main_fused))
-    other_kind = KT_STEP if main_fused else KT_STEP2
-    if kt[other_kind][1]:
-        roofline["other_launches_in_timed_region"] = {"kind": other_kind, "launches": kt[other_kind][1],
-                                                      "ms_total": kt[other_kind][0]}
-    legs = {"fused_pairs" if main_fused else "single_steps":
+    main_kind = {3: KT_STEP3, 2: KT_STEP2}.get(main_mode, KT_STEP)
+    roofline = kernel_roofline(main_kind, kt, traffic_for(main_mode))
+    for other_kind in (KT_STEP, KT_STEP2, KT_STEP3):
+        if other_kind != main_kind and kt[other_kind][1]:
+            roofline.setdefault("other_launches_in_timed_region", []).append({"kind": other_kind, "launches": kt[other_kind][1], "ms_total": kt[other_kind][0]})
+    legs = {{3: "fused_triples", 2: "fused_pairs"}.get(main_mode, "single_steps"):
             {"ms_per_step": elapsed / K * 1e3, "value_GBs": value, "kernel_ms": roofline["kernel_ms"],
              "launches": roofline["launches"], "warmup_extra_steps": extra}}
     out = {
@@ -547,7 +573,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "3D diffusion %d^3 per GPU, fused 7-pt update + norm, %d iteration%s per launch" % (n, 2 if main_fused else 1, "s" if main_fused else ""),
+        "config": {"workload": "3D diffusion %d^3 per GPU, fused 7-pt update + norm, %d iteration%s per launch" % (n, max(main_mode, 1), "s" if main_fused else ""),
                    "local_grid": list(nloc), "process_grid": list(dims), "global_grid": [gg.nx_g(), gg.ny_g(), gg.nz_g()],
                    "bytes_per_cell_per_iteration": A_EFF_BYTES,
                    "norm": "fused every iteration; all-reduce + host check every %d" % ce,
@@ -589,35 +615,15 @@ def main():
         out["roofline_single"] = r2
         legs["single_steps"] = {"ms_per_step": e2 / K * 1e3, "value_GBs": A_EFF_BYTES * cells * K / e2 / 1e9,
                                 "kernel_ms": r2["kernel_ms"], "launches": r2["launches"]}
-        # third leg: fused pairs WITHOUT storing dHdtau -- what the native solver loop (fpr_diffusion3d_solve) runs: it needs
-        # the residual's norm every iteration and the residual array only when it returns.  24 B per cell and launch;
-        # not part of `value` (the step of the metric writes both outputs of the reference's kernel).
-        ctx.call("fpr_kernel_timer", 1)
+        if main_mode == 3:
+            # the pair kernel on the same arrays (what a rank WITH neighbours runs per launch; the projections below are relative to it)
+            state["cur"], state["parity"] = Hτ, 0
+            Hτ.copy_(Ht); Hτ3.copy_(Ht)
+            e2p, kt2p, _ = timed_leg(2, 50.0)
+            out["roofline_pairs"] = kernel_roofline(KT_STEP2, kt2p, traffic_for(2))
+            legs["fused_pairs"] = {"ms_per_step": e2p / K * 1e3, "value_GBs": A_EFF_BYTES * cells * K / e2p / 1e9,
+                                   "kernel_ms": out["roofline_pairs"]["kernel_ms"], "launches": out["roofline_pairs"]["launches"]}
         import ctypes as C
-        state["cur"], state["parity"] = Hτ, 0
-        fp = F._lib.fptr
-        def pair_nores(nsteps):
-            for i in range(nsteps // 2):
-                outb = Hτ3 if state["cur"] is Hτ else Hτ
-                ctx.call("fpr_diffusion3d_step2", fp(Ht, 3), fp(state["cur"], 3), fp(Hτ2, 3), fp(outb, 3), None, *nloc, *coef, dt,
-                         sq[2 * i:2 * i + 2].data_ptr())
-                state["cur"] = outb
-        pair_nores(W + (W & 1))
-        barrier()
-        ctx.call("fpr_kernel_timer", 1)
-        t0 = time.perf_counter()
-        pair_nores(K)
-        barrier()
-        e3 = time.perf_counter() - t0
-        ms3, cnt3 = timer_read(ctx, KT_STEP2)
-        ctx.call("fpr_kernel_timer", 0)
-        k3 = ms3 / max(cnt3, 1)
-        nb = 24.0 * cells
-        legs["fused_pairs_no_residual_store"] = {
-            "ms_per_step": e3 / max(2 * (K // 2), 1) * 1e3, "value_GBs": A_EFF_BYTES * cells * 2 * (K // 2) / e3 / 1e9,
-            "kernel_ms": k3, "launches": cnt3, "bytes_per_launch": nb,
-            "achieved": nb / (k3 * 1e-3) / 1e9 if k3 > 0 else 0.0, "frac": nb / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS if k3 > 0 else 0.0,
-            "note": "read Htau, read Ht, write the new field; both norms reduced; dHdtau not materialised (solver loop mode)"}
         # fourth / fifth leg: what a rank WITH neighbours does per pair, on this one card -- a rank that is its own periodic
         # neighbour over the library's RCCL transport (the planes really travel through ncclSend / ncclRecv on the comm stream
         # of the split device).  Links excluded; they are hidden by construction (the chain with both exchanges ends inside
@@ -687,37 +693,9 @@ def main():
             def reset_state():
                 state["cur"], state["parity"] = Hτ, 0
 
-            out["power_probe"] = legs_mod.power_probe(torch, device_index, lambda k: run(k, 0, True), lambda k: run(k, 0, False), reset_state)
+            out["power_probe"] = legs_mod.power_probe(torch, device_index, lambda k: run(k, 0, main_mode), lambda k: run(k, 0, False), reset_state)
         except Exception as e:
             out["power_probe"] = {"error": repr(e)}
-        # Leg `fused_pairs_fma` (opt-in option fp_contract = 1: "(or 1 * fma)", part1_kernel_programming.jl:55,94; SURVEY 7's speed
-        # variant): the same pairs with the contracted point update -- 18 instead of 25 FP64 instructions per cell and iteration,
-        # results within 1e-12 of the exact path (tests/test_gpu_part1.py), NOT bit-identical to the reference, so never part of
-        # `value`.  Event time of K timed pairs, then a second under the power sampler.
-        try:
-            ctx.set_option("fp_contract", 1)
-            reset_state()
-            run(W + (W & 1) + 8, 0, True)
-            barrier()
-            ctx.call("fpr_kernel_timer", 1)
-            t0 = time.perf_counter()
-            run(K + (K & 1), 0, True)
-            barrier()
-            e5 = time.perf_counter() - t0
-            ms5, cnt5 = timer_read(ctx, KT_STEP2)
-            ctx.call("fpr_kernel_timer", 0)
-            k5 = ms5 / max(cnt5, 1)
-            pr = legs_mod.probe_under_load(torch, device_index, lambda k: run(k, 0, True))
-            legs["fused_pairs_fma"] = {
-                "ms_per_step": e5 / (K + (K & 1)) * 1e3, "value_GBs": A_EFF_BYTES * cells * (K + (K & 1)) / e5 / 1e9, "kernel_ms": k5, "launches": cnt5,
-                "achieved": min_bytes / (k5 * 1e-3) / 1e9 if k5 > 0 else 0.0, "frac": min_bytes / (k5 * 1e-3) / 1e9 / HBM_PEAK_GBS if k5 > 0 else 0.0,
-                "steady_ms_per_iteration": pr["ms_per_iteration"], "steady_sclk_MHz": pr["sclk_MHz_avg"], "steady_power_W": pr["power_W_avg"],
-                "note": "option fp_contract = 1: explicit fma sequence in the point update (18 instead of 25 FP64 instructions per cell and "
-                        "iteration); within 1e-12 of the exact path, bit for bit the oracle's fma restatement; opt-in, not part of `value`"}
-        except Exception as e:
-            legs["fused_pairs_fma"] = {"error": repr(e)}
-        finally:
-            ctx.set_option("fp_contract", 0)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             try:

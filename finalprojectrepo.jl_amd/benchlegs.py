@@ -12,7 +12,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 A_EFF_BYTES = 32.0     # read Htau + read Ht + write Htau2 + write dHdtau, per interior cell
-KT_STEP, KT_STEP2, KT_MG_PRE, KT_MG_POST, KT_MG_SEAM, KT_MG_CG, KT_MG_PATCH, KT_CORE = 0, 1, 2, 3, 4, 5, 6, 7   # include/fpr.h FPR_KT_*
+KT_STEP, KT_STEP2, KT_MG_PRE, KT_MG_POST, KT_MG_SEAM, KT_MG_CG, KT_MG_PATCH, KT_CORE, KT_STEP3 = 0, 1, 2, 3, 4, 5, 6, 7, 8   # include/fpr.h FPR_KT_*
 
 
 def _read_json(path):
@@ -394,7 +394,8 @@ def compact_record(out):
         "unplaced_kernel_ms": unplaced_ms,
         "unplaced_frac": (bpl / (unplaced_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (unplaced_ms and bpl) else None,
         "single_kernel_ms": _g(out, "roofline_single", "kernel_ms"), "single_frac": _g(out, "roofline_single", "frac"),
-        "steady_ms_per_iteration": _g(out, "power_probe", "fused_pairs", "ms_per_iteration"),
+        "pair_kernel_ms": _g(out, "roofline_pairs", "kernel_ms"), "pair_frac": _g(out, "roofline_pairs", "frac"),
+        "steady_ms_per_iteration": _g(out, "power_probe", "fused_pairs", "ms_per_iteration"),      # (key kept: the main fused kernel, whatever its depth)
     }
     if cb:
         rec["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),

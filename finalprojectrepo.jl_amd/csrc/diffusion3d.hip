@@ -9,6 +9,7 @@
 #include "diffusion3d_launch.hpp"
 // two pseudo-iterations per pass (temporal blocking): main kernel and the kernel for boxes that are narrow in x
 #include "diffusion3d_fused2.hpp"
+#include "diffusion3d_fused3.hpp"
 #include "diffusion3d_slab2.hpp"
 // the shell next to an x-neighbour in compact strips
 #include "diffusion3d_xstrip.hpp"
@@ -250,6 +251,73 @@ extern "C" int fpr_diffusion3d_step2_box(fpr_ctx* ctx, const double* Ht, const d
                       scale, sumsq2_dev, true, stream_sel);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Three pseudo-iterations in one pass (diffusion3d_fused3.hpp): step(X -> [Y']); step([Y'] -> [X']); step([X'] -> Y), the two fields
+// in between never materialised.  X and Y are the reference's two ping-pong buffers in either order: an odd depth needs no third buffer.
+// ------------------------------------------------------------------------------------------------
+static bool diff3_fuse3_ok(fpr_ctx* ctx, const double* Ht, const double* X, const double* Y, const double* dH, int nx, int ny, int nz)
+{
+    return fpr_opt(ctx, "diff3_fuse3", 1) != 0 && diff3_can_fuse3(Ht, X, Y, Y, dH, nx, ny, nz);
+}
+
+// sumsq3_dev: three doubles (first, second, third iteration); nullptr = no norm.  nparts_only: leave the three lists of per-workgroup
+// partials (thirds of the stream's scratch) to the caller.  Whole interior, compute stream.
+static int diff3_run3(fpr_ctx* ctx, const double* Ht, const double* X, double* Y, double* dH, int nx, int ny, int nz, double dtau,
+                      double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy, double D_dz, double scale,
+                      double* sumsq3_dev, const int* skip = nullptr, int* nparts_only = nullptr)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, Ht && X && Y, "null field pointer");   // dH may be null: residual not stored
+    FPR_REQUIRE(ctx, X != Y && Ht != Y && dH != Y && dH != X, "Htau, Hout and dHdtau must be distinct buffers");
+    FPR_REQUIRE(ctx, diff3_fuse3_ok(ctx, Ht, X, Y, dH, nx, ny, nz), "problem not supported by the fused three-step kernel");
+    Diff3Args3 a;
+    memset(&a, 0, sizeof a);
+    a.skip = skip;
+    a.lane_off = 1;
+    a.Ht = Ht; a.X = X; a.Bnd = Y; a.Y = Y; a.dH = dH;
+    a.nx = nx; a.ny = ny; a.nz = nz;
+    a.lo[0] = a.lo[1] = a.lo[2] = 1;
+    a.hi[0] = nx - 1; a.hi[1] = ny - 1; a.hi[2] = nz - 1;
+    a.dtau = dtau; a._dt = _dt; a._dx = _dx; a._dy = _dy; a._dz = _dz;
+    a.D_dx = D_dx; a.D_dy = D_dy; a.D_dz = D_dz;
+    a.scale = scale;
+    const int pcap = FPR_MAX_PARTIALS / 3;
+    a.partials1 = ctx->partials; a.partials2 = a.partials1 + pcap; a.partials3 = a.partials2 + pcap;
+    const bool norm = sumsq3_dev != nullptr || nparts_only != nullptr;
+    if (ctx->ncu <= 0) {
+        int v = 0;
+        ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
+    }
+    int nparts = 0;
+    const bool timed = fpr_ktimer_begin(ctx, FPR_KT_DIFF3_STEP3, ctx->stream[0]);
+    const hipError_t e = diff3_launch3(a, norm, 0, 0, ctx->stream[0], pcap, &nparts, ctx->ncu);
+    fpr_ktimer_end(ctx, timed, ctx->stream[0]);
+    if (e != hipSuccess) return fpr_fail(ctx, FPR_ERR_HIP, "fused three-step diffusion3d launch: %s", hipGetErrorString(e));
+    if (nparts_only) {
+        *nparts_only = nparts;
+        return FPR_OK;
+    }
+    if (norm) return fprx_finish_sum3(ctx, a.partials1, a.partials2, a.partials3, nparts, sumsq3_dev, 0);
+    return FPR_OK;
+}
+
+extern "C" int fpr_diffusion3d_can_step3(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hout, const double* dHdtau,
+                                         int nx, int ny, int nz)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    return (Ht && Htau && Hout && Htau != Hout && Ht != Hout && dHdtau != Hout && dHdtau != Htau &&   // dHdtau may be NULL
+            diff3_fuse3_ok(ctx, Ht, Htau, Hout, dHdtau, nx, ny, nz))
+               ? 1
+               : 0;
+}
+
+extern "C" int fpr_diffusion3d_step3(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Hout, double* dHdtau, int nx, int ny,
+                                     int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy,
+                                     double D_dz, double scale, double* sumsq3_dev)
+{
+    return diff3_run3(ctx, Ht, Htau, Hout, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale, sumsq3_dev);
+}
+
 // ---- the solver's loop with its exit test on the device (pairs enqueued ahead of the host) ---------------------------
 // part1_kernel_programming.jl:179-192 is "iterate, read the norm on the host, compare, iterate".  At 128^3 a fused pair of
 // iterations takes ~15 us on the device and the host round trip behind it ~40 us.  As for MGsolve: the norms of
@@ -263,30 +331,37 @@ __global__ void k_diff3_ctl_init(FprCycleCtl* ctl, double tol, double sqrtN)
     ctl->tolf = tol; ctl->rms = 0.0; ctl->frms = sqrtN;
 }
 
-// finishes both norms of a pair exactly as k_finish2 does (same order of summation) and takes the loop's decision
+// finishes the norms of a fused launch (two or three iterations) exactly as k_finish2 / k_finish3 do (same order of summation) and takes the
+// loop's decision: the first iteration j whose norm is wanted and ends the loop stops it -- coarse_iters = j if later iterations of the launch
+// exist (the host then redoes j iterations from the launch's intact input), 0 if it is the launch's last
 __global__ __launch_bounds__(256) void k_diff3_check(FprCycleCtl* ctl, const double* __restrict__ p1, const double* __restrict__ p2,
-                                                      int nparts, int n1, int n2, int it_base, int seq, FprCycleCtl* rec_host)
+                                                      const double* __restrict__ p3, int depth, int nparts, int n1, int n2, int n3,
+                                                      int it_base, int seq, FprCycleCtl* rec_host)
 {
     __shared__ double red[16];
     if (ctl->stop) return;
-    const double s1 = fpr_sum_partials_256(p1, nparts, red);
+    double sj[3];
+    sj[0] = fpr_sum_partials_256(p1, nparts, red);
     __syncthreads();
-    const double s2 = fpr_sum_partials_256(p2, nparts, red);
+    sj[1] = fpr_sum_partials_256(p2, nparts, red);
+    if (depth > 2) {
+        __syncthreads();
+        sj[2] = fpr_sum_partials_256(p3, nparts, red);
+    }
     if (threadIdx.x != 0) return;
     FprCycleCtl c = *ctl;
     c.coarse_iters = 0;
-    bool done = false;
-    if (n1) {
-        const double e1 = sqrt(s1) / c.frms;   // :191 after the first iteration of the pair
-        c.rms = e1;
-        if (!(e1 > c.tolf)) { c.stop = 1; c.coarse_iters = 1; c.ncycles = it_base + 1; done = true; }
-    }
-    if (!done) {
-        c.ncycles = it_base + 2;
-        if (n2) {
-            const double e2 = sqrt(s2) / c.frms;
-            c.rms = e2;
-            if (!(e2 > c.tolf)) c.stop = 1;
+    c.ncycles = it_base + depth;
+    const int want[3] = {n1, n2, n3};
+    for (int j = 0; j < depth; ++j) {
+        if (!want[j]) continue;
+        const double e = sqrt(sj[j]) / c.frms;   // :191 after iteration j + 1 of the launch
+        c.rms = e;
+        if (!(e > c.tolf)) {
+            c.stop = 1;
+            c.coarse_iters = (j + 1 < depth) ? j + 1 : 0;
+            c.ncycles = it_base + j + 1;
+            break;
         }
     }
     *ctl = c;
@@ -327,6 +402,9 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
         int rc = fpr_copy(ctx, E1, Htau, N);   // boundary of the even buffers (interior is overwritten)
         if (rc) return rc;
     }
+    // Three iterations per launch (k_diff3_march3) need no third buffer: the field goes from the buffer it is in to the reference's other
+    // one -- Htau <-> Htau2 as in the reference, three iterations at a time; taken whenever three iterations are left, whatever the parity
+    const bool fuse3 = diff3_fuse3_ok(ctx, Ht, Htau, Htau2, dHdtau, nx, ny, nz) && (!E1 || diff3_fuse3_ok(ctx, Ht, E1, Htau2, dHdtau, nx, ny, nz));
     double* cur = Htau;   // current field
     int parity = 0;       // 0: cur is an even buffer (Htau or E1), 1: cur == Htau2
     long swaps = 0;
@@ -345,8 +423,23 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
     const bool lazy_res = fpr_opt(ctx, "diff3_lazy_residual", 1) != 0;
     int ahead = (int)fpr_opt(ctx, "diff3_ahead", 2);   // fused pairs enqueued ahead of the host's view of the norm (0: wait for every norm)
     if (ahead > FPR_CYC_SLOTS - 2) ahead = FPR_CYC_SLOTS - 2;
-    const double* stale_in = nullptr;   // input of the last fused pair if dHdtau has not been written since
+    const double* stale_in = nullptr;   // input of the last fused launch if dHdtau has not been written since
     double* stale_out = nullptr;
+    int stale_depth = 2;
+    // j single iterations from `in` (1 <= j <= 2): what the reference has done when it stops inside a fused launch
+    auto redo_singles = [&](const double* in, int par, int j, double** cur_out) -> int {
+        const double* src = in;
+        double* out = nullptr;
+        for (int q = 0; q < j; ++q) {
+            out = par ? Htau : Htau2;
+            if (int rc = diff3_run(ctx, Ht, src, out, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, nullptr, nullptr, false, 0.0,
+                                   nullptr, false, 0))
+                return rc;
+            src = out; par ^= 1;
+        }
+        *cur_out = out;
+        return FPR_OK;
+    };
     for (int t = 0; t < nt; ++t) {
         long it = 0;
         double err = 2 * tol;  // :178
@@ -354,6 +447,93 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
         auto want_norm = [&](long j) { return fixed_iters > 0 ? (j == fixed_iters) : (j % check_every == 0); };
         while (more()) {
             const long left = fixed_iters > 0 ? fixed_iters - it : iter_max - it;
+            if (fuse3 && left >= 3 && fixed_iters <= 0 && ahead > 0) {
+                // ---- a run of fused TRIPLES enqueued `ahead` deep before the host looks at the norm of the oldest one ----
+                struct Trip { const double* in; double* out; long it_base; int slot, seq, par; bool rec; } ring[FPR_CYC_SLOTS];
+                hipStream_t s = ctx->stream[0];
+                k_diff3_ctl_init<<<1, 1, 0, s>>>(ctx->cyc, tol, sqrtN);
+                FPR_CHECK_LAUNCH(ctx);
+                long it_enq = it;
+                double* cur_enq = cur;
+                int par_enq = parity;
+                int enq = 0, seen = 0, nrec = 0;
+                const int pcap3 = FPR_MAX_PARTIALS / 3;
+                while (true) {
+                    while (enq - seen < 1 + ahead && iter_max - it_enq >= 3) {
+                        double* out = par_enq ? Htau : Htau2;
+                        const bool n1 = want_norm(it_enq + 1), n2 = want_norm(it_enq + 2), n3 = want_norm(it_enq + 3);
+                        int nparts = 0;
+                        int rc = diff3_run3(ctx, Ht, cur_enq, out, lazy_res ? nullptr : dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy,
+                                            D_dz, dt, nullptr, &ctx->cyc->stop, (n1 || n2 || n3) ? &nparts : nullptr);
+                        if (rc) return rc;
+                        Trip& p = ring[enq % FPR_CYC_SLOTS];
+                        p.in = cur_enq; p.out = out; p.it_base = it_enq; p.par = par_enq; p.rec = n1 || n2 || n3; p.slot = 0; p.seq = 0;
+                        if (p.rec) {
+                            p.slot = nrec % FPR_CYC_SLOTS;
+                            p.seq = ++nrec;
+                            __atomic_store_n(&ctx->cyc_h[p.slot].seq, 0, __ATOMIC_RELEASE);
+                            k_diff3_check<<<1, 256, 0, s>>>(ctx->cyc, ctx->partials, ctx->partials + pcap3, ctx->partials + 2 * pcap3, 3, nparts,
+                                                            n1 ? 1 : 0, n2 ? 1 : 0, n3 ? 1 : 0, (int)it_enq, p.seq, &ctx->cyc_h[p.slot]);
+                            FPR_CHECK_LAUNCH(ctx);
+                        }
+                        cur_enq = out; par_enq ^= 1; it_enq += 3; ++enq;
+                    }
+                    if (seen == enq) break;   // iter_max is less than three iterations away: the paths below finish
+                    const Trip& p = ring[seen % FPR_CYC_SLOTS];
+                    ++seen;
+                    bool stop_now = false;
+                    if (p.rec) {
+                        FprCycleCtl rec;
+                        if (int rc = fprx_cycle_wait(ctx, p.slot, p.seq, &rec)) return rc;
+                        err = rec.rms;
+                        if (rec.stop && rec.coarse_iters) {
+                            // the reference stops after iteration j < 3 of this launch: redo those j iterations one by one from the launch's
+                            // input (intact: everything enqueued behind it has returned at once)
+                            const int j = (int)rec.coarse_iters;
+                            if (int rc = redo_singles(p.in, p.par, j, &cur)) return rc;
+                            stale_in = nullptr;
+                            parity = p.par ^ (j & 1); swaps += j; it = p.it_base + j;
+                            break;
+                        }
+                        stop_now = rec.stop != 0;
+                    }
+                    stale_in = lazy_res ? p.in : nullptr;
+                    stale_out = p.out; stale_depth = 3;
+                    cur = p.out; parity = p.par ^ 1; swaps += 3; it = p.it_base + 3;
+                    if (stop_now) break;
+                }
+                if (seen > 0) continue;
+            }
+            if (fuse3 && left >= 3) {
+                // one triple, the host waits for its norms (fixed iteration counts, diff3_ahead = 0)
+                double* out = parity ? Htau : Htau2;
+                const bool n1 = want_norm(it + 1), n2 = want_norm(it + 2), n3 = want_norm(it + 3);
+                const bool any = n1 || n2 || n3;
+                int rc = diff3_run3(ctx, Ht, cur, out, lazy_res ? nullptr : dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, dt,
+                                    any ? (double*)pinned : nullptr);
+                if (rc) return rc;
+                if (any) FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
+                int jstop = 0;
+                if (fixed_iters <= 0) {
+                    if (n1 && !(sqrt(pinned[0]) / sqrtN > tol)) jstop = 1;
+                    else if (n2 && !(sqrt(pinned[1]) / sqrtN > tol)) jstop = 2;
+                }
+                if (jstop) {
+                    err = sqrt(pinned[jstop - 1]) / sqrtN;
+                    const int par0 = parity;
+                    if (int rc2 = redo_singles(cur, par0, jstop, &cur)) return rc2;
+                    stale_in = nullptr;
+                    parity = par0 ^ (jstop & 1); swaps += jstop; it += jstop;
+                    continue;
+                }
+                stale_in = lazy_res ? cur : nullptr;
+                stale_out = out; stale_depth = 3;
+                cur = out; parity ^= 1; swaps += 3; it += 3;
+                if (n3) err = sqrt(pinned[2]) / sqrtN;
+                else if (n2) err = sqrt(pinned[1]) / sqrtN;
+                else if (n1) err = sqrt(pinned[0]) / sqrtN;
+                continue;
+            }
             if (fuse && parity == 0 && left >= 2 && fixed_iters <= 0 && ahead > 0) {
                 // ---- a run of fused pairs enqueued `ahead` deep before the host looks at the norm of the oldest one ----
                 struct Pair { const double* in; double* out; long it_base; int slot, seq; bool rec; } ring[FPR_CYC_SLOTS];
@@ -379,8 +559,8 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
                             p.slot = nrec % FPR_CYC_SLOTS;
                             p.seq = ++nrec;
                             __atomic_store_n(&ctx->cyc_h[p.slot].seq, 0, __ATOMIC_RELEASE);
-                            k_diff3_check<<<1, 256, 0, s>>>(ctx->cyc, ctx->partials, ctx->partials + FPR_MAX_PARTIALS / 2, nparts,
-                                                            n1 ? 1 : 0, n2 ? 1 : 0, (int)it_enq, p.seq, &ctx->cyc_h[p.slot]);
+                            k_diff3_check<<<1, 256, 0, s>>>(ctx->cyc, ctx->partials, ctx->partials + FPR_MAX_PARTIALS / 2, nullptr, 2, nparts,
+                                                            n1 ? 1 : 0, n2 ? 1 : 0, 0, (int)it_enq, p.seq, &ctx->cyc_h[p.slot]);
                             FPR_CHECK_LAUNCH(ctx);
                         }
                         cur_enq = out; it_enq += 2; ++enq;
@@ -404,12 +584,12 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
                             break;
                         }
                         stale_in = lazy_res ? p.in : nullptr;
-                        stale_out = p.out;
+                        stale_out = p.out; stale_depth = 2;
                         cur = p.out; swaps += 2; it = p.it_base + 2;
                         if (rec.stop) { stopped = true; break; }
                     } else {
                         stale_in = lazy_res ? p.in : nullptr;
-                        stale_out = p.out;
+                        stale_out = p.out; stale_depth = 2;
                         cur = p.out; swaps += 2; it = p.it_base + 2;
                     }
                 }
@@ -423,7 +603,7 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
                                     D_dx, D_dy, D_dz, nullptr, nullptr, dt, (n1 || n2) ? (double*)pinned : nullptr, false, 0);
                 if (rc) return rc;
                 stale_in = lazy_res ? cur : nullptr;
-                stale_out = out;
+                stale_out = out; stale_depth = 2;
                 if (n1 || n2) FPR_HIP(ctx, hipStreamSynchronize(ctx->stream[0]));
                 if (n1 && fixed_iters <= 0) {
                     const double e1 = sqrt(pinned[0]) / sqrtN;  // :191 after the first of the two iterations
@@ -460,9 +640,11 @@ extern "C" int fpr_diffusion3d_solve(fpr_ctx* ctx, double* Ht, double* Htau, dou
         }
         if (iters_host) iters_host[t] = it;
         if (err_host) err_host[t] = err;
-        if (t == nt - 1 && stale_in) {   // the call ends on a pair that did not store its residual: replay it with the store
-            int rc = diff3_run2(ctx, Ht, stale_in, Htau2, stale_out, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy,
-                                D_dz, nullptr, nullptr, dt, nullptr, false, 0);
+        if (t == nt - 1 && stale_in) {   // the call ends on a fused launch that did not store its residual: replay it with the store
+            int rc = stale_depth == 3
+                         ? diff3_run3(ctx, Ht, stale_in, stale_out, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, dt, nullptr)
+                         : diff3_run2(ctx, Ht, stale_in, Htau2, stale_out, dHdtau, nx, ny, nz, dtau, _dt, _dx, _dy, _dz, D_dx, D_dy,
+                                      D_dz, nullptr, nullptr, dt, nullptr, false, 0);
             if (rc) return rc;
             stale_in = nullptr;
         }

@@ -46,7 +46,7 @@
 // and this one) waits in LDS instead of registers: 3 ds_write_b128 + 3 ds_read_b128 per wave and iteration buy the twelve registers
 // the budget is short of
 #ifndef DIFF3_M3_PARK
-#define DIFF3_M3_PARK 1
+#define DIFF3_M3_PARK 0
 #endif
 // 1: the three running sums of squares (one per level and lane) live in LDS -- one ds_add_f64 per level and iteration -- instead of six
 // registers

@@ -514,3 +514,4 @@ int fprx_halo_exchange3d_comm_x(fpr_ctx* ctx, double* A, int nx, int ny, int nz,
                                 double* const xrecv[2]);
 int fprx_finish_sum2(fpr_ctx* ctx, const double* p0, const double* p1, int nparts, double* out2_dev, bool accumulate,
                      int stream_sel);
+int fprx_finish_sum3(fpr_ctx* ctx, const double* p0, const double* p1, const double* p2, int nparts, double* out3_dev, int stream_sel);

@@ -93,6 +93,24 @@ def diffusion_3D_step_τ2(Ht, Hτ, Hmid, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D
                 sumsq2_dev.data_ptr() if sumsq2_dev is not None else None)
 
 
+def can_step_τ3(Ht, Hτ, Hout, dHdτ):
+    """True if the fused three-iteration kernel serves these arrays (else pairs or single steps)."""
+    nx, ny, nz = Ht.shape
+    c = _ctx()
+    return c.L.fpr_diffusion3d_can_step3(c.h, fptr(Ht, 3), fptr(Hτ, 3), fptr(Hout, 3), fptr(dHdτ, 3) if dHdτ is not None else None,
+                                         nx, ny, nz) == 1
+
+
+def diffusion_3D_step_τ3(Ht, Hτ, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale=0.0, sumsq3_dev=None):
+    """Three trips through the loop body of part1_kernel_programming.jl:179-192 in one pass over memory: Hτ -> Hout, the two fields in
+    between never written.  Hτ and Hout are the reference's two ping-pong buffers in either order (Hout carries the other buffer's
+    boundary values and keeps them): no third work buffer.  sumsq3_dev: 3 device doubles (norm sums of the three iterations), or None;
+    dHdτ may be None (the residual of the third iteration is then not stored)."""
+    nx, ny, nz = Ht.shape
+    _ctx().call("fpr_diffusion3d_step3", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hout, 3), fptr(dHdτ, 3) if dHdτ is not None else None,
+                nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale, sumsq3_dev.data_ptr() if sumsq3_dev is not None else None)
+
+
 def diffusion_3D_step_τ2_box(Ht, Hτ, Hmid, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, lo, hi, scale=0.0,
                              sumsq2_dev=None, stream_sel=0, z2=None):
     """Sub-box form of diffusion_3D_step_τ2 (0-based [lo, hi)); the two sums are accumulated into sumsq2_dev.

@@ -70,6 +70,7 @@ enum {
     FPR_KT_MG_CG = 5,         /* coarse solve by cg! as ONE persistent launch (k_cg_persistent): a launch = a solve      */
     FPR_KT_MG_PATCH = 6,      /* coarse solve by damped Jacobi on a large coarse grid: one launch = up to 32 groups of 8 sweeps
                                  (k_jacobi_persist; option mg_jacobi_persist = 0: one launch per 8 sweeps, k_jacobi_patch) */
+    FPR_KT_DIFF3_STEP3 = 8,   /* k_diff3_march3: three pseudo-iterations per launch                           */
     FPR_KT_DIFF3_CORE = 7     /* fpr_diffusion3d_step2_core: the core launch of a decomposed run's fused pair (the shell
                                  launches beside it stay FPR_KT_DIFF3_STEP / _STEP2 and OVERLAP it in time)              */
 };
@@ -99,6 +100,19 @@ int fpr_diffusion3d_step_norm_host(fpr_ctx* ctx, const double* Ht, const double*
                                    int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz,
                                    double D_dx, double D_dy, double D_dz, double scale, double* sumsq_host);
 
+/* THREE iterations in one launch (k_diff3_march3; the same loop body :179-192 three times): Htau -> Hout with the two fields in
+ * between never materialised -- 32 bytes per cell and launch for three iterations.  Htau and Hout are the reference's TWO ping-pong
+ * buffers in either order (Hout must carry the boundary values of the buffer the reference would write the third iteration into, i.e.
+ * the other one of the pair; its boundary cells are read, its interior written): no third work buffer.  dHdtau (nullable) receives the
+ * residual of the third iteration; sumsq3_dev (nullable): three device doubles, sum((r*scale)^2) of each iteration.  Fields bit for bit
+ * three fpr_diffusion3d_step calls.  Requirements: nx even >= 128, ny >= 24, nz >= 5, 16-byte aligned arrays, nx*ny*128 < 2^31 -- query
+ * with fpr_diffusion3d_can_step3.  At 512^3 on MI355X: 0.92 ms per launch against 0.76-0.86 for two iterations (profiles/r6_march3_*).
+ * Option diff3_fuse3 [1]. */
+int fpr_diffusion3d_can_step3(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hout, const double* dHdtau, int nx,
+                              int ny, int nz);
+int fpr_diffusion3d_step3(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Hout, double* dHdtau, int nx, int ny, int nz,
+                          double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy, double D_dz,
+                          double scale, double* sumsq3_dev);
 /* A1x2: TWO pseudo-transient iterations in one pass over memory (temporal blocking of two trips through the loop body
  * part1_kernel_programming.jl:179-192).  Equivalent, bit for bit, to
  *     fpr_diffusion3d_step(Ht, Htau -> Hmid, dHdtau);  fpr_diffusion3d_step(Ht, Hmid -> Hout, dHdtau)

@@ -395,6 +395,20 @@ function diffusion_3D_step_τ2(Ht::DA, Hτ::DA, Hmid::DA, Hout::DA, dHdτ::DA, d
                 ctx(), p(Ht), p(Hτ), p(Hmid), p(Hout), p(dHdτ), nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale,
                 sumsq2 === nothing ? Ptr{Cdouble}(C_NULL) : p(sumsq2)))
 end
+"Three loop trips (part1_kernel_programming.jl:179-192) in one pass: Hτ -> Hout, the reference's two ping-pong buffers in either order; no third buffer."
+can_step_τ3(Ht::DA, Hτ::DA, Hout::DA, dHdτ::DA) =
+    ccall((:fpr_diffusion3d_can_step3, libfpr), Cint,
+          (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint),
+          ctx(), p(Ht), p(Hτ), p(Hout), p(dHdτ), size(Ht)...) == 1
+function diffusion_3D_step_τ3(Ht::DA, Hτ::DA, Hout::DA, dHdτ::DA, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz;
+                              scale = 0.0, sumsq3::Union{DA,Nothing} = nothing)
+    nx, ny, nz = size(Ht)
+    check(ccall((:fpr_diffusion3d_step3, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint,
+                 Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cdouble}),
+                ctx(), p(Ht), p(Hτ), p(Hout), p(dHdτ), nx, ny, nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, scale,
+                sumsq3 === nothing ? Ptr{Cdouble}(C_NULL) : p(sumsq3)))
+end
 function diffusion_3D_step_τ2_box(Ht::DA, Hτ::DA, Hmid::DA, Hout::DA, dHdτ::DA, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz,
                                   lo::NTuple{3,Int}, hi::NTuple{3,Int}; scale = 0.0, sumsq2::Union{DA,Nothing} = nothing, stream_sel = 0)
     nx, ny, nz = size(Ht)

@@ -464,8 +464,11 @@ def test_solve_with_fused_pairs_equals_plain_loop(fpr, oracle, case):
     # plain loop; fused pairs that store the residual every launch; fused pairs that store it only when the call returns -- each
     # fused form with the host waiting for every norm (diff3_ahead = 0) and with the exit test on the device and 1, 2 (default)
     # or 5 pairs enqueued ahead of the host (the pairs behind the one that ends the loop must not run)
-    for fuse, lazy, ahead in ((0, 1, 0), (1, 0, 0), (1, 1, 0), (1, 0, 2), (1, 1, 1), (1, 1, 2), (1, 1, 5)):
+    # ... and the same forms with THREE iterations per launch (diff3_fuse3, the default since round 6; remainders as pairs or single steps)
+    for fuse, fuse3, lazy, ahead in ((0, 0, 1, 0), (1, 0, 0, 0), (1, 0, 1, 0), (1, 0, 0, 2), (1, 0, 1, 1), (1, 0, 1, 2), (1, 0, 1, 5),
+                                     (1, 1, 0, 0), (1, 1, 1, 0), (0, 1, 1, 0), (1, 1, 0, 2), (1, 1, 1, 1), (1, 1, 1, 2), (0, 1, 1, 2), (1, 1, 1, 5)):
         c.set_option("diff3_fuse2", fuse)
+        c.set_option("diff3_fuse3", fuse3)
         c.set_option("diff3_lazy_residual", lazy)
         c.set_option("diff3_ahead", ahead)
         try:
@@ -475,6 +478,7 @@ def test_solve_with_fused_pairs_equals_plain_loop(fpr, oracle, case):
             out.append((H, info["iters"], info["err"], F.tonumpy(info["residual_H"])))
         finally:
             c.set_option("diff3_fuse2", 1)
+            c.set_option("diff3_fuse3", 1)
             c.set_option("diff3_lazy_residual", 1)
             c.set_option("diff3_ahead", 2)
     (H0, it0, e0, r0) = out[0]
@@ -960,3 +964,110 @@ def test_placement_alloc_fields(fpr):
     pA.copy_(pHt)
     F.part1.diffusion_3D_step_τ(pHt, pA, pB, pR, *coef)
     assert torch.equal(B2, pB) and torch.equal(R, pR)
+
+
+# ---------------------------------------------------------------- three iterations per launch (k_diff3_march3, round 6)
+SHAPES3 = [(128, 24, 5), (128, 48, 40), (130, 50, 23), (256, 26, 9), (192, 64, 33), (128, 100, 7), (384, 25, 12)]
+
+
+def _oracle_steps(oracle, Ht, A, B, k):
+    """k reference iterations from the field in A, ping-pong A <-> B (each buffer keeps its own boundary); returns the buffer that holds
+    the field, the residual of the last iteration and the sums of all k."""
+    A, B = A.copy(order="F"), B.copy(order="F")
+    dH = asf(np.full(A.shape, -9.0))
+    sums = []
+    for _ in range(k):
+        oracle.diffusion3d_step(Ht, A, B, dH, *COEF.values())
+        sums.append(oracle.sumsq_scaled(dH[1:-1, 1:-1, 1:-1].copy(order="F"), 0.2))
+        A, B = B, A
+    return A, dH, sums
+
+
+@pytest.mark.parametrize("shape", SHAPES3, ids=lambda s: "x".join(map(str, s)))
+def test_fused_three_steps_bit_exact(fpr, oracle, shape):
+    """fpr_diffusion3d_step3 == three oracle steps, bit for bit, in BOTH directions of the reference's ping-pong (X -> Y, then Y -> X: six
+    iterations): the two buffers carry different random boundary values, so a boundary taken from the wrong buffer at any of the three
+    levels cannot go unnoticed; the input buffer is not written; the three fused sums to 1e-13; without a residual array the same field."""
+    F = fpr
+    c = F.ctx()
+    Ht, A, B = rnd(shape, 31), rnd(shape, 32), rnd(shape, 33)
+    dHt, dA, dB = F.asdevice(Ht), F.asdevice(A), F.asdevice(B)
+    dD = F.asdevice(np.full(shape, -9.0))
+    assert F.part1.can_step_τ3(dHt, dA, dB, dD)
+    f3, r3, s3 = _oracle_steps(oracle, Ht, A, B, 3)
+    sq3 = c.scal[:3]
+    F.part1.diffusion_3D_step_τ3(dHt, dA, dB, dD, *COEF.values(), 0.2, sq3)
+    assert np.array_equal(F.tonumpy(dB), f3) and np.array_equal(F.tonumpy(dD), r3)
+    assert np.array_equal(F.tonumpy(dA), A)
+    got = [float(x) for x in sq3.tolist()]
+    assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, s3)), (got, s3)
+    # back: Y -> X (the field after six iterations lives in the first buffer again, with ITS boundary)
+    f6, r6, s6 = _oracle_steps(oracle, Ht, A, B, 6)
+    F.part1.diffusion_3D_step_τ3(dHt, dB, dA, dD, *COEF.values(), 0.2, sq3)
+    assert np.array_equal(F.tonumpy(dA), f6) and np.array_equal(F.tonumpy(dD), r6)
+    got = [float(x) for x in sq3.tolist()]
+    assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, s6[3:])), (got, s6[3:])
+    # without norms / without a residual array
+    dA2, dB2 = F.asdevice(A), F.asdevice(B)
+    F.part1.diffusion_3D_step_τ3(dHt, dA2, dB2, None, *COEF.values())
+    assert np.array_equal(F.tonumpy(dB2), f3)
+    dB2.copy_(F.asdevice(B))
+    sq3.zero_()
+    F.part1.diffusion_3D_step_τ3(dHt, dA2, dB2, None, *COEF.values(), 0.2, sq3)
+    assert np.array_equal(F.tonumpy(dB2), f3)
+    got2 = [float(x) for x in sq3.tolist()]
+    assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got2, s3))
+
+
+def test_fused_three_steps_unsupported_shapes_are_reported(fpr):
+    F = fpr
+    for shape in ((126, 24, 8), (129, 24, 8), (128, 23, 8), (128, 24, 4)):
+        t = [F.fzeros(*shape) for _ in range(4)]
+        assert not F.part1.can_step_τ3(*t), shape
+        with pytest.raises(F.FprError):
+            F.part1.diffusion_3D_step_τ3(*t, *COEF.values())
+    t = [F.fzeros(128, 24, 8) for _ in range(4)]
+    assert F.part1.can_step_τ3(*t)
+    assert not F.part1.can_step_τ3(t[0], t[1], t[1], t[3])          # in place: not possible
+    c = F.ctx()
+    c.set_option("diff3_fuse3", 0)
+    try:
+        assert not F.part1.can_step_τ3(*t)
+    finally:
+        c.set_option("diff3_fuse3", 1)
+
+
+def test_full_size_512_fused_triples_against_the_oracle(fpr):
+    """BASELINE config 2 at its own size: two fused triples (X -> Y -> X: six iterations) at 512^3 against six oracle steps (OpenMP build of
+    the same C restatement): fields and residuals bit for bit, the six fused sums to 1e-13.  This is the launch bench.py times."""
+    import os
+
+    from fixtures_io import splitmix64_uniform
+    from oracle.oracle import Oracle, asf as asf_, farr
+
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
+    orc = Oracle(openmp=True)
+    F = fpr
+    n = 512
+    dx = 10.0 / n
+    dt = 0.2
+    coef = (dx * dx / 8.1, 1 / dt, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx, 1 / dx)
+    Ht = orc.init_gaussian((n, n, n), dx, dx, dx, (4.0, 5.5, 6.0))
+    Ht *= 1.0 + 0.25 * asf_(splitmix64_uniform(n ** 3, 78).reshape((n, n, n), order="F"))
+    A, B, R = Ht.copy(order="F"), farr(n, n, n), farr(n, n, n)
+    B[...] = 0.5 * Ht          # (another boundary than A's)
+    gHt, gA, gB, gR = F.asdevice(Ht), F.asdevice(A), F.asdevice(B), F.fzeros(n, n, n)
+    sq = F.ctx().scal[:3]
+    assert F.part1.can_step_τ3(gHt, gA, gB, gR)
+    for rnd_ in range(2):
+        refs = []
+        for _ in range(3):
+            orc.diffusion3d_step(Ht, A, B, R, *coef)
+            A, B = B, A
+            refs.append(orc.sumsq_scaled(R, dt))
+        F.part1.diffusion_3D_step_τ3(gHt, gA, gB, gR, *coef, dt, sq)
+        gA, gB = gB, gA
+        got = [float(v) for v in sq.tolist()]
+        assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs)), (rnd_, got, refs)
+        assert np.array_equal(F.tonumpy(gA), A), rnd_
+        assert np.array_equal(F.tonumpy(gR), R), rnd_

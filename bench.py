@@ -263,112 +263,40 @@ def main():
     D, dt = 1.0, 0.2
     dτ = min(dx, dy, dz) ** 2 / D / 8.1
     coef = (dτ, 1.0 / dt, 1.0 / dx, 1.0 / dy, 1.0 / dz, D / dx, D / dy, D / dz)
-    # The five field arrays, placed for the streaming kernels (finalprojectrepo.jl_amd/placement.py: which physical pages an
-    # allocation receives decides whether two arrays streamed at equal offsets get in each other's way -- 0.775 against 0.85-0.91 ms
-    # for the same launch; a pool of candidates is timed pairwise once, outside every timed region, and the best-matched five stay).
-    # Every rank does the same thing for itself; --no-placement allocates plainly.
-    placement = {}
+    # The field arrays.  A single rank runs three iterations per launch (k_diff3_march3), which does not care where its arrays lie
+    # (profiles/r6_placement_on_off.txt: 0.916 ms placed, 0.913-0.916 plain on one lease): plain allocations, as the reference's `@zeros`.
+    # Ranks with neighbours run fused pairs, whose time depends on the physical pages the arrays received (0.76 against 0.85-0.91 ms): there
+    # a pool of candidates is timed once, outside every timed region, and the best-matched five stay (placement.py; --no-placement: plain).
+    want_fuse3 = world == 1 and not args.no_fuse3 and not args.no_fuse2
+    placement = {"selected": False}
     unplaced = {}
-    try:      # what the card had free before this process allocated anything (a lease whose pool is of one class: is the card shared / fragmented?)
+    try:
         _free0, _total0 = torch.cuda.mem_get_info()
         unplaced["mem_free_GiB_at_start"], unplaced["mem_total_GiB"] = _free0 / 2.0 ** 30, _total0 / 2.0 ** 30
     except Exception:
         pass
-
-    # three iterations per launch on a single rank (k_diff3_march3: Hτ <-> Hτ2, no third buffer); between ranks fused pairs
-    want_fuse3 = world == 1 and not args.no_fuse3 and not args.no_fuse2
-
-    def fused_launch(arrs, i, with_norm=None):
-        """Launch i of a chain of fused launches on the five arrays (Ht, Hτ, Hτ3, res, Hτ2): triples Hτ <-> Hτ2, or pairs Hτ <-> Hτ3."""
-        tHt, tA, tC, tR, tB = arrs
-        if want_fuse3 and F.part1.can_step_τ3(tHt, tA, tB, tR):
-            F.part1.diffusion_3D_step_τ3(tHt, tA, tB, tR, *coef) if (i & 1) == 0 else F.part1.diffusion_3D_step_τ3(tHt, tB, tA, tR, *coef)
-        else:
-            F.part1.diffusion_3D_step_τ2(tHt, tA, tB, tC, tR, *coef) if (i & 1) == 0 else F.part1.diffusion_3D_step_τ2(tHt, tC, tB, tA, tR, *coef)
-
-    def pair_ms_of(arrs, pairs_warm, pairs_timed):
-        """Event time [ms] of one fused launch on the given five arrays (zeros: the arithmetic does not depend on the values)."""
-        tHt, tA, tC, tR, tB = arrs
-        if not F.part1.can_step_τ2(tHt, tA, tB, tC, tR):
-            return None
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for i in range(pairs_warm + pairs_timed):
-            if i == pairs_warm:
-                e0.record()
-            fused_launch(arrs, i)
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) / pairs_timed
-
-    if args.no_placement or as_one:
+    if args.no_placement or as_one or world == 1:
         Ht, Hτ, Hτ3, res, Hτ2 = (F.fzeros(*nloc) for _ in range(5))
-        placement["selected"] = False
     else:
-        # What a host that simply allocates gets (the reference's `@zeros`): the first five allocations of this process, timed once
-        # with the fused kernel in steady state (about 0.25 s, outside every timed region) -- reported beside the placed number.
-        plain = None
-        if world == 1:
-            try:
-                plain = [F.fzeros(*nloc) for _ in range(5)]
-                ms = pair_ms_of(plain, 200, 100)
-                unplaced.update({"kernel_ms": ms, "launches": 100,
-                                 "note": "k_diff3_march2 on the first five plain allocations of the process (no pool, no search), "
-                                         "100 launches behind 200 of warm-up, torch events"})
-            except Exception as e:
-                plain = None
-                unplaced["error"] = repr(e)
-        # streamed together at equal offsets: (Ht, field read), (field written, residual) -- the field alternates between Hτ and Hτ3.
-        # A trial = a few fused pairs on the candidate arrays (zeros: the arithmetic does not depend on the values), timed by events.
         def trial(arrs):
+            """A few fused pairs on the candidate arrays (zeros: the arithmetic does not depend on the values), timed by events."""
             tHt, tA, tC, tR, tB = arrs
             if not F.part1.can_step_τ2(tHt, tA, tB, tC, tR):
-                raise RuntimeError("the fused kernel does not serve these arrays")     # (no search without a judge: plain arrays below)
+                raise RuntimeError("the fused kernel does not serve these arrays")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            # (without the norm: the same streams, and another instantiation of the kernel than the timed region's -- a rocprofv3
-            # --stats summary of this command then lists the trial launches on discarded placements under a name of their own)
             for i in range(3):
                 if i == 1:
                     e0.record()
                 for _ in range(3 if i else 2):
-                    fused_launch(arrs, 0)
-                    fused_launch(arrs, 1)
+                    F.part1.diffusion_3D_step_τ2(tHt, tA, tB, tC, tR, *coef)
+                    F.part1.diffusion_3D_step_τ2(tHt, tC, tB, tA, tR, *coef)
             e1.record()
             e1.synchronize()
             return e0.elapsed_time(e1) / 12.0
 
         try:
-            # (the plain five are the first candidates: the search keeps them unless an assignment from the pool is faster)
-            # The chosen arrays are accepted when the fused launch takes at most 1.07 x the one-iteration kernel on the same arrays (26
-            # leases with a mixed pool: 1.016-1.058; four whose pool held ONE candidate of another class among eleven alike -- a fast
-            # pair, no good assignment: 1.083-1.090, 0.788-0.795 ms; profiles/r5_driver_repro.txt); otherwise the pool is rebuilt once
-            # behind placement.churn() with the chosen arrays kept as candidates
-            def accept(arrs):
-                tHt, tA, tC, tR, tB = arrs
-                pair = trial(arrs)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                for i in range(24):
-                    if i == 8:
-                        e0.record()
-                    F.part1.diffusion_3D_step_τ(tHt, tA if (i & 1) == 0 else tB, tB if (i & 1) == 0 else tA, tR, *coef)
-                e1.record()
-                e1.synchronize()
-                single = e0.elapsed_time(e1) / 16.0
-                placement.setdefault("accept_pair_over_single_first_pool", pair / single)
-                placement["accept_pair_over_single"] = pair / single      # (of the arrays kept)
-                # The fused launch's own rate is the steadier judge: 0.7429-0.7541 ms (0.704-0.714 of the HBM peak by its compulsory bytes)
-                # over 45 leases with a mixed pool, 0.788-0.795 (0.667-0.673) on the six pools with one candidate of another class --
-                # while the one-iteration kernel varies by 5 % from card to card (ratios 1.04-1.08 against 1.09-1.10: four pools that
-                # were fine refused in fifteen at 1.07).  Refused: below 0.69 of the peak, or a ratio beyond doubt.
-                frac = A_EFF_BYTES * (nloc[0] - 2) * (nloc[1] - 2) * (nloc[2] - 2) / (pair * 1e-3) / 1e9 / HBM_PEAK_GBS
-                placement.setdefault("accept_trial_frac_first_pool", frac)
-                placement["accept_trial_frac"] = frac
-                if want_fuse3:       # (three iterations per launch: 1.25-1.32 x the one-iteration kernel on a mixed pool)
-                    return pair <= 1.40 * single
-                return frac >= 0.69 and pair <= 1.12 * single
-
-            Ht, Hτ, Hτ3, res, Hτ2 = F.placement.alloc_fields(5, *nloc, report=placement, pairs=[(0, 1), (0, 4), (4, 3), (1, 3), (1, 4)] if want_fuse3 else [(0, 1), (0, 2), (2, 3), (1, 3), (1, 2)],
-                                                          trial=trial, first=plain, accept=None if shared else accept)   # (ranks that share one card do not churn its memory under each other)
-            del plain
+            # streamed together at equal offsets: (Ht, field read), (field written, residual) -- the field alternates between Hτ and Hτ3
+            Ht, Hτ, Hτ3, res, Hτ2 = F.placement.alloc_fields(5, *nloc, report=placement, pairs=[(0, 1), (0, 2), (2, 3), (1, 3), (1, 2)], trial=trial)
         except Exception as e:       # the search is an optimisation: plainly allocated arrays give the same results
             torch.cuda.empty_cache()
             Ht, Hτ, Hτ3, res, Hτ2 = (F.fzeros(*nloc) for _ in range(5))
@@ -726,9 +654,13 @@ def main():
         sys.exit(3)
     hb("done" if not norm_failed else "norm_failed", **({"norm_check": out["norm_check"]} if norm_failed else {}))
     if rank == 0:
-        out["config"]["unplaced_kernel_ms"] = unplaced.get("kernel_ms")
+        # (plain allocations: the timed arrays ARE what a host that simply allocates gets)
+        out["config"]["unplaced_kernel_ms"] = out["roofline"]["kernel_ms"] if not placement.get("selected") else None
         out["config"]["mem_free_GiB_at_start"], out["config"]["mem_total_GiB"] = unplaced.get("mem_free_GiB_at_start"), unplaced.get("mem_total_GiB")
-        out["unplaced"] = unplaced
+        try:        # memory this process still holds beyond what it uses (placement leaves nothing behind; the caching allocator's reserve counts)
+            out["config"]["mem_held_GiB"] = max(0.0, (torch.cuda.memory_reserved() - torch.cuda.memory_allocated()) / 2.0 ** 30)
+        except Exception:
+            pass
         legs_mod.emit(out, root=os.environ.get("FPR_BENCH_DETAIL_DIR", ROOT))     # full record -> bench_detail.json; the compact line is the last line of stdout
     if use_dist:
         dist.destroy_process_group()

@@ -87,7 +87,7 @@ def place_vcycle_fields(F, n, b0, placement):
     x_plain = F.fzeros(n, n)
     placement["plain_allocation_ms"] = solve_ms(x_plain, b0)      # four plain arrays + the library's own arena: what a host gets unplaced
     del x_plain
-    P, Q = F.placement.alloc_fields(2, GiB // 8, pool=12, report=placement, pairs=[(0, 1)], trial=trial, trials=3)
+    P, Q = F.placement.alloc_fields(2, GiB // 8, pool=12, report=placement, pairs=[(0, 1)], trial=trial)
     x, b, t1, t2, cs = windows(P, Q)
     for a in cs:
         a.zero_()

@@ -1,4 +1,5 @@
 // context.hip -- lifecycle, streams, reductions and flat-array utilities of libfpr_hip.so (gfx950).
+#include <cstring>
 #include "fpr_internal.hpp"
 
 extern "C" const char* fpr_version(void) { return "fpr-hip 0.1 (gfx950, fp64, no-fma)"; }
@@ -60,15 +61,12 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
         }
     for (auto& e : ctx->ktimer_ev) hipEventDestroy(e);
     if (ctx->cg_buf) hipFree(ctx->cg_buf);
-    if (ctx->pyr_buf) hipFree(ctx->pyr_buf);
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->partials2) hipFree(ctx->partials2);
     if (ctx->core_partials) hipFree(ctx->core_partials);
     if (ctx->tickets) hipFree(ctx->tickets);
     if (ctx->xstrips) hipFree(ctx->xstrips);
     if (ctx->ns_ev) hipEventDestroy(ctx->ns_ev);
-    if (ctx->aux_stream) { hipStreamSynchronize(ctx->aux_stream); hipStreamDestroy(ctx->aux_stream); }
-    for (auto& e : ctx->aux_ev) if (e) hipEventDestroy(e);
     fprx_ns_worker_free(ctx);
     if (ctx->reserved_map) hipFree(ctx->reserved_map);
     if (ctx->scalars) hipFree(ctx->scalars);
@@ -152,7 +150,7 @@ extern "C" int fpr_reserve_comm_cus(fpr_ctx* ctx, int k)
     //      does not find exactly k units, k is rounded up to the next multiple of 32 and form (a) is used.
     const int words = (ctx->ncu + 31) / 32;
     const int asked = k;
-    const long force = fpr_opt(ctx, "core_unmasked", -1);    // experiments: 0 = never (b), 1 = (b) for every k
+    const long force = -1;    // experiments: 0 = never (b), 1 = (b) for every k
     bool unmasked = force == 1 || (force != 0 && k % 32 != 0);
     // every failure below leaves the context unsplit and owns no stream (comm_cus stays 0)
     auto undo = [&](hipError_t e, const char* what) {
@@ -226,9 +224,22 @@ extern "C" int fpr_stream_handle(fpr_ctx* ctx, int sel, void** out)
 
 extern "C" const char* fpr_last_error(fpr_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 
+// Every switch the library reads (DESIGN 6 lists what each one does).  Tuning knobs of earlier rounds are compile-time constants now; a key
+// that is not in this list is an error, not a silent no-op.
+static const char* const FPR_OPTION_KEYS[] = {
+    "diff3_fuse2", "diff3_fuse3", "diff3_ahead", "diff3_lazy_residual", "diff3_xstrips", "diff3_comm_units", "fp_contract",
+    "mg_multi", "mg_seam", "mg_mid", "mg_small", "mg_patch", "mg_fuse_restrict", "mg_fuse_prolong", "mg_zero_guess", "mg_zero_fuse",
+    "mg_fold_finish", "mg_fold_fsq", "mg_ahead", "mg_seam_history", "mg_jacobi_persist", "cg_fused", "handoff_fences", "ns_pipeline",
+    "grid_drop_faces",                                                                    // measurement aid (bench.py's neighbour legs)
+    "diff3_bal_g", "diff3_reserved_test", "diff3_zc2", "mg_jacobi_persist_test_abort", "mg_seam_predict",   // test hooks
+    "cg_persistent_timeouts", "mg_jacobi_persist_timeouts"};                              // diagnostics the library counts (resettable)
+
 extern "C" int fpr_set_option(fpr_ctx* ctx, const char* key, long value)
 {
     if (!ctx || !key) return FPR_ERR_INVALID;
+    bool known = false;
+    for (const char* k : FPR_OPTION_KEYS) known = known || std::strcmp(k, key) == 0;
+    if (!known) return fpr_fail(ctx, FPR_ERR_INVALID, "unknown option '%s'", key);
     ctx->options[key] = value;
     // asking for the persistent Jacobi coarse solve again lifts the switch a timed-out hand-off left behind (multigrid2d.hip)
     if (value != 0 && std::string(key) == "mg_jacobi_persist") ctx->jacp_resident = -1;

@@ -42,17 +42,11 @@ static int diff3_run(fpr_ctx* ctx, const double* Ht, const double* Htau, double*
     const bool empty = a.lo[0] >= a.hi[0] || a.lo[1] >= a.hi[1] || a.lo[2] >= a.hi[2];
     int nparts = 0;
     if (!empty) {
-        Diff3Tuning t;
-        t.variant = (int)fpr_opt(ctx, "diff3_variant", 0);
-        t.zc = (int)fpr_opt(ctx, "diff3_zc", 0);
-        t.xcd_remap = (int)fpr_opt(ctx, "diff3_xcd_remap", -1);
-        t.ry = (int)fpr_opt(ctx, "diff3_ry", 0);
-        t.nt = (int)fpr_opt(ctx, "diff3_nt", -1);
-        t.vx = (int)fpr_opt(ctx, "diff3_vx", 0);
+        const Diff3Tuning t;      // the library runs the default form only (the other tilings live in tools/diffusion_tune.hip, -DFPR_TUNE)
         const bool timed = fpr_ktimer_begin(ctx, FPR_KT_DIFF3_STEP, ctx->stream[stream_sel]);
         // a box up to 8 cells wide in x (the slab next to an x-neighbour) goes to the kernel whose lanes run along y;
         // needs 8-byte loads through buffer descriptors only, so any size / alignment qualifies
-        const bool narrow = t.variant == 0 && (a.hi[0] - a.lo[0]) <= (int)fpr_opt(ctx, "diff3_slab_max1", 8) &&
+        const bool narrow = (a.hi[0] - a.lo[0]) <= 8 &&
                             (long)nx * ny * 8 * 12 < (1L << 31) && ny >= 3;
         hipError_t e = narrow ? diff3_launch_slab1(a, norm, ctx->stream[stream_sel], FPR_MAX_PARTIALS, &nparts)
                               : diff3_launch(a, norm, t, ctx->stream[stream_sel], FPR_MAX_PARTIALS, &nparts);
@@ -130,7 +124,7 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
     FPR_REQUIRE(ctx, diff3_fuse2_ok(ctx, Ht, A, B, C, dH, nx, ny, nz), "problem not supported by the fused two-step kernel");
     Diff3Args2 a;
     a.skip = skip;
-    a.lane_off = fpr_opt(ctx, "diff3_lane_off", 1) != 0;
+    a.lane_off = 1;
     a.Ht = Ht; a.A = A; a.B = B; a.C = C; a.dH = dH;
     a.nx = nx; a.ny = ny; a.nz = nz;
     const int n[3] = {nx, ny, nz};
@@ -165,7 +159,7 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
         }
         // boxes up to 12 cells wide in x (the slab next to an x-neighbour of a decomposed run) go to the kernel whose
         // lanes run along y; everything else to the wave-tile kernel.  A second z-range rides along in either case.
-        const bool narrow = (a.hi[0] - a.lo[0]) <= (int)fpr_opt(ctx, "diff3_slab_max", 12);
+        const bool narrow = (a.hi[0] - a.lo[0]) <= 12;
         const bool timed = fpr_ktimer_begin(ctx, is_core ? FPR_KT_DIFF3_CORE : FPR_KT_DIFF3_STEP2, ctx->stream[stream_sel]);
         hipError_t e;
         if (narrow) {
@@ -186,7 +180,7 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
             // the reserved form of a core launch takes tickets: one workgroup per device slot, the ones the split leaves no slot for find no work
             // (a launch leaves its counters zeroed; launches of ONE stream follow each other, and every stream selector has a block of
             // its own, so a ticketed launch on the compute stream cannot meet a pending pair's core launch in the same counters)
-            const bool tickets = reserve_cus != 0 && stream_sel != 1 && fpr_opt(ctx, "diff3_tickets", 1) != 0;
+            const bool tickets = reserve_cus != 0 && stream_sel != 1;
             if (tickets && !ctx->tickets) {
                 FPR_HIP(ctx, hipMalloc(&ctx->tickets, 3 * 16 * sizeof(int)));
                 FPR_HIP(ctx, hipMemset(ctx->tickets, 0, 3 * 16 * sizeof(int)));   // once, complete before any stream goes on
@@ -199,9 +193,9 @@ static int diff3_run2(fpr_ctx* ctx, const double* Ht, const double* A, const dou
                                             ctx->stream[stream_sel]));
                 rmap = ctx->reserved_map + 64;
             }
-            e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), (int)fpr_opt(ctx, "diff3_xcd2", 0) & 3,
-                              ctx->stream[stream_sel], pcap, &nparts,
-                              (int)fpr_opt(ctx, "diff3_nw2", 0), ncu_plan, zlo2, zhi2, reserve_cus, &bal_info,
+            // (option diff3_zc2: planes per z-chunk, a test hook -- small test grids otherwise run as one chunk)
+            e = diff3_launch2(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), 0, ctx->stream[stream_sel], pcap, &nparts, 0, ncu_plan, zlo2, zhi2,
+                              reserve_cus, &bal_info,
                               tickets ? ctx->tickets + 16 * stream_sel : nullptr, rmap);
             if (reserve_cus != 0) ctx->options["diff3_last_bal"] = bal_info;   // diagnostic (fpr_get_option): which form ran
         }
@@ -290,7 +284,7 @@ static int diff3_run3(fpr_ctx* ctx, const double* Ht, const double* X, double* Y
     }
     int nparts = 0;
     const bool timed = fpr_ktimer_begin(ctx, FPR_KT_DIFF3_STEP3, ctx->stream[0]);
-    const hipError_t e = diff3_launch3(a, norm, 0, 0, ctx->stream[0], pcap, &nparts, ctx->ncu);
+    const hipError_t e = diff3_launch3(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), 0, ctx->stream[0], pcap, &nparts, ctx->ncu);
     fpr_ktimer_end(ctx, timed, ctx->stream[0]);
     if (e != hipSuccess) return fpr_fail(ctx, FPR_ERR_HIP, "fused three-step diffusion3d launch: %s", hipGetErrorString(e));
     if (nparts_only) {
@@ -764,7 +758,7 @@ static int diff3_join(fpr_ctx* ctx, bool async)
     if (!ctx) return FPR_ERR_INVALID;
     if (!ctx->pair_pending) return FPR_OK;
     ctx->pair_pending = false;
-    if (async || fpr_opt(ctx, "diff3_join_async", 0)) {
+    if (async) {
         if (int rc = fpr_stream_wait(ctx, 0, 2)) return rc;   // the core launch (which has taken in the shell chain's exchanges)
         return fpr_stream_wait(ctx, 0, 1);                    // the pair's sums, finished on the comm stream
     }
@@ -854,7 +848,7 @@ extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const 
         int fm = 0;
         for (int q = 0; q < xs_faces; ++q) fm |= 1 << xs.f[q].high;
         const bool cont = was_pending && ctx->xs_field == Htau && ctx->xs_ht == Ht && ctx->xs_faces == fm && ctx->xs_n[0] == nx &&
-                          ctx->xs_n[1] == ny && ctx->xs_n[2] == nz && fpr_opt(ctx, "diff3_xstrips_keep", 1) != 0;
+                          ctx->xs_n[1] == ny && ctx->xs_n[2] == nz;
         if (!cont) {
             Diff3StripArgs ga = xs;
             ga.C = const_cast<double*>(Htau);

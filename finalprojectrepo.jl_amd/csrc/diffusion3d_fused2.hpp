@@ -38,13 +38,6 @@
 #ifndef DIFF3_STORE_NOP
 #define DIFF3_STORE_NOP 1
 #endif
-// Synchronisation of the waves of a workgroup in the z-march: 0 = one s_barrier per iteration (all 8 waves in lockstep);
-// 1 = point to point: a wave needs the rows of its two y-neighbours only, so it publishes "my rows of iteration m are in LDS"
-// in a flag word and waits for the flags of the wave below and the wave above -- waves drift apart by up to an iteration per
-// neighbour, and the two waves of a SIMD stop entering their load, compute and store phases together.
-#ifndef DIFF3_P2P_SYNC
-#define DIFF3_P2P_SYNC 0
-#endif
 // 1: lanes whose pair of cells lies outside what the tile needs (level 0 on [ol - 2, oh + 1]) are switched OFF for the whole march
 // (EXEC) instead of re-reading the nearest needed pair and computing on it: 5 x-tiles of 128 cells cover a 510-cell line, so about
 // a sixth of the lanes of every vector instruction works on nothing -- at the same issue rate, but the kernel runs at the card's
@@ -230,9 +223,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_diff3_march2(Diff3
     // [parity][slot 0..5][row kind][TXW]; wave w owns slot w+1, slot 0 / 5 receive the global halo rows of
     // the bottom / top wave, so every wave reads "the slot below" and "the slot above" without a select
     __shared__ __attribute__((aligned(16))) double xrow[2 * (NW + 2) * SLOT];
-#if DIFF3_P2P_SYNC
-    __shared__ int zflag[NW + 2];                 // [w + 1]: last iteration whose rows wave w has written; [0], [NW + 1]: no neighbour there
-#endif
 
     if (a.skip && *a.skip) return;   // a pair enqueued behind the iteration that ended the solver's loop (diffusion3d.hip)
 
@@ -375,13 +365,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_diff3_march2(Diff3
 
     // ---- z: owned planes [k0, k1) (above); iterations m0 .. m1 ----
     const int m0 = k0 - 1, m1 = k1;
-#if DIFF3_P2P_SYNC
-    if (NW > 1) {
-        if (item > 0) __syncthreads();            // (every wave is through its last poll of the first unit)
-        if (tid < NW + 2) zflag[tid] = (tid == 0 || tid == NW + 1) ? 0x7fffffff : m0 - 1;
-        __syncthreads();
-    }
-#endif
 
     bool cm[VX], rm[RY];
 #pragma unroll
@@ -489,22 +472,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_diff3_march2(Diff3
                 *reinterpret_cast<d2l*>(buf + ((w == 0 && !top1) ? TXW : (NW + 1) * SLOT) + lane * VX) = t;
             }
         }
-#if DIFF3_P2P_SYNC
-        if constexpr (NW > 1) {
-            // LDS executes a wave's instructions in order and all waves' in one sequence: the flag is written behind the rows,
-            // and a wave that has seen a neighbour's flag reads that neighbour's rows behind it.  The buffer of this parity was
-            // last read by the neighbours in iteration m - 2, before they published m - 1, which this wave saw before it got here.
-            asm volatile("" ::: "memory");
-            if (lane == 0) __hip_atomic_store(&zflag[w + 1], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            for (int spin = 0; spin < (1 << 20); ++spin) {   // (bounded: a wave that never arrives ends the launch wrong, not hung)
-                const int fb = __hip_atomic_load(&zflag[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int fa = __hip_atomic_load(&zflag[w + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (__builtin_amdgcn_readfirstlane(fb < fa ? fb : fa) >= m) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            asm volatile("" ::: "memory");
-        } else
-#endif
         diff3_lds_barrier();
         DVec<VX> yd0, yu0, yd1, yu1;
         {

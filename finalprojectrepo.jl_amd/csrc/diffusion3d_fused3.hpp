@@ -201,7 +201,6 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
     };
     const __amdgpu_buffer_rsrc_t rA = rsrc_at(a.X, 0, j0);        // L0 plane m+3
     const __amdgpu_buffer_rsrc_t rHt = rsrc_at(a.Ht, -1, j0);     // Ht plane m+2
-    const __amdgpu_buffer_rsrc_t rEA = rsrc_at(a.X, -2, j0);      // L0 tile-edge cells, plane m+1
     const __amdgpu_buffer_rsrc_t rEB = rsrc_at(a.Bnd, -2, j0);    // Bnd x-boundary cells, plane m+1
     const __amdgpu_buffer_rsrc_t rH = rsrc_at(Hsrc, -2, hrow);    // halo row, plane m+1
     const __amdgpu_buffer_rsrc_t rC = rsrc_at(a.Y, -5, j0);       // L3 plane m-2
@@ -219,15 +218,11 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
 #else
     auto flush = [&](int, double sl, double& acc) { acc += sl; };
 #endif
+    // A lane owns both cells of its pair or neither (dropped at the end), except the lane that holds an x-boundary cell (the launch covers
+    // the whole interior: an odd end of the owned range is the domain's): that cell's residual is zeroed in the x-boundary branch below
     auto accum = [&](double& acc, const double (&r)[VX]) {
-        if (has_split) {
-            asm volatile("" ::: "memory");
-            acc = __builtin_fma(cm[0] ? r[0] : 0.0, r[0], acc);
-            acc = __builtin_fma(cm[1] ? r[1] : 0.0, r[1], acc);
-        } else {
-            acc = __builtin_fma(r[0], r[0], acc);
-            acc = __builtin_fma(r[1], r[1], acc);
-        }
+        acc = __builtin_fma(r[0], r[0], acc);
+        acc = __builtin_fma(r[1], r[1], acc);
     };
 #pragma unroll
     for (int q = 0; q < NR; ++q)
@@ -236,16 +231,19 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
 #pragma unroll
             for (int v = 0; v < VX; ++v) { Q1[q][r].v[v] = 0.0; Q2[q][r].v[v] = 0.0; HT[q][r].v[v] = 0.0; }
 
-    double* const park = xrow + (size_t)2 * (NW + 2) * SLOT + (size_t)w * (RY * TXW) + lane * VX;   // this wave's parked L2 plane (DIFF3_M3_PARK)
+#if DIFF3_M3_PARK
+    double* const park = xrow + (size_t)2 * (NW + 2) * SLOT + (size_t)w * (RY * TXW) + lane * VX;   // this wave's parked L2 plane
+#endif
     auto row_off = [&](int soff, int r) { return soff == (int)OOR ? (int)OOR : soff + r * rs; };
     auto load_rows = [&](DVec<VX>(&dst)[RY], __amdgpu_buffer_rsrc_t rsrc, int soff) {
 #pragma unroll
         for (int r = 0; r < RY; ++r) dst[r] = diff3_bld2(rsrc, voff, row_off(soff, r));
     };
-    auto load_halo = [&](DVec<VX>& yh, double (&e)[RY], int soff) {
+    // soff: plane offset for the descriptors based two planes below rA (rEB, rH); soffA: the same plane relative to rA
+    auto load_halo = [&](DVec<VX>& yh, double (&e)[RY], int soff, int soffA) {
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-            const double ea = diff3_bld1(rEA, eoff, row_off(soff, r));
+            const double ea = diff3_bld1(rA, eoff, row_off(soffA, r));
             const double eb = diff3_bld1(rEB, boff, row_off(soff, r));
             e[r] = __longlong_as_double(__double_as_longlong(ea) | __double_as_longlong(eb));
         }
@@ -263,8 +261,8 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
 #if DIFF3_M3_SCHED == 0
     load_rows(HT[3], rHt, (m0 + 1 - pbA + 1) * ps);
 #endif
-    load_halo(YH, ED, (kcl(m0) - pbA + 2) * ps);
-    // scalar offset of iteration m: plane m+3 of rA = plane m+2 of rHt = plane m+1 of rEA / rEB / rH = plane m-2 of rC / rD
+    load_halo(YH, ED, (kcl(m0) - pbA + 2) * ps, (kcl(m0) - pbA) * ps);
+    // scalar offset of iteration m: plane m+3 of rA = plane m+2 of rHt = plane m+1 of rEB / rH = plane m-2 of rC / rD
     int so = (m0 + 3 - pbA) * ps;
 
     auto step = [&](auto Sc, auto Do2c, auto Do3c, int m) {
@@ -341,13 +339,14 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
                     r1[v] = diff3_point<false>(cR[r].v[v], xm, xp, ym, yp, zmR[r].v[v], zpR[r].v[v],
                                                HT[(S + 2) % NR][r].v[v], cf, Q1n[r].v[v]);
                 }
-                if constexpr (NORM) {
-                    if (own_plane && rm[r]) accum(sl1, r1);
-                }
-                if (xb_tile) {   // x-boundary own cells of L1 come from Bnd (through the edge register)
+                if (xb_tile) {   // x-boundary own cells of L1 come from Bnd (through the edge register); they have no residual
                     asm volatile("" ::: "memory");
                     Q1n[r].v[0] = bndL ? xl0 : Q1n[r].v[0];
                     Q1n[r].v[VX - 1] = bndR ? xrL : Q1n[r].v[VX - 1];
+                    if constexpr (NORM) { r1[0] = bndL ? 0.0 : r1[0]; r1[VX - 1] = bndR ? 0.0 : r1[VX - 1]; }
+                }
+                if constexpr (NORM) {
+                    if (own_plane && rm[r]) accum(sl1, r1);
                 }
 #if DIFF3_M3_ROW_FENCE
                 __builtin_amdgcn_sched_barrier(0);
@@ -359,7 +358,10 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
         }
 
         // the halo registers of plane m are dead: refill with the halos of plane m+1 (nothing once the chunk ends)
-        load_halo(YH, ED, (m + 1 <= m1 && !DIFF3_DBG(a, 2)) ? so : (int)OOR);
+        {
+            const bool more = m + 1 <= m1 && !DIFF3_DBG(a, 2);
+            load_halo(YH, ED, more ? so : (int)OOR, more ? so - 2 * ps : (int)OOR);
+        }
 #if DIFF3_M3_SCHED == 2
         // Ht plane m+1 (needed by the first step of iteration m+1) into the slot plane m-3 left at the end of the last iteration
         load_rows(HT[(S + 3) % NR], rHt, (m + 1 <= m1 && !DIFF3_DBG(a, 2)) ? so - ps : (int)OOR);
@@ -389,13 +391,14 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
                         const double yp = (r == RY - 1) ? yu1.v[v] : Q1c[r == RY - 1 ? r : r + 1].v[v];
                         r2[v] = diff3_point<false>(Q1c[r].v[v], xm, xp, ym, yp, Q1m[r].v[v], Q1n[r].v[v], HT[(S + 1) % NR][r].v[v], cf, Q2n[r].v[v]);
                     }
-                    if constexpr (NORM) {
-                        if (own2 && rm[r]) accum(sl2, r2);
-                    }
                     if (xb_tile) {
                         asm volatile("" ::: "memory");
                         Q2n[r].v[0] = bndL ? zmR[r].v[0] : Q2n[r].v[0];
                         Q2n[r].v[VX - 1] = bndR ? zmR[r].v[VX - 1] : Q2n[r].v[VX - 1];
+                        if constexpr (NORM) { r2[0] = bndL ? 0.0 : r2[0]; r2[VX - 1] = bndR ? 0.0 : r2[VX - 1]; }
+                    }
+                    if constexpr (NORM) {
+                        if (own2 && rm[r]) accum(sl2, r2);
                     }
 #if DIFF3_M3_ROW_FENCE
                     __builtin_amdgcn_sched_barrier(0);
@@ -453,6 +456,7 @@ __global__ __launch_bounds__(512, 1) void k_diff3_march3(Diff3Args3 a)
                 __builtin_amdgcn_sched_barrier(0);
 #endif
                 if constexpr (NORM) {
+                    if (xb_tile) { asm volatile("" ::: "memory"); res[0] = bndL ? 0.0 : res[0]; res[VX - 1] = bndR ? 0.0 : res[VX - 1]; }
                     if (rm[r]) accum(sl3, res);
                 }
             }

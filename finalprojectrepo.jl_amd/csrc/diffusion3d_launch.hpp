@@ -74,6 +74,11 @@ static inline hipError_t diff3_launch(Diff3Args a, bool norm, const Diff3Tuning&
     int variant = t.variant ? t.variant : DIFF3_DEFAULT_VARIANT_ID;
     *nparts = 0;
     if (wx <= 0 || wy <= 0 || wz <= 0) return hipSuccess;
+#ifndef FPR_TUNE
+    // the library: the default form only (variant 5 = ring-pipelined march with the LDS row exchange, non-temporal stores; 2 cells per
+    // lane where nx is even and the arrays are 16-byte aligned, else 1; 4, 2 or 1 rows per lane by the box's height)
+    if (t.variant || t.zc || t.xcd_remap >= 0 || t.ry || t.nt >= 0 || t.vx) return hipErrorInvalidValue;
+#else
     if (variant == 1) {
         const dim3 grid((wx + 63) / 64, (wy + 3) / 4, wz);
         const size_t nb = (size_t)grid.x * grid.y * grid.z;
@@ -83,6 +88,7 @@ static inline hipError_t diff3_launch(Diff3Args a, bool norm, const Diff3Tuning&
         *nparts = (int)nb;
         return hipGetLastError();
     }
+#endif
     if (variant < 2 || variant > 5) return hipErrorInvalidValue;
     bool pipe = variant >= 4;  // 4 = variant 2 + ring pipeline, 5 = variant 3 + ring pipeline
     const bool ldsy = (variant == 3 || variant == 5);
@@ -125,7 +131,16 @@ static inline hipError_t diff3_launch(Diff3Args a, bool norm, const Diff3Tuning&
         // geometry runs the exact kernel below
         if (norm) k_diff3_march<2, 4, true, true, true, true, true><<<(int)nblk, 256, 0, stream>>>(a);
         else k_diff3_march<2, 4, false, true, true, true, true><<<(int)nblk, 256, 0, stream>>>(a);
-    } else if (pipe && vx == 2 && (ry == 4 || ry == 2)) {
+    }
+#ifndef FPR_TUNE
+    else if (vx == 2 && ry == 4) { if (norm) k_diff3_march<2, 4, true, true, true, true><<<(int)nblk, 256, 0, stream>>>(a); else k_diff3_march<2, 4, false, true, true, true><<<(int)nblk, 256, 0, stream>>>(a); }
+    else if (vx == 2 && ry == 2) { if (norm) k_diff3_march<2, 2, true, true, true, true><<<(int)nblk, 256, 0, stream>>>(a); else k_diff3_march<2, 2, false, true, true, true><<<(int)nblk, 256, 0, stream>>>(a); }
+    else if (vx == 2) diff3_march_go<2, 1, true, true>(a, norm, (int)nblk, stream);
+    else if (ry == 4) diff3_march_go<1, 4, true, true>(a, norm, (int)nblk, stream);
+    else if (ry == 2) diff3_march_go<1, 2, true, true>(a, norm, (int)nblk, stream);
+    else diff3_march_go<1, 1, true, true>(a, norm, (int)nblk, stream);
+#else
+    else if (pipe && vx == 2 && (ry == 4 || ry == 2)) {
         if (ry == 4) diff3_pipe_go<4>(a, norm, ldsy, nt, (int)nblk, stream);
         else diff3_pipe_go<2>(a, norm, ldsy, nt, (int)nblk, stream);
     } else if (vx == 2) {
@@ -137,6 +152,7 @@ static inline hipError_t diff3_launch(Diff3Args a, bool norm, const Diff3Tuning&
         else if (ry == 2) diff3_march_go2<1, 2>(a, norm, ldsy, nt, (int)nblk, stream);
         else diff3_march_go2<1, 1>(a, norm, ldsy, nt, (int)nblk, stream);
     }
+#endif
     *nparts = (int)nblk;
     return hipGetLastError();
 }

@@ -69,9 +69,6 @@ struct FprLevel {  // one multigrid level's scratch (role of prealloc_dict, mult
     double* coarse_own[3] = {nullptr, nullptr, nullptr};   // the library's own three while the caller's stand in (they come back as they were)
 };
 
-#ifndef FPR_SEAM_COLS_DEFAULT
-#define FPR_SEAM_COLS_DEFAULT 2    // columns per lane of the seam pass (option mg_seam_cols: 2 = k_seam_march_v3)
-#endif
 #ifndef FPR_FOLD_FINISH_DEFAULT
 #define FPR_FOLD_FINISH_DEFAULT 1  // the finish of cycle k (norm, exit test, record) runs in an extra workgroup row of cycle k+1's first pass below the finest
                                    // level instead of a launch of its own between the two (option mg_fold_finish)
@@ -79,20 +76,6 @@ struct FprLevel {  // one multigrid level's scratch (role of prealloc_dict, mult
 #ifndef FPR_FOLD_FSQ_DEFAULT
 #define FPR_FOLD_FSQ_DEFAULT 1     // sum(f.^2) (f_rms, multigrid.jl:53) as block partials of the solve's first pass over the finest grid instead of a pass of
                                    // its own over f (option mg_fold_fsq)
-#endif
-#ifndef FPR_MID4_DEFAULT
-#define FPR_MID4_DEFAULT 0         // the level above k_mid_down's three rides along in its prologue (option mg_mid4): bit-exact, measured 3-4 us per cycle
-                                   // SLOWER than that level's own pass (3.8x redundant recomputation in LDS against a 10 us pass + a launch boundary)
-#endif
-#ifndef FPR_CG_TAGGED_DEFAULT
-#define FPR_CG_TAGGED_DEFAULT 0    // k_cg_persistent: tile-edge values of r as data-tagged granules (option cg_tagged_edges): measured 6.01 against
-                                   // 5.83 us per iteration -- the loads in flight in front of barrier 2 lengthen its poll by more than they save behind it
-#endif
-#ifndef FPR_JACP_TAGGED_DEFAULT
-#define FPR_JACP_TAGGED_DEFAULT 1  // k_jacobi_persist_tag (data-tagged hand-offs) instead of k_jacobi_persist (flags); option mg_jacp_tagged
-#endif
-#ifndef FPR_JACP_PY_DEFAULT
-#define FPR_JACP_PY_DEFAULT 1      // rows of a thread's register patch in k_jacobi_persist (option mg_jacp_py)
 #endif
 
 struct FprGrid {  // implicit global grid of the decomposed diffusion path (role of ImplicitGlobalGrid's global state)
@@ -140,15 +123,9 @@ struct fpr_ctx {
     int* tickets = nullptr;            // 9 counters of the ticketed reserved form (Diff3Args2::ticket), zero between launches
     unsigned* reserved_map = nullptr;  // 2048 bits, one per (XCC, SE, SH, CU) key: the comm stream's compute units (fpr_reserve_comm_cus), found by a probe launch
     bool core_unmasked = false;        // the core stream has every unit; workgroups of a core launch that land on a comm unit leave at once
-    int cgp_resident = -1;             // k_cg_persistent: 16 workgroups of 1024 threads resident together? (-1 = not asked yet)
     int cgp_resident64 = -1;      // the same for the 64-workgroup geometry of k_cg_persistent
     int jacp_resident = -1;       // k_jacobi_persist: workgroups of 256 threads the device holds at once (-1 = not asked yet)
-    hipStream_t aux_stream = nullptr;  // k_jacobi_persist_tag: the exit tests of a launch run here, beside the next launch
-    hipEvent_t aux_ev[3] = {nullptr, nullptr, nullptr};   // [0] compute -> side stream; [1], [2] the tests of even / odd launches
     long long jacp_epoch = 0;          // k_jacobi_persist_tag: solves so far (upper half of every granule's tag)
-    void* pyr_buf = nullptr;           // k_pyr_down: the right-hand sides of three levels as granules
-    size_t pyr_cap = 0;
-    long long pyr_epoch = 0;           // k_pyr_down: launches so far * 4 (a level's granules carry epoch + level)
     int jacp_resident_key = 0;         // (sweeps per group * 10 + patch rows) the occupancy answer above belongs to
     double* partials = nullptr;     // FPR_MAX_PARTIALS doubles: block partial sums (slot 0)
     double* partials2 = nullptr;    // second slot (comm stream / second reduction of a kernel)

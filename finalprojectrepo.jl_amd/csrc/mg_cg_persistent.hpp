@@ -38,8 +38,6 @@ struct CgpArgs {
     double ihx2, ihy2;     // pow2: 1 / hx2, 1 / hy2 (exact)
     int pow2;              // hx2 and hy2 are powers of two (every grid of the multigrid hierarchy: h = 2^-k): x / hx2 == x * (1 / hx2) bit for
                            // bit -- an exact scaling either way -- and the operator needs no division (two per point: ~0.4 us per iteration)
-    long long* prof;       // diagnostic (option cg_prof = device address of 8 int64): ticks of workgroup 0 per section, summed
-    long long tag_base;    // != 0 (option cg_tagged_edges, default): the tile-edge values of r travel as 16-byte granules {value, tag = tag_base +
                            // iteration} through r_glob (2 N doubles): one sc1 store, one sc1 load issued BEFORE barrier 2 and checked behind
                            // it -- no drain in front of the barrier words, no load round trip behind them (k_jacobi_persist_tag's hand-off)
     int fences;            // option handoff_fences = 1: the hand-off of the r edges ALSO inside the HIP memory model -- an agent-scope release
@@ -102,7 +100,7 @@ __device__ __forceinline__ double cgp_allsum(unsigned long long* slots, unsigned
     }
     // wave totals in LDS; the workgroup's earlier sc1 stores (tile-edge values of r) have left every wave before the barrier, the
     // barrier words are published behind it
-    if constexpr (DRAIN) { if (drain) __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0) (not with tagged edges: nothing waits for the stores)
+    if constexpr (DRAIN) { if (drain) __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0)
     __syncthreads();
     if (threadIdx.x < 64) {                // wave 0 sums the workgroup, publishes, polls and sums the grid
         const int w = threadIdx.x;
@@ -183,10 +181,6 @@ __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
     double* P = sm;                                // (thm + 2) x lw image of p: tile cell (ti, tj) at (ti + 1) + lw * (tj + 1)
     const __amdgpu_buffer_rsrc_t rR = fpr_rsrc(a.r_glob);   // tile-edge values of r (sc1 stores / loads)
     unsigned gen = 0;
-    const bool tagged = a.tag_base != 0;   // (uniform)
-    fpr_u4v rq[CGP_RPT];
-#pragma unroll
-    for (int m = 0; m < CGP_RPT; ++m) { rq[m].x = 0; rq[m].y = 0; rq[m].z = 0; rq[m].w = 0; }
     unsigned long long* slots = reinterpret_cast<unsigned long long*>(a.part);   // 4 sets x 16 slots, all EMPTY at the start
     bool ok = true;
     if (tid == 0) s_abort = 0;
@@ -246,10 +240,6 @@ __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
         rr = rho;
     }
     const double thresh = a.tol * sqrt(rho);
-    long long tsec[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
-    const bool prof = a.prof != nullptr && blockIdx.x == 0 && tid == 0;
-    auto lap = [&](int k) { if (prof) { const long long t = wall_clock64(); tsec[k] += t - tprev; tprev = t; } };
-    if (prof) tprev = wall_clock64();
     for (; alive && it < a.Nmax; ++it) {
         // ---- exit test and beta of iteration it-1 (krylov.jl:73-84), new direction (:85), operator and p.p_hat (:68-69) ----
         double beta = 0.0;
@@ -260,28 +250,9 @@ __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
             rho = rr;
 #pragma unroll
             for (int k = 0; k < CGP_PPT; ++k) p[k] = r[k] + beta * p[k];
-            if (tagged) {
-                // the granules were loaded in front of barrier 2; one whose tag is not this iteration's yet is loaded again until it is
-                const unsigned long long want = (unsigned long long)(a.tag_base + it);
 #pragma unroll
-                for (int m = 0; m < CGP_RPT; ++m) {
-                    if (rg[m] >= 0) {
-                        unsigned spins = 0;
-                        while ((((unsigned long long)rq[m].w << 32) | rq[m].z) != want) {
-                            rq[m] = __builtin_amdgcn_raw_buffer_load_b128(rR, (unsigned)rg[m] * 16u, 0, CGP_SC1);
-                            if ((++spins & 0xff) == 0) {
-                                if (__hip_atomic_load(&a.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                                if (spins > (1u << 20)) { __hip_atomic_store(&a.ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                            }
-                        }
-                        p_ring[m] = __builtin_bit_cast(double, ((unsigned long long)rq[m].y << 32) | rq[m].x) + beta * p_ring[m];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int m = 0; m < CGP_RPT; ++m)   // sc1 loads behind barrier 2 (its poll, then the workgroup barrier)
-                    if (rg[m] >= 0) p_ring[m] = cgp_ld_sc1(rR, (unsigned)rg[m] * 8u) + beta * p_ring[m];
-            }
+            for (int m = 0; m < CGP_RPT; ++m)   // sc1 loads behind barrier 2 (its poll, then the workgroup barrier)
+                if (rg[m] >= 0) p_ring[m] = cgp_ld_sc1(rR, (unsigned)rg[m] * 8u) + beta * p_ring[m];
         }
 #pragma unroll
         for (int k = 0; k < CGP_PPT; ++k)
@@ -290,7 +261,6 @@ __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
         for (int m = 0; m < CGP_RPT; ++m)
             if (rl[m] >= 0) P[rl[m]] = p_ring[m];
         __syncthreads();
-        lap(0);   // beta, new p, ring loads, LDS image
         double acc = 0.0, acce = 0.0;
 #pragma unroll
         for (int k = 0; k < CGP_PPT; ++k) {
@@ -302,10 +272,8 @@ __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
             }
             if (gi[k] >= 0) fpr_s2_add_prod(acc, acce, p[k], q[k]);
         }
-        lap(1);   // operator
         const double pq = cgp_allsum<false, CGP_NB, CGP_NT>(slots, &a.ctr[1], acc, acce, gen, red, fold, &gsum, &s_abort, &ok);   // barrier 1 of the iteration
         if (!ok) { alive = false; break; }
-        lap(3);   // barrier 1
         // ---- alpha, x and r (krylov.jl:69-72), r.r; the tile-edge values of r go to the neighbours ----
         const double alpha = rho / pq;
         double acc2 = 0.0, acc2e = 0.0;
@@ -316,30 +284,13 @@ __global__ __launch_bounds__(CGP_NT) void k_cg_persistent(CgpArgs a)
                 const double rn = r[k] - alpha * q[k];
                 r[k] = rn;
                 fpr_s2_add_prod(acc2, acc2e, rn, rn);
-                if (edge[k]) {
-                    if (tagged) {
-                        const unsigned long long v = __builtin_bit_cast(unsigned long long, rn), tg = (unsigned long long)(a.tag_base + it + 1);
-                        fpr_u4v q;
-                        q.x = (unsigned)v; q.y = (unsigned)(v >> 32); q.z = (unsigned)tg; q.w = (unsigned)(tg >> 32);
-                        __builtin_amdgcn_raw_buffer_store_b128(q, rR, (unsigned)gi[k] * 16u, 0, CGP_SC1);
-                    } else {
-                        cgp_st_sc1(rR, (unsigned)gi[k] * 8u, rn);   // write-through; drained before barrier 2 publishes (an atomic
-                    }                                                // store each would be issued behind an s_waitcnt of its own)
-                }
+                if (edge[k]) cgp_st_sc1(rR, (unsigned)gi[k] * 8u, rn);   // write-through; drained before barrier 2 publishes (an atomic
+                                                                          // store each would be issued behind an s_waitcnt of its own)
             }
         }
-        if (tagged) {   // the neighbours' edge values of this iteration: asked for now, looked at behind barrier 2
-#pragma unroll
-            for (int m = 0; m < CGP_RPT; ++m)
-                rq[m] = __builtin_amdgcn_raw_buffer_load_b128(rR, rg[m] >= 0 ? (unsigned)rg[m] * 16u : FPR_OOR, 0, CGP_SC1);
-        }
-        lap(4);   // update
-        rr = cgp_allsum<true, CGP_NB, CGP_NT>(slots, &a.ctr[1], acc2, acc2e, gen, red, fold, &gsum, &s_abort, &ok, a.fences, !tagged);   // barrier 2 (publishes the r edges)
+        rr = cgp_allsum<true, CGP_NB, CGP_NT>(slots, &a.ctr[1], acc2, acc2e, gen, red, fold, &gsum, &s_abort, &ok, a.fences, true);   // barrier 2 (publishes the r edges)
         if (!ok) { alive = false; break; }
-        lap(5);   // barrier 2
     }
-    if (prof)
-        for (int k = 0; k < 6; ++k) a.prof[k] += tsec[k];
     if (alive && !conv && it == a.Nmax && a.Nmax > 0) conv = sqrt(rr) < thresh;   // the loop ran out: the last norm (k_cg_tail_f)
 #pragma unroll
     for (int k = 0; k < CGP_PPT; ++k)

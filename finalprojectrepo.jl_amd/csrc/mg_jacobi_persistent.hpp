@@ -36,191 +36,6 @@ struct JacPersistArgs {
 
 constexpr int JACP_SC1 = 16;   // cache-policy bit sc1 of the raw buffer intrinsics (gfx94x / gfx950)
 
-// PY = rows of a thread's register patch (2 columns wide): 2 = 2 x 2 patches, 256 threads, one wave per SIMD; 1 = 2 x 1 patches, 512
-// threads, two waves per SIMD (a sweep is a chain of dependent FP64 operations behind an LDS round trip and a barrier: a second wave
-// per SIMD fills the gaps of the first)
-template <int S, int P, int PY = 2>
-__global__ __launch_bounds__((P / 2) * (P / PY)) void k_jacobi_persist(JacPersistArgs a)
-{
-    constexpr int T = P - 2 * S;
-    constexpr int HT = P / 2;
-    constexpr int NT = HT * (P / PY), NWV = (NT + 63) / 64;
-    static_assert(T > 0 && P % 2 == 0 && HT == 16 && (PY == 1 || PY == 2), "32 x 32 regions: a row of threads is one 16-lane DPP row");
-    __shared__ __attribute__((aligned(16))) double img[2][P * P];
-    __shared__ double red[NWV][S];
-    __shared__ int s_abort;
-    if (a.state->done) return;    // a launch enqueued behind the group that met the criterion
-    const int tid = threadIdx.x;
-    const int nx = a.nx, ny = a.ny;
-    const int ty = tid / HT, tx = tid - ty * HT;
-    const int lx = 2 * tx, ly = PY * ty;
-    const int x0 = blockIdx.x * T, y0 = blockIdx.y * T;
-    const int gx = x0 - S + lx, gy = y0 - S + ly;
-    const int blk = blockIdx.x + gridDim.x * blockIdx.y, nblk = gridDim.x * gridDim.y;
-    double ff[PY][2];
-    bool inter[PY][2], own[PY][2];
-    unsigned voff[PY][2], vst[PY][2];
-#pragma unroll
-    for (int b = 0; b < PY; ++b)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int gi = gx + c, gj = gy + b;
-            const bool in = gi >= 0 && gj >= 0 && gi < nx && gj < ny;
-            const size_t g = in ? (size_t)gi + (size_t)nx * gj : 0;
-            ff[b][c] = in ? a.rhs[g] : 0.0;
-            inter[b][c] = gi >= 1 && gj >= 1 && gi < nx - 1 && gj < ny - 1;
-            own[b][c] = in && gi >= x0 && gi < x0 + T && gj >= y0 && gj < y0 + T;
-            voff[b][c] = in ? (unsigned)g * 8u : FPR_OOR;        // outside the grid: the load is dropped and returns 0
-            vst[b][c] = own[b][c] ? (unsigned)g * 8u : FPR_OOR;
-        }
-    // the (up to) eight neighbours whose tiles this region reads: lanes 0..7 of wave 0 watch one flag each
-    int nb = -1;
-    if (tid < 8) {
-        const int k = tid < 4 ? tid : tid + 1;                    // 0..8 without the centre
-        const int bx = (int)blockIdx.x + k % 3 - 1, by = (int)blockIdx.y + k / 3 - 1;
-        if (bx >= 0 && by >= 0 && bx < (int)gridDim.x && by < (int)gridDim.y) nb = bx + (int)gridDim.x * by;
-    }
-    const int xl = lx > 0 ? lx - 1 : lx, xr = lx + 2 < P ? lx + 2 : lx + 1;
-    const int yd = ly > 0 ? ly - 1 : ly, yu = ly + PY < P ? ly + PY : ly + PY - 1;
-    (void)xl; (void)xr;
-    if (tid == 0) s_abort = 0;
-    bool alive = true;
-    long long pd0 = 0, pd1 = 0, pd2 = 0, pd3 = 0, pd4 = 0, pt = 0;
-    const bool prof = a.prof != nullptr;          // (uniform)
-    for (int g = 0; g < a.ngroups && alive; ++g) {
-        const double* in = g == 0 ? a.X : a.W[g % 3];
-        double* out = a.W[(g + 1) % 3];
-        if (prof) pt = wall_clock64();
-        if (g > 0) {
-            if (tid < 64) {
-                int ab = 0;
-                if (nb >= 0) {
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(a.flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.g0 + g) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if ((++spins & 0x3ff) == 0) {
-                            if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
-                            if (spins > (1u << 21)) {   // seconds: a neighbour that never became resident
-                                __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                ab = 1;
-                                break;
-                            }
-                        }
-                    }
-                }
-                ab = __any(ab);
-                asm volatile("" ::: "memory");       // the region's sc1 loads stay behind the poll
-                if (a.fences) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                if (tid == 0 && ab) s_abort = 1;
-            }
-            __syncthreads();
-            if (s_abort) { alive = false; break; }
-        }
-        if (prof) { const long long t = wall_clock64(); pd0 += t - pt; pt = t; }
-        const __amdgpu_buffer_rsrc_t rIn = fpr_rsrc(in), rOut = fpr_rsrc(out);
-        const int nsw = (g == a.ngroups - 1) ? a.nsw_last : S;
-        double u[PY][2];
-#pragma unroll
-        for (int b = 0; b < PY; ++b)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-                u[b][c] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rIn, voff[b][c], 0, JACP_SC1));
-        double acc[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) acc[s] = 0.0;
-        {
-            double* w = img[0];
-#pragma unroll
-            for (int b = 0; b < PY; ++b) *reinterpret_cast<double2*>(&w[lx + P * (ly + b)]) = make_double2(u[b][0], u[b][1]);
-        }
-        __syncthreads();
-        if (prof) { const long long t = wall_clock64(); pd1 += t - pt; pt = t; }
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (s < nsw) {
-                const double* cur = img[s & 1];
-                double* nxt = img[(s + 1) & 1];
-                // x-neighbours of a patch from the adjacent lanes' registers (zero beyond the region's edge: such garbage stays more
-                // than S cells away from the own tile), y-neighbours from the LDS image
-                double E[PY][2], Wv[PY][2], Nn[PY][2], Sx[PY][2];
-#pragma unroll
-                for (int b = 0; b < PY; ++b) {
-                    E[b][0] = u[b][1]; E[b][1] = fpr_dpp<0x101>(u[b][0]);
-                    Wv[b][0] = fpr_dpp<0x111>(u[b][1]); Wv[b][1] = u[b][0];
-                }
-                const double2 dn = *reinterpret_cast<const double2*>(&cur[lx + P * yd]);
-                const double2 up = *reinterpret_cast<const double2*>(&cur[lx + P * yu]);
-#pragma unroll
-                for (int b = 0; b < PY; ++b) {
-                    Nn[b][0] = b == PY - 1 ? up.x : u[b == PY - 1 ? b : b + 1][0];
-                    Nn[b][1] = b == PY - 1 ? up.y : u[b == PY - 1 ? b : b + 1][1];
-                    Sx[b][0] = b == 0 ? dn.x : u[b == 0 ? 0 : b - 1][0];
-                    Sx[b][1] = b == 0 ? dn.y : u[b == 0 ? 0 : b - 1][1];
-                }
-                double un[PY][2];
-#pragma unroll
-                for (int b = 0; b < PY; ++b)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const double rr = ((((E[b][c] + Wv[b][c]) + Nn[b][c]) + Sx[b][c]) - a.C * u[b][c]) * a._h2 - ff[b][c];
-                        un[b][c] = inter[b][c] ? u[b][c] + a.fac * rr : u[b][c];
-                        if (inter[b][c] && own[b][c]) acc[s] += rr * rr;
-                    }
-#pragma unroll
-                for (int b = 0; b < PY; ++b)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) u[b][c] = un[b][c];
-#pragma unroll
-                for (int b = 0; b < PY; ++b) *reinterpret_cast<double2*>(&nxt[lx + P * (ly + b)]) = make_double2(u[b][0], u[b][1]);
-            }
-            __syncthreads();
-        }
-        if (prof) { const long long t = wall_clock64(); pd2 += t - pt; pt = t; }
-        // the own tile, write-through; its stores have left every wave before the flag is published behind the workgroup barrier
-#pragma unroll
-        for (int b = 0; b < PY; ++b)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fpr_u2v, u[b][c]), rOut, vst[b][c], 0, JACP_SC1);
-        {
-            const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const double v = fpr_wave_sum_all(acc[s]);
-                if (lane == 0) red[wv][s] = v;
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-        __syncthreads();
-        if (prof) { const long long t = wall_clock64(); pd3 += t - pt; pt = t; }
-        if (tid < S) {
-            double v = red[0][tid];
-#pragma unroll
-            for (int w = 1; w < NWV; ++w) v += red[w][tid];
-            a.partials[((size_t)g * S + tid) * nblk + blk] = v;     // read by k_jacobi_check_groups behind the launch
-        }
-        if (tid == 0) {
-            if (a.fences) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            asm volatile("" ::: "memory");           // the tile's stores (drained above, behind the workgroup barrier) stay in front of the flag
-            __hip_atomic_store(a.flags + blk, a.g0 + g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // (red / img are rewritten only behind the next group's barriers)
-        if (prof) { const long long t = wall_clock64(); pd4 += t - pt; pt = t; }
-    }
-    if (prof && tid == 0) {
-        long long* q = a.prof + (size_t)blk * 8;
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        q[0] += pd0; q[1] += pd1; q[2] += pd2; q[3] += pd3; q[4] += pd4; q[5] += a.ngroups; q[6] = (long long)(xcc & 7u);
-    }
-}
-
 // ================================================================================================================================
 // k_jacobi_persist_tag: the same groups of sweeps, but the hand-off between neighbours is the DATA itself.
 //

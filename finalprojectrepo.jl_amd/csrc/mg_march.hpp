@@ -37,176 +37,12 @@ __device__ __forceinline__ void fpr_bst(__amdgpu_buffer_rsrc_t r, unsigned voff,
 // the zero initial coarse correction (multigrid.jl:128-132): the residual/restriction pass disappears
 // too.  Strips then overlap by 6 columns and chunks by 3+2 rows.  Coarse boundary points get 0; the
 // Neumann rows of apply_BCs are copied afterwards by k_bc_neumann on the (small) coarse array.
-template <bool NORM, bool PROLONG, bool RESTRICT>
-__global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict__ uin, const double* __restrict__ f,
-                                                        double* __restrict__ uout, int nx, int ny, double C, double _h2,
-                                                        double fac, int rows_per_chunk, int nstrips,
-                                                        double* __restrict__ partials, const double* __restrict__ corr_c,
-                                                        int apply_BCs, double* __restrict__ res_c_out,
-                                                        double* __restrict__ corr_c_out, const int* __restrict__ skip)
-{
-    if (skip && *skip) return;   // a cycle enqueued ahead of the exit test that ended the loop (FprCycleCtl)
-    __shared__ double red[16];
-    constexpr int HX = RESTRICT ? 3 : 2;                     // feeder lanes on each side of a strip
-    constexpr int SW = 64 - 2 * HX;                          // columns owned by a strip
-    apply_BCs &= 255;                                        // (bit 8, non-temporal stores, is ignored by this kernel)
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int strip = blockIdx.x * 4 + w;
-    const bool active = strip < nstrips;
-    const int gi = strip * SW - HX + lane;                   // global column of this lane
-    const bool col_ok = active && gi >= 0 && gi < nx;
-    const int gic = gi < 0 ? 0 : (gi > nx - 1 ? nx - 1 : gi);  // clamped for loads
-    const bool col_bnd = gi <= 0 || gi >= nx - 1;            // domain boundary column (or outside)
-    const bool owner = col_ok && lane >= HX && lane < 64 - HX;
-    const int y0 = blockIdx.y * rows_per_chunk;
-    const int y1 = (y0 + rows_per_chunk < ny) ? y0 + rows_per_chunk : ny;  // output rows [y0, y1)
-    const int rs = y0 - HX < 0 ? 0 : y0 - HX;
-    double acc = 0.0;
-    if (active) {
-        const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
-        int gis = gic;  // Neumann rows of the prolongated correction (part2_utils.jl:35-39)
-        if (PROLONG && apply_BCs) gis = (gic == 0) ? 1 : (gic == nx - 1 ? nx - 2 : gic);
-        // PROLONG: the two coarse columns this lane interpolates from, cached for coarse rows pj and pj+1
-        // (rows are visited in increasing order, so a coarse row is loaded once per two fine rows)
-        const int p_io = gis & 1, p_icl = gis >> 1, p_ich = (p_icl + 1 < nxc) ? p_icl + 1 : nxc - 1;
-        const bool p_sx0 = p_icl >= 1 && p_icl <= nxc - 2, p_sx1 = p_io && (p_icl + 1 <= nxc - 2);
-        const bool p_inx = gis >= 1 && gis <= nx - 2;
-        int pj = -2;
-        double pc00 = 0.0, pc10 = 0.0, pc01 = 0.0, pc11 = 0.0;
-        // rows are addressed relative to the first row of the chunk: (rows_per_chunk + 8) * nx * 8 < 2^31
-        const int rowB = nx * 8;
-        const __amdgpu_buffer_rsrc_t rUin = fpr_rsrc(uin + (size_t)nx * rs), rF = fpr_rsrc(f + (size_t)nx * rs);
-        const __amdgpu_buffer_rsrc_t rUout = fpr_rsrc(uout + (size_t)nx * rs);
-        const unsigned vld = (unsigned)gic * 8u;
-        const unsigned vst = owner ? (unsigned)gi * 8u : FPR_OOR;   // lanes that own nothing store out of range
-        auto ldu = [&](int r) {
-            const int rc = r > ny - 1 ? ny - 1 : r;
-            const double v = fpr_bld(rUin, vld, (rc - rs) * rowB);
-            if constexpr (PROLONG) {
-                const int jo = rc & 1, jcl = rc >> 1;
-                if (jcl != pj) {
-                    const int jch = (jcl + 1 < nyc) ? jcl + 1 : nyc - 1;
-                    if (jcl == pj + 1) { pc00 = pc01; pc10 = pc11; }
-                    else { pc00 = corr_c[(size_t)p_icl + (size_t)nxc * jcl]; pc10 = corr_c[(size_t)p_ich + (size_t)nxc * jcl]; }
-                    pc01 = corr_c[(size_t)p_icl + (size_t)nxc * jch];
-                    pc11 = corr_c[(size_t)p_ich + (size_t)nxc * jch];
-                    pj = jcl;
-                }
-                // same value and accumulation order as prolong_bf
-                const bool in = p_inx && rc >= 1 && rc <= ny - 2;
-                const double wgt = (p_io | jo) ? ((p_io & jo) ? 0.25 : 0.5) : 1.0;
-                const bool sy0 = jcl >= 1 && jcl <= nyc - 2, sy1 = jo && (jcl + 1 <= nyc - 2);
-                double pv = 0.0;
-                pv = pv + ((in && p_sx0 && sy0) ? wgt * pc00 : 0.0);
-                pv = pv + ((in && p_sx1 && sy0) ? wgt * pc10 : 0.0);
-                pv = pv + ((in && p_sx0 && sy1) ? wgt * pc01 : 0.0);
-                pv = pv + ((in && p_sx1 && sy1) ? wgt * pc11 : 0.0);
-                return v - pv;
-            } else {
-                return v;
-            }
-        };
-        auto ldf = [&](int r) { const int rc = r > ny - 1 ? ny - 1 : r; return fpr_bld(rF, vld, (rc - rs) * rowB); };
-        double a0 = 0.0, a1 = 0.0, a2 = ldu(rs);       // u   rows r-2, r-1, r
-        double b0 = 0.0, b1 = 0.0, b2 = 0.0;           // u1  rows r-3, r-2, r-1
-        double f0 = 0.0, f1 = 0.0, f2 = ldf(rs);       // f   rows r-2, r-1, r
-        double c0 = 0.0, c1 = 0.0, c2 = 0.0, fm = 0.0; // RESTRICT: u2 rows r-4, r-3, r-2 and f row r-3
-        // software pipeline: rows r+1 .. r+PF are in flight (PF loads of u and of f per lane)
-        constexpr int PF = 4;
-        double pu[PF], pfv[PF];
-#pragma unroll
-        for (int q = 0; q < PF; ++q) { pu[q] = ldu(rs + 1 + q); pfv[q] = ldf(rs + 1 + q); }
-        const int nxc_r = 1 + (nx - 1) / 2, nyc_r = 1 + (ny - 1) / 2;
-        // RESTRICT: coarse arrays (whole-array descriptors: nxc * nyc * 8 < 2^31), even owned columns only
-        const __amdgpu_buffer_rsrc_t rResC = fpr_rsrc(res_c_out), rCorC = fpr_rsrc(corr_c_out);
-        const unsigned vstc = (RESTRICT && owner && !(gi & 1)) ? (unsigned)(gi >> 1) * 8u : FPR_OOR;
-        // RESTRICT with apply_BCs: the coarse right-hand side gets its Neumann columns here (part2_utils.jl:35-39 as applied
-        // at multigrid.jl:355-357: column 0 = column 1, column nxc-1 = column nxc-2) -- the lanes of coarse columns 1 and
-        // nxc-2 store their value a second time, the lanes of columns 0 and nxc-1 do not store theirs
-        const bool nbc = RESTRICT && apply_BCs != 0;
-        const unsigned vstr = (nbc && (gi == 0 || gi == nx - 1)) ? FPR_OOR : vstc;
-        const unsigned vstn = (nbc && owner && (gi == 2 || gi == nx - 3)) ? (gi == 2 ? 0u : (unsigned)(nxc_r - 1) * 8u) : FPR_OOR;
-        // The ring slot is a compile-time constant (the row loop is unrolled by PF): a slot is consumed and
-        // refilled in place, so no register of an in-flight load is ever copied (a copy would make hipcc wait
-        // for that load) and PF rows stay in flight per lane.
-        auto step = [&](auto Qc, int r) {
-            constexpr int Q = decltype(Qc)::value;
-            // An explicit register copy of the (completed) row ends the live range of the slot, so the refill below
-            // can target the slot's own registers and nothing in flight has to be copied at the loop's back edge.
-            double an, fn;
-            asm volatile("v_mov_b64 %0, %1" : "=v"(an) : "v"(pu[Q]));
-            asm volatile("v_mov_b64 %0, %1" : "=v"(fn) : "v"(pfv[Q]));
-            pu[Q] = ldu(r + 1 + PF);                           // issue the loads of row r+1+PF
-            pfv[Q] = ldf(r + 1 + PF);
-            // ---- sweep 1 at row r-1 (needs u rows r-2, r-1, r) ----
-            const int j1 = r - 1;
-            double u1;
-            {
-                const double L = fpr_lane_up1z(a1), R = fpr_lane_down1z(a1);
-                const double rr = ((((R + L) + a2) + a0) - C * a1) * _h2 - f1;
-                const bool bnd = col_bnd || j1 <= 0 || j1 >= ny - 1;
-                u1 = bnd ? a1 : a1 + fac * rr;
-            }
-            b0 = b1; b1 = b2; b2 = u1;                 // u1 rows r-3, r-2, r-1
-            // ---- sweep 2 at row r-2 (needs u1 rows r-3, r-2, r-1) ----
-            const int j2 = r - 2;
-            {
-                const double L = fpr_lane_up1z(b1), R = fpr_lane_down1z(b1);
-                const double rr = ((((R + L) + b2) + b0) - C * b1) * _h2 - f0;
-                const bool bnd = col_bnd || j2 <= 0 || j2 >= ny - 1;
-                const double u2 = bnd ? b1 : b1 + fac * rr;
-                const bool row_own = j2 >= y0 && j2 < y1;        // uniform
-                fpr_bst(rUout, vst, row_own ? (j2 - rs) * rowB : (int)FPR_OOR, u2);   // unconditional (see FPR_OOR)
-                if constexpr (NORM) {
-                    if (owner && row_own && !bnd) acc += rr * rr;
-                }
-                if constexpr (RESTRICT) {
-                    c0 = c1; c1 = c2; c2 = u2;         // u2 rows r-4, r-3, r-2
-                }
-            }
-            if constexpr (RESTRICT) {
-                // ---- residual of u2 at row r-3, injected at even (row, column) ----
-                const int j3 = r - 3;
-                const double L = fpr_lane_up1z(c1), R = fpr_lane_down1z(c1);
-                const double rr = ((((R + L) + c2) + c0) - C * c1) * _h2 - fm;
-                {
-                    const int ic = gi >> 1, jc = j3 >> 1;
-                    const bool cint = ic >= 1 && ic <= nxc_r - 2 && jc >= 1 && jc <= nyc_r - 2;
-                    const bool row_inj = j3 >= y0 && j3 < y1 && !(j3 & 1);   // uniform
-                    const int sc = row_inj ? jc * (nxc_r * 8) : (int)FPR_OOR;
-                    fpr_bst(rResC, vstr, sc, cint ? rr : 0.0);
-                    fpr_bst(rResC, vstn, sc, cint ? rr : 0.0);
-                    fpr_bst(rCorC, vstc, sc, 0.0);
-                }
-                fm = f0;                               // becomes f row (r+1)-3
-            }
-            a0 = a1; a1 = a2; a2 = an;
-            f0 = f1; f1 = f2; f2 = fn;
-        };
-        const int rend = y1 + (RESTRICT ? 2 : 1);
-        int r = rs;
-        static_assert(PF == 4, "the unrolled row loop below is written for PF = 4 (PF = 8 measured 12 % slower)");
-        for (; r + PF - 1 <= rend; r += PF) {
-            step(std::integral_constant<int, 0>{}, r);
-            step(std::integral_constant<int, 1>{}, r + 1);
-            step(std::integral_constant<int, 2>{}, r + 2);
-            step(std::integral_constant<int, 3>{}, r + 3);
-        }
-        if (r <= rend) { step(std::integral_constant<int, 0>{}, r); ++r; }
-        if (r <= rend) { step(std::integral_constant<int, 1>{}, r); ++r; }
-        if (r <= rend) { step(std::integral_constant<int, 2>{}, r); ++r; }
-    }
-    if constexpr (NORM) {
-        const double sblk = fpr_block_sum<256>(acc, red);
-        if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
-    }
-}
-
+//
 // ---- the seam between two V-cycles on the finest level: FOUR sweeps in one pass ------------------------------
 // MGsolve_2DPoisson! (multigrid.jl:57-71) runs V-cycle after V-cycle on the same arrays: the post-smoothing pair of
 // cycle k (:142-143, on the field corrected by the prolongated coarse solution, :136-139) is followed -- if the exit
 // test :70 does not end the loop -- by the pre-smoothing pair of cycle k+1 (:124-125) and its residual + injection
-// (:128-132).  k_seam_march does all of that in ONE pass over the finest grid: the same register-rolling march as
+// (:128-132).  The seam kernels (k_seam_march_v2 / _v3) do all of that in ONE pass over the finest grid: the same register-rolling march as
 // k_smooth2_march with five 3-row windows (the corrected input, the fields after sweeps 1..4) and a residual stage,
 //     read  uin (+ P(corr_c) on the fly), f                          (8 + 8 + 2 bytes per point)
 //     write the twice pre-smoothed field of cycle k+1, its restricted residual, the zero coarse guess   (8 + 2 + 2)
@@ -218,166 +54,8 @@ __global__ __launch_bounds__(256) void k_smooth2_march(const double* __restrict_
 // between two cycles (:60-62) act on the field between sweep 2 and sweep 3 (Neumann columns; see below), the correction
 // is prolongated with its Neumann rows, and the host copies the Neumann columns of the coarse residual afterwards
 // (k_bc_neumann, as behind the separate pre-smoothing pass).
-template <bool BCS>
-__global__ __launch_bounds__(256) void k_seam_march(const double* __restrict__ uin, const double* __restrict__ f,
-                                                     double* __restrict__ uout, int nx, int ny, double C, double _h2,
-                                                     double fac, int rows_per_chunk, int nstrips,
-                                                     double* __restrict__ partials, const double* __restrict__ corr_c,
-                                                     double* __restrict__ res_c_out, double* __restrict__ corr_c_out,
-                                                     const int* __restrict__ skip)
-{
-    if (skip && *skip) return;
-    __shared__ double red[16];
-    constexpr int HX = 5;                                    // feeder lanes on each side of a strip
-    constexpr int SW = 64 - 2 * HX;                          // columns owned by a strip
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int strip = blockIdx.x * 4 + w;
-    const bool active = strip < nstrips;
-    const int gi = strip * SW - HX + lane;                   // global column of this lane
-    const bool col_ok = active && gi >= 0 && gi < nx;
-    const int gic = gi < 0 ? 0 : (gi > nx - 1 ? nx - 1 : gi);  // clamped for loads
-    const bool col_bnd = gi <= 0 || gi >= nx - 1;            // domain boundary column (or outside)
-    const bool owner = col_ok && lane >= HX && lane < 64 - HX;
-    const int y0 = blockIdx.y * rows_per_chunk;
-    const int y1 = (y0 + rows_per_chunk < ny) ? y0 + rows_per_chunk : ny;  // output rows [y0, y1)
-    const int rs = y0 - HX < 0 ? 0 : y0 - HX;
-    double acc = 0.0;
-    if (active) {
-        const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
-        // the two coarse columns this lane interpolates from, cached for coarse rows pj and pj+1 (see k_smooth2_march)
-        int gis = gic;  // Neumann rows of the prolongated correction (part2_utils.jl:35-39)
-        if (BCS) gis = (gic == 0) ? 1 : (gic == nx - 1 ? nx - 2 : gic);
-        const int p_io = gis & 1, p_icl = gis >> 1, p_ich = (p_icl + 1 < nxc) ? p_icl + 1 : nxc - 1;
-        const bool p_sx0 = p_icl >= 1 && p_icl <= nxc - 2, p_sx1 = p_io && (p_icl + 1 <= nxc - 2);
-        const bool p_inx = gis >= 1 && gis <= nx - 2;
-        int pj = -2;
-        double pc00 = 0.0, pc10 = 0.0, pc01 = 0.0, pc11 = 0.0;
-        const int rowB = nx * 8;
-        const __amdgpu_buffer_rsrc_t rUin = fpr_rsrc(uin + (size_t)nx * rs), rF = fpr_rsrc(f + (size_t)nx * rs);
-        const __amdgpu_buffer_rsrc_t rUout = fpr_rsrc(uout + (size_t)nx * rs);
-        const unsigned vld = (unsigned)gic * 8u;
-        const unsigned vst = owner ? (unsigned)gi * 8u : FPR_OOR;   // lanes that own nothing store out of range
-        auto ldu = [&](int r) {
-            const int rc = r > ny - 1 ? ny - 1 : r;
-            const double v = fpr_bld(rUin, vld, (rc - rs) * rowB);
-            const int jo = rc & 1, jcl = rc >> 1;
-            if (jcl != pj) {
-                const int jch = (jcl + 1 < nyc) ? jcl + 1 : nyc - 1;
-                if (jcl == pj + 1) { pc00 = pc01; pc10 = pc11; }
-                else { pc00 = corr_c[(size_t)p_icl + (size_t)nxc * jcl]; pc10 = corr_c[(size_t)p_ich + (size_t)nxc * jcl]; }
-                pc01 = corr_c[(size_t)p_icl + (size_t)nxc * jch];
-                pc11 = corr_c[(size_t)p_ich + (size_t)nxc * jch];
-                pj = jcl;
-            }
-            // same value and accumulation order as prolong_bf
-            const bool in = p_inx && rc >= 1 && rc <= ny - 2;
-            const double wgt = (p_io | jo) ? ((p_io & jo) ? 0.25 : 0.5) : 1.0;
-            const bool sy0 = jcl >= 1 && jcl <= nyc - 2, sy1 = jo && (jcl + 1 <= nyc - 2);
-            double pv = 0.0;
-            pv = pv + ((in && p_sx0 && sy0) ? wgt * pc00 : 0.0);
-            pv = pv + ((in && p_sx1 && sy0) ? wgt * pc10 : 0.0);
-            pv = pv + ((in && p_sx0 && sy1) ? wgt * pc01 : 0.0);
-            pv = pv + ((in && p_sx1 && sy1) ? wgt * pc11 : 0.0);
-            return v - pv;
-        };
-        auto ldf = [&](int r) { const int rc = r > ny - 1 ? ny - 1 : r; return fpr_bld(rF, vld, (rc - rs) * rowB); };
-        // 3-row windows with COMPILE-TIME slots: row j of every field lives in slot (j - rs) mod 3 (f: mod 6), and the row
-        // loop is unrolled by 12 = lcm(3, 4, 6) so that the slot of every operand is a constant: no register moves to
-        // shift fifteen window rows per step (the 2-sweep kernel shifts its windows; here that would be a fifth of the VALU work).
-        // w[0] = corrected input, w[K] = field after sweep K.
-        double w[5][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-        double fw[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        w[0][0] = ldu(rs);
-        fw[0] = ldf(rs);
-        constexpr int PF = 4;
-        double pu[PF], pfv[PF];
-#pragma unroll
-        for (int q = 0; q < PF; ++q) { pu[q] = ldu(rs + 1 + q); pfv[q] = ldf(rs + 1 + q); }
-        const __amdgpu_buffer_rsrc_t rResC = fpr_rsrc(res_c_out), rCorC = fpr_rsrc(corr_c_out);
-        const unsigned vstc = (owner && !(gi & 1)) ? (unsigned)(gi >> 1) * 8u : FPR_OOR;
-        // BCS: Neumann columns of the coarse right-hand side (:355-357), see k_smooth2_march
-        const unsigned vstr = (BCS && (gi == 0 || gi == nx - 1)) ? FPR_OOR : vstc;
-        const unsigned vstn = (BCS && owner && (gi == 2 || gi == nx - 3)) ? (gi == 2 ? 0u : (unsigned)(nxc - 1) * 8u) : FPR_OOR;
-        // one Jacobi sweep at row j of a field whose rows j-1, j, j+1 are (lo, mid, hi); rr = residual used by the update
-        auto sweep = [&](double lo, double mid, double hi, double fv, int j, double& rr) {
-            const double L = fpr_lane_up1z(mid), R = fpr_lane_down1z(mid);
-            rr = ((((R + L) + hi) + lo) - C * mid) * _h2 - fv;
-            const bool bnd = col_bnd || j <= 0 || j >= ny - 1;
-            return bnd ? mid : mid + fac * rr;
-        };
-        auto step = [&](auto Tc, int r) {
-            constexpr int T = decltype(Tc)::value;               // (r - rs) mod 12
-            constexpr int Q = T % 4, M = T % 3, F = T % 6;
-            constexpr int M1 = (M + 1) % 3, M2 = (M + 2) % 3;    // slots of rows r-2 (= r+1) and r-1
-            auto fs = [](int k) { return (F - k + 6) % 6; };     // slot of f row r-k
-            double an, fn;
-            asm volatile("v_mov_b64 %0, %1" : "=v"(an) : "v"(pu[Q]));
-            asm volatile("v_mov_b64 %0, %1" : "=v"(fn) : "v"(pfv[Q]));
-            pu[Q] = ldu(r + 1 + PF);                           // issue the loads of row r+1+PF
-            pfv[Q] = ldf(r + 1 + PF);
-            double rr;
-            // ---- cycle k, post-smoothing (:142-143): sweeps 1 and 2 at rows r-1, r-2 ----
-            w[1][M2] = sweep(w[0][M1], w[0][M2], w[0][M], fw[fs(1)], r - 1, rr);
-            const int j2 = r - 2;
-            double u2 = sweep(w[1][M], w[1][M1], w[1][M2], fw[fs(2)], j2, rr);   // u at the end of cycle k (not stored)
-            if constexpr (BCS) {
-                // apply_boundary_conditions! between the cycles (multigrid.jl:60-62, part2_utils.jl:22-31): its Dirichlet
-                // rows hold their values already (set before the first cycle, never changed by a sweep or a correction);
-                // its Neumann columns copy their inner neighbour of THIS field
-                const double fromR = fpr_lane_down1z(u2), fromL = fpr_lane_up1z(u2);
-                u2 = (gi == 0) ? fromR : ((gi == nx - 1) ? fromL : u2);
-            }
-            w[2][M1] = u2;
-            {
-                const bool bnd = col_bnd || j2 <= 0 || j2 >= ny - 1;
-                const bool row_own = j2 >= y0 && j2 < y1;      // uniform
-                acc += (owner && row_own && !bnd) ? rr * rr : 0.0;  // r_rms of cycle k (:252); branch-free (+0.0 is exact)
-            }
-            // ---- cycle k+1, pre-smoothing (:124-125): sweeps 3 and 4 at rows r-3, r-4 ----
-            w[3][M] = sweep(w[2][M2], w[2][M], w[2][M1], fw[fs(3)], r - 3, rr);
-            const int j4 = r - 4;
-            const double u4 = sweep(w[3][M1], w[3][M2], w[3][M], fw[fs(4)], j4, rr);
-            {
-                const bool row_own = j4 >= y0 && j4 < y1;      // uniform
-                fpr_bst(rUout, vst, row_own ? (j4 - rs) * rowB : (int)FPR_OOR, u4);   // unconditional (see FPR_OOR)
-            }
-            w[4][M2] = u4;
-            // ---- residual of the pre-smoothed field at row r-5, injected at even (row, column) (:128-132) ----
-            {
-                const int j5 = r - 5;
-                const double mid = w[4][M1];
-                const double L = fpr_lane_up1z(mid), R = fpr_lane_down1z(mid);
-                const double rres = ((((R + L) + w[4][M2]) + w[4][M]) - C * mid) * _h2 - fw[fs(5)];
-                const int ic = gi >> 1, jc = j5 >> 1;
-                const bool cint = ic >= 1 && ic <= nxc - 2 && jc >= 1 && jc <= nyc - 2;
-                const bool row_inj = j5 >= y0 && j5 < y1 && !(j5 & 1);   // uniform
-                const int sc = row_inj ? jc * (nxc * 8) : (int)FPR_OOR;
-                fpr_bst(rResC, vstr, sc, cint ? rres : 0.0);
-                if constexpr (BCS) fpr_bst(rResC, vstn, sc, cint ? rres : 0.0);
-                fpr_bst(rCorC, vstc, sc, 0.0);
-            }
-            w[0][M1] = an;             // row r+1 takes the slot of row r-2
-            fw[(F + 1) % 6] = fn;      // row r+1 takes the slot of row r-5
-        };
-        const int rend = y1 + 4;
-        int r = rs;
-        static_assert(PF == 4, "the row loop below is unrolled by 12 = lcm(3 window slots, PF = 4, 6 rows of f)");
-#define FPR_SEAM_STEP(T) step(std::integral_constant<int, T>{}, r + T)
-        for (; r + 11 <= rend; r += 12) {
-            FPR_SEAM_STEP(0); FPR_SEAM_STEP(1); FPR_SEAM_STEP(2); FPR_SEAM_STEP(3); FPR_SEAM_STEP(4); FPR_SEAM_STEP(5);
-            FPR_SEAM_STEP(6); FPR_SEAM_STEP(7); FPR_SEAM_STEP(8); FPR_SEAM_STEP(9); FPR_SEAM_STEP(10); FPR_SEAM_STEP(11);
-        }
-#undef FPR_SEAM_STEP
-#define FPR_SEAM_TAIL(T) if (r <= rend) { step(std::integral_constant<int, T>{}, r); ++r; }
-        FPR_SEAM_TAIL(0) FPR_SEAM_TAIL(1) FPR_SEAM_TAIL(2) FPR_SEAM_TAIL(3) FPR_SEAM_TAIL(4) FPR_SEAM_TAIL(5)
-        FPR_SEAM_TAIL(6) FPR_SEAM_TAIL(7) FPR_SEAM_TAIL(8) FPR_SEAM_TAIL(9) FPR_SEAM_TAIL(10)
-#undef FPR_SEAM_TAIL
-    }
-    const double sblk = fpr_block_sum<256>(acc, red);
-    if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
-}
-
-// ---- k_seam_march, second version: the same pass with ~half the vector instructions per row (round 3) -----------------------
+//
+// ---- k_seam_march_v2: the pass with ~half the vector instructions per row of the first version (round 3; that version is history) ----
 // Counters of the first version (profiles/r2_mg_seam_pmc.txt): 49.8 M vector instructions per launch at 4097^2 = 138 per
 // wave-row = a VALU floor of 81-91 us beside a memory floor of 91 us for a pass that takes 130 us -- as much VALU-bound as
 // memory-bound.  What changed, results unchanged (same operations on the same operands in the same order per point):
@@ -1038,239 +716,3 @@ __global__ __launch_bounds__(256) void k_smooth2_march_v2(const double* __restri
         if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
     }
 }
-
-// ---- k_smooth2_march, two columns per lane (opt-in; measured slower, see vcycle_level) -------------------------------------------------
-// Same algorithm as k_smooth2_march with a strip of 128 columns per wave: a lane holds two adjacent
-// columns, loads/stores them with one 16-byte access (the hardware accepts the 8-byte alignment that
-// (2^k+1)-wide rows impose), needs a shuffle only for the outer neighbour of each pair, and halves the
-// loop and address arithmetic per point.
-struct __attribute__((aligned(8))) FprD2 { double x, y; };
-
-template <bool NORM, bool PROLONG, bool RESTRICT>
-__global__ __launch_bounds__(256) void k_smooth2_march2(const double* __restrict__ uin, const double* __restrict__ f,
-                                                         double* __restrict__ uout, int nx, int ny, double C, double _h2,
-                                                         double fac, int rows_per_chunk, int nstrips,
-                                                         double* __restrict__ partials, const double* __restrict__ corr_c,
-                                                         int apply_BCs, double* __restrict__ res_c_out,
-                                                         double* __restrict__ corr_c_out, const int* __restrict__ skip)
-{
-    if (skip && *skip) return;   // a cycle enqueued ahead of the exit test that ended the loop (FprCycleCtl)
-    __shared__ double red[16];
-    // Feeder COLUMNS: HXL on the left, HXR on the right.  On rows whose start is only 8-byte aligned (odd rows of
-    // an odd-width grid) the lane <-> column mapping is shifted by one column so that every 16-byte access stays
-    // 16-byte aligned; the wave then loses its last column on those rows, hence one more feeder on the right.
-    // All widths are even so that strips start on even columns.
-    constexpr int HX = RESTRICT ? 4 : 2;   // left feeders (3 needed with RESTRICT, rounded up to an even number)
-    constexpr int HXR = RESTRICT ? 4 : 4;  // right feeders: needed (2 or 3) + 1 lost column, rounded up to even
-    constexpr int SW = 128 - HX - HXR;     // columns owned by a strip
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int strip = blockIdx.x * 4 + w;
-    const bool active = strip < nstrips;
-    const int g0 = strip * SW - HX + 2 * lane;   // global column of element 0 (element 1 = g0 + 1)
-    const int y0 = blockIdx.y * rows_per_chunk;
-    const int y1 = (y0 + rows_per_chunk < ny) ? y0 + rows_per_chunk : ny;
-    const int rs = y0 - HX < 0 ? 0 : y0 - HX;
-    double acc = 0.0;
-    if (active) {
-        const int nxc = 1 + (nx - 1) / 2, nyc = 1 + (ny - 1) / 2;
-        int gi[2], gic[2], gis[2];
-        bool colbnd[2], owner[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            gi[e] = g0 + e;
-            gic[e] = gi[e] < 0 ? 0 : (gi[e] > nx - 1 ? nx - 1 : gi[e]);
-            colbnd[e] = gi[e] <= 0 || gi[e] >= nx - 1;
-            const int q = 2 * lane + e;
-            owner[e] = gi[e] >= 0 && gi[e] < nx && q >= HX && q < 128 - HXR;
-            gis[e] = gic[e];
-            if (PROLONG && apply_BCs) gis[e] = (gic[e] == 0) ? 1 : (gic[e] == nx - 1 ? nx - 2 : gic[e]);
-        }
-        const bool vec_ok = g0 >= 0 && g0 + 1 < nx;   // both columns exist: one 16-byte access (unshifted rows)
-        const bool vec_ok_s = g0 >= 1 && g0 < nx;     // columns g0-1, g0 exist (shifted rows)
-        const bool odd_pitch = (nx & 1) != 0;
-        // element 1 of the previous lane is owned / exists (needed for the shifted store)
-        const bool owner_prev = (2 * lane - 1 >= HX) && (2 * lane - 1 < 128 - HXR) && g0 - 1 >= 0 && g0 - 1 < nx;
-        // PROLONG: per element, the two coarse columns it interpolates from, cached for coarse rows pj, pj+1
-        int p_icl[2], p_ich[2], p_io[2];
-        bool p_sx0[2], p_sx1[2], p_inx[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            p_io[e] = gis[e] & 1;
-            p_icl[e] = gis[e] >> 1;
-            p_ich[e] = (p_icl[e] + 1 < nxc) ? p_icl[e] + 1 : nxc - 1;
-            p_sx0[e] = p_icl[e] >= 1 && p_icl[e] <= nxc - 2;
-            p_sx1[e] = p_io[e] && (p_icl[e] + 1 <= nxc - 2);
-            p_inx[e] = gis[e] >= 1 && gis[e] <= nx - 2;
-        }
-        int pj = -2;
-        double pc00[2] = {0.0, 0.0}, pc10[2] = {0.0, 0.0}, pc01[2] = {0.0, 0.0}, pc11[2] = {0.0, 0.0};
-        auto ld2 = [&](const double* __restrict__ p, int r, double& v0, double& v1) {
-            const int rc = r > ny - 1 ? ny - 1 : r;
-            const size_t row = (size_t)nx * rc;
-            if (odd_pitch && (rc & 1)) {
-                // shifted row: this lane fetches columns (g0-1, g0), 16-byte aligned; element 1 (column g0+1) is the
-                // first element of the next lane's pair
-                double s0, s1;
-                if (vec_ok_s) {
-                    const double2 t = *reinterpret_cast<const double2*>(p + row + (g0 - 1));
-                    s0 = t.x; s1 = t.y;
-                } else {
-                    const int c0 = g0 - 1 < 0 ? 0 : (g0 - 1 > nx - 1 ? nx - 1 : g0 - 1);
-                    s0 = p[row + c0]; s1 = p[row + gic[0]];
-                }
-                v0 = s1;
-                v1 = fpr_lane_down1(s0);
-            } else {
-                if (vec_ok) {
-                    const double2 t = *reinterpret_cast<const double2*>(p + row + g0);
-                    v0 = t.x; v1 = t.y;
-                } else {
-                    v0 = p[row + gic[0]]; v1 = p[row + gic[1]];
-                }
-            }
-        };
-        auto ldu = [&](int r, double& v0, double& v1) {
-            ld2(uin, r, v0, v1);
-            if constexpr (PROLONG) {
-                const int rc = r > ny - 1 ? ny - 1 : r;
-                const int jo = rc & 1, jcl = rc >> 1;
-                if (jcl != pj) {
-                    const int jch = (jcl + 1 < nyc) ? jcl + 1 : nyc - 1;
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        if (jcl == pj + 1) { pc00[e] = pc01[e]; pc10[e] = pc11[e]; }
-                        else { pc00[e] = corr_c[(size_t)p_icl[e] + (size_t)nxc * jcl]; pc10[e] = corr_c[(size_t)p_ich[e] + (size_t)nxc * jcl]; }
-                        pc01[e] = corr_c[(size_t)p_icl[e] + (size_t)nxc * jch];
-                        pc11[e] = corr_c[(size_t)p_ich[e] + (size_t)nxc * jch];
-                    }
-                    pj = jcl;
-                }
-                const bool sy0 = jcl >= 1 && jcl <= nyc - 2, sy1 = jo && (jcl + 1 <= nyc - 2);
-                const bool iny = rc >= 1 && rc <= ny - 2;
-                double pv[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {  // same value and accumulation order as prolong_bf
-                    const bool in = p_inx[e] && iny;
-                    const double wgt = (p_io[e] | jo) ? ((p_io[e] & jo) ? 0.25 : 0.5) : 1.0;
-                    double t = 0.0;
-                    t = t + ((in && p_sx0[e] && sy0) ? wgt * pc00[e] : 0.0);
-                    t = t + ((in && p_sx1[e] && sy0) ? wgt * pc10[e] : 0.0);
-                    t = t + ((in && p_sx0[e] && sy1) ? wgt * pc01[e] : 0.0);
-                    t = t + ((in && p_sx1[e] && sy1) ? wgt * pc11[e] : 0.0);
-                    pv[e] = t;
-                }
-                v0 = v0 - pv[0];
-                v1 = v1 - pv[1];
-            }
-        };
-        double a0[2] = {0, 0}, a1[2] = {0, 0}, a2[2], an[2];   // u  rows r-2, r-1, r, r+1
-        double b0[2] = {0, 0}, b1[2] = {0, 0}, b2[2] = {0, 0}; // u1 rows r-3, r-2, r-1
-        double c0[2] = {0, 0}, c1[2] = {0, 0}, c2[2] = {0, 0}; // u2 rows r-4, r-3, r-2 (RESTRICT)
-        double f0[2] = {0, 0}, f1[2] = {0, 0}, f2[2], fn[2], fm[2] = {0, 0};
-        ldu(rs, a2[0], a2[1]);
-        ld2(f, rs, f2[0], f2[1]);
-        // prefetch ring with compile-time slots (see k_smooth2_march): rows r+1 .. r+PF in flight
-        constexpr int PF = 4;
-        double pu[PF][2], pfv[PF][2];
-#pragma unroll
-        for (int q = 0; q < PF; ++q) { ldu(rs + 1 + q, pu[q][0], pu[q][1]); ld2(f, rs + 1 + q, pfv[q][0], pfv[q][1]); }
-        auto step = [&](auto Qc, int r) {
-            constexpr int Q = decltype(Qc)::value;
-            an[0] = pu[Q][0]; an[1] = pu[Q][1];
-            fn[0] = pfv[Q][0]; fn[1] = pfv[Q][1];
-            ldu(r + 1 + PF, pu[Q][0], pu[Q][1]);
-            ld2(f, r + 1 + PF, pfv[Q][0], pfv[Q][1]);
-            // ---- sweep 1 at row r-1 ----
-            const int j1 = r - 1;
-            double u1[2];
-            {
-                const double Lo = fpr_lane_up1(a1[1]), Ro = fpr_lane_down1(a1[0]);
-                const bool rowb = j1 <= 0 || j1 >= ny - 1;
-                const double rr0 = ((((a1[1] + Lo) + a2[0]) + a0[0]) - C * a1[0]) * _h2 - f1[0];
-                const double rr1 = ((((Ro + a1[0]) + a2[1]) + a0[1]) - C * a1[1]) * _h2 - f1[1];
-                u1[0] = (rowb || colbnd[0]) ? a1[0] : a1[0] + fac * rr0;
-                u1[1] = (rowb || colbnd[1]) ? a1[1] : a1[1] + fac * rr1;
-            }
-#pragma unroll
-            for (int e = 0; e < 2; ++e) { b0[e] = b1[e]; b1[e] = b2[e]; b2[e] = u1[e]; }
-            // ---- sweep 2 at row r-2 ----
-            const int j2 = r - 2;
-            {
-                const double Lo = fpr_lane_up1(b1[1]), Ro = fpr_lane_down1(b1[0]);
-                const bool rowb = j2 <= 0 || j2 >= ny - 1;
-                const double rr0 = ((((b1[1] + Lo) + b2[0]) + b0[0]) - C * b1[0]) * _h2 - f0[0];
-                const double rr1 = ((((Ro + b1[0]) + b2[1]) + b0[1]) - C * b1[1]) * _h2 - f0[1];
-                const bool bn0 = rowb || colbnd[0], bn1 = rowb || colbnd[1];
-                const double u20 = bn0 ? b1[0] : b1[0] + fac * rr0;
-                const double u21 = bn1 ? b1[1] : b1[1] + fac * rr1;
-                const bool shifted_row = odd_pitch && (j2 & 1) && j2 >= 0;
-                const double prev21 = fpr_lane_up1(u21);  // column g0-1 (element 1 of the previous lane)
-                if (j2 >= y0 && j2 < y1) {
-                    const size_t o = (size_t)nx * j2;
-                    if (shifted_row) {
-                        if (owner_prev && owner[0]) {
-                            *reinterpret_cast<double2*>(uout + o + (g0 - 1)) = make_double2(prev21, u20);
-                        } else {
-                            if (owner_prev) uout[o + g0 - 1] = prev21;
-                            if (owner[0]) uout[o + gi[0]] = u20;
-                        }
-                        // (this lane's element 1, column g0+1, is stored by the next lane as its `prev21`)
-                    } else if (owner[0] && owner[1]) {
-                        *reinterpret_cast<double2*>(uout + o + g0) = make_double2(u20, u21);
-                    } else {
-                        if (owner[0]) uout[o + gi[0]] = u20;
-                        if (owner[1]) uout[o + gi[1]] = u21;
-                    }
-                    if constexpr (NORM) {
-                        if (owner[0] && !bn0) acc += rr0 * rr0;
-                        if (owner[1] && !bn1) acc += rr1 * rr1;
-                    }
-                }
-                if constexpr (RESTRICT) {
-                    c0[0] = c1[0]; c1[0] = c2[0]; c2[0] = u20;
-                    c0[1] = c1[1]; c1[1] = c2[1]; c2[1] = u21;
-                }
-            }
-            if constexpr (RESTRICT) {
-                // ---- residual of u2 at row r-3, injected at even (row, column): one of the lane's two columns ----
-                const int j3 = r - 3;
-                const double Lo = fpr_lane_up1(c1[1]), Ro = fpr_lane_down1(c1[0]);
-                const double rr0 = ((((c1[1] + Lo) + c2[0]) + c0[0]) - C * c1[0]) * _h2 - fm[0];
-                const double rr1 = ((((Ro + c1[0]) + c2[1]) + c0[1]) - C * c1[1]) * _h2 - fm[1];
-                if (j3 >= y0 && j3 < y1 && !(j3 & 1)) {
-                    const int e = (gi[0] & 1) ? 1 : 0;  // the even column
-                    const double rr = e ? rr1 : rr0;
-                    if (e ? owner[1] : owner[0]) {
-                        const int ic = (e ? gi[1] : gi[0]) >> 1, jc = j3 >> 1;
-                        const bool cint = ic >= 1 && ic <= nxc - 2 && jc >= 1 && jc <= nyc - 2;
-                        const size_t cid = (size_t)ic + (size_t)nxc * jc;
-                        res_c_out[cid] = cint ? rr : 0.0;
-                        corr_c_out[cid] = 0.0;
-                    }
-                }
-                fm[0] = f0[0]; fm[1] = f0[1];
-            }
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                a0[e] = a1[e]; a1[e] = a2[e]; a2[e] = an[e];
-                f0[e] = f1[e]; f1[e] = f2[e]; f2[e] = fn[e];
-            }
-        };
-        const int rend = y1 + (RESTRICT ? 2 : 1);
-        int r = rs;
-        for (; r + PF - 1 <= rend; r += PF) {
-            step(std::integral_constant<int, 0>{}, r);
-            step(std::integral_constant<int, 1>{}, r + 1);
-            step(std::integral_constant<int, 2>{}, r + 2);
-            step(std::integral_constant<int, 3>{}, r + 3);
-        }
-        if (r <= rend) { step(std::integral_constant<int, 0>{}, r); ++r; }
-        if (r <= rend) { step(std::integral_constant<int, 1>{}, r); ++r; }
-        if (r <= rend) { step(std::integral_constant<int, 2>{}, r); ++r; }
-    }
-    if constexpr (NORM) {
-        const double sblk = fpr_block_sum<256>(acc, red);
-        if (threadIdx.x == 0) partials[blockIdx.x + gridDim.x * blockIdx.y] = sblk;
-    }
-}
-

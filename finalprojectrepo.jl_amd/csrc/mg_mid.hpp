@@ -38,8 +38,6 @@ struct MidLevel {
 };
 struct MidArgs {
     MidLevel L[3];       // A, B, C
-    MidLevel P;          // top4: the level above A (k_mid_down's prologue: f = its right-hand side, tmp = its pre-smoothed field, fout = A's right-hand side)
-    int top4;
     int zfuse;           // k_mid_down: the two sweeps from the zero guess as one pass (option mg_zero_fuse)
     FprFinishArgs fin;   // k_mid_down: partials != null = the finish of the cycle before, done by one more row of workgroups
     int nxD, nyD;        // the level below C (top of the LDS-resident sub-hierarchy)
@@ -153,76 +151,6 @@ __global__ __launch_bounds__(MID_NT_DOWN) void k_mid_down(MidArgs a)
     }
     // LDS: F | U1 (on rf) | U2 (on rt) of the current level, then the next level's F behind them
     double* F = sm;
-    if (a.top4) {
-        // The level ABOVE A rides along: its two pre-smoothing sweeps from the zero guess and its residual at the injected points are
-        // functions of its right-hand side in a radius of two, recomputed here per point from a staged region S of that right-hand side
-        // (the same expressions in the same order as its own pass: k_smooth2_march_v2 with the zero-guess bit, the per-level block below):
-        // F of level A on rf[0] stays in LDS, the owned parts of F and of the level's pre-smoothed field go to memory.
-        const MidLevel& P = a.P;
-        const MidReg rs = mid_clip(2 * rf[0].x0 - 2, 2 * rf[0].x1 + 2, 2 * rf[0].y0 - 2, 2 * rf[0].y1 + 2, P.nx, P.ny);
-        double* S = sm + mid_n(rf[0]);
-        {
-            const int w = mid_w(rs), n = mid_n(rs);
-            const float rw = 1.0f / (float)w;
-            for (int idx = tid; idx < n; idx += NT) {
-                const int jj = mgs_row(idx, rw), ii = idx - jj * w;
-                S[idx] = P.f[(size_t)(rs.x0 + ii) + (size_t)P.nx * (rs.y0 + jj)];
-            }
-        }
-        __syncthreads();
-        const int ws = mid_w(rs);
-        auto sw1 = [&](int i, int j) -> double {   // first sweep from the zero guess (:124 with u = 0; the literal arithmetic on zeros)
-            double v = 0.0;
-            if (i >= 1 && j >= 1 && i < P.nx - 1 && j < P.ny - 1) {
-                const double r = ((((0.0 + 0.0) + 0.0) + 0.0) - P.C * 0.0) * P._h2 - S[(i - rs.x0) + ws * (j - rs.y0)];
-                v = 0.0 + P.fac * r;
-            }
-            return v;
-        };
-        auto sw2 = [&](int i, int j) -> double {   // second sweep (:125)
-            const double uc = sw1(i, j);
-            double v = uc;
-            if (i >= 1 && j >= 1 && i < P.nx - 1 && j < P.ny - 1) {
-                const double r = ((((sw1(i + 1, j) + sw1(i - 1, j)) + sw1(i, j + 1)) + sw1(i, j - 1)) - P.C * uc) * P._h2 - S[(i - rs.x0) + ws * (j - rs.y0)];
-                v = uc + P.fac * r;
-            }
-            return v;
-        };
-        {   // residual at the injected points = right-hand side of level A (:128-131; Neumann columns :355-357)
-            const MidLevel& LA = a.L[0];
-            const int nxc = LA.nx, nyc = LA.ny;
-            MidReg o;   // owned part of that right-hand side
-            o.x0 = 8 * own.x0; o.x1 = (bx == ntx - 1) ? nxc - 1 : 8 * (own.x1 + 1) - 1;
-            o.y0 = 8 * own.y0; o.y1 = (by == nty - 1) ? nyc - 1 : 8 * (own.y1 + 1) - 1;
-            const int w = mid_w(rf[0]), n = mid_n(rf[0]);
-            const float rw = 1.0f / (float)w;
-            for (int idx = tid; idx < n; idx += NT) {
-                const int jj = mgs_row(idx, rw), ii = idx - jj * w;
-                const int ic = rf[0].x0 + ii, jc = rf[0].y0 + jj;
-                int is = ic;
-                if (a.apply_BCs) is = (ic == 0) ? 1 : (ic == nxc - 1 ? nxc - 2 : ic);
-                double v = 0.0;
-                if (is >= 1 && is <= nxc - 2 && jc >= 1 && jc <= nyc - 2) {
-                    const int i = 2 * is, j = 2 * jc;
-                    v = ((((sw2(i + 1, j) + sw2(i - 1, j)) + sw2(i, j + 1)) + sw2(i, j - 1)) - P.C * sw2(i, j)) * P._h2 - S[(i - rs.x0) + ws * (j - rs.y0)];
-                }
-                F[idx] = v;
-                if (ic >= o.x0 && ic <= o.x1 && jc >= o.y0 && jc <= o.y1) P.fout[(size_t)ic + (size_t)nxc * jc] = v;
-            }
-        }
-        {   // the owned part of the level's pre-smoothed field goes to memory (its post-smoothing pass reads it)
-            MidReg o;
-            o.x0 = 16 * own.x0; o.x1 = (bx == ntx - 1) ? P.nx - 1 : 16 * (own.x1 + 1) - 1;
-            o.y0 = 16 * own.y0; o.y1 = (by == nty - 1) ? P.ny - 1 : 16 * (own.y1 + 1) - 1;
-            const int w = mid_w(o), n = mid_n(o);
-            const float rw = 1.0f / (float)w;
-            for (int idx = tid; idx < n; idx += NT) {
-                const int jj = mgs_row(idx, rw), ii = idx - jj * w;
-                const int i = o.x0 + ii, j = o.y0 + jj;
-                P.tmp[(size_t)i + (size_t)P.nx * j] = sw2(i, j);
-            }
-        }
-    } else
     {   // right-hand side of level A from memory
         const MidLevel& L = a.L[0];
         const int w = mid_w(rf[0]), n = mid_n(rf[0]);

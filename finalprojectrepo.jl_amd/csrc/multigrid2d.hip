@@ -184,12 +184,11 @@ __device__ __forceinline__ double prolong_bf(const double* __restrict__ cc, int 
 
 #include "mg_march.hpp"   // k_smooth2_march, k_seam_march, k_smooth2_march2: the register-rolling marches of the fine levels
 
-// the two-sweep pass in its first or second version ("mg_march_v", default 2; same fields)
+// the two-sweep pass without a carried finish
 template <bool N, bool P, bool R, class... A>
 static inline void march_go(fpr_ctx* ctx, dim3 g, hipStream_t s, A... a)
 {
-    if (fpr_opt(ctx, "mg_march_v", 2) == 1) k_smooth2_march<N, P, R><<<g, 256, 0, s>>>(a...);
-    else k_smooth2_march_v2<N, P, R><<<g, 256, 0, s>>>(a..., FprFinishArgs{});
+    k_smooth2_march_v2<N, P, R><<<g, 256, 0, s>>>(a..., FprFinishArgs{});
 }
 
 // ---- S fused Jacobi sweeps, register patches (coarse solve on grids too large for one workgroup) ------
@@ -775,18 +774,16 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
     // iteration, 1 = three, 0 = five (one per operation)
     long fused = fpr_opt(ctx, "cg_fused", 3);
     if (fused == 3) {
-        // geometry: 64 workgroups of 256 threads (default) or 16 of 1024 (option cg_persistent_wgs = 16; rounds 2-3)
-        const bool g64 = fpr_opt(ctx, "cg_persistent_wgs", 64) != 16;
-        const int nbx = g64 ? 8 : 4, nb = nbx * nbx, nt = g64 ? 256 : 1024;
+        // geometry: 64 workgroups of 256 threads (one wave per SIMD)
+        constexpr int nbx = 8, nb = nbx * nbx, nt = 256;
         const int twm = (nx + nbx - 1) / nbx, thm = (ny + nbx - 1) / nbx;
         const size_t lds = (size_t)(twm + 2) * (thm + 2) * sizeof(double);
         // its workgroups synchronise through memory, so all of them have to be resident at once: ask the runtime once
         // whether a compute unit takes one (this many threads, this much LDS) and whether the device has enough units
-        int& resident = g64 ? ctx->cgp_resident64 : ctx->cgp_resident;
+        int& resident = ctx->cgp_resident64;
         if (resident < 0) {
             int per_cu = 0, ncu = 0;
-            const hipError_t eo = g64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_persistent<64, 8, 256>, nt, 64 * 1024)
-                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_persistent<16, 4, 1024>, nt, 64 * 1024);
+            const hipError_t eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_persistent<64, 8, 256>, nt, 64 * 1024);
             const bool ok = eo == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess;
             resident = (ok && per_cu >= 1 && ncu >= nb) ? 1 : 0;    // one workgroup per unit: a unit of its own for every workgroup
         }
@@ -802,16 +799,11 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
                 int ex = 0, ey = 0;
                 const bool px = std::frexp(a.hx2, &ex) == 0.5 && ex > -1000 && ex < 1000;
                 const bool py = std::frexp(a.hy2, &ey) == 0.5 && ey > -1000 && ey < 1000;
-                a.pow2 = (px && py && fpr_opt(ctx, "cg_pow2", 1) != 0) ? 1 : 0;
+                a.pow2 = (px && py) ? 1 : 0;
                 a.ihx2 = a.pow2 ? 1.0 / a.hx2 : 0.0;
                 a.ihy2 = a.pow2 ? 1.0 / a.hy2 : 0.0;
             }
-            a.prof = (long long*)(uintptr_t)fpr_opt(ctx, "cg_prof", 0);
             a.fences = fpr_opt(ctx, "handoff_fences", 0) != 0 ? 1 : 0;
-            // r_glob: N doubles (flag form) or N granules = the work vectors r and p, which lie one behind the other (cg_work) and are not used
-            // otherwise by this form; tags of one solve never meet another solve's
-            a.tag_base = (fpr_opt(ctx, "cg_tagged_edges", FPR_CG_TAGGED_DEFAULT) != 0 && !a.fences && (size_t)N * 16 < 0x7fffffffu && w.p == w.r + N)
-                             ? fpr_next_epoch(ctx) << 32 : 0;
             FPR_HIP(ctx, hipMemsetAsync(a.ctr, 0, 2 * sizeof(unsigned), s));
             k_cgp_slots_init<<<1, 64, 0, s>>>(reinterpret_cast<unsigned long long*>(a.part), nb);
             // An ordinary launch: the workgroups are resident together on any device this library runs on (one per CU, 256 CUs),
@@ -819,8 +811,7 @@ static int cg_solve(fpr_ctx* ctx, double* x_in, const double* b, double hx, doub
             // kernels of two streams no longer overlap (measured: the side-by-side T / W solves of the NS step 1.61 -> 1.96 ms,
             // tools/exp_ns_only.py).
             const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_CG, s);
-            if (g64) k_cg_persistent<64, 8, 256><<<dim3(nb), dim3(nt), lds, s>>>(a);
-            else k_cg_persistent<16, 4, 1024><<<dim3(nb), dim3(nt), lds, s>>>(a);
+            k_cg_persistent<64, 8, 256><<<dim3(nb), dim3(nt), lds, s>>>(a);
             fpr_ktimer_end(ctx, timed, s);
             FPR_CHECK_LAUNCH(ctx);
             if (int rc = read_state(ctx)) return rc;
@@ -980,7 +971,6 @@ extern "C" int fpr_mg_arena_provide_coarse(fpr_ctx* ctx, int nx, int ny, double*
 }
 
 #include "mg_mid.hpp"     // k_mid_down, k_mid_up: three launch-bound levels in two launches
-#include "mg_pyramid.hpp" // k_pyr_down: four levels of the way down in one launch, halos exchanged as tagged granules (experiment)
 
 // Does the sub-hierarchy below an (nx, ny) level fit k_mg_small's LDS arena?  nlev = its levels, tot = doubles needed.
 static bool mgs_plan(int nx, int ny, int css, int* nlev_out, size_t* tot_out)
@@ -1032,17 +1022,16 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
 
 // Levels dA, dA+1, dA+2 (A > B > C) in two launches around the LDS-resident sub-hierarchy that starts at dA+3 (k_mid_down, k_mg_small,
 // k_mid_up); *taken = false when the levels do not fit that form (nothing launched).  uA / rhsA / hA: solution, right-hand side and mesh
-// width of level A.  LP != null: the level ABOVE A (A', at most 1025^2) rides along on the way down -- k_mid_down's prologue does its two
-// pre-smoothing sweeps from the zero guess and its residual + injection from rhsP (pointwise recomputation, no pass of its own), stores
-// its pre-smoothed field and A's right-hand side; its post-smoothing pass stays the caller's.  A finish handed over by the loop
-// (fprx_cycle_finish_defer) rides in one more row of k_mid_down's workgroups.
+// width of level A.  A finish handed over by the loop (fprx_cycle_finish_defer) rides in one more row of k_mid_down's workgroups.  (A fourth
+// level recomputed in k_mid_down's prologue, and the four levels as one launch with tagged halos between workgroups, were built, are bit-exact
+// and slower: EXPERIMENTS 13.14, 13.16.)
 static int mid_path(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double* uA, const double* rhsA, double hA, double c, double tol, int css,
-                    int solver, int apply_BCs, const FprLevel* LP, const double* rhsP, double hP, bool* taken)
+                    int solver, int apply_BCs, bool* taken)
 {
     *taken = false;
     if (!(solver == FPR_COARSE_JACOBI && fpr_opt(ctx, "mg_mid", 1) && fpr_opt(ctx, "mg_small", 1) &&
           fpr_opt(ctx, "mg_multi", 1) == 1 && fpr_opt(ctx, "mg_fuse_restrict", 1) && fpr_opt(ctx, "mg_fuse_prolong", 1) &&
-          fpr_opt(ctx, "mg_vx", 1) != 2 && d + 3 < A.size()))
+          d + 3 < A.size()))
         return FPR_OK;
     hipStream_t s = ctx->stream[0];
     const int* skp = ctx->cyc_skip;
@@ -1054,9 +1043,6 @@ static int mid_path(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double* uA
         ok = Lk.res_c && Lk.corr_c && Lk.tmp && (Lk.nx - 1) % 2 == 0 && (Lk.ny - 1) % 2 == 0 && m > 0 && (m & (m - 1)) == 0 &&
              (Lk.nx < Lk.ny ? Lk.nx : Lk.ny) > css && Lk.nx >= 64 && Lk.ny >= 16 && Lk.nx <= 1025 && Lk.ny <= 1025;
     }
-    if (ok && LP)
-        ok = LP->res_c && LP->corr_c && LP->tmp && LP->nx == 2 * (nx - 1) + 1 && LP->ny == 2 * (ny - 1) + 1 && LP->nx <= 1025 && LP->ny <= 1025 &&
-             rhsA == LP->res_c;
     int nlevD = 0;
     size_t totD = 0;
     ok = ok && mgs_plan(A[d + 3].nx, A[d + 3].ny, css, &nlevD, &totD);
@@ -1076,13 +1062,6 @@ static int mid_path(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double* uA
                 if (fy > A[d + k].ny) fy = A[d + k].ny;
                 lds_down += (size_t)(2 * fx * fy + tx * ty);
                 wx = fx; wy = fy;
-            }
-            if (LP) {   // the prologue: F of level A on rf[0] | the level above's right-hand side on rf[0] doubled and grown by two
-                long sx = 2 * wx + 3, sy = 2 * wy + 3;
-                if (sx > LP->nx) sx = LP->nx;
-                if (sy > LP->ny) sy = LP->ny;
-                const size_t need = (size_t)(wx * wy + sx * sy);
-                if (need > lds_down) lds_down = need;
             }
         }
         {   // k_mid_up: X on rc, F and U1 on r1, U2 on r2 per level, the level-D field
@@ -1117,16 +1096,7 @@ static int mid_path(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double* uA
         a.L[k].fac = (4.0 / 5.0) * ((hk * hk) / (4.0 + c * (hk * hk)));
         hk = hk * 2;   // the recursion passes h*2 (multigrid.jl:133)
     }
-    a.top4 = LP ? 1 : 0;
     a.zfuse = fpr_opt(ctx, "mg_zero_fuse", 1) != 0;
-    a.P = a.L[0];
-    if (LP) {
-        a.P.f = rhsP; a.P.tmp = LP->tmp; a.P.fout = LP->res_c;
-        a.P.nx = LP->nx; a.P.ny = LP->ny;
-        a.P.C = 4.0 + c * (hP * hP);
-        a.P._h2 = 1 / (hP * hP);
-        a.P.fac = (4.0 / 5.0) * ((hP * hP) / (4.0 + c * (hP * hP)));
-    }
     a.nxD = A[d + 3].nx; a.nyD = A[d + 3].ny;
     a.uD = A[d + 2].corr_c;
     a.uA = uA;
@@ -1136,50 +1106,6 @@ static int mid_path(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double* uA
     ctx->fin = FprFinishArgs{};
     const dim3 gd((a.nxD - 1) / MID_TD > 0 ? (a.nxD - 1) / MID_TD : 1, ((a.nyD - 1) / MID_TD > 0 ? (a.nyD - 1) / MID_TD : 1) + (a.fin.partials ? 1 : 0));
     const dim3 gu((nx - 1) / MID_TA > 0 ? (nx - 1) / MID_TA : 1, (ny - 1) / MID_TA > 0 ? (ny - 1) / MID_TA : 1);
-    bool pyr = false;
-    if (LP && fpr_opt(ctx, "mg_pyr_down", 0)) {
-        // the four levels in one launch with exchanged halos (k_pyr_down, mg_pyramid.hpp): every workgroup must be resident -- one per
-        // compute unit (its arena takes most of a CU's LDS)
-        if (ctx->ncu <= 0) {
-            int v = 0;
-            ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
-        }
-        auto own_max = [](int n, int t) { return (n - 1) / t > 0 ? t + 1 + (n - 1) % t : n; };
-        const long w0 = 16L * own_max(a.nxD, MID_TD) - 15 + 4, h0 = 16L * own_max(a.nyD, MID_TD) - 15 + 4;       // the top level's tile grown by two
-        const long w1 = 8L * own_max(a.nxD, MID_TD) - 7 + 4, h1 = 8L * own_max(a.nyD, MID_TD) - 7 + 4;
-        const size_t lds_pyr = (size_t)(2 * w0 * h0 + (w0 - 2) * (h0 - 2) + w1 * h1);
-        const size_t ngr = (size_t)A[d].nx * A[d].ny + (size_t)A[d + 1].nx * A[d + 1].ny + (size_t)A[d + 2].nx * A[d + 2].ny;
-        const long nwg = (long)gd.x * (gd.y - (a.fin.partials ? 1 : 0));
-        if (lds_pyr <= 20000 && nwg <= ctx->ncu && (size_t)A[d].nx * A[d].ny * 16 < 0x7fffffffu) {
-            if (ctx->pyr_cap < ngr * 16) {
-                if (ctx->pyr_buf) { FPR_HIP(ctx, hipStreamSynchronize(s)); FPR_HIP(ctx, hipFree(ctx->pyr_buf)); ctx->pyr_buf = nullptr; ctx->pyr_cap = 0; }
-                FPR_HIP(ctx, hipMalloc(&ctx->pyr_buf, ngr * 16));
-                FPR_HIP(ctx, hipMemsetAsync(ctx->pyr_buf, 0, ngr * 16, s));
-                ctx->pyr_cap = ngr * 16;
-            }
-            static bool attr_pyr = false;
-            if (!attr_pyr) {
-                FPR_HIP(ctx, hipFuncSetAttribute((const void*)k_pyr_down, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_pyr = true;
-            }
-            PyrArgs pa;
-            pa.L[0] = a.P;
-            for (int k = 0; k < 3; ++k) pa.L[k + 1] = a.L[k];
-            char* tb = (char*)ctx->pyr_buf;
-            pa.ftag[0] = tb; tb += (size_t)A[d].nx * A[d].ny * 16;
-            pa.ftag[1] = tb; tb += (size_t)A[d + 1].nx * A[d + 1].ny * 16;
-            pa.ftag[2] = tb;
-            pa.nxD = a.nxD; pa.nyD = a.nyD; pa.uD = a.uD;
-            pa.apply_BCs = apply_BCs; pa.skip = skp;
-            ctx->pyr_epoch += 4;
-            pa.tag_base = (unsigned long long)ctx->pyr_epoch;
-            pa.fin = a.fin;
-            pa.prof = (long long*)(uintptr_t)fpr_opt(ctx, "mg_pyr_prof", 0);
-            k_pyr_down<<<gd, MID_NT_DOWN, lds_pyr * sizeof(double), s>>>(pa);
-            pyr = true;
-        }
-    }
-    if (!pyr)
     k_mid_down<<<gd, MID_NT_DOWN, lds_down * sizeof(double), s>>>(a);   // :124-132 of levels d, d+1, d+2 (and of the level above)
     FPR_CHECK_LAUNCH(ctx);
     a.fin = FprFinishArgs{};
@@ -1231,11 +1157,11 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             a.out_sumsq = ctx->scalars;
             a.state = ctx->state;
             a.skip = ctx->cyc_skip;
-            a.row_solve = fpr_opt(ctx, "mg_small_row", 1) != 0;
+            a.row_solve = true;
             // below the top level u is the zero guess the level above has just stored (:132): not loaded, and the two pre-smoothing
             // sweeps of every level of the sub-hierarchy are one pass (option mg_zero_fuse; mg_zero_guess = 0: u is read like any field)
             a.zfuse = fpr_opt(ctx, "mg_zero_fuse", 1) != 0 ? ((!top && fpr_opt(ctx, "mg_zero_guess", 1) != 0) ? 2 : 1) : 0;
-            a.prof = (long long*)(uintptr_t)fpr_opt(ctx, "mg_small_prof", 0);   // tools/exp_mg_small_prof.py: device address of 32 int64, or 0
+            a.prof = nullptr;   // tools/exp_mg_small_prof.py: device address of 32 int64, or 0
             if (int rc = fprx_cycle_finish_flush(ctx)) return rc;
             k_mg_small<<<1, MGS_NT, (tot + MGS_RED) * sizeof(double), s>>>(a);
             FPR_CHECK_LAUNCH(ctx);
@@ -1251,7 +1177,7 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
     // ---- three launch-bound levels in two launches (k_mid_down / k_mid_up) around the LDS-resident sub-hierarchy ----
     if (!top) {
         bool taken = false;
-        if (int rc = mid_path(ctx, A, d, u, rhs, h, c, tol, css, solver, apply_BCs, nullptr, nullptr, 0.0, &taken)) return rc;
+        if (int rc = mid_path(ctx, A, d, u, rhs, h, c, tol, css, solver, apply_BCs, &taken)) return rc;
         if (taken) return FPR_OK;
     }
 
@@ -1261,26 +1187,17 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
         // a finish handed over by the loop (fprx_cycle_finish_defer) rides on the restricting two-sweep pass below; every other way
         // down launches it first
         const bool carry_fin = ctx->fin.partials && !top && fpr_opt(ctx, "mg_multi", 1) == 1 && nx >= 64 && ny >= 16 &&
-                               fpr_opt(ctx, "mg_fuse_restrict", 1) != 0 && fpr_opt(ctx, "mg_vx", 1) != 2 && fpr_opt(ctx, "mg_march_v", 2) != 1;
+                               fpr_opt(ctx, "mg_fuse_restrict", 1) != 0;
         if (!carry_fin)
             if (int rc = fprx_cycle_finish_flush(ctx)) return rc;
         if (fpr_opt(ctx, "mg_multi", 1) == 1 && nx >= 64 && ny >= 16) {
             // temporal blocking, register-rolling march: each smoothing pair is ONE pass (u -> tmp, tmp -> u)
             const bool fuse_r = fpr_opt(ctx, "mg_fuse_restrict", 1) != 0;
-            const int ntf = fpr_opt(ctx, "mg_nt", 0) ? 256 : 0;
-            // two columns per lane (128-column strips, aligned 16-byte accesses with a per-row lane shift): bit-identical but
-            // measured SLOWER on MI355X (4.4 vs 2.8 ms per 4097^2 solve; 114-204 VGPRs against 36-60), so it is opt-in (mg_vx = 2)
-            const bool al16 = ((((uintptr_t)u | (uintptr_t)rhs | (uintptr_t)L.tmp) & 15) == 0);
-            const bool vx2 = fpr_opt(ctx, "mg_vx", 1) == 2 && nx >= 128 && al16;
-            const int sw = vx2 ? 122 : 60, sw_r = vx2 ? 120 : 58;
+            const int sw = 60, sw_r = 58;             // columns a 64-column strip owns (plain / restricting pass)
             const int nstrips = (nx + sw - 1) / sw;
             const int nstrips_r = (nx + sw_r - 1) / sw_r;  // strips of the restricting pre-smoothing pass
-            int rpc = (int)fpr_opt(ctx, "mg_rows_per_chunk", 0);
-            if (rpc <= 0) {  // enough chunks for >= ~16 waves per CU, chunks of at least 16 rows
-                const long target = fpr_opt(ctx, "mg_wave_target", 4096);
-                rpc = 64;
-                while (rpc > 16 && (long)nstrips * ((ny + rpc - 1) / rpc) < target) rpc >>= 1;
-            }
+            int rpc = 64;    // enough chunks for >= ~16 waves per CU (4096 strip-chunks), chunks of at least 16 rows
+            while (rpc > 16 && (long)nstrips * ((ny + rpc - 1) / rpc) < 4096) rpc >>= 1;
             rpc += rpc & 1;   // chunks start on even rows (k_smooth2_march_v2)
             const dim3 gm((nstrips + 3) / 4, (ny + rpc - 1) / rpc);
             const int npm = (int)(gm.x * gm.y);
@@ -1288,73 +1205,38 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             // below the top level u is the zero guess the level above has just stored (:132): the pre-smoothing pass is told so
             // (bit 9) and does not read it (k_smooth2_march_v2; option mg_zero_guess = 0: read it like any field)
             const int uz = (!top && fpr_opt(ctx, "mg_zero_guess", 1) != 0) ? 512 : 0;
-            // Where the three levels below are k_mid_down's, this level rides along on the way down (mid_path with LP = this level): its
-            // two sweeps from the zero guess and its residual are recomputed pointwise in that launch's prologue, so its pre-smoothing
-            // pass is not launched at all (option mg_mid4, off by default: 1025^2 under a 2049^2 or 4097^2 top level saves a 10.4 us pass and a
-            // launch boundary and costs 16-17 us of recomputation in LDS -- EXPERIMENTS 13.14)
-            bool down4 = false;
-            if (!top && fuse_r && fuse_p && !vx2 && uz && nx <= 1025 && ny <= 1025 && d + 4 < A.size() &&
-                (fpr_opt(ctx, "mg_mid4", FPR_MID4_DEFAULT) || fpr_opt(ctx, "mg_pyr_down", 0)))
-                if (int rc = mid_path(ctx, A, d + 1, L.corr_c, L.res_c, h * 2, c, tol, css, solver, apply_BCs, &L, rhs, h, &down4)) return rc;
-            if (down4) {
-            } else
             if (fuse_r) {  // pre-smoothing pair + residual + injection + zero coarse guess in ONE pass (:124-132)
                 const dim3 gr((nstrips_r + 3) / 4, (ny + rpc - 1) / rpc);
                 const bool timed = top && fpr_ktimer_begin(ctx, FPR_KT_MG_PRE, s);
                 if (carry_fin) {   // + one workgroup row: the finish of the cycle before (k_smooth2_march_v2)
                     const FprFinishArgs fa = ctx->fin;
                     ctx->fin = FprFinishArgs{};
-                    k_smooth2_march_v2<false, false, true><<<dim3(gr.x, gr.y + 1), 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, apply_BCs | ntf | uz, L.res_c, L.corr_c, skp, fa);
+                    k_smooth2_march_v2<false, false, true><<<dim3(gr.x, gr.y + 1), 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, apply_BCs | uz, L.res_c, L.corr_c, skp, fa);
                 } else
-                { if (vx2) k_smooth2_march2<false, false, true><<<gr, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, ntf, L.res_c, L.corr_c, skp); else march_go<false, false, true>(ctx, gr, s, u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, apply_BCs | ntf | uz, L.res_c, L.corr_c, skp); }
+                march_go<false, false, true>(ctx, gr, s, u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, apply_BCs | uz, L.res_c, L.corr_c, skp);
                 fpr_ktimer_end(ctx, timed, s);
-                if (apply_BCs && vx2) k_bc_neumann<<<(nyc + 255) / 256, 256, 0, s>>>(L.res_c, nxc, nyc, skp);  // :355-357 (k_smooth2_march does it itself)
             } else {
-                { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); else march_go<false, false, false>(ctx, gm, s, u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf | uz, nullptr, nullptr, skp); }  // :124-125
+                march_go<false, false, false>(ctx, gm, s, u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, uz, nullptr, nullptr, skp);  // :124-125
                 k_restrict_residual2d<<<grid2(nxc, nyc), blk2, 0, s>>>(L.tmp, rhs, L.res_c, nx, ny, C, _h2, apply_BCs, L.corr_c);  // :128-132
             }
             FPR_CHECK_LAUNCH(ctx);
             double dummy; bool dh;
-            if (!down4)
             if (int rc = vcycle_level(ctx, A, d + 1, L.corr_c, L.res_c, h * 2, c, tol, css, solver, apply_BCs, false, &dummy, &dh))
                 return rc;  // :133
             if (!fuse_p) k_prolong2d<true><<<g, blk2, 0, s>>>(L.corr_c, L.tmp, nx, ny, apply_BCs);  // :136-139
             // post-smoothing pair (:142-143); with fuse_p the correction u - P(corr_c) is applied while loading
             if (top) {
                 const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_POST, s);
-                if (fuse_p) { if (vx2) k_smooth2_march2<true, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs | ntf, nullptr, nullptr, skp); else march_go<true, true, false>(ctx, gm, s, L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs | ntf, nullptr, nullptr, skp); }
-                else { if (vx2) k_smooth2_march2<true, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, ntf, nullptr, nullptr, skp); else march_go<true, false, false>(ctx, gm, s, L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, ntf, nullptr, nullptr, skp); }
+                if (fuse_p) march_go<true, true, false>(ctx, gm, s, L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, L.corr_c, apply_BCs, nullptr, nullptr, skp);
+                else march_go<true, false, false>(ctx, gm, s, L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, ctx->partials, nullptr, 0, nullptr, nullptr, skp);
                 fpr_ktimer_end(ctx, timed, s);
                 FPR_CHECK_LAUNCH(ctx);
                 if (skp) { if (int rc = fprx_cycle_finish(ctx, ctx->partials, npm, ctx->scalars, (double)nx * (double)ny, ctx->cyc_slot)) return rc; }
                 else if (int rc = fprx_finish_sum(ctx, ctx->partials, npm, ctx->scalars, false, 0)) return rc;
                 *rms_is_host = false;
             } else {
-                if (fuse_p) { if (vx2) k_smooth2_march2<false, true, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs | ntf, nullptr, nullptr, skp); else march_go<false, true, false>(ctx, gm, s, L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs | ntf, nullptr, nullptr, skp); }
-                else { if (vx2) k_smooth2_march2<false, false, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); else march_go<false, false, false>(ctx, gm, s, L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, ntf, nullptr, nullptr, skp); }
-                FPR_CHECK_LAUNCH(ctx);
-            }
-            return FPR_OK;
-        }
-        if (fpr_opt(ctx, "mg_multi", 1) == 2 && nx >= 64 && ny >= 32) {
-            // temporal blocking, LDS tile variant (kept for A/B comparison; slower than the march on gfx950)
-            constexpr int TX = 64, TY = 32;
-            const dim3 gm((nx + TX - 1) / TX, (ny + TY - 1) / TY);
-            const int npm = (int)(gm.x * gm.y);
-            k_sweep2d_multi<2, TX, TY, 0, false><<<gm, 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, 2, nullptr, nullptr);  // :124-125
-            k_restrict_residual2d<<<grid2(nxc, nyc), blk2, 0, s>>>(L.tmp, rhs, L.res_c, nx, ny, C, _h2, apply_BCs, L.corr_c);  // :128-132
-            FPR_CHECK_LAUNCH(ctx);
-            double dummy; bool dh;
-            if (int rc = vcycle_level(ctx, A, d + 1, L.corr_c, L.res_c, h * 2, c, tol, css, solver, apply_BCs, false, &dummy, &dh))
-                return rc;  // :133
-            k_prolong2d<true><<<g, blk2, 0, s>>>(L.corr_c, L.tmp, nx, ny, apply_BCs);  // :136-139
-            if (top) {
-                k_sweep2d_multi<2, TX, TY, 1, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, 2, ctx->partials, nullptr);  // :142-143
-                FPR_CHECK_LAUNCH(ctx);
-                if (int rc = fprx_finish_sum(ctx, ctx->partials, npm, ctx->scalars, false, 0)) return rc;
-                *rms_is_host = false;
-            } else {
-                k_sweep2d_multi<2, TX, TY, 0, false><<<gm, 256, 0, s>>>(L.tmp, rhs, u, nx, ny, C, _h2, fac, 2, nullptr, nullptr);
+                if (fuse_p) march_go<false, true, false>(ctx, gm, s, L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, L.corr_c, apply_BCs, nullptr, nullptr, skp);
+                else march_go<false, false, false>(ctx, gm, s, L.tmp, rhs, u, nx, ny, C, _h2, fac, rpc, nstrips, nullptr, nullptr, 0, nullptr, nullptr, skp);
                 FPR_CHECK_LAUNCH(ctx);
             }
             return FPR_OK;
@@ -1404,8 +1286,8 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             constexpr int S8 = 8, TX = 16, TY = 16;
             constexpr int PP = 32;
             const bool patch = fpr_opt(ctx, "mg_patch", 1) != 0;
-            int PS = (int)fpr_opt(ctx, "mg_patch_sweeps", 0);
-            if (PS < 6 || PS > 8) {
+            int PS;
+            {
                 // default: 8 sweeps per group (own tiles of 16 x 16) -- or 7 (18 x 18) where that brings the number of workgroups from above
                 // the number of compute units to below it: the persistent kernels hand tiles from neighbour to neighbour, and a compute unit
                 // that holds two workgroups sets the pace for everybody (257^2: 289 -> 225 workgroups, 0.68 -> 0.54 us per sweep)
@@ -1421,33 +1303,28 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
             const dim3 gm((nx + TXp - 1) / TXp, (ny + TYp - 1) / TYp);
             const int nblk = (int)(gm.x * gm.y);
             if ((size_t)nblk * S > (size_t)FPR_MAX_PARTIALS) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for partial buffer");
-            int Sg = (int)fpr_opt(ctx, "mg_group_sweeps", S);  // sweeps per launch (<= S; tuning/diagnostic knob)
-            if (Sg < 1 || Sg > S) Sg = S;
+            const int Sg = S;          // sweeps per launch
             const int groups = (iters + Sg - 1) / Sg;
             int g_resume = 0;          // the plain loop below starts at this group (> 0: behind a persistent launch that gave up)
             // ---- the persistent form: launches of up to 16 groups of 8 sweeps with neighbour-to-neighbour hand-offs inside
             //      (mg_jacobi_persistent.hpp); the plain form below stays for A/B, for grids it does not fit and as the replay ----
             // (options mg_patch_sweeps = 7: groups of 7 sweeps on own tiles of 18 x 18 -- 225 workgroups for 257^2 instead of 289; mg_jacp_py = 1: 2 x 1 register
             //  patches, 512 threads, two waves per SIMD)
-            const long pyv = fpr_opt(ctx, "mg_jacp_py", 0);
-            const int PYo = pyv == 2 ? 2 : (pyv == 1 ? 1 : FPR_JACP_PY_DEFAULT);
-            if (patch && (PS == 8 || PS == 7) && Sg == PS && fpr_opt(ctx, "mg_jacobi_persist", 1) != 0 && (size_t)N * 8 < 0x7fffffffu) {
+            // Option handoff_fences = 1 asks for hand-offs inside the HIP memory model: the data-tagged granules are not (a 16-byte sc1 access
+            // being untorn is a property of the hardware, not of the model), so the coarse solve then runs as plain launches of k_jacobi_patch
+            // -- kernel boundaries are its hand-offs (1.5 us per sweep against 0.54; flags + agent-scope release / acquire cost 1.21:
+            // profiles/r6_handoff_fences.txt)
+            constexpr int PYo = 1;          // rows of a thread's register patch: 2 x 1 patches, 512 threads, two waves per SIMD
+            if (patch && (PS == 8 || PS == 7) && Sg == PS && fpr_opt(ctx, "mg_jacobi_persist", 1) != 0 && fpr_opt(ctx, "handoff_fences", 0) == 0 &&
+                (size_t)N * 8 < 0x7fffffffu) {
                 const int jnt = (PP / 2) * (PP / PYo);
-                const int tgo = fpr_opt(ctx, "mg_jacp_tagged", FPR_JACP_TAGGED_DEFAULT) != 0 ? 1 : 0;
-                if (ctx->jacp_resident < 0 || ctx->jacp_resident_key != PS * 100 + PYo * 10 + tgo) {
+                if (ctx->jacp_resident < 0 || ctx->jacp_resident_key != PS * 100 + PYo * 10 + 1) {
                     int per_cu = 0;
                     hipError_t oe;
-                    if (tgo) {
-                        if (PS == 8) oe = PYo == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist_tag<8, PP, 2>, jnt, 0)
-                                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist_tag<8, PP, 1>, jnt, 0);
-                        else oe = PYo == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist_tag<7, PP, 2>, jnt, 0)
-                                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist_tag<7, PP, 1>, jnt, 0);
-                    } else if (PS == 8) oe = PYo == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist<8, PP, 2>, jnt, 0)
-                                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist<8, PP, 1>, jnt, 0);
-                    else oe = PYo == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist<7, PP, 2>, jnt, 0)
-                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist<7, PP, 1>, jnt, 0);
+                    oe = PS == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist_tag<8, PP, 1>, jnt, 0)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_jacobi_persist_tag<7, PP, 1>, jnt, 0);
                     const bool ok = oe == hipSuccess;
-                    ctx->jacp_resident_key = PS * 100 + PYo * 10 + tgo;
+                    ctx->jacp_resident_key = PS * 100 + PYo * 10 + 1;
                     if (ctx->ncu <= 0) {
                         int v = 0;
                         ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
@@ -1455,28 +1332,20 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                     ctx->jacp_resident = ok ? per_cu * ctx->ncu : 0;    // workgroups the device holds at once
                 }
                 const int GMAX = 32;    // groups per launch: 256 sweeps, whose exit tests one workgroup replays behind the launch
-                // ---- the data-tagged form (k_jacobi_persist_tag: a cell travels as a 16-byte {value, tag} granule, no flags, no drains);
-                //      option mg_jacp_tagged = 0: the flag form below ----
+                // ---- k_jacobi_persist_tag: a cell travels as a 16-byte {value, tag} granule, no flags, no drains ----
                 {
                     CgWork w2;
-                    if (fpr_opt(ctx, "mg_jacp_tagged", FPR_JACP_TAGGED_DEFAULT) != 0 && nblk <= ctx->jacp_resident / 2 &&
+                    if (nblk <= ctx->jacp_resident / 2 &&
                         (size_t)2 * GMAX * PS * nblk <= (size_t)FPR_MAX_PARTIALS - 2048 && (size_t)N * 16 < 0x7fffffffu && cg_work(ctx, 3 * N, &w2) == FPR_OK) {
                         // five rotating granule buffers (2 N doubles each): a launch reads one, writes three, and leaves the input of the launch
                         // BEFORE it alone -- the exit test of that launch runs beside it (below) and may still ask for a replay from there
                         void* Gb[5];
                         for (int k = 0; k < 5; ++k) Gb[k] = w2.r + (size_t)2 * N * k;
                         double* P0 = w2.r + (size_t)10 * N;          // plain scratch (N doubles): the input of a launch that is replayed
-                        // The exit tests of a launch (k_jacobi_check_groups: 8 us) run on a side stream BESIDE the next launch instead of between
-                        // two launches: the partial sums alternate between two halves of the scratch, and a launch that starts before the tests of
-                        // its predecessor have found the exit only wastes itself (it reads `done` at its start; everything behind it sees it).
-                        if (!ctx->aux_stream) {
-                            FPR_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-                            for (int k = 0; k < 3; ++k) FPR_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev[k], hipEventDisableTiming));
-                        }
-                        // (measured: 3.63 ms per five-level V-cycle beside against 3.37 in line -- two cross-stream event waits per launch cost more
-                        //  than the 8 us test they hide: option mg_jacp_check_beside, default off)
-                        const bool beside = fpr_opt(ctx, "mg_jacp_check_beside", 0) != 0;
-                        hipStream_t sc = beside ? ctx->aux_stream : s;
+                        // The exit tests of a launch (k_jacobi_check_groups: 8 us) run in line behind it (on a side stream beside the next launch they
+                        // cost two cross-stream event waits per launch: 3.63 against 3.37 ms per five-level V-cycle, EXPERIMENTS 13.5); a launch that
+                        // starts before the tests of its predecessor have found the exit only wastes itself (it reads `done` at its start).
+                        hipStream_t sc = s;
                         const size_t phalf = (size_t)GMAX * PS * nblk;
                         int* flags = reinterpret_cast<int*>(ctx->partials + FPR_MAX_PARTIALS - 1024);
                         int* abort_flag = flags + 2040;
@@ -1488,14 +1357,7 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                         std::vector<RecT> recs;
                         int cur = -1, prevx = -1, gdone = 0, poll_after = 1, since_poll = 0;
                         const unsigned ugrid = (unsigned)((N + 255) / 256);
-                        if (beside) {      // the side stream starts behind everything the solve's inputs depend on
-                            FPR_HIP(ctx, hipEventRecord(ctx->aux_ev[0], s));
-                            FPR_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_ev[0], 0));
-                        }
-                        auto state_now = [&]() -> int {      // the host's view of the solve: behind the tests enqueued so far
-                            if (beside && !recs.empty()) FPR_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_ev[1 + ((recs.size() - 1) & 1)], 0));
-                            return read_state(ctx);
-                        };
+                        auto state_now = [&]() -> int { return read_state(ctx); };      // the host's view of the solve: behind the tests enqueued so far
                         while (gdone < groups) {
                             const int G = groups - gdone < GMAX ? groups - gdone : GMAX;
                             RecT r;
@@ -1503,7 +1365,6 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                             for (int k = 0, q = 0; k < 5 && q < 3; ++k) if (k != cur && k != prevx) r.w[q++] = k;
                             double* parts = ctx->partials + (recs.size() & 1) * phalf;
                             // (this launch overwrites the partial sums of the launch before the last one: its tests are through)
-                            if (beside && recs.size() >= 2) FPR_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_ev[1 + (recs.size() & 1)], 0));
                             JacTagArgs a;
                             a.X = u; a.Xg = cur >= 0 ? Gb[cur] : nullptr; a.x_tagged = cur >= 0 ? 1 : 0;
                             for (int q = 0; q < 3; ++q) a.W[q] = Gb[r.w[q]];
@@ -1512,20 +1373,15 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                             a.nsw_last = (gdone + G == groups) ? iters - (groups - 1) * PS : PS;
                             a.partials = parts; a.abort_flag = abort_flag; a.state = ctx->state;
                             a.g0 = gdone; a.tag_base = tag_base;
-                            a.prof = fpr_opt(ctx, "mg_jacp_prof", 0) != 0 ? reinterpret_cast<long long*>(fpr_opt(ctx, "mg_jacp_prof", 0)) : nullptr;
+                            a.prof = nullptr;
                             if ((long)recs.size() + 1 == fpr_opt(ctx, "mg_jacobi_persist_test_abort", 0))      // (test hook: this launch "times out")
                                 FPR_HIP(ctx, hipMemsetAsync(abort_flag, 1, 1, s));
                             const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_PATCH, s);
-                            if (PS == 8) { if (PYo == 2) k_jacobi_persist_tag<8, PP, 2><<<gm, jnt, 0, s>>>(a); else k_jacobi_persist_tag<8, PP, 1><<<gm, jnt, 0, s>>>(a); }
-                            else { if (PYo == 2) k_jacobi_persist_tag<7, PP, 2><<<gm, jnt, 0, s>>>(a); else k_jacobi_persist_tag<7, PP, 1><<<gm, jnt, 0, s>>>(a); }
+                            if (PS == 8) k_jacobi_persist_tag<8, PP, 1><<<gm, jnt, 0, s>>>(a);
+                            else k_jacobi_persist_tag<7, PP, 1><<<gm, jnt, 0, s>>>(a);
                             fpr_ktimer_end(ctx, timed, s);
-                            if (beside) {
-                                FPR_HIP(ctx, hipEventRecord(ctx->aux_ev[0], s));
-                                FPR_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_ev[0], 0));
-                            }
                             k_jacobi_check_groups<<<G, 256, 0, sc>>>(ctx->state, parts, nblk, G, PS, a.nsw_last, (double)N, gdone, abort_flag, gsums, counter);
                             FPR_CHECK_LAUNCH(ctx);
-                            if (beside) FPR_HIP(ctx, hipEventRecord(ctx->aux_ev[1 + (recs.size() & 1)], ctx->aux_stream));
                             recs.push_back(r);
                             prevx = cur;
                             cur = r.w[G % 3];                  // the last group (index G - 1) wrote W[G % 3]
@@ -1588,109 +1444,6 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                         *rms_is_host = true;
                         return FPR_OK;
                     }
-                }
-                CgWork w;
-                if (nblk <= ctx->jacp_resident / 2 && (size_t)GMAX * PS * nblk <= (size_t)FPR_MAX_PARTIALS - 2048 && cg_work(ctx, N, &w) == FPR_OK) {
-                    double* B[4] = {u, L.tmp, w.r, w.p};
-                    int* flags = reinterpret_cast<int*>(ctx->partials + FPR_MAX_PARTIALS - 1024);   // nblk <= 2048 words + the abort word
-                    if (nblk + 8 > 2048) return fpr_fail(ctx, FPR_ERR_INVALID, "grid too large for the flag block");
-                    int* abort_flag = flags + 2040;      // [2040] abort, [2041] arrival counter of the check's workgroups
-                    int* counter = flags + 2041;
-                    double* gsums = ctx->partials + FPR_MAX_PARTIALS - 2048;   // 256 sums of a launch (behind the partial lists, before the flags)
-                    FPR_HIP(ctx, hipMemsetAsync(flags, 0, 2048 * sizeof(int), s));   // flags count groups since the start of the solve
-                    struct Rec { int x, w[3], g0, G; };
-                    std::vector<Rec> recs;
-                    int cur = 0, gdone = 0, poll_after = 1, since_poll = 0;   // the host looks after 1, 2, 4, 8, 8, ... launches (a launch behind
-                                                                              // the one that met the criterion returns at once: 5 us)
-                    while (gdone < groups) {
-                        const int G = groups - gdone < GMAX ? groups - gdone : GMAX;
-                        Rec r;
-                        r.x = cur; r.g0 = gdone; r.G = G;
-                        for (int k = 0, q = 0; k < 4; ++k) if (k != cur) r.w[q++] = k;
-                        JacPersistArgs a;
-                        a.X = B[r.x];
-                        for (int q = 0; q < 3; ++q) a.W[q] = B[r.w[q]];
-                        // (group g of a launch reads X for g = 0, else W[g % 3], and writes W[(g + 1) % 3])
-                        a.rhs = rhs; a.nx = nx; a.ny = ny; a.C = C; a._h2 = _h2; a.fac = fac;
-                        a.ngroups = G;
-                        a.nsw_last = (gdone + G == groups) ? iters - (groups - 1) * PS : PS;
-                        a.partials = ctx->partials; a.flags = flags; a.abort_flag = abort_flag; a.state = ctx->state;
-                        a.g0 = gdone;
-                        a.fences = fpr_opt(ctx, "handoff_fences", 0) != 0 ? 1 : 0;
-                        a.prof = nullptr;
-                        if (fpr_opt(ctx, "mg_jacp_prof", 0) != 0) {      // diagnostic: 8 words per workgroup behind the solver's work vectors (tools/exp_jacp_prof.py)
-                            a.prof = reinterpret_cast<long long*>(fpr_opt(ctx, "mg_jacp_prof", 0));
-                        }
-                        if ((long)recs.size() + 1 == fpr_opt(ctx, "mg_jacobi_persist_test_abort", 0))      // (test hook: this launch "times out")
-                            FPR_HIP(ctx, hipMemsetAsync(abort_flag, 1, 1, s));
-                        const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_PATCH, s);
-                        if (PS == 8) { if (PYo == 2) k_jacobi_persist<8, PP, 2><<<gm, jnt, 0, s>>>(a); else k_jacobi_persist<8, PP, 1><<<gm, jnt, 0, s>>>(a); }
-                        else { if (PYo == 2) k_jacobi_persist<7, PP, 2><<<gm, jnt, 0, s>>>(a); else k_jacobi_persist<7, PP, 1><<<gm, jnt, 0, s>>>(a); }
-                        fpr_ktimer_end(ctx, timed, s);
-                        k_jacobi_check_groups<<<G, 256, 0, s>>>(ctx->state, ctx->partials, nblk, G, PS, a.nsw_last, (double)N, gdone, abort_flag, gsums, counter);
-                        FPR_CHECK_LAUNCH(ctx);
-                        recs.push_back(r);
-                        cur = r.w[G % 3];                  // the last group (index G - 1) wrote W[G % 3]
-                        gdone += G;
-                        if (++since_poll >= poll_after || gdone >= groups) {
-                            since_poll = 0;
-                            if (poll_after < 8) poll_after *= 2;
-                            if (int rc = read_state(ctx)) return rc;
-                            if (ctx->state_h->done) break;
-                        }
-                    }
-                    if (ctx->state_h->done < 0) {
-                        // A neighbour hand-off timed out (workgroups not resident together: a shared card, a long kernel of another
-                        // context).  Launches enqueued behind the one that gave up returned at once, and a launch never writes its
-                        // input: that input is the field after `g0` groups.  Resume there with the plain launches (one per 8 sweeps),
-                        // and keep this context off the persistent form from now on (as cg! does: cg_persistent_timeouts).
-                        const Rec* r = nullptr;
-                        for (const Rec& q : recs) if (q.g0 == ctx->state_h->group) r = &q;
-                        if (!r) return fpr_fail(ctx, FPR_ERR_HIP, "k_jacobi_persist: a neighbour hand-off timed out and the launch that gave up is unknown");
-                        ctx->jacp_resident = 0;
-                        ctx->options["mg_jacobi_persist_timeouts"] = fpr_opt(ctx, "mg_jacobi_persist_timeouts", 0) + 1;
-                        FPR_HIP(ctx, hipMemsetAsync(flags, 0, 2048 * sizeof(int), s));
-                        double* want = (r->g0 & 1) ? L.tmp : u;       // the plain loop reads group gi from u (even) / L.tmp (odd)
-                        if (B[r->x] != want) {
-                            double* via = B[r->x];
-                            if (via == u || via == L.tmp) {          // (the two may not be copied onto each other's partner directly: same buffers are fine, but keep it simple)
-                                FPR_HIP(ctx, hipMemcpyAsync(w.r, via, N * sizeof(double), hipMemcpyDeviceToDevice, s));
-                                via = w.r;
-                            }
-                            FPR_HIP(ctx, hipMemcpyAsync(want, via, N * sizeof(double), hipMemcpyDeviceToDevice, s));
-                        }
-                        k_state_resume<<<1, 1, 0, s>>>(ctx->state);
-                        FPR_CHECK_LAUNCH(ctx);
-                        ctx->state_h->done = 0;
-                        g_resume = r->g0;
-                        goto plain_jacobi_groups;
-                    }
-                    double* result = B[cur];
-                    if (ctx->state_h->done) {
-                        // the criterion was met inside launch `r`: launches behind it returned at once; replay the exact number of sweeps
-                        // from that launch's untouched input with the ordinary launches
-                        const int gs = ctx->state_h->group, redo = ctx->state_h->redo;
-                        const Rec* r = nullptr;
-                        for (const Rec& q : recs) if (gs >= q.g0 && gs < q.g0 + q.G) r = &q;
-                        if (!r) return fpr_fail(ctx, FPR_ERR_INVALID, "k_jacobi_persist: exit group outside the launches");
-                        int left = (gs - r->g0) * PS + redo;
-                        const double* in = B[r->x];
-                        int o = 0;
-                        while (left > 0) {
-                            const int m = left < PS ? left : PS;
-                            double* out = B[r->w[o & 1]];
-                            if (PS == 8) k_jacobi_patch<8, PP, false, false><<<gm, (PP / 2) * (PP / 2), 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, m, nullptr, nullptr, nullptr, 0, 0, 0.0);
-                            else k_jacobi_patch<7, PP, false, false><<<gm, (PP / 2) * (PP / 2), 0, s>>>(in, rhs, out, nx, ny, C, _h2, fac, m, nullptr, nullptr, nullptr, 0, 0, 0.0);
-                            in = out; ++o; left -= m;
-                        }
-                        FPR_CHECK_LAUNCH(ctx);
-                        result = const_cast<double*>(in);
-                    }
-                    if (result != u) FPR_HIP(ctx, hipMemcpyAsync(u, result, N * sizeof(double), hipMemcpyDeviceToDevice, s));
-                    ctx->last_coarse_iters += ctx->state_h->iters;
-                    *rms_out_host = ctx->state_h->last_rms;
-                    *rms_is_host = true;
-                    return FPR_OK;
                 }
             }
         plain_jacobi_groups:
@@ -1788,7 +1541,7 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
 
 // ---- finest level of fpr_mgsolve2d when consecutive cycles share a pass (k_seam_march) -------------------------------
 struct TopGeom {
-    int nx, ny, rpc, rpc_s, nstrips, nstrips_r, nstrips_s, ntf, seam_cols;
+    int nx, ny, rpc, rpc_s, nstrips, nstrips_r, nstrips_s, seam_cols;
     dim3 gm, gr, gs;
     double C, _h2, fac;
 };
@@ -1799,51 +1552,34 @@ static TopGeom top_geom(fpr_ctx* ctx, int nx, int ny, double h, double c)
     g.nx = nx; g.ny = ny;
     g.C = 4.0 + c * (h * h); g._h2 = 1 / (h * h);
     g.fac = (4.0 / 5.0) * ((h * h) / (4.0 + c * (h * h)));
-    g.ntf = fpr_opt(ctx, "mg_nt", 0) ? 256 : 0;
     g.nstrips = (nx + 59) / 60;      // as vcycle_level (one column per lane)
     g.nstrips_r = (nx + 57) / 58;
-    // seam pass: one column per lane (k_seam_march_v2: 54 owned of 64) or two (k_seam_march_v3: 118 of 128; option mg_seam_cols)
-    // Two columns per lane halve the number of strips: taken (default) where one workgroup per CU still leaves chunks of 128 rows or more
-    // (4097^2: 9 x 27 workgroups, chunks of 152 rows: 112 against 118 us; 2049^2 would get 43-row chunks: 38 against 33 us), forced by 2, off by 1.
+    // seam pass: one column per lane (k_seam_march_v2: 54 owned of 64) or two (k_seam_march_v3: 118 of 128).  Two columns per lane halve
+    // the number of strips: taken where one workgroup per CU still leaves chunks of 128 rows or more (4097^2: 9 x 27 workgroups, chunks of
+    // 152 rows: 112 against 118 us; 2049^2 would get 43-row chunks: 38 against 33 us)
     {
         if (ctx->ncu <= 0) {
             int v = 0;
             ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
         }
-        const long want = fpr_opt(ctx, "mg_seam_cols", 0);
         const int gx3 = ((nx + 117) / 118 + 3) / 4;
         const int chunks3 = (int)(0.95 * ctx->ncu) / gx3;
-        const bool fits = chunks3 >= 1 && ny / chunks3 >= 128 && nx >= 256;
-        g.seam_cols = (fpr_opt(ctx, "mg_seam_v", 2) != 1 && nx >= 256 && (want == 2 || (want == 0 && FPR_SEAM_COLS_DEFAULT == 2 && fits))) ? 2 : 1;
+        g.seam_cols = (chunks3 >= 1 && ny / chunks3 >= 128 && nx >= 256) ? 2 : 1;
     }
     g.nstrips_s = g.seam_cols == 2 ? (nx + 117) / 118 : (nx + 53) / 54;
-    int rpc = (int)fpr_opt(ctx, "mg_rows_per_chunk", 0);
-    if (rpc <= 0) {
-        const long target = fpr_opt(ctx, "mg_wave_target", 4096);
-        rpc = 64;
-        while (rpc > 16 && (long)g.nstrips * ((ny + rpc - 1) / rpc) < target) rpc >>= 1;
-    }
+    int rpc = 64;
+    while (rpc > 16 && (long)g.nstrips * ((ny + rpc - 1) / rpc) < 4096) rpc >>= 1;
     rpc += rpc & 1;   // chunks start on even rows (k_smooth2_march_v2)
     g.rpc = rpc;
-    // k_seam_march holds 3 waves per SIMD (151 VGPRs) = 3 workgroups per CU, and a workgroup works for most of the pass:
-    // the chunks are made as tall as a single round allows (all workgroups resident at once, ~95 % of the slots) -- the
-    // 9 overlap rows weigh less and no second, half-empty round trails (4097^2: 38 chunks of 108 rows 127 us, 65 chunks of
-    // 64 rows 133 us, 52 of 80 rows 150 us)
-    int rs = (int)fpr_opt(ctx, "mg_seam_rows_per_chunk", 0);
-    if (rs <= 0) {
-        if (ctx->ncu <= 0) {
-            int v = 0;
-            ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
-        }
+    // A seam workgroup works for most of the pass: the chunks are made as tall as a single round allows (all workgroups resident at once,
+    // ~95 % of the slots) -- the 9 overlap rows weigh less and no second, half-empty round trails.  One column per lane (108 VGPRs): TWO
+    // workgroups per CU (what counts is that no CU gets one workgroup more than the others: 25 chunks of 164 rows 116 us where 50 of 82 rows
+    // take 121 us; counts just above a multiple of the CU count are the slow ones -- profiles/r4_mg_seam_chunks.txt); two columns per lane
+    // (twice the loads in flight per wave): ONE workgroup per CU keeps the chunks as tall.
+    int rs;
+    {
         const int gx = (g.nstrips_s + 3) / 4;
-        // First version (151 VGPRs): three workgroups per CU.  Second version (108 VGPRs, four fit): TWO per CU -- chunks twice as tall
-        // halve the share of the 5 + 4 overlap rows, and what counts is that no CU gets one workgroup more than the others: 25
-        // chunks of 164 rows (475 workgroups, at most 2 per CU) 116 us where 50 chunks of 82 rows (950, at most 4) take 121 us, and
-        // counts just above a multiple of the CU count are the slow ones (28 chunks = 532 workgroups: 143 us; 43 = 817: 132 us;
-        // tools/exp_seam_chunks.py, profiles/r4_mg_seam_chunks.txt)
-        // Third version (two columns per lane, twice the loads in flight per wave): ONE workgroup per CU keeps the chunks as tall.
-        const long wpc_opt = fpr_opt(ctx, "mg_seam_wg_per_cu", 0);
-        const int wg_per_cu = wpc_opt > 0 ? (int)wpc_opt : (fpr_opt(ctx, "mg_seam_v", 2) == 1 ? 3 : (g.seam_cols == 2 ? 1 : 2));
+        const int wg_per_cu = g.seam_cols == 2 ? 1 : 2;
         int chunks = (int)(0.95 * wg_per_cu * ctx->ncu) / gx;
         if (chunks < 1) chunks = 1;
         rs = (ny + chunks - 1) / chunks;
@@ -1870,10 +1606,10 @@ static int top_pre(fpr_ctx* ctx, const TopGeom& g, const double* uin, const doub
     const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_PRE, s);
     if (fsq_partials)   // the first pass of a solve also leaves sum(f.^2) as block partials (one per workgroup)
         k_smooth2_march_v2<false, false, true, true><<<g.gr, 256, 0, s>>>(uin, rhs, out, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips_r, fsq_partials,
-                                                                          nullptr, apply_BCs | g.ntf, res_c, corr_zero, skp, FprFinishArgs{});
+                                                                          nullptr, apply_BCs, res_c, corr_zero, skp, FprFinishArgs{});
     else
     march_go<false, false, true>(ctx, g.gr, s, uin, rhs, out, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips_r, nullptr,
-                                                             nullptr, apply_BCs | g.ntf, res_c, corr_zero, skp);   // (:355-357 included)
+                                                             nullptr, apply_BCs, res_c, corr_zero, skp);   // (:355-357 included)
     fpr_ktimer_end(ctx, timed, s);
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
@@ -1885,8 +1621,8 @@ static int top_post(fpr_ctx* ctx, const TopGeom& g, const double* X, const doubl
 {
     hipStream_t s = ctx->stream[0];
     const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_POST, s);
-    if (norm) march_go<true, true, false>(ctx, g.gm, s, X, rhs, uout, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips, ctx->partials, corr, apply_BCs | g.ntf, nullptr, nullptr, skp);
-    else march_go<false, true, false>(ctx, g.gm, s, X, rhs, uout, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips, nullptr, corr, apply_BCs | g.ntf, nullptr, nullptr, skp);
+    if (norm) march_go<true, true, false>(ctx, g.gm, s, X, rhs, uout, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips, ctx->partials, corr, apply_BCs, nullptr, nullptr, skp);
+    else march_go<false, true, false>(ctx, g.gm, s, X, rhs, uout, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc, g.nstrips, nullptr, corr, apply_BCs, nullptr, nullptr, skp);
     fpr_ktimer_end(ctx, timed, s);
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
@@ -1898,18 +1634,11 @@ static int top_seam(fpr_ctx* ctx, const TopGeom& g, const double* X, const doubl
 {
     hipStream_t s = ctx->stream[0];
     const bool timed = fpr_ktimer_begin(ctx, FPR_KT_MG_SEAM, s);
-    if (fpr_opt(ctx, "mg_seam_v", 2) == 1) {   // the first version of the pass (A/B; same fields)
-        if (apply_BCs) k_seam_march<true><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
-        else k_seam_march<false><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
-    } else if (g.seam_cols == 2) {
-        const bool pf6 = fpr_opt(ctx, "mg_seam_pf", 6) == 6;     // (six rows in flight per half: 112 us; four: 114-115; twelve: 115)
-        if (fpr_opt(ctx, "mg_seam_pf", 6) == 12 && !apply_BCs) k_seam_march_v3<false, 12, 2><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
-        else if (apply_BCs) k_seam_march_v3<true, 4, 2><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
-        else if (pf6) k_seam_march_v3<false, 6, 2><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
-        else k_seam_march_v3<false, 4, 2><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
+    if (g.seam_cols == 2) {     // (six rows in flight per half: 112 us at 4097^2; four: 114-115; twelve: 115)
+        if (apply_BCs) k_seam_march_v3<true, 4, 2><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
+        else k_seam_march_v3<false, 6, 2><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
     } else {
         if (apply_BCs) k_seam_march_v2<true><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
-        else if (fpr_opt(ctx, "mg_seam_pf", 4) == 6) k_seam_march_v2<false, 6><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
         else k_seam_march_v2<false><<<g.gs, 256, 0, s>>>(X, rhs, Y, g.nx, g.ny, g.C, g._h2, g.fac, g.rpc_s, g.nstrips_s, ctx->partials, corr, res_c, corr_zero, skp);
     }
     fpr_ktimer_end(ctx, timed, s);
@@ -1999,10 +1728,10 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
         ctx->cyc_skip = &ctx->cyc->stop;
         const int* skp = ctx->cyc_skip;
         int enq = 0;
-        const bool seam_path = fpr_opt(ctx, "mg_seam", 1) && fpr_opt(ctx, "mg_vx", 1) != 2;
+        const bool seam_path = fpr_opt(ctx, "mg_seam", 1) != 0;
         // sum(f.^2) rides on the first pass over the finest grid where that is the two-sweep march (k_smooth2_march_v2<..., FSQ>): the cycle
         // state is reset now, f_rms and the threshold follow behind that pass (fprx_cycle_init_from); otherwise a pass over f of its own
-        bool fsq = seam_path && fpr_opt(ctx, "mg_fold_fsq", FPR_FOLD_FSQ_DEFAULT) && fpr_opt(ctx, "mg_march_v", 2) != 1;
+        bool fsq = seam_path && fpr_opt(ctx, "mg_fold_fsq", FPR_FOLD_FSQ_DEFAULT);
         if (!seam_path)
             if (int rc = fprx_cycle_init(ctx, f, N, tol)) return rc;
         if (seam_path) {
@@ -2065,7 +1794,7 @@ extern "C" int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h,
                     X = L.tmp; p = 0; need_head = false;
                 }
                 bool last = (k == niters);
-                // mg_seam_predict: 1 = extrapolate (default); 0 = never (every cycle but the niters-th ends in a seam, the
+                // mg_seam_predict (a test hook): 1 = extrapolate (default); 0 = never (every cycle but the niters-th ends in a seam, the
                 // last one is replayed); 2 = odd cycles end in a plain pass (exercises the restart after a wrong guess)
                 const long predict = fpr_opt(ctx, "mg_seam_predict", 1);
                 if (predict == 2 && (k & 1)) last = true;

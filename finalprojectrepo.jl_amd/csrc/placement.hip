@@ -109,10 +109,14 @@ extern "C" int fpr_placement_rank(fpr_ctx* ctx, double* const* cand, int k, size
 
     // ---- copy time of every ordered pair (events on the compute stream) ----
     hipStream_t s = ctx->stream[0];
-    hipEvent_t e0, e1;
-    FPR_HIP(ctx, hipEventCreate(&e0));
-    FPR_HIP(ctx, hipEventCreate(&e1));
-    const int reps = (int)std::max(1L, fpr_opt(ctx, "place_copy_reps", 2));
+    struct Events {          // (destroyed on every return path)
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
+    } ev;
+    FPR_HIP(ctx, hipEventCreate(&ev.a));
+    FPR_HIP(ctx, hipEventCreate(&ev.b));
+    hipEvent_t e0 = ev.a, e1 = ev.b;
+    const int reps = 2;
     const size_t nb = (n + 1) / 2;
     // 2048 workgroups walking through the arrays together (fpr_copy's grid): the pattern the class thresholds were measured with, and
     // the one that resembles a march -- a grid of one 16-byte access per thread copies at 6.2-6.4 TB/s whatever the classes
@@ -136,8 +140,6 @@ extern "C" int fpr_placement_rank(fpr_ctx* ctx, double* const* cand, int k, size
         for (int i = 0; i < k; ++i)
             for (int j = 0; j < k; ++j) sym[(size_t)i * k + j] = 0.5 * (t[(size_t)i * k + j] + t[(size_t)j * k + i]);
     }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
     auto gbs = [&](double ms) { return ms > 0 ? bytes2 / (ms * 1e-3) / 1e9 : 0.0; };
     std::vector<double> flat;
     for (int i = 0; i < k; ++i)
@@ -150,7 +152,7 @@ extern "C" int fpr_placement_rank(fpr_ctx* ctx, double* const* cand, int k, size
     }
 
     // ---- rank the assignments by their slowest streamed-together pair ----
-    const int ntrials = (int)std::max(1L, fpr_opt(ctx, "place_trials", 4));
+    const int ntrials = 4;          // assignments handed to the caller's kernel besides the candidates as given
     Search S;
     S.k = k; S.nroles = nroles; S.keep = trial ? ntrials : 1; S.sym = &sym;
     for (auto& p : pp) {
@@ -199,8 +201,8 @@ extern "C" int fpr_placement_rank(fpr_ctx* ctx, double* const* cand, int k, size
         // the copy times only rank the candidates roughly; the caller's kernel decides.  First the candidates AS GIVEN (positions
         // 0 .. count-1 = what a host that simply allocates would use: the result is never worse than that), then the best few
         // assignments, then a local search: one position at a time swapped for a candidate not in use, kept when faster.
-        const double gain = (double)fpr_opt(ctx, "place_gain_pct_x10", 5) * 1e-3;
-        if (fpr_opt(ctx, "place_try_identity", 1) != 0) {
+        const double gain = 5e-3;       // a swap of the local search is kept when it is 0.5 % faster
+        {
             std::vector<int> ident;
             for (int q = 0; q < nroles; ++q) ident.push_back(roles[q]);
             ident_ms = run_trial(ident);
@@ -246,8 +248,8 @@ extern "C" int fpr_placement_rank(fpr_ctx* ctx, double* const* cand, int k, size
     // "more candidates would help": every pair of the pool copies below the rate at which pools with a second class start
     // (measured 5076-5160 GB/s where one exists, < 4950 where not: 1 GiB arrays), or the caller's kernel sees less than 2.5 % between any
     // two assignments (arrays that fit in the Infinity Cache copy at cache speed whatever their pages: only the trial can rank them)
-    const double below = (double)fpr_opt(ctx, "place_extend_below_GBs", 5050);
-    const double min_spread = (double)fpr_opt(ctx, "place_spread_pct_x10", 25) * 1e-3;
+    const double below = 5050.0;
+    const double min_spread = 25e-3;
     const bool uniform_copy = !flat.empty() && report[FPR_PLACE_POOL_FASTEST_GBS] < below;
     const bool uniform_trial = trial && tried >= 4 && spread < min_spread;
     report[FPR_PLACE_WANT_MORE] = uniform_copy ? 1.0 : (uniform_trial ? 2.0 : 0.0);

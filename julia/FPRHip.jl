@@ -48,7 +48,7 @@ export @init_parallel_stencil, @reset_parallel_stencil, @parallel, @parallel_ind
        halo_pack!, halo_unpack!, fpr_version,
        init_global_grid, finalize_global_grid, select_device, update_halo!, gather!, nx_g, ny_g, nz_g, x_g, y_g, z_g,
        halo_exchange_begin!, halo_exchange_end!, halo_exchange_comm!, allreduce_sum!,
-       diffusion_3D_step_τ2_halo!, join_pair!, alloc_fields, alloc_vcycle_fields, churn!, provide_arena!, provide_arena_coarse!
+       diffusion_3D_step_τ2_halo!, join_pair!, alloc_fields, alloc_vcycle_fields, provide_arena!, provide_arena_coarse!
 
 const libfpr = get(ENV, "FPR_HIP_LIB", joinpath(@__DIR__, "..", "finalprojectrepo.jl_amd", "lib", "libfpr_hip.so"))
 
@@ -521,38 +521,17 @@ kernel streams at equal offsets get in each other's way when their allocations c
 pages: the fused diffusion launch takes 0.76 ms at 512^3 on arrays that differ, 0.85-0.91 ms on arrays of one class).  The measurement and
 the search are ONE call into the library (`fpr_placement_rank`, include/fpr.h); the host only allocates the pool -- the first `count`
 plainly, as `@zeros` would, the rest behind untouched spacers -- and frees what was not chosen.  `pairs`: 1-based positions streamed
-together (default all); `trial(arrays) -> ms`: the caller's own kernel as the judge (optional).  Replaces nothing in the reference:
-`@zeros` (part1_kernel_programming.jl:134-142) keeps working without it.
+together (default all); `trial(arrays) -> ms`: the caller's own kernel as the judge (optional; the candidates as allocated are always among
+its trials).  The candidates' contents are scratch during the search; nothing but the returned arrays stays allocated.  Replaces nothing in the
+reference: `@zeros` (part1_kernel_programming.jl:134-142) keeps working without it -- and the three-iteration launch of a single rank does not
+need it at all (DESIGN.md 3).
 """
-"""
-    churn!(fraction = 0.7)
-
-Allocate, write and free most of the card's free memory once: on a lease whose fresh allocations are all of one placement class (report
-index 11 of `fpr_placement_rank` = 1) the pools built afterwards show the usual mix (INTEGRATION.md 5, `placement.churn` in the mirror).
-"""
-function churn!(fraction = 0.7)
-    left = floor(Int, fraction * AMDGPU.Runtime.Mem.info()[1])
-    held = Any[]
-    while left >= (1 << 30)
-        nb = min(left, 48 << 30)
-        A = try ROCArray{UInt8}(undef, nb) catch; break end
-        fill!(A, 0x00); push!(held, A); left -= nb
-    end
-    AMDGPU.synchronize()
-    foreach(AMDGPU.unsafe_free!, held)
-    return nothing
-end
-const CHURNS = Ref(0)          # churn!() calls of this process (at most MAX_CHURNS: the mix does not always outlast the next allocate / free cycle)
-const MAX_CHURNS = 3
-
-function alloc_fields(count::Integer, dims::Integer...; pool::Integer = count + 7, pairs = nothing, trial = nothing, spacer_bytes = nothing,
-                      accept = nothing, first = nothing)
+function alloc_fields(count::Integer, dims::Integer...; pool::Integer = count + 7, pairs = nothing, trial = nothing, spacer_bytes = nothing)
     nbytes = 8 * prod(dims)
     (nbytes < (256 << 20) || count < 2) && return [AMDGPU.zeros(Float64, dims...) for _ in 1:count]
     spacer = spacer_bytes === nothing ? max(4 << 30, 3 * nbytes) : spacer_bytes
     cands, spacers = DA[], Any[]
-    first === nothing || append!(cands, first)            # arrays the caller already holds: the first candidates (the search cannot end below them)
-    for i in (length(cands) + 1):pool
+    for i in 1:pool
         (spacer > 0 && i > count) && push!(spacers, ROCArray{UInt8}(undef, spacer))      # reserved, never touched
         push!(cands, AMDGPU.zeros(Float64, dims...))
     end
@@ -568,20 +547,9 @@ function alloc_fields(count::Integer, dims::Integer...; pool::Integer = count + 
                     ctx(), ptrs, length(cands), prod(dims), count, flat, length(flat) ÷ 2,
                     cb === C_NULL ? C_NULL : Base.unsafe_convert(Ptr{Cvoid}, cb), C_NULL, chosen, report))
     end
-    if report[12] == 1 && CHURNS[] < MAX_CHURNS          # FPR_PLACE_WANT_MORE: a pool of one class -- churn once, then build the pool afresh
-        foreach(AMDGPU.unsafe_free!, cands); foreach(AMDGPU.unsafe_free!, spacers)
-        churn!(); CHURNS[] += 1
-        return alloc_fields(count, dims...; pool = pool, pairs = pairs, trial = trial, spacer_bytes = spacer_bytes)
-    end
     out = DA[cands[c + 1] for c in chosen]
     for (i, A) in enumerate(cands); (i - 1) in chosen || AMDGPU.unsafe_free!(A); end
     for q in spacers; AMDGPU.unsafe_free!(q); end
-    if accept !== nothing && trial !== nothing && CHURNS[] < MAX_CHURNS && !accept(out)
-        # a fast pair and still no good assignment (one candidate of another class among many alike: the fused diffusion launch at 1.08-1.09 x the
-        # one-iteration kernel where a mixed pool gives 1.02-1.06): rebuild the pool once behind churn!(), the chosen arrays its first candidates
-        churn!(); CHURNS[] += 1
-        return alloc_fields(count, dims...; pool = pool, pairs = pairs, trial = trial, spacer_bytes = spacer_bytes, first = out)     # (accept is not asked again: one churn per call)
-    end
     foreach(A -> fill_device!(A, 0.0), out)
     return out
 end

@@ -153,20 +153,15 @@ def test_cg_launch_forms_agree_bit_for_bit(fpr, oracle, shape, nmax, fences):
         b[:, 0] = b[:, -1] = 0.0
     outs = []
     try:
-        # the persistent kernel in both geometries (64 x 256 and 16 x 1024 threads), its r edges as data-tagged granules (option cg_tagged_edges = 1) or as
-        # sc1 stores + drain + barrier words (default; with handoff_fences the flag form is taken anyway)
-        for form, wgs, tagged in ((3, 64, 1), (3, 16, 1), (3, 64, 0), (2, 64, 1), (1, 64, 1), (0, 64, 1)):
+        # one persistent launch (3), two dependent launches per iteration (2), three (1), five (0)
+        for form in (3, 2, 1, 0):
             c.set_option("cg_fused", form)
-            c.set_option("cg_persistent_wgs", wgs)
-            c.set_option("cg_tagged_edges", tagged)
             x = F.asdevice(np.full(shape, 3.0))
             r, it = mg.cg_(x, F.asdevice(b), 0.05, 0.07, 0.9, 1e-7, nmax, return_iters=True)
             outs.append((r, it, F.tonumpy(x)))
         assert c.get_option("cg_persistent_timeouts") == 0
     finally:
         c.set_option("cg_fused", 3)
-        c.set_option("cg_persistent_wgs", 64)
-        c.set_option("cg_tagged_edges", 0)
         c.set_option("handoff_fences", 0)
     for r, it, x in outs[1:]:
         assert it == outs[0][1] and r == outs[0][0]
@@ -358,13 +353,12 @@ def test_bench_vcycle_config_4097_l2_full_solve_against_the_oracle(fpr, oracle):
     assert np.array_equal(F.tonumpy(x), xo)
 
 
-@pytest.mark.parametrize("n,bcs,cols", [(513, False, 2), (513, True, 2), (1025, True, 2), (2049, False, 2), (4097, True, 0), (4097, True, 1)])
-def test_seam_pass_with_two_columns_per_lane(fpr, oracle, n, bcs, cols):
+@pytest.mark.parametrize("n,bcs", [(513, False), (513, True), (1025, True), (2049, False), (4097, True), (4097, False)])
+def test_seam_pass_one_and_two_columns_per_lane(fpr, oracle, n, bcs):
     """k_seam_march_v3 (a lane owns columns g and g + 64 of a 128-column strip; the halves' x-neighbours through wave rotations and
-    shifts; taken by default at 4097^2, forced here on smaller grids by option mg_seam_cols = 2) against the oracle: full solves with
-    and without apply_BCs (Neumann columns cross the halves' seam handling at the first and last strip), fields bit for bit,
-    histories to 1e-10.  4097^2 with apply_BCs: the default choice (cols = 0 -> v3) and the one-column form (1) against each other
-    and against the oracle's first cycles (the solve stops at niters, multigrid.jl:60-62 between the cycles)."""
+    shifts; taken at 4097^2, where one workgroup per CU still leaves chunks of 128 rows) and k_seam_march_v2 (one column per lane: every
+    smaller grid) against the oracle: full solves with and without apply_BCs (Neumann columns cross the halves' seam handling at the first
+    and last strip), fields bit for bit, histories to 1e-10 (at 4097^2 the oracle's first cycles: the solve stops at niters)."""
     F, mg = fpr, fpr.multigrid
     c = F.ctx()
     h = 1.0 / (n - 1)
@@ -372,12 +366,8 @@ def test_seam_pass_with_two_columns_per_lane(fpr, oracle, n, bcs, cols):
     niters = 6 if n == 4097 else 12
     xo = farr(n, n)
     r_o, hist_o, frms_o = oracle.mgsolve2d(xo, b, h, 0.0, 1e-9, niters, bcs, 5, 0)
-    try:
-        c.set_option("mg_seam_cols", cols)
-        x = F.fzeros(n, n)
-        r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, F.asdevice(b), h, 0.0, 1e-9, niters, bcs, opt=mg.MGOpt(), return_history=True)
-    finally:
-        c.set_option("mg_seam_cols", 0)
+    x = F.fzeros(n, n)
+    r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, F.asdevice(b), h, 0.0, 1e-9, niters, bcs, opt=mg.MGOpt(), return_history=True)
     assert len(hist) == len(hist_o)
     assert np.allclose(hist, hist_o, rtol=1e-10, atol=0), (hist, hist_o)
     assert np.array_equal(F.tonumpy(x), xo)
@@ -427,88 +417,6 @@ def test_cycle_finish_rides_on_the_next_pass(fpr, oracle, n, bcs, css, solver, t
         if solver == 0:
             assert np.array_equal(got[1][0], xo)
             assert got[1][2] == oracle.last_coarse_iters()
-
-
-@pytest.mark.parametrize("nx,ny,bcs,cc,tol", [(2049, 2049, False, 0.0, 1e-9), (2049, 2049, True, 0.0, 1e-9), (2049, 2049, False, 5.0e6, 1e-7),
-                                              (2049, 1025, True, 3.0, 1e-9), (1025, 2049, False, 0.0, 1e-9), (4097, 4097, True, 0.0, 1e-6),
-                                              (1025, 1025, True, 0.0, 1e-9)])
-def test_four_levels_down_in_one_launch_with_exchanged_halos(fpr, oracle, nx, ny, bcs, cc, tol):
-    """Option mg_pyr_down (an experiment, off by default): k_pyr_down -- the pre-smoothing passes of four levels in one launch, every
-    workgroup on its own tile grown by two, the halo of each level's right-hand side received from the neighbours as data-tagged
-    granules -- against the launches it replaces (the level's own pass + k_mid_down): fields bit for bit, histories, cycle and
-    coarse-iteration counts equal, and equal to the oracle's."""
-    F, mg = fpr, fpr.multigrid
-    c = F.ctx()
-    h = 1.0 / (nx - 1)
-    b = asf(splitmix64_uniform(nx * ny, 13).reshape((nx, ny), order="F"))
-    gb = F.asdevice(b)
-    import warnings
-    got = {}
-    for pyr in (1, 0, 1):
-        try:
-            c.set_option("mg_pyr_down", pyr)
-            x = F.fzeros(nx, ny)
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
-                r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, gb, h, cc, tol, 8, bcs, opt=mg.MGOpt(), return_history=True)
-        finally:
-            c.set_option("mg_pyr_down", 0)
-        if pyr in got:
-            assert np.array_equal(F.tonumpy(x), got[pyr][0]) and list(hist) == got[pyr][1]
-        got[pyr] = (F.tonumpy(x), list(hist), cit, r)
-    assert not np.isnan(got[1][0]).any()
-    assert np.array_equal(got[1][0], got[0][0])
-    assert got[1][1] == got[0][1], (got[1][1], got[0][1])
-    assert got[1][2] == got[0][2] and got[1][3] == got[0][3]
-    if nx * ny <= 2049 * 2049:
-        xo = farr(nx, ny)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            r_o, hist_o, frms_o = oracle.mgsolve2d(xo, b, h, cc, tol, 8, bcs, 5, 0)
-        assert np.allclose(got[1][1], hist_o, rtol=1e-10, atol=0)
-        assert np.array_equal(got[1][0], xo)
-
-
-@pytest.mark.parametrize("nx,ny,bcs,cc,tol", [(2049, 2049, False, 0.0, 1e-9), (2049, 2049, True, 0.0, 1e-9), (2049, 2049, False, 5.0e6, 1e-7),
-                                              (2049, 1025, True, 3.0, 1e-9), (1025, 2049, False, 0.0, 1e-9), (4097, 4097, True, 0.0, 1e-6),
-                                              (1025, 1025, True, 0.0, 1e-9)])
-def test_level_above_the_three_rides_along(fpr, oracle, nx, ny, bcs, cc, tol):
-    """Option mg_mid4 (opt-in; measured 3-4 us per cycle slower than the pass it replaces, EXPERIMENTS 13.14): where the three levels below a level of at most 1025^2 are k_mid_down's, that level's pre-smoothing
-    pass is not launched -- its two sweeps from the zero guess (multigrid.jl:124-125 after :132) and its residual + injection (:128-131)
-    are recomputed pointwise from its right-hand side in k_mid_down's prologue, which stores its pre-smoothed field and the next level's
-    right-hand side.  Against the launch of its own (0): fields bit for bit, histories, cycle and coarse-iteration counts equal; against
-    the oracle: field bit for bit, history to 1e-10.  Poisson and Helmholtz (the Navier-Stokes solves' c = 1 / (beta dt)), with and without
-    apply_BCs (the Neumann columns of the injected residual, part2_utils.jl:35-39), non-square grids, 1025^2 (not taken: the level
-    below the top is k_mid_down's own)."""
-    F, mg = fpr, fpr.multigrid
-    c = F.ctx()
-    h = 1.0 / (nx - 1)
-    b = asf(splitmix64_uniform(nx * ny, 11).reshape((nx, ny), order="F"))
-    gb = F.asdevice(b)
-    import warnings
-    got = {}
-    for m4 in (1, 0):
-        try:
-            c.set_option("mg_mid4", m4)
-            x = F.fzeros(nx, ny)
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
-                r, hist, frms, cit = mg.MGsolve_2DPoisson_(x, gb, h, cc, tol, 8, bcs, opt=mg.MGOpt(), return_history=True)
-        finally:
-            c.set_option("mg_mid4", 0)
-        got[m4] = (F.tonumpy(x), list(hist), cit, r)
-    assert np.array_equal(got[1][0], got[0][0])
-    assert got[1][1] == got[0][1], (got[1][1], got[0][1])
-    assert got[1][2] == got[0][2] and got[1][3] == got[0][3]
-    if nx * ny <= 2049 * 2049:
-        xo = farr(nx, ny)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            r_o, hist_o, frms_o = oracle.mgsolve2d(xo, b, h, cc, tol, 8, bcs, 5, 0)
-        assert len(hist_o) == len(got[1][1])
-        assert np.allclose(got[1][1], hist_o, rtol=1e-10, atol=0)
-        assert np.array_equal(got[1][0], xo)
-        assert got[1][2] == oracle.last_coarse_iters()
 
 
 @pytest.mark.parametrize("n,bcs,cc", [(129, False, 0.0), (257, True, 0.0), (1025, False, 2.5), (2049, True, 0.0)])
@@ -649,9 +557,9 @@ def test_coarse_jacobi_exit_inside_a_fused_group(fpr, oracle, tol):
         assert np.array_equal(F.tonumpy(gu), u_ref)
 
 
-@pytest.mark.parametrize("tagged", [1, 0, -1])
+@pytest.mark.parametrize("fences", [0, 1])
 @pytest.mark.parametrize("tol", [0.5, 0.2, 0.05, 0.02, 1e-9])
-def test_coarse_jacobi_persistent_launches_equal_the_plain_ones(fpr, oracle, tol, tagged):
+def test_coarse_jacobi_persistent_launches_equal_the_plain_ones(fpr, oracle, tol, fences):
     """k_jacobi_persist (up to 32 groups of 8 sweeps per launch, tiles handed from neighbour to neighbour, exit test behind the
     launch and the exact number of sweeps replayed from the launch's input) against one launch per 8 sweeps and against the
     oracle: a 257 x 129 coarse grid solved directly by Vcycle_2DPoisson! (:147-159) with exits in the first launch, in a later
@@ -668,10 +576,9 @@ def test_coarse_jacobi_persistent_launches_equal_the_plain_ones(fpr, oracle, tol
     outs = []
     c = F.ctx()
     try:
-        # tagged = 1: k_jacobi_persist_tag (every cell a {value, tag} granule, no flags); 0: k_jacobi_persist (flags); -1: the flag form
-        # with option handoff_fences (agent-scope release / acquire around the flag as well)
-        c.set_option("mg_jacp_tagged", 1 if tagged == 1 else 0)
-        c.set_option("handoff_fences", 1 if tagged < 0 else 0)
+        # k_jacobi_persist_tag (every cell a {value, tag} granule, no flags); with option handoff_fences = 1 (hand-offs inside the HIP memory
+        # model only) the coarse solve runs as plain launches whatever mg_jacobi_persist says
+        c.set_option("handoff_fences", fences)
         for persist in (1, 0):
             c.set_option("mg_jacobi_persist", persist)
             gu = F.asdevice(u0)
@@ -679,7 +586,6 @@ def test_coarse_jacobi_persistent_launches_equal_the_plain_ones(fpr, oracle, tol
             outs.append((r, F.tonumpy(gu)))
     finally:
         c.set_option("mg_jacobi_persist", 1)
-        c.set_option("mg_jacp_tagged", 1)
         c.set_option("handoff_fences", 0)
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
     assert abs(outs[0][0] - r_ref) <= 1e-12 * abs(r_ref)
@@ -687,9 +593,8 @@ def test_coarse_jacobi_persistent_launches_equal_the_plain_ones(fpr, oracle, tol
     assert it_ref > 0
 
 
-@pytest.mark.parametrize("tagged", [1, 0])
 @pytest.mark.parametrize("tol,abort_launch", [(1e-9, 1), (1e-9, 2), (1e-9, 4), (0.02, 1), (0.02, 3)])
-def test_coarse_jacobi_persistent_launch_that_gives_up_is_resumed_by_the_plain_ones(fpr, oracle, tol, abort_launch, tagged):
+def test_coarse_jacobi_persistent_launch_that_gives_up_is_resumed_by_the_plain_ones(fpr, oracle, tol, abort_launch):
     """A neighbour hand-off of k_jacobi_persist that times out (workgroups not resident together: a shared card) must not fail the
     solve: the launch that gave up never wrote its input, so the solve resumes there with one launch per 8 sweeps, the context
     stays off the persistent form and counts the event (option mg_jacobi_persist_timeouts), and the result is the oracle's bit for
@@ -706,7 +611,6 @@ def test_coarse_jacobi_persistent_launch_that_gives_up_is_resumed_by_the_plain_o
     r_ref = oracle.vcycle2d(u_ref, f, h, 0.0, tol, 257, 0, False)
     it_ref = oracle.last_coarse_iters() - it0
     c = F.ctx()
-    c.set_option("mg_jacp_tagged", tagged)
     c.set_option("mg_jacobi_persist", 1)
     before = c.L.fpr_get_option(c.h, b"mg_jacobi_persist_timeouts")
     launches_needed = -(-it_ref // 256)
@@ -722,7 +626,6 @@ def test_coarse_jacobi_persistent_launch_that_gives_up_is_resumed_by_the_plain_o
         r2 = mg.Vcycle_2DPoisson_(gu2, F.asdevice(f), h, 0.0, tol, 257, mg.jacobi, mg.parallel_shmem, False)
     finally:
         c.set_option("mg_jacobi_persist_test_abort", 0)
-        c.set_option("mg_jacp_tagged", 1)
         c.set_option("mg_jacobi_persist", 1)           # lifts the switch again
     assert abs(r - r_ref) <= 1e-12 * abs(r_ref) and r2 == r
     assert np.array_equal(F.tonumpy(gu), u_ref) and np.array_equal(F.tonumpy(gu2), u_ref)
@@ -805,11 +708,6 @@ def test_multisweep_and_single_sweep_paths_agree(fpr):
     r = mg.Vcycle_2DPoisson_(gu, F.asdevice(f), 1.0 / 256, 0.3, 1e-7, 5, mg.jacobi, mg.parallel, True)
     outs.append((r, F.tonumpy(gu)))
     F.ctx().set_option("mg_fuse_restrict", 1)
-    F.ctx().set_option("mg_vx", 2)
-    gu = F.asdevice(u0)
-    r = mg.Vcycle_2DPoisson_(gu, F.asdevice(f), 1.0 / 256, 0.3, 1e-7, 5, mg.jacobi, mg.parallel, True)
-    outs.append((r, F.tonumpy(gu)))
-    F.ctx().set_option("mg_vx", 1)
     # the zero coarse guess read from memory like any field (default: not read at all, its loads are dropped by the range check)
     for fuse_r in (1, 0):
         F.ctx().set_option("mg_zero_guess", 0)
@@ -999,7 +897,7 @@ def test_stream_mode_equals_plain_loop_over_many_small_problems(fpr):
     combos = list(itertools.product(shapes, (3, 5, 9, 17), (False, True), (1, 2, 3, 9), (1e-2, 1e-7, 1e-13)))
     rng = np.random.default_rng(11)
     picks = [combos[i] for i in sorted(rng.choice(len(combos), size=90, replace=False))]
-    plain = {"mg_ahead": 0, "mg_seam": 0, "mg_mid": 0, "mg_small_row": 0}
+    plain = {"mg_ahead": 0, "mg_seam": 0, "mg_mid": 0, "mg_small": 0}
     checked = 0
     for shape, css, bcs, niters, tol in picks:
         f = rnd(shape, 31) - (0.5 if bcs else 0.0)

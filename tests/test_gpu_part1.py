@@ -14,33 +14,18 @@ pytestmark = pytest.mark.gpu
 SHAPES = [(32, 32, 32), (45, 45, 45), (64, 40, 24), (91, 33, 17), (130, 6, 5), (3, 3, 3), (4, 5, 6), (128, 9, 70),
           (258, 11, 7)]
 COEF = dict(dτ=0.0031, _dt=5.0, _dx=3.2, _dy=2.9, _dz=3.7, D_dx=3.2, D_dy=2.9, D_dz=3.7)
-VARIANTS = [dict(diff3_variant=1), dict(diff3_variant=2, diff3_ry=1), dict(diff3_variant=2, diff3_ry=2),
-            dict(diff3_variant=2, diff3_ry=4), dict(diff3_variant=2, diff3_ry=4, diff3_vx=1),
-            dict(diff3_variant=2, diff3_ry=4, diff3_nt=1, diff3_zc=5), dict(diff3_variant=3, diff3_ry=1),
-            dict(diff3_variant=3, diff3_ry=2, diff3_zc=7), dict(diff3_variant=3, diff3_ry=4, diff3_xcd_remap=1),
-            dict(diff3_variant=4, diff3_ry=4), dict(diff3_variant=4, diff3_ry=2, diff3_zc=3),
-            dict(diff3_variant=5, diff3_ry=2, diff3_zc=7), dict(diff3_variant=5, diff3_ry=4, diff3_nt=0),
-            dict()]
-ALL_OPTS = ["diff3_variant", "diff3_ry", "diff3_vx", "diff3_nt", "diff3_zc", "diff3_xcd_remap"]
-
 
 def rnd(shape, seed):
     return asf(splitmix64_uniform(int(np.prod(shape)), seed).reshape(shape, order="F"))
 
 
-def set_opts(F, opts):
-    c = F.ctx()
-    defaults = dict(diff3_variant=0, diff3_ry=0, diff3_vx=0, diff3_nt=-1, diff3_zc=0, diff3_xcd_remap=-1)
-    for k in ALL_OPTS:
-        c.set_option(k, opts.get(k, defaults[k]))
-
-
-@pytest.mark.parametrize("opts", VARIANTS, ids=lambda o: "-".join("%s%s" % (k[6:], v) for k, v in o.items()) or "default")
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
-def test_fused_step_bit_exact(fpr, oracle, shape, opts):
+def test_fused_step_bit_exact(fpr, oracle, shape):
+    """fpr_diffusion3d_step against the oracle, bit for bit, sentinels outside the interior untouched, the fused norm to 1e-13.  The
+    shapes walk through the forms the library picks by itself: two cells per lane (even nx, aligned) or one, four / two / one rows per
+    lane by the height of the box, one or several z-chunks.  (Round 1-5's other tilings live in tools/diffusion_tune.hip.)"""
     F = fpr
-    set_opts(F, opts)
-    try:
+    if True:
         Ht, Hτ = rnd(shape, 11), rnd(shape, 12)
         H2_ref, dH_ref = asf(np.full(shape, -7.0)), asf(np.full(shape, -9.0))  # sentinels: boundary untouched
         oracle.diffusion3d_step(Ht, Hτ, H2_ref, dH_ref, *COEF.values())
@@ -56,15 +41,11 @@ def test_fused_step_bit_exact(fpr, oracle, shape, opts):
         inner = dH_ref[1:-1, 1:-1, 1:-1].copy(order="F")
         ref = oracle.sumsq_scaled(inner, 0.2)
         assert abs(sq.item() - ref) <= 1e-13 * ref
-    finally:
-        set_opts(F, {})
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(diff3_variant=3, diff3_ry=2), dict(diff3_variant=1)])
-def test_box_form_covers_interior(fpr, oracle, opts):
+def test_box_form_covers_interior(fpr, oracle):
     F = fpr
-    set_opts(F, opts)
-    try:
+    if True:
         shape = (40, 36, 30)
         Ht, Hτ = rnd(shape, 1), rnd(shape, 2)
         H2_ref, dH_ref = farr(*shape), farr(*shape)
@@ -84,8 +65,6 @@ def test_box_form_covers_interior(fpr, oracle, opts):
         assert np.array_equal(F.tonumpy(dH), dH_ref) and np.array_equal(F.tonumpy(H2), H2_ref)
         ref = oracle.sumsq_scaled(dH_ref, 0.2)
         assert abs(sq.item() - ref) <= 1e-13 * ref
-    finally:
-        set_opts(F, {})
 
 
 @pytest.mark.parametrize("shape", [(24, 24, 24), (33, 18, 9), (3, 3, 3)], ids=str)
@@ -211,7 +190,7 @@ def test_config1_64cubed_50_iterations(fpr, oracle):
 
 def test_full_size_512_properties(fpr):
     """BASELINE config 2 size (512^3): size-independent properties instead of the (slow) oracle:
-    constant fields are fixed points; every kernel variant agrees bit for bit; mirror symmetry."""
+    constant fields are fixed points; mirror symmetry."""
     import torch
 
     F = fpr
@@ -227,16 +206,9 @@ def test_full_size_512_properties(fpr):
     F.part1.init_local_gaussian((5.0, 5.0, 5.0), dx, dx, dx, Ht)
     Hτ.copy_(Ht)
     Hτ.mul_(1.0 + 0.001 * torch.arange(n, device=Hτ.device, dtype=torch.float64).reshape(n, 1, 1))  # break symmetry in x
-    results = []
-    for opts in (dict(diff3_variant=1), dict(diff3_variant=2), dict(diff3_variant=3), dict(diff3_variant=4),
-                 dict(diff3_variant=5, diff3_zc=16), dict()):
-        set_opts(F, opts)
-        H2.zero_(); dH.zero_()
-        F.part1.diffusion_3D_step_τ(Ht, Hτ, H2, dH, *coef)
-        results.append((H2.clone(), dH.clone()))
-    set_opts(F, {})
-    for a, b in results[1:]:
-        assert torch.equal(a, results[0][0]) and torch.equal(b, results[0][1])
+    H2.zero_(); dH.zero_()
+    F.part1.diffusion_3D_step_τ(Ht, Hτ, H2, dH, *coef)
+    results = [(H2.clone(), dH.clone())]
     # mirror symmetry j -> n-1-j (and k -> n-1-k) of the input is preserved bit for bit
     # (dx = 10/512 is exact in binary, so the Gaussian is exactly mirror-symmetric)
     d = results[0][1]
@@ -311,16 +283,15 @@ def _two_oracle_steps(oracle, Ht, A, B):
     return Cp, dH2, s1, s2
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(diff3_zc2=5), dict(diff3_zc2=16, diff3_xcd2=1), dict(diff3_xcd2=2, diff3_zc2=3),
-                                  dict(diff3_nw2=4), dict(diff3_nw2=8, diff3_zc2=7)],
-                         ids=["default", "zc5", "zc16-xcd1", "zc3-xcd2", "nw4", "nw8-zc7"])
+@pytest.mark.parametrize("opts", [dict(), dict(diff3_zc2=5), dict(diff3_zc2=16), dict(diff3_zc2=3), dict(diff3_zc2=7)],
+                         ids=["default", "zc5", "zc16", "zc3", "zc7"])
 @pytest.mark.parametrize("shape", SHAPES2, ids=lambda s: "x".join(map(str, s)))
 def test_fused_two_steps_bit_exact(fpr, oracle, shape, opts):
     """fpr_diffusion3d_step2 == two oracle steps, bit for bit; the intermediate buffer is not written, only its
     boundary is read (random here, so a wrong boundary source cannot go unnoticed); sentinels outside the interior."""
     F = fpr
     c = F.ctx()
-    for k in ("diff3_zc2", "diff3_xcd2", "diff3_nw2"):
+    for k in ("diff3_zc2",):
         c.set_option(k, opts.get(k, 0))
     try:
         Ht, A, B = rnd(shape, 21), rnd(shape, 22), rnd(shape, 23)
@@ -346,7 +317,7 @@ def test_fused_two_steps_bit_exact(fpr, oracle, shape, opts):
         assert np.array_equal(F.tonumpy(dC), C_ref)
         assert [float(x) for x in sq2.tolist()] == [g1, g2]
     finally:
-        for k in ("diff3_zc2", "diff3_xcd2", "diff3_nw2"):
+        for k in ("diff3_zc2",):
             c.set_option(k, 0)
 
 
@@ -373,7 +344,6 @@ def test_fused_two_steps_stay_inside_their_arrays(fpr, oracle, shape):
     try:
         for zc, nw in ((0, 0), (1, 4), (2, 8), (3, 0), (7, 4)):
             c.set_option("diff3_zc2", zc)
-            c.set_option("diff3_nw2", nw)
             for box in (None, ((1, 1, 1), (shape[0] - 1, shape[1] - 1, 2)), ((3, 2, shape[2] - 2), (shape[0] - 5, shape[1] - 1, shape[2] - 1))):
                 dHt.copy_(F.asdevice(Ht)); dA.copy_(F.asdevice(A)); dB.copy_(F.asdevice(B)); dC.copy_(dA); dD.fill_(-9.0)
                 if box is None:
@@ -389,7 +359,6 @@ def test_fused_two_steps_stay_inside_their_arrays(fpr, oracle, shape):
                 assert np.array_equal(F.tonumpy(dHt), Ht) and np.array_equal(F.tonumpy(dA), A) and np.array_equal(F.tonumpy(dB), B)
     finally:
         c.set_option("diff3_zc2", 0)
-        c.set_option("diff3_nw2", 0)
 
 
 def test_fused_two_steps_unsupported_shapes_are_reported(fpr):
@@ -668,7 +637,7 @@ def test_full_size_512_fused_equals_two_steps(fpr):
     # the fused result as the next input (the way the solver chains launches), other launch geometries
     c = F.ctx()
     try:
-        for opts in (dict(diff3_nw2=4), dict(diff3_nw2=8, diff3_zc2=24), dict(diff3_xcd2=3)):
+        for opts in (dict(diff3_zc2=24), dict(diff3_zc2=61)):
             for k, v in opts.items():
                 c.set_option(k, v)
             C2.copy_(A); dH2.zero_()
@@ -677,7 +646,7 @@ def test_full_size_512_fused_equals_two_steps(fpr):
             for k in opts:
                 c.set_option(k, 0)
     finally:
-        for k in ("diff3_nw2", "diff3_zc2", "diff3_xcd2"):
+        for k in ("diff3_zc2",):
             c.set_option(k, 0)
 
 
@@ -693,8 +662,8 @@ def test_fused_two_steps_random_shapes_and_boxes(fpr, oracle):
             lo = tuple(int(rng.randint(1, max(2, n // 3))) if rng.rand() < 0.6 else 1 for n in shape)
             hi = tuple(int(rng.randint(max(l + 1, 2 * n // 3), n)) if rng.rand() < 0.6 else n - 1 for l, n in zip(lo, shape))
             c.set_option("diff3_zc2", int(rng.choice([0, 3, 4, 7, 16])))
-            c.set_option("diff3_xcd2", int(rng.choice([0, 1])))
-            c.set_option("diff3_nw2", int(rng.choice([0, 4, 8])))
+            _ = int(rng.choice([0, 1]))      # (a draw kept: the seeded sequence of shapes stays the one the test was written for)
+            _ = int(rng.choice([0, 4, 8]))      # (a draw kept: the seeded sequence of shapes stays the one the test was written for)
             Ht, A, B = rnd(shape, 100 + trial), rnd(shape, 200 + trial), rnd(shape, 300 + trial)
             C_ref, dH_ref, _, _ = _two_oracle_steps(oracle, Ht, A, B)
             sl = tuple(slice(l, h) for l, h in zip(lo, hi))
@@ -706,8 +675,6 @@ def test_fused_two_steps_random_shapes_and_boxes(fpr, oracle):
             assert (Cg == -3.0).all() and (Dg == -9.0).all(), (trial, shape, lo, hi)
     finally:
         c.set_option("diff3_zc2", 0)
-        c.set_option("diff3_xcd2", 0)
-        c.set_option("diff3_nw2", 0)
 
 
 def test_fused_two_steps_reserved_form_random_shapes_and_boxes(fpr, oracle):
@@ -725,10 +692,10 @@ def test_fused_two_steps_reserved_form_random_shapes_and_boxes(fpr, oracle):
             shape = (nx, int(rng.randint(16, 80)), int(rng.randint(6, 40)))
             lo = tuple(int(rng.randint(1, max(2, n // 3))) if rng.rand() < 0.5 else 1 for n in shape)
             hi = tuple(int(rng.randint(max(l + 1, 2 * n // 3), n)) if rng.rand() < 0.5 else n - 1 for l, n in zip(lo, shape))
-            c.set_option("diff3_nw2", int(rng.choice([0, 4, 8])))
+            _ = int(rng.choice([0, 4, 8]))      # (a draw kept: the seeded sequence of shapes stays the one the test was written for)
             zc = int(rng.choice([3, 4, 5, 7, 9]))
             c.set_option("diff3_zc2", zc)
-            c.set_option("diff3_xcd2", int(rng.choice([0, 1, 3])))
+            _ = int(rng.choice([0, 1, 3]))      # (a draw kept: the seeded sequence of shapes stays the one the test was written for)
             # plain grid: tiles (>= ceil(span / 124) x-tiles, y-blocks of 30 or 14 owned rows) x chunks of zc planes;
             # ask for a little less than a lower bound of that, so that mostly 1 .. a third of the units are left over
             span = hi[0] - (lo[0] & ~1)
@@ -757,7 +724,7 @@ def test_fused_two_steps_reserved_form_random_shapes_and_boxes(fpr, oracle):
             Cg[sl] = -3.0; Dg[sl] = -9.0
             assert (Cg == -3.0).all() and (Dg == -9.0).all(), (trial, shape, lo, hi, G, info)
     finally:
-        for k in ("diff3_bal_g", "diff3_nw2", "diff3_zc2", "diff3_xcd2"):
+        for k in ("diff3_bal_g", "diff3_zc2"):
             c.set_option(k, 0)
     assert ran_reserved >= 12, ran_reserved     # the sweep must exercise the reserved form, not its fallback
 
@@ -907,47 +874,20 @@ def test_placement_alloc_fields(fpr):
         return e0.elapsed_time(e1)
 
     rep = {}
-    arrs = F.placement.alloc_fields(4, *n, pool=7, report=rep, pairs=[(0, 1), (2, 3)], trial=trial, trials=2, extend_by=0)
+    free0, _ = torch.cuda.mem_get_info()
+    arrs = F.placement.alloc_fields(4, *n, pool=7, report=rep, pairs=[(0, 1), (2, 3)], trial=trial)
     assert len(arrs) == 4 and len({a.data_ptr() for a in arrs}) == 4
     assert rep["selected"] is True and rep["pool"] == 7 and len(rep["chosen"]) == 4 and rep["trials"] == len(calls) >= 2
-    # a pool that looks like one class (here: a threshold no pool can meet) is rebuilt behind churn(), and when that has not helped its
-    # candidates are carved out of one allocation at a pitch of 6 GiB (the arrays are views of it: column-major, zeroed, usable as any)
-    F.placement._CHURNED[0] = 0
+    assert rep["trial_ms_plain_allocation"] > 0 and rep["trial_ms_best"] <= rep["trial_ms_plain_allocation"]      # never worse than a plain allocation
+    assert all(tuple(a.shape) == n and a.stride() == (1, n[0], n[0] * n[1]) and float(a.abs().max()) == 0.0 for a in arrs)
+    # nothing but the returned arrays stays allocated (round 5's fallbacks held up to 72 GiB)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 <= 4 * (256 << 20) + (64 << 20), (free0 - free1) / 2.0 ** 30
+    # without a trial the pair copies alone decide
     rep2 = {}
-    more = F.placement.alloc_fields(2, *n, pool=4, report=rep2, spacer_bytes=256 << 20, extend_below_GBs=1e9, extend_by=3)
-    assert len(more) == 2 and rep2["pool_first"] == 4 and rep2["pool"] == 4 and rep2["churned_because_fastest_pair_GBs"] > 100.0
-    assert rep2["slab_because_fastest_pair_GBs_after_churn"] > 100.0 and rep2["slab_bytes"] == 4 * (6 << 30) and F.placement._CHURNED[0] == 1
-    assert all(tuple(a.shape) == n and a.stride() == (1, n[0], n[0] * n[1]) and float(a.abs().max()) == 0.0 for a in more)
-    assert abs(more[1].data_ptr() - more[0].data_ptr()) % (6 << 30) == 0
-    del more
-    # ... a process that has used up its churns extends the pool once instead
-    F.placement._CHURNED[0] = F.placement.MAX_CHURNS
-    rep2 = {}
-    more = F.placement.alloc_fields(2, *n, pool=4, report=rep2, spacer_bytes=256 << 20, extend_below_GBs=1e9, extend_by=3)
-    assert len(more) == 2 and rep2["pool_first"] == 4 and rep2["pool"] == 7 and rep2["pool_extended_because_fastest_pair_GBs"] > 100.0
-    del more
-    # ... and so is a pool in which the caller's kernel sees no difference between any two assignments
-    rep3 = {}
-    more = F.placement.alloc_fields(3, *n, pool=4, report=rep3, spacer_bytes=256 << 20, extend_below_GBs=0.0, extend_by=2, trial=lambda a: 1.0, trials=2)
-    assert len(more) == 3 and rep3["pool_first"] == 4 and rep3["pool"] == 6 and rep3["pool_extended_because_trial_spread"] == 0.0
-    assert rep3["trials"] > 6 and all(float(a.abs().max()) == 0.0 for a in more)
-    del more
-    # ... and a pool whose chosen arrays the caller does not accept is rebuilt once behind churn(), the chosen arrays staying its first
-    # candidates (so the second search starts from the first one's result); a second refusal changes nothing more
-    F.placement._CHURNED[0] = 0
-    rep4, seen = {}, []
-    more = F.placement.alloc_fields(3, *n, pool=5, report=rep4, spacer_bytes=256 << 20, extend_by=0, trial=trial, trials=2,
-                                    accept=lambda a: (seen.append([t.data_ptr() for t in a]), False)[1])
-    # (asked three times: about the first pool's choice, the second's behind the churn, and the third's -- the kept arrays + five carved out of one
-    #  allocation)
-    assert len(more) == 3 and len(seen) == 3 and rep4["churned_because_not_accepted_ms"] > 0.0 and rep4["accepted_after_churn"] is False
-    assert rep4["pool"] == 3 + 5 and rep4["slab_because_not_accepted_after_churn_ms"] > 0.0 and rep4["accepted_after_slab"] is False
-    assert rep4["pool_before_churn"]["trial_ms_best"] == rep4["churned_because_not_accepted_ms"] and F.placement._CHURNED[0] == 1
-    assert all(float(a.abs().max()) == 0.0 for a in more)
-    F.placement._CHURNED[0] = F.placement.MAX_CHURNS      # a process that has churned that often does not churn again
-    rep5 = {}
-    again = F.placement.alloc_fields(3, *n, pool=5, report=rep5, spacer_bytes=256 << 20, extend_by=0, trial=trial, trials=2, accept=lambda a: False)
-    assert len(again) == 3 and "churned_because_not_accepted_ms" not in rep5
+    more = F.placement.alloc_fields(2, *n, pool=4, report=rep2, spacer_bytes=256 << 20, pairs=[(0, 1)])
+    assert len(more) == 2 and rep2["pool"] == 4 and rep2["trials"] == 0 and rep2["pair_copy_GBs_chosen"]["slowest"] > 100.0
     del more, again
     assert rep["pair_copy_GBs_all"]["fastest"] >= rep["pair_copy_GBs_chosen"]["slowest"] >= rep["pair_copy_GBs_all"]["slowest"] > 100.0
     for a in arrs:

@@ -236,7 +236,7 @@ def test_pairs_chained_on_core_and_comm_streams(fpr, oracle, periodic_grid, peri
 
 
 @pytest.mark.parametrize("periods,n", [((1, 0, 0), (128, 24, 16)), ((1, 1, 0), (130, 30, 21)), ((1, 1, 1), (132, 70, 13))], ids=["x", "xy", "xyz"])
-@pytest.mark.parametrize("form", ["strips", "strips-regathered", "strips-no-residual", "field"])
+@pytest.mark.parametrize("form", ["strips", "strips-no-residual", "field"])
 def test_x_shell_in_compact_strips(fpr, oracle, periodic_grid, periods, n, form):
     """The shell next to an x-neighbour in compact strips (csrc/diffusion3d_xstrip.hpp; part1_kernel_programming.jl:182-188 for a
     fused pair): seven chained pairs (the strips of a pair's level 0 come from the pair before it: `turn` between two core
@@ -261,7 +261,6 @@ def test_x_shell_in_compact_strips(fpr, oracle, periodic_grid, periods, n, form)
         pytest.skip("no fused pairs at this size")
     res = None if form == "strips-no-residual" else gR
     c.set_option("diff3_xstrips", 0 if form == "field" else 1)
-    c.set_option("diff3_xstrips_keep", 0 if form == "strips-regathered" else 1)
     try:
         npairs = 8
         sq = F.fzeros(2 * npairs)
@@ -291,7 +290,6 @@ def test_x_shell_in_compact_strips(fpr, oracle, periodic_grid, periods, n, form)
             assert np.array_equal(F.tonumpy(gR)[inner], R[inner])
     finally:
         c.set_option("diff3_xstrips", 1)
-        c.set_option("diff3_xstrips_keep", 1)
 
 
 def test_x_strips_are_gathered_afresh_after_a_join(fpr, oracle, periodic_grid):
@@ -721,108 +719,21 @@ def test_bench_two_ranks_rehearsal_python_twin_of_the_choreography():
 
 
 @pytest.mark.parametrize("choreography", ["pairs", "plain"])
-@pytest.mark.parametrize("dims", [(2, 2, 2), (1, 1, 8)], ids=["2x2x2", "1x1x8"])
-def test_eight_ranks_as_threads_equal_the_single_domain_run(fpr, dims, choreography):
+@pytest.mark.parametrize("dims", ["2,2,2", "1,1,8"], ids=["2x2x2", "1x1x8"])
+def test_eight_ranks_as_threads_equal_the_single_domain_run(dims, choreography):
     """The two process grids the reference's scaling runs use at eight ranks (part1_scaling_experiments.jl:35-41: (2,2,2); z-slabs
     (1,1,8) is this repository's default), EXECUTED by the library's own exchange code and one-call pair choreography with eight
-    ranks -- every rank a thread of this process with its own library context (bind_context), planes over fpr_comm_init_hosted and
-    in-process queues (grid.ThreadWorld).  A GPU box admits six processes on its card, so eight real processes
-    cannot run there; the rank code that runs is the same.  Local grids 128^3, 12 pseudo-iterations; every rank's field and residual
+    ranks -- every rank a thread of ONE process with its own library context (bind_context), planes over fpr_comm_init_hosted and
+    in-process queues (grid.ThreadWorld; tests/thread_ranks_worker.py is that process).  A GPU box admits six processes on its card, so
+    eight real processes cannot run there.  Local grids 128^3, 12 pseudo-iterations; every rank's field and residual
     equal the single-domain run's slice bit for bit, the all-reduced sums of squares agree to 1e-12 (summation order)."""
-    import threading
+    import os
+    import subprocess
+    import sys
 
-    import torch
-
-    F = fpr
-    n, iters = 128, 12
-    world = dims[0] * dims[1] * dims[2]
-    nglob = tuple(d * (n - 2) + 2 for d in dims)
-    lx, ly, lz = (d * 10.0 for d in dims)
-    dx, dy, dz = lx / nglob[0], ly / nglob[1], lz / nglob[2]
-    D, dt = 1.0, 0.2
-    coef = (min(dx, dy, dz) ** 2 / D / 8.1, 1.0 / dt, 1.0 / dx, 1.0 / dy, 1.0 / dz, D / dx, D / dy, D / dz)
-
-    def run(gg, nloc, fused):
-        """`iters` pseudo-iterations from the Gaussian on this thread's context; returns (field, residual, sums of squares)."""
-        Ht = F.fzeros(*nloc)
-        F.part1.init_local_gaussian((lx / 2, ly / 2, lz / 2), dx, dy, dz, Ht, gg.coords)
-        A, B, C3, R = Ht.clone(memory_format=torch.preserve_format), F.fzeros(*nloc), Ht.clone(memory_format=torch.preserve_format), F.fzeros(*nloc)
-        sq = torch.zeros(iters, dtype=torch.float64, device=Ht.device)
-        if fused:
-            assert gg.can_step2(Ht, A, B, C3, R)
-            for i in range(0, iters, 2):
-                gg.step2(Ht, A, B, C3, R, *coef, dt, sq[i:i + 2], join=False)
-                A, C3 = C3, A
-            gg.join()
-        else:
-            for i in range(iters):
-                gg.step(Ht, A, B, R, *coef, dt, sq[i:i + 1])
-                A, B = B, A
-        gg.allreduce_(sq)
-        F.ctx().synchronize()
-        return F.tonumpy(A), F.tonumpy(R), sq.cpu().numpy()
-
-    # the single-domain control on the default context (no neighbours: plain fused pairs)
-    g1 = F.grid.GlobalGrid(*nglob, dims=(1, 1, 1), transport=None, use_dist=False)
-    A1, R1, sq1 = run(g1, nglob, True)
-    assert np.all(sq1 > 0)
-
-    tw = F.grid.ThreadWorld(world)
-    results, errors = [None] * world, []
-
-    def rank_main(r):
-        c = None
-        try:
-            c = F.Context(0, secondary=True)
-            F.bind_context(c)
-            gg = F.grid.GlobalGrid(n, n, n, dims=dims, transport="hosted", dist=tw.rank_view(r))
-            assert c.L.fpr_comm_size(c.h) == world and c.L.fpr_comm_rank(c.h) == r
-            out = run(gg, (n, n, n), choreography == "pairs")
-            results[r] = (gg.coords, out, c.L.fpr_comm_cus(c.h))
-            gg.barrier()
-            F.grid.finalize_global_grid()
-        except BaseException as e:      # noqa: BLE001  (reported by the main thread)
-            errors.append((r, repr(e)))
-            try:
-                tw.bar.abort()
-            except Exception:
-                pass
-        finally:
-            F.bind_context(None)
-            if c is not None:
-                try:
-                    c.synchronize()
-                except Exception:
-                    pass
-
-    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join(timeout=300.0)
-    assert not errors, errors
-    assert all(not t.is_alive() for t in threads) and all(r is not None for r in results)
-    for r, (coords, (A, R, sq), cus) in enumerate(results):
-        off = tuple(ci * (n - 2) for ci in coords)
-        sl = tuple(slice(o, o + n) for o in off)
-        inner = (slice(1, -1),) * 3
-        assert np.array_equal(A[inner], A1[sl][inner]), "rank %d field" % r
-        assert np.array_equal(R[inner], R1[sl][inner]), "rank %d residual" % r
-        # halo planes that were received (faces with a neighbour) hold the neighbour's cells of the single-domain field
-        for d in range(3):
-            for side in (0, 1):
-                cc = coords[d] + (1 if side else -1)
-                if 0 <= cc < dims[d]:
-                    idx = [slice(1, -1)] * 3
-                    idx[d] = -1 if side else 0
-                    assert np.array_equal(A[tuple(idx)], A1[sl][tuple(idx)]), "rank %d halo %d" % (r, 2 * d + side)
-        assert np.allclose(sq, sq1, rtol=1e-12, atol=0.0), (r, sq, sq1)
-        if choreography == "pairs":
-            assert cus > 0          # the device was split for the shell chain (comm stream on its own units)
-    if n == 128 and dims == (2, 2, 2):
-        # ... and the committed control (what bench.py's norm_check compares an N-rank run with): same numbers
-        import json
-        import os
-
-        ent = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "scale_norms.json")))["entries"]["n128_dims2,2,2"]
-        assert abs(results[0][1][2][iters - 1] - ent["sumsq"][iters - 1]) <= 1e-12 * ent["sumsq"][iters - 1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "thread_ranks_worker.py"), dims, choreography], capture_output=True, text=True,
+                       timeout=420, cwd=root)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "dims (%s) %s n 128: OK" % (dims.replace(",", ", "), choreography) in r.stdout
+    assert r.stdout.count("field True residual True") == 8

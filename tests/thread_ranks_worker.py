@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""N ranks as threads of one process (grid.ThreadWorld, one library context per thread) against the single-domain run: diagnostic twin of
-tests/test_gpu_rccl.py::test_eight_ranks_as_threads...   usage: thread_ranks.py dx,dy,dz pairs|plain [n] [iters]"""
+"""N ranks as THREADS of one process (grid.ThreadWorld: one library context per thread, planes over fpr_comm_init_hosted and in-process
+queues) against the single-domain run of the same global problem: every rank's field and residual bit for bit, the all-reduced sums of
+squares to 1e-12.  One process per configuration (tests/test_gpu_rccl.py::test_eight_ranks_as_threads... starts it): a GPU box admits six
+processes on its card, so eight REAL processes cannot run there; the rank code that runs here is the library's own exchange code and
+one-call pair choreography.   usage: thread_ranks_worker.py dx,dy,dz pairs|plain [n] [iters]"""
 import os
 import sys
 import threading

@@ -33,11 +33,9 @@ b[:, 0] = b[:, -1] = 0.0
 gb = F.asdevice(b)
 ref = None
 t0 = time.time()
-for form, wgs, tagged in ((2, 64, 1), (3, 64, 1), (3, 16, 1), (3, 64, 0)):
+for form in (2, 3):        # two launches per iteration (the reference for the bits), then the persistent kernel
     c.set_option("cg_fused", form)
-    c.set_option("cg_persistent_wgs", wgs)
-    c.set_option("cg_tagged_edges", tagged)       # r edges of the persistent kernel as data-tagged granules (option) or sc1 + drain + flags (default)
-    for i in range((reps if tagged else reps // 4) if form == 3 else 2):
+    for i in range(reps if form == 3 else 2):
         if i % 8 == 0:
             noise()
         x = F.fzeros(n, n)
@@ -47,13 +45,11 @@ for form, wgs, tagged in ((2, 64, 1), (3, 64, 1), (3, 16, 1), (3, 64, 0)):
             ref = got
         elif not (got[0] == ref[0] and got[1] == ref[1] and np.array_equal(got[2], ref[2])):
             bad += 1
-            print("cg mismatch: form %d wgs %d rep %d: it %d vs %d" % (form, wgs, i, got[1], ref[1]), flush=True)
+            print("cg mismatch: form %d rep %d: it %d vs %d" % (form, i, got[1], ref[1]), flush=True)
 c.set_option("cg_fused", 3)
-c.set_option("cg_persistent_wgs", 64)
-c.set_option("cg_tagged_edges", 0)
-print("cg!: %d solves of %d iterations, %d mismatches, %d barrier time-outs, %.1f s" % (2 * reps + 2, ref[1], bad, c.get_option("cg_persistent_timeouts"), time.time() - t0), flush=True)
+print("cg!: %d solves of %d iterations, %d mismatches, %d barrier time-outs, %.1f s" % (reps + 2, ref[1], bad, c.get_option("cg_persistent_timeouts"), time.time() - t0), flush=True)
 # ---- Jacobi coarse solve directly (cap 5140 sweeps) and with an exit inside a launch: 257 x 129 (153 workgroups, groups of 8 sweeps) and
-#      257 x 257 (225 workgroups, groups of 7); the data-tagged hand-off (k_jacobi_persist_tag, default) and the flag form ----
+#      257 x 257 (225 workgroups, groups of 7): the data-tagged hand-off (k_jacobi_persist_tag) against plain launches ----
 t0 = time.time()
 nsolves = 0
 for shape in ((257, 129), (257, 257)):
@@ -64,9 +60,8 @@ for shape in ((257, 129), (257, 257)):
     gf = F.asdevice(f)
     for tol in (1e-9, 0.05):
         ref = None
-        for persist, tagged, n_rep in ((0, 1, 1), (1, 1, reps // 4), (1, 0, max(reps // 16, 2))):
+        for persist, n_rep in ((0, 1), (1, reps // 4)):
             c.set_option("mg_jacobi_persist", persist)
-            c.set_option("mg_jacp_tagged", tagged)
             for i in range(n_rep):
                 if i % 4 == 0:
                     noise()
@@ -78,9 +73,8 @@ for shape in ((257, 129), (257, 257)):
                     ref = got
                 elif not (abs(got[0] - ref[0]) <= 1e-13 * abs(ref[0]) and np.array_equal(got[1], ref[1])):
                     bad += 1
-                    print("jacobi mismatch: shape %s tol %g tagged %d rep %d: r %.17g vs %.17g, %d cells differ"
-                          % (shape, tol, tagged, i, got[0], ref[0], int((got[1] != ref[1]).sum())), flush=True)
-c.set_option("mg_jacp_tagged", 1)
+                    print("jacobi mismatch: shape %s tol %g rep %d: r %.17g vs %.17g, %d cells differ"
+                          % (shape, tol, i, got[0], ref[0], int((got[1] != ref[1]).sum())), flush=True)
 c.set_option("mg_jacobi_persist", 1)
 torch.cuda.synchronize()
 print("jacobi: %d persistent solves, %d mismatches in all, %d hand-off time-outs, %.1f s" % (nsolves, bad, c.get_option("mg_jacobi_persist_timeouts"), time.time() - t0), flush=True)

@@ -69,7 +69,7 @@ enum {
                                  pre pair + residual + injection of cycle k+1 in one pass (k_seam_march)         */
     FPR_KT_MG_CG = 5,         /* coarse solve by cg! as ONE persistent launch (k_cg_persistent): a launch = a solve      */
     FPR_KT_MG_PATCH = 6,      /* coarse solve by damped Jacobi on a large coarse grid: one launch = up to 32 groups of 8 sweeps
-                                 (k_jacobi_persist; option mg_jacobi_persist = 0: one launch per 8 sweeps, k_jacobi_patch) */
+                                 (k_jacobi_persist_tag; options mg_jacobi_persist = 0 or handoff_fences = 1: one launch per 8 sweeps, k_jacobi_patch) */
     FPR_KT_DIFF3_STEP3 = 8,   /* k_diff3_march3: three pseudo-iterations per launch                           */
     FPR_KT_DIFF3_CORE = 7     /* fpr_diffusion3d_step2_core: the core launch of a decomposed run's fused pair (the shell
                                  launches beside it stay FPR_KT_DIFF3_STEP / _STEP2 and OVERLAP it in time)              */
@@ -130,7 +130,7 @@ int fpr_diffusion3d_step3(fpr_ctx* ctx, const double* Ht, const double* Htau, do
  * Placement: the launch streams Ht and Htau in and Hout and dHdtau out at equal offsets; on MI355X its time depends on which
  * physical pages the four allocations received (0.775 ms at 512^3 when they all differ in their placement label, 0.85-0.91 ms when
  * they agree) -- a host that owns its arrays picks them from a pool of candidates once.
- * Option diff3_lane_off [1]: lanes of a tile that hold no needed cell are switched off for the march. */
+ * Lanes of a tile that hold no needed cell are switched off for the march. */
 int fpr_diffusion3d_can_step2(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hmid, const double* Hout,
                               const double* dHdtau, int nx, int ny, int nz);
 int fpr_diffusion3d_step2(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hmid, double* Hout,
@@ -166,7 +166,7 @@ int fpr_diffusion3d_step2_core(fpr_ctx* ctx, const double* Ht, const double* Hta
  * physical-boundary values; sumsq2_dev (nullable) receives the LOCAL sums of both iterations; dHdtau may be NULL (residual not
  * stored).  join = 0 leaves the pair on the core /
  * comm streams: the next _halo call continues from there; fpr_diffusion3d_join waits for it (the HOST waits for the core and comm
- * streams: a wait parked on the compute stream while pairs are in flight slows them; option diff3_join_async = 1 for stream waits
+ * streams: a wait parked on the compute stream while pairs are in flight slows them
  * instead); call it before anything else reads OR WRITES the fields or the sums.  Without neighbours: fpr_diffusion3d_step2.
  * x-faces (csrc/diffusion3d_xstrip.hpp; option diff3_xstrips, default 1): the shell column next to an x-neighbour, the three columns
  * around it and the planes that travel live in compact strips (ny*nz doubles per column, kept in the context): both iterations of
@@ -174,7 +174,7 @@ int fpr_diffusion3d_step2_core(fpr_ctx* ctx, const double* Ht, const double* Hta
  * unpack kernels), and the strided accesses to the fields -- the received halo column, the shell column and its residual into Hout /
  * dHdtau, the columns next to the face out of Hout for the next pair -- are ONE launch between two core launches.  While a chain of
  * pairs (join = 0) continues -- this call's Htau is the pending pair's Hout, same Ht -- the strips are reused; otherwise they are
- * gathered afresh before the core launch (option diff3_xstrips_keep = 0: always).  Edge and corner cells of the halo planes are not
+ * gathered afresh before the core launch.  Edge and corner cells of the halo planes are not
  * refreshed (as with fpr_halo_exchange3d_begin / _end: all faces travel at once).  diff3_xstrips = 0: the x-shell in the field
  * (narrow-box kernels, pack / unpack kernels; rounds 2-3). */
 int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Hmid, double* Hout, double* dHdtau,
@@ -386,9 +386,10 @@ int fpr_mgsolve2d(fpr_ctx* ctx, double* u, const double* f, double h, double c, 
 /* B9: cg!(x_in, b, hx, hy, c, tol, Nmax) -- krylov.jl:55-91 (starts from x = 0, overwrites x_in).
  * The dot products (:57, :64, :69, :72, :83, :90; the reference does not specify their summation order) are Dot2 sums: twofold
  * precision, rounded once -- x, the iteration count and the returned rms do not depend on the launch form (option cg_fused [3]:
- * 3 = one persistent launch where the grid fits, 2 / 1 / 0 = two / three / five launches per iteration; cg_persistent_wgs [64]:
- * 64 workgroups of 256 threads, 16 = 16 of 1024) and equal the CPU restatement's bit for bit.  cg_pow2 [1]: on meshes with
- * hx^2, hy^2 powers of two the persistent form multiplies by the exact reciprocals instead of dividing (same bits). */
+ * 3 = one persistent launch of 64 workgroups of 256 threads where the grid fits, 2 / 1 / 0 = two / three / five launches per iteration)
+ * and equal the CPU restatement's bit for bit.  On meshes with hx^2, hy^2 powers of two the persistent form multiplies by the exact
+ * reciprocals instead of dividing (same bits).  Option handoff_fences [0]: 1 = its neighbour hand-offs carry agent-scope release /
+ * acquire pairs (the form inside the HIP memory model: +12 % per iteration, profiles/r6_handoff_fences.txt). */
 int fpr_cg2d(fpr_ctx* ctx, double* x_in, const double* b, double hx, double hy, double c, double tol, int Nmax,
              int nx, int ny, double* rms_host, int* iters_host);
 
@@ -414,11 +415,10 @@ int fpr_mg_arena_provide_coarse(fpr_ctx* ctx, int nx, int ny, double* res_c, dou
  * would use), on the best-ranked assignments and through a short local search, and keeps the fastest.
  *   trial(user, chosen, count) -> ms of the caller's kernel on arrays cand[chosen[0]], ..., cand[chosen[count-1]]; <= 0: cannot judge
  *   chosen_out[count]: index into cand for every position;  report[FPR_PLACE_REPORT_LEN]: what was measured (indices below)
- * Contents of the candidates are overwritten by the copies.  Options (fpr_set_option) with their measured defaults: place_trials [4]
- * best-ranked assignments tried, place_gain_pct_x10 [5] a swap is kept when 0.5 % faster, place_extend_below_GBs [5050] and
- * place_spread_pct_x10 [25]: report[FPR_PLACE_WANT_MORE] = 1 when every pair of the pool copies below that rate, 2 when the
- * trial sees less than 2.5 % between any two assignments -- the pool is of one class and the caller may allocate more candidates
- * and call again; place_copy_reps [2]; place_try_identity [1]. */
+ * Contents of the candidates are overwritten by the copies (scratch during the search).  Measured constants: the candidates as given first,
+ * then the 4 best-ranked assignments, then a local search in which a swap is kept when 0.5 % faster; report[FPR_PLACE_WANT_MORE] = 1 when
+ * every pair of the pool copies below 5050 GB/s (a pool of one placement class), 2 when the trial sees less than 2.5 % between any two
+ * assignments. */
 typedef double (*fpr_place_trial_fn)(void* user, const int* chosen, int count);
 enum {
     FPR_PLACE_POOL_FASTEST_GBS = 0,   /* fastest / median / slowest pair of the pool, GB/s (read + write)  */
@@ -428,7 +428,7 @@ enum {
     FPR_PLACE_CHOSEN_MEAN_GBS = 4,
     FPR_PLACE_TRIALS = 5,             /* trial() calls that returned a time                                */
     FPR_PLACE_TRIAL_BEST_MS = 6,      /* the assignment kept                                               */
-    FPR_PLACE_TRIAL_FIRST_MS = 7,     /* the first trial (the candidates as given when place_try_identity) */
+    FPR_PLACE_TRIAL_FIRST_MS = 7,     /* the first trial (the candidates as given)                       */
     FPR_PLACE_TRIAL_WORST_MS = 8,
     FPR_PLACE_TRIAL_IDENTITY_MS = 9,  /* cand[0 .. count-1] as given: a host that simply allocates        */
     FPR_PLACE_TRIAL_SPREAD = 10,      /* worst / best - 1 over all trials                                  */

@@ -27,11 +27,11 @@ try:
 except OSError:
     box = None
 entries = []
-for fused, kern in ((True, "k_diff3_march2<true, 8, true, false, false>"), (False, "k_diff3_march<")):
+for fused, kern in ((3, "k_diff3_march3<true, true>"), (True, "k_diff3_march2<true, 8, true, false, false>"), (False, "k_diff3_march<")):
     fe, nf = mean(os.path.join(root, "profiles", tag + "_pmc_fetch.txt"), kern, "FETCH_SIZE")
     wr, nw = mean(os.path.join(root, "profiles", tag + "_pmc_write.txt"), kern, "WRITE_SIZE")
     traffic = fe * 1024 * 2 + wr * 1024
-    entries.append({"n": n, "fuse2": fused, "kernel": kern.rstrip("<") if kern.endswith("<") else kern, "FETCH_SIZE_KiB_mean": fe, "fetch_dispatches": nf,
+    entries.append({"n": n, "fuse2": fused is True, "depth": 3 if fused == 3 else (2 if fused else 1), "kernel": kern.rstrip("<") if kern.endswith("<") else kern, "FETCH_SIZE_KiB_mean": fe, "fetch_dispatches": nf,
                     "WRITE_SIZE_KiB_mean": wr, "write_dispatches": nw, "fetch_correction": 2.0, "box": box,
                     "traffic_bytes_per_launch": traffic, "min_bytes_per_launch": 32.0 * cells,
                     "traffic_over_min_bytes": traffic / (32.0 * cells),

@@ -883,7 +883,7 @@ def test_placement_alloc_fields(fpr):
     # nothing but the returned arrays stays allocated (round 5's fallbacks held up to 72 GiB)
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
-    assert free0 - free1 <= 4 * (256 << 20) + (64 << 20), (free0 - free1) / 2.0 ** 30
+    assert free0 - free1 <= 4 * (256 << 20) + (1 << 30), (free0 - free1) / 2.0 ** 30       # (the arrays + the allocator's slack; not tens of GiB)
     # without a trial the pair copies alone decide
     rep2 = {}
     more = F.placement.alloc_fields(2, *n, pool=4, report=rep2, spacer_bytes=256 << 20, pairs=[(0, 1)])

@@ -24,7 +24,8 @@ d = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"][:70]
     if not any(s in k for s in ("k_smooth2_march_v2", "k_seam_march", "k_mid_down", "k_mid_up", "k_mg_small", "k_cycle")): continue
-    d[(k, int(r["Grid_Size"]))].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    g = int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+    d[(k, g)].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 for (k, g), v in sorted(d.items(), key=lambda q: (q[0][0], -q[0][1])):
     v = v[-30:]
     print("%s  grid %d: %.2f us (n=%d)" % (k, g, sum(e - s for s, e in v) / len(v) / 1e3, len(v)))

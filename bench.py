@@ -267,7 +267,8 @@ def main():
     # (profiles/r6_placement_on_off.txt: 0.916 ms placed, 0.913-0.916 plain on one lease): plain allocations, as the reference's `@zeros`.
     # Ranks with neighbours run fused pairs, whose time depends on the physical pages the arrays received (0.76 against 0.85-0.91 ms): there
     # a pool of candidates is timed once, outside every timed region, and the best-matched five stay (placement.py; --no-placement: plain).
-    want_fuse3 = world == 1 and not args.no_fuse3 and not args.no_fuse2
+    # (z-slab decompositions run triples between ranks too: fpr_diffusion3d_step3_halo)
+    want_fuse3 = (world == 1 or dims[0] == dims[1] == 1) and not args.no_fuse3 and not args.no_fuse2
     placement = {"selected": False}
     unplaced = {}
     try:
@@ -275,7 +276,7 @@ def main():
         unplaced["mem_free_GiB_at_start"], unplaced["mem_total_GiB"] = _free0 / 2.0 ** 30, _total0 / 2.0 ** 30
     except Exception:
         pass
-    if args.no_placement or as_one or world == 1:
+    if args.no_placement or as_one or want_fuse3:
         Ht, Hτ, Hτ3, res, Hτ2 = (F.fzeros(*nloc) for _ in range(5))
     else:
         def trial(arrs):
@@ -330,7 +331,7 @@ def main():
             gg.step(Ht, Hτ2, Hτ, res, *coef, dt, sq1)
             state["cur"], state["parity"] = Hτ, 0
 
-    can_fuse3 = want_fuse3 and not as_one and F.part1.can_step_τ3(Ht, Hτ, Hτ2, res)
+    can_fuse3 = want_fuse3 and not as_one and gg.can_step3(Ht, Hτ, Hτ2, res)
 
     def run(nsteps, base, fuse2):
         """fuse2: False / 0 = one iteration per launch, True / 2 = fused pairs, 3 = fused triples (remainders as a pair or single steps)"""
@@ -340,10 +341,10 @@ def main():
             if fuse2 == 3 and i + 2 < nsteps:
                 X = state["cur"]
                 Y = Hτ if X is Hτ2 else Hτ2
-                F.part1.diffusion_3D_step_τ3(Ht, X, Y, res, *coef, dt, sq[base + i:base + i + 3])
+                gg.step3(Ht, X, Y, res, *coef, dt, sq[base + i:base + i + 3], join=False)
                 state["cur"], state["parity"] = Y, state["parity"] ^ 1
                 i += 3
-            elif fuse2 and state["parity"] == 0 and i + 1 < nsteps:
+            elif fuse2 and (fuse2 != 3 or world == 1) and state["parity"] == 0 and i + 1 < nsteps:   # (between ranks triples and pairs split the device differently: remainders of triples as single steps)
                 out = Hτ3 if state["cur"] is Hτ else Hτ
                 gg.step2(Ht, state["cur"], Hτ2, out, res, *coef, dt, sq[base + i:base + i + 2], join=False)
                 state["cur"] = out
@@ -426,7 +427,10 @@ def main():
         ms_tot, cnt = kt[kind]
         ipl = 3 if kind == KT_STEP3 else (2 if kind == KT_STEP2 else 1)
         nbytes = min_bytes
-        if world > 1 and kind == KT_STEP2 and kt[KT_CORE][1]:
+        if world > 1 and kind == KT_STEP3:
+            # between ranks a fused triple is ONE core launch (planes [3, nz-3) next to z-neighbours) and the thin shell chain beside it
+            nbytes = A_EFF_BYTES * (nloc[0] - 2) * (nloc[1] - 2) * (nloc[2] - 2 - 2 * sum(1 for f in gg.neighbors if f >= 4))
+        elif world > 1 and kind == KT_STEP2 and kt[KT_CORE][1]:
             # between ranks a fused pair is ONE core launch on the core stream (the dominant kernel, priced here: 32 B per
             # core cell) and thin shell launches BESIDE it on the comm stream (reported below; they overlap it in time)
             ms_tot, cnt = kt[KT_CORE]
@@ -448,8 +452,8 @@ def main():
              "effective_accounting": "SURVEY 8d: 32 B per interior cell per ITERATION x iterations per launch",
              "traffic": None, "traffic_source": None}
         if world > 1:
-            r["kernel"] += ("; between ranks: the CORE launch of the local grid (one per pair, on the core stream of the split device); the "
-                            "shell launches run beside it on the comm stream") if kt[KT_CORE][1] else "; between ranks: all launches of one pass"
+            r["kernel"] += ("; between ranks: the CORE launch of the local grid (one per pair / triple, on the core stream of the split device); the "
+                            "shell launches run beside it on the comm stream") if (kt[KT_CORE][1] or kind == KT_STEP3) else "; between ranks: all launches of one pass"
             r["launches_by_kind"] = {"single_step_boxes": kt[KT_STEP][1], "fused_boxes": kt[KT_STEP2][1] + kt[KT_CORE][1], "core": kt[KT_CORE][1]}
             r["shell_launches_ms_total"] = kt[KT_STEP][0] + kt[KT_STEP2][0]
         if traffic_entry:
@@ -556,24 +560,30 @@ def main():
         # neighbour over the library's RCCL transport (the planes really travel through ncclSend / ncclRecv on the comm stream
         # of the split device).  Links excluded; they are hidden by construction (the chain with both exchanges ends inside
         # the core launch).  Not part of `value`.
-        def neighbour_leg(key, periods, drop, eff_key, note):
+        def neighbour_leg(key, periods, drop, eff_key, note, depth=2):
             gp = None
             try:
                 if args.no_neighbour_leg:
                     raise RuntimeError("skipped (--no-neighbour-leg)")
                 gp = F.grid.GlobalGrid(*nloc, dims=(1, 1, 1), periods=periods, transport="rccl", use_dist=False, drop_faces=drop)
                 state["cur"] = Hτ
+                if depth == 3 and not gp.can_step3(Ht, Hτ, Hτ2, res):
+                    raise RuntimeError("the three-step choreography does not serve this grid")
                 def pair_n(nsteps):
-                    for i in range(nsteps // 2):
-                        outb = Hτ3 if state["cur"] is Hτ else Hτ
-                        gp.step2(Ht, state["cur"], Hτ2, outb, res, *coef, dt, sq[2 * i:2 * i + 2], join=False)
+                    for i in range(nsteps // depth):
+                        if depth == 3:
+                            outb = Hτ2 if state["cur"] is Hτ else Hτ
+                            gp.step3(Ht, state["cur"], outb, res, *coef, dt, sq[3 * i:3 * i + 3], join=False)
+                        else:
+                            outb = Hτ3 if state["cur"] is Hτ else Hτ
+                            gp.step2(Ht, state["cur"], Hτ2, outb, res, *coef, dt, sq[2 * i:2 * i + 2], join=False)
                         state["cur"] = outb
                 # (the communicator has just been set up: the card idled for more than 10 ms, and launches 4-12 behind such a
                 # pause are throttled, tools/exp_ramp.py -- 24 pairs of warm-up carry the leg past that)
                 pair_n(max(W + (W & 1) + 4, 48))
                 gp.join()
                 barrier()
-                K4 = max(K, 80)                    # steady state: the fork from / join into the compute stream weigh 1/40 each
+                K4 = max(K, 80) if depth == 2 else max(K, 120) // 6 * 6   # steady state: the fork from / join into the compute stream weigh 1/40 each
                 t0 = time.perf_counter()
                 pair_n(K4)                         # wall time without the event timer (its records stand between the launches)
                 gp.join()
@@ -583,15 +593,17 @@ def main():
                 pair_n(K)                          # once more for the kernels' own durations
                 gp.join()
                 barrier()
-                kt4 = {kind: timer_read(ctx, kind) for kind in (KT_STEP, KT_STEP2, KT_CORE)}
+                kt4 = {kind: timer_read(ctx, kind) for kind in (KT_STEP, KT_STEP2, KT_CORE, KT_STEP3)}
                 ctx.call("fpr_kernel_timer", 0)
-                npair, npair_t = max(K4 // 2, 1), max(K // 2, 1)
-                plain_pair_ms = 2 * legs["fused_pairs"]["ms_per_step"]
+                npair, npair_t = max(K4 // depth, 1), max(K // depth, 1)
+                plain_pair_ms = depth * legs["fused_triples" if depth == 3 else "fused_pairs"]["ms_per_step"]
+                kcore = KT_STEP3 if depth == 3 else KT_CORE
                 legs[key] = {
-                    "ms_per_step": e4 / (2 * npair) * 1e3, "pair_ms": e4 / npair * 1e3, "plain_pair_ms": plain_pair_ms,
+                    "ms_per_step": e4 / (depth * npair) * 1e3, "pair_ms": e4 / npair * 1e3, "plain_pair_ms": plain_pair_ms,
+                    "iterations_per_launch": depth,
                     "over_plain_pair": e4 / npair * 1e3 / plain_pair_ms,
                     eff_key: plain_pair_ms / (e4 / npair * 1e3),
-                    "core_kernel_ms": kt4[KT_CORE][0] / max(kt4[KT_CORE][1], 1), "core_launches": kt4[KT_CORE][1],
+                    "core_kernel_ms": kt4[kcore][0] / max(kt4[kcore][1], 1), "core_launches": kt4[kcore][1],
                     "shell_launches_ms_per_pair": (kt4[KT_STEP][0] + kt4[KT_STEP2][0]) / npair_t, "pairs_timed": npair, "comm_units": ctx.L.fpr_comm_cus(ctx.h),
                     "note": note}
             except Exception as e:   # a projection, never required for the GPU number
@@ -610,6 +622,11 @@ def main():
                       "one rank, periodic in z = its own neighbour over ncclSend / ncclRecv (RCCL, comm stream of the CU-split "
                       "device); two faces with a neighbour like an interior rank of (1,1,N); a projection from one card, link "
                       "time not included (hidden behind the core launch by construction)")
+        if main_mode == 3:
+            neighbour_leg("fused_triples_as_interior_rank_of_z_slabs", (0, 0, 1), 0, "projected_weak_scaling_efficiency_z_slabs_triples",
+                          "as above with THREE iterations per launch (fpr_diffusion3d_step3_halo: core planes [3, nz-3) in one launch, the two "
+                          "planes next to each z-face in three rounds of single-step launches + one-plane exchanges on the comm stream's 32 "
+                          "units); relative to this card's plain triples, i.e. to the N = 1 line", depth=3)
         neighbour_leg("fused_pairs_as_rank_of_2x2x2", (1, 1, 1), 0b010101, "projected_weak_scaling_efficiency_2x2x2",
                       "one rank, periodic in x, y and z with the three low faces dropped = one face with a neighbour per dimension, "
                       "the face set of every rank of the reference's (2,2,2) layout (part1_scaling_experiments.jl:40); the x-shell "

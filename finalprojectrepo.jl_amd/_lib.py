@@ -64,6 +64,8 @@ _SIG = {
     "fpr_diffusion3d_step2_box2": [_vp] + [_dp] * 5 + [_i] * 3 + [_d] * 8 + [C.POINTER(_i), C.POINTER(_i), _i, _i, _d, _dp, _i],
     "fpr_diffusion3d_step2_core": [_vp] + [_dp] * 5 + [_i] * 3 + [_d] * 8 + [C.POINTER(_i), C.POINTER(_i), _d, _dp, _i, _i, _i],
     "fpr_diffusion3d_step2_halo": [_vp] + [_dp] * 5 + [_i] * 3 + [_d] * 8 + [_d, _dp, _i],
+    "fpr_diffusion3d_can_step3_halo": [_vp] + [_dp] * 4 + [_i] * 3,
+    "fpr_diffusion3d_step3_halo": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 8 + [_d, _dp, _i],
     "fpr_diffusion3d_join": [_vp],
     "fpr_diffusion3d_flux": [_vp] + [_dp] * 4 + [_i] * 3 + [_d] * 4,
     "fpr_diffusion3d_dHdtau": [_vp] + [_dp] * 6 + [_i] * 3 + [_d] * 4,

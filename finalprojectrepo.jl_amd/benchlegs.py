@@ -409,6 +409,7 @@ def compact_record(out):
         "vcycle5_jacobi_s": _g(out, "vcycle_5levels", "jacobi", "value"), "vcycle5_cg_s": _g(out, "vcycle_5levels", "conjugate_gradient", "value"),
         "ns_step_s": _g(out, "ns_step", "value"),
         "proj_eff_z_slabs": _g(out, "legs", "fused_pairs_as_interior_rank_of_z_slabs", "projected_weak_scaling_efficiency_z_slabs"),
+        "proj_eff_z_slabs_triples": _g(out, "legs", "fused_triples_as_interior_rank_of_z_slabs", "projected_weak_scaling_efficiency_z_slabs_triples"),
         "proj_eff_2x2x2": _g(out, "legs", "fused_pairs_as_rank_of_2x2x2", "projected_weak_scaling_efficiency_2x2x2"),
         "detail": DETAIL_FILE,
     })

@@ -304,8 +304,10 @@ static int check_grid(fpr_ctx* ctx, const double* A, int nx, int ny, int nz)
 // low side first, sends high side first -- when both neighbours of a dimension are the same rank (periodic with
 // dims <= 2, including a rank that is its own neighbour) RCCL matches the k-th send to a peer with the k-th receive
 // from it, so the high plane lands in the peer's low halo and vice versa.
-static int post_group(fpr_ctx* ctx, double* A, int mask, hipStream_t s, const double* const* xsend = nullptr, double* const* xrecv = nullptr)
-{   // xsend / xrecv: buffers for the two x-faces instead of the grid's packed-plane buffers
+static int post_group(fpr_ctx* ctx, double* A, int mask, hipStream_t s, const double* const* xsend = nullptr, double* const* xrecv = nullptr,
+                      const double* const* zsend = nullptr, double* const* zrecv = nullptr)
+{   // xsend / xrecv: buffers for the two x-faces instead of the grid's packed-plane buffers; zsend / zrecv: planes of the caller
+    // instead of the second / last planes of A
     const FprGrid& g = ctx->grid;
     const int nx = g.n[0], ny = g.n[1], nz = g.n[2];
     const size_t pz = (size_t)nx * ny;
@@ -323,7 +325,7 @@ static int post_group(fpr_ctx* ctx, double* A, int mask, hipStream_t s, const do
         for (int side = 0; side < 2 && first == ncclSuccess; ++side) {
             const int f = 2 * d + side;
             if (!((mask >> f) & 1) || g.nb[f] < 0) continue;
-            double* dst = d == 2 ? A + (side ? (size_t)(nz - 1) * pz : 0) : ((d == 0 && xrecv) ? xrecv[side] : g.recvbuf[f]);
+            double* dst = d == 2 ? (zrecv ? zrecv[side] : A + (side ? (size_t)(nz - 1) * pz : 0)) : ((d == 0 && xrecv) ? xrecv[side] : g.recvbuf[f]);
             first = x_recv(ctx, dst, count[d], g.nb[f], s, &hrc);
             what = "ncclRecv";
         }
@@ -331,7 +333,7 @@ static int post_group(fpr_ctx* ctx, double* A, int mask, hipStream_t s, const do
         for (int side = 1; side >= 0 && first == ncclSuccess; --side) {
             const int f = 2 * d + side;
             if (!((mask >> f) & 1) || g.nb[f] < 0) continue;
-            const double* src = d == 2 ? A + (side ? (size_t)(nz - 2) * pz : pz) : ((d == 0 && xsend) ? xsend[side] : g.sendbuf[f]);
+            const double* src = d == 2 ? (zsend ? zsend[side] : A + (side ? (size_t)(nz - 2) * pz : pz)) : ((d == 0 && xsend) ? xsend[side] : g.sendbuf[f]);
             first = x_send(ctx, src, count[d], g.nb[f], s, &hrc);
             what = "ncclSend";
         }
@@ -407,6 +409,15 @@ int fprx_halo_exchange3d_comm_x(fpr_ctx* ctx, double* A, int nx, int ny, int nz,
         if (((face_mask >> f) & 1) && g.nb[f] >= 0)
             if (int rc = fpr_halo_unpack3d(ctx, A, nx, ny, nz, f, g.recvbuf[f], 1)) return rc;
     return FPR_OK;
+}
+
+int fprx_exchange_zplanes(fpr_ctx* ctx, const double* const zsend[2], double* const zrecv[2])
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, ctx->grid.on && zsend && zrecv, "fpr_grid_init has not been called / null plane lists");
+    for (int side = 0; side < 2; ++side)
+        FPR_REQUIRE(ctx, ctx->grid.nb[4 + side] < 0 || (zsend[side] && zrecv[side]), "a z-face with a neighbour needs its two planes");
+    return post_group(ctx, nullptr, 0x30, ctx->stream[1], nullptr, nullptr, zsend, zrecv);
 }
 
 extern "C" int fpr_halo_exchange3d_comm(fpr_ctx* ctx, double* A, int nx, int ny, int nz, int face_mask)

@@ -64,6 +64,7 @@ extern "C" int fpr_ctx_destroy(fpr_ctx* ctx)
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->partials2) hipFree(ctx->partials2);
     if (ctx->core_partials) hipFree(ctx->core_partials);
+    if (ctx->shell3) hipFree(ctx->shell3);
     if (ctx->tickets) hipFree(ctx->tickets);
     if (ctx->xstrips) hipFree(ctx->xstrips);
     if (ctx->ns_ev) hipEventDestroy(ctx->ns_ev);
@@ -584,16 +585,17 @@ int fprx_finish_sum2_plus(fpr_ctx* ctx, const double* p0, const double* p1, int 
 
 // three partial lists of equal length -> out[0..2] in one launch (k_diff3_march3: the sums of its three iterations)
 __global__ __launch_bounds__(256) void k_finish3(const double* __restrict__ p0, const double* __restrict__ p1, const double* __restrict__ p2,
-                                                  int n, double* __restrict__ out)
+                                                  int n, double* __restrict__ out, const double* __restrict__ add)
 {
     __shared__ double red[16];
     const double s = fpr_sum_partials_256(blockIdx.x == 0 ? p0 : (blockIdx.x == 1 ? p1 : p2), n, red);
-    if (threadIdx.x == 0) out[blockIdx.x] = s;
+    if (threadIdx.x == 0) out[blockIdx.x] = add ? s + add[blockIdx.x] : s;
 }
 
-int fprx_finish_sum3(fpr_ctx* ctx, const double* p0, const double* p1, const double* p2, int nparts, double* out3_dev, int stream_sel)
+int fprx_finish_sum3(fpr_ctx* ctx, const double* p0, const double* p1, const double* p2, int nparts, double* out3_dev, int stream_sel,
+                     const double* add3_dev)
 {
-    k_finish3<<<3, 256, 0, ctx->stream[stream_sel]>>>(p0, p1, p2, nparts, out3_dev);
+    k_finish3<<<3, 256, 0, ctx->stream[stream_sel]>>>(p0, p1, p2, nparts, out3_dev, add3_dev);
     FPR_CHECK_LAUNCH(ctx);
     return FPR_OK;
 }

@@ -256,9 +256,12 @@ static bool diff3_fuse3_ok(fpr_ctx* ctx, const double* Ht, const double* X, cons
 
 // sumsq3_dev: three doubles (first, second, third iteration); nullptr = no norm.  nparts_only: leave the three lists of per-workgroup
 // partials (thirds of the stream's scratch) to the caller.  Whole interior, compute stream.
+// lo / hi: output box (nullptr = the whole interior); stream_sel 2 = the core launch of a triple between ranks (fpr_diffusion3d_step3_halo):
+// planned for the compute units the split leaves to the core stream, partials in partial_base (three lists of partial_cap doubles).
 static int diff3_run3(fpr_ctx* ctx, const double* Ht, const double* X, double* Y, double* dH, int nx, int ny, int nz, double dtau,
                       double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy, double D_dz, double scale,
-                      double* sumsq3_dev, const int* skip = nullptr, int* nparts_only = nullptr)
+                      double* sumsq3_dev, const int* skip = nullptr, int* nparts_only = nullptr, const int* lo = nullptr, const int* hi = nullptr,
+                      int stream_sel = 0, double* partial_base = nullptr, int partial_cap = 0)
 {
     if (!ctx) return FPR_ERR_INVALID;
     FPR_REQUIRE(ctx, Ht && X && Y, "null field pointer");   // dH may be null: residual not stored
@@ -270,28 +273,35 @@ static int diff3_run3(fpr_ctx* ctx, const double* Ht, const double* X, double* Y
     a.lane_off = 1;
     a.Ht = Ht; a.X = X; a.Bnd = Y; a.Y = Y; a.dH = dH;
     a.nx = nx; a.ny = ny; a.nz = nz;
-    a.lo[0] = a.lo[1] = a.lo[2] = 1;
-    a.hi[0] = nx - 1; a.hi[1] = ny - 1; a.hi[2] = nz - 1;
+    const int n[3] = {nx, ny, nz};
+    for (int d = 0; d < 3; ++d) {
+        a.lo[d] = lo ? (lo[d] < 1 ? 1 : lo[d]) : 1;
+        a.hi[d] = hi ? (hi[d] > n[d] - 1 ? n[d] - 1 : hi[d]) : n[d] - 1;
+    }
     a.dtau = dtau; a._dt = _dt; a._dx = _dx; a._dy = _dy; a._dz = _dz;
     a.D_dx = D_dx; a.D_dy = D_dy; a.D_dz = D_dz;
     a.scale = scale;
-    const int pcap = FPR_MAX_PARTIALS / 3;
-    a.partials1 = ctx->partials; a.partials2 = a.partials1 + pcap; a.partials3 = a.partials2 + pcap;
+    FPR_REQUIRE(ctx, stream_sel == 0 || stream_sel == 2, "stream_sel");
+    const int pcap = partial_base ? partial_cap : FPR_MAX_PARTIALS / 3;
+    a.partials1 = partial_base ? partial_base : ctx->partials; a.partials2 = a.partials1 + pcap; a.partials3 = a.partials2 + pcap;
     const bool norm = sumsq3_dev != nullptr || nparts_only != nullptr;
     if (ctx->ncu <= 0) {
         int v = 0;
         ctx->ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && v > 0) ? v : 256;
     }
+    // a launch on the core stream of a split device has the units the comm stream does not own: one whole unit of work per such unit,
+    // the left-over units in thin slices
+    const int ncu_plan = (stream_sel == 2 && ctx->comm_cus > 0 && !ctx->core_unmasked) ? ctx->ncu - ctx->comm_cus : ctx->ncu;
     int nparts = 0;
-    const bool timed = fpr_ktimer_begin(ctx, FPR_KT_DIFF3_STEP3, ctx->stream[0]);
-    const hipError_t e = diff3_launch3(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), 0, ctx->stream[0], pcap, &nparts, ctx->ncu);
-    fpr_ktimer_end(ctx, timed, ctx->stream[0]);
+    const bool timed = fpr_ktimer_begin(ctx, FPR_KT_DIFF3_STEP3, ctx->stream[stream_sel]);
+    const hipError_t e = diff3_launch3(a, norm, (int)fpr_opt(ctx, "diff3_zc2", 0), 0, ctx->stream[stream_sel], pcap, &nparts, ncu_plan);
+    fpr_ktimer_end(ctx, timed, ctx->stream[stream_sel]);
     if (e != hipSuccess) return fpr_fail(ctx, FPR_ERR_HIP, "fused three-step diffusion3d launch: %s", hipGetErrorString(e));
     if (nparts_only) {
         *nparts_only = nparts;
         return FPR_OK;
     }
-    if (norm) return fprx_finish_sum3(ctx, a.partials1, a.partials2, a.partials3, nparts, sumsq3_dev, 0);
+    if (norm) return fprx_finish_sum3(ctx, a.partials1, a.partials2, a.partials3, nparts, sumsq3_dev, stream_sel);
     return FPR_OK;
 }
 
@@ -871,8 +881,8 @@ extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const 
     // finished on the COMM stream once the core has ended -- on the core stream nothing stands between this core launch and the
     // next pair's (a finish and an add there cost 26 us per pair, profiles/r3_overlap_timeline_native.txt)
     if (sumsq2_dev && !ctx->core_partials)
-        FPR_HIP(ctx, hipMalloc(&ctx->core_partials, (size_t)4 * FPR_CORE_PARTIALS * sizeof(double)));
-    double* cpart = sumsq2_dev ? ctx->core_partials + (size_t)(ctx->pair_parity & 1) * 2 * FPR_CORE_PARTIALS : nullptr;
+        FPR_HIP(ctx, hipMalloc(&ctx->core_partials, (size_t)6 * FPR_CORE_PARTIALS * sizeof(double)));
+    double* cpart = sumsq2_dev ? ctx->core_partials + (size_t)(ctx->pair_parity & 1) * 3 * FPR_CORE_PARTIALS : nullptr;
     ctx->pair_parity ^= 1;
     int core_nparts = 0;
     if (int rc = diff3_run2(ctx, Ht, Htau, Hmid, Hout, dHdtau, D3ARGS, lo, hi, scale, nullptr, false, 2, 0, 0, nullptr,
@@ -949,6 +959,156 @@ extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const 
     rejoin.armed = false;
     ctx->pair_pending = true;
     return join ? diff3_join(ctx, true) : FPR_OK;   // join = 1: the compute stream is ordered behind this pair (stream waits; the host goes on)
+}
+
+// ---- three iterations per launch BETWEEN ranks: z-slab decompositions (the process grid (1,1,N) of the scaling runs) -----------------
+// Levels as in diffusion3d_fused3.hpp: L0 = X (halo planes valid), L1 / L2 never leave the chip in the CORE, L3 -> Y.  A cell's third iterate
+// depends on L0 three planes away, so next to a z-face with a neighbour the two interior planes 1, 2 (nz-3, nz-2) -- the SHELL -- need the
+// neighbour's L1 and L2 halo planes, which exist nowhere unless somebody stores them:
+//   core stream : k_diff3_march3 on planes [3, nz-3) -- everything it needs of L1 / L2 it computes from X itself ----------------------------> join
+//   comm stream : L1 on planes 1..4 (single-step launches into a 6-plane slab) -> exchange(L1 plane 1) -> L2 on planes 1..3 -> exchange(L2
+//                 plane 1) -> L3 on planes 1, 2 into Y -> exchange(Y) ---------------------------------------------------------------------^
+// (the same on the high side, mirrored).  One exchange per iteration, as in the reference (:185-188), each a single plane per face; the
+// shell chain is ten thin launches beside a core launch of ~1 ms on the units the comm stream owns (fpr_reserve_comm_cus(32)).
+// The slabs are 6-plane views: a single-step launch on a view is the reference's update on those planes (same diff3_point expression),
+// so shell and core agree bit for bit with three exchanged single steps.  The x / y boundary cells of the L1 slabs are Y's (L1 lives in
+// the reference's other buffer), those of the L2 slabs X's.
+struct Diff3Ring {
+    double* dst[4];
+    const double* src[4];
+    int nx, ny;
+};
+
+__global__ __launch_bounds__(256) void k_diff3_ring(Diff3Ring r)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int per = 2 * r.nx + 2 * (r.ny - 2);
+    if (t >= per) return;
+    int i, j;
+    if (t < r.nx) { i = t; j = 0; }
+    else if (t < 2 * r.nx) { i = t - r.nx; j = r.ny - 1; }
+    else { const int q = t - 2 * r.nx; j = 1 + (q >> 1); i = (q & 1) ? r.nx - 1 : 0; }
+    const size_t o = ((size_t)blockIdx.z * r.ny + j) * r.nx + i;
+    r.dst[blockIdx.y][o] = r.src[blockIdx.y][o];
+}
+
+constexpr int S3_PLANES = 6;   // planes of a shell slab: halo, two shell planes, two planes of L1 / one of L2 the shell's L3 needs, one unused
+
+extern "C" int fpr_diffusion3d_can_step3_halo(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hout,
+                                              const double* dHdtau, int nx, int ny, int nz)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    const FprGrid& g = ctx->grid;
+    if (!g.on || nx != g.n[0] || ny != g.n[1] || nz != g.n[2]) return 0;
+    for (int f = 0; f < 4; ++f)
+        if (g.nb[f] >= 0) return 0;   // x / y neighbours: fused pairs (fpr_diffusion3d_step2_halo)
+    if ((g.nb[4] >= 0 || g.nb[5] >= 0) && nz < 2 * S3_PLANES) return 0;
+    return fpr_diffusion3d_can_step3(ctx, Ht, Htau, Hout, dHdtau, nx, ny, nz);
+}
+
+extern "C" int fpr_diffusion3d_step3_halo(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Hout, double* dHdtau, int nx,
+                                          int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx,
+                                          double D_dy, double D_dz, double scale, double* sumsq3_dev, int join)
+{
+    if (!ctx) return FPR_ERR_INVALID;
+    FPR_REQUIRE(ctx, fpr_diffusion3d_can_step3_halo(ctx, Ht, Htau, Hout, dHdtau, nx, ny, nz) == 1,
+                "three fused iterations between ranks need fpr_grid_init for arrays of this size, z-neighbours only, nz >= 12 and a problem "
+                "the three-step kernel serves (fpr_diffusion3d_can_step3_halo)");
+    const FprGrid& g = ctx->grid;
+    const bool nbz[2] = {g.nb[4] >= 0, g.nb[5] >= 0};
+#define D3ARGS dtau, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz
+    if (!nbz[0] && !nbz[1]) {   // no neighbour: the plain launch on the compute stream
+        if (int rc = fpr_diffusion3d_join(ctx)) return rc;
+        return diff3_run3(ctx, Ht, Htau, Hout, dHdtau, nx, ny, nz, D3ARGS, scale, sumsq3_dev);
+    }
+    const size_t pz = (size_t)nx * ny, slab = (size_t)S3_PLANES * pz;
+    if (ctx->shell3_doubles < 6 * slab) {
+        if (ctx->shell3) { FPR_HIP(ctx, hipDeviceSynchronize()); FPR_HIP(ctx, hipFree(ctx->shell3)); ctx->shell3 = nullptr; ctx->shell3_doubles = 0; }
+        FPR_HIP(ctx, hipMalloc(&ctx->shell3, 6 * slab * sizeof(double)));
+        FPR_HIP(ctx, hipMemset(ctx->shell3, 0, 6 * slab * sizeof(double)));
+        FPR_HIP(ctx, hipDeviceSynchronize());
+        ctx->shell3_doubles = 6 * slab;
+    }
+    const long k_opt = fpr_opt(ctx, "diff3_comm_units", 0);
+    if (int rc = fpr_reserve_comm_cus(ctx, k_opt > 0 ? (int)k_opt : 32)) return rc;
+    double* sqs = ctx->scalars + 50;   // the shell chain's three sums (comm stream)
+    struct Rejoin {   // as in fpr_diffusion3d_step2_halo: an error half way must not leave launches the caller's next ones overtake
+        fpr_ctx* c; bool armed;
+        ~Rejoin() { if (armed) { char msg[sizeof(c->err)]; memcpy(msg, c->err, sizeof(msg)); fpr_stream_wait(c, 0, 1); fpr_stream_wait(c, 0, 2); c->pair_pending = false; memcpy(c->err, msg, sizeof(msg)); } }
+    } rejoin{ctx, true};
+    if (!ctx->pair_pending) {
+        if (int rc = fpr_stream_wait(ctx, 1, 0)) return rc;   // fork: the triple's inputs are ready
+        if (int rc = fpr_stream_wait(ctx, 2, 0)) return rc;
+    }
+    ctx->xs_field = nullptr;   // (a pair's x-strips, if any were kept, describe another field now)
+    // ---- core ----
+    if (sumsq3_dev && !ctx->core_partials)
+        FPR_HIP(ctx, hipMalloc(&ctx->core_partials, (size_t)6 * FPR_CORE_PARTIALS * sizeof(double)));
+    double* cpart = sumsq3_dev ? ctx->core_partials + (size_t)(ctx->pair_parity & 1) * 3 * FPR_CORE_PARTIALS : nullptr;
+    ctx->pair_parity ^= 1;
+    const int clo[3] = {1, 1, nbz[0] ? 3 : 1}, chi[3] = {nx - 1, ny - 1, nbz[1] ? nz - 3 : nz - 1};
+    int core_nparts = 0;
+    if (int rc = diff3_run3(ctx, Ht, Htau, Hout, dHdtau, nx, ny, nz, D3ARGS, scale, nullptr, nullptr, sumsq3_dev ? &core_nparts : nullptr, clo, chi,
+                            2, cpart, FPR_CORE_PARTIALS)) return rc;
+    // ---- shell chain ----
+    if (sumsq3_dev)
+        if (int rc = fpr_fill_on(ctx, sqs, 0.0, 3, 1)) return rc;
+    double* const S1[2] = {ctx->shell3, ctx->shell3 + slab};
+    double* const S2[2] = {ctx->shell3 + 2 * slab, ctx->shell3 + 3 * slab};
+    double* const R[2] = {ctx->shell3 + 4 * slab, ctx->shell3 + 5 * slab};
+    const size_t off[2] = {0, (size_t)(nz - S3_PLANES) * pz};
+    {
+        Diff3Ring r;
+        for (int sd = 0; sd < 2; ++sd) {
+            r.dst[sd] = S1[sd]; r.src[sd] = Hout + off[sd];
+            r.dst[2 + sd] = S2[sd]; r.src[2 + sd] = Htau + off[sd];
+        }
+        r.nx = nx; r.ny = ny;
+        k_diff3_ring<<<dim3((2 * nx + 2 * (ny - 2) + 255) / 256, 4, S3_PLANES), 256, 0, ctx->stream[1]>>>(r);
+        FPR_CHECK_LAUNCH(ctx);
+    }
+    // a level on view planes [a, b) of side sd (low side: as given; high side: mirrored), its sum over the two shell planes only
+    auto level = [&](int sd, const double* in, double* out, double* res, int a, int b, int lv) -> int {
+        const int za = sd ? S3_PLANES - b : a, zb = sd ? S3_PLANES - a : b;        // mirrored box
+        const int s0 = sd ? S3_PLANES - 3 : 1, s1 = sd ? S3_PLANES - 1 : 3;        // the shell planes of the view
+        const int lo1[3] = {1, 1, s0}, hi1[3] = {nx - 1, ny - 1, s1};
+        if (int rc = diff3_run(ctx, Ht + off[sd], in, out, res, nx, ny, S3_PLANES, D3ARGS, lo1, hi1, sumsq3_dev != nullptr, scale,
+                               sumsq3_dev ? sqs + lv : nullptr, true, 1)) return rc;
+        const int lo2[3] = {1, 1, sd ? za : s1}, hi2[3] = {nx - 1, ny - 1, sd ? s0 : zb};   // the planes beyond the shell
+        if (lo2[2] < hi2[2])
+            if (int rc = diff3_run(ctx, Ht + off[sd], in, out, res, nx, ny, S3_PLANES, D3ARGS, lo2, hi2, false, 0.0, nullptr, true, 1)) return rc;
+        return FPR_OK;
+    };
+    auto exchange = [&](double* const P[2]) -> int {   // plane 1 of the low slab / plane 4 of the high slab travel; planes 0 / 5 receive
+        const double* snd[2] = {P[0] + pz, P[1] + (size_t)(S3_PLANES - 2) * pz};
+        double* rcv[2] = {P[0], P[1] + (size_t)(S3_PLANES - 1) * pz};
+        return fprx_exchange_zplanes(ctx, snd, rcv);
+    };
+    for (int sd = 0; sd < 2; ++sd)
+        if (nbz[sd])
+            if (int rc = level(sd, Htau + off[sd], S1[sd], R[sd], 1, 5, 0)) return rc;
+    if (int rc = exchange(S1)) return rc;
+    for (int sd = 0; sd < 2; ++sd)
+        if (nbz[sd])
+            if (int rc = level(sd, S1[sd], S2[sd], R[sd], 1, 4, 1)) return rc;
+    if (int rc = exchange(S2)) return rc;
+    for (int sd = 0; sd < 2; ++sd)
+        if (nbz[sd])
+            if (int rc = level(sd, S2[sd], Hout + off[sd], dHdtau ? dHdtau + off[sd] : R[sd], 1, 3, 2)) return rc;
+    if (int rc = fprx_halo_exchange3d_comm_x(ctx, Hout, nx, ny, nz, 0x30, nullptr, nullptr)) return rc;
+#undef D3ARGS
+    if (int rc = fpr_stream_wait(ctx, 2, 1)) return rc;       // the core stream takes in the shell chain
+    if (int rc = fpr_stream_wait(ctx, 1, 2)) return rc;       // the comm stream goes on behind the core launch: the next chain ...
+    if (sumsq3_dev) {   // ... and the triple's sums = core partials + the shell chain's sums
+        if (core_nparts > 0) {
+            if (int rc = fprx_finish_sum3(ctx, cpart, cpart + FPR_CORE_PARTIALS, cpart + 2 * FPR_CORE_PARTIALS, core_nparts, sumsq3_dev, 1, sqs)) return rc;
+        } else {
+            FPR_HIP(ctx, hipMemcpyAsync(sumsq3_dev, sqs, 3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream[1]));
+        }
+    }
+    rejoin.armed = false;
+    ctx->pair_pending = true;
+    return join ? diff3_join(ctx, true) : FPR_OK;
 }
 
 extern "C" int fpr_diffusion3d_step_box(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Htau2,

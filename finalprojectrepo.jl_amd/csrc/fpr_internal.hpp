@@ -104,7 +104,9 @@ struct fpr_ctx {
     int comm_cus = 0;                  // units of the comm stream (0: device not split)
     int comm_cus_asked = 0;            // what fpr_reserve_comm_cus was asked for (it may round up)
     bool pair_pending = false;         // a fused pair of fpr_diffusion3d_step2_halo left on the core / comm streams (join = 0)
-    double* core_partials = nullptr;   // 2 pairs x 2 lists x FPR_CORE_PARTIALS: the core launch's partials, finished on the comm stream
+    double* core_partials = nullptr;   // 2 parities x 3 lists x FPR_CORE_PARTIALS: the core launch's partials (pairs use 2 lists), finished on the comm stream
+    double* shell3 = nullptr;          // fpr_diffusion3d_step3_halo: levels 1 and 2 of the z-shells (6 slabs of 6 planes: L1 low / high, L2 low / high, residuals)
+    size_t shell3_doubles = 0;
     int pair_parity = 0;
     // fpr_mgsolve2d: V-cycles the last solve with the same (u, f, nx, ny) took -- a time stepper solves the same systems step after
     // step (part2.jl:187,221,226) and their convergence histories hardly move: the seam pass's guess of the last cycle takes the
@@ -491,4 +493,7 @@ int fprx_halo_exchange3d_comm_x(fpr_ctx* ctx, double* A, int nx, int ny, int nz,
                                 double* const xrecv[2]);
 int fprx_finish_sum2(fpr_ctx* ctx, const double* p0, const double* p1, int nparts, double* out2_dev, bool accumulate,
                      int stream_sel);
-int fprx_finish_sum3(fpr_ctx* ctx, const double* p0, const double* p1, const double* p2, int nparts, double* out3_dev, int stream_sel);
+int fprx_finish_sum3(fpr_ctx* ctx, const double* p0, const double* p1, const double* p2, int nparts, double* out3_dev, int stream_sel,
+                     const double* add3_dev = nullptr);   // add3_dev: three device doubles added to the three sums
+// one group of sends / receives of whole z-planes between the caller's buffers and the z-neighbours (side 0 = low face), comm stream
+int fprx_exchange_zplanes(fpr_ctx* ctx, const double* const zsend[2], double* const zrecv[2]);

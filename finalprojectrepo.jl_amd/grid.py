@@ -583,6 +583,42 @@ class GlobalGrid:
         self.step2_middle(st)
         self.step2_end(st, join)
 
+    def can_step3(self, Ht, Hτ, Hout, dHdτ):
+        """True if step3 can run three iterations as one fused launch (+ the z-shell chain) on this grid: the three-step kernel serves
+        the arrays and the rank has neighbours on z-faces only (process grid (1,1,N)) through the library's own transport."""
+        from . import part1
+        from . import ctx as _ctx
+        from ._lib import fptr
+
+        if not self.neighbors:
+            return part1.can_step_τ3(Ht, Hτ, Hout, dHdτ)
+        if self.transport_kind != "rccl" or self._reserve is not None:
+            return False
+        c = _ctx()
+        return c.L.fpr_diffusion3d_can_step3_halo(c.h, fptr(Ht, 3), fptr(Hτ, 3), fptr(Hout, 3), fptr(dHdτ, 3) if dHdτ is not None else None,
+                                                  self.nx, self.ny, self.nz) == 1
+
+    def step3(self, Ht, Hτ, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq3_dev, join=True):
+        """THREE pseudo-iterations: Hout <- update(update(update(Hτ))), dHdτ <- residual of the third, halos of Hout refreshed.  Hτ and
+        Hout are the reference's two ping-pong buffers in either order.  sq3_dev (3 doubles, or None) receives the LOCAL sums of the three
+        iterations.  Fields bit-identical to three calls of step().  Between ranks: fpr_diffusion3d_step3_halo (z-slab decompositions;
+        join as for step2)."""
+        from . import part1
+
+        if not self.neighbors:
+            part1.diffusion_3D_step_τ3(Ht, Hτ, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, norm_scale, sq3_dev)
+            return
+        from . import ctx as _ctx
+        from ._lib import fptr
+
+        if self._pending:
+            self.join()
+        self._singles = 0
+        _ctx().call("fpr_diffusion3d_step3_halo", fptr(Ht, 3), fptr(Hτ, 3), fptr(Hout, 3), fptr(dHdτ, 3) if dHdτ is not None else None,
+                    self.nx, self.ny, self.nz, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz, float(norm_scale),
+                    sq3_dev.data_ptr() if sq3_dev is not None else None, 1 if join else 0)
+        self._native_pending = not join
+
     @property
     def pending(self):
         """True while a fused pair of step2(join=False) sits on the core / comm streams, not yet joined."""

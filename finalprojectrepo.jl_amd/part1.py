@@ -339,6 +339,61 @@ def diffusion_3D_kernel_programming(*, nx, ny, nz, ttot=1.0, tol=1e-8, use_share
     # that carries Hτ's boundary; Hτ2 keeps the role of the reference's second work buffer.  Pairs start from an "even"
     # state only (field in Hτ / Hτ3); single steps handle the odd state (field in Hτ2) and odd iteration counts.  An
     # iteration whose norm ends the loop is replayed alone, so results are those of the plain loop.
+    # Fused triples between ranks (z-slab decompositions, GlobalGrid.step3): Hτ and Hτ2 alternate as in the reference, three iterations at
+    # a time; a norm inside a triple that ends the loop has the iterations up to it replayed singly from the (intact) input.
+    coefs = (dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
+    fuse3 = gg.nprocs > 1 and gg.can_step3(Ht, Hτ, Hτ2, residual_H)
+    sq3 = ctx.scal[:3]
+    for _ in range(nt if fuse3 else 0):  # :166, triples
+        if iter_outer == 3:  # manual warm-up, :170-176
+            ctx.synchronize()
+            tic = time.time()
+            timed_iter_total = 0
+        iter_inner = 0
+        err = 2 * tol
+        while (iter_inner < fixed_iters) if fixed_iters > 0 else (err > tol and iter_inner < iter_max):  # :179
+            left = (fixed_iters if fixed_iters > 0 else iter_max) - iter_inner
+            if left >= 3:
+                wanted = [(j % check_every == 0) if fixed_iters == 0 else (j == fixed_iters) for j in range(iter_inner + 1, iter_inner + 4)]
+                gg.step3(Ht, Hτ, Hτ2, residual_H, *coefs, dt, sq3 if any(wanted) else None)
+                stop_at = None
+                if any(wanted):
+                    s3 = [float(v) for v in gg.allreduce_(sq3).tolist()]
+                    for j in range(3):
+                        if wanted[j]:
+                            err = math.sqrt(s3[j]) / sqrtN  # :191
+                            if fixed_iters == 0 and not err > tol:
+                                stop_at = j
+                                break
+                if stop_at is not None and stop_at < 2:   # the reference stops inside the triple: replay up to there
+                    for _j in range(stop_at + 1):
+                        gg.step(Ht, Hτ, Hτ2, residual_H, *coefs, dt, None)
+                        Hτ, Hτ2 = Hτ2, Hτ  # :190
+                    iter_inner += stop_at + 1
+                    continue
+                Hτ, Hτ2 = Hτ2, Hτ
+                iter_inner += 3
+                continue
+            need_norm = (iter_inner + 1) % check_every == 0 if fixed_iters == 0 else iter_inner + 1 == fixed_iters
+            gg.step(Ht, Hτ, Hτ2, residual_H, *coefs, dt, sq if need_norm else None)
+            Hτ, Hτ2 = Hτ2, Hτ  # :190
+            if need_norm:
+                err = math.sqrt(gg.allreduce_sum(sq)) / sqrtN  # :191
+            iter_inner += 1
+        if verbose and me == 0:
+            print("Converged after %d iterations." % iter_inner if err <= tol else
+                  "Couldn't converge within %d iterations." % iter_inner)
+        iters_per_step.append(iter_inner)
+        err_per_step.append(err)
+        timed_iter_total += iter_inner
+        iter_outer += 1
+        gg.join()
+        ctx.call("fpr_copy", fptr(Ht), fptr(Hτ), Ht.numel())  # Ht .= Hτ, :203
+    if fuse3:
+        ctx.synchronize()
+        Δt = time.time() - tic
+        return _finish(gg, nx, ny, nz, dims, dx, lx, Δt, timed_iter_total, use_shared_memory, iters_per_step, err_per_step,
+                       dτ, Ht, Hτ, residual_H, return_device)
     Hτ3 = Hτ.clone(memory_format=torch.preserve_format)
     fuse = gg.can_step2(Ht, Hτ, Hτ2, Hτ3, residual_H)   # false as well when option diff3_fuse2 is 0
     if not fuse:
@@ -354,7 +409,6 @@ def diffusion_3D_kernel_programming(*, nx, ny, nz, ttot=1.0, tol=1e-8, use_share
             gg.dist.all_reduce(t, op=gg.dist.ReduceOp.SUM, group=gg.group)
         return [float(v) for v in t.tolist()]
 
-    coefs = (dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz)
     for _ in range(nt if fuse else 0):  # :166, fused form
         if iter_outer == 3:  # manual warm-up, :170-176
             ctx.synchronize()

@@ -181,6 +181,21 @@ int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const double* Hta
                                int nx, int ny, int nz, double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx,
                                double D_dy, double D_dz, double scale, double* sumsq2_dev, int join);
 int fpr_diffusion3d_join(fpr_ctx* ctx);
+/* _step3_halo: THREE iterations on a rank of a z-slab decomposition (process grid (1,1,N): neighbours on z-faces only), halos of Hout
+ * refreshed -- three trips through part1_kernel_programming.jl:185-190.  The core (planes [3, nz-3)) is ONE launch of the three-step
+ * kernel on the core stream (everything it needs of the two fields in between it computes from Htau itself, whose halo planes are
+ * valid); beside it, on the comm stream's 32 units, the two planes next to each z-face with a neighbour go through three rounds of
+ * single-step launches on 6-plane slabs kept in the context, each followed by the exchange of ONE plane per face (iterate 1, iterate 2,
+ * Hout) -- one exchange per iteration, as in the reference.  Same results as three fpr_diffusion3d_step calls each followed by
+ * fpr_halo_exchange3d of the written buffer.  Htau and Hout are the reference's two ping-pong buffers in either order (as for
+ * fpr_diffusion3d_step3); sumsq3_dev (nullable) receives the LOCAL sums of the three iterations; dHdtau may be NULL.  join as for
+ * _step2_halo (the two forms may alternate in one chain).  _can_step3_halo: 1 if the grid (fpr_grid_init) has no x / y neighbours,
+ * nz >= 12 and fpr_diffusion3d_can_step3 holds; without any neighbour the call is fpr_diffusion3d_step3. */
+int fpr_diffusion3d_can_step3_halo(fpr_ctx* ctx, const double* Ht, const double* Htau, const double* Hout, const double* dHdtau,
+                                   int nx, int ny, int nz);
+int fpr_diffusion3d_step3_halo(fpr_ctx* ctx, const double* Ht, const double* Htau, double* Hout, double* dHdtau, int nx, int ny, int nz,
+                               double dtau, double _dt, double _dx, double _dy, double _dz, double D_dx, double D_dy, double D_dz,
+                               double scale, double* sumsq3_dev, int join);
 
 /* A5: the single-rank host loop of diffusion_3D_kernel_programming (part1_kernel_programming.jl:166-204) in
  * native code: for each of `nt` physical steps iterate the fused update until err <= tol (err =

@@ -48,7 +48,7 @@ export @init_parallel_stencil, @reset_parallel_stencil, @parallel, @parallel_ind
        halo_pack!, halo_unpack!, fpr_version,
        init_global_grid, finalize_global_grid, select_device, update_halo!, gather!, nx_g, ny_g, nz_g, x_g, y_g, z_g,
        halo_exchange_begin!, halo_exchange_end!, halo_exchange_comm!, allreduce_sum!,
-       diffusion_3D_step_τ2_halo!, join_pair!, alloc_fields, alloc_vcycle_fields, provide_arena!, provide_arena_coarse!
+       diffusion_3D_step_τ2_halo!, diffusion_3D_step_τ3_halo!, can_step_τ3_halo, join_pair!, alloc_fields, alloc_vcycle_fields, provide_arena!, provide_arena_coarse!
 
 const libfpr = get(ENV, "FPR_HIP_LIB", joinpath(@__DIR__, "..", "finalprojectrepo.jl_amd", "lib", "libfpr_hip.so"))
 
@@ -756,6 +756,30 @@ function diffusion_3D_step_τ2_halo!(Ht::DA, Hτ::DA, Hτ2::DA, Hout::DA, dHdτ:
                  Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cdouble}, Cint),
                 ctx(), p(Ht), p(Hτ), p(Hτ2), p(Hout), dHdτ === nothing ? Ptr{Cdouble}(C_NULL) : p(dHdτ), nx, ny, nz, dτ, _dt, _dx, _dy, _dz,
                 D_dx, D_dy, D_dz, scale, sumsq2 === nothing ? Ptr{Cdouble}(C_NULL) : p(sumsq2), join ? 1 : 0))
+    return nothing
+end
+
+"""
+    diffusion_3D_step_τ3_halo!(Ht, Hτ, Hout, dHdτ, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz; scale, sumsq3, join)
+
+Three trips through the loop body of part1_kernel_programming.jl:179-192 on a rank of a z-slab decomposition (`dimz = N`, neighbours on
+z-faces only), halos of `Hout` refreshed: ONE call of the library (`fpr_diffusion3d_step3_halo`).  `Hτ` and `Hout` are the reference's
+two ping-pong buffers in either order.  The core planes run as one launch of the three-step kernel; the two planes next to each z-face
+go through three rounds of single-step launches with the exchange of one plane per face after each -- one exchange per iteration, as in
+the reference.  `can_step_τ3_halo` says whether the grid and the arrays qualify (else pairs: `diffusion_3D_step_τ2_halo!`).
+"""
+can_step_τ3_halo(Ht::DA, Hτ::DA, Hout::DA, dHdτ::Union{DA,Nothing}) =
+    ccall((:fpr_diffusion3d_can_step3_halo, libfpr), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint),
+          ctx(), p(Ht), p(Hτ), p(Hout), dHdτ === nothing ? Ptr{Cdouble}(C_NULL) : p(dHdτ), size(Ht)...) == 1
+
+function diffusion_3D_step_τ3_halo!(Ht::DA, Hτ::DA, Hout::DA, dHdτ::Union{DA,Nothing}, dτ, _dt, _dx, _dy, _dz, D_dx, D_dy, D_dz;
+                                    scale = 0.0, sumsq3::Union{DA,Nothing} = nothing, join::Bool = true)
+    nx, ny, nz = size(Ht)
+    check(ccall((:fpr_diffusion3d_step3_halo, libfpr), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint,
+                 Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cdouble}, Cint),
+                ctx(), p(Ht), p(Hτ), p(Hout), dHdτ === nothing ? Ptr{Cdouble}(C_NULL) : p(dHdτ), nx, ny, nz, dτ, _dt, _dx, _dy, _dz,
+                D_dx, D_dy, D_dz, scale, sumsq3 === nothing ? Ptr{Cdouble}(C_NULL) : p(sumsq3), join ? 1 : 0))
     return nothing
 end
 

@@ -888,7 +888,7 @@ def test_placement_alloc_fields(fpr):
     rep2 = {}
     more = F.placement.alloc_fields(2, *n, pool=4, report=rep2, spacer_bytes=256 << 20, pairs=[(0, 1)])
     assert len(more) == 2 and rep2["pool"] == 4 and rep2["trials"] == 0 and rep2["pair_copy_GBs_chosen"]["slowest"] > 100.0
-    del more, again
+    del more
     assert rep["pair_copy_GBs_all"]["fastest"] >= rep["pair_copy_GBs_chosen"]["slowest"] >= rep["pair_copy_GBs_all"]["slowest"] > 100.0
     for a in arrs:
         assert tuple(a.shape) == n and a.stride() == (1, n[0], n[0] * n[1]) and float(a.abs().max()) == 0.0

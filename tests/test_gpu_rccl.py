@@ -176,6 +176,74 @@ def test_fused_pair_over_rccl_periodic_xyz(fpr, oracle, periodic_grid):
         assert np.array_equal(F.tonumpy(gR)[1:-1, 1:-1, 1:-1], R[1:-1, 1:-1, 1:-1])
 
 
+@pytest.mark.parametrize("n", [(128, 40, 36), (130, 30, 12), (256, 50, 23)], ids=str)
+def test_triples_chained_over_rccl_periodic_z(fpr, oracle, periodic_grid, n):
+    """GlobalGrid.step3 between ranks (fpr_diffusion3d_step3_halo): a rank that is its own z-neighbour over the library's transport.  Core
+    planes [3, nz-3) as one launch of the three-step kernel, the two planes next to each z-face in three rounds of single-step launches on
+    6-plane slabs with one-plane exchanges in between.  Eight triples chained on the core / comm streams (join=False), then one left pending
+    and joined by a single step: fields (halo planes and all), residual bit for bit and every norm to 1e-13 against the oracle's single
+    steps with wrapped z halos.  The second buffer starts as zeros, so its boundary ring differs from the first one's (the reference's
+    Hτ2 = @zeros, :141): iterates 1 and 3 carry one ring, iterate 2 the other."""
+    F = fpr
+    gg = periodic_grid(n, (0, 0, 1))
+    nx, ny, nz = n
+    dx, dy, dz = 10.0 / nx, 10.0 / ny, 10.0 / (nz - 2)
+    D, dt = 1.0, 0.2
+    dτ = min(dx, dy, dz) ** 2 / D / 8.1
+    coef = (dτ, 1 / dt, 1 / dx, 1 / dy, 1 / dz, D / dx, D / dy, D / dz)
+    Ht = wrap(rnd(n, 77), dims=(2,))
+    A, B, R = Ht.copy(order="F"), farr(*n), farr(*n)
+    gHt, gA, gB, gR = F.asdevice(Ht), F.asdevice(A), F.fzeros(*n), F.fzeros(*n)
+    assert gg.can_step3(gHt, gA, gB, gR)
+    ntr = 8
+    sq = F.fzeros(3 * ntr + 3)
+    refs = []
+
+    def oracle_steps(k):
+        nonlocal A, B
+        for _ in range(k):
+            oracle.diffusion3d_step(Ht, A, B, R, *coef)
+            wrap(B, dims=(2,))
+            A, B = B, A
+            refs.append(oracle.sumsq_scaled(R, dt))
+
+    for t in range(ntr):
+        oracle_steps(3)
+        gg.step3(gHt, gA, gB, gR, *coef, dt, sq[3 * t:3 * t + 3], join=False)
+        gA, gB = gB, gA
+    assert gg.pending
+    gg.allreduce_(sq)
+    assert not gg.pending
+    got = sq.cpu().tolist()[:3 * ntr]
+    assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs)), (got, refs)
+    assert np.array_equal(F.tonumpy(gA), A) and np.array_equal(F.tonumpy(gR)[1:-1, 1:-1, 1:-1], R[1:-1, 1:-1, 1:-1])
+    # without sums and without a residual array; then a triple left pending and a single step that joins it
+    oracle_steps(3)
+    gg.step3(gHt, gA, gB, None, *coef, dt, None)
+    gA, gB = gB, gA
+    assert np.array_equal(F.tonumpy(gA), A)
+    oracle_steps(3)
+    gg.step3(gHt, gA, gB, gR, *coef, dt, sq[0:3], join=False)
+    gA, gB = gB, gA
+    oracle_steps(1)
+    gg.step(gHt, gA, gB, gR, *coef, dt, sq[3:4])
+    gA, gB = gB, gA
+    assert not gg.pending
+    assert abs(float(sq[3].item()) - refs[-1]) <= 1e-13 * refs[-1]
+    assert np.array_equal(F.tonumpy(gA), A) and np.array_equal(F.tonumpy(gR)[1:-1, 1:-1, 1:-1], R[1:-1, 1:-1, 1:-1])
+    # x / y neighbours or too few planes: the caller is told (and runs pairs)
+    F.grid.finalize_global_grid()
+    g2 = periodic_grid((128, 24, 16), (0, 1, 1))
+    z = [F.fzeros(128, 24, 16) for _ in range(4)]
+    assert not g2.can_step3(*z)
+    F.grid.finalize_global_grid()
+    g3 = periodic_grid((128, 24, 10), (0, 0, 1))
+    z = [F.fzeros(128, 24, 10) for _ in range(4)]
+    assert not g3.can_step3(*z)
+    with pytest.raises(Exception, match="three fused iterations between ranks"):
+        g3.step3(*z, *coef, dt, None)
+
+
 @pytest.mark.parametrize("periods,n", [((0, 0, 1), (128, 40, 36)), ((1, 1, 1), (256, 36, 20)), ((1, 0, 1), (128, 24, 16))], ids=["z", "xyz", "xz"])
 def test_pairs_chained_on_core_and_comm_streams(fpr, oracle, periodic_grid, periods, n):
     """step2(join=False): consecutive fused pairs chain on the core / comm streams of the split device without passing through
@@ -718,8 +786,8 @@ def test_bench_two_ranks_rehearsal_python_twin_of_the_choreography():
     assert "Python HaloExchanger" in out["config"]["halo"]
 
 
-@pytest.mark.parametrize("choreography", ["pairs", "plain"])
-@pytest.mark.parametrize("dims", ["2,2,2", "1,1,8"], ids=["2x2x2", "1x1x8"])
+@pytest.mark.parametrize("dims,choreography", [("2,2,2", "pairs"), ("2,2,2", "plain"), ("1,1,8", "pairs"), ("1,1,8", "plain"), ("1,1,8", "triples")],
+                         ids=["2x2x2-pairs", "2x2x2-plain", "1x1x8-pairs", "1x1x8-plain", "1x1x8-triples"])
 def test_eight_ranks_as_threads_equal_the_single_domain_run(dims, choreography):
     """The two process grids the reference's scaling runs use at eight ranks (part1_scaling_experiments.jl:35-41: (2,2,2); z-slabs
     (1,1,8) is this repository's default), EXECUTED by the library's own exchange code and one-call pair choreography with eight

@@ -3,7 +3,7 @@
 queues) against the single-domain run of the same global problem: every rank's field and residual bit for bit, the all-reduced sums of
 squares to 1e-12.  One process per configuration (tests/test_gpu_rccl.py::test_eight_ranks_as_threads... starts it): a GPU box admits six
 processes on its card, so eight REAL processes cannot run there; the rank code that runs here is the library's own exchange code and
-one-call pair choreography.   usage: thread_ranks_worker.py dx,dy,dz pairs|plain [n] [iters]"""
+one-call pair / triple choreography.   usage: thread_ranks_worker.py dx,dy,dz pairs|triples|plain [n] [iters]"""
 import os
 import sys
 import threading
@@ -16,7 +16,8 @@ import torch
 
 F = fpr_amd.load(0)
 dims = tuple(int(x) for x in sys.argv[1].split(","))
-fused = (sys.argv[2] if len(sys.argv) > 2 else "pairs") == "pairs"
+mode = sys.argv[2] if len(sys.argv) > 2 else "pairs"
+fused = {"pairs": 2, "triples": 3}.get(mode, 0)
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 12
 world = dims[0] * dims[1] * dims[2]
@@ -32,7 +33,13 @@ def run(gg, nloc, fused, local_only=False):
     F.part1.init_local_gaussian((lx / 2, ly / 2, lz / 2), dx, dy, dz, Ht, gg.coords)
     A, B, C3, R = Ht.clone(memory_format=torch.preserve_format), F.fzeros(*nloc), Ht.clone(memory_format=torch.preserve_format), F.fzeros(*nloc)
     sq = torch.zeros(iters, dtype=torch.float64, device=Ht.device)
-    if fused:
+    if fused == 3:      # Hτ and Hτ2 alternate (fpr_diffusion3d_step3_halo between ranks)
+        assert gg.can_step3(Ht, A, B, R) and iters % 3 == 0
+        for i in range(0, iters, 3):
+            gg.step3(Ht, A, B, R, *coef, dt, sq[i:i + 3], join=False)
+            A, B = B, A
+        gg.join()
+    elif fused:
         assert gg.can_step2(Ht, A, B, C3, R)
         for i in range(0, iters, 2):
             gg.step2(Ht, A, B, C3, R, *coef, dt, sq[i:i + 2], join=False)
@@ -50,7 +57,7 @@ def run(gg, nloc, fused, local_only=False):
 
 
 g1 = F.grid.GlobalGrid(*nglob, dims=(1, 1, 1), transport=None, use_dist=False)
-A1, R1, sq1, _ = run(g1, nglob, True)
+A1, R1, sq1, _ = run(g1, nglob, 2)
 tw = F.grid.ThreadWorld(world)
 results, errors = [None] * world, []
 
@@ -99,5 +106,5 @@ for r, res in enumerate(results):
 print("sum of local sums:", locsum)
 print("single domain    :", sq1)
 print("reduced (rank 0) :", results[0][1][2] if results[0] else None)
-print("dims %s %s n %d: %s" % (dims, "pairs" if fused else "plain", n, "OK" if ok else "MISMATCH"))
+print("dims %s %s n %d: %s" % (dims, mode if fused else "plain", n, "OK" if ok else "MISMATCH"))
 sys.exit(0 if ok else 1)

@@ -27,8 +27,8 @@ try:
 except OSError:
     box = None
 entries = []
-for name, kern, col_min in (("seam", "k_seam_march_v3<false, 6, 2>", 30.0 * N2), ("post", "k_smooth2_march_v2<true, true, false>", 26.0 * N2),
-                            ("pre", "k_smooth2_march_v2<false, false, true>", 28.0 * N2)):
+for name, kern, col_min in (("seam", "k_seam_march_v3<false, 6, 2>", 30.0 * N2), ("post", "k_smooth2_march_v2<true, true, false, false>", 26.0 * N2),
+                            ("pre", "k_smooth2_march_v2<false, false, true, true>", 28.0 * N2)):
     fe, nf = mean(os.path.join(root, "profiles", tag + "_mg_pmc_fetch.txt"), kern, "FETCH_SIZE")
     wr, nw = mean(os.path.join(root, "profiles", tag + "_mg_pmc_write.txt"), kern, "WRITE_SIZE")
     traffic = fe * 1024 * 2 + wr * 1024

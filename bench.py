@@ -268,7 +268,8 @@ def main():
     # Ranks with neighbours run fused pairs, whose time depends on the physical pages the arrays received (0.76 against 0.85-0.91 ms): there
     # a pool of candidates is timed once, outside every timed region, and the best-matched five stay (placement.py; --no-placement: plain).
     # (z-slab decompositions run triples between ranks too: fpr_diffusion3d_step3_halo)
-    want_fuse3 = (world == 1 or dims[0] == dims[1] == 1) and not args.no_fuse3 and not args.no_fuse2
+    _d3 = as_one or dims     # (a control run --as-one-rank-of dx,dy,dz takes the launches the decomposed run takes: same iteration counts)
+    want_fuse3 = _d3[0] == _d3[1] == 1 and not args.no_fuse3 and not args.no_fuse2 and not (world > 1 and choreography == "plain")
     placement = {"selected": False}
     unplaced = {}
     try:
@@ -331,7 +332,7 @@ def main():
             gg.step(Ht, Hτ2, Hτ, res, *coef, dt, sq1)
             state["cur"], state["parity"] = Hτ, 0
 
-    can_fuse3 = want_fuse3 and not as_one and gg.can_step3(Ht, Hτ, Hτ2, res)
+    can_fuse3 = want_fuse3 and gg.can_step3(Ht, Hτ, Hτ2, res)
 
     def run(nsteps, base, fuse2):
         """fuse2: False / 0 = one iteration per launch, True / 2 = fused pairs, 3 = fused triples (remainders as a pair or single steps)"""
@@ -516,7 +517,7 @@ def main():
                    "pct_of_hbm_peak_effective_per_gpu": 100.0 * value / world / HBM_PEAK_GBS,
                    "pct_of_hbm_peak_physical_dominant_kernel": 100.0 * roofline["frac"],
                    "last_err": last_err, "last_sumsq": last_sumsq, "iterations_since_start": iters_main,
-                   "choreography": ("pairs" if main_fused else "plain") if world > 1 else "none (1 rank)", "attempt": attempt,
+                   "choreography": (("triples" if main_mode == 3 else "pairs") if main_fused else "plain") if world > 1 else "none (1 rank)", "attempt": attempt,
                    "field_placement": placement},
         "roofline": roofline,
         "legs": legs,

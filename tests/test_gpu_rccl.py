@@ -673,9 +673,11 @@ def test_bench_two_ranks_rehearsal_on_one_card():
     r, out, line = _run_bench(["--gpus", "2", "--rehearse-shared-gpu", "--n", "128"] + common)
     assert line["config"]["rccl_ranks"] == 2 and line["config"]["rehearsal"] is True and line["norm_check"]["ok"] is True
     assert out["n_gpus"] == 2 and out["config"]["process_grid"] == [1, 1, 2] and out["config"]["global_grid"] == [128, 128, 254]
-    assert "rehearsal" in out and out["legs"]["fused_pairs"]["launches"] == 6     # passes over the local grid, 12 steps
-    assert 0.0 < out["roofline"]["frac"] <= 1.0      # priced per pass: shell + thin slabs + core halves together
-    assert out["roofline"]["launches_by_kind"]["fused_boxes"] >= 2 * 6       # per pair: the core launch + the shell launch(es)
+    # z-slabs run THREE iterations per launch between ranks (fpr_diffusion3d_step3_halo): 12 steps = 4 core launches of the three-step
+    # kernel, each with its chain of single-step launches on the two-plane shells
+    assert "rehearsal" in out and out["legs"]["fused_triples"]["launches"] == 4
+    assert 0.0 < out["roofline"]["frac"] <= 1.0 and out["roofline"]["iterations_per_launch"] == 3
+    assert out["roofline"]["launches_by_kind"]["single_step_boxes"] >= 4 * 5       # per triple and face: 2 + 2 + 1 shell launches
     assert out["config"]["last_err"] is not None and 0.0 < out["config"]["last_err"] < 1.0
     # the same global problem (128 x 128 x 254, lz = 20) on ONE rank, same number of iterations: the sum of squares behind
     # the norm rank 0 printed must be the single-domain one (summation order differs: 1e-12)
@@ -687,8 +689,12 @@ def test_bench_two_ranks_rehearsal_on_one_card():
     # driver's N > 1 runs carry in their line)
     for o in (out, one):
         nc = o["norm_check"]
-        assert nc["ok"] is True and nc["key"] == "n128_dims1,1,2" and nc["iterations"] == o["config"]["iterations_since_start"] == 32
-    assert out["config"]["choreography"] == "pairs" and out["config"]["attempt"] == 1 and "first_attempt" not in out
+        assert nc["ok"] is True and nc["key"] == "n128_dims1,1,2" and nc["iterations"] == o["config"]["iterations_since_start"] == 34
+    assert out["config"]["choreography"] == "triples" and out["config"]["attempt"] == 1 and "first_attempt" not in out
+    # fused PAIRS between the same two ranks (--no-fuse3: what every other process grid runs): same control
+    rq, pairs, _ = _run_bench(["--gpus", "2", "--rehearse-shared-gpu", "--n", "128", "--no-fuse3"] + common)
+    assert pairs["config"]["choreography"] == "pairs" and pairs["norm_check"]["ok"] is True and pairs["legs"]["fused_pairs"]["launches"] == 6
+    assert pairs["roofline"]["launches_by_kind"]["fused_boxes"] >= 2 * 6       # per pair: the core launch + the shell launch(es)
     # the watchdog's fallback choreography (single steps, no split of the device) on the same problem: same norm
     rp, plain, pline = _run_bench(["--gpus", "2", "--rehearse-shared-gpu", "--n", "128", "--choreography", "plain"] + common)
     assert pline["config"]["choreography"] == "plain" and pline["norm_check"]["ok"] is True

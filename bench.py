@@ -345,7 +345,7 @@ def main():
                 gg.step3(Ht, X, Y, res, *coef, dt, sq[base + i:base + i + 3], join=False)
                 state["cur"], state["parity"] = Y, state["parity"] ^ 1
                 i += 3
-            elif fuse2 and (fuse2 != 3 or world == 1) and state["parity"] == 0 and i + 1 < nsteps:   # (between ranks triples and pairs split the device differently: remainders of triples as single steps)
+            elif fuse2 and state["parity"] == 0 and i + 1 < nsteps:   # (between ranks a pair behind triples runs on the triples' split of the device)
                 out = Hτ3 if state["cur"] is Hτ else Hτ
                 gg.step2(Ht, state["cur"], Hτ2, out, res, *coef, dt, sq[base + i:base + i + 2], join=False)
                 state["cur"] = out

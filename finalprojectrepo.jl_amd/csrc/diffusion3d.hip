@@ -821,7 +821,10 @@ extern "C" int fpr_diffusion3d_step2_halo(fpr_ctx* ctx, const double* Ht, const 
                        (long)nx * ny * 8 * 12 < (1L << 31);
     if (!xs_on) ctx->xs_field = nullptr;   // a pair in the field form may overwrite the array the strips were taken from
     const long k_opt = fpr_opt(ctx, "diff3_comm_units", 0);   // experiments: 8, 16, 32, 64
-    const int k = k_opt > 0 ? (int)k_opt : diff3_comm_units(g, xs_on);
+    int k = k_opt > 0 ? (int)k_opt : diff3_comm_units(g, xs_on);
+    // a device already split with MORE units for the comm stream and a masked core stream (32: fpr_diffusion3d_step3_halo) serves this pair as
+    // it is: a chain of triples that ends in a pair does not stop to split the device anew
+    if (k_opt <= 0 && ctx->comm_cus > k && !ctx->core_unmasked) k = ctx->comm_cus;
     if (int rc = fpr_reserve_comm_cus(ctx, k)) return rc;
     double* sqs = ctx->scalars + 46;   // the shell chain's two sums (comm stream)
     // an error half way leaves launches on the core / comm streams: the compute stream is ordered behind both before the call

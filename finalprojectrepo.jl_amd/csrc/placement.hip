@@ -253,6 +253,6 @@ extern "C" int fpr_placement_rank(fpr_ctx* ctx, double* const* cand, int k, size
     const bool uniform_copy = !flat.empty() && report[FPR_PLACE_POOL_FASTEST_GBS] < below;
     const bool uniform_trial = trial && tried >= 4 && spread < min_spread;
     report[FPR_PLACE_WANT_MORE] = uniform_copy ? 1.0 : (uniform_trial ? 2.0 : 0.0);
-    report[FPR_PLACE_SEARCH_NODES] = (double)S.nodes;
+    report[FPR_PLACE_SEARCH_NODES] = S.nodes > 20000000L ? -(double)S.nodes : (double)S.nodes;   // negative: the search hit its cap (the best found so far was kept)
     return FPR_OK;
 }

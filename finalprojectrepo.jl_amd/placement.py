@@ -69,7 +69,7 @@ def alloc_fields(count, *shape, pool=None, min_bytes=256 << 20, report=None, pai
                    "spacer_bytes": spacer if spacers else 0, "trials": int(rep[_R["trials"]]),
                    "pair_copy_GBs_all": {"slowest": rep[_R["slowest"]], "median": rep[_R["median"]], "fastest": rep[_R["fastest"]]},
                    "pair_copy_GBs_chosen": {"slowest": rep[_R["chosen_slowest"]], "mean": rep[_R["chosen_mean"]]},
-                   "one_class_pool": rep[_R["want_more"]] == 1})
+                   "one_class_pool": rep[_R["want_more"]] == 1, "search_truncated": rep[12] < 0})   # (12 = FPR_PLACE_SEARCH_NODES)
     if trial is not None:
         report.update({"trial_ms_best": rep[_R["best"]], "trial_ms_first": rep[_R["first"]], "trial_ms_worst": rep[_R["worst"]],
                        "trial_ms_plain_allocation": rep[_R["identity"]]})

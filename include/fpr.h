@@ -448,7 +448,7 @@ enum {
     FPR_PLACE_TRIAL_IDENTITY_MS = 9,  /* cand[0 .. count-1] as given: a host that simply allocates        */
     FPR_PLACE_TRIAL_SPREAD = 10,      /* worst / best - 1 over all trials                                  */
     FPR_PLACE_WANT_MORE = 11,         /* 0, 1 (pair copies uniform) or 2 (trials uniform)                  */
-    FPR_PLACE_SEARCH_NODES = 12,
+    FPR_PLACE_SEARCH_NODES = 12,      /* nodes of the assignment search; NEGATIVE when it ended at its cap     */
     FPR_PLACE_REPORT_LEN = 16
 };
 int fpr_placement_rank(fpr_ctx* ctx, double* const* cand, int k, size_t n, int count, const int* pairs, int npairs,

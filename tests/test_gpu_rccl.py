@@ -231,6 +231,20 @@ def test_triples_chained_over_rccl_periodic_z(fpr, oracle, periodic_grid, n):
     assert not gg.pending
     assert abs(float(sq[3].item()) - refs[-1]) <= 1e-13 * refs[-1]
     assert np.array_equal(F.tonumpy(gA), A) and np.array_equal(F.tonumpy(gR)[1:-1, 1:-1, 1:-1], R[1:-1, 1:-1, 1:-1])
+    # a chain of triples that ends in a PAIR (bench.py's remainder): the pair runs on the triples' split of the device (32 units)
+    gC = gB.clone()          # the pair's third buffer carries the boundary ring of the triple's OUTPUT buffer (nothing is pending here)
+    oracle_steps(3)
+    gg.step3(gHt, gA, gB, gR, *coef, dt, sq[0:3], join=False)
+    gA, gB = gB, gA
+    if gg.can_step2(gHt, gA, gB, gC, gR):
+        oracle_steps(2)
+        gg.step2(gHt, gA, gB, gC, gR, *coef, dt, sq[3:5], join=False)
+        gA, gC = gC, gA
+        gg.join()
+        assert F.ctx().L.fpr_comm_cus(F.ctx().h) == 32
+        got = sq.cpu().tolist()[3:5]
+        assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs[-2:])), (got, refs[-2:])
+        assert np.array_equal(F.tonumpy(gA)[1:-1, 1:-1, :], A[1:-1, 1:-1, :]) and np.array_equal(F.tonumpy(gR)[1:-1, 1:-1, 1:-1], R[1:-1, 1:-1, 1:-1])
     # x / y neighbours or too few planes: the caller is told (and runs pairs)
     F.grid.finalize_global_grid()
     g2 = periodic_grid((128, 24, 16), (0, 1, 1))

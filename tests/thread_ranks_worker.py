@@ -56,6 +56,60 @@ def run(gg, nloc, fused, local_only=False):
     return F.tonumpy(A), F.tonumpy(R), sq.cpu().numpy(), loc
 
 
+if mode == "solver":
+    # the decomposed LOOP of part1.diffusion_3D_kernel_programming with triples between ranks (norms all-reduced, an iteration that ends the
+    # loop inside a triple replayed singly) against the same loop with one iteration per launch (options diff3_fuse3 = diff3_fuse2 = 0):
+    # iteration counts and errors per physical step, every rank's field bit for bit.  (The single-domain run is no control for the COUNTS:
+    # the reference's total_N counts the halo cells of every rank, :124, so its norm is scaled differently.)
+    kw = dict(ttot=0.4, tol=float(sys.argv[5]) if len(sys.argv) > 5 else 2e-4, verbose=False)
+
+    def solve(plain):
+        res_s, err_s = [None] * world, []
+        tw = F.grid.ThreadWorld(world)
+
+        def solver_rank(r):
+            try:
+                c = F.Context(0, secondary=True)
+                F.bind_context(c)
+                if plain:
+                    c.set_option("diff3_fuse3", 0)
+                    c.set_option("diff3_fuse2", 0)
+                gg = F.grid.GlobalGrid(n, n, n, dims=dims, transport="hosted", dist=tw.rank_view(r))
+                _, H, _, info = F.part1.diffusion_3D_kernel_programming(nx=n, ny=n, nz=n, global_grid=gg, **kw)
+                res_s[r] = (gg.coords, H, list(info["iters"]), list(info["err"]), F.ctx().L.fpr_comm_cus(F.ctx().h))
+                gg.barrier()
+                F.grid.finalize_global_grid()
+            except BaseException:
+                import traceback
+                err_s.append((r, traceback.format_exc()))
+                try:
+                    tw.bar.abort()
+                except Exception:
+                    pass
+            finally:
+                F.bind_context(None)
+
+        ths = [threading.Thread(target=solver_rank, args=(r,), daemon=True) for r in range(world)]
+        [t.start() for t in ths]
+        [t.join(timeout=300) for t in ths]
+        for r, e in err_s:
+            print("rank", r, e)
+        return res_s, not err_s and all(x is not None for x in res_s)
+
+    fused_res, ok1 = solve(False)
+    plain_res, ok2 = solve(True)
+    ok = ok1 and ok2
+    for r in range(world):
+        if fused_res[r] is None or plain_res[r] is None:
+            continue
+        coords, H, its, errs, cus = fused_res[r]
+        _, Hp, itsp, errsp, _ = plain_res[r]
+        same = np.array_equal(H, Hp)
+        print("rank %d coords %s: iterations %s (one per launch: %s) field %s comm units %d" % (r, coords, its, itsp, same, cus))
+        ok = ok and same and its == itsp and np.allclose(errs, errsp, rtol=1e-10, atol=0)
+    print("dims %s solver n %d: %s" % (dims, n, "OK" if ok else "MISMATCH"))
+    sys.exit(0 if ok else 1)
+
 g1 = F.grid.GlobalGrid(*nglob, dims=(1, 1, 1), transport=None, use_dist=False)
 A1, R1, sq1, _ = run(g1, nglob, 2)
 tw = F.grid.ThreadWorld(world)

@@ -825,3 +825,20 @@ def test_eight_ranks_as_threads_equal_the_single_domain_run(dims, choreography):
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
     assert "dims (%s) %s n 128: OK" % (dims.replace(",", ", "), choreography) in r.stdout
     assert r.stdout.count("field True residual True") == 8
+
+
+def test_decomposed_solver_loop_with_triples_equals_the_plain_loop():
+    """part1.diffusion_3D_kernel_programming on four ranks (threads of one process, z-slabs): its loop runs three iterations per launch
+    between ranks (GlobalGrid.step3), all-reduces the three norms and, when the reference's loop (:179-192) would have ended inside a
+    triple, replays the iterations up to there singly from the triple's intact input.  Against the same loop with one iteration per launch
+    (options diff3_fuse3 = diff3_fuse2 = 0): the same iteration counts and errors per physical step, every rank's field bit for bit."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "thread_ranks_worker.py"), "1,1,4", "solver", "128", "0", "8e-3"],
+                       capture_output=True, text=True, timeout=420, cwd=root)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "dims (1, 1, 4) solver n 128: OK" in r.stdout and r.stdout.count("field True comm units 32") == 4
+

@@ -176,8 +176,8 @@ def test_fused_pair_over_rccl_periodic_xyz(fpr, oracle, periodic_grid):
         assert np.array_equal(F.tonumpy(gR)[1:-1, 1:-1, 1:-1], R[1:-1, 1:-1, 1:-1])
 
 
-@pytest.mark.parametrize("n", [(128, 40, 36), (130, 30, 12), (256, 50, 23)], ids=str)
-def test_triples_chained_over_rccl_periodic_z(fpr, oracle, periodic_grid, n):
+@pytest.mark.parametrize("n,zc", [((128, 40, 36), 0), ((130, 30, 12), 0), ((256, 50, 23), 0), ((128, 64, 40), 9)], ids=str)
+def test_triples_chained_over_rccl_periodic_z(fpr, oracle, periodic_grid, n, zc):
     """GlobalGrid.step3 between ranks (fpr_diffusion3d_step3_halo): a rank that is its own z-neighbour over the library's transport.  Core
     planes [3, nz-3) as one launch of the three-step kernel, the two planes next to each z-face in three rounds of single-step launches on
     6-plane slabs with one-plane exchanges in between.  Eight triples chained on the core / comm streams (join=False), then one left pending
@@ -191,6 +191,18 @@ def test_triples_chained_over_rccl_periodic_z(fpr, oracle, periodic_grid, n):
     D, dt = 1.0, 0.2
     dτ = min(dx, dy, dz) ** 2 / D / 8.1
     coef = (dτ, 1 / dt, 1 / dx, 1 / dy, 1 / dz, D / dx, D / dy, D / dz)
+    if zc:      # test hook: the core [3, nz-3) in chunks of zc planes (a small grid otherwise runs as one chunk)
+        F.ctx().set_option("diff3_zc2", zc)
+        try:
+            _triples_periodic_z(F, oracle, periodic_grid, gg, n, coef, dt)
+        finally:
+            F.ctx().set_option("diff3_zc2", 0)
+        return
+    _triples_periodic_z(F, oracle, periodic_grid, gg, n, coef, dt)
+
+
+def _triples_periodic_z(F, oracle, periodic_grid, gg, n, coef, dt):
+    nx, ny, nz = n
     Ht = wrap(rnd(n, 77), dims=(2,))
     A, B, R = Ht.copy(order="F"), farr(*n), farr(*n)
     gHt, gA, gB, gR = F.asdevice(Ht), F.asdevice(A), F.fzeros(*n), F.fzeros(*n)
@@ -639,6 +651,29 @@ def test_config4_512cubed_over_rccl_self_neighbour(fpr, oracle, periodic_grid, p
         assert np.array_equal(loc[inner], A[inner]) and faces_equal(loc, A)
         del loc
         assert np.array_equal(F.tonumpy(gR)[inner], R[inner])
+    if periods != (0, 0, 1):
+        return
+    # z-slabs at full size: TWO fused triples between ranks (GlobalGrid.step3: core planes [3, 509) as one launch of the three-step kernel on
+    # 224 units -- 260 units of work, 36 of them in thin slices --, the shells in single-step launches on 6-plane slabs with three one-plane
+    # exchanges) against six oracle steps with wrapped halos
+    assert gg.can_step3(gHt, gA, gB, gR)
+    sq3 = F.fzeros(3)
+    for it in range(2):
+        refs = []
+        for k in range(3):
+            oracle.diffusion3d_step(Ht, A, B, R, *coef)
+            wrap(B, dims=dims)
+            A, B = B, A
+            refs.append(oracle.sumsq_scaled(R, dt))
+        gg.step3(gHt, gA, gB, gR, *coef, dt, sq3)
+        gA, gB = gB, gA
+        got = sq3.cpu().tolist()
+        assert all(abs(g - r) <= 1e-13 * r for g, r in zip(got, refs)), (got, refs)
+        loc = F.tonumpy(gA)
+        assert np.array_equal(loc[inner], A[inner]) and faces_equal(loc, A)
+        del loc
+        assert np.array_equal(F.tonumpy(gR)[inner], R[inner])
+    assert F.ctx().L.fpr_comm_cus(F.ctx().h) == 32
 
 
 def _run_bench(argv, timeout=600):

@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void k_seam_march_v3(const double* __restrict_
 // shifting of nine window rows per step); boundary columns keep their value through a per-lane factor, boundary rows
 // through a uniform branch; the residual stage runs in the injected rows only; the norm is masked per lane once at the end.
 // FSQ: the pass also leaves sum(f.^2) of its rows as block partials (the first pass of a solve: f_rms of multigrid.jl:53 without a pass of its own)
-template <bool NORM, bool PROLONG, bool RESTRICT, bool FSQ = false, int PF = 4>   // PF rows of u and f in flight per lane (a divisor of 12)
+template <bool NORM, bool PROLONG, bool RESTRICT, bool FSQ = false>
 __global__ __launch_bounds__(256) void k_smooth2_march_v2(const double* __restrict__ uin, const double* __restrict__ f,
                                                            double* __restrict__ uout, int nx, int ny, double C, double _h2,
                                                            double fac, int rows_per_chunk, int nstrips,
@@ -617,24 +617,12 @@ __global__ __launch_bounds__(256) void k_smooth2_march_v2(const double* __restri
         ldc(1, (rs >> 1) + 1);
         wa[0] = ldu(std::integral_constant<int, 0>{}, rs);
         fw[0] = ldf(rs);
-        static_assert(12 % PF == 0, "the loop is unrolled by 12");
+        constexpr int PF = 4;
         double pu[PF], pfv[PF];
         pu[0] = ldu(std::integral_constant<int, 1>{}, rs + 1); pfv[0] = ldf(rs + 1);
         pu[1] = ldu(std::integral_constant<int, 2>{}, rs + 2); pfv[1] = ldf(rs + 2);
         pu[2] = ldu(std::integral_constant<int, 3>{}, rs + 3); pfv[2] = ldf(rs + 3);
         pu[3] = ldu(std::integral_constant<int, 4>{}, rs + 4); pfv[3] = ldf(rs + 4);
-        if constexpr (PF >= 6) {
-            pu[4] = ldu(std::integral_constant<int, 5>{}, rs + 5); pfv[4] = ldf(rs + 5);
-            pu[5] = ldu(std::integral_constant<int, 6>{}, rs + 6); pfv[5] = ldf(rs + 6);
-        }
-        if constexpr (PF == 12) {
-            pu[6] = ldu(std::integral_constant<int, 7>{}, rs + 7); pfv[6] = ldf(rs + 7);
-            pu[7] = ldu(std::integral_constant<int, 8>{}, rs + 8); pfv[7] = ldf(rs + 8);
-            pu[8] = ldu(std::integral_constant<int, 9>{}, rs + 9); pfv[8] = ldf(rs + 9);
-            pu[9] = ldu(std::integral_constant<int, 10>{}, rs + 10); pfv[9] = ldf(rs + 10);
-            pu[10] = ldu(std::integral_constant<int, 11>{}, rs + 11); pfv[10] = ldf(rs + 11);
-            pu[11] = ldu(std::integral_constant<int, 12>{}, rs + 12); pfv[11] = ldf(rs + 12);
-        }
         // RESTRICT: coarse arrays (whole-array descriptors: nxc * nyc * 8 < 2^31), even owned columns only
         const __amdgpu_buffer_rsrc_t rResC = fpr_rsrc(RESTRICT ? (const void*)res_c_out : (const void*)uout);
         const __amdgpu_buffer_rsrc_t rCorC = fpr_rsrc(RESTRICT ? (const void*)corr_c_out : (const void*)uout);
@@ -654,7 +642,7 @@ __global__ __launch_bounds__(256) void k_smooth2_march_v2(const double* __restri
         };
         auto step = [&](auto Tc, int r) {
             constexpr int T = decltype(Tc)::value;               // (r - rs) mod 12
-            constexpr int Q = T % PF, M = T % 3, F = T % 4;
+            constexpr int Q = T % 4, M = T % 3, F = T % 4;
             constexpr int M1 = (M + 1) % 3, M2 = (M + 2) % 3;    // slots of rows r-2 (= r+1) and r-1
             auto fs = [](int k) { return (F - k + 4) % 4; };     // slot of f row r-k
             double an, fn;

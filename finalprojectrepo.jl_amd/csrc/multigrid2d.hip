@@ -182,17 +182,13 @@ __device__ __forceinline__ double prolong_bf(const double* __restrict__ cc, int 
     return v;
 }
 
-#include "mg_march.hpp"
-#include <cstdlib>   // k_smooth2_march, k_seam_march, k_smooth2_march2: the register-rolling marches of the fine levels
+#include "mg_march.hpp"   // k_smooth2_march, k_seam_march, k_smooth2_march2: the register-rolling marches of the fine levels
 
 // the two-sweep pass without a carried finish
 template <bool N, bool P, bool R, class... A>
 static inline void march_go(fpr_ctx* ctx, dim3 g, hipStream_t s, A... a)
 {
-    static const int pf = getenv("FPR_EXP_PF") ? atoi(getenv("FPR_EXP_PF")) : 4;   // EXPERIMENT (to be removed)
-    if (pf == 6) k_smooth2_march_v2<N, P, R, false, 6><<<g, 256, 0, s>>>(a..., FprFinishArgs{});
-    else if (pf == 12) k_smooth2_march_v2<N, P, R, false, 12><<<g, 256, 0, s>>>(a..., FprFinishArgs{});
-    else k_smooth2_march_v2<N, P, R><<<g, 256, 0, s>>>(a..., FprFinishArgs{});
+    k_smooth2_march_v2<N, P, R><<<g, 256, 0, s>>>(a..., FprFinishArgs{});
 }
 
 // ---- S fused Jacobi sweeps, register patches (coarse solve on grids too large for one workgroup) ------
@@ -1215,10 +1211,6 @@ static int vcycle_level(fpr_ctx* ctx, std::vector<FprLevel>& A, size_t d, double
                 if (carry_fin) {   // + one workgroup row: the finish of the cycle before (k_smooth2_march_v2)
                     const FprFinishArgs fa = ctx->fin;
                     ctx->fin = FprFinishArgs{};
-                    static const int pf = getenv("FPR_EXP_PF") ? atoi(getenv("FPR_EXP_PF")) : 4;   // EXPERIMENT (to be removed)
-                    if (pf == 6) k_smooth2_march_v2<false, false, true, false, 6><<<dim3(gr.x, gr.y + 1), 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, apply_BCs | uz, L.res_c, L.corr_c, skp, fa);
-                    else if (pf == 12) k_smooth2_march_v2<false, false, true, false, 12><<<dim3(gr.x, gr.y + 1), 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, apply_BCs | uz, L.res_c, L.corr_c, skp, fa);
-                    else
                     k_smooth2_march_v2<false, false, true><<<dim3(gr.x, gr.y + 1), 256, 0, s>>>(u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, apply_BCs | uz, L.res_c, L.corr_c, skp, fa);
                 } else
                 march_go<false, false, true>(ctx, gr, s, u, rhs, L.tmp, nx, ny, C, _h2, fac, rpc, nstrips_r, nullptr, nullptr, apply_BCs | uz, L.res_c, L.corr_c, skp);

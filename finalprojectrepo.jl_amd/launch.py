@@ -126,6 +126,17 @@ def _kill_tree(p, grace=3.0):
         p.wait()
 
 
+def _die_with_parent():
+    """In the worker, between fork and exec: SIGKILL when the supervisor dies (a SIGKILLed supervisor runs no handler; its worker sits in a
+    session of its own and would keep the GPU).  prctl(PR_SET_PDEATHSIG = 1, SIGKILL); Linux only, best effort."""
+    try:
+        import ctypes
+
+        ctypes.CDLL(None, use_errno=True).prctl(1, 9, 0, 0, 0)
+    except Exception:
+        pass
+
+
 def supervise(args, script, argv):
     """Rank process of an N > 1 run: start the worker, watch it, fall back once.  Never returns."""
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -165,7 +176,7 @@ def supervise(args, script, argv):
         env.setdefault("NCCL_DEBUG_FILE", os.path.join(jd, "rccl_%d_%d.log" % (attempt, rank)))   # read back on failure
         if first_failure is not None:
             env["FPR_BENCH_FIRST_FAILURE"] = json.dumps(first_failure)
-        p = subprocess.Popen([sys.executable, script] + list(argv), env=env, start_new_session=True)
+        p = subprocess.Popen([sys.executable, script] + list(argv), env=env, start_new_session=True, preexec_fn=_die_with_parent)
         current[0] = p
         t_start = time.time()
         reason, detail = None, None

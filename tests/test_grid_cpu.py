@@ -419,3 +419,47 @@ def test_comm_share_and_box_order_of_fused_pairs():
         # boxes and core are disjoint and cover the interior
         vol = sum((hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]) for lo, hi in boxes + [core])
         assert vol == (n[0] - 2) * (n[1] - 2) * (n[2] - 2)
+
+
+def test_a_worker_does_not_outlive_a_killed_supervisor(tmp_path):
+    """ADVICE r5 (launch.py): a supervisor that is SIGKILLed runs no handler, and its worker lives in a session of its own -- with a hung
+    collective it would hold the GPU for ever.  launch._die_with_parent (prctl PR_SET_PDEATHSIG) in the worker, between fork and exec:
+    a stand-in supervisor starts a sleeping child the way supervise() does, is killed with SIGKILL, and the child is gone."""
+    import signal
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pidfile = tmp_path / "child.pid"
+    code = ("import subprocess, sys, time\n"
+            "sys.path.insert(0, %r)\n"
+            "import importlib.util\n"
+            "spec = importlib.util.spec_from_file_location('launch', %r)\n"
+            "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+            "p = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(120)'], start_new_session=True, preexec_fn=m._die_with_parent)\n"
+            "open(%r, 'w').write(str(p.pid))\n"
+            "time.sleep(120)\n") % (root, os.path.join(root, "finalprojectrepo.jl_amd", "launch.py"), str(pidfile))
+    sup = subprocess.Popen([sys.executable, "-c", code])
+    try:
+        t0 = time.time()
+        while not pidfile.exists() or not pidfile.read_text():
+            assert time.time() - t0 < 60 and sup.poll() is None
+            time.sleep(0.05)
+        child = int(pidfile.read_text())
+        os.kill(child, 0)                       # alive
+        sup.send_signal(signal.SIGKILL)
+        sup.wait(timeout=10)
+        t0 = time.time()
+        while time.time() - t0 < 10:
+            try:
+                os.kill(child, 0)
+            except ProcessLookupError:
+                break
+            time.sleep(0.05)
+        else:
+            os.kill(child, signal.SIGKILL)
+            raise AssertionError("the worker outlived its supervisor")
+    finally:
+        if sup.poll() is None:
+            sup.kill()

@@ -357,8 +357,27 @@ def main():
             if i // ce > prev // ce or i == nsteps:  # convergence check: all-reduce the chunk (RCCL), host reads it
                 chunk = sq[base + (prev // ce) * ce:base + i]
                 gg.allreduce_(chunk)
-                sums.append(float(chunk[-1].item()))
-                errs.append(math.sqrt(sums[-1]) / sqrtN)
+                # ... one launch LATER, as the product's solver does (option diff3_ahead: launches are enqueued ahead of the host's view of
+                # the norm): the value travels to pinned host memory behind the all-reduce, the host picks it up after it has enqueued the
+                # next launch (or at the end of the run) -- no idle card between the launches on either side of a check
+                slot = norm_host[norm_seq[0] & 1]          # (at most two checks are pending: the one just enqueued and the one before it)
+                norm_seq[0] += 1
+                slot.copy_(chunk[-1:], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                norm_pending.append((slot, ev))
+                if len(norm_pending) > 1 or i == nsteps:
+                    read_norms(all_of_them=(i == nsteps))
+
+    norm_host = [torch.zeros(1, dtype=torch.float64).pin_memory() for _ in range(2)]
+    norm_pending, norm_seq = [], [0]
+
+    def read_norms(all_of_them):
+        while norm_pending and (all_of_them or len(norm_pending) > 1):
+            slot, ev = norm_pending.pop(0)
+            ev.synchronize()
+            sums.append(float(slot[0]))
+            errs.append(math.sqrt(sums[-1]) / sqrtN)
 
     def barrier():
         torch.cuda.synchronize()

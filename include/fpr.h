@@ -164,7 +164,8 @@ int fpr_diffusion3d_step2_core(fpr_ctx* ctx, const double* Ht, const double* Hta
  * the shell and the exchange of Hout's planes.  Same
  * results as two fpr_diffusion3d_step calls each followed by fpr_halo_exchange3d of the written buffer; Hout must carry Htau's
  * physical-boundary values; sumsq2_dev (nullable) receives the LOCAL sums of both iterations; dHdtau may be NULL (residual not
- * stored).  join = 0 leaves the pair on the core /
+ * stored).  A device already split with more units and a masked core stream (32: a chain of _step3_halo calls) is used as it is.
+ * join = 0 leaves the pair on the core /
  * comm streams: the next _halo call continues from there; fpr_diffusion3d_join waits for it (the HOST waits for the core and comm
  * streams: a wait parked on the compute stream while pairs are in flight slows them
  * instead); call it before anything else reads OR WRITES the fields or the sums.  Without neighbours: fpr_diffusion3d_step2.
